@@ -1,0 +1,158 @@
+/* skfusion_hip.h -- C ABI of libskfusion_hip.so: the MI355X (gfx950) engine for the DFMF / DFMC /
+ * fold-in update loop of scikit-fusion.
+ *
+ * The reference has no FFI: its seam is the functional solver API that the one-line wrappers
+ * call (reference skfusion/fusion/decomposition/dfmf.py:14-15 -> _dfmf.py:127 `dfmf`,
+ * dfmc.py:14-15 -> _dfmc.py:181 `dfmc`, dfmf.py:109-115 -> _dfmf.py:330 `transform`).  The entry
+ * points below are what a ctypes binding at that seam binds (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success, <0 on error
+ *     (SKF_E_*), and the message is available from skf_last_error() (thread-local).
+ *   - every data pointer is a DEVICE pointer owned by the caller; the library never allocates
+ *     or frees device memory: the caller provides one workspace of skf_plan_workspace_bytes().
+ *   - matrices are row-major with a leading dimension counted in elements.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  No call synchronises
+ *     the host unless stated.
+ *   - a plan is not re-entrant; different plans may be driven from different threads.
+ */
+#ifndef SKFUSION_HIP_H
+#define SKFUSION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* arithmetic type of the engine: storage of the relation / constraint matrices and of every
+ * factor; the reference computes in f64 throughout (numpy float64, _init.py:16). */
+enum { SKF_F64 = 0, SKF_F32 = 1, SKF_BF16 = 2 /* bf16 relation storage + f32 masters */ };
+
+/* which reference solver the plan replaces */
+enum {
+    SKF_DFMF = 0,      /* _dfmf.py:127-327  */
+    SKF_DFMC = 1,      /* _dfmc.py:181-397  */
+    SKF_TRANSFORM = 2  /* _dfmf.py:330-458  */
+};
+
+enum { SKF_ENGINE_MFMA = 0, SKF_ENGINE_VALU = 1 };
+
+enum {
+    SKF_OK = 0,
+    SKF_E_INVALID = -1,    /* bad argument / shape / index */
+    SKF_E_STATE = -2,      /* call order (workspace not bound, factors not set ...) */
+    SKF_E_WORKSPACE = -3,  /* workspace too small / misaligned */
+    SKF_E_HIP = -4         /* a HIP runtime call or kernel launch failed */
+};
+
+typedef struct skf_plan skf_plan;
+
+typedef struct {
+    int64_t n_obj; /* objects of this type   (count_objects, _dfmf.py:95-124) */
+    int32_t rank;  /* factorisation rank c_i (int(ot.rank), dfmf.py:67)       */
+} skf_type_desc;
+
+typedef struct {
+    int32_t row_type, col_type; /* indices into the type array; row_type != col_type */
+    const void* data;           /* n_row x n_col, engine dtype (R[(i,j)][l], dfmf.py:82-85) */
+    int64_t ld;
+    const uint8_t* mask;        /* DFMC only: n_row x n_col bytes, !=0 = unknown entry
+                                   (M[(i,j)][l], dfmc.py:77-90); NULL = no mask */
+    int64_t mask_ld;
+} skf_relation_desc;
+
+typedef struct {
+    int32_t type;     /* constrained object type (Theta[(i,i)][t], dfmf.py:82-85) */
+    const void* data; /* n_i x n_i, engine dtype */
+    int64_t ld;
+} skf_theta_desc;
+
+typedef struct {
+    int32_t dtype;       /* SKF_F64 / SKF_F32 / SKF_BF16 */
+    int32_t variant;     /* SKF_DFMF / SKF_DFMC / SKF_TRANSFORM */
+    int32_t target_type; /* SKF_TRANSFORM: the type whose factor is folded in */
+    int32_t engine;      /* SKF_ENGINE_MFMA (default) / SKF_ENGINE_VALU */
+} skf_options;
+
+/* ---- plan life cycle ------------------------------------------------------------------- */
+
+/* Validates the graph (shape consistency is a hard error here; the reference only logs it,
+ * _dfmf.py:117-123) and builds the per-iteration launch schedule. */
+int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relations,
+                    const skf_relation_desc* relations, int32_t n_thetas,
+                    const skf_theta_desc* thetas, const skf_options* options, skf_plan** out);
+int skf_plan_destroy(skf_plan* plan);
+
+int skf_plan_workspace_bytes(const skf_plan* plan, size_t* bytes);
+/* `workspace` must be 256-byte aligned device memory and stay valid for the plan's lifetime.
+ * For DFMC the masked relations are copied into the workspace here (the caller's relation
+ * data is never written: _dfmc.py:268, tests/test_dfmc.py:62,85). */
+int skf_plan_bind_workspace(skf_plan* plan, void* workspace, size_t bytes, void* stream);
+
+/* ---- factors --------------------------------------------------------------------------- */
+
+/* master dtype = f64 for SKF_F64, f32 otherwise.  set_factor copies an n_obj x rank matrix in
+ * (the G0 of `initialize`, _init.py:6-61, or a frozen fitted factor for SKF_TRANSFORM). */
+int skf_set_factor(skf_plan* plan, int32_t type, const void* G, int64_t ld, void* stream);
+int skf_get_factor(const skf_plan* plan, int32_t type, void* G, int64_t ld, void* stream);
+/* backbone S of relation `rel` (rank_row x rank_col).  set: SKF_TRANSFORM only (frozen S). */
+int skf_set_backbone(skf_plan* plan, int32_t rel, const void* S, int64_t ld, void* stream);
+int skf_get_backbone(const skf_plan* plan, int32_t rel, void* S, int64_t ld, void* stream);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/* Runs `n_iters` full update iterations (the body of `for iter in range(max_iter)`,
+ * _dfmf.py:212-296 / _dfmc.py:270-366 / _dfmf.py:370-428) device-resident on `stream`.
+ * After the call get_backbone returns the S computed from the factors BEFORE the last G update
+ * and get_factor the factors AFTER it -- the same generation mismatch the reference returns
+ * (_dfmf.py:239 vs :295, return :327). */
+int skf_iterate(skf_plan* plan, int32_t n_iters, void* stream);
+
+/* sum over the relation of (R - G_i S G_j^T)^2 with the current (G, S), written as one f64 to
+ * the DEVICE address `out` (reconstruction error of _dfmf.py:306-316 without materialising the
+ * n_i x n_j product).  For DFMC the working copy (completed entries) is used. */
+int skf_relation_sqerr(skf_plan* plan, int32_t rel, double* out, void* stream);
+
+/* ---- stand-alone operators (building blocks, exported for tests / callers) -------------- */
+
+typedef struct {
+    const void* A; /* A(m,k) = A[m*sa_m + k*sa_k] */
+    const void* B; /* B(k,n) = B[k*sb_k + n*sb_n] */
+    void* C;
+    void* C2;
+    const uint8_t* mask;
+    int64_t sa_m, sa_k, sb_k, sb_n, ldc, ldc2, ldmask;
+    int32_t M, N, K;
+    int32_t aop;        /* 0: x   1: max(x,0)   2: max(-x,0)  applied to A on load */
+    int32_t epi;        /* 0 store, 1 accumulate, 2 split-store, 3 split-accumulate, 4 masked store */
+    int32_t nan_to_num; /* numpy.nan_to_num on the product before the epilogue */
+    int32_t splits;     /* 0 = choose; >1 needs workspace of splits*M*N elements */
+} skf_gemm_desc;
+
+/* C = epi(aop(A) * B) on the matrix cores (f64 / f32). */
+int skf_gemm(int32_t dtype, int32_t engine, const skf_gemm_desc* desc, void* workspace,
+             size_t workspace_bytes, void* stream);
+
+/* K = pinv(A) for symmetric A (n x n): f64 Jacobi eigen-decomposition + the singular-value
+ * cut-off of scipy.linalg.pinv (reference _dfmf.py:232, _dfmc.py:307). */
+int skf_pinv_sym_workspace_bytes(int32_t n, size_t* bytes);
+int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk, int32_t n,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* dst(r,c) = hash_uniform(seed, r*cols + c) * scale + shift  (synthetic benchmark data) */
+int skf_fill_uniform(int32_t dtype, void* dst, int64_t rows, int64_t cols, int64_t ld,
+                     uint64_t seed, double scale, double shift, void* stream);
+
+/* dst(r,c) = (dst_dtype) src(r,c), dtypes SKF_F64 / SKF_F32 */
+int skf_cast(int32_t dst_dtype, void* dst, int64_t ldd, int32_t src_dtype, const void* src,
+             int64_t lds, int64_t rows, int64_t cols, void* stream);
+
+const char* skf_last_error(void);
+const char* skf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKFUSION_HIP_H */

@@ -1,0 +1,176 @@
+"""Host-side driver of one solver run: builds a plan in ``libskfusion_hip.so`` from the
+``R / Theta / M`` dictionaries that arrive at the reference's functional seam
+(``dfmf(**params)``, reference _dfmf.py:127; ``dfmc``, _dfmc.py:181; ``transform``,
+_dfmf.py:330), keeps every matrix resident in HBM for the whole ``max_iter`` loop and copies
+``G`` / ``S`` back once at the end (or per iteration when a callback is installed).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+
+
+class DevicePlan(object):
+    """One (run, device) plan: relations + constraints uploaded, workspace bound."""
+
+    def __init__(self, obj_types, n_obj, rank, relations, thetas, variant, dtype='f64',
+                 target=None, engine=None, runtime=None):
+        """relations: list of (row_type, col_type, ndarray, mask-or-None);
+        thetas: list of (type, ndarray)."""
+        self.rt = runtime or nat.get_runtime()
+        self.dtype = nat.DTYPES[dtype] if isinstance(dtype, str) else dtype
+        if self.dtype not in nat.NP_DTYPE:
+            raise ValueError('unsupported engine dtype %r' % (dtype,))
+        self.np_dtype = nat.NP_DTYPE[self.dtype]
+        self.types = list(obj_types)
+        self.index = {t: k for k, t in enumerate(self.types)}
+        self.n_obj = [int(n_obj[t]) for t in self.types]
+        self.rank = [int(rank[t]) for t in self.types]
+        self.relations = relations
+        self.handle = nat._P()
+        self._keep = []
+        mem, lib = self.rt.mem, self.rt.lib
+
+        tdesc = (nat.TypeDesc * len(self.types))()
+        for k in range(len(self.types)):
+            tdesc[k].n_obj, tdesc[k].rank = self.n_obj[k], self.rank[k]
+        rdesc = (nat.RelationDesc * max(len(relations), 1))()
+        for k, (i, j, data, mask) in enumerate(relations):
+            arr = np.ascontiguousarray(data, dtype=self.np_dtype)
+            if arr.ndim != 2:
+                raise ValueError('relation %d is not a matrix' % k)
+            if arr.shape != (n_obj[i], n_obj[j]):
+                raise ValueError('relation (%s,%s) dimension mismatch: %r vs object counts (%d,%d)'
+                                 % (i, j, arr.shape, n_obj[i], n_obj[j]))
+            buf = mem.from_host(arr)
+            self._keep.append(buf)
+            rdesc[k].row_type, rdesc[k].col_type = self.index[i], self.index[j]
+            rdesc[k].data, rdesc[k].ld = buf.ptr, arr.shape[1]
+            if mask is not None:
+                m = np.ascontiguousarray(np.asarray(mask, dtype=bool).astype(np.uint8))
+                if m.shape != arr.shape:
+                    raise ValueError('mask shape mismatch for relation (%s,%s)' % (i, j))
+                mbuf = mem.from_host(m)
+                self._keep.append(mbuf)
+                rdesc[k].mask, rdesc[k].mask_ld = mbuf.ptr, m.shape[1]
+        hdesc = (nat.ThetaDesc * max(len(thetas), 1))()
+        for k, (t, data) in enumerate(thetas):
+            arr = np.ascontiguousarray(data, dtype=self.np_dtype)
+            if arr.shape != (n_obj[t], n_obj[t]):
+                raise ValueError('constraint on %s dimension mismatch' % (t,))
+            buf = mem.from_host(arr)
+            self._keep.append(buf)
+            hdesc[k].type, hdesc[k].data, hdesc[k].ld = self.index[t], buf.ptr, arr.shape[1]
+        opt = nat.Options(self.dtype, variant, self.index[target] if target is not None else -1,
+                          nat.SKF_ENGINE_MFMA if engine is None else engine)
+        self.rt.call('skf_plan_create', len(self.types), tdesc, len(relations), rdesc, len(thetas),
+                     hdesc, C.byref(opt), C.byref(self.handle))
+        nbytes = C.c_size_t()
+        self.rt.call('skf_plan_workspace_bytes', self.handle, C.byref(nbytes))
+        self.workspace_bytes = nbytes.value
+        self.ws = mem.empty(nbytes.value)
+        self.rt.call('skf_plan_bind_workspace', self.handle, self.ws.ptr, nbytes.value, mem.stream)
+        self._scalar = mem.empty(8)
+
+    # -- factors ---------------------------------------------------------------------------
+    def set_factor(self, t, G):
+        k = self.index[t]
+        arr = np.ascontiguousarray(G, dtype=self.np_dtype)
+        if arr.shape != (self.n_obj[k], self.rank[k]):
+            raise ValueError('factor of %s has shape %r, expected %r'
+                             % (t, arr.shape, (self.n_obj[k], self.rank[k])))
+        buf = self.rt.mem.from_host(arr)
+        self.rt.call('skf_set_factor', self.handle, k, buf.ptr, arr.shape[1], self.rt.mem.stream)
+        self.rt.mem.synchronize()
+
+    def get_factor(self, t):
+        k = self.index[t]
+        shape = (self.n_obj[k], self.rank[k])
+        buf = self.rt.mem.empty(shape[0] * shape[1] * np.dtype(self.np_dtype).itemsize)
+        self.rt.call('skf_get_factor', self.handle, k, buf.ptr, shape[1], self.rt.mem.stream)
+        self.rt.mem.synchronize()
+        return self.rt.mem.to_host(buf, shape, self.np_dtype).astype(np.float64)
+
+    def _backbone_shape(self, rel):
+        i, j = self.relations[rel][0], self.relations[rel][1]
+        return (self.rank[self.index[i]], self.rank[self.index[j]])
+
+    def set_backbone(self, rel, S):
+        shape = self._backbone_shape(rel)
+        arr = np.ascontiguousarray(S, dtype=self.np_dtype)
+        if arr.shape != shape:
+            raise ValueError('backbone %d has shape %r, expected %r' % (rel, arr.shape, shape))
+        buf = self.rt.mem.from_host(arr)
+        self.rt.call('skf_set_backbone', self.handle, rel, buf.ptr, shape[1], self.rt.mem.stream)
+        self.rt.mem.synchronize()
+
+    def get_backbone(self, rel):
+        shape = self._backbone_shape(rel)
+        buf = self.rt.mem.empty(shape[0] * shape[1] * np.dtype(self.np_dtype).itemsize)
+        self.rt.call('skf_get_backbone', self.handle, rel, buf.ptr, shape[1], self.rt.mem.stream)
+        self.rt.mem.synchronize()
+        return self.rt.mem.to_host(buf, shape, self.np_dtype).astype(np.float64)
+
+    # -- the loop --------------------------------------------------------------------------
+    def iterate(self, n_iters=1):
+        self.rt.call('skf_iterate', self.handle, int(n_iters), self.rt.mem.stream)
+
+    def synchronize(self):
+        self.rt.mem.synchronize()
+
+    def relation_sqerr(self, rel):
+        """sum (R - G_i S G_j^T)^2 for relation index `rel` (device reduction, one f64 D2H)."""
+        self.rt.call('skf_relation_sqerr', self.handle, rel, self._scalar.ptr, self.rt.mem.stream)
+        self.rt.mem.synchronize()
+        return float(self.rt.mem.to_host(self._scalar, (1,), np.float64)[0])
+
+    def close(self):
+        if self.handle:
+            self.rt.lib.skf_plan_destroy(self.handle)
+            self.handle = nat._P()
+        self._keep = []
+        self.ws = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def flatten_relations(R, M=None):
+    """dict {(i,j): [matrix, ...]} -> [(i, j, matrix, mask)] in dict order, list order
+    (the order the reference walks `R`, _dfmf.py:249-251)."""
+    out = []
+    for (i, j), mats in R.items():
+        for l, m in enumerate(mats):
+            mask = None
+            if M is not None and M.get((i, j)) is not None:
+                mask = M[i, j][l]
+            out.append((i, j, m, mask))
+    return out
+
+
+def flatten_thetas(Theta):
+    out = []
+    for (i, i2), mats in Theta.items():
+        for m in mats:
+            out.append((i, m))
+    return out
+
+
+def count_objects(obj_types, R):
+    """Objects per type from the relation shapes (reference count_objects, _dfmf.py:95-124).
+    A mismatch is a hard error here (the reference only logs it and carries on)."""
+    from .fusion.base import DataFusionError
+    n = {}
+    for (i, j), mats in R.items():
+        for m in mats:
+            for ax, t in enumerate((i, j)):
+                have = n.setdefault(t, m.shape[ax])
+                if have != m.shape[ax]:
+                    raise DataFusionError('Relation matrix R_(%s,%s) dimension mismatch' % (i, j))
+    if set(obj_types) != set(n):
+        raise DataFusionError('Object type specification mismatch')
+    return n

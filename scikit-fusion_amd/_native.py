@@ -1,0 +1,174 @@
+"""ctypes binding of ``libskfusion_hip.so`` (C ABI: include/skfusion_hip.h) and the device-memory
+plumbing (PyTorch-ROCm tensors used purely as HBM containers).
+
+A *runtime* = (shared library, memory backend).  The product runtime is created lazily by
+:func:`get_runtime` and FAILS LOUDLY when the HIP library or a GPU is missing -- there is no
+CPU fallback in this package.  (The test-suite injects an emulated runtime with
+:func:`use_runtime`; that emulator lives under ``tests/emul`` and is not part of the package.)
+"""
+import contextlib
+import ctypes as C
+import os
+
+import numpy as np
+
+SKF_F64, SKF_F32, SKF_BF16 = 0, 1, 2
+SKF_DFMF, SKF_DFMC, SKF_TRANSFORM = 0, 1, 2
+SKF_ENGINE_MFMA, SKF_ENGINE_VALU = 0, 1
+
+DTYPES = {'f64': SKF_F64, 'f32': SKF_F32, 'float64': SKF_F64, 'float32': SKF_F32}
+NP_DTYPE = {SKF_F64: np.float64, SKF_F32: np.float32}
+
+LIB_NAME = 'libskfusion_hip.so'
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', LIB_NAME)
+
+
+class SkfNativeError(RuntimeError):
+    """A call into libskfusion_hip.so returned an error status."""
+
+    def __init__(self, code, message):
+        super().__init__('libskfusion_hip: [%d] %s' % (code, message))
+        self.code = code
+
+
+class TypeDesc(C.Structure):
+    _fields_ = [('n_obj', C.c_int64), ('rank', C.c_int32)]
+
+
+class RelationDesc(C.Structure):
+    _fields_ = [('row_type', C.c_int32), ('col_type', C.c_int32), ('data', C.c_void_p),
+                ('ld', C.c_int64), ('mask', C.c_void_p), ('mask_ld', C.c_int64)]
+
+
+class ThetaDesc(C.Structure):
+    _fields_ = [('type', C.c_int32), ('data', C.c_void_p), ('ld', C.c_int64)]
+
+
+class Options(C.Structure):
+    _fields_ = [('dtype', C.c_int32), ('variant', C.c_int32), ('target_type', C.c_int32),
+                ('engine', C.c_int32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('C2', C.c_void_p),
+                ('mask', C.c_void_p),
+                ('sa_m', C.c_int64), ('sa_k', C.c_int64), ('sb_k', C.c_int64), ('sb_n', C.c_int64),
+                ('ldc', C.c_int64), ('ldc2', C.c_int64), ('ldmask', C.c_int64),
+                ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+                ('aop', C.c_int32), ('epi', C.c_int32), ('nan_to_num', C.c_int32),
+                ('splits', C.c_int32)]
+
+
+# every symbol include/skfusion_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    'skf_plan_create': (C.c_int, [C.c_int32, C.POINTER(TypeDesc), C.c_int32, C.POINTER(RelationDesc),
+                                  C.c_int32, C.POINTER(ThetaDesc), C.POINTER(Options), C.POINTER(_P)]),
+    'skf_plan_destroy': (C.c_int, [_P]),
+    'skf_plan_workspace_bytes': (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    'skf_plan_bind_workspace': (C.c_int, [_P, _P, C.c_size_t, _P]),
+    'skf_set_factor': (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
+    'skf_get_factor': (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
+    'skf_set_backbone': (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
+    'skf_get_backbone': (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
+    'skf_iterate': (C.c_int, [_P, C.c_int32, _P]),
+    'skf_relation_sqerr': (C.c_int, [_P, C.c_int32, _P, _P]),
+    'skf_gemm': (C.c_int, [C.c_int32, C.c_int32, C.POINTER(GemmDesc), _P, C.c_size_t, _P]),
+    'skf_pinv_sym_workspace_bytes': (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
+    'skf_pinv_sym': (C.c_int, [C.c_int32, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
+    'skf_fill_uniform': (C.c_int, [C.c_int32, _P, C.c_int64, C.c_int64, C.c_int64, C.c_uint64,
+                                   C.c_double, C.c_double, _P]),
+    'skf_cast': (C.c_int, [C.c_int32, _P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int64, C.c_int64, _P]),
+    'skf_last_error': (C.c_char_p, []),
+    'skf_version': (C.c_char_p, []),
+}
+
+
+def load_library(path=LIB_PATH):
+    """dlopen the C-ABI library and attach the prototypes of every declared entry point."""
+    if not os.path.exists(path):
+        raise ImportError(
+            '%s not found at %s -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  skfusion_amd has no CPU fallback.' % (LIB_NAME, path))
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+class Buffer(object):
+    """A device allocation: raw address + the object that keeps it alive."""
+    __slots__ = ('ptr', 'nbytes', 'owner')
+
+    def __init__(self, ptr, nbytes, owner):
+        self.ptr, self.nbytes, self.owner = ptr, nbytes, owner
+
+
+class TorchDeviceMemory(object):
+    """HBM through PyTorch-ROCm (allocator + H2D/D2H copies only)."""
+
+    def __init__(self, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError('skfusion_amd needs an AMD GPU (torch.cuda.is_available() is False); '
+                               'there is no CPU fallback')
+        self.torch = torch
+        self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+
+    @property
+    def stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def empty(self, nbytes):
+        t = self.torch.empty(max(int(nbytes), 256), dtype=self.torch.uint8, device=self.device)
+        return Buffer(t.data_ptr(), int(nbytes), t)
+
+    def from_host(self, array):
+        a = np.ascontiguousarray(array)
+        t = self.torch.from_numpy(a.view(np.uint8).reshape(-1)).to(self.device)
+        return Buffer(t.data_ptr(), a.nbytes, t)
+
+    def to_host(self, buf, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        host = buf.owner[:n].cpu().numpy()
+        return host.view(dtype).reshape(shape).copy()
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+class Runtime(object):
+    def __init__(self, lib, mem, name):
+        self.lib, self.mem, self.name = lib, mem, name
+
+    def check(self, status):
+        if status != 0:
+            msg = self.lib.skf_last_error()
+            raise SkfNativeError(status, msg.decode() if msg else '?')
+
+    def call(self, fname, *args):
+        self.check(getattr(self.lib, fname)(*args))
+
+
+_runtime = None
+
+
+def get_runtime():
+    """The product runtime: libskfusion_hip.so + GPU memory.  Raises if either is missing."""
+    global _runtime
+    if _runtime is None:
+        _runtime = Runtime(load_library(), TorchDeviceMemory(), 'hip')
+    return _runtime
+
+
+@contextlib.contextmanager
+def use_runtime(rt):
+    """Temporarily install another runtime (test hook for the host SIMT emulator)."""
+    global _runtime
+    old, _runtime = _runtime, rt
+    try:
+        yield rt
+    finally:
+        _runtime = old

@@ -1,0 +1,868 @@
+// skf_api.hip -- C ABI (include/skfusion_hip.h) and the host-side plan / launch schedule of the
+// DFMF / DFMC / fold-in iteration.  Kernels: skf_kernels.h.
+//
+// One iteration (reference _dfmf.py:228-296, 2-GEMM form of SURVEY.md 7.0; everything reads the
+// OLD factors, G is replaced at the very end):
+//   Gram_i = G_i^T G_i                    split-K MFMA GEMM + fixed-order reduce   (:228-231)
+//   K_i    = pinv(Gram_i)                 Jacobi eigen kernel, one workgroup/type  (:232)
+//   P_r = R_r G_j ; Q_r = R_r^T G_i       the two big contractions (only reads of R)
+//   S_r = K_i (G_i^T P_r) K_j             (:236-239)
+//   [DFMC] R_r[mask] = (G_i S_r G_j^T)[mask], P_r recomputed               (_dfmc.py:319-325)
+//   E_i += (P_r S_r^T)+ + G_i B-  ; D_i += (P_r S_r^T)- + G_i B+ ,  B = S Gram_j S^T  (:254-281)
+//   E_j += (Q_r S_r)+   + G_j D-  ; D_j += (Q_r S_r)-   + G_j D+ ,  D = S^T Gram_i S
+//   D_i += Theta+ G_i ; E_i += Theta- G_i                                   (:284-292)
+//   G_i <- G_i * sqrt(E_i / max(D_i, eps))                                  (:294-296)
+#include "skf_kernels.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/skfusion_hip.h"
+
+namespace skf {
+
+static thread_local std::string g_err;
+
+struct Error {
+    int code;
+    std::string msg;
+};
+
+#define SKF_FAIL(code_, ...)                                  \
+    do {                                                      \
+        char buf_[512];                                       \
+        snprintf(buf_, sizeof buf_, __VA_ARGS__);             \
+        throw Error{(code_), std::string(buf_)};              \
+    } while (0)
+
+#define SKF_HIP(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) SKF_FAIL(SKF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline void check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) SKF_FAIL(SKF_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+}
+
+template <class F>
+static int guarded(F&& f) {
+    try {
+        f();
+        return SKF_OK;
+    } catch (const Error& e) {
+        g_err = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return SKF_E_INVALID;
+    }
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int elem_grid(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;           // grid-stride the rest (256 CUs x 8 blocks)
+    return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------
+// GEMM dispatch
+// ------------------------------------------------------------------------------------------
+struct TileCfg {
+    int bm, bn, bk;
+};
+
+template <typename T> struct Tiles;
+template <> struct Tiles<float> {
+    static constexpr int BK = 32;
+    static TileCfg big() { return {128, 128, BK}; }
+    static TileCfg small() { return {64, 64, BK}; }
+};
+template <> struct Tiles<double> {
+    static constexpr int BK = 16;
+    static TileCfg big() { return {128, 128, BK}; }
+    static TileCfg small() { return {32, 32, BK}; }
+};
+
+static TileCfg pick_tile(bool is_f64, int engine, int M, int N) {
+    if (engine == SKF_ENGINE_VALU) return {64, 64, 16};
+    const bool big = (M > 64 && N > 64);
+    if (is_f64) return big ? Tiles<double>::big() : Tiles<double>::small();
+    return big ? Tiles<float>::big() : Tiles<float>::small();
+}
+
+// number of K slices: fill the chip (>= ~512 workgroups) when the output has few tiles
+static int pick_splits(const TileCfg& t, int M, int N, int K) {
+    const int64_t tiles = (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn);
+    if (tiles >= 256) return 1;
+    const int ktiles = cdiv(K, t.bk);
+    int s = (int)(512 / tiles);
+    const int max_by_k = ktiles / 8 > 0 ? ktiles / 8 : 1;       // at least 8 K tiles per slice
+    if (s > max_by_k) s = max_by_k;
+    if (s > 256) s = 256;
+    return s < 1 ? 1 : s;
+}
+
+template <typename T>
+static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, hipStream_t st) {
+    dim3 grid(cdiv(g.N, t.bn), cdiv(g.M, t.bm), splits);
+    dim3 block(GEMM_THREADS);
+    if (engine == SKF_ENGINE_VALU) {
+        hipLaunchKernelGGL((gemm_valu_kernel<T>), grid, block, 0, st, g);
+    } else if (t.bm == 128) {
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, 128 / (2 * Mfma<T>::MT), 128 / (2 * Mfma<T>::NT), Tiles<T>::BK>),
+                           grid, block, 0, st, g);
+    } else {
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, 1, 1, Tiles<T>::BK>), grid, block, 0, st, g);
+    }
+    check_launch("gemm");
+    if (splits > 1) {
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(elem_grid((int64_t)g.M * g.N)), dim3(256), 0, st,
+                           g, splits);
+        check_launch("splitk_reduce");
+    }
+}
+
+// `part`/`part_elems`: scratch for split-K partials (elements of T); splits is clamped to fit.
+static void run_gemm(bool is_f64, int engine, GemmArgs g, int want_splits, void* part, size_t part_elems,
+                     hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0) return;
+    const TileCfg t = pick_tile(is_f64, engine, g.M, g.N);
+    int splits = want_splits > 0 ? want_splits : pick_splits(t, g.M, g.N, g.K);
+    if (g.epi == EPI_SQDIFF) splits = 1;
+    const size_t per = (size_t)g.M * g.N;
+    if (splits > 1 && (part == nullptr || per * splits > part_elems)) {
+        splits = part ? (int)(part_elems / per) : 1;
+        if (splits < 1) splits = 1;
+    }
+    int ktiles = cdiv(g.K > 0 ? g.K : 1, t.bk);
+    if (splits > ktiles) splits = ktiles;
+    g.k_chunk = cdiv(ktiles, splits) * t.bk;
+    splits = cdiv(g.K > 0 ? g.K : 1, g.k_chunk);
+    g.part = part;
+    if (is_f64) launch_gemm_t<double>(engine, t, g, splits, st);
+    else launch_gemm_t<float>(engine, t, g, splits, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------
+struct Slot {            // a workspace sub-allocation
+    size_t off = 0, bytes = 0;
+    void* ptr = nullptr;
+};
+
+struct TypeState {
+    int64_t n = 0;
+    int c = 0;
+    int n_pad = 0;                 // eigen order (even)
+    Slot G, E, D, Gram, K;
+    Slot Bp_tot, Bn_tot, Ec, Dc;   // SKF_TRANSFORM target only
+    bool set = false;
+};
+
+struct RelState {
+    int row = 0, col = 0;
+    const void* R_in = nullptr;
+    int64_t ld_in = 0;
+    const uint8_t* mask = nullptr;
+    int64_t ldmask = 0;
+    const void* R = nullptr;       // matrix the iteration reads (R_in or the DFMC working copy)
+    int64_t ldr = 0;
+    Slot Rw, P, Q, W, T1, S, U, Bp, Bn, Dp, Dn, H;
+    bool s_set = false;
+};
+
+struct ThetaState {
+    int type = 0;
+    const void* data = nullptr;
+    int64_t ld = 0;
+};
+
+}  // namespace skf
+
+struct skf_plan {
+    int dtype = SKF_F32, variant = SKF_DFMF, target = -1, engine = SKF_ENGINE_MFMA;
+    bool f64 = false;
+    size_t esz = 4;
+    std::vector<skf::TypeState> types;
+    std::vector<skf::RelState> rels;
+    std::vector<skf::ThetaState> thetas;
+    std::vector<skf::Slot*> slots;
+    size_t ws_bytes = 0;
+    bool bound = false, prepared = false, first_iter = true;
+    // shared scratch
+    skf::Slot part;            // split-K partials
+    size_t part_elems = 0;
+    skf::Slot eigA, eigV, eigVs, eigW, eigN, eigNorig, sqpart;
+    int64_t eig_stride = 0;
+    int eig_maxn = 0;
+    size_t sq_elems = 0;
+};
+
+namespace skf {
+
+static void add_slot(skf_plan* p, Slot& s, size_t bytes) {
+    s.bytes = bytes;
+    s.off = p->ws_bytes;
+    p->ws_bytes += align_up(bytes ? bytes : 1, 256);
+    p->slots.push_back(&s);
+}
+
+static hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+static void copy2d(void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows, int64_t cols,
+                   size_t esz, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return;
+    SKF_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * esz, src, (size_t)lds * esz, (size_t)cols * esz, (size_t)rows,
+                             hipMemcpyDeviceToDevice, st));
+}
+
+static GemmArgs gemm_args(const void* A, int64_t sa_m, int64_t sa_k, const void* B, int64_t sb_k, int64_t sb_n,
+                          void* C, int64_t ldc, int M, int N, int K, int epi, int nan) {
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = A; g.B = B; g.C = C; g.C2 = nullptr; g.mask = nullptr; g.part = nullptr;
+    g.sa_m = sa_m; g.sa_k = sa_k; g.sb_k = sb_k; g.sb_n = sb_n;
+    g.ldc = ldc; g.ldc2 = ldc; g.ldmask = 0;
+    g.M = M; g.N = N; g.K = K; g.k_chunk = K;
+    g.aop = AOP_NONE; g.epi = epi; g.nan_to_num = nan;
+    return g;
+}
+
+static void plan_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
+    run_gemm(p->f64, p->engine, g, 0, p->part.ptr, p->part_elems, st);
+}
+
+// K_i = pinv(Gram_i) for every type (one workgroup each); `which` = 0..n_types-1, the order
+// of the per-matrix order arrays uploaded once by skf_plan_bind_workspace.
+static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st) {
+    if (which.empty()) return;
+    const int64_t stride = p->eig_stride;
+    for (size_t b = 0; b < which.size(); ++b) {
+        const TypeState& t = p->types[which[b]];
+        double* A = (double*)p->eigA.ptr + (int64_t)b * stride;
+        const int total = t.n_pad * t.n_pad;
+        if (p->f64)
+            hipLaunchKernelGGL((eigh_pack_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, A, t.n_pad,
+                               (const double*)t.Gram.ptr, (int64_t)t.c, t.c);
+        else
+            hipLaunchKernelGGL((eigh_pack_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st, A, t.n_pad,
+                               (const float*)t.Gram.ptr, (int64_t)t.c, t.c);
+        check_launch("eigh_pack");
+    }
+    EighArgs e;
+    e.A = (double*)p->eigA.ptr; e.V = (double*)p->eigV.ptr; e.Vs = (double*)p->eigVs.ptr;
+    e.w = (double*)p->eigW.ptr; e.stride = stride; e.wstride = p->eig_maxn;
+    e.n = (const int*)p->eigN.ptr; e.n_orig = (const int*)p->eigNorig.ptr;
+    e.max_sweeps = 30;
+    hipLaunchKernelGGL(jacobi_eigh_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), 0, st, e);
+    check_launch("jacobi_eigh");
+    for (size_t b = 0; b < which.size(); ++b) {
+        const TypeState& t = p->types[which[b]];
+        const double* Vs = (const double*)p->eigVs.ptr + (int64_t)b * stride;
+        const double* V = (const double*)p->eigV.ptr + (int64_t)b * stride;
+        const int total = t.c * t.c;
+        if (p->f64)
+            hipLaunchKernelGGL((eigh_unpack_pinv_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st,
+                               (double*)t.K.ptr, (int64_t)t.c, Vs, V, t.n_pad, t.c);
+        else
+            hipLaunchKernelGGL((eigh_unpack_pinv_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st,
+                               (float*)t.K.ptr, (int64_t)t.c, Vs, V, t.n_pad, t.c);
+        check_launch("eigh_unpack");
+    }
+}
+
+static void gram(skf_plan* p, TypeState& t, int nan, hipStream_t st) {
+    // Gram = G^T G : A = G^T (m-contiguous), B = G
+    GemmArgs g = gemm_args(t.G.ptr, 1, t.c, t.G.ptr, t.c, 1, t.Gram.ptr, t.c, t.c, t.c, (int)t.n, EPI_STORE, nan);
+    plan_gemm(p, g, st);
+}
+
+static void mult_update(skf_plan* p, TypeState& t, hipStream_t st) {
+    const int64_t total = t.n * t.c;
+    if (p->f64)
+        hipLaunchKernelGGL((mult_update_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, (double*)t.G.ptr,
+                           (const double*)t.E.ptr, (const double*)t.D.ptr, t.n, t.c, (int64_t)t.c, (int64_t)t.c);
+    else
+        hipLaunchKernelGGL((mult_update_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st, (float*)t.G.ptr,
+                           (const float*)t.E.ptr, (const float*)t.D.ptr, t.n, t.c, (int64_t)t.c, (int64_t)t.c);
+    check_launch("mult_update");
+}
+
+static void theta_terms(skf_plan* p, hipStream_t st) {
+    for (ThetaState& th : p->thetas) {
+        TypeState& t = p->types[th.type];
+        // D += Theta+ G   (_dfmf.py:285-288);  E += Theta- G   (:289-292)
+        GemmArgs g = gemm_args(th.data, th.ld, 1, t.G.ptr, t.c, 1, t.D.ptr, t.c, (int)t.n, t.c, (int)t.n, EPI_ACC, 0);
+        g.aop = AOP_POS;
+        plan_gemm(p, g, st);
+        g.C = t.E.ptr;
+        g.aop = AOP_NEG;
+        plan_gemm(p, g, st);
+    }
+}
+
+// [Xp, Xn] (+)= split( L * Gram * Rr )  helper for B = S Gram_j S^T and D = S^T Gram_i S
+// tmp = first product, then split-store/acc of the second.
+static void relation_small_terms(skf_plan* p, RelState& r, int nan_upd, int epi_split, void* Bp, void* Bn,
+                                 void* Dp, void* Dn, bool want_row, bool want_col, hipStream_t st) {
+    TypeState& ti = p->types[r.row];
+    TypeState& tj = p->types[r.col];
+    const int ci = ti.c, cj = tj.c;
+    if (want_row) {
+        // U = S Gram_j (ci x cj);  B = U S^T (ci x ci)          tmp2 of _dfmf.py:260
+        GemmArgs g = gemm_args(r.S.ptr, cj, 1, tj.Gram.ptr, cj, 1, r.U.ptr, cj, ci, cj, cj, EPI_STORE, 0);
+        plan_gemm(p, g, st);
+        g = gemm_args(r.U.ptr, cj, 1, r.S.ptr, 1, cj, Bp, ci, ci, ci, cj, epi_split, nan_upd);
+        g.C2 = Bn;
+        plan_gemm(p, g, st);
+    }
+    if (want_col) {
+        // U = Gram_i S (ci x cj);  D = S^T U (cj x cj)          tmp5 of _dfmf.py:272
+        GemmArgs g = gemm_args(ti.Gram.ptr, ci, 1, r.S.ptr, cj, 1, r.U.ptr, cj, ci, cj, ci, EPI_STORE, 0);
+        plan_gemm(p, g, st);
+        g = gemm_args(r.S.ptr, 1, cj, r.U.ptr, cj, 1, Dp, cj, cj, cj, ci, epi_split, nan_upd);
+        g.C2 = Dn;
+        plan_gemm(p, g, st);
+    }
+}
+
+static void iterate_fit(skf_plan* p, hipStream_t st) {
+    const bool dfmc = (p->variant == SKF_DFMC);
+    const int nan_upd = dfmc ? 0 : 1;       // _update_G_for_Rij (_dfmc.py:127-178) has no nan_to_num
+
+    if (dfmc && p->first_iter) {            // _dfmc.py:287-292
+        for (RelState& r : p->rels) {
+            if (!r.mask) continue;
+            const int64_t rows = p->types[r.row].n, cols = p->types[r.col].n;
+            if (p->f64)
+                hipLaunchKernelGGL((mask_zero_kernel<double>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
+                                   (double*)r.Rw.ptr, r.ldr, r.mask, r.ldmask, rows, cols);
+            else
+                hipLaunchKernelGGL((mask_zero_kernel<float>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
+                                   (float*)r.Rw.ptr, r.ldr, r.mask, r.ldmask, rows, cols);
+            check_launch("mask_zero");
+        }
+    }
+    p->first_iter = false;
+
+    std::vector<int> all;
+    for (size_t i = 0; i < p->types.size(); ++i) {
+        TypeState& t = p->types[i];
+        gram(p, t, 1, st);
+        SKF_HIP(hipMemsetAsync(t.E.ptr, 0, t.E.bytes, st));
+        SKF_HIP(hipMemsetAsync(t.D.ptr, 0, t.D.bytes, st));
+        all.push_back((int)i);
+    }
+    plan_pinv(p, all, st);
+
+    for (RelState& r : p->rels) {
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        const int ni = (int)ti.n, nj = (int)tj.n, ci = ti.c, cj = tj.c;
+        // P = R G_j
+        GemmArgs g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
+        plan_gemm(p, g, st);
+        // W = G_i^T P ; T1 = K_i W ; S = T1 K_j
+        g = gemm_args(ti.G.ptr, 1, ci, r.P.ptr, cj, 1, r.W.ptr, cj, ci, cj, ni, EPI_STORE, 0);
+        plan_gemm(p, g, st);
+        g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);
+        plan_gemm(p, g, st);
+        g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);
+        plan_gemm(p, g, st);
+        if (dfmc && r.mask) {
+            // H = G_i S ; Rw[mask] = (H G_j^T)[mask] ; P = Rw G_j        (_dfmc.py:319-325)
+            g = gemm_args(ti.G.ptr, ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, ni, cj, ci, EPI_STORE, 0);
+            plan_gemm(p, g, st);
+            g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rw.ptr, r.ldr, ni, nj, cj, EPI_MASKED_STORE, 0);
+            g.mask = r.mask;
+            g.ldmask = r.ldmask;
+            plan_gemm(p, g, st);
+            g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
+            plan_gemm(p, g, st);
+        }
+        // Q = R^T G_i
+        g = gemm_args(r.R, 1, r.ldr, ti.G.ptr, ci, 1, r.Q.ptr, ci, nj, ci, ni, EPI_STORE, 0);
+        plan_gemm(p, g, st);
+        relation_small_terms(p, r, nan_upd, EPI_SPLIT_STORE, r.Bp.ptr, r.Bn.ptr, r.Dp.ptr, r.Dn.ptr, true, true, st);
+        // E_i += (P S^T)+ ; D_i += (P S^T)-          (_dfmf.py:254-258, 278-279)
+        g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, ti.E.ptr, ci, ni, ci, cj, EPI_SPLIT_ACC, nan_upd);
+        g.C2 = ti.D.ptr;
+        plan_gemm(p, g, st);
+        // E_i += G_i B- ; D_i += G_i B+
+        g = gemm_args(ti.G.ptr, ci, 1, r.Bn.ptr, ci, 1, ti.E.ptr, ci, ni, ci, ci, EPI_ACC, 0);
+        plan_gemm(p, g, st);
+        g = gemm_args(ti.G.ptr, ci, 1, r.Bp.ptr, ci, 1, ti.D.ptr, ci, ni, ci, ci, EPI_ACC, 0);
+        plan_gemm(p, g, st);
+        // E_j += (Q S)+ ; D_j += (Q S)-              (_dfmf.py:266-270, 281-282)
+        g = gemm_args(r.Q.ptr, ci, 1, r.S.ptr, cj, 1, tj.E.ptr, cj, nj, cj, ci, EPI_SPLIT_ACC, nan_upd);
+        g.C2 = tj.D.ptr;
+        plan_gemm(p, g, st);
+        g = gemm_args(tj.G.ptr, cj, 1, r.Dn.ptr, cj, 1, tj.E.ptr, cj, nj, cj, cj, EPI_ACC, 0);
+        plan_gemm(p, g, st);
+        g = gemm_args(tj.G.ptr, cj, 1, r.Dp.ptr, cj, 1, tj.D.ptr, cj, nj, cj, cj, EPI_ACC, 0);
+        plan_gemm(p, g, st);
+    }
+    theta_terms(p, st);
+    for (TypeState& t : p->types) mult_update(p, t, st);
+}
+
+// SKF_TRANSFORM: everything that does not depend on G_target is computed once.
+static void prepare_transform(skf_plan* p, hipStream_t st) {
+    TypeState& tt = p->types[p->target];
+    SKF_HIP(hipMemsetAsync(tt.Ec.ptr, 0, tt.Ec.bytes, st));
+    SKF_HIP(hipMemsetAsync(tt.Dc.ptr, 0, tt.Dc.bytes, st));
+    SKF_HIP(hipMemsetAsync(tt.Bp_tot.ptr, 0, tt.Bp_tot.bytes, st));
+    SKF_HIP(hipMemsetAsync(tt.Bn_tot.ptr, 0, tt.Bn_tot.bytes, st));
+    for (size_t i = 0; i < p->types.size(); ++i)
+        if ((int)i != p->target) gram(p, p->types[i], 0, st);
+    for (RelState& r : p->rels) {
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        const int ni = (int)ti.n, nj = (int)tj.n, ci = ti.c, cj = tj.c;
+        if (r.row == p->target) {             // _dfmf.py:392-405
+            GemmArgs g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
+            plan_gemm(p, g, st);
+            g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, tt.Ec.ptr, ci, ni, ci, cj, EPI_SPLIT_ACC, 0);
+            g.C2 = tt.Dc.ptr;
+            plan_gemm(p, g, st);
+            relation_small_terms(p, r, 0, EPI_SPLIT_ACC, tt.Bp_tot.ptr, tt.Bn_tot.ptr, nullptr, nullptr, true,
+                                 false, st);
+        } else {                              // _dfmf.py:407-419
+            GemmArgs g = gemm_args(r.R, 1, r.ldr, ti.G.ptr, ci, 1, r.Q.ptr, ci, nj, ci, ni, EPI_STORE, 0);
+            plan_gemm(p, g, st);
+            g = gemm_args(r.Q.ptr, ci, 1, r.S.ptr, cj, 1, tt.Ec.ptr, cj, nj, cj, ci, EPI_SPLIT_ACC, 0);
+            g.C2 = tt.Dc.ptr;
+            plan_gemm(p, g, st);
+            relation_small_terms(p, r, 0, EPI_SPLIT_ACC, nullptr, nullptr, tt.Bp_tot.ptr, tt.Bn_tot.ptr, false,
+                                 true, st);
+        }
+    }
+    p->prepared = true;
+}
+
+static void iterate_transform(skf_plan* p, hipStream_t st) {
+    TypeState& tt = p->types[p->target];
+    const int n = (int)tt.n, c = tt.c;
+    SKF_HIP(hipMemcpyAsync(tt.E.ptr, tt.Ec.ptr, tt.E.bytes, hipMemcpyDeviceToDevice, st));
+    SKF_HIP(hipMemcpyAsync(tt.D.ptr, tt.Dc.ptr, tt.D.bytes, hipMemcpyDeviceToDevice, st));
+    GemmArgs g = gemm_args(tt.G.ptr, c, 1, tt.Bn_tot.ptr, c, 1, tt.E.ptr, c, n, c, c, EPI_ACC, 0);
+    plan_gemm(p, g, st);
+    g = gemm_args(tt.G.ptr, c, 1, tt.Bp_tot.ptr, c, 1, tt.D.ptr, c, n, c, c, EPI_ACC, 0);
+    plan_gemm(p, g, st);
+    theta_terms(p, st);
+    mult_update(p, tt, st);
+}
+
+}  // namespace skf
+
+using namespace skf;
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* skf_last_error(void) { return g_err.c_str(); }
+const char* skf_version(void) { return "skfusion_hip 0.1 (gfx950)"; }
+
+int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relations,
+                    const skf_relation_desc* relations, int32_t n_thetas, const skf_theta_desc* thetas,
+                    const skf_options* opt, skf_plan** out) {
+    return guarded([&] {
+        if (!out || !types || !opt || n_types <= 0) SKF_FAIL(SKF_E_INVALID, "null argument / no object types");
+        if (n_relations < 0 || n_thetas < 0 || (n_relations > 0 && !relations) || (n_thetas > 0 && !thetas))
+            SKF_FAIL(SKF_E_INVALID, "bad relation / constraint arrays");
+        if (opt->dtype != SKF_F64 && opt->dtype != SKF_F32)
+            SKF_FAIL(SKF_E_INVALID, "dtype %d not supported by this build (SKF_F64, SKF_F32)", opt->dtype);
+        if (opt->variant < SKF_DFMF || opt->variant > SKF_TRANSFORM) SKF_FAIL(SKF_E_INVALID, "bad variant");
+        if (opt->engine != SKF_ENGINE_MFMA && opt->engine != SKF_ENGINE_VALU) SKF_FAIL(SKF_E_INVALID, "bad engine");
+        skf_plan* p = new skf_plan();
+        struct Guard { skf_plan* p; ~Guard() { delete p; } } guard{p};
+        p->dtype = opt->dtype;
+        p->variant = opt->variant;
+        p->engine = opt->engine;
+        p->f64 = (opt->dtype == SKF_F64);
+        p->esz = p->f64 ? 8 : 4;
+        p->target = opt->target_type;
+        if (p->variant == SKF_TRANSFORM && (p->target < 0 || p->target >= n_types))
+            SKF_FAIL(SKF_E_INVALID, "target type %d out of range", p->target);
+        p->types.resize(n_types);
+        for (int i = 0; i < n_types; ++i) {
+            if (types[i].n_obj <= 0 || types[i].rank <= 0 || types[i].rank > EIGH_MAXN - 1)
+                SKF_FAIL(SKF_E_INVALID, "object type %d: n_obj=%lld rank=%d invalid", i, (long long)types[i].n_obj,
+                         types[i].rank);
+            if (types[i].n_obj > 2000000000LL) SKF_FAIL(SKF_E_INVALID, "object type %d too large", i);
+            p->types[i].n = types[i].n_obj;
+            p->types[i].c = types[i].rank;
+            p->types[i].n_pad = (types[i].rank + 1) / 2 * 2;
+        }
+        p->rels.resize(n_relations);
+        for (int r = 0; r < n_relations; ++r) {
+            const skf_relation_desc& d = relations[r];
+            if (d.row_type < 0 || d.row_type >= n_types || d.col_type < 0 || d.col_type >= n_types)
+                SKF_FAIL(SKF_E_INVALID, "relation %d: type index out of range", r);
+            if (d.row_type == d.col_type) SKF_FAIL(SKF_E_INVALID, "relation %d: row type == column type (pass it as a constraint)", r);
+            if (!d.data || d.ld < p->types[d.col_type].n)
+                SKF_FAIL(SKF_E_INVALID, "relation %d: dimension mismatch (ld %lld < %lld columns)", r, (long long)d.ld,
+                         (long long)p->types[d.col_type].n);
+            if (d.mask && p->variant != SKF_DFMC) SKF_FAIL(SKF_E_INVALID, "relation %d: masks need SKF_DFMC", r);
+            if (d.mask && d.mask_ld < p->types[d.col_type].n) SKF_FAIL(SKF_E_INVALID, "relation %d: mask ld", r);
+            if (p->variant == SKF_TRANSFORM && d.row_type != p->target && d.col_type != p->target)
+                SKF_FAIL(SKF_E_INVALID, "relation %d must include the target object type", r);
+            RelState& s = p->rels[r];
+            s.row = d.row_type; s.col = d.col_type;
+            s.R_in = d.data; s.ld_in = d.ld; s.mask = d.mask; s.ldmask = d.mask_ld;
+            s.R = d.data; s.ldr = d.ld;
+        }
+        p->thetas.resize(n_thetas);
+        for (int t = 0; t < n_thetas; ++t) {
+            if (thetas[t].type < 0 || thetas[t].type >= n_types || !thetas[t].data ||
+                thetas[t].ld < p->types[thetas[t].type].n)
+                SKF_FAIL(SKF_E_INVALID, "constraint %d invalid", t);
+            if (p->variant == SKF_TRANSFORM && thetas[t].type != p->target)
+                SKF_FAIL(SKF_E_INVALID, "constraint %d must be on the target object type", t);
+            p->thetas[t].type = thetas[t].type;
+            p->thetas[t].data = thetas[t].data;
+            p->thetas[t].ld = thetas[t].ld;
+        }
+        // ---- workspace layout
+        const size_t es = p->esz;
+        size_t part_elems = 0;
+        auto want_part = [&](int M, int N, int K) {
+            TileCfg t = pick_tile(p->f64, p->engine, M, N);
+            size_t need = (size_t)pick_splits(t, M, N, K) * (size_t)M * (size_t)N;
+            if (need > part_elems) part_elems = need;
+        };
+        int maxn = 2;
+        for (int i = 0; i < n_types; ++i) {
+            TypeState& t = p->types[i];
+            const bool active = (p->variant != SKF_TRANSFORM) || i == p->target;
+            add_slot(p, t.G, (size_t)t.n * t.c * es);
+            add_slot(p, t.Gram, (size_t)t.c * t.c * es);
+            want_part(t.c, t.c, (int)t.n);
+            if (active) {
+                add_slot(p, t.E, (size_t)t.n * t.c * es);
+                add_slot(p, t.D, (size_t)t.n * t.c * es);
+            }
+            if (p->variant != SKF_TRANSFORM) {
+                add_slot(p, t.K, (size_t)t.c * t.c * es);
+                if (t.n_pad > maxn) maxn = t.n_pad;
+            } else if (i == p->target) {
+                add_slot(p, t.Ec, (size_t)t.n * t.c * es);
+                add_slot(p, t.Dc, (size_t)t.n * t.c * es);
+                add_slot(p, t.Bp_tot, (size_t)t.c * t.c * es);
+                add_slot(p, t.Bn_tot, (size_t)t.c * t.c * es);
+            }
+        }
+        size_t sq_elems = 1;
+        for (RelState& r : p->rels) {
+            TypeState& ti = p->types[r.row];
+            TypeState& tj = p->types[r.col];
+            const size_t cc = (size_t)ti.c * tj.c * es;
+            add_slot(p, r.S, cc);
+            add_slot(p, r.U, cc);
+            add_slot(p, r.H, (size_t)ti.n * tj.c * es);
+            if (p->variant != SKF_TRANSFORM || r.row == p->target) add_slot(p, r.P, (size_t)ti.n * tj.c * es);
+            if (p->variant != SKF_TRANSFORM || r.col == p->target) add_slot(p, r.Q, (size_t)tj.n * ti.c * es);
+            if (p->variant != SKF_TRANSFORM) {
+                add_slot(p, r.W, cc);
+                add_slot(p, r.T1, cc);
+                add_slot(p, r.Bp, (size_t)ti.c * ti.c * es);
+                add_slot(p, r.Bn, (size_t)ti.c * ti.c * es);
+                add_slot(p, r.Dp, (size_t)tj.c * tj.c * es);
+                add_slot(p, r.Dn, (size_t)tj.c * tj.c * es);
+                want_part(ti.c, tj.c, (int)ti.n);
+            }
+            if (r.mask) add_slot(p, r.Rw, (size_t)ti.n * tj.n * es);
+            want_part((int)ti.n, tj.c, (int)tj.n);
+            want_part((int)tj.n, ti.c, (int)ti.n);
+            want_part((int)ti.n, ti.c, tj.c);
+            want_part((int)tj.n, tj.c, ti.c);
+            size_t blocks = (size_t)cdiv(ti.n, 32) * cdiv(tj.n, 32);
+            if (blocks > sq_elems) sq_elems = blocks;
+        }
+        for (ThetaState& th : p->thetas) want_part((int)p->types[th.type].n, p->types[th.type].c, (int)p->types[th.type].n);
+        p->part_elems = part_elems;
+        add_slot(p, p->part, part_elems * es);
+        p->sq_elems = sq_elems;
+        add_slot(p, p->sqpart, sq_elems * es);
+        if (p->variant != SKF_TRANSFORM) {
+            p->eig_maxn = maxn;
+            p->eig_stride = (int64_t)maxn * maxn;
+            const size_t mat = (size_t)p->eig_stride * n_types * sizeof(double);
+            add_slot(p, p->eigA, mat);
+            add_slot(p, p->eigV, mat);
+            add_slot(p, p->eigVs, mat);
+            add_slot(p, p->eigW, (size_t)maxn * n_types * sizeof(double));
+            add_slot(p, p->eigN, (size_t)n_types * sizeof(int));
+            add_slot(p, p->eigNorig, (size_t)n_types * sizeof(int));
+        }
+        guard.p = nullptr;
+        *out = p;
+    });
+}
+
+int skf_plan_destroy(skf_plan* plan) {
+    delete plan;
+    return SKF_OK;
+}
+
+int skf_plan_workspace_bytes(const skf_plan* plan, size_t* bytes) {
+    return guarded([&] {
+        if (!plan || !bytes) SKF_FAIL(SKF_E_INVALID, "null argument");
+        *bytes = plan->ws_bytes;
+    });
+}
+
+int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
+    return guarded([&] {
+        if (!p || !ws) SKF_FAIL(SKF_E_INVALID, "null argument");
+        if (bytes < p->ws_bytes) SKF_FAIL(SKF_E_WORKSPACE, "workspace %zu B < required %zu B", bytes, p->ws_bytes);
+        if (((uintptr_t)ws & 255) != 0) SKF_FAIL(SKF_E_WORKSPACE, "workspace must be 256-byte aligned");
+        for (Slot* s : p->slots) s->ptr = (char*)ws + s->off;
+        hipStream_t st = as_stream(stream);
+        for (RelState& r : p->rels) {
+            if (!r.mask) continue;
+            const int64_t rows = p->types[r.row].n, cols = p->types[r.col].n;
+            copy2d(r.Rw.ptr, cols, r.R_in, r.ld_in, rows, cols, p->esz, st);
+            r.R = r.Rw.ptr;
+            r.ldr = cols;
+        }
+        if (p->variant != SKF_TRANSFORM) {
+            std::vector<int> n_pad, n_orig;
+            for (TypeState& t : p->types) {
+                n_pad.push_back(t.n_pad);
+                n_orig.push_back(t.c);
+            }
+            SKF_HIP(hipMemcpyAsync(p->eigN.ptr, n_pad.data(), n_pad.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            SKF_HIP(hipMemcpyAsync(p->eigNorig.ptr, n_orig.data(), n_orig.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            SKF_HIP(hipStreamSynchronize(st));     // the host vectors die here; bind is not on the hot path
+        }
+        p->bound = true;
+        p->prepared = false;
+        p->first_iter = true;
+    });
+}
+
+static void check_bound(const skf_plan* p) {
+    if (!p) SKF_FAIL(SKF_E_INVALID, "null plan");
+    if (!p->bound) SKF_FAIL(SKF_E_STATE, "workspace not bound");
+}
+
+int skf_set_factor(skf_plan* p, int32_t type, const void* G, int64_t ld, void* stream) {
+    return guarded([&] {
+        check_bound(p);
+        if (type < 0 || type >= (int)p->types.size() || !G) SKF_FAIL(SKF_E_INVALID, "bad type index / pointer");
+        TypeState& t = p->types[type];
+        if (ld < t.c) SKF_FAIL(SKF_E_INVALID, "ld %lld < rank %d", (long long)ld, t.c);
+        copy2d(t.G.ptr, t.c, G, ld, t.n, t.c, p->esz, as_stream(stream));
+        t.set = true;
+        p->prepared = false;
+    });
+}
+
+int skf_get_factor(const skf_plan* p, int32_t type, void* G, int64_t ld, void* stream) {
+    return guarded([&] {
+        check_bound(p);
+        if (type < 0 || type >= (int)p->types.size() || !G) SKF_FAIL(SKF_E_INVALID, "bad type index / pointer");
+        const TypeState& t = p->types[type];
+        if (ld < t.c) SKF_FAIL(SKF_E_INVALID, "ld %lld < rank %d", (long long)ld, t.c);
+        copy2d(G, ld, t.G.ptr, t.c, t.n, t.c, p->esz, as_stream(stream));
+    });
+}
+
+int skf_set_backbone(skf_plan* p, int32_t rel, const void* S, int64_t ld, void* stream) {
+    return guarded([&] {
+        check_bound(p);
+        if (rel < 0 || rel >= (int)p->rels.size() || !S) SKF_FAIL(SKF_E_INVALID, "bad relation index / pointer");
+        RelState& r = p->rels[rel];
+        const int ci = p->types[r.row].c, cj = p->types[r.col].c;
+        if (ld < cj) SKF_FAIL(SKF_E_INVALID, "ld too small");
+        copy2d(r.S.ptr, cj, S, ld, ci, cj, p->esz, as_stream(stream));
+        r.s_set = true;
+        p->prepared = false;
+    });
+}
+
+int skf_get_backbone(const skf_plan* p, int32_t rel, void* S, int64_t ld, void* stream) {
+    return guarded([&] {
+        check_bound(p);
+        if (rel < 0 || rel >= (int)p->rels.size() || !S) SKF_FAIL(SKF_E_INVALID, "bad relation index / pointer");
+        const RelState& r = p->rels[rel];
+        const int ci = p->types[r.row].c, cj = p->types[r.col].c;
+        if (ld < cj) SKF_FAIL(SKF_E_INVALID, "ld too small");
+        copy2d(S, ld, r.S.ptr, cj, ci, cj, p->esz, as_stream(stream));
+    });
+}
+
+int skf_iterate(skf_plan* p, int32_t n_iters, void* stream) {
+    return guarded([&] {
+        check_bound(p);
+        if (n_iters < 0) SKF_FAIL(SKF_E_INVALID, "n_iters < 0");
+        for (size_t i = 0; i < p->types.size(); ++i)
+            if (!p->types[i].set) SKF_FAIL(SKF_E_STATE, "factor of object type %zu not set", i);
+        hipStream_t st = as_stream(stream);
+        if (p->variant == SKF_TRANSFORM) {
+            for (size_t r = 0; r < p->rels.size(); ++r)
+                if (!p->rels[r].s_set) SKF_FAIL(SKF_E_STATE, "backbone of relation %zu not set", r);
+            if (!p->prepared) prepare_transform(p, st);
+            for (int it = 0; it < n_iters; ++it) iterate_transform(p, st);
+        } else {
+            for (int it = 0; it < n_iters; ++it) iterate_fit(p, st);
+        }
+    });
+}
+
+int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
+    return guarded([&] {
+        check_bound(p);
+        if (rel < 0 || rel >= (int)p->rels.size() || !out) SKF_FAIL(SKF_E_INVALID, "bad relation index / pointer");
+        hipStream_t st = as_stream(stream);
+        RelState& r = p->rels[rel];
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        const int ni = (int)ti.n, nj = (int)tj.n, ci = ti.c, cj = tj.c;
+        GemmArgs g = gemm_args(ti.G.ptr, ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, ni, cj, ci, EPI_STORE, 0);
+        plan_gemm(p, g, st);
+        g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, (void*)r.R, r.ldr, ni, nj, cj, EPI_SQDIFF, 0);
+        g.C2 = p->sqpart.ptr;
+        const TileCfg t = pick_tile(p->f64, p->engine, ni, nj);
+        const int blocks = cdiv(ni, t.bm) * cdiv(nj, t.bn);
+        plan_gemm(p, g, st);
+        if (p->f64)
+            hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(1), dim3(256), 0, st, (const double*)p->sqpart.ptr,
+                               blocks, out);
+        else
+            hipLaunchKernelGGL((sum_partials_kernel<float>), dim3(1), dim3(256), 0, st, (const float*)p->sqpart.ptr,
+                               blocks, out);
+        check_launch("sum_partials");
+    });
+}
+
+int skf_gemm(int32_t dtype, int32_t engine, const skf_gemm_desc* d, void* workspace, size_t workspace_bytes,
+             void* stream) {
+    return guarded([&] {
+        if (!d || !d->A || !d->B || !d->C) SKF_FAIL(SKF_E_INVALID, "null argument");
+        if (dtype != SKF_F64 && dtype != SKF_F32) SKF_FAIL(SKF_E_INVALID, "skf_gemm: dtype must be SKF_F64 / SKF_F32");
+        if (d->epi < EPI_STORE || d->epi > EPI_MASKED_STORE) SKF_FAIL(SKF_E_INVALID, "bad epilogue");
+        if ((d->epi == EPI_SPLIT_STORE || d->epi == EPI_SPLIT_ACC) && !d->C2) SKF_FAIL(SKF_E_INVALID, "C2 missing");
+        if (d->epi == EPI_MASKED_STORE && !d->mask) SKF_FAIL(SKF_E_INVALID, "mask missing");
+        if (d->M < 0 || d->N < 0 || d->K < 0) SKF_FAIL(SKF_E_INVALID, "negative dimension");
+        GemmArgs g = gemm_args(d->A, d->sa_m, d->sa_k, d->B, d->sb_k, d->sb_n, d->C, d->ldc, d->M, d->N, d->K,
+                               d->epi, d->nan_to_num);
+        g.C2 = d->C2; g.ldc2 = d->ldc2 ? d->ldc2 : d->ldc;
+        g.mask = d->mask; g.ldmask = d->ldmask;
+        g.aop = d->aop;
+        const size_t es = dtype == SKF_F64 ? 8 : 4;
+        run_gemm(dtype == SKF_F64, engine, g, d->splits, workspace, workspace_bytes / es, as_stream(stream));
+    });
+}
+
+int skf_pinv_sym_workspace_bytes(int32_t n, size_t* bytes) {
+    return guarded([&] {
+        if (n <= 0 || n > EIGH_MAXN - 1 || !bytes) SKF_FAIL(SKF_E_INVALID, "bad order");
+        const size_t np = (size_t)(n + 1) / 2 * 2;
+        *bytes = align_up(np * np * 8, 256) * 3 + align_up(np * 8, 256) + 512;
+    });
+}
+
+int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk, int32_t n, void* ws,
+                 size_t ws_bytes, void* stream) {
+    return guarded([&] {
+        size_t need = 0;
+        if (skf_pinv_sym_workspace_bytes(n, &need) != SKF_OK) SKF_FAIL(SKF_E_INVALID, "bad order %d", n);
+        if (!A || !K || !ws || ws_bytes < need) SKF_FAIL(SKF_E_WORKSPACE, "pinv workspace too small / null pointer");
+        if (dtype != SKF_F64 && dtype != SKF_F32) SKF_FAIL(SKF_E_INVALID, "bad dtype");
+        hipStream_t st = as_stream(stream);
+        const int np = (n + 1) / 2 * 2;
+        const size_t mat = align_up((size_t)np * np * 8, 256);
+        char* base = (char*)ws;
+        double* eA = (double*)base;
+        double* eV = (double*)(base + mat);
+        double* eVs = (double*)(base + 2 * mat);
+        double* eW = (double*)(base + 3 * mat);
+        int* eN = (int*)(base + 3 * mat + align_up((size_t)np * 8, 256));
+        int* eNo = eN + 16;
+        const int total = np * np;
+        if (dtype == SKF_F64)
+            hipLaunchKernelGGL((eigh_pack_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, eA, np,
+                               (const double*)A, lda, n);
+        else
+            hipLaunchKernelGGL((eigh_pack_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st, eA, np,
+                               (const float*)A, lda, n);
+        check_launch("eigh_pack");
+        int hn = np, ho = n;
+        SKF_HIP(hipMemcpyAsync(eN, &hn, sizeof(int), hipMemcpyHostToDevice, st));
+        SKF_HIP(hipMemcpyAsync(eNo, &ho, sizeof(int), hipMemcpyHostToDevice, st));
+        SKF_HIP(hipStreamSynchronize(st));
+        EighArgs e;
+        e.A = eA; e.V = eV; e.Vs = eVs; e.w = eW; e.stride = (int64_t)np * np; e.wstride = np;
+        e.n = eN; e.n_orig = eNo; e.max_sweeps = 30;
+        hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, e);
+        check_launch("jacobi_eigh");
+        const int tot2 = n * n;
+        if (dtype == SKF_F64)
+            hipLaunchKernelGGL((eigh_unpack_pinv_kernel<double>), dim3(elem_grid(tot2)), dim3(256), 0, st, (double*)K,
+                               ldk, eVs, eV, np, n);
+        else
+            hipLaunchKernelGGL((eigh_unpack_pinv_kernel<float>), dim3(elem_grid(tot2)), dim3(256), 0, st, (float*)K,
+                               ldk, eVs, eV, np, n);
+        check_launch("eigh_unpack");
+    });
+}
+
+int skf_fill_uniform(int32_t dtype, void* dst, int64_t rows, int64_t cols, int64_t ld, uint64_t seed, double scale,
+                     double shift, void* stream) {
+    return guarded([&] {
+        if (!dst || rows < 0 || cols < 0 || ld < cols) SKF_FAIL(SKF_E_INVALID, "bad argument");
+        hipStream_t st = as_stream(stream);
+        const int grid = elem_grid(rows * cols);
+        if (dtype == SKF_F64)
+            hipLaunchKernelGGL((fill_uniform_kernel<double>), dim3(grid), dim3(256), 0, st, (double*)dst, rows, cols, ld,
+                               seed, scale, shift);
+        else if (dtype == SKF_F32)
+            hipLaunchKernelGGL((fill_uniform_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)dst, rows, cols, ld,
+                               seed, scale, shift);
+        else if (dtype == SKF_BF16)
+            hipLaunchKernelGGL((fill_uniform_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, (uint16_t*)dst, rows, cols,
+                               ld, seed, scale, shift);
+        else
+            SKF_FAIL(SKF_E_INVALID, "bad dtype");
+        check_launch("fill_uniform");
+    });
+}
+
+int skf_cast(int32_t dst_dtype, void* dst, int64_t ldd, int32_t src_dtype, const void* src, int64_t lds, int64_t rows,
+             int64_t cols, void* stream) {
+    return guarded([&] {
+        if (!dst || !src || rows < 0 || cols < 0) SKF_FAIL(SKF_E_INVALID, "bad argument");
+        hipStream_t st = as_stream(stream);
+        const int grid = elem_grid(rows * cols);
+        if (dst_dtype == SKF_F32 && src_dtype == SKF_F64)
+            hipLaunchKernelGGL((cast_kernel<float, double>), dim3(grid), dim3(256), 0, st, (float*)dst, ldd,
+                               (const double*)src, lds, rows, cols);
+        else if (dst_dtype == SKF_F64 && src_dtype == SKF_F32)
+            hipLaunchKernelGGL((cast_kernel<double, float>), dim3(grid), dim3(256), 0, st, (double*)dst, ldd,
+                               (const float*)src, lds, rows, cols);
+        else if (dst_dtype == SKF_F32 && src_dtype == SKF_F32)
+            hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (float*)dst, ldd,
+                               (const float*)src, lds, rows, cols);
+        else if (dst_dtype == SKF_F64 && src_dtype == SKF_F64)
+            hipLaunchKernelGGL((cast_kernel<double, double>), dim3(grid), dim3(256), 0, st, (double*)dst, ldd,
+                               (const double*)src, lds, rows, cols);
+        else
+            SKF_FAIL(SKF_E_INVALID, "unsupported cast %d -> %d", src_dtype, dst_dtype);
+        check_launch("cast");
+    });
+}
+
+}  // extern "C"

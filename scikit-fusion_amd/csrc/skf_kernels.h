@@ -1,0 +1,654 @@
+// skf_kernels.h -- hand-written gfx950 (CDNA4, wave64) kernels of the DFMF/DFMC update loop.
+//
+// Data layout in HBM: every matrix is row-major with an explicit leading dimension.
+// Masters (G, E, D, S, Gram, K, P, Q) are f64 in the SKF_F64 engine and f32 otherwise.
+//
+// Kernels
+//   gemm_mfma_kernel<T,..>   C = epi(aop(A) * B)   tall-skinny / small dense contractions on the
+//                            matrix cores: v_mfma_f32_32x32x2_f32 (T=float, exact f32, 157 TF
+//                            peak) and v_mfma_f64_16x16x4_f64 (T=double).  Operands are addressed
+//                            through (row,col) strides so that R, R^T, G, G^T, S, S^T all feed
+//                            the same kernel; tiles are staged k-major in LDS so that the MFMA
+//                            fragment reads are conflict-free ds_read_b32 / b64.
+//   gemm_valu_kernel<T>      the same contract on the vector ALU (bring-up / cross-check engine).
+//   splitk_reduce_kernel<T>  deterministic second stage for split-K launches + the epilogues.
+//   jacobi_eigh_kernel       symmetric c x c eigen-decomposition (parallel two-sided cyclic
+//                            Jacobi, f64, one workgroup per matrix) -> pinv with the SVD cut-off
+//                            of scipy.linalg.pinv (reference _dfmf.py:232).
+//   mult_update_kernel<T>    G <- G * sqrt(E / max(D, eps))               (_dfmf.py:294-296)
+//   fill_uniform_kernel<T>   counter-based synthetic data, identical to oracle hash_uniform().
+//   mask / cast / sqerr helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace skf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+enum AOp { AOP_NONE = 0, AOP_POS = 1, AOP_NEG = 2 };                 // x, max(x,0), max(-x,0)
+enum Epi {
+    EPI_STORE = 0,         // C  = v
+    EPI_ACC = 1,           // C += v
+    EPI_SPLIT_STORE = 2,   // C  = max(v,0) ; C2  = max(-v,0)
+    EPI_SPLIT_ACC = 3,     // C += max(v,0) ; C2 += max(-v,0)       (_dfmf.py:256-258,278-282)
+    EPI_MASKED_STORE = 4,  // C  = v where mask != 0                (_dfmc.py:319-325)
+    EPI_SQDIFF = 5         // per-workgroup partial of sum (C - v)^2 -> C2[block]  (C untouched)
+};
+
+struct GemmArgs {
+    const void* A;
+    const void* B;
+    void* C;
+    void* C2;
+    const uint8_t* mask;     // EPI_MASKED_STORE: byte mask, same shape as C, leading dim ldmask
+    void* part;              // split-K partials [gridDim.z][M][N] (used when gridDim.z > 1)
+    int64_t sa_m, sa_k;      // A(m,k) = A[m*sa_m + k*sa_k]
+    int64_t sb_k, sb_n;      // B(k,n) = B[k*sb_k + n*sb_n]
+    int64_t ldc, ldc2, ldmask;
+    int M, N, K;
+    int k_chunk;             // K range handled by one z-slice
+    int aop, epi, nan_to_num;
+};
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+template <typename T> struct Lim;
+template <> struct Lim<float> { static __device__ __host__ float big() { return 3.40282346638528859812e+38f; } };
+template <> struct Lim<double> { static __device__ __host__ double big() { return 1.79769313486231570815e+308; } };
+
+// numpy.nan_to_num: NaN -> 0, +inf -> largest finite, -inf -> most negative finite
+template <typename T>
+__device__ __forceinline__ T nan_to_num(T x) {
+    if (x != x) return (T)0;
+    if (x > Lim<T>::big()) return Lim<T>::big();
+    if (x < -Lim<T>::big()) return -Lim<T>::big();
+    return x;
+}
+
+template <typename T>
+__device__ __forceinline__ T apply_aop(T x, int aop) {
+    if (aop == AOP_POS) return x > (T)0 ? x : (T)0;
+    if (aop == AOP_NEG) return x > (T)0 ? (T)0 : -x;      // (t-1)*x of the reference, >= 0
+    return x;
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int m, int n, T v) {
+    T* C = (T*)g.C;
+    T* C2 = (T*)g.C2;
+    if (g.nan_to_num) v = nan_to_num(v);
+    const int64_t i = (int64_t)m * g.ldc + n;
+    const int64_t i2 = (int64_t)m * g.ldc2 + n;
+    switch (g.epi) {
+        case EPI_STORE: C[i] = v; break;
+        case EPI_ACC: C[i] += v; break;
+        case EPI_SPLIT_STORE:
+            C[i] = v > (T)0 ? v : (T)0;
+            C2[i2] = v > (T)0 ? (T)0 : -v;
+            break;
+        case EPI_SPLIT_ACC:
+            C[i] += v > (T)0 ? v : (T)0;
+            C2[i2] += v > (T)0 ? (T)0 : -v;
+            break;
+        case EPI_MASKED_STORE:
+            if (g.mask[(int64_t)m * g.ldmask + n]) C[i] = v;
+            break;
+        default: break;
+    }
+}
+
+// sum over the 64 lanes of a wave (result valid in every lane)
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA traits: one matrix-core instruction per (T): tile MT x NT, depth KT per instruction
+// ------------------------------------------------------------------------------------------
+template <typename T> struct Mfma;
+
+template <> struct Mfma<float> {          // v_mfma_f32_32x32x2_f32: 16 accumulator regs / lane
+    static constexpr int MT = 32, NT = 32, KT = 2, NREG = 16;
+    typedef f32x16 acc_t;
+    static __device__ __forceinline__ int a_row(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int ab_k(int lane) { return lane >> 5; }
+    static __device__ __forceinline__ int d_row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+    static __device__ __forceinline__ int d_col(int lane) { return lane & 31; }
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+};
+
+template <> struct Mfma<double> {         // v_mfma_f64_16x16x4_f64: 4 f64 accumulators / lane
+    static constexpr int MT = 16, NT = 16, KT = 4, NREG = 4;
+    typedef f64x4 acc_t;
+    static __device__ __forceinline__ int a_row(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int ab_k(int lane) { return lane >> 4; }
+    static __device__ __forceinline__ int d_row(int lane, int r) { return (lane >> 4) + 4 * r; }
+    static __device__ __forceinline__ int d_col(int lane) { return lane & 15; }
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// cooperative tile staging: global (any strides) -> registers -> LDS (k-major, padded)
+// 256 threads; element e = tid + i*256.  The fast index follows the contiguous global stride
+// so that a wave touches whole 128-256 B segments.
+// ------------------------------------------------------------------------------------------
+constexpr int GEMM_THREADS = 256;
+
+template <typename T, int ROWS, int BK>
+__device__ __forceinline__ void stage_load(T (&reg)[ROWS * BK / GEMM_THREADS], const T* __restrict__ src,
+                                           int64_t s_row, int64_t s_k, int row0, int k0, int row_end,
+                                           int k_end, int aop, int tid) {
+    constexpr int PER = ROWS * BK / GEMM_THREADS;
+    const bool k_fast = (s_k == 1);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + i * GEMM_THREADS;
+        const int k = k_fast ? (e % BK) : (e / ROWS);
+        const int r = k_fast ? (e / BK) : (e % ROWS);
+        const int gr = row0 + r, gk = k0 + k;
+        T v = (T)0;
+        if (gr < row_end && gk < k_end) v = src[(int64_t)gr * s_row + (int64_t)gk * s_k];
+        reg[i] = apply_aop(v, aop);
+    }
+}
+
+template <typename T, int ROWS, int BK, int LD>
+__device__ __forceinline__ void stage_store(T (*lds)[LD], const T (&reg)[ROWS * BK / GEMM_THREADS],
+                                            bool k_fast, int tid) {
+    constexpr int PER = ROWS * BK / GEMM_THREADS;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + i * GEMM_THREADS;
+        const int k = k_fast ? (e % BK) : (e / ROWS);
+        const int r = k_fast ? (e / BK) : (e % ROWS);
+        lds[k][r] = reg[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA GEMM.  Workgroup = 4 waves in a 2 x 2 arrangement; wave tile = (WR*MT) x (WC*NT);
+// block tile BM x BN = 2*WR*MT x 2*WC*NT; K tile BK; grid = (ceil(N/BN), ceil(M/BM), splits).
+// One K step:  [global loads of tile t+1 in flight]  MFMA on tile t from LDS  | barrier |
+//              registers -> LDS | barrier.
+// ------------------------------------------------------------------------------------------
+template <typename T, int WR, int WC, int BK>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
+    typedef Mfma<T> MF;
+    constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
+    constexpr int LDA = BM + 1, LDB = BN + 1;
+    __shared__ T As[BK][LDA];
+    __shared__ T Bs[BK][LDB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * (WR * MF::MT), wn0 = (wave & 1) * (WC * MF::NT);
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    const int kz0 = blockIdx.z * g.k_chunk;
+    const int kz1 = (kz0 + g.k_chunk < g.K) ? kz0 + g.k_chunk : g.K;
+    const T* __restrict__ A = (const T*)g.A;
+    const T* __restrict__ B = (const T*)g.B;
+    const bool a_kfast = (g.sa_k == 1), b_kfast = (g.sb_k == 1);
+
+    typename MF::acc_t acc[WR][WC];
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int j = 0; j < WC; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) acc[i][j][r] = (T)0;
+
+    T ra[BM * BK / GEMM_THREADS], rb[BN * BK / GEMM_THREADS];
+    const int nkt = (kz1 - kz0 + BK - 1) / BK;
+    if (nkt > 0) {
+        stage_load<T, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, kz0, g.M, kz1, g.aop, tid);
+        stage_load<T, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, kz0, g.N, kz1, AOP_NONE, tid);
+        stage_store<T, BM, BK, LDA>(As, ra, a_kfast, tid);
+        stage_store<T, BN, BK, LDB>(Bs, rb, b_kfast, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1 < nkt);
+        if (more) {
+            const int k0 = kz0 + (kt + 1) * BK;
+            stage_load<T, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, k0, g.M, kz1, g.aop, tid);
+            stage_load<T, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, k0, g.N, kz1, AOP_NONE, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += MF::KT) {
+            T a[WR], b[WC];
+            const int kr = kk + MF::ab_k(lane);
+#pragma unroll
+            for (int i = 0; i < WR; ++i) a[i] = As[kr][wm0 + i * MF::MT + MF::a_row(lane)];
+#pragma unroll
+            for (int j = 0; j < WC; ++j) b[j] = Bs[kr][wn0 + j * MF::NT + MF::a_row(lane)];
+#pragma unroll
+            for (int i = 0; i < WR; ++i)
+#pragma unroll
+                for (int j = 0; j < WC; ++j) acc[i][j] = MF::mma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+        if (more) {
+            stage_store<T, BM, BK, LDA>(As, ra, a_kfast, tid);
+            stage_store<T, BN, BK, LDB>(Bs, rb, b_kfast, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const bool split = (gridDim.z > 1);
+    T sq = (T)0;
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int j = 0; j < WC; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) {
+                const int m = bm0 + wm0 + i * MF::MT + MF::d_row(lane, r);
+                const int n = bn0 + wn0 + j * MF::NT + MF::d_col(lane);
+                if (m < g.M && n < g.N) {
+                    const T v = acc[i][j][r];
+                    if (split) {
+                        ((T*)g.part)[((int64_t)blockIdx.z * g.M + m) * g.N + n] = v;
+                    } else if (g.epi == EPI_SQDIFF) {
+                        const T d = ((const T*)g.C)[(int64_t)m * g.ldc + n] - v;
+                        sq += d * d;
+                    } else {
+                        epilogue_store<T>(g, m, n, v);
+                    }
+                }
+            }
+    if (!split && g.epi == EPI_SQDIFF) {
+        __shared__ T red[GEMM_THREADS / 64];
+        sq = wave_sum(sq);
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            T s = (T)0;
+            for (int w = 0; w < GEMM_THREADS / 64; ++w) s += red[w];
+            ((T*)g.C2)[blockIdx.y * gridDim.x + blockIdx.x] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// vector-ALU GEMM with the same contract (64 x 64 block tile, 4 x 4 outputs per thread).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_valu_kernel(GemmArgs g) {
+    constexpr int BM = 64, BN = 64, BK = 16, LDT = BM + 1;
+    __shared__ T As[BK][LDT];
+    __shared__ T Bs[BK][LDT];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;          // 16 x 16 threads, 4 x 4 outputs each
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    const int kz0 = blockIdx.z * g.k_chunk;
+    const int kz1 = (kz0 + g.k_chunk < g.K) ? kz0 + g.k_chunk : g.K;
+    const T* __restrict__ A = (const T*)g.A;
+    const T* __restrict__ B = (const T*)g.B;
+    const bool a_kfast = (g.sa_k == 1), b_kfast = (g.sb_k == 1);
+    T acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (T)0;
+    T ra[BM * BK / GEMM_THREADS], rb[BN * BK / GEMM_THREADS];
+    for (int k0 = kz0; k0 < kz1; k0 += BK) {
+        stage_load<T, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, k0, g.M, kz1, g.aop, tid);
+        stage_load<T, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, k0, g.N, kz1, AOP_NONE, tid);
+        __syncthreads();
+        stage_store<T, BM, BK, LDT>(As, ra, a_kfast, tid);
+        stage_store<T, BN, BK, LDT>(Bs, rb, b_kfast, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) {
+            T a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty + 16 * i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+    }
+    const bool split = (gridDim.z > 1);
+    T sq = (T)0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = bm0 + ty + 16 * i, n = bn0 + tx + 16 * j;
+            if (m < g.M && n < g.N) {
+                const T v = acc[i][j];
+                if (split) {
+                    ((T*)g.part)[((int64_t)blockIdx.z * g.M + m) * g.N + n] = v;
+                } else if (g.epi == EPI_SQDIFF) {
+                    const T d = ((const T*)g.C)[(int64_t)m * g.ldc + n] - v;
+                    sq += d * d;
+                } else {
+                    epilogue_store<T>(g, m, n, v);
+                }
+            }
+        }
+    if (!split && g.epi == EPI_SQDIFF) {
+        __shared__ T red[GEMM_THREADS / 64];
+        sq = wave_sum(sq);
+        if ((tid & 63) == 0) red[tid >> 6] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            T s = (T)0;
+            for (int w = 0; w < GEMM_THREADS / 64; ++w) s += red[w];
+            ((T*)g.C2)[blockIdx.y * gridDim.x + blockIdx.x] = s;
+        }
+    }
+}
+
+// second stage of a split-K launch: fixed-order sum over the slices, then the epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int splits) {
+    const int64_t total = (int64_t)g.M * g.N;
+    const T* part = (const T*)g.part;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        T v = (T)0;
+        for (int z = 0; z < splits; ++z) v += part[(int64_t)z * total + e];
+        epilogue_store<T>(g, (int)(e / g.N), (int)(e % g.N), v);
+    }
+}
+
+// out[0] = sum_k part[k] in f64, fixed order (single workgroup)
+template <typename T>
+__global__ __launch_bounds__(256) void sum_partials_kernel(const T* __restrict__ part, int n, double* out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int k = threadIdx.x; k < n; k += 256) s += (double)part[k];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// G <- G * sqrt(E / max(D, eps))     reference _dfmf.py:294-296, eps = finfo(float64).eps
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mult_update_kernel(T* __restrict__ G, const T* __restrict__ E,
+                                                          const T* __restrict__ D, int64_t rows, int cols,
+                                                          int64_t ldg, int64_t lde) {
+    const T eps = (T)2.220446049250313e-16;
+    const int64_t total = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / cols;
+        const int c = (int)(e % cols);
+        const T d = D[r * lde + c];
+        const T den = (d > eps || d != d) ? d : eps;     // np.maximum(D, eps) (NaN propagates)
+        const T q = E[r * lde + c] / den;
+        G[r * ldg + c] = G[r * ldg + c] * (T)sqrt(q);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// counter-based synthetic data, bit-identical to oracle/dfmf_oracle.py::hash_uniform
+// ------------------------------------------------------------------------------------------
+__device__ __host__ __forceinline__ double hash_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + idx;
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 40) * (1.0 / 16777216.0);
+}
+
+__device__ __host__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    union { float f; uint32_t u; } x;
+    x.f = f;
+    if ((x.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x.u >> 16) | 0x40);   // quiet NaN
+    const uint32_t r = 0x7fffu + ((x.u >> 16) & 1u);
+    return (uint16_t)((x.u + r) >> 16);
+}
+
+template <typename T> __device__ __forceinline__ T from_double(double v) { return (T)v; }
+template <> __device__ __forceinline__ uint16_t from_double<uint16_t>(double v) { return f32_to_bf16_rne((float)v); }
+
+// element (r, c) of a rows x cols matrix gets hash_uniform(seed, r*cols + c) * scale + shift
+template <typename T>
+__global__ __launch_bounds__(256) void fill_uniform_kernel(T* __restrict__ dst, int64_t rows, int64_t cols,
+                                                           int64_t ld, uint64_t seed, double scale,
+                                                           double shift) {
+    const int64_t total = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / cols, c = e % cols;
+        dst[r * ld + c] = from_double<T>(hash_uniform(seed, (uint64_t)e) * scale + shift);
+    }
+}
+
+// dst(r,c) = (TD) src(r,c)   (f64 <-> f32 conversions of factors / relations)
+template <typename TD, typename TS>
+__global__ __launch_bounds__(256) void cast_kernel(TD* __restrict__ dst, int64_t ldd,
+                                                   const TS* __restrict__ src, int64_t lds, int64_t rows,
+                                                   int64_t cols) {
+    const int64_t total = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / cols, c = e % cols;
+        dst[r * ldd + c] = (TD)src[r * lds + c];
+    }
+}
+
+// DFMC iteration 0: R[mask] = 0   (_dfmc.py:287-292)
+template <typename T>
+__global__ __launch_bounds__(256) void mask_zero_kernel(T* __restrict__ R, int64_t ldr,
+                                                        const uint8_t* __restrict__ mask, int64_t ldm,
+                                                        int64_t rows, int64_t cols) {
+    const int64_t total = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / cols, c = e % cols;
+        if (mask[r * ldm + c]) R[r * ldr + c] = (T)0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Symmetric eigen-decomposition by parallel two-sided cyclic Jacobi (f64), one workgroup per
+// matrix (blockIdx.x selects the matrix).  A (n x n, row-major, ld = n) is overwritten; V
+// receives the eigenvectors as columns; w the eigenvalues.  n must be even (the host pads an
+// odd matrix with one decoupled row/column).  Round-robin ("chess tournament") ordering gives
+// n/2 disjoint rotation pairs per round and n-1 rounds per sweep.
+// Afterwards:  Vs = V * diag(winv),  winv_k = 1/w_k if |w_k| > n_orig * eps * max|w| else 0
+// (scipy.linalg.pinv cut-off, rtol = max(M,N)*eps), so that pinv(A) = Vs * V^T.
+// ------------------------------------------------------------------------------------------
+struct EighArgs {
+    double* A;        // [batch] pointers are derived as A + b*stride
+    double* V;
+    double* Vs;
+    double* w;
+    int64_t stride;   // elements between consecutive matrices in A / V / Vs
+    int64_t wstride;
+    const int* n;     // per-matrix (padded, even) order
+    const int* n_orig;
+    int max_sweeps;
+};
+
+constexpr int EIGH_THREADS = 512;
+constexpr int EIGH_MAXN = 1024;
+
+__device__ __forceinline__ void jacobi_pair(int round, int k, int n, int& p, int& q) {
+    // players 0..n-1, player n-1 fixed, the others rotate
+    const int m = n - 1;
+    int a, b;
+    if (k == 0) {
+        a = n - 1;
+        b = round % m;
+    } else {
+        a = (round + k) % m;
+        b = (round - k + m) % m;
+    }
+    p = a < b ? a : b;
+    q = a < b ? b : a;
+}
+
+__global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) {
+    __shared__ double cs[EIGH_MAXN / 2], sn[EIGH_MAXN / 2];
+    __shared__ int pp[EIGH_MAXN / 2], qq[EIGH_MAXN / 2];
+    __shared__ double red[EIGH_THREADS / 64];
+    __shared__ double s_off, s_diag;
+    const int b = blockIdx.x;
+    const int n = e.n[b];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double* A = e.A + (int64_t)b * e.stride;
+    double* V = e.V + (int64_t)b * e.stride;
+    double* Vs = e.Vs + (int64_t)b * e.stride;
+    double* w = e.w + (int64_t)b * e.wstride;
+    const int half = n / 2;
+
+    // symmetrise, V = I
+    for (int idx = tid; idx < n * n; idx += nt) {
+        const int r = idx / n, c = idx % n;
+        V[idx] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += nt) {
+        const int r = idx / n, c = idx % n;
+        if (r < c) {
+            const double s = 0.5 * (A[r * n + c] + A[c * n + r]);
+            A[r * n + c] = s;
+            A[c * n + r] = s;
+        }
+    }
+    __syncthreads();
+
+    for (int sweep = 0; sweep < e.max_sweeps; ++sweep) {
+        // convergence: off-diagonal Frobenius mass relative to the diagonal
+        double off = 0.0, dg = 0.0;
+        for (int idx = tid; idx < n * n; idx += nt) {
+            const int r = idx / n, c = idx % n;
+            const double v = A[idx];
+            if (r == c) dg += v * v; else off += v * v;
+        }
+        off = wave_sum(off);
+        dg = wave_sum(dg);
+        if ((tid & 63) == 0) red[tid >> 6] = off;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < nt / 64; ++i) s += red[i];
+            s_off = s;
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = dg;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < nt / 64; ++i) s += red[i];
+            s_diag = s;
+        }
+        __syncthreads();
+        if (s_off <= 1e-30 * s_diag || s_off == 0.0) break;       // uniform across the block
+
+        for (int round = 0; round < n - 1; ++round) {
+            // phase 1: rotation angles of the n/2 disjoint pairs
+            for (int k = tid; k < half; k += nt) {
+                int p, q;
+                jacobi_pair(round, k, n, p, q);
+                const double app = A[p * n + p], aqq = A[q * n + q], apq = A[p * n + q];
+                double c = 1.0, s = 0.0;
+                if (apq != 0.0) {
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + t * t);
+                    s = t * c;
+                }
+                cs[k] = c; sn[k] = s; pp[k] = p; qq[k] = q;
+            }
+            __syncthreads();
+            // phase 2: columns  A <- A J,  V <- V J   (row r, pair k)
+            for (int idx = tid; idx < n * half; idx += nt) {
+                const int r = idx / half, k = idx % half;
+                const int p = pp[k], q = qq[k];
+                const double c = cs[k], s = sn[k];
+                const double arp = A[r * n + p], arq = A[r * n + q];
+                A[r * n + p] = c * arp - s * arq;
+                A[r * n + q] = s * arp + c * arq;
+                const double vrp = V[r * n + p], vrq = V[r * n + q];
+                V[r * n + p] = c * vrp - s * vrq;
+                V[r * n + q] = s * vrp + c * vrq;
+            }
+            __syncthreads();
+            // phase 3: rows  A <- J^T A   (pair k, column col)
+            for (int idx = tid; idx < half * n; idx += nt) {
+                const int k = idx / n, col = idx % n;
+                const int p = pp[k], q = qq[k];
+                const double c = cs[k], s = sn[k];
+                const double apc = A[p * n + col], aqc = A[q * n + col];
+                A[p * n + col] = c * apc - s * aqc;
+                A[q * n + col] = s * apc + c * aqc;
+            }
+            __syncthreads();
+        }
+    }
+
+    // eigenvalues, cut-off, scaled eigenvectors
+    double mx = 0.0;
+    for (int k = tid; k < n; k += nt) {
+        const double v = A[k * n + k];
+        w[k] = v;
+        mx = fmax(mx, fabs(v));
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nt / 64; ++i) s = fmax(s, red[i]);
+        s_off = s;
+    }
+    __syncthreads();
+    const double thr = (double)e.n_orig[b] * 2.220446049250313e-16 * s_off;
+    for (int idx = tid; idx < n * n; idx += nt) {
+        const int c = idx % n;
+        const double wc = w[c];
+        const double inv = (fabs(wc) > thr) ? 1.0 / wc : 0.0;
+        Vs[idx] = V[idx] * inv;
+    }
+}
+
+// pad / unpad helpers for the eigen workspace: dst (f64, n_pad x n_pad) <- src (T, n x n);
+// the padding row/column is decoupled (zero off-diagonal, zero diagonal -> eigenvalue 0).
+template <typename T>
+__global__ __launch_bounds__(256) void eigh_pack_kernel(double* __restrict__ dst, int n_pad,
+                                                        const T* __restrict__ src, int64_t lds, int n) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_pad * n_pad; idx += gridDim.x * blockDim.x) {
+        const int r = idx / n_pad, c = idx % n_pad;
+        dst[idx] = (r < n && c < n) ? (double)src[(int64_t)r * lds + c] : 0.0;
+    }
+}
+
+// K(r,c) = sum_k Vs(r,k) * V(c,k), r,c < n  (tiny c x c product, f64 accumulate, cast to T)
+template <typename T>
+__global__ __launch_bounds__(256) void eigh_unpack_pinv_kernel(T* __restrict__ K, int64_t ldk,
+                                                               const double* __restrict__ Vs,
+                                                               const double* __restrict__ V, int n_pad, int n) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
+        const int r = idx / n, c = idx % n;
+        double s = 0.0;
+        for (int k = 0; k < n_pad; ++k) s += Vs[r * n_pad + k] * V[c * n_pad + k];
+        K[(int64_t)r * ldk + c] = (T)s;
+    }
+}
+
+}  // namespace skf

@@ -1,0 +1,157 @@
+"""Functional solver seam of DFMF and of the fold-in transform -- same signatures as the
+reference's ``dfmf()`` (_dfmf.py:127-129) and ``transform()`` (_dfmf.py:330-333) -- driving the
+device engine.  ``R`` / ``Theta`` are dictionaries keyed by (row_type, col_type) whose values
+are LISTS of matrices; the result is ``(G, S)`` with ``G[(t, t)]`` and ``S[(i, j)] = [..]``.
+
+Extra keyword-only engine options (defaults keep the reference behaviour):
+  dtype   'f64' (default, parity with the float64 reference) | 'f32'
+  G0      dict {(t,t): ndarray} overriding the initialiser (warm start / parity tests)
+"""
+import logging
+
+import numpy as np
+
+from ... import _native as nat
+from ..._engine import DevicePlan, flatten_relations, flatten_thetas, count_objects
+from ._init import initialize
+
+log = logging.getLogger('skfusion_amd')
+
+
+def _as_rs(random_state):
+    if isinstance(random_state, np.random.RandomState):
+        return random_state
+    return np.random.RandomState(random_state)
+
+
+def _collect(plan, obj_types, rel_list):
+    G = {(t, t): plan.get_factor(t) for t in obj_types}
+    S = {}
+    for k, (i, j, _, _) in enumerate(rel_list):
+        S.setdefault((i, j), []).append(plan.get_backbone(k))
+    return G, S
+
+
+def _rel_index(rel_list, target):
+    """target = (row, col) or ((row, col), l) -> flat relation index."""
+    if isinstance(target[0], tuple):
+        pair, l = target
+    else:
+        pair, l = target, 0
+    hits = [k for k, (i, j, _, _) in enumerate(rel_list) if (i, j) == tuple(pair)]
+    return hits[l]
+
+
+def run_fit(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type, stopping,
+            stopping_system, verbose, compute_err, callback, random_state, dtype, G0, engine):
+    """Shared driver of dfmf / dfmc: the body of the reference loops (_dfmf.py:212-322,
+    _dfmc.py:270-392) with the arithmetic on the device."""
+    logging.basicConfig(format="%(asctime)s %(levelname)s: %(message)s", level=50 - verbose)
+    obj_types = list(obj_types)
+    n_obj = count_objects(obj_types, R)
+    if G0 is None:
+        R_first = {k: np.asarray(v[0], dtype=float) for k, v in R.items()}
+        G0 = initialize(obj_types, n_obj, obj_type2rank, R_first, init_type, _as_rs(random_state))
+    rel_list = flatten_relations(R, M)
+    plan = DevicePlan(obj_types, n_obj, obj_type2rank, rel_list, flatten_thetas(Theta), variant,
+                      dtype=dtype, engine=engine)
+    try:
+        for t in obj_types:
+            plan.set_factor(t, G0[t, t])
+        if stopping_system:
+            compute_err = True
+        host_loop = bool(callback or stopping or compute_err)
+        if not host_loop:
+            plan.iterate(max_iter)              # whole loop device-resident, no host sync
+        else:
+            err_t = (None, None)
+            err_s = (None, None)
+            objective = []
+            for it in range(max_iter):
+                if it > 1 and stopping and err_t[1] - err_t[0] < stopping[1]:
+                    log.info("Early stopping: target matrix change < %5.4f", stopping[1])
+                    break
+                if it > 1 and stopping_system and err_s[1] - err_s[0] < stopping_system:
+                    log.info("Early stopping: matrix system change < %5.4f", stopping_system)
+                    break
+                plan.iterate(1)
+                if stopping:
+                    k = _rel_index(rel_list, stopping[0])
+                    err_t = (np.sqrt(plan.relation_sqerr(k)), err_t[0])
+                if compute_err:
+                    s = 0.
+                    for k, (i, j, _, _) in enumerate(rel_list):
+                        e = np.sqrt(plan.relation_sqerr(k))
+                        log.info("Relation R_%s,%s norm difference: %5.4f", i, j, e)
+                        s += e
+                    log.info("Error (objective function value): %5.4f", s)
+                    objective.append(s)
+                    err_s = (s, err_s[0])
+                if callback:
+                    G, S = _collect(plan, obj_types, rel_list)
+                    callback(G, S, it)
+            if compute_err:
+                log.info("Violations of optimization objective: %d/%d",
+                         int(np.sum(np.diff(objective) > 0)), len(objective))
+        return _collect(plan, obj_types, rel_list)
+    finally:
+        plan.close()
+
+
+def dfmf(R, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol",
+         stopping=None, stopping_system=None, verbose=0, compute_err=False, callback=None,
+         random_state=None, n_jobs=1, dtype='f64', G0=None, engine=None):
+    """Data fusion by matrix factorization -- drop-in for reference ``dfmf`` (_dfmf.py:127)."""
+    return run_fit(nat.SKF_DFMF, R, None, Theta, obj_types, obj_type2rank, max_iter, init_type,
+                   stopping, stopping_system, verbose, compute_err, callback, random_state,
+                   dtype, G0, engine)
+
+
+def transform(R_ij, Theta_i, target_obj_type, obj_type2rank, G, S, max_iter=10,
+              init_type="random_c", stopping=None, stopping_system=None, verbose=0,
+              compute_err=False, callback=None, random_state=None, dtype='f64', G0=None,
+              engine=None):
+    """Fold new objects of ``target_obj_type`` into a fitted latent space -- drop-in for
+    reference ``transform`` (_dfmf.py:330-458): only the target factor moves, ``G`` of the other
+    types and ``S`` (1-element lists per pair) stay frozen.  callback(G_i, iter)."""
+    logging.basicConfig(format="%(asctime)s %(levelname)s: %(message)s", level=50 - verbose)
+    t = target_obj_type
+    sizes = [R_ij[i, j][0].shape[0 if t == i else 1] for i, j in R_ij]
+    if len(set(sizes)) > 1:
+        from ..base import DataFusionError
+        raise DataFusionError("Target object type: %s size mismatch" % t)
+    n_t = sizes[0]
+    if G0 is None:
+        R_first = {k: np.asarray(v[0], dtype=float) for k, v in R_ij.items()}
+        G0 = initialize([t], {t: n_t}, obj_type2rank, R_first, init_type,
+                        _as_rs(random_state))[t, t]
+    # object types taking part: the target + every partner type of the new relations
+    types = [t]
+    for (i, j) in R_ij:
+        for o in (i, j):
+            if o not in types:
+                types.append(o)
+    n_obj = {t: n_t}
+    for o in types[1:]:
+        n_obj[o] = G[o, o].shape[0]
+    rel_list = flatten_relations(R_ij)
+    plan = DevicePlan(types, n_obj, obj_type2rank, rel_list, flatten_thetas(Theta_i),
+                      nat.SKF_TRANSFORM, dtype=dtype, target=t, engine=engine)
+    try:
+        plan.set_factor(t, G0)
+        for o in types[1:]:
+            plan.set_factor(o, G[o, o])
+        seen = {}
+        for k, (i, j, _, _) in enumerate(rel_list):
+            l = seen.get((i, j), 0)
+            seen[i, j] = l + 1
+            plan.set_backbone(k, S[i, j][l])
+        if callback:
+            for it in range(max_iter):
+                plan.iterate(1)
+                callback(plan.get_factor(t), it)
+        else:
+            plan.iterate(max_iter)
+        return plan.get_factor(t)
+    finally:
+        plan.close()

@@ -1,0 +1,144 @@
+"""``Dfmf`` and ``DfmfTransform`` -- the class layer of the drop-in boundary.
+
+Same constructor keywords, ``fuse`` / ``transform`` entry points and result containers as the
+reference (``skfusion/fusion/decomposition/dfmf.py``: Dfmf :18-106, DfmfTransform :118-204).
+What changes is where the arithmetic runs: each of the ``n_run`` restarts is one device plan
+in ``libskfusion_hip.so`` (the reference ships every run to a joblib worker, dfmf.py:87-95).
+Engine-specific keywords (``dtype``) are additions with behaviour-preserving defaults.
+"""
+from collections import defaultdict
+from itertools import product
+
+import numpy as np
+
+from ..base import FusionFit, FusionTransform
+from . import _dfmf
+
+__all__ = ['Dfmf', 'DfmfTransform']
+
+
+def _random_state(obj):
+    return obj if isinstance(obj, np.random.RandomState) else np.random.RandomState(obj)
+
+
+def graph_matrices(fusion_graph, with_masks=False):
+    """FusionGraph -> (R, Theta[, M]) dictionaries in the reference's walking order
+    (dfmf.py:70-85, dfmc.py:70-93): pairs from product(object_types, repeat=2), each relation
+    filled, then preprocessed; relations between two different types go to R, same-type
+    relations are constraints (Theta).  For a masked result the raw ``.data`` is used and,
+    with ``with_masks``, the mask is kept as the completion mask."""
+    R, Theta, M = {}, {}, {}
+    for row_type, col_type in product(fusion_graph.object_types, repeat=2):
+        for relation in fusion_graph.get_relations(row_type, col_type):
+            data = relation.filled()
+            if relation.preprocessor:
+                data = relation.preprocessor(data)
+            mask = None
+            if np.ma.is_masked(data):
+                mask = data.mask
+                data = data.data
+            key = (relation.row_type, relation.col_type)
+            if relation.row_type != relation.col_type:
+                R.setdefault(key, []).append(data)
+                M.setdefault(key, []).append(mask)
+            else:
+                Theta.setdefault(key, []).append(data)
+    return (R, Theta, M) if with_masks else (R, Theta)
+
+
+def store_runs(fuser, runs):
+    """(G, S) per run -> factors_[object_type][run], backbones_[relation][run]
+    (dfmf.py:97-105)."""
+    fuser.factors_ = defaultdict(list)
+    fuser.backbones_ = defaultdict(list)
+    graph = fuser.fusion_graph
+    for G, S in runs:
+        for (object_type, _), factor in G.items():
+            fuser.factors_[object_type].append(factor)
+        for (row_type, col_type), backbones in S.items():
+            for k, relation in enumerate(graph.get_relations(row_type, col_type)):
+                fuser.backbones_[relation].append(backbones[k])
+
+
+class Dfmf(FusionFit):
+    """Data fusion by matrix factorization.
+
+    Parameters (identical to the reference): max_iter=100, init_type='random_c', n_run=1,
+    stopping=None, stopping_system=None, verbose=0, compute_err=False, callback=None,
+    random_state=None, n_jobs=1.  Addition: dtype='f64' | 'f32' (device arithmetic type).
+    """
+
+    def __init__(self, max_iter=100, init_type='random_c', n_run=1, stopping=None,
+                 stopping_system=None, verbose=0, compute_err=False, callback=None,
+                 random_state=None, n_jobs=1, dtype='f64'):
+        super(Dfmf, self).__init__()
+        self._set_params(vars())
+
+    def fuse(self, fusion_graph):
+        self.fusion_graph = fusion_graph
+        self.random_state = _random_state(self.random_state)
+        object_types = list(fusion_graph.object_types)
+        rank = {ot: int(ot.rank) for ot in object_types}
+        R, Theta = graph_matrices(fusion_graph)
+        runs = [_dfmf.dfmf(R=R, Theta=Theta, obj_types=object_types, obj_type2rank=rank,
+                           max_iter=self.max_iter, init_type=self.init_type,
+                           stopping=self.stopping, stopping_system=self.stopping_system,
+                           verbose=self.verbose, compute_err=self.compute_err,
+                           callback=self.callback, random_state=self.random_state,
+                           n_jobs=self.n_jobs, dtype=self.dtype)
+                for _ in range(self.n_run)]
+        store_runs(self, runs)
+        return self
+
+
+class DfmfTransform(FusionTransform):
+    """Online transformer of new objects into a fitted fused space.
+
+    Parameters (identical to the reference): max_iter=100, init_type=None (use the fuser's),
+    n_run=1, stopping=None, stopping_system=None, fill_value=0, verbose=0, compute_err=False,
+    callback=None, random_state=None, n_jobs=1.  Addition: dtype.
+    """
+
+    def __init__(self, max_iter=100, init_type=None, n_run=1, stopping=None,
+                 stopping_system=None, fill_value=0, verbose=0, compute_err=False,
+                 callback=None, random_state=None, n_jobs=1, dtype='f64'):
+        super(DfmfTransform, self).__init__()
+        self._set_params(vars())
+
+    def transform(self, target, fusion_graph, fuser):
+        self.target = target
+        self.fusion_graph = fusion_graph
+        self.fuser = fuser
+        self._validate_graph()
+        init_type = self.init_type if self.init_type is not None else fuser.init_type
+        self.random_state = _random_state(self.random_state)
+        rank = {ot: int(ot.rank) for ot in fusion_graph.object_types}
+
+        # dfmf.py:176-189: preprocess, fill masked / non-finite entries with `fill_value`
+        R, Theta = {}, {}
+        for row_type, col_type in product(fusion_graph.object_types, repeat=2):
+            for relation in fusion_graph.get_relations(row_type, col_type):
+                data = relation.preprocessor(relation.data) if relation.preprocessor \
+                    else relation.data
+                if np.ma.is_masked(data):
+                    data.fill_value = self.fill_value
+                    data = data.filled()
+                data[~np.isfinite(data)] = self.fill_value
+                dest = R if relation.row_type != relation.col_type else Theta
+                dest.setdefault((relation.row_type, relation.col_type), []).append(data)
+
+        self.factors_ = defaultdict(list)
+        for run in range(self.n_run):
+            # frozen model of this run (dfmf.py:109-115); only the LAST relation of a type pair
+            # survives in S there -- kept: one backbone per pair
+            G = {(ot, ot): fuser.factor(ot, run) for ot in fuser.fusion_graph.object_types}
+            S = {(rel.row_type, rel.col_type): [fuser.backbone(rel, run)]
+                 for rel in fuser.fusion_graph.relations if rel.row_type != rel.col_type}
+            G_new = _dfmf.transform(R_ij=R, Theta_i=Theta, target_obj_type=target,
+                                    obj_type2rank=rank, G=G, S=S, max_iter=self.max_iter,
+                                    init_type=init_type, stopping=self.stopping,
+                                    stopping_system=self.stopping_system, verbose=self.verbose,
+                                    compute_err=self.compute_err, callback=self.callback,
+                                    random_state=self.random_state, dtype=self.dtype)
+            self.factors_[target].append(G_new)
+        return self

@@ -1,0 +1,380 @@
+// =====================================================================================
+// HOST SIMT EMULATOR  --  TEST INFRASTRUCTURE ONLY (never part of the product build)
+//
+// A stand-in for <hip/hip_runtime.h> that lets the UNMODIFIED kernel sources under
+// scikit-fusion_amd/csrc/ be compiled with host clang++ (-x c++) and executed on the CPU:
+// every GPU thread of a workgroup is a ucontext fiber; __syncthreads() and the wave-level
+// collectives (__shfl*, the MFMA builtins) are rendezvous points between fibers.  The
+// point is to check index arithmetic, tile/boundary handling, LDS staging and the barrier
+// structure of the kernels in the build container, which has no GPU.  Timing, caches,
+// async copies and memory-model effects are NOT modelled.
+//
+// The MFMA builtins are emulated with the gfx950 lane<->element maps given in
+// /opt/skills/guides/cdna_hip_programming.md (section 3):
+//   mfma_f32_32x32x2f32 : A[i=l&31][k=l>>5]  B[k=l>>5][j=l&31]
+//                         D reg r: row=(r&3)+8*(r>>2)+4*(l>>5), col=l&31
+//   mfma_f32_16x16x4f32 : A[i=l&15][k=l>>4]  B[k=l>>4][j=l&15]   D reg r: row=4*(l>>4)+r, col=l&15
+//   mfma_f64_16x16x4f64 : A[i=l&15][k=l>>4]  B[k=l>>4][j=l&15]   D reg r: row=(l>>4)+4*r, col=l&15
+//   mfma_f32_16x16x32_bf16 : A[i=l&15][k=8*(l>>4)+e]  B[k=8*(l>>4)+e][j=l&15]
+//                         D reg r: row=4*(l>>4)+r, col=l&15
+// Set SKF_EMUL_REVERSE=1 to schedule fibers in reverse order (flushes out missing barriers
+// that a forward order hides).
+// =====================================================================================
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct simt_uint3 { unsigned x, y, z; };
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2,
+                     hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+    memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h,
+                                   hipMemcpyKind, hipStream_t) {
+    for (size_t r = 0; r < h; ++r) memmove((char*)d + r * dp, (const char*)s + r * sp, w);
+    return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+#define hipEventDisableTiming 0x2
+#define hipStreamNonBlocking 0x1
+
+namespace simt {
+
+enum State { READY = 0, AT_BARRIER = 1, WAVE_WAIT = 2, DONE = 3 };
+constexpr int WAVE = 64;
+constexpr size_t STACK_BYTES = 192 * 1024;
+constexpr size_t XCHG_BYTES = 160;          // per-lane exchange slot for wave collectives
+
+struct Fiber {
+    ucontext_t ctx;
+    simt_uint3 tid;
+    int linear = 0;
+    int state = READY;
+    char* stack = nullptr;
+};
+
+struct WaveSync {
+    int arrived = 0;
+    unsigned gen = 0;
+    alignas(16) unsigned char xchg[WAVE][XCHG_BYTES];
+};
+
+inline Fiber* g_cur = nullptr;
+inline simt_uint3 g_blockIdx{0, 0, 0};
+inline dim3 g_blockDim, g_gridDim;
+inline ucontext_t g_sched;
+inline std::vector<Fiber> g_fibers;
+inline std::vector<WaveSync> g_waves;
+inline std::function<void()>* g_body = nullptr;
+inline int g_nthreads = 0;
+inline int g_progress = 0;
+
+inline void die(const char* msg) {
+    fprintf(stderr, "[simt-emul] fatal: %s (block %u,%u,%u)\n", msg, g_blockIdx.x, g_blockIdx.y, g_blockIdx.z);
+    abort();
+}
+
+inline void yield_to_scheduler() { swapcontext(&g_cur->ctx, &g_sched); }
+
+inline void block_barrier() {
+    g_cur->state = AT_BARRIER;
+    yield_to_scheduler();
+}
+
+inline int wave_lanes(int wave) {           // lanes that exist in this wave
+    int lo = wave * WAVE, hi = lo + WAVE;
+    if (hi > g_nthreads) hi = g_nthreads;
+    return hi - lo;
+}
+
+// rendezvous of all lanes of the calling lane's wave
+inline void wave_sync() {
+    Fiber* me = g_cur;
+    int w = me->linear / WAVE;
+    WaveSync& ws = g_waves[w];
+    unsigned gen = ws.gen;
+    if (++ws.arrived == wave_lanes(w)) {
+        ws.arrived = 0;
+        ws.gen++;
+        for (int l = 0; l < wave_lanes(w); ++l) {
+            Fiber& f = g_fibers[w * WAVE + l];
+            if (f.state == WAVE_WAIT) f.state = READY;
+        }
+        return;
+    }
+    while (ws.gen == gen) {
+        me->state = WAVE_WAIT;
+        yield_to_scheduler();
+    }
+}
+
+inline void trampoline() {
+    (*g_body)();
+    g_cur->state = DONE;
+    yield_to_scheduler();
+    die("resumed a finished fiber");
+}
+
+inline void run_block(std::function<void()>& body) {
+    static const bool reverse = getenv("SKF_EMUL_REVERSE") && atoi(getenv("SKF_EMUL_REVERSE")) != 0;
+    const int n = g_nthreads;
+    if ((int)g_fibers.size() < n) {
+        size_t old = g_fibers.size();
+        g_fibers.resize(n);
+        for (size_t i = old; i < (size_t)n; ++i) g_fibers[i].stack = (char*)malloc(STACK_BYTES);
+    }
+    int nw = (n + WAVE - 1) / WAVE;
+    if ((int)g_waves.size() < nw) g_waves.resize(nw);
+    for (int w = 0; w < nw; ++w) { g_waves[w].arrived = 0; g_waves[w].gen = 0; }
+    g_body = &body;
+    for (int t = 0; t < n; ++t) {
+        Fiber& f = g_fibers[t];
+        f.linear = t;
+        f.tid.x = t % g_blockDim.x;
+        f.tid.y = (t / g_blockDim.x) % g_blockDim.y;
+        f.tid.z = t / (g_blockDim.x * g_blockDim.y);
+        f.state = READY;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = STACK_BYTES;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    for (;;) {
+        bool progressed = false;
+        for (int k = 0; k < n; ++k) {
+            Fiber& f = g_fibers[reverse ? n - 1 - k : k];
+            if (f.state == READY) {
+                g_cur = &f;
+                swapcontext(&g_sched, &f.ctx);
+                progressed = true;
+            }
+        }
+        int n_bar = 0, n_done = 0;
+        for (int t = 0; t < n; ++t) {
+            n_bar += g_fibers[t].state == AT_BARRIER;
+            n_done += g_fibers[t].state == DONE;
+        }
+        if (n_done == n) break;
+        if (n_bar > 0 && n_bar + n_done == n) {
+            for (int t = 0; t < n; ++t)
+                if (g_fibers[t].state == AT_BARRIER) g_fibers[t].state = READY;
+            progressed = true;
+        }
+        if (!progressed) die("deadlock: divergent barrier / wave collective");
+    }
+    g_cur = nullptr;
+}
+
+template <class F>
+inline void launch(dim3 grid, dim3 block, F&& f) {
+    std::function<void()> body = f;
+    g_gridDim = grid;
+    g_blockDim = block;
+    g_nthreads = (int)(block.x * block.y * block.z);
+    if (g_nthreads <= 0 || g_nthreads > 1024) die("bad block size");
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                g_blockIdx = simt_uint3{bx, by, bz};
+                run_block(body);
+            }
+}
+
+inline int lane_id() { return g_cur->linear % WAVE; }
+inline WaveSync& my_wave() { return g_waves[g_cur->linear / WAVE]; }
+
+template <class T>
+inline T wave_read(T mine, int src_lane) {
+    static_assert(sizeof(T) <= XCHG_BYTES, "exchange slot too small");
+    WaveSync& ws = my_wave();
+    memcpy(ws.xchg[lane_id()], &mine, sizeof(T));
+    wave_sync();
+    T r;
+    memcpy(&r, ws.xchg[src_lane & (WAVE - 1)], sizeof(T));
+    wave_sync();
+    return r;
+}
+
+}  // namespace simt
+
+#define threadIdx (simt::g_cur->tid)
+#define blockIdx (simt::g_blockIdx)
+#define blockDim (simt::g_blockDim)
+#define gridDim (simt::g_gridDim)
+#define warpSize 64
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    simt::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+
+inline void __syncthreads() { simt::block_barrier(); }
+
+template <class T> inline T __shfl(T v, int src, int width = 64) {
+    int l = simt::lane_id();
+    int base = l & ~(width - 1);
+    return simt::wave_read(v, base + (src & (width - 1)));
+}
+template <class T> inline T __shfl_xor(T v, int mask, int width = 64) {
+    int l = simt::lane_id();
+    int t = l ^ mask;
+    if ((t & ~(width - 1)) != (l & ~(width - 1))) t = l;
+    return simt::wave_read(v, t);
+}
+template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int l = simt::lane_id();
+    int t = l + (int)d;
+    if ((t & ~(width - 1)) != (l & ~(width - 1))) t = l;
+    return simt::wave_read(v, t);
+}
+template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) {
+    int l = simt::lane_id();
+    int t = l - (int)d;
+    if (t < 0 || (t & ~(width - 1)) != (l & ~(width - 1))) t = l;
+    return simt::wave_read(v, t);
+}
+inline unsigned long long __ballot(int pred) {
+    unsigned long long m = 0;
+    for (int s = 0; s < 64; ++s) {
+        int p = simt::wave_read(pred, s);
+        if (p) m |= 1ull << s;
+    }
+    return m;
+}
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+// ---- vector types used by the MFMA builtins (clang ext vectors work on the host too)
+typedef float simt_f32x4 __attribute__((ext_vector_type(4)));
+typedef float simt_f32x16 __attribute__((ext_vector_type(16)));
+typedef double simt_f64x4 __attribute__((ext_vector_type(4)));
+typedef short simt_s16x8 __attribute__((ext_vector_type(8)));
+
+inline float simt_bf16_to_f32(unsigned short h) {
+    unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+inline simt_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, simt_f32x16 c, int, int, int) {
+    struct AB { float a, b; } mine{a, b};
+    simt::WaveSync& ws = simt::my_wave();
+    int l = simt::lane_id();
+    memcpy(ws.xchg[l], &mine, sizeof mine);
+    simt::wave_sync();
+    simt_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            AB pa, pb;
+            memcpy(&pa, ws.xchg[row + 32 * k], sizeof pa);
+            memcpy(&pb, ws.xchg[col + 32 * k], sizeof pb);
+            acc = fmaf(pa.a, pb.b, acc);
+        }
+        d[r] = acc;
+    }
+    simt::wave_sync();
+    return d;
+}
+
+inline simt_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, simt_f32x4 c, int, int, int) {
+    struct AB { float a, b; } mine{a, b};
+    simt::WaveSync& ws = simt::my_wave();
+    int l = simt::lane_id();
+    memcpy(ws.xchg[l], &mine, sizeof mine);
+    simt::wave_sync();
+    simt_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            AB pa, pb;
+            memcpy(&pa, ws.xchg[row + 16 * k], sizeof pa);
+            memcpy(&pb, ws.xchg[col + 16 * k], sizeof pb);
+            acc = fmaf(pa.a, pb.b, acc);
+        }
+        d[r] = acc;
+    }
+    simt::wave_sync();
+    return d;
+}
+
+inline simt_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, simt_f64x4 c, int, int, int) {
+    struct AB { double a, b; } mine{a, b};
+    simt::WaveSync& ws = simt::my_wave();
+    int l = simt::lane_id();
+    memcpy(ws.xchg[l], &mine, sizeof mine);
+    simt::wave_sync();
+    simt_f64x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) + 4 * r, col = l & 15;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            AB pa, pb;
+            memcpy(&pa, ws.xchg[row + 16 * k], sizeof pa);
+            memcpy(&pb, ws.xchg[col + 16 * k], sizeof pb);
+            acc = fma(pa.a, pb.b, acc);
+        }
+        d[r] = acc;
+    }
+    simt::wave_sync();
+    return d;
+}
+
+// bf16 operands are passed as 8 raw 16-bit patterns per lane
+inline simt_f32x4 simt_mfma_f32_16x16x32_bf16(simt_s16x8 a, simt_s16x8 b, simt_f32x4 c) {
+    struct AB { simt_s16x8 a, b; } mine{a, b};
+    simt::WaveSync& ws = simt::my_wave();
+    int l = simt::lane_id();
+    memcpy(ws.xchg[l], &mine, sizeof mine);
+    simt::wave_sync();
+    simt_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            AB pa, pb;
+            memcpy(&pa, ws.xchg[row + 16 * (k >> 3)], sizeof pa);
+            memcpy(&pb, ws.xchg[col + 16 * (k >> 3)], sizeof pb);
+            acc += simt_bf16_to_f32((unsigned short)pa.a[k & 7]) * simt_bf16_to_f32((unsigned short)pb.b[k & 7]);
+        }
+        d[r] = acc;
+    }
+    simt::wave_sync();
+    return d;
+}

@@ -1,0 +1,167 @@
+"""The whole device engine (plan + launch schedule + kernels) on the CPU via the host SIMT
+emulator, compared with the golden vectors of the reference and with the oracle.  The same
+comparisons run on the hardware in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import skfusion_amd._native as nat
+from skfusion_amd.fusion.decomposition import _dfmf, _dfmc
+from emul.runtime import emulated_runtime
+from oracle import dfmf_oracle as orc
+from helpers import (golden, readme_graph, probe_graph, rank_deficient_graph, dicty_graph, g0_from,
+                     Snapshots, compare_snapshots, relerr, TYPES)
+
+
+@pytest.fixture(scope='module', autouse=True)
+def emul():
+    with nat.use_runtime(emulated_runtime()) as rt:
+        yield rt
+
+
+@pytest.mark.parametrize('engine', [nat.SKF_ENGINE_MFMA, nat.SKF_ENGINE_VALU])
+def test_c1_readme_f64_matches_reference_golden(engine):
+    z = golden('c1_readme_dfmf.npz')
+    R, types, rank = readme_graph()
+    snaps = Snapshots((0, 1, 9))
+    G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=10, callback=snaps,
+                      G0=g0_from(z, 'random_vcol/', types), dtype='f64', engine=engine)
+    worst = compare_snapshots(z, 'random_vcol/', snaps.snap, 1e-10)
+    assert worst < 1e-10
+
+
+def test_c1_readme_device_resident_loop_f64_and_f32():
+    z = golden('c1_readme_dfmf.npz')
+    R, types, rank = readme_graph()
+    G0 = g0_from(z, 'random/', types)
+    G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=10, G0=G0, dtype='f64')   # one skf_iterate(10)
+    for t in types:
+        assert relerr(G[t, t], z['random/G_%s_it9' % t]) < 1e-9
+    for (i, j) in R:
+        assert relerr(S[i, j][0], z['random/S_%s_%s_0_it9' % (i, j)]) < 1e-9
+    # fp32 engine (SURVEY 8d tolerances: 1e-4 on G, 1e-5 on the reconstruction error); the
+    # 30- and 100-iteration versions of this check run on the GPU (tests/test_gpu_parity.py)
+    G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=12, G0=G0, dtype='f32')
+    Go, So = orc.dfmf(R, {}, types, rank, max_iter=12, G0=G0)
+    for t in types:
+        assert relerr(G[t, t], Go[t, t]) < 1e-4
+    for k in So:
+        assert relerr(S[k][0], So[k][0]) < 1e-3
+    e, eo = orc.relation_errors(R, G, S), orc.relation_errors(R, Go, So)
+    for k in e:
+        assert abs(e[k][0] - eo[k][0]) / eo[k][0] < 1e-5
+
+
+def test_seeded_initialisers_match_reference_stream():
+    """Without G0 the host initialisers must consume the RandomState like the reference."""
+    z = golden('c1_readme_dfmf.npz')
+    R, types, rank = readme_graph()
+    for init in ('random', 'random_c', 'random_vcol'):
+        snaps = Snapshots((0,))
+        _dfmf.dfmf(R, {}, types, rank, max_iter=1, init_type=init, callback=snaps,
+                   random_state=np.random.RandomState(0), dtype='f64')
+        compare_snapshots(z, init + '/', snaps.snap, 1e-9)
+    with pytest.raises(KeyError):
+        _dfmf.dfmf(R, {}, types, rank, max_iter=1, init_type='nope',
+                   random_state=np.random.RandomState(0))
+
+
+def test_probe_graph_dfmf_theta_multirelation_negative_values():
+    z = golden('probe_multirel.npz')
+    R, Theta, M, types, rank = probe_graph(z)
+    snaps = Snapshots((0, 1, 9, 29))
+    _dfmf.dfmf(R, Theta, types, rank, max_iter=30, callback=snaps, G0=g0_from(z, 'dfmf/', types))
+    compare_snapshots(z, 'dfmf/', snaps.snap, 1e-9)
+
+
+def test_probe_graph_dfmc_masks_and_inputs_untouched():
+    z = golden('probe_multirel.npz')
+    R, Theta, M, types, rank = probe_graph(z)
+    keep = {k: [m.copy() for m in v] for k, v in R.items()}
+    snaps = Snapshots((0, 1, 9, 29))
+    _dfmc.dfmc(R, M, Theta, types, rank, max_iter=30, callback=snaps, G0=g0_from(z, 'dfmc/', types))
+    compare_snapshots(z, 'dfmc/', snaps.snap, 1e-9)
+    for k in R:
+        for a, b in zip(R[k], keep[k]):
+            np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('variant', ['dfmf', 'dfmc'])
+def test_rank_deficient_gram(variant):
+    z = golden('rank_deficient.npz')
+    R, types, rank = rank_deficient_graph(z)
+    G0 = g0_from(z, variant + '/', types)
+    snaps = Snapshots((0, 1))
+    if variant == 'dfmf':
+        G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=4, callback=snaps, G0=G0)
+        Go, So = orc.dfmf(R, {}, types, rank, max_iter=4, G0=G0)
+    else:
+        M = {k: [None] for k in R}
+        G, S = _dfmc.dfmc(R, M, {}, types, rank, max_iter=4, callback=snaps, G0=G0)
+        Go, So = orc.dfmc(R, M, {}, types, rank, max_iter=4, G0=G0)
+    compare_snapshots(z, variant + '/', snaps.snap, 1e-7)
+    assert all(np.isfinite(v).all() for v in G.values())
+    e, eo = orc.relation_errors(R, G, S), orc.relation_errors(R, Go, So)
+    for k in e:
+        assert abs(e[k][0] - eo[k][0]) <= 1e-6 * max(1.0, eo[k][0])
+
+
+@pytest.mark.parametrize('init', ['random_c', 'random'])
+def test_transform_fold_in(init):
+    z = golden('transform_readme.npz')
+    G = {(t, t): z['G_%s' % t] for t in TYPES}
+    S = {('t1', 't2'): [z['S_t1_t2']], ('t1', 't3'): [z['S_t1_t3']], ('t2', 't1'): [z['S_t2_t1']]}
+    Rn = {('t1', 't2'): [z['new_t1_t2']], ('t1', 't3'): [z['new_t1_t3']], ('t2', 't1'): [z['new_t2_t1']]}
+    rank = {'t1': 10, 't2': 20, 't3': 30}
+    snaps = {}
+    Gi = _dfmf.transform(Rn, {('t1', 't1'): [z['theta_t1']]}, 't1', rank, G, S, max_iter=100,
+                         init_type=init, random_state=np.random.RandomState(4),
+                         callback=lambda g, it: snaps.__setitem__(it, g.copy()))
+    for it in (0, 9, 99):
+        assert relerr(snaps[it], z['%s/G_it%d' % (init, it)]) < 1e-9
+    assert relerr(Gi, z['%s/G_it99' % init]) < 1e-9
+    Gi32 = _dfmf.transform(Rn, {('t1', 't1'): [z['theta_t1']]}, 't1', rank, G, S, max_iter=100,
+                           G0=z[init + '/G0'], dtype='f32')
+    assert relerr(Gi32, z['%s/G_it99' % init]) < 1e-4
+
+
+def test_c2_dicty_first_iteration_f64():
+    """BASELINE config 2 inputs; the full 100-iteration run is a GPU test (emulation is slow)."""
+    z = golden('c2_dicty.npz')
+    R, Theta, types, rank = dicty_graph()
+    G0 = g0_from(z, 'dfmf/', types)
+    snaps = Snapshots((0,))
+    G, S = _dfmf.dfmf(R, Theta, types, rank, max_iter=1, callback=snaps, G0=G0)
+    compare_snapshots(z, 'dfmf/', snaps.snap, 1e-9)
+    Go, So = orc.dfmf(R, Theta, types, rank, max_iter=1, G0=G0)
+    for t in types:
+        assert relerr(G[t, t], Go[t, t]) < 1e-9
+
+
+def test_relation_sqerr_and_stopping_path():
+    R, types, rank = readme_graph()
+    z = golden('c1_readme_dfmf.npz')
+    G0 = g0_from(z, 'random/', types)
+    seen = []
+    G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=5, G0=G0, compute_err=True,
+                      stopping=(('t1', 't2'), 1e-9), callback=lambda g, s, it: seen.append(it))
+    assert seen == list(range(5))
+    from skfusion_amd._engine import DevicePlan, flatten_relations
+    rel = flatten_relations(R)
+    plan = DevicePlan(types, {'t1': 50, 't2': 100, 't3': 40}, rank, rel, [], nat.SKF_DFMF)
+    for t in types:
+        plan.set_factor(t, G0[t, t])
+    plan.iterate(3)
+    Gd = {(t, t): plan.get_factor(t) for t in types}
+    for k, (i, j, Rm, _) in enumerate(rel):
+        Sd = plan.get_backbone(k)
+        want = np.linalg.norm(Rm - Gd[i, i] @ Sd @ Gd[j, j].T) ** 2
+        assert abs(plan.relation_sqerr(k) - want) < 1e-9 * want
+    plan.close()
+
+
+def test_shape_mismatch_is_a_hard_error():
+    from skfusion_amd.fusion import DataFusionError
+    R = {('a', 'b'): [np.ones((4, 5))], ('a', 'c'): [np.ones((3, 2))]}
+    with pytest.raises(DataFusionError):
+        _dfmf.dfmf(R, {}, ['a', 'b', 'c'], {'a': 2, 'b': 2, 'c': 2}, max_iter=1,
+                   random_state=np.random.RandomState(0))

@@ -1,0 +1,186 @@
+"""Kernel logic on the CPU: the real kernel sources run under the host SIMT emulator
+(tests/emul) and are compared with NumPy.  These tests validate indexing / tiling / epilogues
+/ the launch schedule; the `-m gpu` tests repeat them on the hardware."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import skfusion_amd._native as nat
+from emul.runtime import emulated_runtime
+from helpers import relerr
+
+
+@pytest.fixture(scope='module')
+def rt():
+    return emulated_runtime()
+
+
+def run_gemm(rt, dtype, engine, A, B, transA=False, transB=False, aop=0, epi=0, C0=None, C20=None,
+             mask=None, nan=0, splits=0):
+    """C = epi(aop(op(A)) @ op(B)) through skf_gemm; A/B given as stored (row-major)."""
+    npd = nat.NP_DTYPE[dtype]
+    A = np.ascontiguousarray(A, dtype=npd)
+    B = np.ascontiguousarray(B, dtype=npd)
+    M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+    N = B.shape[0] if transB else B.shape[1]
+    mem = rt.mem
+    a, b = mem.from_host(A), mem.from_host(B)
+    Cm = np.zeros((M, N), npd) if C0 is None else np.array(C0, dtype=npd)
+    C2m = np.zeros((M, N), npd) if C20 is None else np.array(C20, dtype=npd)
+    c, c2 = mem.from_host(Cm), mem.from_host(C2m)
+    d = nat.GemmDesc()
+    d.A, d.B, d.C, d.C2 = a.ptr, b.ptr, c.ptr, c2.ptr
+    d.sa_m, d.sa_k = (1, A.shape[1]) if transA else (A.shape[1], 1)
+    d.sb_k, d.sb_n = (1, B.shape[1]) if transB else (B.shape[1], 1)
+    d.ldc = d.ldc2 = N
+    d.M, d.N, d.K = M, N, K
+    d.aop, d.epi, d.nan_to_num, d.splits = aop, epi, nan, splits
+    keep = None
+    if mask is not None:
+        keep = mem.from_host(np.ascontiguousarray(mask, dtype=np.uint8))
+        d.mask, d.ldmask = keep.ptr, N
+    ws = mem.empty(64 * M * N * 8 + 256)
+    rt.call('skf_gemm', dtype, engine, C.byref(d), ws.ptr, ws.nbytes, None)
+    return mem.to_host(c, (M, N), npd), mem.to_host(c2, (M, N), npd)
+
+
+SHAPES = [(1, 1, 1), (5, 3, 7), (50, 10, 100), (64, 64, 32), (70, 130, 33), (129, 200, 65),
+          (200, 129, 17), (33, 260, 40)]
+
+
+@pytest.mark.parametrize('dtype', [nat.SKF_F64, nat.SKF_F32])
+@pytest.mark.parametrize('engine', [nat.SKF_ENGINE_MFMA, nat.SKF_ENGINE_VALU])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_gemm_plain_all_layouts(rt, dtype, engine, shape):
+    M, N, K = shape
+    rs = np.random.RandomState(M * 1000 + N * 10 + K)
+    tol = 1e-13 if dtype == nat.SKF_F64 else 2e-6
+    for transA in (False, True):
+        for transB in (False, True):
+            A = rs.randn(*((K, M) if transA else (M, K)))
+            B = rs.randn(*((N, K) if transB else (K, N)))       # asymmetric operands
+            got, _ = run_gemm(rt, dtype, engine, A, B, transA, transB)
+            want = (A.T if transA else A) @ (B.T if transB else B)
+            assert relerr(got, want) < tol, (transA, transB)
+
+
+@pytest.mark.parametrize('dtype', [nat.SKF_F64, nat.SKF_F32])
+@pytest.mark.parametrize('engine', [nat.SKF_ENGINE_MFMA, nat.SKF_ENGINE_VALU])
+def test_gemm_epilogues_and_operand_ops(rt, dtype, engine):
+    rs = np.random.RandomState(5)
+    M, N, K = 70, 45, 90
+    tol = 1e-13 if dtype == nat.SKF_F64 else 2e-6
+    A, B = rs.randn(M, K), rs.randn(K, N)
+    C0, C20 = rs.rand(M, N), rs.rand(M, N)
+    P = A @ B
+    got, _ = run_gemm(rt, dtype, engine, A, B, epi=1, C0=C0)
+    assert relerr(got, C0 + P) < tol
+    g1, g2 = run_gemm(rt, dtype, engine, A, B, epi=2, C0=C0, C20=C20)
+    assert relerr(g1, np.maximum(P, 0)) < tol and relerr(g2, np.maximum(-P, 0)) < tol
+    g1, g2 = run_gemm(rt, dtype, engine, A, B, epi=3, C0=C0, C20=C20)
+    assert relerr(g1, C0 + np.maximum(P, 0)) < tol and relerr(g2, C20 + np.maximum(-P, 0)) < tol
+    mask = rs.rand(M, N) > 0.6
+    got, _ = run_gemm(rt, dtype, engine, A, B, epi=4, C0=C0, mask=mask)
+    assert relerr(got, np.where(mask, P, C0)) < tol
+    got, _ = run_gemm(rt, dtype, engine, A, B, aop=1)
+    assert relerr(got, np.maximum(A, 0) @ B) < tol
+    got, _ = run_gemm(rt, dtype, engine, A, B, aop=2)
+    assert relerr(got, np.maximum(-A, 0) @ B) < tol
+
+
+@pytest.mark.parametrize('dtype', [nat.SKF_F64, nat.SKF_F32])
+def test_gemm_split_k_and_nan_to_num(rt, dtype):
+    rs = np.random.RandomState(6)
+    tol = 1e-13 if dtype == nat.SKF_F64 else 3e-6
+    A, B = rs.randn(700, 20), rs.randn(700, 30)          # Gram-like: K = 700, tiny output
+    want = A.T @ B
+    for splits in (0, 1, 3, 7):
+        got, _ = run_gemm(rt, dtype, nat.SKF_ENGINE_MFMA, A, B, transA=True, splits=splits)
+        assert relerr(got, want) < tol, splits
+    g1, g2 = run_gemm(rt, dtype, nat.SKF_ENGINE_MFMA, A, B, transA=True, splits=4, epi=3,
+                      C0=np.ones((20, 30)), C20=np.ones((20, 30)))
+    assert relerr(g1, 1 + np.maximum(want, 0)) < tol and relerr(g2, 1 + np.maximum(-want, 0)) < tol
+    A2 = A.copy()
+    A2[3, 2] = np.nan
+    A2[5, 4] = np.inf
+    got, _ = run_gemm(rt, dtype, nat.SKF_ENGINE_MFMA, A2, B, transA=True, nan=1, splits=2)
+    with np.errstate(invalid='ignore'):
+        ref = np.nan_to_num((A2.T @ B).astype(nat.NP_DTYPE[dtype]))
+    assert np.isfinite(got).all()
+    np.testing.assert_array_equal(got[2] == 0, ref[2] == 0)
+    assert relerr(np.delete(got, [2, 4], axis=0), np.delete(ref, [2, 4], axis=0)) < tol
+
+
+def run_pinv(rt, dtype, A):
+    npd = nat.NP_DTYPE[dtype]
+    n = A.shape[0]
+    need = C.c_size_t()
+    rt.call('skf_pinv_sym_workspace_bytes', n, C.byref(need))
+    a = rt.mem.from_host(np.ascontiguousarray(A, dtype=npd))
+    k = rt.mem.empty(n * n * np.dtype(npd).itemsize)
+    ws = rt.mem.empty(need.value)
+    rt.call('skf_pinv_sym', dtype, a.ptr, n, k.ptr, n, n, ws.ptr, need.value, None)
+    return rt.mem.to_host(k, (n, n), npd)
+
+
+@pytest.mark.parametrize('n', [1, 2, 5, 10, 31, 50])
+def test_pinv_full_rank_matches_scipy(rt, n):
+    import scipy.linalg as spla
+    rs = np.random.RandomState(n)
+    G = rs.rand(4 * n + 3, n)
+    A = G.T @ G
+    got = run_pinv(rt, nat.SKF_F64, A)
+    want = spla.pinv(A)
+    assert relerr(got, want) < 1e-9 * max(1.0, np.linalg.cond(A) * 1e-3)
+    assert relerr(A @ got @ A, A) < 1e-11
+
+
+def test_pinv_rank_deficient_truncates_like_scipy(rt):
+    """reference tests/test_n_run.py:14: rank 50 factor of 30 objects -> Gram has rank 30."""
+    import scipy.linalg as spla
+    rs = np.random.RandomState(1)
+    G = rs.rand(30, 50)
+    A = G.T @ G
+    got = run_pinv(rt, nat.SKF_F64, A)
+    want = spla.pinv(A)
+    assert np.abs(got).max() < 10 * np.abs(want).max()
+    assert relerr(got, want) < 1e-7
+    got32 = run_pinv(rt, nat.SKF_F32, A)
+    assert np.isfinite(got32).all()
+
+
+def test_pinv_zero_and_diagonal(rt):
+    got = run_pinv(rt, nat.SKF_F64, np.zeros((6, 6)))
+    assert (got == 0).all()
+    d = np.diag([4.0, 2.0, 0.0, 1e-30, 5.0])
+    got = run_pinv(rt, nat.SKF_F64, d)
+    np.testing.assert_allclose(got, np.diag([0.25, 0.5, 0.0, 0.0, 0.2]), atol=1e-15)
+
+
+def test_fill_uniform_matches_oracle_hash(rt):
+    from oracle.dfmf_oracle import hash_uniform_matrix
+    for dtype, npd in ((nat.SKF_F64, np.float64), (nat.SKF_F32, np.float32)):
+        buf = rt.mem.empty(37 * 53 * 8)
+        rt.call('skf_fill_uniform', dtype, buf.ptr, 37, 53, 53, 9, 1.0, 0.0, None)
+        got = rt.mem.to_host(buf, (37, 53), npd)
+        np.testing.assert_array_equal(got, hash_uniform_matrix(9, 37, 53).astype(npd))
+    buf = rt.mem.empty(8 * 16 * 2)
+    rt.call('skf_fill_uniform', nat.SKF_BF16, buf.ptr, 8, 16, 16, 3, 2.0, -1.0, None)
+    got = rt.mem.to_host(buf, (8, 16), np.uint16)
+    want = (hash_uniform_matrix(3, 8, 16) * 2.0 - 1.0).astype(np.float32)
+    back = (got.astype(np.uint32) << 16).view(np.float32)
+    assert np.abs(back - want).max() <= np.abs(want).max() * 2 ** -8
+
+
+def test_errors_are_reported_not_thrown(rt):
+    lib = rt.lib
+    assert lib.skf_gemm(nat.SKF_F32, 0, None, None, 0, None) == -1
+    assert b'null' in lib.skf_last_error()
+    with pytest.raises(nat.SkfNativeError):
+        rt.call('skf_pinv_sym', nat.SKF_F64, None, 1, None, 1, 4, None, 0, None)
+    out = nat._P()
+    t = (nat.TypeDesc * 1)()
+    t[0].n_obj, t[0].rank = 5, 0
+    opt = nat.Options(nat.SKF_F64, nat.SKF_DFMF, -1, 0)
+    assert lib.skf_plan_create(1, t, 0, None, 0, None, C.byref(opt), C.byref(out)) == -1
