@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py -- DFMF update iterations/sec + reconstruction RMSE on the synthetic 3-type graph of
+BASELINE.json (configs[2]: 50k x 100k / 50k x 40k / 100k x 40k, ranks 128/256/256).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full DFMF iteration (Gram + pinv, S closed form, the two relation contractions
+per relation, the multiplicative G update) over the whole graph, data resident in HBM
+(generated on the device by the counter-based generator shared with the oracle).  With N > 1
+every rank runs an independent random restart of the same graph (BASELINE config 4, the
+joblib n_run loop of reference dfmf.py:87-95): no data-path collective, weak scaling,
+value = N * K / max-over-ranks time.
+
+The JSON line also carries
+  roofline     : the dominant kernel = the relation contractions P = R G_j, Q = R^T G_i;
+                 achieved = their algorithmic flops (2*n_i*n_j*c per launch) / their summed
+                 hipEvent duration inside the timed region; bound = matrix cores of the dtype.
+  cpu_baseline : the NumPy oracle (reference operation order, fp64, all host cores) timed on a
+                 bounded 1/10-linear-scale sample of the same graph and scaled to full size.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FULL = {'t1': 50000, 't2': 100000, 't3': 40000}
+RANKS = {'t1': 128, 't2': 256, 't3': 256}
+TYPES = ['t1', 't2', 't3']
+PAIRS = [('t1', 't2', 0), ('t1', 't3', 1), ('t2', 't3', 2)]     # (row, col, data seed)
+PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6, 'bf16': 2500.0}        # MI355X dense matrix peaks
+MASTER = {'f32': 'f32', 'f64': 'f64', 'bf16': 'f32'}
+
+
+def sizes(scale):
+    return {t: max(int(round(n * scale)), 64) for t, n in FULL.items()}
+
+
+def alg_flops(n):
+    """sum over relations of 2 * n_i * n_j * (c_i + c_j)."""
+    return sum(2.0 * n[i] * n[j] * (RANKS[i] + RANKS[j]) for i, j, _ in PAIRS)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Oracle (kind=port) on the host cores at 1/10 linear scale, scaled to the full graph."""
+    from oracle import dfmf_oracle as orc
+    n = sizes(0.1)
+    R = {(i, j): [orc.hash_uniform_matrix(s, n[i], n[j])] for i, j, s in PAIRS}
+    G = {(t, t): orc.hash_uniform_matrix(100 + k, n[t], RANKS[t]) for k, t in enumerate(TYPES)}
+
+    def step(G):
+        S, _ = orc._update_S(R, G)
+        return orc._update_G(R, G, S, {}, {}, True)
+    G = step(G)                                   # warm-up (BLAS threads, page faults)
+    t0 = time.perf_counter()
+    done = 0
+    while done < 2 or (time.perf_counter() - t0 < seconds_budget and done < 20):
+        G = step(G)
+        done += 1
+    dt = time.perf_counter() - t0
+    sample_ips = done / dt
+    ratio = alg_flops(n) / alg_flops(FULL)       # the n_i*n_j work shrinks by 100
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {'value': sample_ips * ratio, 'unit': 'iters/s', 'cores': int(threads), 'kind': 'port',
+            'sample': '%d oracle iterations (NumPy fp64, reference op order) at 1/10 linear scale '
+                      '(%dx%d / %dx%d / %dx%d, ranks 128/256/256) = %.3f it/s measured, scaled by the '
+                      'n_i*n_j work ratio %.4f to the full graph; os.cpu_count()=%d'
+                      % (done, n['t1'], n['t2'], n['t1'], n['t3'], n['t2'], n['t3'], sample_ips, ratio,
+                         os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f64', 'bf16'])
+    ap.add_argument('--scale', type=float, default=1.0, help='linear scale of the object counts')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if dist is not None:
+        dist.barrier()
+    import skfusion_amd._native as nat
+    from skfusion_amd._engine import DevicePlan, fill_uniform
+
+    n = sizes(args.scale)
+    rels = [(i, j, fill_uniform((n[i], n[j]), s, args.dtype), None) for i, j, s in PAIRS]
+    plan = DevicePlan(TYPES, n, RANKS, rels, [], nat.SKF_DFMF, dtype=args.dtype)
+    for k, t in enumerate(TYPES):      # one random restart per rank: G0 seed depends on the rank
+        plan.set_factor(t, fill_uniform((n[t], RANKS[t]), 100 + 10 * rank + k, MASTER[args.dtype]))
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    plan.iterate(args.warmup)
+    sync()
+    plan.set_profiling(True)
+    t0 = time.perf_counter()
+    plan.iterate(args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_launches, k_flops = plan.get_profile()
+    plan.set_profiling(False)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    rmse = {}
+    for k, (i, j, _) in enumerate(PAIRS):
+        rmse['%s-%s' % (i, j)] = float(np.sqrt(plan.relation_sqerr(k) / (n[i] * n[j])))
+
+    if rank == 0:
+        achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
+        peak = PEAK_TFLOPS[args.dtype]
+        out = {
+            'metric': 'DFMF update iters/sec (+ reconstruction RMSE), 3-relation graph @ ranks 128/256/256',
+            'value': world * args.steps / elapsed,
+            'unit': 'iters/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': args.dtype,
+            'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[2]: synthetic dense 3-type graph %dx%d / %dx%d / %dx%d, '
+                                   'ranks 128/256/256, Dfmf, one random restart per GPU'
+                                   % (n['t1'], n['t2'], n['t1'], n['t3'], n['t2'], n['t3']),
+                       'scale': args.scale, 'restarts': world,
+                       'alg_flops_per_iter': alg_flops(n)},
+            'rmse': rmse,
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': None,
+                         'kernel': 'relation contractions P=R*G_j, Q=R^T*G_i (gemm_mfma_kernel<..,TAG=1>)',
+                         'launches': int(k_launches),
+                         'avg_launch_ms': k_ms / k_launches if k_launches else None,
+                         'alg_flops_per_launch': k_flops / k_launches if k_launches else None,
+                         'whole_iteration_frac': alg_flops(n) * args.steps / elapsed / 1e12 / peak},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    plan.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -115,6 +115,13 @@ int skf_iterate(skf_plan* plan, int32_t n_iters, void* stream);
  * n_i x n_j product).  For DFMC the working copy (completed entries) is used. */
 int skf_relation_sqerr(skf_plan* plan, int32_t rel, double* out, void* stream);
 
+/* Optional hipEvent timing of the two contractions that stream a relation matrix
+ * (P = R G_j, Q = R^T G_i -- the dominant kernel).  get_profile synchronises on the recorded
+ * events, returns the summed duration [ms], the number of launches and their algorithmic flops
+ * (2*M*N*K each) since the last call, and resets the counters. */
+int skf_plan_set_profiling(skf_plan* plan, int32_t enable);
+int skf_plan_get_profile(skf_plan* plan, double* total_ms, int64_t* launches, double* flops);
+
 /* ---- stand-alone operators (building blocks, exported for tests / callers) -------------- */
 
 typedef struct {

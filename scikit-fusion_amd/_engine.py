@@ -11,6 +11,25 @@ import numpy as np
 from . import _native as nat
 
 
+class DeviceMatrix(object):
+    """A row-major matrix that already lives in HBM (engine dtype), e.g. synthetic benchmark
+    data generated on the device with ``fill_uniform``."""
+
+    def __init__(self, buf, shape, ld=None):
+        self.buf, self.shape, self.ld = buf, tuple(shape), ld if ld is not None else shape[1]
+
+
+def fill_uniform(shape, seed, dtype='f32', scale=1.0, shift=0.0, runtime=None):
+    """Device matrix of counter-based uniforms (bit-identical to oracle hash_uniform_matrix)."""
+    rt = runtime or nat.get_runtime()
+    code = {'f64': nat.SKF_F64, 'f32': nat.SKF_F32, 'bf16': nat.SKF_BF16}[dtype]
+    esz = {'f64': 8, 'f32': 4, 'bf16': 2}[dtype]
+    buf = rt.mem.empty(shape[0] * shape[1] * esz)
+    rt.call('skf_fill_uniform', code, buf.ptr, shape[0], shape[1], shape[1], int(seed),
+            float(scale), float(shift), rt.mem.stream)
+    return DeviceMatrix(buf, shape)
+
+
 class DevicePlan(object):
     """One (run, device) plan: relations + constraints uploaded, workspace bound."""
 
@@ -37,16 +56,19 @@ class DevicePlan(object):
             tdesc[k].n_obj, tdesc[k].rank = self.n_obj[k], self.rank[k]
         rdesc = (nat.RelationDesc * max(len(relations), 1))()
         for k, (i, j, data, mask) in enumerate(relations):
-            arr = np.ascontiguousarray(data, dtype=self.np_dtype)
-            if arr.ndim != 2:
-                raise ValueError('relation %d is not a matrix' % k)
-            if arr.shape != (n_obj[i], n_obj[j]):
+            if isinstance(data, DeviceMatrix):
+                arr, buf, ld = data, data.buf, data.ld
+            else:
+                arr = np.ascontiguousarray(data, dtype=self.np_dtype)
+                if arr.ndim != 2:
+                    raise ValueError('relation %d is not a matrix' % k)
+                buf, ld = mem.from_host(arr), arr.shape[1]
+            if tuple(arr.shape) != (n_obj[i], n_obj[j]):
                 raise ValueError('relation (%s,%s) dimension mismatch: %r vs object counts (%d,%d)'
-                                 % (i, j, arr.shape, n_obj[i], n_obj[j]))
-            buf = mem.from_host(arr)
+                                 % (i, j, tuple(arr.shape), n_obj[i], n_obj[j]))
             self._keep.append(buf)
             rdesc[k].row_type, rdesc[k].col_type = self.index[i], self.index[j]
-            rdesc[k].data, rdesc[k].ld = buf.ptr, arr.shape[1]
+            rdesc[k].data, rdesc[k].ld = buf.ptr, ld
             if mask is not None:
                 m = np.ascontiguousarray(np.asarray(mask, dtype=bool).astype(np.uint8))
                 if m.shape != arr.shape:
@@ -76,6 +98,12 @@ class DevicePlan(object):
     # -- factors ---------------------------------------------------------------------------
     def set_factor(self, t, G):
         k = self.index[t]
+        if isinstance(G, DeviceMatrix):
+            if G.shape != (self.n_obj[k], self.rank[k]):
+                raise ValueError('factor of %s has shape %r' % (t, G.shape))
+            self.rt.call('skf_set_factor', self.handle, k, G.buf.ptr, G.ld, self.rt.mem.stream)
+            self.rt.mem.synchronize()
+            return
         arr = np.ascontiguousarray(G, dtype=self.np_dtype)
         if arr.shape != (self.n_obj[k], self.rank[k]):
             raise ValueError('factor of %s has shape %r, expected %r'
@@ -124,6 +152,15 @@ class DevicePlan(object):
         self.rt.call('skf_relation_sqerr', self.handle, rel, self._scalar.ptr, self.rt.mem.stream)
         self.rt.mem.synchronize()
         return float(self.rt.mem.to_host(self._scalar, (1,), np.float64)[0])
+
+    def set_profiling(self, enable=True):
+        self.rt.call('skf_plan_set_profiling', self.handle, 1 if enable else 0)
+
+    def get_profile(self):
+        """(total ms, launches, algorithmic flops) of the relation contractions since last call."""
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        self.rt.call('skf_plan_get_profile', self.handle, C.byref(ms), C.byref(n), C.byref(fl))
+        return ms.value, n.value, fl.value
 
     def close(self):
         if self.handle:

@@ -111,16 +111,18 @@ static int pick_splits(const TileCfg& t, int M, int N, int K) {
 }
 
 template <typename T>
-static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, hipStream_t st) {
+static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, bool relation, hipStream_t st) {
     dim3 grid(cdiv(g.N, t.bn), cdiv(g.M, t.bm), splits);
     dim3 block(GEMM_THREADS);
+    constexpr int WRB = 128 / (2 * Mfma<T>::MT), WCB = 128 / (2 * Mfma<T>::NT);
     if (engine == SKF_ENGINE_VALU) {
         hipLaunchKernelGGL((gemm_valu_kernel<T>), grid, block, 0, st, g);
+    } else if (t.bm == 128 && relation) {
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, WRB, WCB, Tiles<T>::BK, 1>), grid, block, 0, st, g);
     } else if (t.bm == 128) {
-        hipLaunchKernelGGL((gemm_mfma_kernel<T, 128 / (2 * Mfma<T>::MT), 128 / (2 * Mfma<T>::NT), Tiles<T>::BK>),
-                           grid, block, 0, st, g);
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, WRB, WCB, Tiles<T>::BK, 0>), grid, block, 0, st, g);
     } else {
-        hipLaunchKernelGGL((gemm_mfma_kernel<T, 1, 1, Tiles<T>::BK>), grid, block, 0, st, g);
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, 1, 1, Tiles<T>::BK, 0>), grid, block, 0, st, g);
     }
     check_launch("gemm");
     if (splits > 1) {
@@ -132,7 +134,7 @@ static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, 
 
 // `part`/`part_elems`: scratch for split-K partials (elements of T); splits is clamped to fit.
 static void run_gemm(bool is_f64, int engine, GemmArgs g, int want_splits, void* part, size_t part_elems,
-                     hipStream_t st) {
+                     hipStream_t st, bool relation = false) {
     if (g.M <= 0 || g.N <= 0) return;
     const TileCfg t = pick_tile(is_f64, engine, g.M, g.N);
     int splits = want_splits > 0 ? want_splits : pick_splits(t, g.M, g.N, g.K);
@@ -147,8 +149,8 @@ static void run_gemm(bool is_f64, int engine, GemmArgs g, int want_splits, void*
     g.k_chunk = cdiv(ktiles, splits) * t.bk;
     splits = cdiv(g.K > 0 ? g.K : 1, g.k_chunk);
     g.part = part;
-    if (is_f64) launch_gemm_t<double>(engine, t, g, splits, st);
-    else launch_gemm_t<float>(engine, t, g, splits, st);
+    if (is_f64) launch_gemm_t<double>(engine, t, g, splits, relation, st);
+    else launch_gemm_t<float>(engine, t, g, splits, relation, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -205,6 +207,15 @@ struct skf_plan {
     int64_t eig_stride = 0;
     int eig_maxn = 0;
     size_t sq_elems = 0;
+    // optional hipEvent timing of the relation contractions (skf_plan_set_profiling)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double prof_flops = 0.0;
+    int64_t prof_launches = 0;
+    ~skf_plan() {
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    }
 };
 
 namespace skf {
@@ -239,6 +250,26 @@ static GemmArgs gemm_args(const void* A, int64_t sa_m, int64_t sa_k, const void*
 
 static void plan_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
     run_gemm(p->f64, p->engine, g, 0, p->part.ptr, p->part_elems, st);
+}
+
+static hipEvent_t next_event(skf_plan* p) {
+    if (p->ev_used == p->ev_pool.size()) {
+        hipEvent_t e;
+        SKF_HIP(hipEventCreate(&e));
+        p->ev_pool.push_back(e);
+    }
+    return p->ev_pool[p->ev_used++];
+}
+
+// one of the two contractions that stream a relation matrix: P = R G_j or Q = R^T G_i
+static void relation_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
+    if (p->profiling) SKF_HIP(hipEventRecord(next_event(p), st));
+    run_gemm(p->f64, p->engine, g, 0, p->part.ptr, p->part_elems, st, true);
+    if (p->profiling) {
+        SKF_HIP(hipEventRecord(next_event(p), st));
+        p->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
+        p->prof_launches += 1;
+    }
 }
 
 // K_i = pinv(Gram_i) for every type (one workgroup each); `which` = 0..n_types-1, the order
@@ -370,7 +401,7 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
         const int ni = (int)ti.n, nj = (int)tj.n, ci = ti.c, cj = tj.c;
         // P = R G_j
         GemmArgs g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
-        plan_gemm(p, g, st);
+        relation_gemm(p, g, st);
         // W = G_i^T P ; T1 = K_i W ; S = T1 K_j
         g = gemm_args(ti.G.ptr, 1, ci, r.P.ptr, cj, 1, r.W.ptr, cj, ci, cj, ni, EPI_STORE, 0);
         plan_gemm(p, g, st);
@@ -387,11 +418,11 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
             g.ldmask = r.ldmask;
             plan_gemm(p, g, st);
             g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
-            plan_gemm(p, g, st);
+            relation_gemm(p, g, st);
         }
         // Q = R^T G_i
         g = gemm_args(r.R, 1, r.ldr, ti.G.ptr, ci, 1, r.Q.ptr, ci, nj, ci, ni, EPI_STORE, 0);
-        plan_gemm(p, g, st);
+        relation_gemm(p, g, st);
         relation_small_terms(p, r, nan_upd, EPI_SPLIT_STORE, r.Bp.ptr, r.Bn.ptr, r.Dp.ptr, r.Dn.ptr, true, true, st);
         // E_i += (P S^T)+ ; D_i += (P S^T)-          (_dfmf.py:254-258, 278-279)
         g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, ti.E.ptr, ci, ni, ci, cj, EPI_SPLIT_ACC, nan_upd);
@@ -430,7 +461,7 @@ static void prepare_transform(skf_plan* p, hipStream_t st) {
         const int ni = (int)ti.n, nj = (int)tj.n, ci = ti.c, cj = tj.c;
         if (r.row == p->target) {             // _dfmf.py:392-405
             GemmArgs g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
-            plan_gemm(p, g, st);
+            relation_gemm(p, g, st);
             g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, tt.Ec.ptr, ci, ni, ci, cj, EPI_SPLIT_ACC, 0);
             g.C2 = tt.Dc.ptr;
             plan_gemm(p, g, st);
@@ -438,7 +469,7 @@ static void prepare_transform(skf_plan* p, hipStream_t st) {
                                  false, st);
         } else {                              // _dfmf.py:407-419
             GemmArgs g = gemm_args(r.R, 1, r.ldr, ti.G.ptr, ci, 1, r.Q.ptr, ci, nj, ci, ni, EPI_STORE, 0);
-            plan_gemm(p, g, st);
+            relation_gemm(p, g, st);
             g = gemm_args(r.Q.ptr, ci, 1, r.S.ptr, cj, 1, tt.Ec.ptr, cj, nj, cj, ci, EPI_SPLIT_ACC, 0);
             g.C2 = tt.Dc.ptr;
             plan_gemm(p, g, st);
@@ -745,6 +776,35 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
             hipLaunchKernelGGL((sum_partials_kernel<float>), dim3(1), dim3(256), 0, st, (const float*)p->sqpart.ptr,
                                blocks, out);
         check_launch("sum_partials");
+    });
+}
+
+int skf_plan_set_profiling(skf_plan* p, int32_t enable) {
+    return guarded([&] {
+        if (!p) SKF_FAIL(SKF_E_INVALID, "null plan");
+        p->profiling = enable != 0;
+        p->ev_used = 0;
+        p->prof_flops = 0.0;
+        p->prof_launches = 0;
+    });
+}
+
+int skf_plan_get_profile(skf_plan* p, double* total_ms, int64_t* launches, double* flops) {
+    return guarded([&] {
+        if (!p || !total_ms || !launches || !flops) SKF_FAIL(SKF_E_INVALID, "null argument");
+        double ms = 0.0;
+        for (size_t k = 0; k + 1 < p->ev_used; k += 2) {
+            SKF_HIP(hipEventSynchronize(p->ev_pool[k + 1]));
+            float t = 0.f;
+            SKF_HIP(hipEventElapsedTime(&t, p->ev_pool[k], p->ev_pool[k + 1]));
+            ms += t;
+        }
+        *total_ms = ms;
+        *launches = p->prof_launches;
+        *flops = p->prof_flops;
+        p->ev_used = 0;
+        p->prof_flops = 0.0;
+        p->prof_launches = 0;
     });
 }
 

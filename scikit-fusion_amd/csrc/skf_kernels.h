@@ -182,7 +182,10 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const T (&reg)[ROWS * 
 // One K step:  [global loads of tile t+1 in flight]  MFMA on tile t from LDS  | barrier |
 //              registers -> LDS | barrier.
 // ------------------------------------------------------------------------------------------
-template <typename T, int WR, int WC, int BK>
+// TAG only changes the symbol name: TAG=1 instantiations are the two relation contractions
+// P = R G_j and Q = R^T G_i (the only launches that read R), so that profilers list the
+// dominant kernel separately from the small n x c x c products that share the code.
+template <typename T, int WR, int WC, int BK, int TAG>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
     typedef Mfma<T> MF;
     constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;

@@ -1,0 +1,284 @@
+"""Parity tests proper: the HIP engine on a real MI355X, called through the C ABI
+(libskfusion_hip.so), against the golden vectors of the reference and the CPU oracle.
+Run with `pytest -m gpu`.  Tolerances: f64 <= 1e-9 relative on (G, S) vs the
+goldens; f32 <= 1e-4 on G / 1e-3 on S after 30 iterations and <= 1e-5 relative on the
+per-relation reconstruction error."""
+import numpy as np
+import pytest
+
+import skfusion_amd._native as nat
+from skfusion_amd.fusion.decomposition import _dfmf, _dfmc
+from skfusion_amd._engine import DevicePlan, fill_uniform
+from oracle import dfmf_oracle as orc
+from helpers import (golden, readme_graph, probe_graph, rank_deficient_graph, dicty_graph,
+                     c3_scaled_graph, g0_from, Snapshots, compare_snapshots, relerr, TYPES)
+import test_emul_kernels as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def rt():
+    return nat.get_runtime()           # raises if libskfusion_hip.so or the GPU is missing
+
+
+def test_native_library_is_the_one_loaded(rt):
+    assert rt.name == 'hip'
+    assert b'gfx950' in rt.lib.skf_version()
+
+
+# ---- kernels (same checks as the emulator suite, on the hardware) -----------------------------
+@pytest.mark.parametrize('dtype', [nat.SKF_F64, nat.SKF_F32])
+@pytest.mark.parametrize('engine', [nat.SKF_ENGINE_MFMA, nat.SKF_ENGINE_VALU])
+@pytest.mark.parametrize('shape', K.SHAPES + [(1000, 256, 3000), (300, 128, 5000)])
+def test_gemm_all_layouts(rt, dtype, engine, shape):
+    K.test_gemm_plain_all_layouts(rt, dtype, engine, shape)
+
+
+@pytest.mark.parametrize('dtype', [nat.SKF_F64, nat.SKF_F32])
+@pytest.mark.parametrize('engine', [nat.SKF_ENGINE_MFMA, nat.SKF_ENGINE_VALU])
+def test_gemm_epilogues(rt, dtype, engine):
+    K.test_gemm_epilogues_and_operand_ops(rt, dtype, engine)
+
+
+@pytest.mark.parametrize('dtype', [nat.SKF_F64, nat.SKF_F32])
+def test_gemm_split_k(rt, dtype):
+    K.test_gemm_split_k_and_nan_to_num(rt, dtype)
+
+
+def test_mfma_and_valu_engines_agree_bitwise_in_f32(rt):
+    """v_mfma_f32_32x32x2_f32 is an exact k-ordered fma chain: identical to the VALU kernel when
+    the K tiling is the same chain order (single K slice)."""
+    rs = np.random.RandomState(3)
+    A, B = rs.randn(200, 300), rs.randn(300, 150)
+    a, _ = K.run_gemm(rt, nat.SKF_F32, nat.SKF_ENGINE_MFMA, A, B, splits=1)
+    b, _ = K.run_gemm(rt, nat.SKF_F32, nat.SKF_ENGINE_VALU, A, B, splits=1)
+    assert relerr(a, b) < 1e-6
+
+
+@pytest.mark.parametrize('n', [1, 2, 5, 10, 31, 50, 128, 256])
+def test_pinv_full_rank(rt, n):
+    K.test_pinv_full_rank_matches_scipy(rt, n)
+
+
+def test_pinv_rank_deficient(rt):
+    K.test_pinv_rank_deficient_truncates_like_scipy(rt)
+    K.test_pinv_zero_and_diagonal(rt)
+
+
+def test_fill_uniform(rt):
+    K.test_fill_uniform_matches_oracle_hash(rt)
+
+
+def test_errors(rt):
+    K.test_errors_are_reported_not_thrown(rt)
+
+
+# ---- engine vs goldens of the reference ----------------------------------------------------------
+@pytest.mark.parametrize('init', ['random', 'random_c', 'random_vcol'])
+def test_c1_readme_100_iterations_f64(init):
+    z = golden('c1_readme_dfmf.npz')
+    R, types, rank = readme_graph()
+    snaps = Snapshots((0, 1, 9, 99))
+    G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=100, callback=snaps,
+                      G0=g0_from(z, init + '/', types), dtype='f64')
+    compare_snapshots(z, init + '/', snaps.snap, 1e-9)
+    errs = orc.relation_errors(R, G, S)
+    for (i, j), e in errs.items():
+        assert relerr(e, z['%s/err_%s_%s' % (init, i, j)]) < 1e-9
+    # device-resident loop without callback gives the same result
+    G2, S2 = _dfmf.dfmf(R, {}, types, rank, max_iter=100, G0=g0_from(z, init + '/', types))
+    for k in G:
+        assert relerr(G2[k], G[k]) < 1e-12
+
+
+def test_c1_readme_f32_tolerances():
+    z = golden('c1_readme_dfmf.npz')
+    R, types, rank = readme_graph()
+    G0 = g0_from(z, 'random_vcol/', types)
+    G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=30, G0=G0, dtype='f32')
+    Go, So = orc.dfmf(R, {}, types, rank, max_iter=30, G0=G0)
+    for t in types:
+        assert relerr(G[t, t], Go[t, t]) < 1e-4
+    for k in So:
+        assert relerr(S[k][0], So[k][0]) < 1e-3
+    e, eo = orc.relation_errors(R, G, S), orc.relation_errors(R, Go, So)
+    for k in e:
+        assert abs(e[k][0] - eo[k][0]) / eo[k][0] < 1e-5
+
+
+def test_seeded_run_matches_reference_rng_stream():
+    z = golden('c1_readme_dfmf.npz')
+    R, types, rank = readme_graph()
+    for init in ('random', 'random_c', 'random_vcol'):
+        snaps = Snapshots((0, 99))
+        _dfmf.dfmf(R, {}, types, rank, max_iter=100, init_type=init, callback=snaps,
+                   random_state=np.random.RandomState(0))
+        compare_snapshots(z, init + '/', snaps.snap, 1e-9)
+
+
+def test_probe_graph_dfmf_and_dfmc():
+    z = golden('probe_multirel.npz')
+    R, Theta, M, types, rank = probe_graph(z)
+    snaps = Snapshots((0, 1, 9, 29))
+    _dfmf.dfmf(R, Theta, types, rank, max_iter=30, callback=snaps, G0=g0_from(z, 'dfmf/', types))
+    compare_snapshots(z, 'dfmf/', snaps.snap, 1e-9)
+    keep = {k: [m.copy() for m in v] for k, v in R.items()}
+    snaps = Snapshots((0, 1, 9, 29))
+    _dfmc.dfmc(R, M, Theta, types, rank, max_iter=30, callback=snaps, G0=g0_from(z, 'dfmc/', types))
+    compare_snapshots(z, 'dfmc/', snaps.snap, 1e-9)
+    for k in R:
+        for a, b in zip(R[k], keep[k]):
+            np.testing.assert_array_equal(a, b)
+    # f32 engine on the same graph stays within the f32 tolerance of the f64 golden
+    snaps = Snapshots((29,))
+    _dfmc.dfmc(R, M, Theta, types, rank, max_iter=30, callback=snaps, G0=g0_from(z, 'dfmc/', types),
+               dtype='f32')
+    compare_snapshots(z, 'dfmc/', snaps.snap, 2e-3)
+
+
+@pytest.mark.parametrize('variant', ['dfmf', 'dfmc'])
+def test_rank_deficient_100_iterations(variant):
+    z = golden('rank_deficient.npz')
+    R, types, rank = rank_deficient_graph(z)
+    G0 = g0_from(z, variant + '/', types)
+    snaps = Snapshots((0, 1))
+    if variant == 'dfmf':
+        G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=100, callback=snaps, G0=G0)
+    else:
+        G, S = _dfmc.dfmc(R, {k: [None] for k in R}, {}, types, rank, max_iter=100,
+                          callback=snaps, G0=G0)
+    compare_snapshots(z, variant + '/', snaps.snap, 1e-7)
+    assert all(np.isfinite(v).all() for v in G.values())
+    errs = orc.relation_errors(R, G, S)
+    for (i, j), e in errs.items():
+        want = z['%s/err_%s_%s' % (variant, i, j)]
+        assert abs(e[0] - want[0]) <= 1e-5 * max(1.0, want[0])
+
+
+@pytest.mark.parametrize('init', ['random_c', 'random_vcol', 'random'])
+def test_transform_fold_in(init):
+    z = golden('transform_readme.npz')
+    G = {(t, t): z['G_%s' % t] for t in TYPES}
+    S = {('t1', 't2'): [z['S_t1_t2']], ('t1', 't3'): [z['S_t1_t3']], ('t2', 't1'): [z['S_t2_t1']]}
+    Rn = {('t1', 't2'): [z['new_t1_t2']], ('t1', 't3'): [z['new_t1_t3']], ('t2', 't1'): [z['new_t2_t1']]}
+    rank = {'t1': 10, 't2': 20, 't3': 30}
+    snaps = {}
+    Gi = _dfmf.transform(Rn, {('t1', 't1'): [z['theta_t1']]}, 't1', rank, G, S, max_iter=100,
+                         init_type=init, random_state=np.random.RandomState(4),
+                         callback=lambda g, it: snaps.__setitem__(it, g.copy()))
+    for it in (0, 9, 99):
+        assert relerr(snaps[it], z['%s/G_it%d' % (init, it)]) < 1e-9
+    Gi32 = _dfmf.transform(Rn, {('t1', 't1'): [z['theta_t1']]}, 't1', rank, G, S, max_iter=100,
+                           G0=z[init + '/G0'], dtype='f32')
+    assert relerr(Gi32, z['%s/G_it99' % init]) < 1e-4
+
+
+def test_c2_dicty_dfmf_100_iterations_f64_and_f32():
+    """BASELINE config 2: dicty (2 relations + the ppi constraint), ranks 50/15/5."""
+    z = golden('c2_dicty.npz')
+    R, Theta, types, rank = dicty_graph()
+    G0 = g0_from(z, 'dfmf/', types)
+    snaps = Snapshots((0, 9, 99))
+    G, S = _dfmf.dfmf(R, Theta, types, rank, max_iter=100, callback=snaps, G0=G0, dtype='f64')
+    compare_snapshots(z, 'dfmf/', snaps.snap, 1e-8)
+    errs = orc.relation_errors(R, G, S)
+    for (i, j), e in errs.items():
+        assert relerr(e, z['dfmf/err_%s_%s' % (i, j)]) < 1e-9
+    G32, S32 = _dfmf.dfmf(R, Theta, types, rank, max_iter=100, G0=G0, dtype='f32')
+    e32 = orc.relation_errors(R, G32, S32)
+    for k in errs:
+        assert abs(e32[k][0] - errs[k][0]) / errs[k][0] < 1e-4
+
+
+def test_c2_dicty_dfmc_row_block_mask():
+    z = golden('c2_dicty.npz')
+    R, Theta, types, rank = dicty_graph()
+    lo, hi = [int(v) for v in z['dfmc/mask_rows']]
+    mask = np.zeros(R['gene', 'go'][0].shape, dtype=bool)
+    mask[lo:hi] = True
+    M = {('gene', 'go'): [mask], ('gene', 'exc'): [None]}
+    snaps = Snapshots((0, 9, 29))
+    G, S = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=30, callback=snaps,
+                      G0=g0_from(z, 'dfmf/', types))
+    compare_snapshots(z, 'dfmc/', snaps.snap, 1e-8)
+    assert relerr(G['gene', 'gene'][:256], z['dfmc/G_gene_final_rows']) < 1e-8
+
+
+def test_c3_scaled_f64_and_f32():
+    """1/25-linear-scale BASELINE config 3 (ranks 128/256/256): errors per iteration, S, G rows."""
+    z = golden('c3_scaled.npz')
+    R, G0, types, rank = c3_scaled_graph(z)
+    errs = []
+
+    def cb(G, S, it):
+        e = orc.relation_errors(R, G, S)
+        errs.append([e[k][0] for k in sorted(e)])
+        for t in types:
+            assert relerr(G[t, t][:16], z['Grows_%s_it%d' % (t, it)]) < 1e-8
+    G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=5, callback=cb, G0=G0, dtype='f64')
+    assert relerr(np.array(errs), z['errs']) < 1e-9
+    for (i, j) in R:
+        assert relerr(S[i, j][0], z['S_%s_%s_it4' % (i, j)]) < 1e-7
+    G32, S32 = _dfmf.dfmf(R, {}, types, rank, max_iter=5, G0=G0, dtype='f32')
+    e32 = orc.relation_errors(R, G32, S32)
+    want = z['errs'][4]
+    got = [e32[k][0] for k in sorted(e32)]
+    assert relerr(got, want) < 1e-5
+
+
+def test_device_side_error_and_generated_data_match_oracle(rt):
+    """fill_uniform data + relation_sqerr on the device == the same graph built on the host."""
+    n = {'t1': 300, 't2': 500, 't3': 200}
+    rank = {'t1': 16, 't2': 32, 't3': 24}
+    rels = [('t1', 't2', fill_uniform((300, 500), 0, 'f64'), None),
+            ('t1', 't3', fill_uniform((300, 200), 1, 'f64'), None),
+            ('t2', 't3', fill_uniform((500, 200), 2, 'f64'), None)]
+    plan = DevicePlan(TYPES, n, rank, rels, [], nat.SKF_DFMF, dtype='f64')
+    G0 = {}
+    for k, t in enumerate(TYPES):
+        plan.set_factor(t, fill_uniform((n[t], rank[t]), 100 + k, 'f64'))
+        G0[t, t] = orc.hash_uniform_matrix(100 + k, n[t], rank[t])
+    plan.iterate(8)
+    R = {('t1', 't2'): [orc.hash_uniform_matrix(0, 300, 500)],
+         ('t1', 't3'): [orc.hash_uniform_matrix(1, 300, 200)],
+         ('t2', 't3'): [orc.hash_uniform_matrix(2, 500, 200)]}
+    Go, So = orc.dfmf(R, {}, TYPES, rank, max_iter=8, G0=G0)
+    for t in TYPES:
+        assert relerr(plan.get_factor(t), Go[t, t]) < 1e-9
+    eo = orc.relation_errors(R, Go, So)
+    for k, (i, j, _, _) in enumerate(rels):
+        assert abs(np.sqrt(plan.relation_sqerr(k)) - eo[i, j][0]) < 1e-9 * eo[i, j][0]
+    plan.close()
+
+
+def test_full_size_properties_c3(rt):
+    """BASELINE config 3 at FULL size (50k x 100k / 50k x 40k / 100k x 40k, ranks 128/256/256,
+    f32): size-independent properties -- factors stay finite and non-negative, the summed
+    reconstruction error does not increase over iterations (DFMF objective), and the RMSE sits
+    at the iid-uniform floor sqrt(1/12) within 1%."""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 120e9:
+        pytest.skip('needs > 120 GB of HBM')
+    n = {'t1': 50000, 't2': 100000, 't3': 40000}
+    rank = {'t1': 128, 't2': 256, 't3': 256}
+    rels = [('t1', 't2', fill_uniform((n['t1'], n['t2']), 0, 'f32'), None),
+            ('t1', 't3', fill_uniform((n['t1'], n['t3']), 1, 'f32'), None),
+            ('t2', 't3', fill_uniform((n['t2'], n['t3']), 2, 'f32'), None)]
+    plan = DevicePlan(TYPES, n, rank, rels, [], nat.SKF_DFMF, dtype='f32')
+    for k, t in enumerate(TYPES):
+        plan.set_factor(t, fill_uniform((n[t], rank[t]), 100 + k, 'f32'))
+    prev = None
+    for it in range(4):
+        plan.iterate(1)
+        tot = sum(np.sqrt(plan.relation_sqerr(k)) for k in range(3))
+        assert np.isfinite(tot)
+        if prev is not None:
+            assert tot <= prev * (1 + 1e-6)
+        prev = tot
+    for k, (i, j, _, _) in enumerate(rels):
+        rmse = np.sqrt(plan.relation_sqerr(k) / (n[i] * n[j]))
+        assert abs(rmse - np.sqrt(1 / 12.)) < 0.01 * np.sqrt(1 / 12.)
+    G1 = plan.get_factor('t1')
+    assert np.isfinite(G1).all() and (G1 >= 0).all()
+    plan.close()

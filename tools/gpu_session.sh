@@ -1,0 +1,47 @@
+#!/bin/bash
+# One GPU-box session: build, smoke, parity tests, bench, rocprof.  Outputs -> gpurun_out/
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out/$1; shift
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+echo "== build + smoke" | tee "$OUT/summary.txt"
+( time python __graft_entry__.py --smoke ) > "$OUT/smoke.log" 2>&1; echo "smoke exit $?" | tee -a "$OUT/summary.txt"
+tail -3 "$OUT/smoke.log" | tee -a "$OUT/summary.txt"
+for step in "$@"; do
+case "$step" in
+  tests)
+    echo "== pytest -m gpu" | tee -a "$OUT/summary.txt"
+    ( time timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 ) > "$OUT/pytest.log" 2>&1
+    echo "pytest exit $?" | tee -a "$OUT/summary.txt"; tail -25 "$OUT/pytest.log" | tee -a "$OUT/summary.txt" ;;
+  tests_all)
+    echo "== pytest -m gpu (no -x)" | tee -a "$OUT/summary.txt"
+    ( time timeout 1500 python -m pytest tests -m gpu -q --durations=10 ) > "$OUT/pytest.log" 2>&1
+    echo "pytest exit $?" | tee -a "$OUT/summary.txt"; tail -40 "$OUT/pytest.log" | tee -a "$OUT/summary.txt" ;;
+  bench_*)
+    dt=${step#bench_}
+    echo "== bench $dt" | tee -a "$OUT/summary.txt"
+    ( time timeout 900 python bench.py --dtype $dt --steps 10 --warmup 3 ) > "$OUT/bench_$dt.log" 2>&1
+    echo "bench exit $?" | tee -a "$OUT/summary.txt"; tail -4 "$OUT/bench_$dt.log" | tee -a "$OUT/summary.txt" ;;
+  prof_*)
+    dt=${step#prof_}
+    echo "== rocprofv3 kernel-trace $dt" | tee -a "$OUT/summary.txt"
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_$dt" -o prof -- python "$OLDPWD/bench.py" --dtype $dt --steps 5 --warmup 2 --no-cpu-baseline ) > "$OUT/prof_$dt.log" 2>&1
+    echo "rocprof exit $?" | tee -a "$OUT/summary.txt"; tail -3 "$OUT/prof_$dt.log" | tee -a "$OUT/summary.txt"
+    f=$(find "$OUT/prof_$dt" -name '*kernel_stats.csv' | head -1)
+    [ -n "$f" ] && head -25 "$f" | tee -a "$OUT/summary.txt"
+    # keep only the small summaries (traces can be large)
+    find "$OUT/prof_$dt" -name '*kernel_trace.csv' -size +20M -delete ;;
+  pmc_*)
+    dt=${step#pmc_}
+    echo "== rocprofv3 pmc $dt" | tee -a "$OUT/summary.txt"
+    ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE -d "$OLDPWD/$OUT/pmc_fetch_$dt" -o pmc -- python "$OLDPWD/bench.py" --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline ) > "$OUT/pmc_fetch_$dt.log" 2>&1
+    echo "pmc fetch exit $?" | tee -a "$OUT/summary.txt"
+    ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE -d "$OLDPWD/$OUT/pmc_write_$dt" -o pmc -- python "$OLDPWD/bench.py" --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline ) > "$OUT/pmc_write_$dt.log" 2>&1
+    echo "pmc write exit $?" | tee -a "$OUT/summary.txt"
+    python tools/pmc_summary.py "$OUT/pmc_fetch_$dt" "$OUT/pmc_write_$dt" 2>&1 | tee -a "$OUT/summary.txt"
+    find "$OUT" -name '*counter_collection.csv' -size +20M -delete ;;
+esac
+done
+rocm-smi --showmeminfo vram 2>/dev/null | head -5 >> "$OUT/summary.txt"
+nproc >> "$OUT/summary.txt"
