@@ -93,7 +93,13 @@ int skf_plan_bind_workspace(skf_plan* plan, void* workspace, size_t bytes, void*
 
 /* ---- factors --------------------------------------------------------------------------- */
 
-/* master dtype = f64 for SKF_F64, f32 otherwise.  set_factor copies an n_obj x rank matrix in
+/* Precision model: the n-sized matrices (relations, factors G, accumulators E/D, P, Q) live in
+ * the master type -- f64 for SKF_F64, f32 otherwise.  Every c x c matrix (Gram, its
+ * pseudo-inverse, backbones S and the B/D terms) is kept and combined in f64 in ALL engines, and
+ * the two reductions over the object dimension that feed them (G^T G, G^T P) accumulate in f64:
+ * the Gram matrices of real data are ill-conditioned (cond ~1e5 for the reference's dicty
+ * example) and an all-f32 pipeline diverges where the f64 reference does not.
+ * set_factor copies an n_obj x rank matrix in  set_factor copies an n_obj x rank matrix in
  * (the G0 of `initialize`, _init.py:6-61, or a frozen fitted factor for SKF_TRANSFORM). */
 int skf_set_factor(skf_plan* plan, int32_t type, const void* G, int64_t ld, void* stream);
 int skf_get_factor(const skf_plan* plan, int32_t type, void* G, int64_t ld, void* stream);
@@ -136,9 +142,11 @@ typedef struct {
     int32_t epi;        /* 0 store, 1 accumulate, 2 split-store, 3 split-accumulate, 4 masked store */
     int32_t nan_to_num; /* numpy.nan_to_num on the product before the epilogue */
     int32_t splits;     /* 0 = choose; >1 needs workspace of splits*M*N elements */
+    int32_t a_dtype;    /* storage type of A / B: -1 = same as `dtype`, else SKF_F64 / SKF_F32.   */
+    int32_t b_dtype;    /* supported (C,A,B): (f64,f64,f64) (f32,f32,f32) (f64,f32,f32) (f32,f32,f64) */
 } skf_gemm_desc;
 
-/* C = epi(aop(A) * B) on the matrix cores (f64 / f32). */
+/* C = epi(aop(A) * B) on the matrix cores; `dtype` = arithmetic and result type (f64 / f32). */
 int skf_gemm(int32_t dtype, int32_t engine, const skf_gemm_desc* desc, void* workspace,
              size_t workspace_bytes, void* stream);
 

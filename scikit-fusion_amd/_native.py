@@ -56,7 +56,7 @@ class GemmDesc(C.Structure):
                 ('ldc', C.c_int64), ('ldc2', C.c_int64), ('ldmask', C.c_int64),
                 ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
                 ('aop', C.c_int32), ('epi', C.c_int32), ('nan_to_num', C.c_int32),
-                ('splits', C.c_int32)]
+                ('splits', C.c_int32), ('a_dtype', C.c_int32), ('b_dtype', C.c_int32)]
 
 
 # every symbol include/skfusion_hip.h declares: name -> (restype, argtypes)
@@ -92,6 +92,15 @@ def load_library(path=LIB_PATH):
         raise ImportError(
             '%s not found at %s -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(hipcc --offload-arch=gfx950).  skfusion_amd has no CPU fallback.' % (LIB_NAME, path))
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (SONAME
+    # libamdhip64.so.7, the same as /opt/rocm's).  If torch is imported FIRST the dynamic loader
+    # satisfies our DT_NEEDED with torch's already-loaded copy, so device pointers and stream
+    # handles are shared; loaded the other way round the process ends up with two HSA runtimes
+    # and the second one sees "no ROCm-capable device".
+    try:
+        import torch                                     # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
@@ -161,7 +170,8 @@ def get_runtime():
     """The product runtime: libskfusion_hip.so + GPU memory.  Raises if either is missing."""
     global _runtime
     if _runtime is None:
-        _runtime = Runtime(load_library(), TorchDeviceMemory(), 'hip')
+        mem = TorchDeviceMemory()                  # imports torch + initialises its HIP runtime
+        _runtime = Runtime(load_library(), mem, 'hip')
     return _runtime
 
 

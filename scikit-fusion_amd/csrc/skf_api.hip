@@ -110,19 +110,19 @@ static int pick_splits(const TileCfg& t, int M, int N, int K) {
     return s < 1 ? 1 : s;
 }
 
-template <typename T>
+template <typename T, typename TA, typename TB>
 static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, bool relation, hipStream_t st) {
     dim3 grid(cdiv(g.N, t.bn), cdiv(g.M, t.bm), splits);
     dim3 block(GEMM_THREADS);
     constexpr int WRB = 128 / (2 * Mfma<T>::MT), WCB = 128 / (2 * Mfma<T>::NT);
     if (engine == SKF_ENGINE_VALU) {
-        hipLaunchKernelGGL((gemm_valu_kernel<T>), grid, block, 0, st, g);
+        hipLaunchKernelGGL((gemm_valu_kernel<T, TA, TB>), grid, block, 0, st, g);
     } else if (t.bm == 128 && relation) {
-        hipLaunchKernelGGL((gemm_mfma_kernel<T, WRB, WCB, Tiles<T>::BK, 1>), grid, block, 0, st, g);
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 1>), grid, block, 0, st, g);
     } else if (t.bm == 128) {
-        hipLaunchKernelGGL((gemm_mfma_kernel<T, WRB, WCB, Tiles<T>::BK, 0>), grid, block, 0, st, g);
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 0>), grid, block, 0, st, g);
     } else {
-        hipLaunchKernelGGL((gemm_mfma_kernel<T, 1, 1, Tiles<T>::BK, 0>), grid, block, 0, st, g);
+        hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, 1, 1, Tiles<T>::BK, 0>), grid, block, 0, st, g);
     }
     check_launch("gemm");
     if (splits > 1) {
@@ -132,14 +132,25 @@ static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, 
     }
 }
 
-// `part`/`part_elems`: scratch for split-K partials (elements of T); splits is clamped to fit.
-static void run_gemm(bool is_f64, int engine, GemmArgs g, int want_splits, void* part, size_t part_elems,
+// operand / result types of one contraction (SKF_F64 or SKF_F32 each).  Supported:
+//   (f64,f64,f64)  f64 engine, and the c x c algebra of every engine
+//   (f32,f32,f32)  relation contractions and Theta products of the f32 engine
+//   (f64,f32,f32)  Gram = G^T G and W = G^T P of the f32 engine: f32 operands, f64 arithmetic
+//   (f32,f32,f64)  n x c x c products of the f32 engine with an f64 backbone / B, D matrix
+struct GemmTypes {
+    int c, a, b;
+};
+
+// `part`/`part_bytes`: scratch for split-K partials; splits is clamped to fit.
+static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void* part, size_t part_bytes,
                      hipStream_t st, bool relation = false) {
     if (g.M <= 0 || g.N <= 0) return;
+    const bool is_f64 = (ty.c == SKF_F64);
     const TileCfg t = pick_tile(is_f64, engine, g.M, g.N);
     int splits = want_splits > 0 ? want_splits : pick_splits(t, g.M, g.N, g.K);
     if (g.epi == EPI_SQDIFF) splits = 1;
     const size_t per = (size_t)g.M * g.N;
+    const size_t part_elems = part_bytes / (is_f64 ? 8 : 4);
     if (splits > 1 && (part == nullptr || per * splits > part_elems)) {
         splits = part ? (int)(part_elems / per) : 1;
         if (splits < 1) splits = 1;
@@ -149,8 +160,16 @@ static void run_gemm(bool is_f64, int engine, GemmArgs g, int want_splits, void*
     g.k_chunk = cdiv(ktiles, splits) * t.bk;
     splits = cdiv(g.K > 0 ? g.K : 1, g.k_chunk);
     g.part = part;
-    if (is_f64) launch_gemm_t<double>(engine, t, g, splits, relation, st);
-    else launch_gemm_t<float>(engine, t, g, splits, relation, st);
+    if (ty.c == SKF_F64 && ty.a == SKF_F64 && ty.b == SKF_F64)
+        launch_gemm_t<double, double, double>(engine, t, g, splits, relation, st);
+    else if (ty.c == SKF_F32 && ty.a == SKF_F32 && ty.b == SKF_F32)
+        launch_gemm_t<float, float, float>(engine, t, g, splits, relation, st);
+    else if (ty.c == SKF_F64 && ty.a == SKF_F32 && ty.b == SKF_F32)
+        launch_gemm_t<double, float, float>(engine, t, g, splits, relation, st);
+    else if (ty.c == SKF_F32 && ty.a == SKF_F32 && ty.b == SKF_F64)
+        launch_gemm_t<float, float, double>(engine, t, g, splits, relation, st);
+    else
+        SKF_FAIL(SKF_E_INVALID, "unsupported operand type combination (c=%d a=%d b=%d)", ty.c, ty.a, ty.b);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -193,7 +212,8 @@ struct ThetaState {
 struct skf_plan {
     int dtype = SKF_F32, variant = SKF_DFMF, target = -1, engine = SKF_ENGINE_MFMA;
     bool f64 = false;
-    size_t esz = 4;
+    size_t esz = 4;            // bytes of a master element (factors, E, D, P, Q, relations)
+    int mt = SKF_F32;          // master type code; the c x c algebra is always SKF_F64
     std::vector<skf::TypeState> types;
     std::vector<skf::RelState> rels;
     std::vector<skf::ThetaState> thetas;
@@ -202,7 +222,7 @@ struct skf_plan {
     bool bound = false, prepared = false, first_iter = true;
     // shared scratch
     skf::Slot part;            // split-K partials
-    size_t part_elems = 0;
+    size_t part_bytes = 0;
     skf::Slot eigA, eigV, eigVs, eigW, eigN, eigNorig, sqpart;
     int64_t eig_stride = 0;
     int eig_maxn = 0;
@@ -248,8 +268,21 @@ static GemmArgs gemm_args(const void* A, int64_t sa_m, int64_t sa_k, const void*
     return g;
 }
 
+// master x master -> master
 static void plan_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
-    run_gemm(p->f64, p->engine, g, 0, p->part.ptr, p->part_elems, st);
+    run_gemm(GemmTypes{p->mt, p->mt, p->mt}, p->engine, g, 0, p->part.ptr, p->part_bytes, st);
+}
+// c x c algebra: f64 x f64 -> f64
+static void small_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
+    run_gemm(GemmTypes{SKF_F64, SKF_F64, SKF_F64}, p->engine, g, 0, p->part.ptr, p->part_bytes, st);
+}
+// master x master -> f64 (Gram, G^T P: long f64 accumulation over the object dimension)
+static void wide_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
+    run_gemm(GemmTypes{SKF_F64, p->mt, p->mt}, p->engine, g, 0, p->part.ptr, p->part_bytes, st);
+}
+// master x f64 -> master (n x c x c products with an f64 backbone / B / D matrix)
+static void mixed_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
+    run_gemm(GemmTypes{p->mt, p->mt, SKF_F64}, p->engine, g, 0, p->part.ptr, p->part_bytes, st);
 }
 
 static hipEvent_t next_event(skf_plan* p) {
@@ -264,7 +297,7 @@ static hipEvent_t next_event(skf_plan* p) {
 // one of the two contractions that stream a relation matrix: P = R G_j or Q = R^T G_i
 static void relation_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
     if (p->profiling) SKF_HIP(hipEventRecord(next_event(p), st));
-    run_gemm(p->f64, p->engine, g, 0, p->part.ptr, p->part_elems, st, true);
+    run_gemm(GemmTypes{p->mt, p->mt, p->mt}, p->engine, g, 0, p->part.ptr, p->part_bytes, st, true);
     if (p->profiling) {
         SKF_HIP(hipEventRecord(next_event(p), st));
         p->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
@@ -281,12 +314,8 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
         const TypeState& t = p->types[which[b]];
         double* A = (double*)p->eigA.ptr + (int64_t)b * stride;
         const int total = t.n_pad * t.n_pad;
-        if (p->f64)
-            hipLaunchKernelGGL((eigh_pack_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, A, t.n_pad,
-                               (const double*)t.Gram.ptr, (int64_t)t.c, t.c);
-        else
-            hipLaunchKernelGGL((eigh_pack_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st, A, t.n_pad,
-                               (const float*)t.Gram.ptr, (int64_t)t.c, t.c);
+        hipLaunchKernelGGL((eigh_pack_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, A, t.n_pad,
+                           (const double*)t.Gram.ptr, (int64_t)t.c, t.c);
         check_launch("eigh_pack");
     }
     EighArgs e;
@@ -301,12 +330,8 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
         const double* Vs = (const double*)p->eigVs.ptr + (int64_t)b * stride;
         const double* V = (const double*)p->eigV.ptr + (int64_t)b * stride;
         const int total = t.c * t.c;
-        if (p->f64)
-            hipLaunchKernelGGL((eigh_unpack_pinv_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st,
-                               (double*)t.K.ptr, (int64_t)t.c, Vs, V, t.n_pad, t.c);
-        else
-            hipLaunchKernelGGL((eigh_unpack_pinv_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st,
-                               (float*)t.K.ptr, (int64_t)t.c, Vs, V, t.n_pad, t.c);
+        hipLaunchKernelGGL((eigh_unpack_pinv_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st,
+                           (double*)t.K.ptr, (int64_t)t.c, Vs, V, t.n_pad, t.c);
         check_launch("eigh_unpack");
     }
 }
@@ -314,7 +339,7 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
 static void gram(skf_plan* p, TypeState& t, int nan, hipStream_t st) {
     // Gram = G^T G : A = G^T (m-contiguous), B = G
     GemmArgs g = gemm_args(t.G.ptr, 1, t.c, t.G.ptr, t.c, 1, t.Gram.ptr, t.c, t.c, t.c, (int)t.n, EPI_STORE, nan);
-    plan_gemm(p, g, st);
+    wide_gemm(p, g, st);
 }
 
 static void mult_update(skf_plan* p, TypeState& t, hipStream_t st) {
@@ -351,18 +376,18 @@ static void relation_small_terms(skf_plan* p, RelState& r, int nan_upd, int epi_
     if (want_row) {
         // U = S Gram_j (ci x cj);  B = U S^T (ci x ci)          tmp2 of _dfmf.py:260
         GemmArgs g = gemm_args(r.S.ptr, cj, 1, tj.Gram.ptr, cj, 1, r.U.ptr, cj, ci, cj, cj, EPI_STORE, 0);
-        plan_gemm(p, g, st);
+        small_gemm(p, g, st);
         g = gemm_args(r.U.ptr, cj, 1, r.S.ptr, 1, cj, Bp, ci, ci, ci, cj, epi_split, nan_upd);
         g.C2 = Bn;
-        plan_gemm(p, g, st);
+        small_gemm(p, g, st);
     }
     if (want_col) {
         // U = Gram_i S (ci x cj);  D = S^T U (cj x cj)          tmp5 of _dfmf.py:272
         GemmArgs g = gemm_args(ti.Gram.ptr, ci, 1, r.S.ptr, cj, 1, r.U.ptr, cj, ci, cj, ci, EPI_STORE, 0);
-        plan_gemm(p, g, st);
+        small_gemm(p, g, st);
         g = gemm_args(r.S.ptr, 1, cj, r.U.ptr, cj, 1, Dp, cj, cj, cj, ci, epi_split, nan_upd);
         g.C2 = Dn;
-        plan_gemm(p, g, st);
+        small_gemm(p, g, st);
     }
 }
 
@@ -404,15 +429,15 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
         relation_gemm(p, g, st);
         // W = G_i^T P ; T1 = K_i W ; S = T1 K_j
         g = gemm_args(ti.G.ptr, 1, ci, r.P.ptr, cj, 1, r.W.ptr, cj, ci, cj, ni, EPI_STORE, 0);
-        plan_gemm(p, g, st);
+        wide_gemm(p, g, st);
         g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);
-        plan_gemm(p, g, st);
+        small_gemm(p, g, st);
         g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);
-        plan_gemm(p, g, st);
+        small_gemm(p, g, st);
         if (dfmc && r.mask) {
             // H = G_i S ; Rw[mask] = (H G_j^T)[mask] ; P = Rw G_j        (_dfmc.py:319-325)
             g = gemm_args(ti.G.ptr, ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, ni, cj, ci, EPI_STORE, 0);
-            plan_gemm(p, g, st);
+            mixed_gemm(p, g, st);
             g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rw.ptr, r.ldr, ni, nj, cj, EPI_MASKED_STORE, 0);
             g.mask = r.mask;
             g.ldmask = r.ldmask;
@@ -427,20 +452,20 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
         // E_i += (P S^T)+ ; D_i += (P S^T)-          (_dfmf.py:254-258, 278-279)
         g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, ti.E.ptr, ci, ni, ci, cj, EPI_SPLIT_ACC, nan_upd);
         g.C2 = ti.D.ptr;
-        plan_gemm(p, g, st);
+        mixed_gemm(p, g, st);
         // E_i += G_i B- ; D_i += G_i B+
         g = gemm_args(ti.G.ptr, ci, 1, r.Bn.ptr, ci, 1, ti.E.ptr, ci, ni, ci, ci, EPI_ACC, 0);
-        plan_gemm(p, g, st);
+        mixed_gemm(p, g, st);
         g = gemm_args(ti.G.ptr, ci, 1, r.Bp.ptr, ci, 1, ti.D.ptr, ci, ni, ci, ci, EPI_ACC, 0);
-        plan_gemm(p, g, st);
+        mixed_gemm(p, g, st);
         // E_j += (Q S)+ ; D_j += (Q S)-              (_dfmf.py:266-270, 281-282)
         g = gemm_args(r.Q.ptr, ci, 1, r.S.ptr, cj, 1, tj.E.ptr, cj, nj, cj, ci, EPI_SPLIT_ACC, nan_upd);
         g.C2 = tj.D.ptr;
-        plan_gemm(p, g, st);
+        mixed_gemm(p, g, st);
         g = gemm_args(tj.G.ptr, cj, 1, r.Dn.ptr, cj, 1, tj.E.ptr, cj, nj, cj, cj, EPI_ACC, 0);
-        plan_gemm(p, g, st);
+        mixed_gemm(p, g, st);
         g = gemm_args(tj.G.ptr, cj, 1, r.Dp.ptr, cj, 1, tj.D.ptr, cj, nj, cj, cj, EPI_ACC, 0);
-        plan_gemm(p, g, st);
+        mixed_gemm(p, g, st);
     }
     theta_terms(p, st);
     for (TypeState& t : p->types) mult_update(p, t, st);
@@ -464,7 +489,7 @@ static void prepare_transform(skf_plan* p, hipStream_t st) {
             relation_gemm(p, g, st);
             g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, tt.Ec.ptr, ci, ni, ci, cj, EPI_SPLIT_ACC, 0);
             g.C2 = tt.Dc.ptr;
-            plan_gemm(p, g, st);
+            mixed_gemm(p, g, st);
             relation_small_terms(p, r, 0, EPI_SPLIT_ACC, tt.Bp_tot.ptr, tt.Bn_tot.ptr, nullptr, nullptr, true,
                                  false, st);
         } else {                              // _dfmf.py:407-419
@@ -472,7 +497,7 @@ static void prepare_transform(skf_plan* p, hipStream_t st) {
             relation_gemm(p, g, st);
             g = gemm_args(r.Q.ptr, ci, 1, r.S.ptr, cj, 1, tt.Ec.ptr, cj, nj, cj, ci, EPI_SPLIT_ACC, 0);
             g.C2 = tt.Dc.ptr;
-            plan_gemm(p, g, st);
+            mixed_gemm(p, g, st);
             relation_small_terms(p, r, 0, EPI_SPLIT_ACC, nullptr, nullptr, tt.Bp_tot.ptr, tt.Bn_tot.ptr, false,
                                  true, st);
         }
@@ -486,9 +511,9 @@ static void iterate_transform(skf_plan* p, hipStream_t st) {
     SKF_HIP(hipMemcpyAsync(tt.E.ptr, tt.Ec.ptr, tt.E.bytes, hipMemcpyDeviceToDevice, st));
     SKF_HIP(hipMemcpyAsync(tt.D.ptr, tt.Dc.ptr, tt.D.bytes, hipMemcpyDeviceToDevice, st));
     GemmArgs g = gemm_args(tt.G.ptr, c, 1, tt.Bn_tot.ptr, c, 1, tt.E.ptr, c, n, c, c, EPI_ACC, 0);
-    plan_gemm(p, g, st);
+    mixed_gemm(p, g, st);
     g = gemm_args(tt.G.ptr, c, 1, tt.Bp_tot.ptr, c, 1, tt.D.ptr, c, n, c, c, EPI_ACC, 0);
-    plan_gemm(p, g, st);
+    mixed_gemm(p, g, st);
     theta_terms(p, st);
     mult_update(p, tt, st);
 }
@@ -523,6 +548,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         p->engine = opt->engine;
         p->f64 = (opt->dtype == SKF_F64);
         p->esz = p->f64 ? 8 : 4;
+        p->mt = p->f64 ? SKF_F64 : SKF_F32;
         p->target = opt->target_type;
         if (p->variant == SKF_TRANSFORM && (p->target < 0 || p->target >= n_types))
             SKF_FAIL(SKF_E_INVALID, "target type %d out of range", p->target);
@@ -565,40 +591,40 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             p->thetas[t].data = thetas[t].data;
             p->thetas[t].ld = thetas[t].ld;
         }
-        // ---- workspace layout
+        // ---- workspace layout: n-sized buffers in the master type, every c x c matrix in f64
         const size_t es = p->esz;
-        size_t part_elems = 0;
-        auto want_part = [&](int M, int N, int K) {
-            TileCfg t = pick_tile(p->f64, p->engine, M, N);
-            size_t need = (size_t)pick_splits(t, M, N, K) * (size_t)M * (size_t)N;
-            if (need > part_elems) part_elems = need;
+        size_t part_bytes = 0;
+        auto want_part = [&](int M, int N, int K, bool out_f64) {
+            TileCfg t = pick_tile(out_f64, p->engine, M, N);
+            size_t need = (size_t)pick_splits(t, M, N, K) * (size_t)M * (size_t)N * (out_f64 ? 8 : 4);
+            if (need > part_bytes) part_bytes = need;
         };
         int maxn = 2;
         for (int i = 0; i < n_types; ++i) {
             TypeState& t = p->types[i];
             const bool active = (p->variant != SKF_TRANSFORM) || i == p->target;
             add_slot(p, t.G, (size_t)t.n * t.c * es);
-            add_slot(p, t.Gram, (size_t)t.c * t.c * es);
-            want_part(t.c, t.c, (int)t.n);
+            add_slot(p, t.Gram, (size_t)t.c * t.c * 8);
+            want_part(t.c, t.c, (int)t.n, true);
             if (active) {
                 add_slot(p, t.E, (size_t)t.n * t.c * es);
                 add_slot(p, t.D, (size_t)t.n * t.c * es);
             }
             if (p->variant != SKF_TRANSFORM) {
-                add_slot(p, t.K, (size_t)t.c * t.c * es);
+                add_slot(p, t.K, (size_t)t.c * t.c * 8);
                 if (t.n_pad > maxn) maxn = t.n_pad;
             } else if (i == p->target) {
                 add_slot(p, t.Ec, (size_t)t.n * t.c * es);
                 add_slot(p, t.Dc, (size_t)t.n * t.c * es);
-                add_slot(p, t.Bp_tot, (size_t)t.c * t.c * es);
-                add_slot(p, t.Bn_tot, (size_t)t.c * t.c * es);
+                add_slot(p, t.Bp_tot, (size_t)t.c * t.c * 8);
+                add_slot(p, t.Bn_tot, (size_t)t.c * t.c * 8);
             }
         }
         size_t sq_elems = 1;
         for (RelState& r : p->rels) {
             TypeState& ti = p->types[r.row];
             TypeState& tj = p->types[r.col];
-            const size_t cc = (size_t)ti.c * tj.c * es;
+            const size_t cc = (size_t)ti.c * tj.c * 8;
             add_slot(p, r.S, cc);
             add_slot(p, r.U, cc);
             add_slot(p, r.H, (size_t)ti.n * tj.c * es);
@@ -607,23 +633,27 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             if (p->variant != SKF_TRANSFORM) {
                 add_slot(p, r.W, cc);
                 add_slot(p, r.T1, cc);
-                add_slot(p, r.Bp, (size_t)ti.c * ti.c * es);
-                add_slot(p, r.Bn, (size_t)ti.c * ti.c * es);
-                add_slot(p, r.Dp, (size_t)tj.c * tj.c * es);
-                add_slot(p, r.Dn, (size_t)tj.c * tj.c * es);
-                want_part(ti.c, tj.c, (int)ti.n);
+                add_slot(p, r.Bp, (size_t)ti.c * ti.c * 8);
+                add_slot(p, r.Bn, (size_t)ti.c * ti.c * 8);
+                add_slot(p, r.Dp, (size_t)tj.c * tj.c * 8);
+                add_slot(p, r.Dn, (size_t)tj.c * tj.c * 8);
+                want_part(ti.c, tj.c, (int)ti.n, true);
             }
             if (r.mask) add_slot(p, r.Rw, (size_t)ti.n * tj.n * es);
-            want_part((int)ti.n, tj.c, (int)tj.n);
-            want_part((int)tj.n, ti.c, (int)ti.n);
-            want_part((int)ti.n, ti.c, tj.c);
-            want_part((int)tj.n, tj.c, ti.c);
+            want_part((int)ti.n, tj.c, (int)tj.n, p->f64);
+            want_part((int)tj.n, ti.c, (int)ti.n, p->f64);
+            want_part((int)ti.n, ti.c, tj.c, p->f64);
+            want_part((int)tj.n, tj.c, ti.c, p->f64);
+            want_part(ti.c, tj.c, ti.c > tj.c ? ti.c : tj.c, true);
+            want_part(ti.c, ti.c, tj.c, true);
+            want_part(tj.c, tj.c, ti.c, true);
             size_t blocks = (size_t)cdiv(ti.n, 32) * cdiv(tj.n, 32);
             if (blocks > sq_elems) sq_elems = blocks;
         }
-        for (ThetaState& th : p->thetas) want_part((int)p->types[th.type].n, p->types[th.type].c, (int)p->types[th.type].n);
-        p->part_elems = part_elems;
-        add_slot(p, p->part, part_elems * es);
+        for (ThetaState& th : p->thetas)
+            want_part((int)p->types[th.type].n, p->types[th.type].c, (int)p->types[th.type].n, p->f64);
+        p->part_bytes = part_bytes;
+        add_slot(p, p->part, part_bytes);
         p->sq_elems = sq_elems;
         add_slot(p, p->sqpart, sq_elems * es);
         if (p->variant != SKF_TRANSFORM) {
@@ -718,7 +748,14 @@ int skf_set_backbone(skf_plan* p, int32_t rel, const void* S, int64_t ld, void* 
         RelState& r = p->rels[rel];
         const int ci = p->types[r.row].c, cj = p->types[r.col].c;
         if (ld < cj) SKF_FAIL(SKF_E_INVALID, "ld too small");
-        copy2d(r.S.ptr, cj, S, ld, ci, cj, p->esz, as_stream(stream));
+        if (p->f64) {
+            copy2d(r.S.ptr, cj, S, ld, ci, cj, 8, as_stream(stream));
+        } else {
+            hipLaunchKernelGGL((cast_kernel<double, float>), dim3(elem_grid((int64_t)ci * cj)), dim3(256), 0,
+                               as_stream(stream), (double*)r.S.ptr, (int64_t)cj, (const float*)S, ld, (int64_t)ci,
+                               (int64_t)cj);
+            check_launch("cast");
+        }
         r.s_set = true;
         p->prepared = false;
     });
@@ -731,7 +768,14 @@ int skf_get_backbone(const skf_plan* p, int32_t rel, void* S, int64_t ld, void* 
         const RelState& r = p->rels[rel];
         const int ci = p->types[r.row].c, cj = p->types[r.col].c;
         if (ld < cj) SKF_FAIL(SKF_E_INVALID, "ld too small");
-        copy2d(S, ld, r.S.ptr, cj, ci, cj, p->esz, as_stream(stream));
+        if (p->f64) {
+            copy2d(S, ld, r.S.ptr, cj, ci, cj, 8, as_stream(stream));
+        } else {
+            hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid((int64_t)ci * cj)), dim3(256), 0,
+                               as_stream(stream), (float*)S, ld, (const double*)r.S.ptr, (int64_t)cj, (int64_t)ci,
+                               (int64_t)cj);
+            check_launch("cast");
+        }
     });
 }
 
@@ -763,7 +807,7 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
         TypeState& tj = p->types[r.col];
         const int ni = (int)ti.n, nj = (int)tj.n, ci = ti.c, cj = tj.c;
         GemmArgs g = gemm_args(ti.G.ptr, ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, ni, cj, ci, EPI_STORE, 0);
-        plan_gemm(p, g, st);
+        mixed_gemm(p, g, st);
         g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, (void*)r.R, r.ldr, ni, nj, cj, EPI_SQDIFF, 0);
         g.C2 = p->sqpart.ptr;
         const TileCfg t = pick_tile(p->f64, p->engine, ni, nj);
@@ -822,8 +866,8 @@ int skf_gemm(int32_t dtype, int32_t engine, const skf_gemm_desc* d, void* worksp
         g.C2 = d->C2; g.ldc2 = d->ldc2 ? d->ldc2 : d->ldc;
         g.mask = d->mask; g.ldmask = d->ldmask;
         g.aop = d->aop;
-        const size_t es = dtype == SKF_F64 ? 8 : 4;
-        run_gemm(dtype == SKF_F64, engine, g, d->splits, workspace, workspace_bytes / es, as_stream(stream));
+        GemmTypes ty{dtype, d->a_dtype < 0 ? dtype : d->a_dtype, d->b_dtype < 0 ? dtype : d->b_dtype};
+        run_gemm(ty, engine, g, d->splits, workspace, workspace_bytes, as_stream(stream));
     });
 }
 

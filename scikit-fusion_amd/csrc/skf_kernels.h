@@ -145,8 +145,8 @@ template <> struct Mfma<double> {         // v_mfma_f64_16x16x4_f64: 4 f64 accum
 // ------------------------------------------------------------------------------------------
 constexpr int GEMM_THREADS = 256;
 
-template <typename T, int ROWS, int BK>
-__device__ __forceinline__ void stage_load(T (&reg)[ROWS * BK / GEMM_THREADS], const T* __restrict__ src,
+template <typename T, typename TS, int ROWS, int BK>
+__device__ __forceinline__ void stage_load(T (&reg)[ROWS * BK / GEMM_THREADS], const TS* __restrict__ src,
                                            int64_t s_row, int64_t s_k, int row0, int k0, int row_end,
                                            int k_end, int aop, int tid) {
     constexpr int PER = ROWS * BK / GEMM_THREADS;
@@ -158,7 +158,7 @@ __device__ __forceinline__ void stage_load(T (&reg)[ROWS * BK / GEMM_THREADS], c
         const int r = k_fast ? (e / BK) : (e % ROWS);
         const int gr = row0 + r, gk = k0 + k;
         T v = (T)0;
-        if (gr < row_end && gk < k_end) v = src[(int64_t)gr * s_row + (int64_t)gk * s_k];
+        if (gr < row_end && gk < k_end) v = (T)src[(int64_t)gr * s_row + (int64_t)gk * s_k];
         reg[i] = apply_aop(v, aop);
     }
 }
@@ -185,7 +185,10 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const T (&reg)[ROWS * 
 // TAG only changes the symbol name: TAG=1 instantiations are the two relation contractions
 // P = R G_j and Q = R^T G_i (the only launches that read R), so that profilers list the
 // dominant kernel separately from the small n x c x c products that share the code.
-template <typename T, int WR, int WC, int BK, int TAG>
+// T = arithmetic / output type (f32 or f64 MFMA); TA, TB = storage types of the operands (a f32
+// operand feeding an f64 contraction is widened while it is staged: Gram / G^T P in the f32
+// engine; an f64 backbone feeding an f32 contraction is narrowed the same way).
+template <typename T, typename TA, typename TB, int WR, int WC, int BK, int TAG>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
     typedef Mfma<T> MF;
     constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
@@ -199,8 +202,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
     const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
     const int kz0 = blockIdx.z * g.k_chunk;
     const int kz1 = (kz0 + g.k_chunk < g.K) ? kz0 + g.k_chunk : g.K;
-    const T* __restrict__ A = (const T*)g.A;
-    const T* __restrict__ B = (const T*)g.B;
+    const TA* __restrict__ A = (const TA*)g.A;
+    const TB* __restrict__ B = (const TB*)g.B;
     const bool a_kfast = (g.sa_k == 1), b_kfast = (g.sb_k == 1);
 
     typename MF::acc_t acc[WR][WC];
@@ -214,8 +217,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
     T ra[BM * BK / GEMM_THREADS], rb[BN * BK / GEMM_THREADS];
     const int nkt = (kz1 - kz0 + BK - 1) / BK;
     if (nkt > 0) {
-        stage_load<T, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, kz0, g.M, kz1, g.aop, tid);
-        stage_load<T, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, kz0, g.N, kz1, AOP_NONE, tid);
+        stage_load<T, TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, kz0, g.M, kz1, g.aop, tid);
+        stage_load<T, TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, kz0, g.N, kz1, AOP_NONE, tid);
         stage_store<T, BM, BK, LDA>(As, ra, a_kfast, tid);
         stage_store<T, BN, BK, LDB>(Bs, rb, b_kfast, tid);
     }
@@ -224,8 +227,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
         const bool more = (kt + 1 < nkt);
         if (more) {
             const int k0 = kz0 + (kt + 1) * BK;
-            stage_load<T, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, k0, g.M, kz1, g.aop, tid);
-            stage_load<T, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, k0, g.N, kz1, AOP_NONE, tid);
+            stage_load<T, TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, k0, g.M, kz1, g.aop, tid);
+            stage_load<T, TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, k0, g.N, kz1, AOP_NONE, tid);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += MF::KT) {
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------
 // vector-ALU GEMM with the same contract (64 x 64 block tile, 4 x 4 outputs per thread).
 // ------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, typename TA, typename TB>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_valu_kernel(GemmArgs g) {
     constexpr int BM = 64, BN = 64, BK = 16, LDT = BM + 1;
     __shared__ T As[BK][LDT];
@@ -297,8 +300,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_valu_kernel(GemmArgs g) {
     const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
     const int kz0 = blockIdx.z * g.k_chunk;
     const int kz1 = (kz0 + g.k_chunk < g.K) ? kz0 + g.k_chunk : g.K;
-    const T* __restrict__ A = (const T*)g.A;
-    const T* __restrict__ B = (const T*)g.B;
+    const TA* __restrict__ A = (const TA*)g.A;
+    const TB* __restrict__ B = (const TB*)g.B;
     const bool a_kfast = (g.sa_k == 1), b_kfast = (g.sb_k == 1);
     T acc[4][4];
 #pragma unroll
@@ -307,8 +310,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_valu_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (T)0;
     T ra[BM * BK / GEMM_THREADS], rb[BN * BK / GEMM_THREADS];
     for (int k0 = kz0; k0 < kz1; k0 += BK) {
-        stage_load<T, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, k0, g.M, kz1, g.aop, tid);
-        stage_load<T, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, k0, g.N, kz1, AOP_NONE, tid);
+        stage_load<T, TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, k0, g.M, kz1, g.aop, tid);
+        stage_load<T, TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, k0, g.N, kz1, AOP_NONE, tid);
         __syncthreads();
         stage_store<T, BM, BK, LDT>(As, ra, a_kfast, tid);
         stage_store<T, BN, BK, LDT>(Bs, rb, b_kfast, tid);

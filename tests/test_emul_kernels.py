@@ -17,11 +17,11 @@ def rt():
 
 
 def run_gemm(rt, dtype, engine, A, B, transA=False, transB=False, aop=0, epi=0, C0=None, C20=None,
-             mask=None, nan=0, splits=0):
+             mask=None, nan=0, splits=0, a_dtype=-1, b_dtype=-1):
     """C = epi(aop(op(A)) @ op(B)) through skf_gemm; A/B given as stored (row-major)."""
     npd = nat.NP_DTYPE[dtype]
-    A = np.ascontiguousarray(A, dtype=npd)
-    B = np.ascontiguousarray(B, dtype=npd)
+    A = np.ascontiguousarray(A, dtype=npd if a_dtype < 0 else nat.NP_DTYPE[a_dtype])
+    B = np.ascontiguousarray(B, dtype=npd if b_dtype < 0 else nat.NP_DTYPE[b_dtype])
     M, K = (A.shape[1], A.shape[0]) if transA else A.shape
     N = B.shape[0] if transB else B.shape[1]
     mem = rt.mem
@@ -36,6 +36,7 @@ def run_gemm(rt, dtype, engine, A, B, transA=False, transB=False, aop=0, epi=0, 
     d.ldc = d.ldc2 = N
     d.M, d.N, d.K = M, N, K
     d.aop, d.epi, d.nan_to_num, d.splits = aop, epi, nan, splits
+    d.a_dtype, d.b_dtype = a_dtype, b_dtype
     keep = None
     if mask is not None:
         keep = mem.from_host(np.ascontiguousarray(mask, dtype=np.uint8))
@@ -110,6 +111,26 @@ def test_gemm_split_k_and_nan_to_num(rt, dtype):
     assert np.isfinite(got).all()
     np.testing.assert_array_equal(got[2] == 0, ref[2] == 0)
     assert relerr(np.delete(got, [2, 4], axis=0), np.delete(ref, [2, 4], axis=0)) < tol
+
+
+@pytest.mark.parametrize('engine', [nat.SKF_ENGINE_MFMA, nat.SKF_ENGINE_VALU])
+def test_gemm_mixed_operand_types(rt, engine):
+    """f32 operands with f64 arithmetic (Gram / G^T P) and f32 x f64 -> f32 (P S^T, G B)."""
+    rs = np.random.RandomState(8)
+    G = rs.rand(900, 40).astype(np.float32)
+    P = rs.randn(900, 70).astype(np.float32)
+    got, _ = run_gemm(rt, nat.SKF_F64, engine, G, P, transA=True, a_dtype=nat.SKF_F32, b_dtype=nat.SKF_F32)
+    want = G.astype(np.float64).T @ P.astype(np.float64)
+    assert got.dtype == np.float64 and relerr(got, want) < 1e-14
+    S = rs.randn(40, 70)
+    got, _ = run_gemm(rt, nat.SKF_F32, engine, P, S, transB=True, a_dtype=nat.SKF_F32, b_dtype=nat.SKF_F64)
+    assert got.dtype == np.float32 and relerr(got, P.astype(np.float64) @ S.T) < 2e-6
+    lib = rt.lib
+    d = nat.GemmDesc()
+    d.A = d.B = d.C = 1
+    d.a_dtype, d.b_dtype = nat.SKF_F64, nat.SKF_F32
+    d.M = d.N = d.K = 4
+    assert lib.skf_gemm(nat.SKF_F32, engine, C.byref(d), None, 0, None) == -1
 
 
 def run_pinv(rt, dtype, A):
