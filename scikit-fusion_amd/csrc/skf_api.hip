@@ -15,6 +15,7 @@
 #include "skf_kernels.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -223,7 +224,7 @@ struct skf_plan {
     // shared scratch
     skf::Slot part;            // split-K partials
     size_t part_bytes = 0;
-    skf::Slot eigA, eigV, eigVs, eigW, eigN, eigNorig, sqpart;
+    skf::Slot eigA, eigV, eigVs, eigW, eigN, eigNorig, eigOk, sqpart;
     int64_t eig_stride = 0;
     int eig_maxn = 0;
     size_t sq_elems = 0;
@@ -305,6 +306,15 @@ static void relation_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
     }
 }
 
+// Relative pivot threshold of the Cholesky fast path: below it the Gram matrix goes to the
+// eigen-solver, which applies the exact singular-value cut-off.  SKF_PINV_JACOBI=1 forces the
+// eigen path (tests).
+static double chol_rel_threshold() {
+    const char* f = getenv("SKF_PINV_JACOBI");
+    if (f && atoi(f) != 0) return 1e300;
+    return 1e-8;
+}
+
 // K_i = pinv(Gram_i) for every type (one workgroup each); `which` = 0..n_types-1, the order
 // of the per-matrix order arrays uploaded once by skf_plan_bind_workspace.
 static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st) {
@@ -322,7 +332,20 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
     e.A = (double*)p->eigA.ptr; e.V = (double*)p->eigV.ptr; e.Vs = (double*)p->eigVs.ptr;
     e.w = (double*)p->eigW.ptr; e.stride = stride; e.wstride = p->eig_maxn;
     e.n = (const int*)p->eigN.ptr; e.n_orig = (const int*)p->eigNorig.ptr;
+    e.chol_ok = (int*)p->eigOk.ptr;
     e.max_sweeps = 30;
+    // fast path (Cholesky inverse) with an on-device verdict; the Jacobi eigen-solver only does
+    // work for the matrices the fast path rejected -- no host round trip either way
+    hipLaunchKernelGGL(chol_inverse_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), 0, st, e,
+                       chol_rel_threshold());
+    check_launch("chol_inverse");
+    for (size_t b = 0; b < which.size(); ++b) {
+        const TypeState& t = p->types[which[b]];
+        const double* X = (const double*)p->eigV.ptr + (int64_t)b * stride;
+        hipLaunchKernelGGL((chol_unpack_kernel<double>), dim3(elem_grid(t.c * t.c)), dim3(256), 0, st,
+                           (double*)t.K.ptr, (int64_t)t.c, X, t.n_pad, t.c, (const int*)p->eigOk.ptr + b);
+        check_launch("chol_unpack");
+    }
     hipLaunchKernelGGL(jacobi_eigh_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), 0, st, e);
     check_launch("jacobi_eigh");
     for (size_t b = 0; b < which.size(); ++b) {
@@ -331,7 +354,7 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
         const double* V = (const double*)p->eigV.ptr + (int64_t)b * stride;
         const int total = t.c * t.c;
         hipLaunchKernelGGL((eigh_unpack_pinv_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st,
-                           (double*)t.K.ptr, (int64_t)t.c, Vs, V, t.n_pad, t.c);
+                           (double*)t.K.ptr, (int64_t)t.c, Vs, V, t.n_pad, t.c, (const int*)p->eigOk.ptr + b);
         check_launch("eigh_unpack");
     }
 }
@@ -666,6 +689,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             add_slot(p, p->eigW, (size_t)maxn * n_types * sizeof(double));
             add_slot(p, p->eigN, (size_t)n_types * sizeof(int));
             add_slot(p, p->eigNorig, (size_t)n_types * sizeof(int));
+            add_slot(p, p->eigOk, (size_t)n_types * sizeof(int));
         }
         guard.p = nullptr;
         *out = p;
@@ -896,6 +920,7 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
         double* eW = (double*)(base + 3 * mat);
         int* eN = (int*)(base + 3 * mat + align_up((size_t)np * 8, 256));
         int* eNo = eN + 16;
+        int* eOk = eN + 32;
         const int total = np * np;
         if (dtype == SKF_F64)
             hipLaunchKernelGGL((eigh_pack_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, eA, np,
@@ -910,16 +935,25 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
         SKF_HIP(hipStreamSynchronize(st));
         EighArgs e;
         e.A = eA; e.V = eV; e.Vs = eVs; e.w = eW; e.stride = (int64_t)np * np; e.wstride = np;
-        e.n = eN; e.n_orig = eNo; e.max_sweeps = 30;
+        e.n = eN; e.n_orig = eNo; e.chol_ok = eOk; e.max_sweeps = 30;
+        const int tot2 = n * n;
+        hipLaunchKernelGGL(chol_inverse_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, e, chol_rel_threshold());
+        check_launch("chol_inverse");
+        if (dtype == SKF_F64)
+            hipLaunchKernelGGL((chol_unpack_kernel<double>), dim3(elem_grid(tot2)), dim3(256), 0, st, (double*)K, ldk,
+                               eV, np, n, eOk);
+        else
+            hipLaunchKernelGGL((chol_unpack_kernel<float>), dim3(elem_grid(tot2)), dim3(256), 0, st, (float*)K, ldk,
+                               eV, np, n, eOk);
+        check_launch("chol_unpack");
         hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, e);
         check_launch("jacobi_eigh");
-        const int tot2 = n * n;
         if (dtype == SKF_F64)
             hipLaunchKernelGGL((eigh_unpack_pinv_kernel<double>), dim3(elem_grid(tot2)), dim3(256), 0, st, (double*)K,
-                               ldk, eVs, eV, np, n);
+                               ldk, eVs, eV, np, n, eOk);
         else
             hipLaunchKernelGGL((eigh_unpack_pinv_kernel<float>), dim3(elem_grid(tot2)), dim3(256), 0, st, (float*)K,
-                               ldk, eVs, eV, np, n);
+                               ldk, eVs, eV, np, n, eOk);
         check_launch("eigh_unpack");
     });
 }

@@ -486,6 +486,7 @@ struct EighArgs {
     int64_t wstride;
     const int* n;     // per-matrix (padded, even) order
     const int* n_orig;
+    int* chol_ok;     // per matrix: 1 = the Cholesky fast path produced the inverse (Jacobi skips)
     int max_sweeps;
 };
 
@@ -513,6 +514,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) {
     __shared__ double red[EIGH_THREADS / 64];
     __shared__ double s_off, s_diag;
     const int b = blockIdx.x;
+    if (e.chol_ok[b]) return;                 // uniform: fast path already inverted this matrix
     const int n = e.n[b];
     const int tid = threadIdx.x, nt = blockDim.x;
     double* A = e.A + (int64_t)b * e.stride;
@@ -633,6 +635,93 @@ __global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fast path of the pseudo-inverse: a symmetric positive definite Gram matrix whose pivots stay
+// above rel_thr * max(diag) is inverted through its Cholesky factor (pinv == inverse when no
+// singular value falls under the cut-off).  One workgroup per matrix:
+//   L L^T = A   right-looking, column k staged in LDS, 2 barriers per column
+//   X = L^-1    one thread per column (forward substitution)
+// and chol_unpack_kernel forms K = X^T X on the whole grid.  A failed pivot test sets
+// chol_ok[b] = 0 and leaves the matrix to the Jacobi eigen-solver above (rank-deficient /
+// severely ill-conditioned Gram matrices, reference tests/test_n_run.py:14).
+// Scratch: L lives in e.Vs, X in e.V (both are only written by the Jacobi path afterwards).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_kernel(EighArgs e, double rel_thr) {
+    __shared__ double col[EIGH_MAXN];
+    __shared__ double red[EIGH_THREADS / 64];
+    __shared__ double s_max;
+    __shared__ int s_fail;
+    const int b = blockIdx.x;
+    const int n = e.n_orig[b], ld = e.n[b];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const double* A = e.A + (int64_t)b * e.stride;
+    double* L = e.Vs + (int64_t)b * e.stride;
+    double* X = e.V + (int64_t)b * e.stride;
+
+    double mx = 0.0;
+    for (int idx = tid; idx < n * n; idx += nt) {
+        const int r = idx / n, c = idx % n;
+        const double v = 0.5 * (A[r * ld + c] + A[c * ld + r]);
+        L[r * ld + c] = v;
+        X[r * ld + c] = 0.0;
+        if (r == c) mx = fmax(mx, fabs(v));
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nt / 64; ++i) s = fmax(s, red[i]);
+        s_max = s;
+    }
+    __syncthreads();
+    const double thr = rel_thr * s_max;
+
+    for (int k = 0; k < n; ++k) {
+        const double piv = L[k * ld + k];
+        if (!(piv > thr) || !(piv > 0.0)) {          // uniform: every thread reads the same word
+            if (tid == 0) e.chol_ok[b] = 0;
+            return;
+        }
+        const double d = sqrt(piv);
+        for (int i = k + tid; i < n; i += nt) col[i] = (i == k) ? d : L[i * ld + k] / d;
+        __syncthreads();
+        // write the finished column and update the trailing lower triangle
+        const int m = n - k - 1;
+        for (int i = k + tid; i < n; i += nt) L[i * ld + k] = col[i];
+        for (int idx = tid; idx < m * m; idx += nt) {
+            const int i = k + 1 + idx / m, j = k + 1 + idx % m;
+            if (j <= i) L[i * ld + j] -= col[i] * col[j];
+        }
+        __syncthreads();
+    }
+    // X = L^-1 (lower triangular), thread j owns column j
+    for (int j = tid; j < n; j += nt) {
+        X[j * ld + j] = 1.0 / L[j * ld + j];
+        for (int i = j + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int q = j; q < i; ++q) s += L[i * ld + q] * X[q * ld + j];
+            X[i * ld + j] = -s / L[i * ld + i];
+        }
+    }
+    if (tid == 0) e.chol_ok[b] = 1;
+}
+
+// K(r,c) = sum_{k >= max(r,c)} X(k,r) X(k,c)   (inverse from the inverted Cholesky factor)
+template <typename T>
+__global__ __launch_bounds__(256) void chol_unpack_kernel(T* __restrict__ K, int64_t ldk,
+                                                          const double* __restrict__ X, int ld, int n,
+                                                          const int* __restrict__ chol_ok) {
+    if (!chol_ok[0]) return;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
+        const int r = idx / n, c = idx % n;
+        double s = 0.0;
+        for (int k = (r > c ? r : c); k < n; ++k) s += X[k * ld + r] * X[k * ld + c];
+        K[(int64_t)r * ldk + c] = (T)s;
+    }
+}
+
 // pad / unpad helpers for the eigen workspace: dst (f64, n_pad x n_pad) <- src (T, n x n);
 // the padding row/column is decoupled (zero off-diagonal, zero diagonal -> eigenvalue 0).
 template <typename T>
@@ -648,7 +737,9 @@ __global__ __launch_bounds__(256) void eigh_pack_kernel(double* __restrict__ dst
 template <typename T>
 __global__ __launch_bounds__(256) void eigh_unpack_pinv_kernel(T* __restrict__ K, int64_t ldk,
                                                                const double* __restrict__ Vs,
-                                                               const double* __restrict__ V, int n_pad, int n) {
+                                                               const double* __restrict__ V, int n_pad, int n,
+                                                               const int* __restrict__ chol_ok) {
+    if (chol_ok[0]) return;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
         const int r = idx / n, c = idx % n;
         double s = 0.0;

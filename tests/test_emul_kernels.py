@@ -146,15 +146,22 @@ def run_pinv(rt, dtype, A):
 
 
 @pytest.mark.parametrize('n', [1, 2, 5, 10, 31, 50])
-def test_pinv_full_rank_matches_scipy(rt, n):
+def test_pinv_full_rank_matches_scipy(rt, n, monkeypatch=None):
+    """Both routes: Cholesky fast path (default) and the Jacobi eigen-solver (forced)."""
+    import os
     import scipy.linalg as spla
     rs = np.random.RandomState(n)
     G = rs.rand(4 * n + 3, n)
     A = G.T @ G
-    got = run_pinv(rt, nat.SKF_F64, A)
     want = spla.pinv(A)
-    assert relerr(got, want) < 1e-9 * max(1.0, np.linalg.cond(A) * 1e-3)
-    assert relerr(A @ got @ A, A) < 1e-11
+    for force_jacobi in ('0', '1'):
+        os.environ['SKF_PINV_JACOBI'] = force_jacobi
+        try:
+            got = run_pinv(rt, nat.SKF_F64, A)
+        finally:
+            os.environ.pop('SKF_PINV_JACOBI', None)
+        assert relerr(got, want) < 1e-9 * max(1.0, np.linalg.cond(A) * 1e-3), force_jacobi
+        assert relerr(A @ got @ A, A) < 1e-11
 
 
 def test_pinv_rank_deficient_truncates_like_scipy(rt):
