@@ -86,7 +86,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'f64', 'bf16'])
+    ap.add_argument('--dtype', default='bf16', choices=['f32', 'f64', 'bf16'])
     ap.add_argument('--scale', type=float, default=1.0, help='linear scale of the object counts')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -112,6 +112,10 @@ def main():
     n = sizes(args.scale)
     rels = [(i, j, fill_uniform((n[i], n[j]), s, args.dtype), None) for i, j, s in PAIRS]
     plan = DevicePlan(TYPES, n, RANKS, rels, [], nat.SKF_DFMF, dtype=args.dtype)
+    if args.dtype == 'bf16':          # the plan keeps its own padded bf16 copies of R and R^T
+        del rels[:]
+        plan._keep = []
+        torch.cuda.empty_cache()
     for k, t in enumerate(TYPES):      # one random restart per rank: G0 seed depends on the rank
         plan.set_factor(t, fill_uniform((n[t], RANKS[t]), 100 + 10 * rank + k, MASTER[args.dtype]))
 
@@ -163,7 +167,7 @@ def main():
             'rmse': rmse,
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': None,
-                         'kernel': 'relation contractions P=R*G_j, Q=R^T*G_i (gemm_mfma_kernel<..,TAG=1>)',
+                         'kernel': 'relation contractions P=R*G_j, Q=R^T*G_i (%s)' % ('gemm_bf16_kernel<BN,1>' if args.dtype == 'bf16' else 'gemm_mfma_kernel<..,TAG=1>'),
                          'launches': int(k_launches),
                          'avg_launch_ms': k_ms / k_launches if k_launches else None,
                          'alg_flops_per_launch': k_flops / k_launches if k_launches else None,

@@ -56,7 +56,9 @@ typedef struct {
 
 typedef struct {
     int32_t row_type, col_type; /* indices into the type array; row_type != col_type */
-    const void* data;           /* n_row x n_col, engine dtype (R[(i,j)][l], dfmf.py:82-85) */
+    const void* data;           /* n_row x n_col, engine dtype (R[(i,j)][l], dfmf.py:82-85);
+                                   SKF_BF16: bf16 (uint16) data, copied (padded + transposed)
+                                   at bind time and not referenced afterwards */
     int64_t ld;
     const uint8_t* mask;        /* DFMC only: n_row x n_col bytes, !=0 = unknown entry
                                    (M[(i,j)][l], dfmc.py:77-90); NULL = no mask */
@@ -149,6 +151,19 @@ typedef struct {
 /* C = epi(aop(A) * B) on the matrix cores; `dtype` = arithmetic and result type (f64 / f32). */
 int skf_gemm(int32_t dtype, int32_t engine, const skf_gemm_desc* desc, void* workspace,
              size_t workspace_bytes, void* stream);
+
+/* bf16 relation contraction C[M x N] (f32) = A[M x Kp] * Bt[N x Kp]^T, both operands bf16,
+ * row-major and K-contiguous, Kp a multiple of 64 with zero-filled padding, lda/ldb multiples of
+ * 8 and 16-byte aligned bases (v_mfma_f32_16x16x32_bf16, f32 accumulation).  `splits` = 0 lets
+ * the library choose the K slicing; >1 needs a workspace of splits*M*N floats. */
+int skf_gemm_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, float* C, int64_t ldc,
+                  int32_t M, int32_t N, int32_t Kp, int32_t splits, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* dst (bf16, ld ldd) = round-to-nearest-even(src) or its transpose; src dtype SKF_F64 / SKF_F32 /
+ * SKF_BF16.  Padding columns of dst are left untouched (zero them beforehand). */
+int skf_to_bf16(void* dst, int64_t ldd, int32_t src_dtype, const void* src, int64_t lds,
+                int64_t rows, int64_t cols, int32_t transpose, void* stream);
 
 /* K = pinv(A) for symmetric A (n x n): f64 Jacobi eigen-decomposition + the singular-value
  * cut-off of scipy.linalg.pinv (reference _dfmf.py:232, _dfmc.py:307). */

@@ -62,7 +62,9 @@ class DevicePlan(object):
                 arr = np.ascontiguousarray(data, dtype=self.np_dtype)
                 if arr.ndim != 2:
                     raise ValueError('relation %d is not a matrix' % k)
-                buf, ld = mem.from_host(arr), arr.shape[1]
+                # SKF_BF16: relations are handed over as bf16 bit patterns
+                up = nat.to_bf16_bits(arr) if self.dtype == nat.SKF_BF16 else arr
+                buf, ld = mem.from_host(up), arr.shape[1]
             if tuple(arr.shape) != (n_obj[i], n_obj[j]):
                 raise ValueError('relation (%s,%s) dimension mismatch: %r vs object counts (%d,%d)'
                                  % (i, j, tuple(arr.shape), n_obj[i], n_obj[j]))

@@ -16,8 +16,19 @@ SKF_F64, SKF_F32, SKF_BF16 = 0, 1, 2
 SKF_DFMF, SKF_DFMC, SKF_TRANSFORM = 0, 1, 2
 SKF_ENGINE_MFMA, SKF_ENGINE_VALU = 0, 1
 
-DTYPES = {'f64': SKF_F64, 'f32': SKF_F32, 'float64': SKF_F64, 'float32': SKF_F32}
-NP_DTYPE = {SKF_F64: np.float64, SKF_F32: np.float32}
+DTYPES = {'f64': SKF_F64, 'f32': SKF_F32, 'bf16': SKF_BF16, 'float64': SKF_F64, 'float32': SKF_F32}
+NP_DTYPE = {SKF_F64: np.float64, SKF_F32: np.float32, SKF_BF16: np.float32}   # dtype of the masters
+
+
+def to_bf16_bits(a):
+    """float array -> uint16 bf16 bit patterns (round to nearest even), host side."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u >> 16) & 1) + np.uint32(0x7FFF)
+    return ((u + r) >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b):
+    return (np.asarray(b, dtype=np.uint32) << 16).view(np.float32)
 
 LIB_NAME = 'libskfusion_hip.so'
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', LIB_NAME)
@@ -76,6 +87,9 @@ SIGNATURES = {
     'skf_plan_set_profiling': (C.c_int, [_P, C.c_int32]),
     'skf_plan_get_profile': (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'skf_gemm': (C.c_int, [C.c_int32, C.c_int32, C.POINTER(GemmDesc), _P, C.c_size_t, _P]),
+    'skf_gemm_bf16': (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_int32, _P, C.c_size_t, _P]),
+    'skf_to_bf16': (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _P]),
     'skf_pinv_sym_workspace_bytes': (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     'skf_pinv_sym': (C.c_int, [C.c_int32, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
     'skf_fill_uniform': (C.c_int, [C.c_int32, _P, C.c_int64, C.c_int64, C.c_int64, C.c_uint64,

@@ -173,6 +173,84 @@ static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void
         SKF_FAIL(SKF_E_INVALID, "unsupported operand type combination (c=%d a=%d b=%d)", ty.c, ty.a, ty.b);
 }
 
+// ---- bf16 relation contraction --------------------------------------------------------------
+static inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
+
+// K slices for the bf16 contraction: equal work units over the 256 CUs (x resident workgroups)
+// finish in ceil(units/slots) rounds; pick the split that wastes the least of the last round,
+// charging a little for the partial-sum traffic of every extra slice.
+static int pick_splits_bf16(int64_t units, int ktiles) {
+    const double slots = 256.0 * 2.0;          // 2 resident 256-thread workgroups per CU
+    int best = 1;
+    double best_eff = -1.0;
+    for (int s = 1; s <= 32; ++s) {
+        if (s > 1 && ktiles / s < 8) break;
+        const double w = (double)units * s / slots;
+        const double rounds = (double)(int64_t)(w + 0.999999);
+        const double eff = w / (rounds < 1.0 ? 1.0 : rounds) - 0.004 * (s - 1);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best = s;
+        }
+    }
+    return best;
+}
+
+static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, int64_t ldb, float* C, int64_t ldc,
+                          int M, int N, int Kp, int want_splits, void* part, size_t part_bytes, bool relation,
+                          hipStream_t st) {
+    if (M <= 0 || N <= 0) return;
+    if (Kp % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || lda < Kp || ldb < Kp)
+        SKF_FAIL(SKF_E_INVALID, "bf16 contraction: inner dimension must be padded to 64 (Kp=%d lda=%lld ldb=%lld)", Kp,
+                 (long long)lda, (long long)ldb);
+    if ((((uintptr_t)A) | ((uintptr_t)Bt)) & 15) SKF_FAIL(SKF_E_INVALID, "bf16 operands must be 16-byte aligned");
+    const int bn = (N <= 128) ? 128 : 256;
+    const int ktiles = Kp / 64;
+    const int64_t units = (int64_t)cdiv(M, 128) * cdiv(N, bn);
+    int splits = want_splits > 0 ? want_splits : pick_splits_bf16(units, ktiles);
+    const size_t per = (size_t)M * N * sizeof(float);
+    if (splits > 1 && (!part || per * splits > part_bytes)) splits = part ? (int)(part_bytes / per) : 1;
+    if (splits < 1) splits = 1;
+    if (splits > ktiles) splits = ktiles > 0 ? ktiles : 1;
+    Bf16GemmArgs g;
+    g.A = A; g.Bt = Bt; g.C = C; g.part = (float*)part;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.M = M; g.N = N; g.Kp = Kp;
+    g.k_chunk = cdiv(ktiles > 0 ? ktiles : 1, splits) * 64;
+    splits = cdiv(Kp > 0 ? Kp : 1, g.k_chunk);
+    dim3 grid(cdiv(N, bn), cdiv(M, 128), splits), block(256);
+    if (bn == 128 && relation) hipLaunchKernelGGL((gemm_bf16_kernel<128, 1>), grid, block, 0, st, g);
+    else if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, 0>), grid, block, 0, st, g);
+    else if (relation) hipLaunchKernelGGL((gemm_bf16_kernel<256, 1>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<256, 0>), grid, block, 0, st, g);
+    check_launch("gemm_bf16");
+    if (splits > 1) {
+        hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3(elem_grid((int64_t)M * N)), dim3(256), 0, st, C, ldc,
+                           (const float*)part, M, N, splits);
+        check_launch("bf16_splitk_reduce");
+    }
+}
+
+static size_t bf16_part_bytes(int M, int N, int Kp) {
+    const int bn = (N <= 128) ? 128 : 256;
+    const int s = pick_splits_bf16((int64_t)cdiv(M, 128) * cdiv(N, bn), Kp / 64);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+template <typename TS>
+static void launch_to_bf16(uint16_t* dst, int64_t ldd, const TS* src, int64_t lds, int64_t rows, int64_t cols,
+                           bool transpose, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return;
+    if (transpose) {
+        dim3 grid((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32));
+        hipLaunchKernelGGL((transpose_to_bf16_kernel<TS>), grid, dim3(256), 0, st, dst, ldd, src, lds, rows, cols);
+    } else {
+        hipLaunchKernelGGL((to_bf16_kernel<TS>), dim3(elem_grid(rows * cols)), dim3(256), 0, st, dst, ldd, src, lds,
+                           rows, cols);
+    }
+    check_launch("to_bf16");
+}
+
 // ------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------
@@ -187,6 +265,8 @@ struct TypeState {
     int n_pad = 0;                 // eigen order (even)
     Slot G, E, D, Gram, K;
     Slot Bp_tot, Bn_tot, Ec, Dc;   // SKF_TRANSFORM target only
+    Slot GTb;                      // SKF_BF16: bf16 transpose of G, [c][pad64(n)], zero padded
+    int64_t ldgt = 0;
     bool set = false;
 };
 
@@ -199,6 +279,8 @@ struct RelState {
     const void* R = nullptr;       // matrix the iteration reads (R_in or the DFMC working copy)
     int64_t ldr = 0;
     Slot Rw, P, Q, W, T1, S, U, Bp, Bn, Dp, Dn, H;
+    Slot Rb, RTb;                  // SKF_BF16: padded bf16 copies of R and R^T
+    int64_t ldrb = 0, ldrtb = 0;
     bool s_set = false;
 };
 
@@ -212,7 +294,7 @@ struct ThetaState {
 
 struct skf_plan {
     int dtype = SKF_F32, variant = SKF_DFMF, target = -1, engine = SKF_ENGINE_MFMA;
-    bool f64 = false;
+    bool f64 = false, bf16 = false;
     size_t esz = 4;            // bytes of a master element (factors, E, D, P, Q, relations)
     int mt = SKF_F32;          // master type code; the c x c algebra is always SKF_F64
     std::vector<skf::TypeState> types;
@@ -296,14 +378,31 @@ static hipEvent_t next_event(skf_plan* p) {
 }
 
 // one of the two contractions that stream a relation matrix: P = R G_j or Q = R^T G_i
-static void relation_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
+static void relation_gemm(skf_plan* p, GemmArgs g, hipStream_t st, const RelState* r = nullptr, bool is_q = false) {
     if (p->profiling) SKF_HIP(hipEventRecord(next_event(p), st));
-    run_gemm(GemmTypes{p->mt, p->mt, p->mt}, p->engine, g, 0, p->part.ptr, p->part_bytes, st, true);
+    if (p->bf16) {
+        const TypeState& ti = p->types[r->row];
+        const TypeState& tj = p->types[r->col];
+        if (!is_q)      // P = R G_j :  A = R (bf16), Bt = G_j^T (bf16)
+            run_gemm_bf16((const uint16_t*)r->Rb.ptr, r->ldrb, (const uint16_t*)tj.GTb.ptr, tj.ldgt, (float*)g.C,
+                          g.ldc, g.M, g.N, (int)r->ldrb, 0, p->part.ptr, p->part_bytes, true, st);
+        else            // Q = R^T G_i :  A = stored R^T (bf16), Bt = G_i^T (bf16)
+            run_gemm_bf16((const uint16_t*)r->RTb.ptr, r->ldrtb, (const uint16_t*)ti.GTb.ptr, ti.ldgt, (float*)g.C,
+                          g.ldc, g.M, g.N, (int)r->ldrtb, 0, p->part.ptr, p->part_bytes, true, st);
+    } else {
+        run_gemm(GemmTypes{p->mt, p->mt, p->mt}, p->engine, g, 0, p->part.ptr, p->part_bytes, st, true);
+    }
     if (p->profiling) {
         SKF_HIP(hipEventRecord(next_event(p), st));
         p->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
         p->prof_launches += 1;
     }
+}
+
+// SKF_BF16: refresh the bf16 transpose of a factor after it changed
+static void refresh_gt(skf_plan* p, TypeState& t, hipStream_t st) {
+    if (!p->bf16) return;
+    launch_to_bf16<float>((uint16_t*)t.GTb.ptr, t.ldgt, (const float*)t.G.ptr, (int64_t)t.c, t.n, (int64_t)t.c, true, st);
 }
 
 // Relative pivot threshold of the Cholesky fast path: below it the Gram matrix goes to the
@@ -449,7 +548,7 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
         const int ni = (int)ti.n, nj = (int)tj.n, ci = ti.c, cj = tj.c;
         // P = R G_j
         GemmArgs g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
-        relation_gemm(p, g, st);
+        relation_gemm(p, g, st, &r, false);
         // W = G_i^T P ; T1 = K_i W ; S = T1 K_j
         g = gemm_args(ti.G.ptr, 1, ci, r.P.ptr, cj, 1, r.W.ptr, cj, ci, cj, ni, EPI_STORE, 0);
         wide_gemm(p, g, st);
@@ -466,11 +565,11 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
             g.ldmask = r.ldmask;
             plan_gemm(p, g, st);
             g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
-            relation_gemm(p, g, st);
+            relation_gemm(p, g, st, &r, false);
         }
         // Q = R^T G_i
         g = gemm_args(r.R, 1, r.ldr, ti.G.ptr, ci, 1, r.Q.ptr, ci, nj, ci, ni, EPI_STORE, 0);
-        relation_gemm(p, g, st);
+        relation_gemm(p, g, st, &r, true);
         relation_small_terms(p, r, nan_upd, EPI_SPLIT_STORE, r.Bp.ptr, r.Bn.ptr, r.Dp.ptr, r.Dn.ptr, true, true, st);
         // E_i += (P S^T)+ ; D_i += (P S^T)-          (_dfmf.py:254-258, 278-279)
         g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, ti.E.ptr, ci, ni, ci, cj, EPI_SPLIT_ACC, nan_upd);
@@ -491,7 +590,10 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
         mixed_gemm(p, g, st);
     }
     theta_terms(p, st);
-    for (TypeState& t : p->types) mult_update(p, t, st);
+    for (TypeState& t : p->types) {
+        mult_update(p, t, st);
+        refresh_gt(p, t, st);
+    }
 }
 
 // SKF_TRANSFORM: everything that does not depend on G_target is computed once.
@@ -560,8 +662,12 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         if (!out || !types || !opt || n_types <= 0) SKF_FAIL(SKF_E_INVALID, "null argument / no object types");
         if (n_relations < 0 || n_thetas < 0 || (n_relations > 0 && !relations) || (n_thetas > 0 && !thetas))
             SKF_FAIL(SKF_E_INVALID, "bad relation / constraint arrays");
-        if (opt->dtype != SKF_F64 && opt->dtype != SKF_F32)
-            SKF_FAIL(SKF_E_INVALID, "dtype %d not supported by this build (SKF_F64, SKF_F32)", opt->dtype);
+        if (opt->dtype != SKF_F64 && opt->dtype != SKF_F32 && opt->dtype != SKF_BF16)
+            SKF_FAIL(SKF_E_INVALID, "unknown dtype %d", opt->dtype);
+        if (opt->dtype == SKF_BF16 && opt->variant != SKF_DFMF)
+            SKF_FAIL(SKF_E_INVALID, "SKF_BF16 is implemented for SKF_DFMF only (use SKF_F32 for DFMC / fold-in)");
+        if (opt->dtype == SKF_BF16 && opt->engine != SKF_ENGINE_MFMA)
+            SKF_FAIL(SKF_E_INVALID, "SKF_BF16 needs the MFMA engine");
         if (opt->variant < SKF_DFMF || opt->variant > SKF_TRANSFORM) SKF_FAIL(SKF_E_INVALID, "bad variant");
         if (opt->engine != SKF_ENGINE_MFMA && opt->engine != SKF_ENGINE_VALU) SKF_FAIL(SKF_E_INVALID, "bad engine");
         skf_plan* p = new skf_plan();
@@ -570,6 +676,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         p->variant = opt->variant;
         p->engine = opt->engine;
         p->f64 = (opt->dtype == SKF_F64);
+        p->bf16 = (opt->dtype == SKF_BF16);
         p->esz = p->f64 ? 8 : 4;
         p->mt = p->f64 ? SKF_F64 : SKF_F32;
         p->target = opt->target_type;
@@ -628,6 +735,10 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             const bool active = (p->variant != SKF_TRANSFORM) || i == p->target;
             add_slot(p, t.G, (size_t)t.n * t.c * es);
             add_slot(p, t.Gram, (size_t)t.c * t.c * 8);
+            if (p->bf16) {
+                t.ldgt = pad64(t.n);
+                add_slot(p, t.GTb, (size_t)t.c * t.ldgt * 2);
+            }
             want_part(t.c, t.c, (int)t.n, true);
             if (active) {
                 add_slot(p, t.E, (size_t)t.n * t.c * es);
@@ -663,6 +774,15 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 want_part(ti.c, tj.c, (int)ti.n, true);
             }
             if (r.mask) add_slot(p, r.Rw, (size_t)ti.n * tj.n * es);
+            if (p->bf16) {
+                r.ldrb = pad64(tj.n);
+                r.ldrtb = pad64(ti.n);
+                add_slot(p, r.Rb, (size_t)ti.n * r.ldrb * 2);
+                add_slot(p, r.RTb, (size_t)tj.n * r.ldrtb * 2);
+                size_t b1 = bf16_part_bytes((int)ti.n, tj.c, (int)r.ldrb), b2 = bf16_part_bytes((int)tj.n, ti.c, (int)r.ldrtb);
+                if (b1 > part_bytes) part_bytes = b1;
+                if (b2 > part_bytes) part_bytes = b2;
+            }
             want_part((int)ti.n, tj.c, (int)tj.n, p->f64);
             want_part((int)tj.n, ti.c, (int)ti.n, p->f64);
             want_part((int)ti.n, ti.c, tj.c, p->f64);
@@ -722,6 +842,20 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             r.R = r.Rw.ptr;
             r.ldr = cols;
         }
+        if (p->bf16) {
+            // the caller's bf16 relation is copied into a zero-padded layout and transposed once;
+            // it is not referenced after this call
+            for (TypeState& t : p->types) SKF_HIP(hipMemsetAsync(t.GTb.ptr, 0, t.GTb.bytes, st));
+            for (RelState& r : p->rels) {
+                const int64_t rows = p->types[r.row].n, cols = p->types[r.col].n;
+                SKF_HIP(hipMemsetAsync(r.Rb.ptr, 0, r.Rb.bytes, st));
+                SKF_HIP(hipMemsetAsync(r.RTb.ptr, 0, r.RTb.bytes, st));
+                launch_to_bf16<uint16_t>((uint16_t*)r.Rb.ptr, r.ldrb, (const uint16_t*)r.R_in, r.ld_in, rows, cols, false, st);
+                launch_to_bf16<uint16_t>((uint16_t*)r.RTb.ptr, r.ldrtb, (const uint16_t*)r.R_in, r.ld_in, rows, cols, true, st);
+                r.R = r.Rb.ptr;
+                r.ldr = r.ldrb;
+            }
+        }
         if (p->variant != SKF_TRANSFORM) {
             std::vector<int> n_pad, n_orig;
             for (TypeState& t : p->types) {
@@ -750,6 +884,7 @@ int skf_set_factor(skf_plan* p, int32_t type, const void* G, int64_t ld, void* s
         TypeState& t = p->types[type];
         if (ld < t.c) SKF_FAIL(SKF_E_INVALID, "ld %lld < rank %d", (long long)ld, t.c);
         copy2d(t.G.ptr, t.c, G, ld, t.n, t.c, p->esz, as_stream(stream));
+        refresh_gt(p, t, as_stream(stream));
         t.set = true;
         p->prepared = false;
     });
@@ -834,6 +969,7 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
         mixed_gemm(p, g, st);
         g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, (void*)r.R, r.ldr, ni, nj, cj, EPI_SQDIFF, 0);
         g.C2 = p->sqpart.ptr;
+        g.c_bf16 = p->bf16 ? 1 : 0;
         const TileCfg t = pick_tile(p->f64, p->engine, ni, nj);
         const int blocks = cdiv(ni, t.bm) * cdiv(nj, t.bn);
         plan_gemm(p, g, st);
@@ -892,6 +1028,27 @@ int skf_gemm(int32_t dtype, int32_t engine, const skf_gemm_desc* d, void* worksp
         g.aop = d->aop;
         GemmTypes ty{dtype, d->a_dtype < 0 ? dtype : d->a_dtype, d->b_dtype < 0 ? dtype : d->b_dtype};
         run_gemm(ty, engine, g, d->splits, workspace, workspace_bytes, as_stream(stream));
+    });
+}
+
+int skf_gemm_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
+                  int32_t Kp, int32_t splits, void* workspace, size_t workspace_bytes, void* stream) {
+    return guarded([&] {
+        if (!A || !Bt || !C || M < 0 || N < 0 || Kp < 0 || ldc < N) SKF_FAIL(SKF_E_INVALID, "bad argument");
+        run_gemm_bf16((const uint16_t*)A, lda, (const uint16_t*)Bt, ldb, C, ldc, M, N, Kp, splits, workspace,
+                      workspace_bytes, false, as_stream(stream));
+    });
+}
+
+int skf_to_bf16(void* dst, int64_t ldd, int32_t src_dtype, const void* src, int64_t lds, int64_t rows, int64_t cols,
+                int32_t transpose, void* stream) {
+    return guarded([&] {
+        if (!dst || !src || rows < 0 || cols < 0) SKF_FAIL(SKF_E_INVALID, "bad argument");
+        hipStream_t st = as_stream(stream);
+        if (src_dtype == SKF_F64) launch_to_bf16<double>((uint16_t*)dst, ldd, (const double*)src, lds, rows, cols, transpose != 0, st);
+        else if (src_dtype == SKF_F32) launch_to_bf16<float>((uint16_t*)dst, ldd, (const float*)src, lds, rows, cols, transpose != 0, st);
+        else if (src_dtype == SKF_BF16) launch_to_bf16<uint16_t>((uint16_t*)dst, ldd, (const uint16_t*)src, lds, rows, cols, transpose != 0, st);
+        else SKF_FAIL(SKF_E_INVALID, "bad source dtype");
     });
 }
 

@@ -51,6 +51,7 @@ struct GemmArgs {
     int M, N, K;
     int k_chunk;             // K range handled by one z-slice
     int aop, epi, nan_to_num;
+    int c_bf16;              // EPI_SQDIFF: the matrix behind C is stored as bf16
 };
 
 // ------------------------------------------------------------------------------------------
@@ -59,6 +60,12 @@ struct GemmArgs {
 template <typename T> struct Lim;
 template <> struct Lim<float> { static __device__ __host__ float big() { return 3.40282346638528859812e+38f; } };
 template <> struct Lim<double> { static __device__ __host__ double big() { return 1.79769313486231570815e+308; } };
+
+__device__ __host__ __forceinline__ float bf16_to_f32(uint16_t h) {
+    union { uint32_t u; float f; } x;
+    x.u = (uint32_t)h << 16;
+    return x.f;
+}
 
 // numpy.nan_to_num: NaN -> 0, +inf -> largest finite, -inf -> most negative finite
 template <typename T>
@@ -267,7 +274,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
                     if (split) {
                         ((T*)g.part)[((int64_t)blockIdx.z * g.M + m) * g.N + n] = v;
                     } else if (g.epi == EPI_SQDIFF) {
-                        const T d = ((const T*)g.C)[(int64_t)m * g.ldc + n] - v;
+                        const int64_t ci = (int64_t)m * g.ldc + n;
+                        const T rv = g.c_bf16 ? (T)bf16_to_f32(((const uint16_t*)g.C)[ci]) : ((const T*)g.C)[ci];
+                        const T d = rv - v;
                         sq += d * d;
                     } else {
                         epilogue_store<T>(g, m, n, v);
@@ -341,7 +350,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_valu_kernel(GemmArgs g) {
                 if (split) {
                     ((T*)g.part)[((int64_t)blockIdx.z * g.M + m) * g.N + n] = v;
                 } else if (g.epi == EPI_SQDIFF) {
-                    const T d = ((const T*)g.C)[(int64_t)m * g.ldc + n] - v;
+                    const int64_t ci = (int64_t)m * g.ldc + n;
+                    const T rv = g.c_bf16 ? (T)bf16_to_f32(((const uint16_t*)g.C)[ci]) : ((const T*)g.C)[ci];
+                    const T d = rv - v;
                     sq += d * d;
                 } else {
                     epilogue_store<T>(g, m, n, v);
@@ -358,6 +369,144 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_valu_kernel(GemmArgs g) {
             for (int w = 0; w < GEMM_THREADS / 64; ++w) s += red[w];
             ((T*)g.C2)[blockIdx.y * gridDim.x + blockIdx.x] = s;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 relation contraction (the MFMA-roofline kernel of the SKF_BF16 engine):
+//     C[M x N] (f32) = A[M x Kp] (bf16, row-major) * Bt[N x Kp]^T (bf16, row-major)
+// i.e. both operands K-contiguous: A = R (for P = R G_j) or the stored transpose R^T (for
+// Q = R^T G_i), Bt = the bf16 transpose G^T of a factor.  Kp (the padded inner dimension) is a
+// multiple of 64 and the padding is zero-filled by the engine, so the K loop has no tail.
+//
+// Workgroup: 256 threads = 4 waves (2 x 2); block tile 128 x BN (BN = 128 or 256: the whole
+// factor rank in one tile, so R streams from HBM exactly once), K tile 64.
+// v_mfma_f32_16x16x32_bf16: lane l holds A[row = l&15][k = 8*(l>>4) .. +7] -- eight consecutive
+// K elements = one 16-byte LDS read.  LDS tiles are [rows][64] bf16 (128-byte rows, no padding)
+// with the 16-byte chunk index XOR-swizzled by (row & 7): conflict-free ds_read_b128 for the
+// fragment pattern and conflict-free ds_write_b128 for the staging pattern (8 consecutive
+// lanes fill one row).  Global loads are 16 B per lane, 128 B contiguous per row.
+// One K step: [global loads of tile t+1 in flight] 2 x {fragment reads, MFMAs} | barrier |
+//             registers -> LDS | barrier.
+// ------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Bf16GemmArgs {
+    const uint16_t* A;     // [M][lda]
+    const uint16_t* Bt;    // [N][ldb]
+    float* C;              // [M][ldc]           (gridDim.z == 1)
+    float* part;           // [gridDim.z][M][N]  (split-K partials otherwise)
+    int64_t lda, ldb, ldc;
+    int M, N, Kp;          // Kp % 64 == 0
+    int k_chunk;           // K range per z-slice, multiple of 64
+};
+
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return row * 8 + (chunk ^ (row & 7)); }
+
+template <int BN, int TAG>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16GemmArgs g) {
+    constexpr int BM = 128, BK = 64;
+    constexpr int WN = BN / 2;              // wave tile 64 x WN
+    constexpr int NJ = WN / 16;             // 16-wide column blocks per wave
+    constexpr int A_PER = BM * 8 / 256;     // 16-byte chunks per thread and tile
+    constexpr int B_PER = BN * 8 / 256;
+    __shared__ u32x4 As[BM * 8];
+    __shared__ u32x4 Bs[BN * 8];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * WN;
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    const int kz0 = blockIdx.z * g.k_chunk;
+    const int kz1 = (kz0 + g.k_chunk < g.Kp) ? kz0 + g.k_chunk : g.Kp;
+    const int nkt = (kz1 - kz0) / BK;
+    const int srow = tid >> 3, schunk = tid & 7;        // staging: 8 lanes per 128-byte row
+
+    f32x4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[A_PER], rb[B_PER];
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) {
+            const int m = bm0 + srow + 32 * p;
+            ra[p] = (m < g.M) ? *(const u32x4*)(g.A + (int64_t)m * g.lda + k0 + schunk * 8) : zero;
+        }
+#pragma unroll
+        for (int p = 0; p < B_PER; ++p) {
+            const int n = bn0 + srow + 32 * p;
+            rb[p] = (n < g.N) ? *(const u32x4*)(g.Bt + (int64_t)n * g.ldb + k0 + schunk * 8) : zero;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) As[swz_chunk(srow + 32 * p, schunk)] = ra[p];
+#pragma unroll
+        for (int p = 0; p < B_PER; ++p) Bs[swz_chunk(srow + 32 * p, schunk)] = rb[p];
+    };
+
+    if (nkt > 0) {
+        load_tiles(kz0);
+        store_tiles();
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1 < nkt);
+        if (more) load_tiles(kz0 + (kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = 4 * ks + (lane >> 4);
+            bf16x8 a[4], b[NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) store_tiles();
+        __syncthreads();
+    }
+
+    // epilogue: D reg r of a 16 x 16 tile -> row = 4*(lane>>4) + r, col = lane & 15
+    float* out = (gridDim.z > 1) ? g.part + (int64_t)blockIdx.z * g.M * g.N : g.C;
+    const int64_t ldo = (gridDim.z > 1) ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = bm0 + wm0 + i * 16 + 4 * (lane >> 4) + r;
+                const int n = bn0 + wn0 + j * 16 + (lane & 15);
+                if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc[i][j][r];
+            }
+}
+
+// split-K second stage of the bf16 contraction: C = sum_z part[z]  (fixed order)
+__global__ __launch_bounds__(256) void bf16_splitk_reduce_kernel(float* __restrict__ C, int64_t ldc,
+                                                                 const float* __restrict__ part, int M, int N,
+                                                                 int splits) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += part[(int64_t)z * total + e];
+        C[(e / N) * ldc + (e % N)] = v;
     }
 }
 
@@ -452,6 +601,44 @@ __global__ __launch_bounds__(256) void cast_kernel(TD* __restrict__ dst, int64_t
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / cols, c = e % cols;
         dst[r * ldd + c] = (TD)src[r * lds + c];
+    }
+}
+
+template <typename TS> __device__ __forceinline__ uint16_t to_bf16(TS v) { return f32_to_bf16_rne((float)v); }
+template <> __device__ __forceinline__ uint16_t to_bf16<uint16_t>(uint16_t v) { return v; }
+
+// dst[r][c] = bf16(src[r][c]); dst's padding columns are zeroed beforehand by the caller
+template <typename TS>
+__global__ __launch_bounds__(256) void to_bf16_kernel(uint16_t* __restrict__ dst, int64_t ldd,
+                                                      const TS* __restrict__ src, int64_t lds, int64_t rows,
+                                                      int64_t cols) {
+    const int64_t total = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / cols, c = e % cols;
+        dst[r * ldd + c] = to_bf16<TS>(src[r * lds + c]);
+    }
+}
+
+// dst[c][r] = bf16(src[r][c])  -- transposed bf16 copy through a 32 x 32 LDS tile (coalesced
+// reads and writes).  grid = (ceil(cols/32), ceil(rows/32)), 256 threads.
+template <typename TS>
+__global__ __launch_bounds__(256) void transpose_to_bf16_kernel(uint16_t* __restrict__ dst, int64_t ldd,
+                                                                const TS* __restrict__ src, int64_t lds,
+                                                                int64_t rows, int64_t cols) {
+    __shared__ uint16_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < rows && c < cols) ? to_bf16<TS>(src[r * lds + c]) : (uint16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < cols && r < rows) dst[c * ldd + r] = tile[tx][ty + 8 * k];
     }
 }
 

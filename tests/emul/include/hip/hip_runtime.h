@@ -358,6 +358,12 @@ inline simt_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, simt_
     return d;
 }
 
+typedef __bf16 simt_bf16x8 __attribute__((ext_vector_type(8)));
+inline simt_f32x4 simt_mfma_f32_16x16x32_bf16(simt_s16x8 a, simt_s16x8 b, simt_f32x4 c);
+inline simt_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(simt_bf16x8 a, simt_bf16x8 b, simt_f32x4 c, int, int, int) {
+    return simt_mfma_f32_16x16x32_bf16(__builtin_bit_cast(simt_s16x8, a), __builtin_bit_cast(simt_s16x8, b), c);
+}
+
 // bf16 operands are passed as 8 raw 16-bit patterns per lane
 inline simt_f32x4 simt_mfma_f32_16x16x32_bf16(simt_s16x8 a, simt_s16x8 b, simt_f32x4 c) {
     struct AB { simt_s16x8 a, b; } mine{a, b};

@@ -137,6 +137,37 @@ def test_c2_dicty_first_iteration_f64():
         assert relerr(G[t, t], Go[t, t]) < 1e-9
 
 
+def test_bf16_engine_against_oracle_on_bf16_rounded_relations():
+    """SKF_BF16: bf16 R / R^T / G^T feed the relation contractions, everything else as the f32
+    engine.  Oracle run on the bf16-rounded relations (exactly representable in f64) so that
+    only the arithmetic differs; tolerance on the reconstruction RMSE: 1e-2 relative
+    (SURVEY.md 8d), on G: 2e-2."""
+    R, types, rank = readme_graph()
+    Rb = {k: [nat.from_bf16_bits(nat.to_bf16_bits(v[0])).astype(np.float64)] for k, v in R.items()}
+    z = golden('c1_readme_dfmf.npz')
+    G0 = g0_from(z, 'random/', types)
+    G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=8, G0=G0, dtype='bf16')
+    Go, So = orc.dfmf(Rb, {}, types, rank, max_iter=8, G0=G0)
+    for t in types:
+        assert relerr(G[t, t], Go[t, t]) < 2e-2
+    e, eo = orc.relation_errors(Rb, G, S), orc.relation_errors(Rb, Go, So)
+    for k in e:
+        assert abs(e[k][0] - eo[k][0]) / eo[k][0] < 1e-2
+    from skfusion_amd._engine import DevicePlan, flatten_relations
+    rel = flatten_relations(R)
+    plan = DevicePlan(types, {'t1': 50, 't2': 100, 't3': 40}, rank, rel, [], nat.SKF_DFMF, dtype='bf16')
+    for t in types:
+        plan.set_factor(t, G0[t, t])
+    plan.iterate(2)
+    Gd = {(t, t): plan.get_factor(t) for t in types}
+    for k, (i, j, Rm, _) in enumerate(rel):
+        want = np.linalg.norm(Rb[i, j][0] - Gd[i, i] @ plan.get_backbone(k) @ Gd[j, j].T) ** 2
+        assert abs(plan.relation_sqerr(k) - want) < 1e-4 * want
+    plan.close()
+    with pytest.raises(nat.SkfNativeError):
+        _dfmc.dfmc(R, {k: [None] for k in R}, {}, types, rank, max_iter=1, G0=G0, dtype='bf16')
+
+
 def test_relation_sqerr_and_stopping_path():
     R, types, rank = readme_graph()
     z = golden('c1_readme_dfmf.npz')

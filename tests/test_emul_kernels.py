@@ -133,6 +133,52 @@ def test_gemm_mixed_operand_types(rt, engine):
     assert lib.skf_gemm(nat.SKF_F32, engine, C.byref(d), None, 0, None) == -1
 
 
+def run_gemm_bf16(rt, A, B, splits=0):
+    """C = A @ B with bf16 operands through skf_gemm_bf16 (A: M x K, B: K x N given as floats)."""
+    M, K = A.shape
+    N = B.shape[1]
+    Kp = (K + 63) // 64 * 64
+    Ab = np.zeros((M, Kp), np.uint16)
+    Ab[:, :K] = nat.to_bf16_bits(A)
+    Bb = np.zeros((N, Kp), np.uint16)
+    Bb[:, :K] = nat.to_bf16_bits(B.T)
+    a, b = rt.mem.from_host(Ab), rt.mem.from_host(Bb)
+    c = rt.mem.empty(M * N * 4)
+    ws = rt.mem.empty(40 * M * N * 4 + 256)
+    rt.call('skf_gemm_bf16', a.ptr, Kp, b.ptr, Kp, c.ptr, N, M, N, Kp, splits, ws.ptr, ws.nbytes, None)
+    got = rt.mem.to_host(c, (M, N), np.float32)
+    want = nat.from_bf16_bits(Ab[:, :K]).astype(np.float64) @ nat.from_bf16_bits(Bb[:, :K]).astype(np.float64).T
+    return got, want
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1), (16, 16, 32), (128, 128, 64), (130, 100, 70), (257, 128, 200),
+                                   (100, 256, 129), (200, 200, 500), (129, 300, 64)])
+def test_gemm_bf16_contraction(rt, shape):
+    M, N, K = shape
+    rs = np.random.RandomState(M + N + K)
+    A, B = rs.randn(M, K), rs.randn(K, N)           # asymmetric operands
+    for splits in (0, 1, 3):
+        got, want = run_gemm_bf16(rt, A, B, splits)
+        assert relerr(got, want) < 2e-6, splits        # exact bf16 products, f32 accumulation
+
+
+def test_to_bf16_and_transpose(rt):
+    rs = np.random.RandomState(2)
+    X = rs.randn(70, 45)
+    for src_dtype, npd in ((nat.SKF_F64, np.float64), (nat.SKF_F32, np.float32)):
+        src = rt.mem.from_host(X.astype(npd))
+        dst = rt.mem.from_host(np.zeros((70, 64), np.uint16))
+        rt.call('skf_to_bf16', dst.ptr, 64, src_dtype, src.ptr, 45, 70, 45, 0, None)
+        got = rt.mem.to_host(dst, (70, 64), np.uint16)
+        np.testing.assert_array_equal(got[:, :45], nat.to_bf16_bits(X.astype(npd)))
+        assert (got[:, 45:] == 0).all()
+        dstT = rt.mem.from_host(np.zeros((45, 128), np.uint16))
+        rt.call('skf_to_bf16', dstT.ptr, 128, src_dtype, src.ptr, 45, 70, 45, 1, None)
+        gotT = rt.mem.to_host(dstT, (45, 128), np.uint16)
+        np.testing.assert_array_equal(gotT[:, :70], nat.to_bf16_bits(X.astype(npd)).T)
+        assert (gotT[:, 70:] == 0).all()
+
+
 def run_pinv(rt, dtype, A):
     npd = nat.NP_DTYPE[dtype]
     n = A.shape[0]
