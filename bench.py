@@ -144,6 +144,14 @@ def main():
         rmse['%s-%s' % (i, j)] = float(np.sqrt(plan.relation_sqerr(k) / (n[i] * n[j])))
 
     if rank == 0:
+        traffic = None          # HBM bytes per launch from the separate PMC passes (profiles/)
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
+                t = json.load(fh).get(args.dtype)
+            if t and args.scale == 1.0:
+                traffic = t['fetch_bytes_per_launch'] + t['write_bytes_per_launch']
+        except Exception:
+            traffic = None
         achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
         out = {
@@ -166,7 +174,8 @@ def main():
                        'alg_flops_per_iter': alg_flops(n)},
             'rmse': rmse,
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': None,
+                         'frac': achieved / peak, 'traffic': traffic,
+                         'traffic_note': 'HBM bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) measured by rocprofv3 --pmc in a separate pass, profiles/pmc_traffic.json; algorithmic = one read of the bf16 relation',
                          'kernel': 'relation contractions P=R*G_j, Q=R^T*G_i (%s)' % ('gemm_bf16_kernel<BN,1>' if args.dtype == 'bf16' else 'gemm_mfma_kernel<..,TAG=1>'),
                          'launches': int(k_launches),
                          'avg_launch_ms': k_ms / k_launches if k_launches else None,

@@ -1,23 +1,18 @@
-"""Summarise rocprofv3 --pmc counter_collection CSVs: per kernel name, sum / mean of a counter."""
-import csv
-import glob
-import os
+"""Per-kernel mean/sum of the PMC counters in rocprofv3 rocpd databases (one counter per pass)."""
+import re
+import sqlite3
 import sys
-from collections import defaultdict
 
 
-def summarise(d):
-    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
-        acc = defaultdict(lambda: defaultdict(list))
-        with open(f) as fh:
-            for row in csv.DictReader(fh):
-                name = row.get('Kernel_Name', '?')[:90]
-                acc[name][row.get('Counter_Name', '?')].append(float(row.get('Counter_Value', 0)))
-        print('#', f)
-        for name, cs in sorted(acc.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values()))[:12]:
-            for c, vals in cs.items():
-                print('%-90s %-12s n=%-5d mean=%.6g sum=%.6g' % (name, c, len(vals), sum(vals) / len(vals), sum(vals)))
+def short(name):
+    return re.sub(r'\(.*$', '', name).replace('skf::', '').replace('void ', '')[:70]
 
 
-for d in sys.argv[1:]:
-    summarise(d)
+for path in sys.argv[1:]:
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), sum(value), avg(grid_size_x) "
+                       "from counters_collection group by kernel_name, counter_name order by 5 desc").fetchall()
+    print('#', path)
+    print('%-70s %-12s %6s %16s %16s' % ('kernel', 'counter', 'calls', 'mean', 'sum'))
+    for name, cname, n, mean, tot, _ in rows[:14]:
+        print('%-70s %-12s %6d %16.6g %16.6g' % (short(name), cname, n, mean, tot))
