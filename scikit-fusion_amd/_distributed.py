@@ -1,0 +1,47 @@
+"""Sharding of the independent random restarts (``n_run``) over the GPUs of a node.
+
+The reference ships every restart to a joblib worker process (``dfmf.py:87-95``,
+``dfmc.py:96-104``, ``dfmf.py:191-199``).  Here the unit of parallelism is one process per GPU
+(launched with ``python -m torch.distributed.run``): restart ``k`` runs on rank ``k % world``,
+every rank keeps its relations resident on its own GPU, and there is **no collective on the data
+path** -- only the fitted ``(G, S)`` of each run are exchanged once at the end
+(``all_gather_object``; backend ``nccl`` = RCCL on ROCm, ``gloo`` on CPU for tests).
+Single-process use (no process group) degenerates to "all runs here".
+"""
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return None
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def world():
+    """(rank, world_size) of the default process group, (0, 1) without one."""
+    d = _dist()
+    return (d.get_rank(), d.get_world_size()) if d else (0, 1)
+
+
+def my_runs(n_run):
+    """Indices of the restarts this rank computes (round robin)."""
+    rank, size = world()
+    return [k for k in range(n_run) if k % size == rank]
+
+
+def gather_runs(local, n_run):
+    """``local``: {run index: result} computed by this rank -> list of all results in run order,
+    identical on every rank."""
+    d = _dist()
+    if d is None:
+        return [local[k] for k in range(n_run)]
+    parts = [None] * d.get_world_size()
+    d.all_gather_object(parts, local)
+    merged = {}
+    for part in parts:
+        merged.update(part)
+    missing = [k for k in range(n_run) if k not in merged]
+    if missing:
+        raise RuntimeError('restarts %r were not computed by any rank' % missing)
+    return [merged[k] for k in range(n_run)]

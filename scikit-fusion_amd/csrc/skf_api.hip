@@ -513,6 +513,37 @@ static void relation_small_terms(skf_plan* p, RelState& r, int nan_upd, int epi_
     }
 }
 
+// Fused E/D update of one relation side (MFMA engine): E (+)= (X Sop)+ + G Bn, D (+)= (X Sop)- + G Bp
+static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const void* Sop, int64_t ss_k, int64_t ss_n,
+                        TypeState& t, const void* Bn, const void* Bp, bool accumulate, int nan, hipStream_t st) {
+    SideArgs a;
+    a.X = X; a.Sop = Sop; a.G = t.G.ptr; a.Bn = Bn; a.Bp = Bp; a.E = t.E.ptr; a.D = t.D.ptr;
+    a.ldx = ldx; a.ss_k = ss_k; a.ss_n = ss_n; a.ldg = t.c; a.ldb = t.c; a.lde = t.c;
+    a.n = (int)t.n; a.c = t.c; a.k1 = k1;
+    a.accumulate = accumulate ? 1 : 0;
+    a.nan_to_num = nan;
+    const bool big = (t.n > 64 && t.c > 64);
+    dim3 block(GEMM_THREADS);
+    if (p->f64) {
+        if (big) {
+            dim3 grid(cdiv(t.c, 64), cdiv(t.n, 64));
+            hipLaunchKernelGGL((side_update_kernel<double, double, 2, 2, 16>), grid, block, 0, st, a);
+        } else {
+            dim3 grid(cdiv(t.c, 32), cdiv(t.n, 32));
+            hipLaunchKernelGGL((side_update_kernel<double, double, 1, 1, 16>), grid, block, 0, st, a);
+        }
+    } else {
+        if (big) {
+            dim3 grid(cdiv(t.c, 128), cdiv(t.n, 128));
+            hipLaunchKernelGGL((side_update_kernel<float, double, 2, 2, 32>), grid, block, 0, st, a);
+        } else {
+            dim3 grid(cdiv(t.c, 64), cdiv(t.n, 64));
+            hipLaunchKernelGGL((side_update_kernel<float, double, 1, 1, 32>), grid, block, 0, st, a);
+        }
+    }
+    check_launch("side_update");
+}
+
 static void iterate_fit(skf_plan* p, hipStream_t st) {
     const bool dfmc = (p->variant == SKF_DFMC);
     const int nan_upd = dfmc ? 0 : 1;       // _update_G_for_Rij (_dfmc.py:127-178) has no nan_to_num
@@ -532,12 +563,19 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
     }
     p->first_iter = false;
 
+    const bool fused = (p->engine == SKF_ENGINE_MFMA);
     std::vector<int> all;
+    std::vector<char> touched(p->types.size(), 0);     // E/D of the type already written this iteration
     for (size_t i = 0; i < p->types.size(); ++i) {
         TypeState& t = p->types[i];
         gram(p, t, 1, st);
-        SKF_HIP(hipMemsetAsync(t.E.ptr, 0, t.E.bytes, st));
-        SKF_HIP(hipMemsetAsync(t.D.ptr, 0, t.D.bytes, st));
+        bool has_rel = false;
+        for (RelState& r : p->rels) has_rel = has_rel || r.row == (int)i || r.col == (int)i;
+        if (!fused || !has_rel) {          // the fused update overwrites E/D on first touch
+            SKF_HIP(hipMemsetAsync(t.E.ptr, 0, t.E.bytes, st));
+            SKF_HIP(hipMemsetAsync(t.D.ptr, 0, t.D.bytes, st));
+            touched[i] = 1;
+        }
         all.push_back((int)i);
     }
     plan_pinv(p, all, st);
@@ -571,6 +609,14 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
         g = gemm_args(r.R, 1, r.ldr, ti.G.ptr, ci, 1, r.Q.ptr, ci, nj, ci, ni, EPI_STORE, 0);
         relation_gemm(p, g, st, &r, true);
         relation_small_terms(p, r, nan_upd, EPI_SPLIT_STORE, r.Bp.ptr, r.Bn.ptr, r.Dp.ptr, r.Dn.ptr, true, true, st);
+        if (fused) {
+            // row side: A = P S^T (Sop(k,j) = S[j][k]);  column side: C = Q S
+            side_update(p, r.P.ptr, cj, cj, r.S.ptr, 1, cj, ti, r.Bn.ptr, r.Bp.ptr, touched[r.row] != 0, nan_upd, st);
+            touched[r.row] = 1;
+            side_update(p, r.Q.ptr, ci, ci, r.S.ptr, cj, 1, tj, r.Dn.ptr, r.Dp.ptr, touched[r.col] != 0, nan_upd, st);
+            touched[r.col] = 1;
+            continue;
+        }
         // E_i += (P S^T)+ ; D_i += (P S^T)-          (_dfmf.py:254-258, 278-279)
         g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, ti.E.ptr, ci, ni, ci, cj, EPI_SPLIT_ACC, nan_upd);
         g.C2 = ti.D.ptr;

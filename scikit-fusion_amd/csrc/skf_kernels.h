@@ -297,6 +297,152 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused accumulator update of ONE relation side (reference _dfmf.py:254-264 + 278-279, or
+// :266-276 + 281-282 for the column side):
+//     A = X * Sop            X = P (n x k1) with Sop = S^T,  or  X = Q with Sop = S
+//     E (+)= max(A,0) + G * Bn        D (+)= max(-A,0) + G * Bp
+// in one pass over E / D: three MFMA contractions share one output tile.  accE first holds A,
+// is split in registers into (A+, A-) and then both halves keep accumulating G*Bn / G*Bp (the
+// MFMA C-operand), so E and D are written exactly once (read only when `accumulate`).
+// X, G, E, D are T (the master type); Sop, Bn, Bp are TB (f64 c x c matrices).
+// ------------------------------------------------------------------------------------------
+struct SideArgs {
+    const void* X;      // [n][ldx], k1 columns
+    const void* Sop;    // B(k, j) = Sop[k*ss_k + j*ss_n], k < k1, j < c
+    const void* G;      // [n][ldg], c columns
+    const void* Bn;     // [c][ldb]
+    const void* Bp;     // [c][ldb]
+    void* E;            // [n][lde]
+    void* D;
+    int64_t ldx, ss_k, ss_n, ldg, ldb, lde;
+    int n, c, k1;
+    int accumulate;     // 0: E/D are overwritten (first contribution of the iteration)
+    int nan_to_num;     // numpy.nan_to_num on A before the split (DFMF only)
+};
+
+template <typename T, typename TB, int WR, int WC, int BK>
+__global__ __launch_bounds__(GEMM_THREADS) void side_update_kernel(SideArgs a) {
+    typedef Mfma<T> MF;
+    constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
+    constexpr int LDA = BM + 1, LDB = BN + 1;
+    __shared__ T As[BK][LDA];
+    __shared__ T Bs[BK][LDB];
+    __shared__ T Bs2[BK][LDB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * (WR * MF::MT), wn0 = (wave & 1) * (WC * MF::NT);
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+
+    typename MF::acc_t accE[WR][WC], accD[WR][WC];
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int j = 0; j < WC; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) accE[i][j][r] = (T)0;
+
+    T ra[BM * BK / GEMM_THREADS], rb[BN * BK / GEMM_THREADS], rb2[BN * BK / GEMM_THREADS];
+
+    // ---- phase 1: accE = X * Sop
+    {
+        const T* X = (const T*)a.X;
+        const TB* S = (const TB*)a.Sop;
+        const bool s_kfast = (a.ss_k == 1);
+        for (int k0 = 0; k0 < a.k1; k0 += BK) {
+            stage_load<T, T, BM, BK>(ra, X, a.ldx, 1, bm0, k0, a.n, a.k1, AOP_NONE, tid);
+            stage_load<T, TB, BN, BK>(rb, S, a.ss_n, a.ss_k, bn0, k0, a.c, a.k1, AOP_NONE, tid);
+            __syncthreads();
+            stage_store<T, BM, BK, LDA>(As, ra, true, tid);
+            stage_store<T, BN, BK, LDB>(Bs, rb, s_kfast, tid);
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += MF::KT) {
+                T av[WR], bv[WC];
+                const int kr = kk + MF::ab_k(lane);
+#pragma unroll
+                for (int i = 0; i < WR; ++i) av[i] = As[kr][wm0 + i * MF::MT + MF::a_row(lane)];
+#pragma unroll
+                for (int j = 0; j < WC; ++j) bv[j] = Bs[kr][wn0 + j * MF::NT + MF::a_row(lane)];
+#pragma unroll
+                for (int i = 0; i < WR; ++i)
+#pragma unroll
+                    for (int j = 0; j < WC; ++j) accE[i][j] = MF::mma(av[i], bv[j], accE[i][j]);
+            }
+        }
+    }
+    // ---- split A into (A+, A-)
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int j = 0; j < WC; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) {
+                T v = accE[i][j][r];
+                if (a.nan_to_num) v = nan_to_num(v);
+                accE[i][j][r] = v > (T)0 ? v : (T)0;
+                accD[i][j][r] = v > (T)0 ? (T)0 : -v;
+            }
+    // ---- phase 2: accE += G * Bn ; accD += G * Bp   (one staging of the G tile feeds both)
+    {
+        const T* G = (const T*)a.G;
+        const TB* Bn = (const TB*)a.Bn;
+        const TB* Bp = (const TB*)a.Bp;
+        for (int k0 = 0; k0 < a.c; k0 += BK) {
+            stage_load<T, T, BM, BK>(ra, G, a.ldg, 1, bm0, k0, a.n, a.c, AOP_NONE, tid);
+            stage_load<T, TB, BN, BK>(rb, Bn, 1, a.ldb, bn0, k0, a.c, a.c, AOP_NONE, tid);
+            stage_load<T, TB, BN, BK>(rb2, Bp, 1, a.ldb, bn0, k0, a.c, a.c, AOP_NONE, tid);
+            __syncthreads();
+            stage_store<T, BM, BK, LDA>(As, ra, true, tid);
+            stage_store<T, BN, BK, LDB>(Bs, rb, a.ldb == 1, tid);
+            stage_store<T, BN, BK, LDB>(Bs2, rb2, a.ldb == 1, tid);
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += MF::KT) {
+                T av[WR], bv[WC], bv2[WC];
+                const int kr = kk + MF::ab_k(lane);
+#pragma unroll
+                for (int i = 0; i < WR; ++i) av[i] = As[kr][wm0 + i * MF::MT + MF::a_row(lane)];
+#pragma unroll
+                for (int j = 0; j < WC; ++j) {
+                    bv[j] = Bs[kr][wn0 + j * MF::NT + MF::a_row(lane)];
+                    bv2[j] = Bs2[kr][wn0 + j * MF::NT + MF::a_row(lane)];
+                }
+#pragma unroll
+                for (int i = 0; i < WR; ++i)
+#pragma unroll
+                    for (int j = 0; j < WC; ++j) {
+                        accE[i][j] = MF::mma(av[i], bv[j], accE[i][j]);
+                        accD[i][j] = MF::mma(av[i], bv2[j], accD[i][j]);
+                    }
+            }
+        }
+    }
+    // ---- epilogue
+    T* E = (T*)a.E;
+    T* D = (T*)a.D;
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int j = 0; j < WC; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) {
+                const int m = bm0 + wm0 + i * MF::MT + MF::d_row(lane, r);
+                const int n = bn0 + wn0 + j * MF::NT + MF::d_col(lane);
+                if (m < a.n && n < a.c) {
+                    const int64_t idx = (int64_t)m * a.lde + n;
+                    if (a.accumulate) {
+                        E[idx] += accE[i][j][r];
+                        D[idx] += accD[i][j][r];
+                    } else {
+                        E[idx] = accE[i][j][r];
+                        D[idx] = accD[i][j][r];
+                    }
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------
 // vector-ALU GEMM with the same contract (64 x 64 block tile, 4 x 4 outputs per thread).
 // ------------------------------------------------------------------------------------------
 template <typename T, typename TA, typename TB>
@@ -883,13 +1029,25 @@ __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_kernel(EighArgs e, 
         }
         __syncthreads();
     }
-    // X = L^-1 (lower triangular), thread j owns column j
+    // X = L^-1 by forward substitution of L X = I: thread j owns column j and never reads another
+    // thread's data, so no barrier is needed.  The loops run over uniform bounds (q < i for every
+    // lane; the structurally zero X(q,j), q < j, are simply multiplied in): L(i,q) is then a
+    // wave-uniform (scalar) load and the X column loads are coalesced and pipeline freely.
+    __syncthreads();
     for (int j = tid; j < n; j += nt) {
-        X[j * ld + j] = 1.0 / L[j * ld + j];
-        for (int i = j + 1; i < n; ++i) {
-            double s = 0.0;
-            for (int q = j; q < i; ++q) s += L[i * ld + q] * X[q * ld + j];
-            X[i * ld + j] = -s / L[i * ld + i];
+        for (int i = 0; i < n; ++i) {
+            const double* Li = L + i * ld;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int q = 0;
+            for (; q + 3 < i; q += 4) {
+                s0 += Li[q] * X[q * ld + j];
+                s1 += Li[q + 1] * X[(q + 1) * ld + j];
+                s2 += Li[q + 2] * X[(q + 2) * ld + j];
+                s3 += Li[q + 3] * X[(q + 3) * ld + j];
+            }
+            for (; q < i; ++q) s0 += Li[q] * X[q * ld + j];
+            const double rhs = (i == j) ? 1.0 : 0.0;
+            X[i * ld + j] = (rhs - ((s0 + s1) + (s2 + s3))) / Li[i];
         }
     }
     if (tid == 0) e.chol_ok[b] = 1;

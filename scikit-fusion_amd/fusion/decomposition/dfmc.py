@@ -6,7 +6,8 @@ import numpy as np
 
 from ..base import FusionFit
 from . import _dfmc
-from .dfmf import graph_matrices, store_runs, _random_state
+from ..._distributed import my_runs, gather_runs
+from .dfmf import graph_matrices, store_runs, initial_factors, _random_state
 
 __all__ = ['Dfmc']
 
@@ -28,12 +29,13 @@ class Dfmc(FusionFit):
         object_types = list(fusion_graph.object_types)
         rank = {ot: int(ot.rank) for ot in object_types}
         R, Theta, M = graph_matrices(fusion_graph, with_masks=True)
-        runs = [_dfmc.dfmc(R=R, M=M, Theta=Theta, obj_types=object_types, obj_type2rank=rank,
-                           max_iter=self.max_iter, init_type=self.init_type,
-                           stopping=self.stopping, stopping_system=self.stopping_system,
-                           verbose=self.verbose, compute_err=self.compute_err,
-                           callback=self.callback, random_state=self.random_state,
-                           n_jobs=self.n_jobs, dtype=self.dtype)
-                for _ in range(self.n_run)]
-        store_runs(self, runs)
+        G0 = initial_factors(R, object_types, rank, self.init_type, self.random_state, self.n_run)
+        local = {k: _dfmc.dfmc(R=R, M=M, Theta=Theta, obj_types=object_types, obj_type2rank=rank,
+                               max_iter=self.max_iter, init_type=self.init_type,
+                               stopping=self.stopping, stopping_system=self.stopping_system,
+                               verbose=self.verbose, compute_err=self.compute_err,
+                               callback=self.callback, random_state=self.random_state,
+                               n_jobs=self.n_jobs, dtype=self.dtype, G0=G0[k])
+                 for k in my_runs(self.n_run)}
+        store_runs(self, gather_runs(local, self.n_run))
         return self

@@ -12,7 +12,10 @@ from itertools import product
 import numpy as np
 
 from ..base import FusionFit, FusionTransform
+from ..._distributed import my_runs, gather_runs
+from ..._engine import count_objects
 from . import _dfmf
+from ._init import initialize
 
 __all__ = ['Dfmf', 'DfmfTransform']
 
@@ -44,6 +47,17 @@ def graph_matrices(fusion_graph, with_masks=False):
             else:
                 Theta.setdefault(key, []).append(data)
     return (R, Theta, M) if with_masks else (R, Theta)
+
+
+def initial_factors(R, object_types, rank, init_type, random_state, n_run):
+    """G0 of every restart, drawn in run order from the ONE shared RandomState (the reference
+    passes the same generator object to all runs, dfmf.py:92, consumed sequentially for
+    n_jobs=1).  Every rank draws all of them so that the result of run k does not depend on how
+    many GPUs share the work."""
+    n_obj = count_objects(object_types, R)
+    R_first = {k: np.asarray(v[0], dtype=float) for k, v in R.items()}
+    return [initialize(object_types, n_obj, rank, R_first, init_type, random_state)
+            for _ in range(n_run)]
 
 
 def store_runs(fuser, runs):
@@ -80,14 +94,15 @@ class Dfmf(FusionFit):
         object_types = list(fusion_graph.object_types)
         rank = {ot: int(ot.rank) for ot in object_types}
         R, Theta = graph_matrices(fusion_graph)
-        runs = [_dfmf.dfmf(R=R, Theta=Theta, obj_types=object_types, obj_type2rank=rank,
-                           max_iter=self.max_iter, init_type=self.init_type,
-                           stopping=self.stopping, stopping_system=self.stopping_system,
-                           verbose=self.verbose, compute_err=self.compute_err,
-                           callback=self.callback, random_state=self.random_state,
-                           n_jobs=self.n_jobs, dtype=self.dtype)
-                for _ in range(self.n_run)]
-        store_runs(self, runs)
+        G0 = initial_factors(R, object_types, rank, self.init_type, self.random_state, self.n_run)
+        local = {k: _dfmf.dfmf(R=R, Theta=Theta, obj_types=object_types, obj_type2rank=rank,
+                               max_iter=self.max_iter, init_type=self.init_type,
+                               stopping=self.stopping, stopping_system=self.stopping_system,
+                               verbose=self.verbose, compute_err=self.compute_err,
+                               callback=self.callback, random_state=self.random_state,
+                               n_jobs=self.n_jobs, dtype=self.dtype, G0=G0[k])
+                 for k in my_runs(self.n_run)}          # one restart per GPU when distributed
+        store_runs(self, gather_runs(local, self.n_run))
         return self
 
 

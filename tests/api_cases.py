@@ -1,0 +1,168 @@
+"""Class-layer scenarios re-stating the assertions of the reference's own tests
+(skfusion/tests/test_dfmf.py, test_dfmc.py, test_n_run.py, test_multiple_relations.py,
+test_base.py).  `full=True` (GPU) runs the reference's iteration counts and exact-reconstruction
+asserts; `full=False` (host emulator) runs a few iterations and checks shapes / consistency."""
+import numpy as np
+
+from skfusion_amd.fusion import (Relation, ObjectType, FusionGraph, Dfmf, Dfmc, DfmfTransform,
+                                 DataFusionError)
+
+
+def iters(full, n=100):
+    return n if full else 3
+
+
+def exact_reconstruction(cls, full):
+    """test_dfmf.py:9-23 / test_dfmc.py:9-23: full-rank factorisation reproduces the data."""
+    rnds = np.random.RandomState(0)
+    R12 = rnds.rand(50, 30)
+    t1, t2 = ObjectType('type1', 50), ObjectType('type2', 30)
+    relation = Relation(R12, t1, t2)
+    graph = FusionGraph()
+    graph.add_relation(relation)
+    fuser = cls(init_type='random', random_state=rnds, max_iter=iters(full)).fuse(graph)
+    assert fuser.backbone(relation).shape == (50, 30)
+    assert fuser.factor(t1).shape == (50, 50) and fuser.factor(t2).shape == (30, 30)
+    if full:
+        np.testing.assert_almost_equal(fuser.complete(relation), relation.data)
+    np.testing.assert_array_equal(relation.data, R12)
+
+
+def non_finite_inputs(full):
+    """test_dfmf.py:25-46: NaN / inf / masked inputs -> all-finite completion."""
+    rnds = np.random.RandomState(0)
+    R12, R13 = rnds.rand(50, 30), rnds.rand(50, 10)
+    R12 = np.ma.masked_greater(R12, 0.7)
+    R12[R12 < 0.1] = np.nan
+    R13[R13 < 0.5] = np.inf
+    t1, t2, t3 = ObjectType('type1', 50), ObjectType('type2', 30), ObjectType('type3', 10)
+    relations = [Relation(R12, t1, t2, fill_value='row_mean'),
+                 Relation(R13, t1, t3, fill_value='col_mean')]
+    fuser = Dfmf(init_type='random', random_state=rnds, max_iter=iters(full)).fuse(FusionGraph(relations))
+    assert fuser.backbone(relations[0]).shape == (50, 30)
+    assert fuser.backbone(relations[1]).shape == (50, 10)
+    assert np.sum(np.isfinite(fuser.complete(relations[0]))) == R12.size
+
+
+def masked_completion(full):
+    """test_dfmc.py:25-39: the reconstruction equals the data on the unmasked entries."""
+    rnds = np.random.RandomState(0)
+    R12 = np.ma.masked_greater(rnds.rand(50, 30), 0.7)
+    t1, t2 = ObjectType('type1', 50), ObjectType('type2', 30)
+    relation = Relation(R12, t1, t2)
+    fuser = Dfmc(init_type='random', random_state=rnds, max_iter=iters(full)).fuse(FusionGraph([relation]))
+    assert fuser.backbone(relation).shape == (50, 30)
+    if full:
+        R12_hat = fuser.complete(relation)
+        np.testing.assert_almost_equal(R12_hat[~R12.mask], R12.data[~R12.mask])
+
+
+def processors(cls, full):
+    """test_dfmf.py:80-120 / test_dfmc.py:41-85: pre/post-processor hooks, data untouched."""
+    rnds = np.random.RandomState(0)
+    R12 = rnds.rand(50, 30)
+    keep = R12.copy()
+    t1, t2 = ObjectType('type1', 50), ObjectType('type2', 30)
+    rel = Relation(R12, t1, t2, preprocessor=lambda d: np.ones_like(d))
+    fuser = cls(init_type='random', random_state=rnds, max_iter=iters(full)).fuse(FusionGraph([rel]))
+    if full:
+        np.testing.assert_almost_equal(fuser.complete(rel), np.ones_like(R12))
+    np.testing.assert_array_equal(rel.data, keep)
+    rel = Relation(R12, t1, t2, postprocessor=lambda d: d - np.mean(d))
+    fuser = cls(init_type='random', random_state=rnds, max_iter=iters(full)).fuse(FusionGraph([rel]))
+    if full:
+        np.testing.assert_almost_equal(fuser.complete(rel), R12 - np.mean(R12))
+    np.testing.assert_array_equal(rel.data, keep)
+
+
+def several_runs(cls, full):
+    """test_n_run.py: n_run=3 -> generators of length 3; rank 50 > 30 objects (pinv truncation)."""
+    rnds = np.random.RandomState(0)
+    R12, R13 = rnds.rand(30, 30), rnds.rand(30, 30)
+    t1, t2, t3 = ObjectType('type1', 50), ObjectType('type2', 30), ObjectType('type3', 10)
+    relations = [Relation(R12, t1, t2), Relation(R13, t1, t3)]
+    graph = FusionGraph()
+    graph.add_relations_from(relations)
+    fuser = cls(init_type='random', random_state=rnds, n_run=3, max_iter=iters(full)).fuse(graph)
+    for ot in (t1, t2, t3):
+        factors = list(fuser.factor(ot))
+        assert len(factors) == 3
+        for f in factors:
+            assert f.shape == (30, ot.rank) and np.isfinite(f).all()
+    assert len(list(fuser.backbone(relations[0]))) == 3
+    assert len(list(fuser.backbone(relations[1]))) == 3
+    assert len(list(fuser.complete(relations[1]))) == 3
+    G1, S13, G3 = fuser.factor(t1, run=1), fuser.backbone(relations[1], run=1), fuser.factor(t3, run=1)
+    np.testing.assert_almost_equal(fuser.complete(relations[1], run=1), G1.dot(S13).dot(G3.T))
+    # the three restarts differ (one shared RandomState, consumed sequentially)
+    assert not np.allclose(fuser.factor(t1, run=0), fuser.factor(t1, run=2))
+    return fuser
+
+
+def multiple_relations(cls, full):
+    """test_multiple_relations.py: two relations between one pair -> one backbone each."""
+    rnds = np.random.RandomState(0)
+    R12a, R12b, R13 = rnds.rand(30, 20), rnds.rand(30, 20), rnds.rand(30, 10)
+    t1, t2, t3 = ObjectType('type1', 8), ObjectType('type2', 6), ObjectType('type3', 4)
+    relations = [Relation(R12a, t1, t2), Relation(R12b, t1, t2), Relation(R13, t1, t3)]
+    fuser = cls(init_type='random', random_state=rnds, max_iter=iters(full, 50)).fuse(FusionGraph(relations))
+    S = [fuser.backbone(r) for r in relations]
+    assert S[0].shape == (8, 6) and S[1].shape == (8, 6) and S[2].shape == (8, 4)
+    assert not np.allclose(S[0], S[1])
+    for r, s in zip(relations, S):
+        want = fuser.factor(r.row_type).dot(s).dot(fuser.factor(r.col_type).T)
+        np.testing.assert_almost_equal(fuser.complete(r), want)
+
+
+def pipeline_and_transform(full):
+    """test_base.py:9-38 + test_dfmf.py:48-78: default init ('random_c'), fold-in of new rows."""
+    rnds = np.random.RandomState(0)
+    R12, R13, R23 = rnds.rand(50, 30), rnds.rand(50, 40), rnds.rand(30, 40)
+    t1, t2, t3 = ObjectType('type1', 30), ObjectType('type2', 40), ObjectType('type3', 40)
+    relations = [Relation(R12, t1, t2), Relation(R13, t1, t3), Relation(R23, t2, t3)]
+    fuser = Dfmf(random_state=rnds, max_iter=iters(full)).fuse(FusionGraph(relations))
+    assert fuser.factor(t1).shape == (50, 30) and fuser.factor(t2).shape == (30, 40)
+    assert fuser.backbone(relations[2]).shape == (40, 40)
+    new_graph = FusionGraph([Relation(rnds.rand(15, 30), t1, t2), Relation(rnds.rand(15, 40), t1, t3)])
+    tr = DfmfTransform(random_state=rnds, max_iter=iters(full)).transform(t1, new_graph, fuser)
+    assert tr.factor(t1).shape == (15, 30) and np.isfinite(tr.factor(t1)).all()
+    assert [p for p in fuser.chain(t1, t3)] == [[t1, t3], [t1, t2, t3]]
+    # a relation that does not touch the target is rejected (base.py:224-231)
+    bad = FusionGraph([Relation(rnds.rand(30, 40), t2, t3)])
+    try:
+        DfmfTransform(max_iter=1).transform(t1, bad, fuser)
+        raise AssertionError('expected DataFusionError')
+    except DataFusionError:
+        pass
+
+
+def fold_in_recovers_known_rows(full):
+    """test_dfmf.py:48-78: folding in two rows of the training data reproduces their factors."""
+    rs = np.random.RandomState(42)
+    R12 = rs.rand(5, 3)
+    t1, t2 = ObjectType('type1', 2), ObjectType('type2', 2)
+    relation = Relation(R12, t1, t2)
+    fuser = Dfmf(init_type='random', random_state=np.random.RandomState(0), max_iter=100).fuse(
+        FusionGraph([relation]))
+    new_graph = FusionGraph([Relation(R12[:2].copy(), t1, t2)])
+    tr = DfmfTransform(random_state=np.random.RandomState(0), max_iter=iters(full)).transform(
+        t1, new_graph, fuser)
+    new_G1, G1, G2, S12 = tr.factor(t1), fuser.factor(t1), fuser.factor(t2), fuser.backbone(relation)
+    assert new_G1.shape == (2, 2)
+    if full:
+        d_hat = new_G1.dot(S12).dot(G2.T) - G1.dot(S12).dot(G2.T)[:2]
+        assert np.sum(d_hat ** 2) / d_hat.size < 1e-5
+
+
+def error_paths():
+    t1, t2, t9 = ObjectType('type1', 2), ObjectType('type2', 2), ObjectType('nine', 2)
+    rel = Relation(np.random.RandomState(0).rand(5, 3), t1, t2)
+    fuser = Dfmf(max_iter=1, init_type='random', random_state=0).fuse(FusionGraph([rel]))
+    for call in (lambda: fuser.factor(t9), lambda: fuser.backbone(Relation(np.ones((5, 3)), t1, t2)),
+                 lambda: fuser.complete(Relation(np.ones((5, 3)), t1, t9))):
+        try:
+            call()
+            raise AssertionError('expected DataFusionError')
+        except DataFusionError:
+            pass
+    assert 'Dfmf(max_iter=1' in repr(fuser)

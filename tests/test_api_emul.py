@@ -1,0 +1,42 @@
+"""Class-layer API on the CPU (host SIMT emulator, few iterations): shapes, generators,
+consistency, hooks, error paths.  Full-iteration versions: tests/test_gpu_api.py."""
+import pytest
+
+import skfusion_amd._native as nat
+from skfusion_amd.fusion import Dfmf, Dfmc
+from emul.runtime import emulated_runtime
+import api_cases as A
+
+
+@pytest.fixture(scope='module', autouse=True)
+def emul():
+    with nat.use_runtime(emulated_runtime()) as rt:
+        yield rt
+
+
+@pytest.mark.parametrize('cls', [Dfmf, Dfmc])
+def test_shapes_full_rank(cls):
+    A.exact_reconstruction(cls, full=False)
+
+
+def test_non_finite_and_masked_inputs():
+    A.non_finite_inputs(full=False)
+    A.masked_completion(full=False)
+
+
+def test_processors_leave_data_untouched():
+    A.processors(Dfmf, full=False)
+
+
+@pytest.mark.parametrize('cls', [Dfmf, Dfmc])
+def test_several_runs(cls):
+    A.several_runs(cls, full=False)
+
+
+def test_multiple_relations_per_pair():
+    A.multiple_relations(Dfmf, full=False)
+
+
+def test_pipeline_transform_chain_and_errors():
+    A.pipeline_and_transform(full=False)
+    A.error_paths()

@@ -1,0 +1,69 @@
+"""N > 1 path on CPU: two processes (gloo), restarts sharded round robin, results gathered;
+every rank must end up with the same factors as a single-process fit.  The arithmetic runs in
+the host SIMT emulator (no GPU in the build container)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _graph():
+    from skfusion_amd.fusion import Relation, ObjectType, FusionGraph
+    rs = np.random.RandomState(3)
+    t1, t2, t3 = ObjectType('a', 4), ObjectType('b', 3), ObjectType('c', 2)
+    rels = [Relation(rs.rand(12, 9), t1, t2), Relation(rs.rand(12, 7), t1, t3)]
+    return FusionGraph(rels), (t1, t2, t3), rels
+
+
+def _fit():
+    from skfusion_amd.fusion import Dfmf
+    g, types, rels = _graph()
+    fuser = Dfmf(max_iter=3, init_type='random_vcol', n_run=3, random_state=7).fuse(g)
+    return [np.concatenate([f.ravel() for f in fuser.factor(t)]) for t in types] + \
+           [np.concatenate([s.ravel() for s in fuser.backbone(r)]) for r in rels]
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import skfusion_amd._native as nat
+    from skfusion_amd._distributed import my_runs, world as dist_world
+    from emul.runtime import emulated_runtime
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        assert dist_world() == (rank, world)
+        assert my_runs(3) == ([0, 2] if rank == 0 else [1])
+        with nat.use_runtime(emulated_runtime()):
+            res = _fit()
+        np.savez(os.path.join(out, 'rank%d.npz' % rank), *res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_restarts_sharded_over_two_gloo_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    import skfusion_amd._native as nat
+    from emul.runtime import emulated_runtime, build
+    build()                                   # compile once, before the workers race for it
+    with nat.use_runtime(emulated_runtime()):
+        single = _fit()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        z = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % rank))
+        for k, want in enumerate(single):
+            np.testing.assert_array_equal(z['arr_%d' % k], want)

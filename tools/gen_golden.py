@@ -293,8 +293,38 @@ def gen_c3_scaled():
     save('c3_scaled.npz', out)
 
 
+# ------------------------------------------------------------------ fill strategies (host glue)
+def gen_fill():
+    """Relation.filled() of the reference (fusion_graph.py:464-545) on inputs with NaN / inf /
+    masked entries: data and mask of the result for the four strategies."""
+    from skfusion.fusion import Relation, ObjectType
+    rs = np.random.RandomState(0)
+    x = rs.rand(5, 4)
+    xm = np.ma.masked_greater(x.copy(), 0.7)
+    xm[xm < 0.2] = np.nan
+    xm[1, 1] = np.inf
+    y = x.copy()
+    y[y < 0.2] = np.nan
+    y[3, 2] = -np.inf
+    z = np.ma.masked_greater(rs.rand(6, 5), 0.6)            # masked, all finite
+    out = {'masked_data': xm.data, 'masked_mask': np.ma.getmaskarray(xm), 'plain': y,
+           'finite_data': z.data, 'finite_mask': np.ma.getmaskarray(z)}
+    t1, t2 = ObjectType('a'), ObjectType('b')
+    import warnings
+    for tag, arr in (('masked', xm), ('plain', y), ('finite', z)):
+        for fv in ('mean', 'row_mean', 'col_mean', 0.5):
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                f = Relation(arr.copy(), t1, t2, fill_value=fv).filled()
+            key = '%s/%s' % (tag, fv)
+            out[key + '/data'] = np.ma.getdata(f)
+            out[key + '/mask'] = np.ma.getmaskarray(f)
+            out[key + '/is_masked'] = np.array(bool(np.ma.is_masked(f)))
+    save('fill_strategies.npz', out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['c1', 'probe', 'rd', 'transform', 'dicty', 'c3s']
+    which = sys.argv[1:] or ['c1', 'probe', 'rd', 'transform', 'dicty', 'c3s', 'fill']
     G = S = None
     if 'c1' in which or 'transform' in which:
         G, S = gen_c1()
@@ -308,3 +338,5 @@ if __name__ == '__main__':
         gen_dicty()
     if 'c3s' in which:
         gen_c3_scaled()
+    if 'fill' in which:
+        gen_fill()
