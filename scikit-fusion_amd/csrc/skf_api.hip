@@ -179,8 +179,17 @@ static inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
 // K slices for the bf16 contraction: equal work units over the 256 CUs (x resident workgroups)
 // finish in ceil(units/slots) rounds; pick the split that wastes the least of the last round,
 // charging a little for the partial-sum traffic of every extra slice.
-static int pick_splits_bf16(int64_t units, int ktiles) {
-    const double slots = 256.0 * 2.0;          // 2 resident 256-thread workgroups per CU
+// rows per workgroup of the bf16 contraction: the 256-row double-buffered kernel for large
+// problems, the 128-row kernel otherwise (SKF_BF16_TILE=128 / 256 forces one, for A/B runs)
+static int bf16_block_rows(int M) {
+    const char* f = getenv("SKF_BF16_TILE");
+    if (f && atoi(f) == 128) return 128;
+    if (f && atoi(f) == 256) return 256;
+    return M >= 4096 ? 256 : 128;
+}
+
+static int pick_splits_bf16(int64_t units, int ktiles, int bm) {
+    const double slots = 256.0 * (bm == 256 ? 1.0 : 2.0);     // resident workgroups on 256 CUs
     int best = 1;
     double best_eff = -1.0;
     for (int s = 1; s <= 32; ++s) {
@@ -205,9 +214,10 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
                  (long long)lda, (long long)ldb);
     if ((((uintptr_t)A) | ((uintptr_t)Bt)) & 15) SKF_FAIL(SKF_E_INVALID, "bf16 operands must be 16-byte aligned");
     const int bn = (N <= 128) ? 128 : 256;
+    const int bm = bf16_block_rows(M);
     const int ktiles = Kp / 64;
-    const int64_t units = (int64_t)cdiv(M, 128) * cdiv(N, bn);
-    int splits = want_splits > 0 ? want_splits : pick_splits_bf16(units, ktiles);
+    const int64_t units = (int64_t)cdiv(M, bm) * cdiv(N, bn);
+    int splits = want_splits > 0 ? want_splits : pick_splits_bf16(units, ktiles, bm);
     const size_t per = (size_t)M * N * sizeof(float);
     if (splits > 1 && (!part || per * splits > part_bytes)) splits = part ? (int)(part_bytes / per) : 1;
     if (splits < 1) splits = 1;
@@ -218,11 +228,30 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
     g.M = M; g.N = N; g.Kp = Kp;
     g.k_chunk = cdiv(ktiles > 0 ? ktiles : 1, splits) * 64;
     splits = cdiv(Kp > 0 ? Kp : 1, g.k_chunk);
-    dim3 grid(cdiv(N, bn), cdiv(M, 128), splits), block(256);
-    if (bn == 128 && relation) hipLaunchKernelGGL((gemm_bf16_kernel<128, 1>), grid, block, 0, st, g);
-    else if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, 0>), grid, block, 0, st, g);
-    else if (relation) hipLaunchKernelGGL((gemm_bf16_kernel<256, 1>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<256, 0>), grid, block, 0, st, g);
+    dim3 grid(cdiv(N, bn), cdiv(M, bm), splits);
+    if (bm == 256) {
+        // 256 x BN tile, LDS double buffer in dynamic shared memory (> 64 KiB needs the attribute)
+        const int smem = 2 * (256 + bn) * 8 * 16;
+        static bool attr_done = false;
+        if (!attr_done) {
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 8 * 16));
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 8 * 16));
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16));
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16));
+            attr_done = true;
+        }
+        dim3 block(512);
+        if (bn == 128 && relation) hipLaunchKernelGGL((gemm_bf16_v2_kernel<128, 1>), grid, block, smem, st, g);
+        else if (bn == 128) hipLaunchKernelGGL((gemm_bf16_v2_kernel<128, 0>), grid, block, smem, st, g);
+        else if (relation) hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 1>), grid, block, smem, st, g);
+        else hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0>), grid, block, smem, st, g);
+    } else {
+        dim3 block(256);
+        if (bn == 128 && relation) hipLaunchKernelGGL((gemm_bf16_kernel<128, 1>), grid, block, 0, st, g);
+        else if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, 0>), grid, block, 0, st, g);
+        else if (relation) hipLaunchKernelGGL((gemm_bf16_kernel<256, 1>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<256, 0>), grid, block, 0, st, g);
+    }
     check_launch("gemm_bf16");
     if (splits > 1) {
         hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3(elem_grid((int64_t)M * N)), dim3(256), 0, st, C, ldc,
@@ -233,7 +262,10 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
 
 static size_t bf16_part_bytes(int M, int N, int Kp) {
     const int bn = (N <= 128) ? 128 : 256;
-    const int s = pick_splits_bf16((int64_t)cdiv(M, 128) * cdiv(N, bn), Kp / 64);
+    // worst case over the two tile heights (the choice can be overridden at run time)
+    const int s1 = pick_splits_bf16((int64_t)cdiv(M, 128) * cdiv(N, bn), Kp / 64, 128);
+    const int s2 = pick_splits_bf16((int64_t)cdiv(M, 256) * cdiv(N, bn), Kp / 64, 256);
+    const int s = s1 > s2 ? s1 : s2;
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
@@ -310,6 +342,12 @@ struct skf_plan {
     int64_t eig_stride = 0;
     int eig_maxn = 0;
     size_t sq_elems = 0;
+    // second stream: Gram + pseudo-inverse run concurrently with the relation contractions
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    skf::Slot part_aux;
+    size_t part_aux_bytes = 0;
+    bool overlap = false;
     // optional hipEvent timing of the relation contractions (skf_plan_set_profiling)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
@@ -318,6 +356,9 @@ struct skf_plan {
     int64_t prof_launches = 0;
     ~skf_plan() {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (aux) (void)hipStreamDestroy(aux);
     }
 };
 
@@ -458,10 +499,11 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
     }
 }
 
-static void gram(skf_plan* p, TypeState& t, int nan, hipStream_t st) {
-    // Gram = G^T G : A = G^T (m-contiguous), B = G
+static void gram(skf_plan* p, TypeState& t, int nan, hipStream_t st, bool on_aux = false) {
+    // Gram = G^T G : A = G^T (m-contiguous), B = G; f64 accumulation
     GemmArgs g = gemm_args(t.G.ptr, 1, t.c, t.G.ptr, t.c, 1, t.Gram.ptr, t.c, t.c, t.c, (int)t.n, EPI_STORE, nan);
-    wide_gemm(p, g, st);
+    run_gemm(GemmTypes{SKF_F64, p->mt, p->mt}, p->engine, g, 0, on_aux ? p->part_aux.ptr : p->part.ptr,
+             on_aux ? p->part_aux_bytes : p->part_bytes, st);
 }
 
 static void mult_update(skf_plan* p, TypeState& t, hipStream_t st) {
@@ -566,9 +608,24 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
     const bool fused = (p->engine == SKF_ENGINE_MFMA);
     std::vector<int> all;
     std::vector<char> touched(p->types.size(), 0);     // E/D of the type already written this iteration
+    // ---- phase A (second stream when available): Gram_i and K_i = pinv(Gram_i).  They depend
+    // only on G, exactly like the relation contractions of phase B, so the two phases overlap.
+    hipStream_t sa = st;
+    if (p->overlap) {
+        SKF_HIP(hipEventRecord(p->ev_fork, st));
+        SKF_HIP(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
+        sa = p->aux;
+    }
+    for (size_t i = 0; i < p->types.size(); ++i) {
+        gram(p, p->types[i], 1, sa, p->overlap);
+        all.push_back((int)i);
+    }
+    plan_pinv(p, all, sa);
+    if (p->overlap) SKF_HIP(hipEventRecord(p->ev_join, p->aux));
+
+    // ---- phase B (main stream): every product that streams a relation matrix
     for (size_t i = 0; i < p->types.size(); ++i) {
         TypeState& t = p->types[i];
-        gram(p, t, 1, st);
         bool has_rel = false;
         for (RelState& r : p->rels) has_rel = has_rel || r.row == (int)i || r.col == (int)i;
         if (!fused || !has_rel) {          // the fused update overwrites E/D on first touch
@@ -576,10 +633,7 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
             SKF_HIP(hipMemsetAsync(t.D.ptr, 0, t.D.bytes, st));
             touched[i] = 1;
         }
-        all.push_back((int)i);
     }
-    plan_pinv(p, all, st);
-
     for (RelState& r : p->rels) {
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
@@ -587,6 +641,19 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
         // P = R G_j
         GemmArgs g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
         relation_gemm(p, g, st, &r, false);
+        if (!(dfmc && r.mask)) {           // Q = R^T G_i (a masked relation is completed first)
+            g = gemm_args(r.R, 1, r.ldr, ti.G.ptr, ci, 1, r.Q.ptr, ci, nj, ci, ni, EPI_STORE, 0);
+            relation_gemm(p, g, st, &r, true);
+        }
+    }
+    if (p->overlap) SKF_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
+
+    // ---- phase C: backbones and accumulator updates
+    for (RelState& r : p->rels) {
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        const int ni = (int)ti.n, nj = (int)tj.n, ci = ti.c, cj = tj.c;
+        GemmArgs g;
         // W = G_i^T P ; T1 = K_i W ; S = T1 K_j
         g = gemm_args(ti.G.ptr, 1, ci, r.P.ptr, cj, 1, r.W.ptr, cj, ci, cj, ni, EPI_STORE, 0);
         wide_gemm(p, g, st);
@@ -604,10 +671,9 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
             plan_gemm(p, g, st);
             g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
             relation_gemm(p, g, st, &r, false);
+            g = gemm_args(r.R, 1, r.ldr, ti.G.ptr, ci, 1, r.Q.ptr, ci, nj, ci, ni, EPI_STORE, 0);
+            relation_gemm(p, g, st, &r, true);
         }
-        // Q = R^T G_i
-        g = gemm_args(r.R, 1, r.ldr, ti.G.ptr, ci, 1, r.Q.ptr, ci, nj, ci, ni, EPI_STORE, 0);
-        relation_gemm(p, g, st, &r, true);
         relation_small_terms(p, r, nan_upd, EPI_SPLIT_STORE, r.Bp.ptr, r.Bn.ptr, r.Dp.ptr, r.Dn.ptr, true, true, st);
         if (fused) {
             // row side: A = P S^T (Sop(k,j) = S[j][k]);  column side: C = Q S
@@ -843,6 +909,14 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             want_part((int)p->types[th.type].n, p->types[th.type].c, (int)p->types[th.type].n, p->f64);
         p->part_bytes = part_bytes;
         add_slot(p, p->part, part_bytes);
+        size_t aux_bytes = 0;
+        for (TypeState& t : p->types) {
+            TileCfg tc = pick_tile(true, p->engine, t.c, t.c);
+            size_t need = (size_t)pick_splits(tc, t.c, t.c, (int)t.n) * (size_t)t.c * t.c * 8;
+            if (need > aux_bytes) aux_bytes = need;
+        }
+        p->part_aux_bytes = aux_bytes;
+        add_slot(p, p->part_aux, aux_bytes);
         p->sq_elems = sq_elems;
         add_slot(p, p->sqpart, sq_elems * es);
         if (p->variant != SKF_TRANSFORM) {
@@ -911,6 +985,15 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             SKF_HIP(hipMemcpyAsync(p->eigN.ptr, n_pad.data(), n_pad.size() * sizeof(int), hipMemcpyHostToDevice, st));
             SKF_HIP(hipMemcpyAsync(p->eigNorig.ptr, n_orig.data(), n_orig.size() * sizeof(int), hipMemcpyHostToDevice, st));
             SKF_HIP(hipStreamSynchronize(st));     // the host vectors die here; bind is not on the hot path
+        }
+        if (p->variant != SKF_TRANSFORM && !p->aux) {
+            const char* no = getenv("SKF_NO_OVERLAP");
+            if (!(no && atoi(no) != 0)) {
+                SKF_HIP(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+                SKF_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+                SKF_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+                p->overlap = true;
+            }
         }
         p->bound = true;
         p->prepared = false;

@@ -643,6 +643,110 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16GemmArgs g) {
             }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 relation contraction, second generation: 256 x BN block tile, 512 threads = 8 waves
+// (4 x 2, wave tile 64 x BN/2), K tile 64, LDS double-buffered in dynamic shared memory
+// (2 x (256+BN) x 128 B = 128 KiB at BN = 256) so that one barrier per K tile suffices:
+//     [global loads of tile t+1 -> registers]  MFMA on LDS[t&1]  registers -> LDS[(t+1)&1]  barrier
+// Same operand contract, fragment layout and swizzle as gemm_bf16_kernel; twice the rows per
+// workgroup halves the L2 traffic of the shared G^T operand per flop.
+// ------------------------------------------------------------------------------------------
+template <int BN, int TAG>
+__global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
+    constexpr int BM = 256, BK = 64;
+    constexpr int WN = BN / 2;
+    constexpr int NJ = WN / 16;
+    constexpr int A_PER = BM / 64;          // 512 threads cover 64 rows x 8 chunks per pass
+    constexpr int B_PER = BN / 64;
+    constexpr int BUF = (BM + BN) * 8;      // u32x4 entries per buffer
+    HIP_DYNAMIC_SHARED(u32x4, smem)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * WN;
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    const int kz0 = blockIdx.z * g.k_chunk;
+    const int kz1 = (kz0 + g.k_chunk < g.Kp) ? kz0 + g.k_chunk : g.Kp;
+    const int nkt = (kz1 - kz0) / BK;
+    const int srow = tid >> 3, schunk = tid & 7;
+
+    f32x4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[A_PER], rb[B_PER];
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) {
+            const int m = bm0 + srow + 64 * p;
+            ra[p] = (m < g.M) ? *(const u32x4*)(g.A + (int64_t)m * g.lda + k0 + schunk * 8) : zero;
+        }
+#pragma unroll
+        for (int p = 0; p < B_PER; ++p) {
+            const int n = bn0 + srow + 64 * p;
+            rb[p] = (n < g.N) ? *(const u32x4*)(g.Bt + (int64_t)n * g.ldb + k0 + schunk * 8) : zero;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        u32x4* As = smem + buf * BUF;
+        u32x4* Bs = As + BM * 8;
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) As[swz_chunk(srow + 64 * p, schunk)] = ra[p];
+#pragma unroll
+        for (int p = 0; p < B_PER; ++p) Bs[swz_chunk(srow + 64 * p, schunk)] = rb[p];
+    };
+
+    if (nkt > 0) {
+        load_tiles(kz0);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nkt);
+        if (more) load_tiles(kz0 + (kt + 1) * BK);
+        const u32x4* As = smem + cur * BUF;
+        const u32x4* Bs = As + BM * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = 4 * ks + (lane >> 4);
+            bf16x8 a[4], b[NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* out = (gridDim.z > 1) ? g.part + (int64_t)blockIdx.z * g.M * g.N : g.C;
+    const int64_t ldo = (gridDim.z > 1) ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = bm0 + wm0 + i * 16 + 4 * (lane >> 4) + r;
+                const int n = bn0 + wn0 + j * 16 + (lane & 15);
+                if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc[i][j][r];
+            }
+}
+
 // split-K second stage of the bf16 contraction: C = sum_z part[z]  (fixed order)
 __global__ __launch_bounds__(256) void bf16_splitk_reduce_kernel(float* __restrict__ C, int64_t ldc,
                                                                  const float* __restrict__ part, int M, int N,

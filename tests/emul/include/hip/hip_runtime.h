@@ -103,6 +103,15 @@ inline std::vector<WaveSync> g_waves;
 inline std::function<void()>* g_body = nullptr;
 inline int g_nthreads = 0;
 inline int g_progress = 0;
+inline unsigned char* g_dyn_smem = nullptr;
+inline size_t g_dyn_cap = 0;
+inline void set_dynamic_smem(size_t bytes) {
+    if (bytes > g_dyn_cap) {
+        free(g_dyn_smem);
+        g_dyn_smem = (unsigned char*)aligned_alloc(256, (bytes + 255) / 256 * 256);
+        g_dyn_cap = bytes;
+    }
+}
 
 inline void die(const char* msg) {
     fprintf(stderr, "[simt-emul] fatal: %s (block %u,%u,%u)\n", msg, g_blockIdx.x, g_blockIdx.y, g_blockIdx.z);
@@ -240,7 +249,12 @@ inline T wave_read(T mine, int src_lane) {
 #define warpSize 64
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    simt::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+    (simt::set_dynamic_smem(shmem), simt::launch((grid), (block), [=]() { kernel(__VA_ARGS__); }))
+
+// dynamic shared memory: one 16-byte aligned host buffer per launch
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)simt::g_dyn_smem;
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+template <class F> inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
 
 inline void __syncthreads() { simt::block_barrier(); }
 

@@ -154,12 +154,19 @@ def run_gemm_bf16(rt, A, B, splits=0):
 @pytest.mark.parametrize('shape', [(1, 1, 1), (16, 16, 32), (128, 128, 64), (130, 100, 70), (257, 128, 200),
                                    (100, 256, 129), (200, 200, 500), (129, 300, 64)])
 def test_gemm_bf16_contraction(rt, shape):
+    """Both workgroup shapes: 128-row single-buffered and 256-row double-buffered kernels."""
+    import os
     M, N, K = shape
     rs = np.random.RandomState(M + N + K)
     A, B = rs.randn(M, K), rs.randn(K, N)           # asymmetric operands
-    for splits in (0, 1, 3):
-        got, want = run_gemm_bf16(rt, A, B, splits)
-        assert relerr(got, want) < 2e-6, splits        # exact bf16 products, f32 accumulation
+    for tile in ('128', '256'):
+        os.environ['SKF_BF16_TILE'] = tile
+        try:
+            for splits in (0, 1, 3):
+                got, want = run_gemm_bf16(rt, A, B, splits)
+                assert relerr(got, want) < 2e-6, (tile, splits)   # exact products, f32 accumulation
+        finally:
+            os.environ.pop('SKF_BF16_TILE', None)
 
 
 def test_to_bf16_and_transpose(rt):
