@@ -234,17 +234,31 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
         const int smem = 2 * (256 + bn) * 8 * 16;
         static bool attr_done = false;
         if (!attr_done) {
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 8 * 16));
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 8 * 16));
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16));
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 8 * 16));
+            const int s128 = 2 * (256 + 128) * 8 * 16, s256 = 2 * (256 + 256) * 8 * 16;
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<128, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s128));
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<128, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s128));
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<256, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s256));
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<256, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s256));
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<128, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s128));
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s128));
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<256, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s256));
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<256, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s256));
             attr_done = true;
         }
         dim3 block(512);
-        if (bn == 128 && relation) hipLaunchKernelGGL((gemm_bf16_v2_kernel<128, 1>), grid, block, smem, st, g);
-        else if (bn == 128) hipLaunchKernelGGL((gemm_bf16_v2_kernel<128, 0>), grid, block, smem, st, g);
-        else if (relation) hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 1>), grid, block, smem, st, g);
-        else hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0>), grid, block, smem, st, g);
+        const char* mf = getenv("SKF_BF16_MFMA");          // "32" selects the 32x32x16 flavour
+        const bool mf32 = (mf && atoi(mf) == 32);           // (measured 7 % slower than 16x16x32 here)
+        if (mf32) {
+            if (bn == 128 && relation) hipLaunchKernelGGL((gemm_bf16_v2_kernel<128, 1, true>), grid, block, smem, st, g);
+            else if (bn == 128) hipLaunchKernelGGL((gemm_bf16_v2_kernel<128, 0, true>), grid, block, smem, st, g);
+            else if (relation) hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 1, true>), grid, block, smem, st, g);
+            else hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0, true>), grid, block, smem, st, g);
+        } else {
+            if (bn == 128 && relation) hipLaunchKernelGGL((gemm_bf16_v2_kernel<128, 1, false>), grid, block, smem, st, g);
+            else if (bn == 128) hipLaunchKernelGGL((gemm_bf16_v2_kernel<128, 0, false>), grid, block, smem, st, g);
+            else if (relation) hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 1, false>), grid, block, smem, st, g);
+            else hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0, false>), grid, block, smem, st, g);
+        }
     } else {
         dim3 block(256);
         if (bn == 128 && relation) hipLaunchKernelGGL((gemm_bf16_kernel<128, 1>), grid, block, 0, st, g);
@@ -610,15 +624,18 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
     std::vector<char> touched(p->types.size(), 0);     // E/D of the type already written this iteration
     // ---- phase A (second stream when available): Gram_i and K_i = pinv(Gram_i).  They depend
     // only on G, exactly like the relation contractions of phase B, so the two phases overlap.
+    // The Gram products use the whole chip and stay on the main stream; the pseudo-inverses are
+    // three single-workgroup kernels with a long serial chain: they go to the second stream and
+    // run underneath the relation contractions.
+    for (size_t i = 0; i < p->types.size(); ++i) {
+        gram(p, p->types[i], 1, st, false);
+        all.push_back((int)i);
+    }
     hipStream_t sa = st;
     if (p->overlap) {
         SKF_HIP(hipEventRecord(p->ev_fork, st));
         SKF_HIP(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
         sa = p->aux;
-    }
-    for (size_t i = 0; i < p->types.size(); ++i) {
-        gram(p, p->types[i], 1, sa, p->overlap);
-        all.push_back((int)i);
     }
     plan_pinv(p, all, sa);
     if (p->overlap) SKF_HIP(hipEventRecord(p->ev_join, p->aux));

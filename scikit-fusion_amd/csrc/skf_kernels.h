@@ -651,11 +651,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16GemmArgs g) {
 // Same operand contract, fragment layout and swizzle as gemm_bf16_kernel; twice the rows per
 // workgroup halves the L2 traffic of the shared G^T operand per flop.
 // ------------------------------------------------------------------------------------------
-template <int BN, int TAG>
+// swizzle of the 32x32x16 flavour: fragment rows come 32 at a time, chunk ^ ((row >> 1) & 7) is
+// conflict-free for the 16-lane service groups of ds_read_b128 in that pattern
+__device__ __forceinline__ int swz_chunk32(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
+
+// MF32 = true: v_mfma_f32_32x32x16_bf16 (lane l: A[row = l&31][k = 8*(l>>5) .. +7], 16 f32
+// results per lane) -- half the MFMA instructions of the 16x16x32 flavour for the same tile.
+template <int BN, int TAG, bool MF32>
 __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     constexpr int BM = 256, BK = 64;
     constexpr int WN = BN / 2;
-    constexpr int NJ = WN / 16;
+    constexpr int NJ = WN / 16;             // 16-wide column blocks (16x16x32 flavour)
+    constexpr int NJ32 = WN / 32;           // 32-wide column blocks (32x32x16 flavour)
     constexpr int A_PER = BM / 64;          // 512 threads cover 64 rows x 8 chunks per pass
     constexpr int B_PER = BN / 64;
     constexpr int BUF = (BM + BN) * 8;      // u32x4 entries per buffer
@@ -670,36 +677,56 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     const int nkt = (kz1 - kz0) / BK;
     const int srow = tid >> 3, schunk = tid & 7;
 
-    f32x4 acc[4][NJ];
+    f32x4 acc[MF32 ? 1 : 4][MF32 ? 1 : NJ];
+    f32x16 acc32[MF32 ? 2 : 1][MF32 ? NJ32 : 1];
+    if constexpr (MF32) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int j = 0; j < NJ32; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    }
 
     u32x4 ra[A_PER], rb[B_PER];
-    const u32x4 zero = {0u, 0u, 0u, 0u};
 
+    // rows past the end are clamped to the last valid row (no divergent branches around the loads,
+    // no select that would force a wait on the load): they only feed accumulator rows / columns
+    // >= M / N, which are never stored
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < A_PER; ++p) {
             const int m = bm0 + srow + 64 * p;
-            ra[p] = (m < g.M) ? *(const u32x4*)(g.A + (int64_t)m * g.lda + k0 + schunk * 8) : zero;
+            const int mc = m < g.M ? m : g.M - 1;
+            ra[p] = *(const u32x4*)(g.A + (int64_t)mc * g.lda + k0 + schunk * 8);
         }
 #pragma unroll
         for (int p = 0; p < B_PER; ++p) {
             const int n = bn0 + srow + 64 * p;
-            rb[p] = (n < g.N) ? *(const u32x4*)(g.Bt + (int64_t)n * g.ldb + k0 + schunk * 8) : zero;
+            const int nc = n < g.N ? n : g.N - 1;
+            rb[p] = *(const u32x4*)(g.Bt + (int64_t)nc * g.ldb + k0 + schunk * 8);
         }
     };
     auto store_tiles = [&](int buf) {
         u32x4* As = smem + buf * BUF;
         u32x4* Bs = As + BM * 8;
 #pragma unroll
-        for (int p = 0; p < A_PER; ++p) As[swz_chunk(srow + 64 * p, schunk)] = ra[p];
+        for (int p = 0; p < A_PER; ++p) {
+            const int r = srow + 64 * p;
+            As[MF32 ? swz_chunk32(r, schunk) : swz_chunk(r, schunk)] = ra[p];
+        }
 #pragma unroll
-        for (int p = 0; p < B_PER; ++p) Bs[swz_chunk(srow + 64 * p, schunk)] = rb[p];
+        for (int p = 0; p < B_PER; ++p) {
+            const int r = srow + 64 * p;
+            Bs[MF32 ? swz_chunk32(r, schunk) : swz_chunk(r, schunk)] = rb[p];
+        }
     };
 
     if (nkt > 0) {
@@ -713,21 +740,40 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
         if (more) load_tiles(kz0 + (kt + 1) * BK);
         const u32x4* As = smem + cur * BUF;
         const u32x4* Bs = As + BM * 8;
+        if constexpr (MF32) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = 4 * ks + (lane >> 4);
-            bf16x8 a[4], b[NJ];
+            for (int kq = 0; kq < 4; ++kq) {
+                const int chunk = 2 * kq + (lane >> 5);
+                bf16x8 a[2], b[NJ32];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
+                for (int i = 0; i < 2; ++i)
+                    a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk32(wm0 + i * 32 + (lane & 31), chunk)]);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
+                for (int j = 0; j < NJ32; ++j)
+                    b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk32(wn0 + j * 32 + (lane & 31), chunk)]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ32; ++j)
+                        acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc32[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int chunk = 4 * ks + (lane >> 4);
+                bf16x8 a[4], b[NJ];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
         if (more) store_tiles(cur ^ 1);
         __syncthreads();
@@ -735,16 +781,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
 
     float* out = (gridDim.z > 1) ? g.part + (int64_t)blockIdx.z * g.M * g.N : g.C;
     const int64_t ldo = (gridDim.z > 1) ? g.N : g.ldc;
+    if constexpr (MF32) {
+        // D reg r of a 32 x 32 tile -> row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane & 31
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int j = 0; j < NJ32; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = bm0 + wm0 + i * 16 + 4 * (lane >> 4) + r;
-                const int n = bn0 + wn0 + j * 16 + (lane & 15);
-                if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc[i][j][r];
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int m = bm0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int n = bn0 + wn0 + j * 32 + (lane & 31);
+                    if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc32[i][j][r];
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = bm0 + wm0 + i * 16 + 4 * (lane >> 4) + r;
+                    const int n = bn0 + wn0 + j * 16 + (lane & 15);
+                    if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc[i][j][r];
+                }
+    }
 }
 
 // split-K second stage of the bf16 contraction: C = sum_z part[z]  (fixed order)

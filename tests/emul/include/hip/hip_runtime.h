@@ -15,6 +15,7 @@
 //                         D reg r: row=(r&3)+8*(r>>2)+4*(l>>5), col=l&31
 //   mfma_f32_16x16x4f32 : A[i=l&15][k=l>>4]  B[k=l>>4][j=l&15]   D reg r: row=4*(l>>4)+r, col=l&15
 //   mfma_f64_16x16x4f64 : A[i=l&15][k=l>>4]  B[k=l>>4][j=l&15]   D reg r: row=(l>>4)+4*r, col=l&15
+//   mfma_f32_32x32x16_bf16 : A[i=l&31][k=8*(l>>5)+e]  B[k=8*(l>>5)+e][j=l&31]  D as 32x32x2f32
 //   mfma_f32_16x16x32_bf16 : A[i=l&15][k=8*(l>>4)+e]  B[k=8*(l>>4)+e][j=l&15]
 //                         D reg r: row=4*(l>>4)+r, col=l&15
 // Set SKF_EMUL_REVERSE=1 to schedule fibers in reverse order (flushes out missing barriers
@@ -376,6 +377,28 @@ typedef __bf16 simt_bf16x8 __attribute__((ext_vector_type(8)));
 inline simt_f32x4 simt_mfma_f32_16x16x32_bf16(simt_s16x8 a, simt_s16x8 b, simt_f32x4 c);
 inline simt_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(simt_bf16x8 a, simt_bf16x8 b, simt_f32x4 c, int, int, int) {
     return simt_mfma_f32_16x16x32_bf16(__builtin_bit_cast(simt_s16x8, a), __builtin_bit_cast(simt_s16x8, b), c);
+}
+
+inline simt_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(simt_bf16x8 a, simt_bf16x8 b, simt_f32x16 c, int, int, int) {
+    struct AB { simt_s16x8 a, b; } mine{__builtin_bit_cast(simt_s16x8, a), __builtin_bit_cast(simt_s16x8, b)};
+    simt::WaveSync& ws = simt::my_wave();
+    int l = simt::lane_id();
+    memcpy(ws.xchg[l], &mine, sizeof mine);
+    simt::wave_sync();
+    simt_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            AB pa, pb;
+            memcpy(&pa, ws.xchg[row + 32 * (k >> 3)], sizeof pa);
+            memcpy(&pb, ws.xchg[col + 32 * (k >> 3)], sizeof pb);
+            acc += simt_bf16_to_f32((unsigned short)pa.a[k & 7]) * simt_bf16_to_f32((unsigned short)pb.b[k & 7]);
+        }
+        d[r] = acc;
+    }
+    simt::wave_sync();
+    return d;
 }
 
 // bf16 operands are passed as 8 raw 16-bit patterns per lane

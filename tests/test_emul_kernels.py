@@ -159,14 +159,16 @@ def test_gemm_bf16_contraction(rt, shape):
     M, N, K = shape
     rs = np.random.RandomState(M + N + K)
     A, B = rs.randn(M, K), rs.randn(K, N)           # asymmetric operands
-    for tile in ('128', '256'):
+    for tile, mf in (('128', '32'), ('256', '32'), ('256', '16')):
         os.environ['SKF_BF16_TILE'] = tile
+        os.environ['SKF_BF16_MFMA'] = mf
         try:
             for splits in (0, 1, 3):
                 got, want = run_gemm_bf16(rt, A, B, splits)
-                assert relerr(got, want) < 2e-6, (tile, splits)   # exact products, f32 accumulation
+                assert relerr(got, want) < 2e-6, (tile, mf, splits)   # exact products, f32 accumulation
         finally:
             os.environ.pop('SKF_BF16_TILE', None)
+            os.environ.pop('SKF_BF16_MFMA', None)
 
 
 def test_to_bf16_and_transpose(rt):
