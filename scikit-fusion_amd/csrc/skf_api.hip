@@ -469,6 +469,27 @@ static double chol_rel_threshold() {
     return 1e-8;
 }
 
+// Cholesky fast path: the LDS-blocked kernel up to order CHOLB_MAXN, the plain one beyond
+static void launch_chol(const EighArgs& e, int batch, int max_order, hipStream_t st) {
+    const char* f = getenv("SKF_CHOL_UNBLOCKED");
+    if (max_order <= CHOLB_MAXN && !(f && atoi(f) != 0)) {
+        size_t wave_tiles = (size_t)(EIGH_THREADS / 64) * CHOLB_NB * (CHOLB_NB + 1);
+        size_t panel = (size_t)CHOLB_NB * max_order;
+        size_t smem = ((size_t)CHOLB_NB * (CHOLB_NB + 1) + (panel > wave_tiles ? panel : wave_tiles)) * sizeof(double);
+        static bool attr_done = false;
+        if (!attr_done) {
+            SKF_HIP(hipFuncSetAttribute((const void*)chol_inverse_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(((size_t)CHOLB_NB * (CHOLB_NB + 1) + (size_t)CHOLB_NB * CHOLB_MAXN) * sizeof(double))));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(chol_inverse_blocked_kernel, dim3((unsigned)batch), dim3(EIGH_THREADS), smem, st, e,
+                           chol_rel_threshold());
+    } else {
+        hipLaunchKernelGGL(chol_inverse_kernel, dim3((unsigned)batch), dim3(EIGH_THREADS), 0, st, e, chol_rel_threshold());
+    }
+    check_launch("chol_inverse");
+}
+
 // K_i = pinv(Gram_i) for every type (one workgroup each); `which` = 0..n_types-1, the order
 // of the per-matrix order arrays uploaded once by skf_plan_bind_workspace.
 static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st) {
@@ -490,9 +511,7 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
     e.max_sweeps = 30;
     // fast path (Cholesky inverse) with an on-device verdict; the Jacobi eigen-solver only does
     // work for the matrices the fast path rejected -- no host round trip either way
-    hipLaunchKernelGGL(chol_inverse_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), 0, st, e,
-                       chol_rel_threshold());
-    check_launch("chol_inverse");
+    launch_chol(e, (int)which.size(), p->eig_maxn, st);
     for (size_t b = 0; b < which.size(); ++b) {
         const TypeState& t = p->types[which[b]];
         const double* X = (const double*)p->eigV.ptr + (int64_t)b * stride;
@@ -1240,8 +1259,7 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
         e.A = eA; e.V = eV; e.Vs = eVs; e.w = eW; e.stride = (int64_t)np * np; e.wstride = np;
         e.n = eN; e.n_orig = eNo; e.chol_ok = eOk; e.max_sweeps = 30;
         const int tot2 = n * n;
-        hipLaunchKernelGGL(chol_inverse_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, e, chol_rel_threshold());
-        check_launch("chol_inverse");
+        launch_chol(e, 1, np, st);
         if (dtype == SKF_F64)
             hipLaunchKernelGGL((chol_unpack_kernel<double>), dim3(elem_grid(tot2)), dim3(256), 0, st, (double*)K, ldk,
                                eV, np, n, eOk);

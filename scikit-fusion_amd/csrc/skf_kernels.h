@@ -1217,6 +1217,198 @@ __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_kernel(EighArgs e, 
     if (tid == 0) e.chol_ok[b] = 1;
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-blocked version of the fast path (orders up to CHOLB_MAXN): the same contract as
+// chol_inverse_kernel -- L in e.Vs, X = L^-1 in e.V, verdict in chol_ok -- with NB = 32 column
+// panels.  Per panel: the diagonal block is factored in LDS, the rows below are solved one per
+// thread against it and kept as a transposed panel in LDS, and the trailing matrix receives one
+// rank-32 update (global memory is touched once per panel instead of once per column).
+// X = L^-1 by block forward substitution: the diagonal blocks are inverted first, then wave w
+// walks down block column w with 32x32x32 register-tiled products.
+// Dynamic LDS: D[32][33] + max(P[32][n], 8 waves x T[32][33]) doubles.
+// ------------------------------------------------------------------------------------------
+constexpr int CHOLB_NB = 32;
+constexpr int CHOLB_MAXN = 512;
+
+__global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_blocked_kernel(EighArgs e, double rel_thr) {
+    constexpr int NB = CHOLB_NB;
+    HIP_DYNAMIC_SHARED(double, csm)
+    __shared__ double red[EIGH_THREADS / 64];
+    __shared__ double s_max;
+    const int b = blockIdx.x;
+    const int n = e.n_orig[b], ld = e.n[b];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+    const double* A = e.A + (int64_t)b * e.stride;
+    double* L = e.Vs + (int64_t)b * e.stride;
+    double* X = e.V + (int64_t)b * e.stride;
+    double* D = csm;                       // [NB][NB+1]
+    double* P = csm + NB * (NB + 1);       // [NB][n]  transposed panel  /  per-wave T tiles later
+
+    double mx = 0.0;
+    for (int idx = tid; idx < n * n; idx += nt) {
+        const int r = idx / n, c = idx % n;
+        const double v = 0.5 * (A[r * ld + c] + A[c * ld + r]);
+        L[r * ld + c] = v;
+        X[r * ld + c] = 0.0;
+        if (r == c) mx = fmax(mx, fabs(v));
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nwaves; ++i) s = fmax(s, red[i]);
+        s_max = s;
+    }
+    __syncthreads();
+    const double thr = rel_thr * s_max;
+
+    // ---------------- factorisation
+    for (int kb = 0; kb < n; kb += NB) {
+        const int nb = (n - kb < NB) ? n - kb : NB;
+        const int m = n - kb - nb;                       // rows below the diagonal block
+        for (int idx = tid; idx < nb * nb; idx += nt) {
+            const int r = idx / nb, c = idx % nb;
+            D[r * (NB + 1) + c] = L[(kb + r) * ld + kb + c];
+        }
+        __syncthreads();
+        for (int k = 0; k < nb; ++k) {
+            const double piv = D[k * (NB + 1) + k];
+            if (!(piv > thr) || !(piv > 0.0)) {          // uniform: same LDS word for every thread
+                if (tid == 0) e.chol_ok[b] = 0;
+                return;
+            }
+            const double d = sqrt(piv);
+            __syncthreads();                              // everybody has read the pivot
+            for (int r = k + tid; r < nb; r += nt) D[r * (NB + 1) + k] = (r == k) ? d : D[r * (NB + 1) + k] / d;
+            __syncthreads();
+            const int w = nb - k - 1;
+            for (int idx = tid; idx < w * w; idx += nt) {
+                const int r = k + 1 + idx / w, c = k + 1 + idx % w;
+                if (c <= r) D[r * (NB + 1) + c] -= D[r * (NB + 1) + k] * D[c * (NB + 1) + k];
+            }
+            __syncthreads();
+        }
+        // diagonal block back to global; panel rows: x = a * L11^-T, one row per thread
+        for (int idx = tid; idx < nb * nb; idx += nt) {
+            const int r = idx / nb, c = idx % nb;
+            if (c <= r) L[(kb + r) * ld + kb + c] = D[r * (NB + 1) + c];
+        }
+        for (int i = tid; i < m; i += nt) {
+            double* row = L + (int64_t)(kb + nb + i) * ld + kb;
+            double x[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) x[c] = (c < nb) ? row[c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                if (c < nb) {
+                    double s = x[c];
+#pragma unroll
+                    for (int q = 0; q < NB; ++q)
+                        if (q < c) s -= x[q] * D[c * (NB + 1) + q];
+                    x[c] = s / D[c * (NB + 1) + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (c < nb) {
+                    row[c] = x[c];
+                    P[c * n + i] = x[c];
+                }
+        }
+        __syncthreads();
+        // trailing update of the lower triangle: L22 -= L21 L21^T
+        for (int idx = tid; idx < m * m; idx += nt) {
+            const int i = idx / m, j = idx % m;
+            if (j <= i) {
+                double s = 0.0;
+#pragma unroll 8
+                for (int c = 0; c < nb; ++c) s += P[c * n + i] * P[c * n + j];
+                L[(int64_t)(kb + nb + i) * ld + kb + nb + j] -= s;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- X = L^-1
+    const int nblk = (n + NB - 1) / NB;
+    // (a) inverses of the diagonal blocks: 32 threads per block, one column each
+    for (int t = tid; t < nblk * NB; t += nt) {
+        const int blk = t / NB, j = t % NB;
+        const int b0 = blk * NB;
+        const int nb = (n - b0 < NB) ? n - b0 : NB;
+        if (j < nb) {
+            double x[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                x[i] = 0.0;
+                if (i < nb && i >= j) {
+                    double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int q = 0; q < NB; ++q)
+                        if (q < i && q >= j) s -= L[(int64_t)(b0 + i) * ld + b0 + q] * x[q];
+                    x[i] = s / L[(int64_t)(b0 + i) * ld + b0 + i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                if (i < nb && i >= j) X[(int64_t)(b0 + i) * ld + b0 + j] = x[i];
+        }
+    }
+    __syncthreads();
+    // (b) block forward substitution: X[ib,jb] = -Xd[ib] * sum_{kb=jb}^{ib-1} L[ib,kb] X[kb,jb]
+    double* T = P + wave * NB * (NB + 1);                 // per-wave 32 x 33 tile
+    const int r0 = 4 * (lane >> 3), c0 = 4 * (lane & 7);  // 4 x 4 outputs per lane
+    for (int ib = 1; ib < nblk; ++ib) {
+        const int i0 = ib * NB;
+        for (int jb = wave; jb < ib; jb += nwaves) {
+            const int j0 = jb * NB;
+            double acc[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+            for (int k = j0; k < i0; ++k) {               // k runs over the columns of L[ib, jb..ib-1]
+                double a[4], bb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = (i0 + r0 + u < n) ? L[(int64_t)(i0 + r0 + u) * ld + k] : 0.0;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) bb[v] = X[(int64_t)k * ld + j0 + c0 + v];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * bb[v];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) T[(r0 + u) * (NB + 1) + c0 + v] = acc[u][v];
+            // the tile is produced and consumed by the same wave: order the LDS traffic
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u;
+                double o[4] = {0.0, 0.0, 0.0, 0.0};
+                if (i0 + r < n) {
+                    for (int q = 0; q <= r; ++q) {
+                        const double dv = X[(int64_t)(i0 + r) * ld + i0 + q];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) o[v] += dv * T[q * (NB + 1) + c0 + v];
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) X[(int64_t)(i0 + r) * ld + j0 + c0 + v] = -o[v];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+    }
+    if (tid == 0) e.chol_ok[b] = 1;
+}
+
 // K(r,c) = sum_{k >= max(r,c)} X(k,r) X(k,c)   (inverse from the inverted Cholesky factor)
 template <typename T>
 __global__ __launch_bounds__(256) void chol_unpack_kernel(T* __restrict__ K, int64_t ldk,

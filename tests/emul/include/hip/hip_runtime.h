@@ -291,6 +291,9 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+inline void __builtin_amdgcn_fence(int, const char*) {}
+inline void __builtin_amdgcn_wave_barrier() { simt::wave_sync(); }
+inline void __builtin_amdgcn_s_barrier() { simt::block_barrier(); }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 

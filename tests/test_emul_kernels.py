@@ -200,22 +200,25 @@ def run_pinv(rt, dtype, A):
     return rt.mem.to_host(k, (n, n), npd)
 
 
-@pytest.mark.parametrize('n', [1, 2, 5, 10, 31, 50])
+@pytest.mark.parametrize('n', [1, 2, 5, 10, 31, 32, 33, 50, 70])
 def test_pinv_full_rank_matches_scipy(rt, n, monkeypatch=None):
-    """Both routes: Cholesky fast path (default) and the Jacobi eigen-solver (forced)."""
+    """All routes: blocked Cholesky (default), plain Cholesky, Jacobi eigen-solver (forced)."""
     import os
     import scipy.linalg as spla
     rs = np.random.RandomState(n)
     G = rs.rand(4 * n + 3, n)
     A = G.T @ G
     want = spla.pinv(A)
-    for force_jacobi in ('0', '1'):
-        os.environ['SKF_PINV_JACOBI'] = force_jacobi
+    for env in ({}, {'SKF_CHOL_UNBLOCKED': '1'}, {'SKF_PINV_JACOBI': '1'}):
+        if env.get('SKF_PINV_JACOBI') and n > 50:
+            continue
+        os.environ.update(env)
         try:
             got = run_pinv(rt, nat.SKF_F64, A)
         finally:
-            os.environ.pop('SKF_PINV_JACOBI', None)
-        assert relerr(got, want) < 1e-9 * max(1.0, np.linalg.cond(A) * 1e-3), force_jacobi
+            for k in env:
+                os.environ.pop(k, None)
+        assert relerr(got, want) < 1e-9 * max(1.0, np.linalg.cond(A) * 1e-3), env
         assert relerr(A @ got @ A, A) < 1e-11
 
 
