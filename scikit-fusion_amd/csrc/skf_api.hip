@@ -231,34 +231,41 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
     dim3 grid(cdiv(N, bn), cdiv(M, bm), splits);
     if (bm == 256) {
         // 256 x BN tile, LDS double buffer in dynamic shared memory (> 64 KiB needs the attribute)
-        const int smem = 2 * (256 + bn) * 8 * 16;
-        static bool attr_done = false;
-        if (!attr_done) {
-            const int s128 = 2 * (256 + 128) * 8 * 16, s256 = 2 * (256 + 256) * 8 * 16;
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<128, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s128));
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<128, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s128));
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<256, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s256));
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<256, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s256));
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<128, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s128));
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s128));
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<256, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s256));
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<256, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s256));
-            attr_done = true;
-        }
         dim3 block(512);
         const char* mf = getenv("SKF_BF16_MFMA");          // "32" selects the 32x32x16 flavour
         const bool mf32 = (mf && atoi(mf) == 32);           // (measured 7 % slower than 16x16x32 here)
-        if (mf32) {
-            if (bn == 128 && relation) hipLaunchKernelGGL((gemm_bf16_v2_kernel<128, 1, true>), grid, block, smem, st, g);
-            else if (bn == 128) hipLaunchKernelGGL((gemm_bf16_v2_kernel<128, 0, true>), grid, block, smem, st, g);
-            else if (relation) hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 1, true>), grid, block, smem, st, g);
-            else hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0, true>), grid, block, smem, st, g);
-        } else {
-            if (bn == 128 && relation) hipLaunchKernelGGL((gemm_bf16_v2_kernel<128, 1, false>), grid, block, smem, st, g);
-            else if (bn == 128) hipLaunchKernelGGL((gemm_bf16_v2_kernel<128, 0, false>), grid, block, smem, st, g);
-            else if (relation) hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 1, false>), grid, block, smem, st, g);
-            else hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0, false>), grid, block, smem, st, g);
-        }
+        const char* gl = getenv("SKF_BF16_GLDS");          // "0" selects register staging
+        const bool glds = !(gl && atoi(gl) == 0);
+        const char* sg = getenv("SKF_BF16_STAGES");        // "2" disables the 3-stage ring (BN = 128)
+        const bool three = glds && !mf32 && !(sg && atoi(sg) == 2);
+#define SKF_V2_LAUNCH(BN_, TAG_, MF_, GL_, NS_)                                                                   \
+    do {                                                                                                          \
+        const int smem_ = (NS_ * 256 + ((NS_ == 3 && BN_ == 256) ? 2 : NS_) * BN_) * 8 * 16;                      \
+        static bool attr_ = false;                                                                                \
+        if (!attr_) {                                                                                             \
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<BN_, TAG_, MF_, GL_, NS_>,               \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_));                      \
+            attr_ = true;                                                                                         \
+        }                                                                                                         \
+        hipLaunchKernelGGL((gemm_bf16_v2_kernel<BN_, TAG_, MF_, GL_, NS_>), grid, block, smem_, st, g);           \
+    } while (0)
+#define SKF_V2_PICK(BN_, TAG_)                                         \
+    do {                                                               \
+        if (mf32 && glds) SKF_V2_LAUNCH(BN_, TAG_, true, true, 2);     \
+        else if (mf32) SKF_V2_LAUNCH(BN_, TAG_, true, false, 2);       \
+        else if (glds) SKF_V2_LAUNCH(BN_, TAG_, false, true, 2);       \
+        else SKF_V2_LAUNCH(BN_, TAG_, false, false, 2);                \
+    } while (0)
+        if (three && bn == 128 && relation) SKF_V2_LAUNCH(128, 1, false, true, 3);
+        else if (three && bn == 128) SKF_V2_LAUNCH(128, 0, false, true, 3);
+        else if (three && relation) SKF_V2_LAUNCH(256, 1, false, true, 3);
+        else if (three) SKF_V2_LAUNCH(256, 0, false, true, 3);
+        else if (bn == 128 && relation) SKF_V2_PICK(128, 1);
+        else if (bn == 128) SKF_V2_PICK(128, 0);
+        else if (relation) SKF_V2_PICK(256, 1);
+        else SKF_V2_PICK(256, 0);
+#undef SKF_V2_PICK
+#undef SKF_V2_LAUNCH
     } else {
         dim3 block(256);
         if (bn == 128 && relation) hipLaunchKernelGGL((gemm_bf16_kernel<128, 1>), grid, block, 0, st, g);

@@ -152,10 +152,14 @@ template <> struct Mfma<double> {         // v_mfma_f64_16x16x4_f64: 4 f64 accum
 // ------------------------------------------------------------------------------------------
 constexpr int GEMM_THREADS = 256;
 
-template <typename T, typename TS, int ROWS, int BK>
-__device__ __forceinline__ void stage_load(T (&reg)[ROWS * BK / GEMM_THREADS], const TS* __restrict__ src,
+// stage_load only issues loads (indices clamped into the matrix, raw storage type, no use of
+// the loaded value -> no wait, no divergent branch); conversion, the Theta+/- operand op and the
+// zero fill of the K tail happen in stage_store, after the MFMA work that hides the latency.
+// Rows past the end need no zero fill: they only feed accumulator rows that are never stored.
+template <typename TS, int ROWS, int BK>
+__device__ __forceinline__ void stage_load(TS (&reg)[ROWS * BK / GEMM_THREADS], const TS* __restrict__ src,
                                            int64_t s_row, int64_t s_k, int row0, int k0, int row_end,
-                                           int k_end, int aop, int tid) {
+                                           int k_end, int tid) {
     constexpr int PER = ROWS * BK / GEMM_THREADS;
     const bool k_fast = (s_k == 1);
 #pragma unroll
@@ -163,23 +167,24 @@ __device__ __forceinline__ void stage_load(T (&reg)[ROWS * BK / GEMM_THREADS], c
         const int e = tid + i * GEMM_THREADS;
         const int k = k_fast ? (e % BK) : (e / ROWS);
         const int r = k_fast ? (e / BK) : (e % ROWS);
-        const int gr = row0 + r, gk = k0 + k;
-        T v = (T)0;
-        if (gr < row_end && gk < k_end) v = (T)src[(int64_t)gr * s_row + (int64_t)gk * s_k];
-        reg[i] = apply_aop(v, aop);
+        int gr = row0 + r, gk = k0 + k;
+        gr = gr < row_end ? gr : row_end - 1;
+        gk = gk < k_end ? gk : k_end - 1;
+        reg[i] = src[(int64_t)gr * s_row + (int64_t)gk * s_k];
     }
 }
 
-template <typename T, int ROWS, int BK, int LD>
-__device__ __forceinline__ void stage_store(T (*lds)[LD], const T (&reg)[ROWS * BK / GEMM_THREADS],
-                                            bool k_fast, int tid) {
+template <typename T, typename TS, int ROWS, int BK, int LD>
+__device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS * BK / GEMM_THREADS],
+                                            bool k_fast, int k0, int k_end, int aop, int tid) {
     constexpr int PER = ROWS * BK / GEMM_THREADS;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int e = tid + i * GEMM_THREADS;
         const int k = k_fast ? (e % BK) : (e / ROWS);
         const int r = k_fast ? (e / BK) : (e % ROWS);
-        lds[k][r] = reg[i];
+        T v = apply_aop((T)reg[i], aop);
+        lds[k][r] = (k0 + k < k_end) ? v : (T)0;
     }
 }
 
@@ -221,21 +226,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < MF::NREG; ++r) acc[i][j][r] = (T)0;
 
-    T ra[BM * BK / GEMM_THREADS], rb[BN * BK / GEMM_THREADS];
+    TA ra[BM * BK / GEMM_THREADS];
+    TB rb[BN * BK / GEMM_THREADS];
     const int nkt = (kz1 - kz0 + BK - 1) / BK;
     if (nkt > 0) {
-        stage_load<T, TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, kz0, g.M, kz1, g.aop, tid);
-        stage_load<T, TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, kz0, g.N, kz1, AOP_NONE, tid);
-        stage_store<T, BM, BK, LDA>(As, ra, a_kfast, tid);
-        stage_store<T, BN, BK, LDB>(Bs, rb, b_kfast, tid);
+        stage_load<TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, kz0, g.M, kz1, tid);
+        stage_load<TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, kz0, g.N, kz1, tid);
+        stage_store<T, TA, BM, BK, LDA>(As, ra, a_kfast, kz0, kz1, g.aop, tid);
+        stage_store<T, TB, BN, BK, LDB>(Bs, rb, b_kfast, kz0, kz1, AOP_NONE, tid);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const bool more = (kt + 1 < nkt);
+        const int k_next = kz0 + (kt + 1) * BK;
         if (more) {
-            const int k0 = kz0 + (kt + 1) * BK;
-            stage_load<T, TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, k0, g.M, kz1, g.aop, tid);
-            stage_load<T, TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, k0, g.N, kz1, AOP_NONE, tid);
+            stage_load<TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, k_next, g.M, kz1, tid);
+            stage_load<TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, k_next, g.N, kz1, tid);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += MF::KT) {
@@ -252,8 +258,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
         }
         __syncthreads();
         if (more) {
-            stage_store<T, BM, BK, LDA>(As, ra, a_kfast, tid);
-            stage_store<T, BN, BK, LDB>(Bs, rb, b_kfast, tid);
+            stage_store<T, TA, BM, BK, LDA>(As, ra, a_kfast, k_next, kz1, g.aop, tid);
+            stage_store<T, TB, BN, BK, LDB>(Bs, rb, b_kfast, k_next, kz1, AOP_NONE, tid);
         }
         __syncthreads();
     }
@@ -342,7 +348,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void side_update_kernel(SideArgs a) {
 #pragma unroll
             for (int r = 0; r < MF::NREG; ++r) accE[i][j][r] = (T)0;
 
-    T ra[BM * BK / GEMM_THREADS], rb[BN * BK / GEMM_THREADS], rb2[BN * BK / GEMM_THREADS];
+    T ra[BM * BK / GEMM_THREADS];
+    TB rb[BN * BK / GEMM_THREADS], rb2[BN * BK / GEMM_THREADS];
 
     // ---- phase 1: accE = X * Sop
     {
@@ -350,11 +357,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void side_update_kernel(SideArgs a) {
         const TB* S = (const TB*)a.Sop;
         const bool s_kfast = (a.ss_k == 1);
         for (int k0 = 0; k0 < a.k1; k0 += BK) {
-            stage_load<T, T, BM, BK>(ra, X, a.ldx, 1, bm0, k0, a.n, a.k1, AOP_NONE, tid);
-            stage_load<T, TB, BN, BK>(rb, S, a.ss_n, a.ss_k, bn0, k0, a.c, a.k1, AOP_NONE, tid);
+            stage_load<T, BM, BK>(ra, X, a.ldx, 1, bm0, k0, a.n, a.k1, tid);
+            stage_load<TB, BN, BK>(rb, S, a.ss_n, a.ss_k, bn0, k0, a.c, a.k1, tid);
             __syncthreads();
-            stage_store<T, BM, BK, LDA>(As, ra, true, tid);
-            stage_store<T, BN, BK, LDB>(Bs, rb, s_kfast, tid);
+            stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.k1, AOP_NONE, tid);
+            stage_store<T, TB, BN, BK, LDB>(Bs, rb, s_kfast, k0, a.k1, AOP_NONE, tid);
             __syncthreads();
 #pragma unroll
             for (int kk = 0; kk < BK; kk += MF::KT) {
@@ -389,13 +396,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void side_update_kernel(SideArgs a) {
         const TB* Bn = (const TB*)a.Bn;
         const TB* Bp = (const TB*)a.Bp;
         for (int k0 = 0; k0 < a.c; k0 += BK) {
-            stage_load<T, T, BM, BK>(ra, G, a.ldg, 1, bm0, k0, a.n, a.c, AOP_NONE, tid);
-            stage_load<T, TB, BN, BK>(rb, Bn, 1, a.ldb, bn0, k0, a.c, a.c, AOP_NONE, tid);
-            stage_load<T, TB, BN, BK>(rb2, Bp, 1, a.ldb, bn0, k0, a.c, a.c, AOP_NONE, tid);
+            stage_load<T, BM, BK>(ra, G, a.ldg, 1, bm0, k0, a.n, a.c, tid);
+            stage_load<TB, BN, BK>(rb, Bn, 1, a.ldb, bn0, k0, a.c, a.c, tid);
+            stage_load<TB, BN, BK>(rb2, Bp, 1, a.ldb, bn0, k0, a.c, a.c, tid);
             __syncthreads();
-            stage_store<T, BM, BK, LDA>(As, ra, true, tid);
-            stage_store<T, BN, BK, LDB>(Bs, rb, a.ldb == 1, tid);
-            stage_store<T, BN, BK, LDB>(Bs2, rb2, a.ldb == 1, tid);
+            stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.c, AOP_NONE, tid);
+            stage_store<T, TB, BN, BK, LDB>(Bs, rb, a.ldb == 1, k0, a.c, AOP_NONE, tid);
+            stage_store<T, TB, BN, BK, LDB>(Bs2, rb2, a.ldb == 1, k0, a.c, AOP_NONE, tid);
             __syncthreads();
 #pragma unroll
             for (int kk = 0; kk < BK; kk += MF::KT) {
@@ -463,13 +470,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_valu_kernel(GemmArgs g) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (T)0;
-    T ra[BM * BK / GEMM_THREADS], rb[BN * BK / GEMM_THREADS];
+    TA ra[BM * BK / GEMM_THREADS];
+    TB rb[BN * BK / GEMM_THREADS];
     for (int k0 = kz0; k0 < kz1; k0 += BK) {
-        stage_load<T, TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, k0, g.M, kz1, g.aop, tid);
-        stage_load<T, TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, k0, g.N, kz1, AOP_NONE, tid);
+        stage_load<TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, k0, g.M, kz1, tid);
+        stage_load<TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, k0, g.N, kz1, tid);
         __syncthreads();
-        stage_store<T, BM, BK, LDT>(As, ra, a_kfast, tid);
-        stage_store<T, BN, BK, LDT>(Bs, rb, b_kfast, tid);
+        stage_store<T, TA, BM, BK, LDT>(As, ra, a_kfast, k0, kz1, g.aop, tid);
+        stage_store<T, TB, BN, BK, LDT>(Bs, rb, b_kfast, k0, kz1, AOP_NONE, tid);
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < BK; ++kk) {
@@ -657,7 +665,16 @@ __device__ __forceinline__ int swz_chunk32(int row, int chunk) { return row * 8 
 
 // MF32 = true: v_mfma_f32_32x32x16_bf16 (lane l: A[row = l&31][k = 8*(l>>5) .. +7], 16 f32
 // results per lane) -- half the MFMA instructions of the 16x16x32 flavour for the same tile.
-template <int BN, int TAG, bool MF32>
+// GLDS = true: the tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB = 8 swizzled
+// rows per wave instruction; the swizzle is applied to the per-lane SOURCE address because the
+// LDS destination of a wave instruction is linear), no staging registers, no ds_write pass.
+// NSTAGE = 3 (LDS-DMA only): the A operand (the relation, streamed from HBM) lives in a ring of
+// three 32 KiB buffers, so two of its K tiles are in flight while one is consumed.  The B
+// operand (G^T, served by L2) has three buffers at BN = 128 (3 x 48 KiB in total) and two at
+// BN = 256 (3 x 32 + 2 x 32 KiB = the whole 160 KiB LDS); it is issued BEFORE the A tile so
+// that a COUNTED s_waitcnt vmcnt(PW_A) leaves exactly the newest A tile outstanding.  The
+// workgroup meets at a raw s_barrier: __syncthreads() would drain every LDS-DMA (vmcnt(0)).
+template <int BN, int TAG, bool MF32, bool GLDS, int NSTAGE>
 __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     constexpr int BM = 256, BK = 64;
     constexpr int WN = BN / 2;
@@ -665,7 +682,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     constexpr int NJ32 = WN / 32;           // 32-wide column blocks (32x32x16 flavour)
     constexpr int A_PER = BM / 64;          // 512 threads cover 64 rows x 8 chunks per pass
     constexpr int B_PER = BN / 64;
-    constexpr int BUF = (BM + BN) * 8;      // u32x4 entries per buffer
+    constexpr int AST = NSTAGE;                                  // A ring depth
+    constexpr int BST = (NSTAGE == 3 && BN == 256) ? 2 : NSTAGE;  // B ring depth
+    constexpr int ASZ = BM * 8, BSZ = BN * 8;                   // u32x4 entries per buffer
     HIP_DYNAMIC_SHARED(u32x4, smem)
 
     const int tid = threadIdx.x;
@@ -715,8 +734,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
         }
     };
     auto store_tiles = [&](int buf) {
-        u32x4* As = smem + buf * BUF;
-        u32x4* Bs = As + BM * 8;
+        u32x4* As = smem + buf * ASZ;
+        u32x4* Bs = smem + AST * ASZ + buf * BSZ;
 #pragma unroll
         for (int p = 0; p < A_PER; ++p) {
             const int r = srow + 64 * p;
@@ -729,17 +748,93 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
         }
     };
 
+    // direct global -> LDS copy of one K tile of A / B: wave w fills 8-row blocks w*NBLK .. +NBLK-1
+    const int rr = lane >> 3, pc = lane & 7;
+    auto dma_A = [&](int k0, int buf) {
+        u32x4* Ad = smem + buf * ASZ;
+#pragma unroll
+        for (int p = 0; p < BM / 64; ++p) {
+            const int blk = wave * (BM / 64) + p;
+            const int row = blk * 8 + rr;
+            const int c = MF32 ? (pc ^ ((row >> 1) & 7)) : (pc ^ (row & 7));
+            const int m = bm0 + row;
+            const int mc = m < g.M ? m : g.M - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g.A + (int64_t)mc * g.lda + k0 + c * 8),
+                (__attribute__((address_space(3))) void*)(Ad + blk * 64), 16, 0, 0);
+        }
+    };
+    auto dma_B = [&](int k0, int buf) {
+        u32x4* Bd = smem + AST * ASZ + buf * BSZ;
+#pragma unroll
+        for (int p = 0; p < BN / 64; ++p) {
+            const int blk = wave * (BN / 64) + p;
+            const int row = blk * 8 + rr;
+            const int c = MF32 ? (pc ^ ((row >> 1) & 7)) : (pc ^ (row & 7));
+            const int n = bn0 + row;
+            const int nc = n < g.N ? n : g.N - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + k0 + c * 8),
+                (__attribute__((address_space(3))) void*)(Bd + blk * 64), 16, 0, 0);
+        }
+    };
+
+    constexpr int PWA = BM / 64, PWB = BN / 64;          // LDS-DMA instructions per wave and K tile
+    // instructions allowed to stay outstanding when the NEXT tile must be complete
+    constexpr int KEEP = (BST == 3) ? (PWA + PWB) : PWA;
+    static_assert(NSTAGE == 2 || (NSTAGE == 3 && GLDS), "3 stages need the LDS-DMA path");
     if (nkt > 0) {
-        load_tiles(kz0);
-        store_tiles(0);
+        if constexpr (GLDS) {
+            dma_A(kz0, 0);
+            dma_B(kz0, 0);
+            if constexpr (NSTAGE == 3) {
+                if (nkt > 1) {
+                    dma_A(kz0 + BK, 1);
+                    if constexpr (BST == 3) dma_B(kz0 + BK, 1);
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | KEEP);    // tile 0 has landed
+                } else {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the LDS-DMA has landed
+            }
+        } else {
+            load_tiles(kz0);
+            store_tiles(0);
+        }
     }
-    __syncthreads();
+    if constexpr (NSTAGE == 3) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else {
+        __syncthreads();
+    }
     for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
+        const int cur = kt % AST;
+        const int curb = kt % BST;
         const bool more = (kt + 1 < nkt);
-        if (more) load_tiles(kz0 + (kt + 1) * BK);
-        const u32x4* As = smem + cur * BUF;
-        const u32x4* Bs = As + BM * 8;
+        if constexpr (NSTAGE == 3) {
+            // every buffer refilled here was last read in iteration kt-1 and released by its barrier
+            if constexpr (BST == 3) {
+                if (kt + 2 < nkt) {
+                    dma_A(kz0 + (kt + 2) * BK, (kt + 2) % 3);
+                    dma_B(kz0 + (kt + 2) * BK, (kt + 2) % 3);
+                }
+            } else {
+                if (more) dma_B(kz0 + (kt + 1) * BK, (kt + 1) & 1);          // B first ...
+                if (kt + 2 < nkt) dma_A(kz0 + (kt + 2) * BK, (kt + 2) % 3);  // ... newest = A(kt+2)
+            }
+        } else if (more) {
+            if constexpr (GLDS) {
+                dma_A(kz0 + (kt + 1) * BK, cur ^ 1);
+                dma_B(kz0 + (kt + 1) * BK, cur ^ 1);
+            } else {
+                load_tiles(kz0 + (kt + 1) * BK);
+            }
+        }
+        const u32x4* As = smem + cur * ASZ;
+        const u32x4* Bs = smem + AST * ASZ + curb * BSZ;
         if constexpr (MF32) {
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
@@ -775,8 +870,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (more) store_tiles(cur ^ 1);
-        __syncthreads();
+        if constexpr (NSTAGE == 3) {
+            // tile kt+1 must have landed; tile kt+2 (if it was issued) may stay in flight.
+            // lgkmcnt(0): this wave's fragment reads of buffer `cur` are done before it is refilled.
+            if (kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0070 | KEEP);
+            else __builtin_amdgcn_s_waitcnt(0x0070);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            if constexpr (GLDS) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) before the barrier publishes the tile
+            } else {
+                if (more) store_tiles(cur ^ 1);
+            }
+            __syncthreads();
+        }
     }
 
     float* out = (gridDim.z > 1) ? g.part + (int64_t)blockIdx.z * g.M * g.N : g.C;

@@ -291,6 +291,14 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+inline void __builtin_amdgcn_s_waitcnt(int) {}
+// LDS-DMA: destination = the FIRST lane's LDS pointer + lane * size (wave-linear), source per lane
+template <class PS, class PD>
+inline void __builtin_amdgcn_global_load_lds(PS src, PD dst, unsigned size, int offset, unsigned) {
+    unsigned char* base = (unsigned char*)simt::wave_read((uintptr_t)dst, 0);
+    memcpy(base + (size_t)simt::lane_id() * size, (const unsigned char*)(uintptr_t)src + offset, size);
+    simt::wave_sync();
+}
 inline void __builtin_amdgcn_fence(int, const char*) {}
 inline void __builtin_amdgcn_wave_barrier() { simt::wave_sync(); }
 inline void __builtin_amdgcn_s_barrier() { simt::block_barrier(); }

@@ -1,5 +1,5 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1l; export TMPDIR=/tmp
-python __graft_entry__.py > gpurun_out/r1l/build.log 2>&1
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1r; export TMPDIR=/tmp
+python __graft_entry__.py > gpurun_out/r1r/build.log 2>&1
 python -m pytest tests -m gpu -q -k "bf16" 2>&1 | tail -3
-echo "== mfma 32x32x16"; python tools/bench_gemm_bf16.py --shapes P12,Q12,Q23 --tiles 256 --splits 0 
-echo "== mfma 16x16x32"; SKF_BF16_MFMA=16 python tools/bench_gemm_bf16.py --shapes P12,Q12,Q23 --tiles 256 --splits 0
+echo "== 3-stage A ring (default)"; python tools/bench_gemm_bf16.py --shapes P12,Q12,P13,Q13,P23,Q23 --tiles 256 --splits 0
+echo "== 2-stage"; SKF_BF16_STAGES=2 python tools/bench_gemm_bf16.py --shapes P12,Q23 --tiles 256 --splits 0
