@@ -27,6 +27,7 @@ namespace skf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 enum AOp { AOP_NONE = 0, AOP_POS = 1, AOP_NEG = 2 };                 // x, max(x,0), max(-x,0)
 enum Epi {
@@ -156,35 +157,113 @@ constexpr int GEMM_THREADS = 256;
 // the loaded value -> no wait, no divergent branch); conversion, the Theta+/- operand op and the
 // zero fill of the K tail happen in stage_store, after the MFMA work that hides the latency.
 // Rows past the end need no zero fill: they only feed accumulator rows that are never stored.
+//
+// mode (wave-uniform, chosen once per launch by stage_mode):
+//   STAGE_SCALAR  one element per load (any strides, any alignment)
+//   STAGE_VEC_K   16-byte loads along a K-contiguous operand   (element (r, k..k+V-1))
+//   STAGE_VEC_R   16-byte loads along a row-contiguous operand (element (r..r+V-1, k))
+enum { STAGE_SCALAR = 0, STAGE_VEC_K = 1, STAGE_VEC_R = 2 };
+
+template <typename TS>
+__device__ __forceinline__ int stage_mode(const TS* src, int64_t s_row, int64_t s_k, int row_end, int k_lo, int k_end) {
+    constexpr int V = 16 / (int)sizeof(TS);
+    const bool aligned = (((uintptr_t)src) & 15) == 0;
+    if (s_k == 1 && aligned && s_row % V == 0 && k_end % V == 0 && k_lo % V == 0) return STAGE_VEC_K;
+    if (s_row == 1 && aligned && s_k % V == 0 && row_end % V == 0) return STAGE_VEC_R;
+    return STAGE_SCALAR;
+}
+
 template <typename TS, int ROWS, int BK>
 __device__ __forceinline__ void stage_load(TS (&reg)[ROWS * BK / GEMM_THREADS], const TS* __restrict__ src,
                                            int64_t s_row, int64_t s_k, int row0, int k0, int row_end,
-                                           int k_end, int tid) {
+                                           int k_end, int tid, int mode = STAGE_SCALAR) {
     constexpr int PER = ROWS * BK / GEMM_THREADS;
-    const bool k_fast = (s_k == 1);
+    constexpr int V = 16 / (int)sizeof(TS);
+    union Vec { u32x4 v; TS t[V]; };
+    if (PER % V != 0) mode = STAGE_SCALAR;          // tile too small for whole vectors per thread
+    if (mode == STAGE_VEC_K) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int e = tid + i * GEMM_THREADS;
-        const int k = k_fast ? (e % BK) : (e / ROWS);
-        const int r = k_fast ? (e / BK) : (e % ROWS);
-        int gr = row0 + r, gk = k0 + k;
-        gr = gr < row_end ? gr : row_end - 1;
-        gk = gk < k_end ? gk : k_end - 1;
-        reg[i] = src[(int64_t)gr * s_row + (int64_t)gk * s_k];
+        for (int i = 0; i < PER / V; ++i) {
+            const int e = tid + i * GEMM_THREADS;
+            const int k = (e % (BK / V)) * V;
+            const int r = e / (BK / V);
+            int gr = row0 + r, gk = k0 + k;
+            gr = gr < row_end ? gr : row_end - 1;
+            gk = gk < k_end ? gk : k_end - V;               // K tail: a whole in-bounds vector
+            Vec u;
+            u.v = *(const u32x4*)(src + (int64_t)gr * s_row + gk);
+#pragma unroll
+            for (int j = 0; j < V; ++j) reg[i * V + j] = u.t[j];
+        }
+    } else if (mode == STAGE_VEC_R) {
+#pragma unroll
+        for (int i = 0; i < PER / V; ++i) {
+            const int e = tid + i * GEMM_THREADS;
+            const int r = (e % (ROWS / V)) * V;
+            const int k = e / (ROWS / V);
+            int gr = row0 + r, gk = k0 + k;
+            gr = gr < row_end ? gr : row_end - V;
+            gk = gk < k_end ? gk : k_end - 1;
+            Vec u;
+            u.v = *(const u32x4*)(src + gr + (int64_t)gk * s_k);
+#pragma unroll
+            for (int j = 0; j < V; ++j) reg[i * V + j] = u.t[j];
+        }
+    } else {
+        const bool k_fast = (s_k == 1);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * GEMM_THREADS;
+            const int k = k_fast ? (e % BK) : (e / ROWS);
+            const int r = k_fast ? (e / BK) : (e % ROWS);
+            int gr = row0 + r, gk = k0 + k;
+            gr = gr < row_end ? gr : row_end - 1;
+            gk = gk < k_end ? gk : k_end - 1;
+            reg[i] = src[(int64_t)gr * s_row + (int64_t)gk * s_k];
+        }
     }
 }
 
 template <typename T, typename TS, int ROWS, int BK, int LD>
 __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS * BK / GEMM_THREADS],
-                                            bool k_fast, int k0, int k_end, int aop, int tid) {
+                                            bool k_fast, int k0, int k_end, int aop, int tid,
+                                            int mode = STAGE_SCALAR) {
     constexpr int PER = ROWS * BK / GEMM_THREADS;
+    constexpr int V = 16 / (int)sizeof(TS);
+    if (PER % V != 0) mode = STAGE_SCALAR;
+    if (mode == STAGE_VEC_K) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int e = tid + i * GEMM_THREADS;
-        const int k = k_fast ? (e % BK) : (e / ROWS);
-        const int r = k_fast ? (e / BK) : (e % ROWS);
-        T v = apply_aop((T)reg[i], aop);
-        lds[k][r] = (k0 + k < k_end) ? v : (T)0;
+        for (int i = 0; i < PER / V; ++i) {
+            const int e = tid + i * GEMM_THREADS;
+            const int k = (e % (BK / V)) * V;
+            const int r = e / (BK / V);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                T v = apply_aop((T)reg[i * V + j], aop);
+                lds[k + j][r] = (k0 + k + j < k_end) ? v : (T)0;
+            }
+        }
+    } else if (mode == STAGE_VEC_R) {
+#pragma unroll
+        for (int i = 0; i < PER / V; ++i) {
+            const int e = tid + i * GEMM_THREADS;
+            const int r = (e % (ROWS / V)) * V;
+            const int k = e / (ROWS / V);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                T v = apply_aop((T)reg[i * V + j], aop);
+                lds[k][r + j] = (k0 + k < k_end) ? v : (T)0;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * GEMM_THREADS;
+            const int k = k_fast ? (e % BK) : (e / ROWS);
+            const int r = k_fast ? (e / BK) : (e % ROWS);
+            T v = apply_aop((T)reg[i], aop);
+            lds[k][r] = (k0 + k < k_end) ? v : (T)0;
+        }
     }
 }
 
@@ -229,19 +308,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
     TA ra[BM * BK / GEMM_THREADS];
     TB rb[BN * BK / GEMM_THREADS];
     const int nkt = (kz1 - kz0 + BK - 1) / BK;
+    const int ma = stage_mode<TA>(A, g.sa_m, g.sa_k, g.M, kz0, kz1);
+    const int mb = stage_mode<TB>(B, g.sb_n, g.sb_k, g.N, kz0, kz1);
     if (nkt > 0) {
-        stage_load<TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, kz0, g.M, kz1, tid);
-        stage_load<TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, kz0, g.N, kz1, tid);
-        stage_store<T, TA, BM, BK, LDA>(As, ra, a_kfast, kz0, kz1, g.aop, tid);
-        stage_store<T, TB, BN, BK, LDB>(Bs, rb, b_kfast, kz0, kz1, AOP_NONE, tid);
+        stage_load<TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, kz0, g.M, kz1, tid, ma);
+        stage_load<TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, kz0, g.N, kz1, tid, mb);
+        stage_store<T, TA, BM, BK, LDA>(As, ra, a_kfast, kz0, kz1, g.aop, tid, ma);
+        stage_store<T, TB, BN, BK, LDB>(Bs, rb, b_kfast, kz0, kz1, AOP_NONE, tid, mb);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const bool more = (kt + 1 < nkt);
         const int k_next = kz0 + (kt + 1) * BK;
         if (more) {
-            stage_load<TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, k_next, g.M, kz1, tid);
-            stage_load<TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, k_next, g.N, kz1, tid);
+            stage_load<TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, k_next, g.M, kz1, tid, ma);
+            stage_load<TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, k_next, g.N, kz1, tid, mb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += MF::KT) {
@@ -258,8 +339,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
         }
         __syncthreads();
         if (more) {
-            stage_store<T, TA, BM, BK, LDA>(As, ra, a_kfast, k_next, kz1, g.aop, tid);
-            stage_store<T, TB, BN, BK, LDB>(Bs, rb, b_kfast, k_next, kz1, AOP_NONE, tid);
+            stage_store<T, TA, BM, BK, LDA>(As, ra, a_kfast, k_next, kz1, g.aop, tid, ma);
+            stage_store<T, TB, BN, BK, LDB>(Bs, rb, b_kfast, k_next, kz1, AOP_NONE, tid, mb);
         }
         __syncthreads();
     }
@@ -356,12 +437,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void side_update_kernel(SideArgs a) {
         const T* X = (const T*)a.X;
         const TB* S = (const TB*)a.Sop;
         const bool s_kfast = (a.ss_k == 1);
+        const int mx = stage_mode<T>(X, a.ldx, 1, a.n, 0, a.k1);
+        const int ms = stage_mode<TB>(S, a.ss_n, a.ss_k, a.c, 0, a.k1);
         for (int k0 = 0; k0 < a.k1; k0 += BK) {
-            stage_load<T, BM, BK>(ra, X, a.ldx, 1, bm0, k0, a.n, a.k1, tid);
-            stage_load<TB, BN, BK>(rb, S, a.ss_n, a.ss_k, bn0, k0, a.c, a.k1, tid);
+            stage_load<T, BM, BK>(ra, X, a.ldx, 1, bm0, k0, a.n, a.k1, tid, mx);
+            stage_load<TB, BN, BK>(rb, S, a.ss_n, a.ss_k, bn0, k0, a.c, a.k1, tid, ms);
             __syncthreads();
-            stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.k1, AOP_NONE, tid);
-            stage_store<T, TB, BN, BK, LDB>(Bs, rb, s_kfast, k0, a.k1, AOP_NONE, tid);
+            stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.k1, AOP_NONE, tid, mx);
+            stage_store<T, TB, BN, BK, LDB>(Bs, rb, s_kfast, k0, a.k1, AOP_NONE, tid, ms);
             __syncthreads();
 #pragma unroll
             for (int kk = 0; kk < BK; kk += MF::KT) {
@@ -395,14 +478,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void side_update_kernel(SideArgs a) {
         const T* G = (const T*)a.G;
         const TB* Bn = (const TB*)a.Bn;
         const TB* Bp = (const TB*)a.Bp;
+        const int mg = stage_mode<T>(G, a.ldg, 1, a.n, 0, a.c);
+        const int mbn = stage_mode<TB>(Bn, 1, a.ldb, a.c, 0, a.c);
+        const int mbp = stage_mode<TB>(Bp, 1, a.ldb, a.c, 0, a.c);
         for (int k0 = 0; k0 < a.c; k0 += BK) {
-            stage_load<T, BM, BK>(ra, G, a.ldg, 1, bm0, k0, a.n, a.c, tid);
-            stage_load<TB, BN, BK>(rb, Bn, 1, a.ldb, bn0, k0, a.c, a.c, tid);
-            stage_load<TB, BN, BK>(rb2, Bp, 1, a.ldb, bn0, k0, a.c, a.c, tid);
+            stage_load<T, BM, BK>(ra, G, a.ldg, 1, bm0, k0, a.n, a.c, tid, mg);
+            stage_load<TB, BN, BK>(rb, Bn, 1, a.ldb, bn0, k0, a.c, a.c, tid, mbn);
+            stage_load<TB, BN, BK>(rb2, Bp, 1, a.ldb, bn0, k0, a.c, a.c, tid, mbp);
             __syncthreads();
-            stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.c, AOP_NONE, tid);
-            stage_store<T, TB, BN, BK, LDB>(Bs, rb, a.ldb == 1, k0, a.c, AOP_NONE, tid);
-            stage_store<T, TB, BN, BK, LDB>(Bs2, rb2, a.ldb == 1, k0, a.c, AOP_NONE, tid);
+            stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.c, AOP_NONE, tid, mg);
+            stage_store<T, TB, BN, BK, LDB>(Bs, rb, a.ldb == 1, k0, a.c, AOP_NONE, tid, mbn);
+            stage_store<T, TB, BN, BK, LDB>(Bs2, rb2, a.ldb == 1, k0, a.c, AOP_NONE, tid, mbp);
             __syncthreads();
 #pragma unroll
             for (int kk = 0; kk < BK; kk += MF::KT) {
@@ -543,7 +629,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_valu_kernel(GemmArgs g) {
 // One K step: [global loads of tile t+1 in flight] 2 x {fragment reads, MFMAs} | barrier |
 //             registers -> LDS | barrier.
 // ------------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct Bf16GemmArgs {

@@ -1,5 +1,3 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1r; export TMPDIR=/tmp
-python __graft_entry__.py > gpurun_out/r1r/build.log 2>&1
-python -m pytest tests -m gpu -q -k "bf16" 2>&1 | tail -3
-echo "== 3-stage A ring (default)"; python tools/bench_gemm_bf16.py --shapes P12,Q12,P13,Q13,P23,Q23 --tiles 256 --splits 0
-echo "== 2-stage"; SKF_BF16_STAGES=2 python tools/bench_gemm_bf16.py --shapes P12,Q23 --tiles 256 --splits 0
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1u; export TMPDIR=/tmp
+python __graft_entry__.py > gpurun_out/r1u/build.log 2>&1
+python tools/bench_gemm_f32.py 2>&1 | grep -v amdgpu.ids
