@@ -89,6 +89,10 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['f32', 'f64', 'bf16'])
     ap.add_argument('--scale', type=float, default=1.0, help='linear scale of the object counts')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', default='restarts', choices=['restarts', 'relations'],
+                    help='N>1: one independent restart per GPU (weak scaling, no collective; default) or '
+                         'ONE fit with its relations partitioned over the GPUs and an RCCL all-reduce of the '
+                         'E/D accumulators per iteration (strong scaling)')
     args = ap.parse_args()
 
     import torch
@@ -110,14 +114,22 @@ def main():
     from skfusion_amd._engine import DevicePlan, fill_uniform
 
     n = sizes(args.scale)
-    rels = [(i, j, fill_uniform((n[i], n[j]), s, args.dtype), None) for i, j, s in PAIRS]
+    sharded = (args.mode == 'relations' and world > 1)
+    pairs = PAIRS
+    if sharded:                        # this rank keeps only its share of the relations
+        from skfusion_amd._distributed import partition_relations
+        owner, _ = partition_relations([(i, j, None, None) for i, j, _ in PAIRS], [], n, RANKS)
+        pairs = [pr for pr, o in zip(PAIRS, owner) if o == rank]
+    rels = [(i, j, fill_uniform((n[i], n[j]), s, args.dtype), None) for i, j, s in pairs]
     plan = DevicePlan(TYPES, n, RANKS, rels, [], nat.SKF_DFMF, dtype=args.dtype)
     if args.dtype == 'bf16':          # the plan keeps its own padded bf16 copies of R and R^T
         del rels[:]
         plan._keep = []
         torch.cuda.empty_cache()
     for k, t in enumerate(TYPES):      # one random restart per rank: G0 seed depends on the rank
-        plan.set_factor(t, fill_uniform((n[t], RANKS[t]), 100 + 10 * rank + k, MASTER[args.dtype]))
+        seed = 100 + k + (0 if sharded else 10 * rank)       # sharded: replicated factors
+        plan.set_factor(t, fill_uniform((n[t], RANKS[t]), seed, MASTER[args.dtype]))
+    step = plan.iterate_sharded if sharded else plan.iterate
 
     def sync():
         torch.cuda.synchronize()
@@ -125,11 +137,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    plan.iterate(args.warmup)
+    step(args.warmup)
     sync()
     plan.set_profiling(True)
     t0 = time.perf_counter()
-    plan.iterate(args.steps)
+    step(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     k_ms, k_launches, k_flops = plan.get_profile()
@@ -140,8 +152,9 @@ def main():
         elapsed = float(tt.item())
 
     rmse = {}
-    for k, (i, j, _) in enumerate(PAIRS):
+    for k, (i, j, _) in enumerate(pairs):
         rmse['%s-%s' % (i, j)] = float(np.sqrt(plan.relation_sqerr(k) / (n[i] * n[j])))
+    units = 1 if sharded else world        # fits advanced per step by the whole job
 
     if rank == 0:
         traffic = None          # HBM bytes per launch from the separate PMC passes (profiles/)
@@ -156,21 +169,21 @@ def main():
         peak = PEAK_TFLOPS[args.dtype]
         out = {
             'metric': 'DFMF update iters/sec (+ reconstruction RMSE), 3-relation graph @ ranks 128/256/256',
-            'value': world * args.steps / elapsed,
+            'value': units * args.steps / elapsed,
             'unit': 'iters/s',
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': 'strong' if sharded else 'weak',
             'vs_baseline': None,
             'dtype': args.dtype,
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[2]: synthetic dense 3-type graph %dx%d / %dx%d / %dx%d, '
                                    'ranks 128/256/256, Dfmf, one random restart per GPU'
                                    % (n['t1'], n['t2'], n['t1'], n['t3'], n['t2'], n['t3']),
-                       'scale': args.scale, 'restarts': world,
+                       'scale': args.scale, 'restarts': units, 'mode': args.mode,
                        'alg_flops_per_iter': alg_flops(n)},
             'rmse': rmse,
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',

@@ -118,6 +118,19 @@ int skf_get_backbone(const skf_plan* plan, int32_t rel, void* S, int64_t ld, voi
  * (_dfmf.py:239 vs :295, return :327). */
 int skf_iterate(skf_plan* plan, int32_t n_iters, void* stream);
 
+/* The same iteration in two halves, for runs whose relations are partitioned over several GPUs
+ * (one process and one plan per GPU, each plan holding ALL object types but only its share of
+ * the relations / constraints; factors replicated):
+ *     skf_accumulate   : Gram, pinv, contractions, backbones and the E / D accumulator sums of
+ *                        the plan's own relations and constraints
+ *     <all-reduce(sum) of the accumulator range over the ranks -- RCCL via torch.distributed>
+ *     skf_apply_update : G <- G * sqrt(E / max(D, eps))          (identical on every rank)
+ * skf_accumulator_range reports the byte range [offset, offset+bytes) of the workspace that
+ * holds every E and D matrix (master dtype; padding between slots is zero-safe to reduce). */
+int skf_accumulate(skf_plan* plan, void* stream);
+int skf_apply_update(skf_plan* plan, void* stream);
+int skf_accumulator_range(const skf_plan* plan, size_t* offset, size_t* bytes);
+
 /* sum over the relation of (R - G_i S G_j^T)^2 with the current (G, S), written as one f64 to
  * the DEVICE address `out` (reconstruction error of _dfmf.py:306-316 without materialising the
  * n_i x n_j product).  For DFMC the working copy (completed entries) is used. */

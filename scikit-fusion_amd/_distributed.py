@@ -45,3 +45,27 @@ def gather_runs(local, n_run):
     if missing:
         raise RuntimeError('restarts %r were not computed by any rank' % missing)
     return [merged[k] for k in range(n_run)]
+
+
+def partition_relations(rel_list, theta_list, n_obj, rank_of):
+    """Deterministic assignment of relations and constraints to ranks (longest processing time
+    first on the contraction cost n_i*n_j*(c_i+c_j), constraints n_i^2*c_i).  Every rank computes
+    the same table.  Returns (relation owner per index, constraint owner per index)."""
+    _, size = world()
+    load = [0.0] * size
+    jobs = []
+    for k, (i, j, _, _) in enumerate(rel_list):
+        jobs.append((float(n_obj[i]) * n_obj[j] * (rank_of[i] + rank_of[j]), 0, k))
+    for k, (i, _) in enumerate(theta_list):
+        jobs.append((2.0 * float(n_obj[i]) ** 2 * rank_of[i], 1, k))
+    rel_owner, theta_owner = [0] * len(rel_list), [0] * len(theta_list)
+    for cost, kind, k in sorted(jobs, key=lambda t: (-t[0], t[1], t[2])):
+        r = min(range(size), key=lambda q: (load[q], q))
+        load[r] += cost
+        (theta_owner if kind else rel_owner)[k] = r
+    return rel_owner, theta_owner
+
+
+def gather_backbones(local, n_rel):
+    """{relation index: S} of this rank -> list of all backbones, identical on every rank."""
+    return gather_runs(local, n_rel)

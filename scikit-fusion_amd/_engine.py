@@ -149,6 +149,22 @@ class DevicePlan(object):
     def synchronize(self):
         self.rt.mem.synchronize()
 
+    def iterate_sharded(self, n_iters=1):
+        """Iterations of a relation-sharded run: this plan holds only this rank's relations;
+        the E / D accumulators are summed over the ranks (one all-reduce per iteration: RCCL on
+        GPUs, gloo in the CPU tests) before the replicated G update."""
+        import torch.distributed as dist
+        off, nbytes = C.c_size_t(), C.c_size_t()
+        self.rt.call('skf_accumulator_range', self.handle, C.byref(off), C.byref(nbytes))
+        acc = self.rt.mem.as_tensor(self.ws, off.value, nbytes.value, self.np_dtype)
+        for _ in range(int(n_iters)):
+            self.rt.call('skf_accumulate', self.handle, self.rt.mem.stream)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                self.rt.mem.synchronize()          # the collective runs on torch's own stream
+                dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+                self.rt.mem.synchronize()
+            self.rt.call('skf_apply_update', self.handle, self.rt.mem.stream)
+
     def relation_sqerr(self, rel):
         """sum (R - G_i S G_j^T)^2 for relation index `rel` (device reduction, one f64 D2H)."""
         self.rt.call('skf_relation_sqerr', self.handle, rel, self._scalar.ptr, self.rt.mem.stream)

@@ -83,6 +83,9 @@ SIGNATURES = {
     'skf_set_backbone': (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
     'skf_get_backbone': (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
     'skf_iterate': (C.c_int, [_P, C.c_int32, _P]),
+    'skf_accumulate': (C.c_int, [_P, _P]),
+    'skf_apply_update': (C.c_int, [_P, _P]),
+    'skf_accumulator_range': (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     'skf_relation_sqerr': (C.c_int, [_P, C.c_int32, _P, _P]),
     'skf_plan_set_profiling': (C.c_int, [_P, C.c_int32]),
     'skf_plan_get_profile': (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -162,6 +165,11 @@ class TorchDeviceMemory(object):
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
+
+    def as_tensor(self, buf, offset, nbytes, np_dtype):
+        """Zero-copy torch view of a byte range of a device buffer (for RCCL collectives)."""
+        tdt = {np.dtype(np.float32): self.torch.float32, np.dtype(np.float64): self.torch.float64}[np.dtype(np_dtype)]
+        return buf.owner[offset:offset + nbytes].view(tdt)
 
 
 class Runtime(object):

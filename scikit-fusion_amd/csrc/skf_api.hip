@@ -369,6 +369,7 @@ struct skf_plan {
     skf::Slot part_aux;
     size_t part_aux_bytes = 0;
     bool overlap = false;
+    size_t acc_off = 0, acc_bytes = 0;     // contiguous range of all E / D accumulators
     // optional hipEvent timing of the relation contractions (skf_plan_set_profiling)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
@@ -626,7 +627,10 @@ static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const v
     check_launch("side_update");
 }
 
-static void iterate_fit(skf_plan* p, hipStream_t st) {
+// E/D accumulation of one iteration: everything of the loop body except the final G update.
+// With relation sharding every rank runs this on ITS relations / constraints, the E and D
+// accumulators are then summed over the ranks (one all-reduce), and apply_update follows.
+static void accumulate_fit(skf_plan* p, hipStream_t st) {
     const bool dfmc = (p->variant == SKF_DFMC);
     const int nan_upd = dfmc ? 0 : 1;       // _update_G_for_Rij (_dfmc.py:127-178) has no nan_to_num
 
@@ -745,10 +749,19 @@ static void iterate_fit(skf_plan* p, hipStream_t st) {
         mixed_gemm(p, g, st);
     }
     theta_terms(p, st);
+}
+
+// G_i <- G_i * sqrt(E_i / max(D_i, eps)) for every type   (_dfmf.py:294-296)
+static void apply_update(skf_plan* p, hipStream_t st) {
     for (TypeState& t : p->types) {
         mult_update(p, t, st);
         refresh_gt(p, t, st);
     }
+}
+
+static void iterate_fit(skf_plan* p, hipStream_t st) {
+    accumulate_fit(p, st);
+    apply_update(p, st);
 }
 
 // SKF_TRANSFORM: everything that does not depend on G_target is computed once.
@@ -885,9 +898,22 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             if (need > part_bytes) part_bytes = need;
         };
         int maxn = 2;
+        // the E / D accumulators of all types form ONE contiguous range of the workspace, so that
+        // a relation-sharded run sums them over the ranks with a single all-reduce
+        p->acc_off = p->ws_bytes;
         for (int i = 0; i < n_types; ++i) {
             TypeState& t = p->types[i];
             const bool active = (p->variant != SKF_TRANSFORM) || i == p->target;
+            if (active) {
+                add_slot(p, t.E, (size_t)t.n * t.c * es);
+                add_slot(p, t.D, (size_t)t.n * t.c * es);
+            }
+        }
+        p->acc_bytes = p->ws_bytes - p->acc_off;
+        for (int i = 0; i < n_types; ++i) {
+            TypeState& t = p->types[i];
+            const bool active = (p->variant != SKF_TRANSFORM) || i == p->target;
+            (void)active;
             add_slot(p, t.G, (size_t)t.n * t.c * es);
             add_slot(p, t.Gram, (size_t)t.c * t.c * 8);
             if (p->bf16) {
@@ -895,10 +921,6 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 add_slot(p, t.GTb, (size_t)t.c * t.ldgt * 2);
             }
             want_part(t.c, t.c, (int)t.n, true);
-            if (active) {
-                add_slot(p, t.E, (size_t)t.n * t.c * es);
-                add_slot(p, t.D, (size_t)t.n * t.c * es);
-            }
             if (p->variant != SKF_TRANSFORM) {
                 add_slot(p, t.K, (size_t)t.c * t.c * 8);
                 if (t.n_pad > maxn) maxn = t.n_pad;
@@ -1125,6 +1147,32 @@ int skf_iterate(skf_plan* p, int32_t n_iters, void* stream) {
         } else {
             for (int it = 0; it < n_iters; ++it) iterate_fit(p, st);
         }
+    });
+}
+
+int skf_accumulate(skf_plan* p, void* stream) {
+    return guarded([&] {
+        check_bound(p);
+        if (p->variant == SKF_TRANSFORM) SKF_FAIL(SKF_E_INVALID, "skf_accumulate: SKF_DFMF / SKF_DFMC plans only");
+        for (size_t i = 0; i < p->types.size(); ++i)
+            if (!p->types[i].set) SKF_FAIL(SKF_E_STATE, "factor of object type %zu not set", i);
+        accumulate_fit(p, as_stream(stream));
+    });
+}
+
+int skf_apply_update(skf_plan* p, void* stream) {
+    return guarded([&] {
+        check_bound(p);
+        if (p->variant == SKF_TRANSFORM) SKF_FAIL(SKF_E_INVALID, "skf_apply_update: SKF_DFMF / SKF_DFMC plans only");
+        apply_update(p, as_stream(stream));
+    });
+}
+
+int skf_accumulator_range(const skf_plan* p, size_t* offset, size_t* bytes) {
+    return guarded([&] {
+        if (!p || !offset || !bytes) SKF_FAIL(SKF_E_INVALID, "null argument");
+        *offset = p->acc_off;
+        *bytes = p->acc_bytes;
     });
 }
 

@@ -42,6 +42,39 @@ def _rel_index(rel_list, target):
     return hits[l]
 
 
+def run_fit_sharded(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
+                    random_state, dtype, G0, engine):
+    """One fit whose relations are partitioned over the ranks of the process group (one GPU
+    each): replicated factors, local contractions, ONE all-reduce of the E / D accumulators per
+    iteration (second row).  Every rank returns the full (G, S)."""
+    from ..._distributed import partition_relations, gather_backbones, world
+    obj_types = list(obj_types)
+    n_obj = count_objects(obj_types, R)
+    if G0 is None:
+        R_first = {k: np.asarray(v[0], dtype=float) for k, v in R.items()}
+        G0 = initialize(obj_types, n_obj, obj_type2rank, R_first, init_type, _as_rs(random_state))
+    rel_list = flatten_relations(R, M)
+    theta_list = flatten_thetas(Theta)
+    rank, _ = world()
+    rel_owner, theta_owner = partition_relations(rel_list, theta_list, n_obj, obj_type2rank)
+    mine = [k for k, o in enumerate(rel_owner) if o == rank]
+    plan = DevicePlan(obj_types, n_obj, obj_type2rank, [rel_list[k] for k in mine],
+                      [t for t, o in zip(theta_list, theta_owner) if o == rank], variant,
+                      dtype=dtype, engine=engine)
+    try:
+        for t in obj_types:
+            plan.set_factor(t, G0[t, t])
+        plan.iterate_sharded(max_iter)
+        G = {(t, t): plan.get_factor(t) for t in obj_types}
+        backbones = gather_backbones({k: plan.get_backbone(q) for q, k in enumerate(mine)}, len(rel_list))
+        S = {}
+        for k, (i, j, _, _) in enumerate(rel_list):
+            S.setdefault((i, j), []).append(backbones[k])
+        return G, S
+    finally:
+        plan.close()
+
+
 def run_fit(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type, stopping,
             stopping_system, verbose, compute_err, callback, random_state, dtype, G0, engine):
     """Shared driver of dfmf / dfmc: the body of the reference loops (_dfmf.py:212-322,
@@ -98,10 +131,21 @@ def run_fit(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
         plan.close()
 
 
+def _sharded_ok(stopping, stopping_system, compute_err, callback):
+    if stopping or stopping_system or compute_err or callback:
+        raise ValueError("shard='relations' does not support callback / stopping / compute_err")
+
+
 def dfmf(R, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol",
          stopping=None, stopping_system=None, verbose=0, compute_err=False, callback=None,
-         random_state=None, n_jobs=1, dtype='f64', G0=None, engine=None):
-    """Data fusion by matrix factorization -- drop-in for reference ``dfmf`` (_dfmf.py:127)."""
+         random_state=None, n_jobs=1, dtype='f64', G0=None, engine=None, shard=None):
+    """Data fusion by matrix factorization -- drop-in for reference ``dfmf`` (_dfmf.py:127).
+    ``shard='relations'`` (with an initialised torch.distributed group) partitions the relations
+    of this ONE fit over the ranks."""
+    if shard == 'relations':
+        _sharded_ok(stopping, stopping_system, compute_err, callback)
+        return run_fit_sharded(nat.SKF_DFMF, R, None, Theta, obj_types, obj_type2rank, max_iter,
+                               init_type, random_state, dtype, G0, engine)
     return run_fit(nat.SKF_DFMF, R, None, Theta, obj_types, obj_type2rank, max_iter, init_type,
                    stopping, stopping_system, verbose, compute_err, callback, random_state,
                    dtype, G0, engine)

@@ -19,7 +19,7 @@ class Dfmc(FusionFit):
 
     def __init__(self, max_iter=100, init_type='random_c', n_run=1, stopping=None,
                  stopping_system=None, verbose=0, compute_err=False, callback=None,
-                 random_state=None, n_jobs=1, dtype='f64'):
+                 random_state=None, n_jobs=1, dtype='f64', shard='runs'):
         super(Dfmc, self).__init__()
         self._set_params(vars())
 
@@ -30,12 +30,14 @@ class Dfmc(FusionFit):
         rank = {ot: int(ot.rank) for ot in object_types}
         R, Theta, M = graph_matrices(fusion_graph, with_masks=True)
         G0 = initial_factors(R, object_types, rank, self.init_type, self.random_state, self.n_run)
-        local = {k: _dfmc.dfmc(R=R, M=M, Theta=Theta, obj_types=object_types, obj_type2rank=rank,
-                               max_iter=self.max_iter, init_type=self.init_type,
-                               stopping=self.stopping, stopping_system=self.stopping_system,
-                               verbose=self.verbose, compute_err=self.compute_err,
-                               callback=self.callback, random_state=self.random_state,
-                               n_jobs=self.n_jobs, dtype=self.dtype, G0=G0[k])
-                 for k in my_runs(self.n_run)}
+        kw = dict(R=R, M=M, Theta=Theta, obj_types=object_types, obj_type2rank=rank,
+                  max_iter=self.max_iter, init_type=self.init_type, stopping=self.stopping,
+                  stopping_system=self.stopping_system, verbose=self.verbose,
+                  compute_err=self.compute_err, callback=self.callback,
+                  random_state=self.random_state, n_jobs=self.n_jobs, dtype=self.dtype)
+        if self.shard == 'relations':
+            store_runs(self, [_dfmc.dfmc(G0=G0[k], shard='relations', **kw) for k in range(self.n_run)])
+            return self
+        local = {k: _dfmc.dfmc(G0=G0[k], **kw) for k in my_runs(self.n_run)}
         store_runs(self, gather_runs(local, self.n_run))
         return self

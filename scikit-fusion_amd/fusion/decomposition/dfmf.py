@@ -79,12 +79,14 @@ class Dfmf(FusionFit):
 
     Parameters (identical to the reference): max_iter=100, init_type='random_c', n_run=1,
     stopping=None, stopping_system=None, verbose=0, compute_err=False, callback=None,
-    random_state=None, n_jobs=1.  Addition: dtype='f64' | 'f32' (device arithmetic type).
+    random_state=None, n_jobs=1.  Additions: dtype='f64' | 'f32' | 'bf16' (device arithmetic),
+    shard='runs' | 'relations' (what a torch.distributed process group shares out: whole
+    restarts -- no collective -- or the relations of each restart -- one all-reduce/iteration).
     """
 
     def __init__(self, max_iter=100, init_type='random_c', n_run=1, stopping=None,
                  stopping_system=None, verbose=0, compute_err=False, callback=None,
-                 random_state=None, n_jobs=1, dtype='f64'):
+                 random_state=None, n_jobs=1, dtype='f64', shard='runs'):
         super(Dfmf, self).__init__()
         self._set_params(vars())
 
@@ -95,12 +97,15 @@ class Dfmf(FusionFit):
         rank = {ot: int(ot.rank) for ot in object_types}
         R, Theta = graph_matrices(fusion_graph)
         G0 = initial_factors(R, object_types, rank, self.init_type, self.random_state, self.n_run)
-        local = {k: _dfmf.dfmf(R=R, Theta=Theta, obj_types=object_types, obj_type2rank=rank,
-                               max_iter=self.max_iter, init_type=self.init_type,
-                               stopping=self.stopping, stopping_system=self.stopping_system,
-                               verbose=self.verbose, compute_err=self.compute_err,
-                               callback=self.callback, random_state=self.random_state,
-                               n_jobs=self.n_jobs, dtype=self.dtype, G0=G0[k])
+        kw = dict(R=R, Theta=Theta, obj_types=object_types, obj_type2rank=rank,
+                  max_iter=self.max_iter, init_type=self.init_type, stopping=self.stopping,
+                  stopping_system=self.stopping_system, verbose=self.verbose,
+                  compute_err=self.compute_err, callback=self.callback,
+                  random_state=self.random_state, n_jobs=self.n_jobs, dtype=self.dtype)
+        if self.shard == 'relations':                   # all GPUs cooperate on every restart
+            store_runs(self, [_dfmf.dfmf(G0=G0[k], shard='relations', **kw) for k in range(self.n_run)])
+            return self
+        local = {k: _dfmf.dfmf(G0=G0[k], **kw)
                  for k in my_runs(self.n_run)}          # one restart per GPU when distributed
         store_runs(self, gather_runs(local, self.n_run))
         return self

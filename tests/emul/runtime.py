@@ -72,6 +72,10 @@ class HostMemory(object):
     def synchronize(self):
         pass
 
+    def as_tensor(self, buf, offset, nbytes, np_dtype):
+        import torch
+        return torch.from_numpy(buf.owner[offset:offset + nbytes].view(np_dtype))
+
 
 def emulated_runtime():
     import skfusion_amd._native as nat

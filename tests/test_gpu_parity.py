@@ -244,6 +244,20 @@ def test_c3_scaled_f64_and_f32():
     assert relerr(got, want) < 1e-5
 
 
+def test_accumulate_apply_split_equals_iterate():
+    """skf_accumulate + skf_apply_update (the relation-sharded iteration, here on one device and
+    without a process group) gives the same iterates as skf_iterate."""
+    z = golden('probe_multirel.npz')
+    R, Theta, M, types, rank = probe_graph(z)
+    G0 = g0_from(z, 'dfmf/', types)
+    G, S = _dfmf.dfmf(R, Theta, types, rank, max_iter=10, G0=G0, shard='relations')
+    for t in types:
+        assert relerr(G[t, t], z['dfmf/G_%s_it9' % t]) < 1e-9
+    Gc, Sc = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=10, G0=g0_from(z, 'dfmc/', types), shard='relations')
+    for t in types:
+        assert relerr(Gc[t, t], z['dfmc/G_%s_it9' % t]) < 1e-9
+
+
 def test_bf16_engine_c1_and_c3_scaled():
     """SKF_BF16 engine: bf16 relation contractions.  Tolerances: reconstruction
     error within 1e-2 relative of the f64 oracle on the same (bf16-rounded) relations."""
