@@ -196,7 +196,7 @@ static int pick_splits_bf16(int64_t units, int ktiles, int bm) {
         if (s > 1 && ktiles / s < 8) break;
         const double w = (double)units * s / slots;
         const double rounds = (double)(int64_t)(w + 0.999999);
-        const double eff = w / (rounds < 1.0 ? 1.0 : rounds) - 0.004 * (s - 1);
+        const double eff = w / (rounds < 1.0 ? 1.0 : rounds) - 0.008 * (s - 1);
         if (eff > best_eff + 1e-9) {
             best_eff = eff;
             best = s;
@@ -256,7 +256,24 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
         else if (glds) SKF_V2_LAUNCH(BN_, TAG_, false, true, 2);       \
         else SKF_V2_LAUNCH(BN_, TAG_, false, false, 2);                \
     } while (0)
-        if (three && bn == 128 && relation) SKF_V2_LAUNCH(128, 1, false, true, 3);
+        const char* pp = getenv("SKF_BF16_PIPE");          // "1" enables the half-tile fragment pipeline
+        const bool pipe = three && (pp && atoi(pp) == 1);   // (v3: measured equal to v2, kept for A/B runs)
+#define SKF_V3_LAUNCH(BN_, TAG_)                                                                                  \
+    do {                                                                                                          \
+        const int smem_ = (3 * 256 + ((BN_ == 256) ? 2 : 3) * BN_) * 8 * 16;                                      \
+        static bool attr_ = false;                                                                                \
+        if (!attr_) {                                                                                             \
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v3_kernel<BN_, TAG_>,                              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_));                      \
+            attr_ = true;                                                                                         \
+        }                                                                                                         \
+        hipLaunchKernelGGL((gemm_bf16_v3_kernel<BN_, TAG_>), grid, block, smem_, st, g);                          \
+    } while (0)
+        if (pipe && bn == 128 && relation) SKF_V3_LAUNCH(128, 1);
+        else if (pipe && bn == 128) SKF_V3_LAUNCH(128, 0);
+        else if (pipe && relation) SKF_V3_LAUNCH(256, 1);
+        else if (pipe) SKF_V3_LAUNCH(256, 0);
+        else if (three && bn == 128 && relation) SKF_V2_LAUNCH(128, 1, false, true, 3);
         else if (three && bn == 128) SKF_V2_LAUNCH(128, 0, false, true, 3);
         else if (three && relation) SKF_V2_LAUNCH(256, 1, false, true, 3);
         else if (three) SKF_V2_LAUNCH(256, 0, false, true, 3);
@@ -264,6 +281,7 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
         else if (bn == 128) SKF_V2_PICK(128, 0);
         else if (relation) SKF_V2_PICK(256, 1);
         else SKF_V2_PICK(256, 0);
+#undef SKF_V3_LAUNCH
 #undef SKF_V2_PICK
 #undef SKF_V2_LAUNCH
     } else {

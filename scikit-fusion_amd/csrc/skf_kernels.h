@@ -244,15 +244,24 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS *
             }
         }
     } else if (mode == STAGE_VEC_R) {
+        // a lane owns V consecutive rows: written in lane order they would hit the LDS banks V-way;
+        // every group of 8 lanes therefore starts at a different element (rotation by selects,
+        // register indices stay static)
+        const int rot = (tid >> 3) & (V - 1);
 #pragma unroll
         for (int i = 0; i < PER / V; ++i) {
             const int e = tid + i * GEMM_THREADS;
             const int r = (e % (ROWS / V)) * V;
             const int k = e / (ROWS / V);
+            const bool live = (k0 + k < k_end);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                T v = apply_aop((T)reg[i * V + j], aop);
-                lds[k][r + j] = (k0 + k < k_end) ? v : (T)0;
+                TS raw = reg[i * V + j];
+#pragma unroll
+                for (int q = 1; q < V; ++q)
+                    if (rot == q) raw = reg[i * V + ((j + q) & (V - 1))];
+                const T v = apply_aop((T)raw, aop);
+                lds[k][r + ((j + rot) & (V - 1))] = live ? v : (T)0;
             }
         }
     } else {
@@ -999,6 +1008,145 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                     if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc[i][j][r];
                 }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 relation contraction, third generation = the v2 LDS-DMA ring kernel with the fragment
+// reads software-pipelined by half a K tile.  Two fragment register sets alternate:
+//     [ds_read F1 = second half of tile t ]  MFMA on F0 (first half of tile t)
+//     wait (F1 here, tile t+1 landed) ; s_barrier          <- tile t's buffers are free from here
+//     [ds_read F0 = first half of tile t+1]  MFMA on F1
+// so every MFMA block starts on registers that were loaded during the previous block and the
+// only bubble left per K tile is the barrier itself.
+// ------------------------------------------------------------------------------------------
+template <int BN, int TAG>
+__global__ __launch_bounds__(512) void gemm_bf16_v3_kernel(Bf16GemmArgs g) {
+    constexpr int BM = 256, BK = 64;
+    constexpr int WN = BN / 2;
+    constexpr int NJ = WN / 16;
+    constexpr int AST = 3;
+    constexpr int BST = (BN == 256) ? 2 : 3;
+    constexpr int ASZ = BM * 8, BSZ = BN * 8;
+    constexpr int PWA = BM / 64, PWB = BN / 64;
+    constexpr int KEEP = (BST == 3) ? (PWA + PWB) : PWA;
+    HIP_DYNAMIC_SHARED(u32x4, smem)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * WN;
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    const int kz0 = blockIdx.z * g.k_chunk;
+    const int kz1 = (kz0 + g.k_chunk < g.Kp) ? kz0 + g.k_chunk : g.Kp;
+    const int nkt = (kz1 - kz0) / BK;
+    const int rr = lane >> 3, pc = lane & 7;
+
+    f32x4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    auto dma_A = [&](int k0, int buf) {
+        u32x4* Ad = smem + buf * ASZ;
+#pragma unroll
+        for (int p = 0; p < PWA; ++p) {
+            const int blk = wave * PWA + p;
+            const int row = blk * 8 + rr;
+            const int m = bm0 + row;
+            const int mc = m < g.M ? m : g.M - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g.A + (int64_t)mc * g.lda + k0 + (pc ^ (row & 7)) * 8),
+                (__attribute__((address_space(3))) void*)(Ad + blk * 64), 16, 0, 0);
+        }
+    };
+    auto dma_B = [&](int k0, int buf) {
+        u32x4* Bd = smem + AST * ASZ + buf * BSZ;
+#pragma unroll
+        for (int p = 0; p < PWB; ++p) {
+            const int blk = wave * PWB + p;
+            const int row = blk * 8 + rr;
+            const int n = bn0 + row;
+            const int nc = n < g.N ? n : g.N - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + k0 + (pc ^ (row & 7)) * 8),
+                (__attribute__((address_space(3))) void*)(Bd + blk * 64), 16, 0, 0);
+        }
+    };
+    bf16x8 a0[4], b0[NJ], a1[4], b1[NJ];
+    auto read_frags = [&](bf16x8 (&a)[4], bf16x8 (&b)[NJ], int kt, int ks) {
+        const u32x4* As = smem + (kt % AST) * ASZ;
+        const u32x4* Bs = smem + AST * ASZ + (kt % BST) * BSZ;
+        const int chunk = 4 * ks + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
+    };
+    auto mma_block = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[NJ]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+
+    if (nkt > 0) {
+        dma_A(kz0, 0);
+        dma_B(kz0, 0);
+        if (nkt > 1) {
+            dma_A(kz0 + BK, 1);
+            if constexpr (BST == 3) dma_B(kz0 + BK, 1);
+            __builtin_amdgcn_s_waitcnt(0x0F70 | KEEP);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (nkt > 0) read_frags(a0, b0, 0, 0);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1 < nkt);
+        if constexpr (BST == 3) {
+            if (kt + 2 < nkt) {
+                dma_A(kz0 + (kt + 2) * BK, (kt + 2) % 3);
+                dma_B(kz0 + (kt + 2) * BK, (kt + 2) % 3);
+            }
+        } else {
+            if (more) dma_B(kz0 + (kt + 1) * BK, (kt + 1) & 1);
+            if (kt + 2 < nkt) dma_A(kz0 + (kt + 2) * BK, (kt + 2) % 3);
+        }
+        read_frags(a1, b1, kt, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_block(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        // F1 has arrived (lgkmcnt 0) -> this wave no longer reads tile kt; tile kt+1 has landed
+        if (kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0070 | KEEP);
+        else __builtin_amdgcn_s_waitcnt(0x0070);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (more) read_frags(a0, b0, kt + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_block(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    float* out = (gridDim.z > 1) ? g.part + (int64_t)blockIdx.z * g.M * g.N : g.C;
+    const int64_t ldo = (gridDim.z > 1) ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = bm0 + wm0 + i * 16 + 4 * (lane >> 4) + r;
+                const int n = bn0 + wn0 + j * 16 + (lane & 15);
+                if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc[i][j][r];
+            }
 }
 
 // split-K second stage of the bf16 contraction: C = sum_z part[z]  (fixed order)

@@ -159,21 +159,24 @@ def test_gemm_bf16_contraction(rt, shape):
     M, N, K = shape
     rs = np.random.RandomState(M + N + K)
     A, B = rs.randn(M, K), rs.randn(K, N)           # asymmetric operands
-    for tile, mf, gl, st in (('128', '16', '1', '3'), ('256', '32', '1', '2'), ('256', '16', '1', '3'),
-                             ('256', '16', '1', '2'), ('256', '16', '0', '2'), ('256', '32', '0', '2')):
+    for tile, mf, gl, st, pipe in (('128', '16', '1', '3', '1'), ('256', '32', '1', '2', '1'), ('256', '16', '1', '3', '1'),
+                                   ('256', '16', '1', '3', '0'), ('256', '16', '1', '2', '1'), ('256', '16', '0', '2', '1'),
+                                   ('256', '32', '0', '2', '1')):
         os.environ['SKF_BF16_TILE'] = tile
+        os.environ['SKF_BF16_PIPE'] = pipe
         os.environ['SKF_BF16_MFMA'] = mf
         os.environ['SKF_BF16_GLDS'] = gl
         os.environ['SKF_BF16_STAGES'] = st
         try:
             for splits in (0, 1, 3):
                 got, want = run_gemm_bf16(rt, A, B, splits)
-                assert relerr(got, want) < 2e-6, (tile, mf, splits)   # exact products, f32 accumulation
+                assert relerr(got, want) < 2e-6, (tile, mf, gl, st, pipe, splits)   # exact products, f32 accumulation
         finally:
             os.environ.pop('SKF_BF16_TILE', None)
             os.environ.pop('SKF_BF16_MFMA', None)
             os.environ.pop('SKF_BF16_GLDS', None)
             os.environ.pop('SKF_BF16_STAGES', None)
+            os.environ.pop('SKF_BF16_PIPE', None)
 
 
 def test_to_bf16_and_transpose(rt):
