@@ -244,24 +244,15 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS *
             }
         }
     } else if (mode == STAGE_VEC_R) {
-        // a lane owns V consecutive rows: written in lane order they would hit the LDS banks V-way;
-        // every group of 8 lanes therefore starts at a different element (rotation by selects,
-        // register indices stay static)
-        const int rot = (tid >> 3) & (V - 1);
 #pragma unroll
         for (int i = 0; i < PER / V; ++i) {
             const int e = tid + i * GEMM_THREADS;
             const int r = (e % (ROWS / V)) * V;
             const int k = e / (ROWS / V);
-            const bool live = (k0 + k < k_end);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                TS raw = reg[i * V + j];
-#pragma unroll
-                for (int q = 1; q < V; ++q)
-                    if (rot == q) raw = reg[i * V + ((j + q) & (V - 1))];
-                const T v = apply_aop((T)raw, aop);
-                lds[k][r + ((j + rot) & (V - 1))] = live ? v : (T)0;
+                T v = apply_aop((T)reg[i * V + j], aop);
+                lds[k][r + j] = (k0 + k < k_end) ? v : (T)0;
             }
         }
     } else {
