@@ -636,10 +636,10 @@ static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const v
     } else {
         if (big) {
             dim3 grid(cdiv(t.c, 128), cdiv(t.n, 128));
-            hipLaunchKernelGGL((side_update_kernel<float, double, 2, 2, 32>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((side_update_kernel<float, double, 2, 2, 16>), grid, block, 0, st, a);
         } else {
             dim3 grid(cdiv(t.c, 64), cdiv(t.n, 64));
-            hipLaunchKernelGGL((side_update_kernel<float, double, 1, 1, 32>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((side_update_kernel<float, double, 1, 1, 16>), grid, block, 0, st, a);
         }
     }
     check_launch("side_update");

@@ -279,8 +279,10 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS *
 // T = arithmetic / output type (f32 or f64 MFMA); TA, TB = storage types of the operands (a f32
 // operand feeding an f64 contraction is widened while it is staged: Gram / G^T P in the f32
 // engine; an f64 backbone feeding an f32 contraction is narrowed the same way).
+// (f32: at least 2 waves per SIMD, i.e. <= 256 registers per lane -- left alone the compiler
+// spreads the unrolled staging code over 277 registers and halves the occupancy)
 template <typename T, typename TA, typename TB, int WR, int WC, int BK, int TAG>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_mfma_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void gemm_mfma_kernel(GemmArgs g) {
     typedef Mfma<T> MF;
     constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
     constexpr int LDA = BM + 1, LDB = BN + 1;
@@ -408,7 +410,7 @@ struct SideArgs {
 };
 
 template <typename T, typename TB, int WR, int WC, int BK>
-__global__ __launch_bounds__(GEMM_THREADS) void side_update_kernel(SideArgs a) {
+__global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_update_kernel(SideArgs a) {
     typedef Mfma<T> MF;
     constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
     constexpr int LDA = BM + 1, LDB = BN + 1;

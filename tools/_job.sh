@@ -1,5 +1,4 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1z; export TMPDIR=/tmp
-python __graft_entry__.py > gpurun_out/r1z/build.log 2>&1
-python -m pytest tests -m gpu -q -k "bf16" 2>&1 | tail -3
-echo "== v3 pipelined fragments (default)"; python tools/bench_gemm_bf16.py --shapes P12,Q12,P13,Q13,P23,Q23 --tiles 256 --splits 0
-echo "== v2 (SKF_BF16_PIPE=0)"; SKF_BF16_PIPE=0 python tools/bench_gemm_bf16.py --shapes P12,Q12,Q23 --tiles 256 --splits 0
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1D; export TMPDIR=/tmp
+python __graft_entry__.py > gpurun_out/r1D/build.log 2>&1
+python bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep '^{' > gpurun_out/r1D/bench_bf16.json
+cd /tmp && rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/r1D/prof -o prof -- python $GRAFT_REPO_ROOT/bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
