@@ -86,11 +86,16 @@ template <> struct Tiles<float> {
     static TileCfg big() { return {128, 128, BK}; }
     static TileCfg small() { return {64, 64, BK}; }
 };
+// f64: a 128 x 128 tile needs 128 accumulator registers + staging = 376 registers (1 wave per
+// SIMD); 64 x 128 (2 x 4 MFMA tiles per wave) fits several waves per SIMD
 template <> struct Tiles<double> {
     static constexpr int BK = 16;
-    static TileCfg big() { return {128, 128, BK}; }
+    static TileCfg big() { return {64, 128, BK}; }
     static TileCfg small() { return {32, 32, BK}; }
 };
+template <typename T> struct BigWave;
+template <> struct BigWave<float> { static constexpr int WR = 2, WC = 2; };     // 128 x 128
+template <> struct BigWave<double> { static constexpr int WR = 2, WC = 4; };    //  64 x 128
 
 static TileCfg pick_tile(bool is_f64, int engine, int M, int N) {
     if (engine == SKF_ENGINE_VALU) return {64, 64, 16};
@@ -115,12 +120,13 @@ template <typename T, typename TA, typename TB>
 static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, bool relation, hipStream_t st) {
     dim3 grid(cdiv(g.N, t.bn), cdiv(g.M, t.bm), splits);
     dim3 block(GEMM_THREADS);
-    constexpr int WRB = 128 / (2 * Mfma<T>::MT), WCB = 128 / (2 * Mfma<T>::NT);
+    constexpr int WRB = BigWave<T>::WR, WCB = BigWave<T>::WC;
+    const bool big = (t.bm == Tiles<T>::big().bm && t.bn == Tiles<T>::big().bn);
     if (engine == SKF_ENGINE_VALU) {
         hipLaunchKernelGGL((gemm_valu_kernel<T, TA, TB>), grid, block, 0, st, g);
-    } else if (t.bm == 128 && relation) {
+    } else if (big && relation) {
         hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 1>), grid, block, 0, st, g);
-    } else if (t.bm == 128) {
+    } else if (big) {
         hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 0>), grid, block, 0, st, g);
     } else {
         hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, 1, 1, Tiles<T>::BK, 0>), grid, block, 0, st, g);

@@ -282,7 +282,7 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS *
 // (f32: at least 2 waves per SIMD, i.e. <= 256 registers per lane -- left alone the compiler
 // spreads the unrolled staging code over 277 registers and halves the occupancy)
 template <typename T, typename TA, typename TB, int WR, int WC, int BK, int TAG>
-__global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void gemm_mfma_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) {
     typedef Mfma<T> MF;
     constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
     constexpr int LDA = BM + 1, LDB = BN + 1;
