@@ -229,3 +229,39 @@ def count_objects(obj_types, R):
     if set(obj_types) != set(n):
         raise DataFusionError('Object type specification mismatch')
     return n
+
+
+def device_reconstruct(G_row_block, S, G_col, dtype='f64', runtime=None):
+    """R_hat block = G_row_block @ S @ G_col.T on the device (two strided MFMA GEMMs through
+    ``skf_gemm``) -- the building block of ``FusionFit.complete_blocks`` for relations whose dense
+    reconstruction does not fit on the host in one piece."""
+    rt = runtime or nat.get_runtime()
+    code = nat.DTYPES[dtype]
+    if code == nat.SKF_BF16:
+        code = nat.SKF_F32
+    npd = nat.NP_DTYPE[code]
+    es = np.dtype(npd).itemsize
+    A = np.ascontiguousarray(G_row_block, dtype=npd)
+    Sm = np.ascontiguousarray(S, dtype=npd)
+    B = np.ascontiguousarray(G_col, dtype=npd)
+    m, ci = A.shape
+    cj = Sm.shape[1]
+    nj = B.shape[0]
+    if Sm.shape[0] != ci or B.shape[1] != cj:
+        raise ValueError('shape mismatch in reconstruction')
+    mem = rt.mem
+    a, s_, b = mem.from_host(A), mem.from_host(Sm), mem.from_host(B)
+    h = mem.empty(m * cj * es)
+    out = mem.empty(m * nj * es)
+
+    def gemm(Ap, sa_m, sa_k, Bp, sb_k, sb_n, Cp, ldc, M, N, K):
+        d = nat.GemmDesc()
+        d.A, d.B, d.C = Ap, Bp, Cp
+        d.sa_m, d.sa_k, d.sb_k, d.sb_n, d.ldc, d.ldc2 = sa_m, sa_k, sb_k, sb_n, ldc, ldc
+        d.M, d.N, d.K = M, N, K
+        d.splits, d.a_dtype, d.b_dtype = 1, -1, -1
+        rt.call('skf_gemm', code, nat.SKF_ENGINE_MFMA, C.byref(d), None, 0, mem.stream)
+    gemm(a.ptr, ci, 1, s_.ptr, cj, 1, h.ptr, cj, m, cj, ci)              # H = G_blk S
+    gemm(h.ptr, cj, 1, b.ptr, 1, cj, out.ptr, nj, m, nj, cj)             # R_hat = H G_col^T
+    mem.synchronize()
+    return mem.to_host(out, (m, nj), npd).astype(np.float64)

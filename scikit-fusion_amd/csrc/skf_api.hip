@@ -662,7 +662,12 @@ static void accumulate_fit(skf_plan* p, hipStream_t st) {
         for (RelState& r : p->rels) {
             if (!r.mask) continue;
             const int64_t rows = p->types[r.row].n, cols = p->types[r.col].n;
-            if (p->f64)
+            if (p->bf16) {
+                hipLaunchKernelGGL((mask_zero_kernel<uint16_t>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
+                                   (uint16_t*)r.Rb.ptr, r.ldrb, r.mask, r.ldmask, rows, cols);
+                hipLaunchKernelGGL(mask_zero_transposed_kernel, dim3(elem_grid(rows * cols)), dim3(256), 0, st,
+                                   (uint16_t*)r.RTb.ptr, r.ldrtb, r.mask, r.ldmask, rows, cols);
+            } else if (p->f64)
                 hipLaunchKernelGGL((mask_zero_kernel<double>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
                                    (double*)r.Rw.ptr, r.ldr, r.mask, r.ldmask, rows, cols);
             else
@@ -736,7 +741,13 @@ static void accumulate_fit(skf_plan* p, hipStream_t st) {
             // H = G_i S ; Rw[mask] = (H G_j^T)[mask] ; P = Rw G_j        (_dfmc.py:319-325)
             g = gemm_args(ti.G.ptr, ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, ni, cj, ci, EPI_STORE, 0);
             mixed_gemm(p, g, st);
-            g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rw.ptr, r.ldr, ni, nj, cj, EPI_MASKED_STORE, 0);
+            if (p->bf16) {         // completed entries go to both stored copies (R and R^T), as bf16
+                g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rb.ptr, r.ldrb, ni, nj, cj, EPI_MASKED_STORE_BF16, 0);
+                g.C2 = r.RTb.ptr;
+                g.ldc2 = r.ldrtb;
+            } else {
+                g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rw.ptr, r.ldr, ni, nj, cj, EPI_MASKED_STORE, 0);
+            }
             g.mask = r.mask;
             g.ldmask = r.ldmask;
             plan_gemm(p, g, st);
@@ -856,8 +867,8 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             SKF_FAIL(SKF_E_INVALID, "bad relation / constraint arrays");
         if (opt->dtype != SKF_F64 && opt->dtype != SKF_F32 && opt->dtype != SKF_BF16)
             SKF_FAIL(SKF_E_INVALID, "unknown dtype %d", opt->dtype);
-        if (opt->dtype == SKF_BF16 && opt->variant != SKF_DFMF)
-            SKF_FAIL(SKF_E_INVALID, "SKF_BF16 is implemented for SKF_DFMF only (use SKF_F32 for DFMC / fold-in)");
+        if (opt->dtype == SKF_BF16 && opt->variant == SKF_TRANSFORM)
+            SKF_FAIL(SKF_E_INVALID, "SKF_BF16 is implemented for SKF_DFMF / SKF_DFMC (use SKF_F32 for the fold-in)");
         if (opt->dtype == SKF_BF16 && opt->engine != SKF_ENGINE_MFMA)
             SKF_FAIL(SKF_E_INVALID, "SKF_BF16 needs the MFMA engine");
         if (opt->variant < SKF_DFMF || opt->variant > SKF_TRANSFORM) SKF_FAIL(SKF_E_INVALID, "bad variant");
@@ -974,7 +985,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 add_slot(p, r.Dn, (size_t)tj.c * tj.c * 8);
                 want_part(ti.c, tj.c, (int)ti.n, true);
             }
-            if (r.mask) add_slot(p, r.Rw, (size_t)ti.n * tj.n * es);
+            if (r.mask && !p->bf16) add_slot(p, r.Rw, (size_t)ti.n * tj.n * es);
             if (p->bf16) {
                 r.ldrb = pad64(tj.n);
                 r.ldrtb = pad64(ti.n);
@@ -1045,7 +1056,7 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
         for (Slot* s : p->slots) s->ptr = (char*)ws + s->off;
         hipStream_t st = as_stream(stream);
         for (RelState& r : p->rels) {
-            if (!r.mask) continue;
+            if (!r.mask || p->bf16) continue;      // bf16: the padded R / R^T copies are the working set
             const int64_t rows = p->types[r.row].n, cols = p->types[r.col].n;
             copy2d(r.Rw.ptr, cols, r.R_in, r.ld_in, rows, cols, p->esz, st);
             r.R = r.Rw.ptr;

@@ -36,7 +36,8 @@ enum Epi {
     EPI_SPLIT_STORE = 2,   // C  = max(v,0) ; C2  = max(-v,0)
     EPI_SPLIT_ACC = 3,     // C += max(v,0) ; C2 += max(-v,0)       (_dfmf.py:256-258,278-282)
     EPI_MASKED_STORE = 4,  // C  = v where mask != 0                (_dfmc.py:319-325)
-    EPI_SQDIFF = 5         // per-workgroup partial of sum (C - v)^2 -> C2[block]  (C untouched)
+    EPI_SQDIFF = 5,        // per-workgroup partial of sum (C - v)^2 -> C2[block]  (C untouched)
+    EPI_MASKED_STORE_BF16 = 6   // bf16 engine: C[m][n] = C2[n][m] = bf16(v) where mask != 0 (R and R^T copies)
 };
 
 struct GemmArgs {
@@ -61,6 +62,14 @@ struct GemmArgs {
 template <typename T> struct Lim;
 template <> struct Lim<float> { static __device__ __host__ float big() { return 3.40282346638528859812e+38f; } };
 template <> struct Lim<double> { static __device__ __host__ double big() { return 1.79769313486231570815e+308; } };
+
+__device__ __host__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    union { float f; uint32_t u; } x;
+    x.f = f;
+    if ((x.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x.u >> 16) | 0x40);   // quiet NaN
+    const uint32_t r = 0x7fffu + ((x.u >> 16) & 1u);
+    return (uint16_t)((x.u + r) >> 16);
+}
 
 __device__ __host__ __forceinline__ float bf16_to_f32(uint16_t h) {
     union { uint32_t u; float f; } x;
@@ -104,6 +113,13 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int m, int n, 
             break;
         case EPI_MASKED_STORE:
             if (g.mask[(int64_t)m * g.ldmask + n]) C[i] = v;
+            break;
+        case EPI_MASKED_STORE_BF16:
+            if (g.mask[(int64_t)m * g.ldmask + n]) {
+                const uint16_t h = f32_to_bf16_rne((float)v);
+                ((uint16_t*)g.C)[i] = h;
+                ((uint16_t*)g.C2)[(int64_t)n * g.ldc2 + m] = h;
+            }
             break;
         default: break;
     }
@@ -1212,14 +1228,6 @@ __device__ __host__ __forceinline__ double hash_uniform(uint64_t seed, uint64_t 
     return (double)(z >> 40) * (1.0 / 16777216.0);
 }
 
-__device__ __host__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
-    union { float f; uint32_t u; } x;
-    x.f = f;
-    if ((x.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x.u >> 16) | 0x40);   // quiet NaN
-    const uint32_t r = 0x7fffu + ((x.u >> 16) & 1u);
-    return (uint16_t)((x.u + r) >> 16);
-}
-
 template <typename T> __device__ __forceinline__ T from_double(double v) { return (T)v; }
 template <> __device__ __forceinline__ uint16_t from_double<uint16_t>(double v) { return f32_to_bf16_rne((float)v); }
 
@@ -1297,6 +1305,18 @@ __global__ __launch_bounds__(256) void mask_zero_kernel(T* __restrict__ R, int64
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / cols, c = e % cols;
         if (mask[r * ldm + c]) R[r * ldr + c] = (T)0;
+    }
+}
+
+// bf16 engine, DFMC iteration 0: the stored transpose gets the same zeros, RT[c][r] = 0 where mask[r][c]
+__global__ __launch_bounds__(256) void mask_zero_transposed_kernel(uint16_t* __restrict__ RT, int64_t ldrt,
+                                                                   const uint8_t* __restrict__ mask, int64_t ldm,
+                                                                   int64_t rows, int64_t cols) {
+    const int64_t total = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / cols, c = e % cols;
+        if (mask[r * ldm + c]) RT[c * ldrt + r] = 0;
     }
 }
 

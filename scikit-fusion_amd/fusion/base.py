@@ -107,6 +107,25 @@ class FusionFit(FusionBase):
         return self._reconstruct(relation, 0 if run is None else run)
 
 
+    def complete_blocks(self, relation, block_rows=4096, run=None, dtype='f64'):
+        """Blockwise reconstruction on the device: yields ``(row_slice, R_hat[row_slice])`` with
+        at most ``block_rows`` rows per block, so that a relation whose dense reconstruction is too
+        large for the host (BASELINE config 3: up to 40 GB) can be consumed piece by piece.
+        A postprocessor is applied per block (exact for element-wise postprocessors).
+        Extension of the reference API (``complete`` itself is unchanged)."""
+        from .._engine import device_reconstruct
+        run = 0 if run is None else run
+        G1 = self.factor(relation.row_type, run)
+        S12 = self.backbone(relation, run)
+        G2 = self.factor(relation.col_type, run)
+        for r0 in range(0, G1.shape[0], int(block_rows)):
+            sl = slice(r0, min(r0 + int(block_rows), G1.shape[0]))
+            block = device_reconstruct(G1[sl], S12, G2, dtype=dtype)
+            if relation.postprocessor:
+                block = relation.postprocessor(block)
+            yield sl, block
+
+
 class FusionTransform(FusionBase):
     """Base of the online (fold-in) transformers: attributes ``target``, ``fusion_graph``,
     ``fuser``."""

@@ -154,6 +154,24 @@ def fold_in_recovers_known_rows(full):
         assert np.sum(d_hat ** 2) / d_hat.size < 1e-5
 
 
+def blockwise_completion():
+    """complete_blocks (device, blockwise) == complete (host NumPy) for f64, close for f32."""
+    rs = np.random.RandomState(2)
+    t1, t2 = ObjectType('type1', 7), ObjectType('type2', 5)
+    rel = Relation(rs.rand(130, 45), t1, t2)
+    fuser = Dfmf(max_iter=3, init_type='random', random_state=1).fuse(FusionGraph([rel]))
+    want = fuser.complete(rel)
+    got = np.zeros_like(want)
+    seen = []
+    for sl, block in fuser.complete_blocks(rel, block_rows=50):
+        got[sl] = block
+        seen.append((sl.start, sl.stop))
+    assert seen == [(0, 50), (50, 100), (100, 130)]
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    got32 = np.vstack([b for _, b in fuser.complete_blocks(rel, block_rows=64, dtype='f32')])
+    np.testing.assert_allclose(got32, want, rtol=1e-5, atol=1e-5)
+
+
 def error_paths():
     t1, t2, t9 = ObjectType('type1', 2), ObjectType('type2', 2), ObjectType('nine', 2)
     rel = Relation(np.random.RandomState(0).rand(5, 3), t1, t2)

@@ -40,3 +40,4 @@ def test_multiple_relations_per_pair():
 def test_pipeline_transform_chain_and_errors():
     A.pipeline_and_transform(full=False)
     A.error_paths()
+    A.blockwise_completion()

@@ -164,8 +164,32 @@ def test_bf16_engine_against_oracle_on_bf16_rounded_relations():
         want = np.linalg.norm(Rb[i, j][0] - Gd[i, i] @ plan.get_backbone(k) @ Gd[j, j].T) ** 2
         assert abs(plan.relation_sqerr(k) - want) < 1e-4 * want
     plan.close()
-    with pytest.raises(nat.SkfNativeError):
-        _dfmc.dfmc(R, {k: [None] for k in R}, {}, types, rank, max_iter=1, G0=G0, dtype='bf16')
+    with pytest.raises(nat.SkfNativeError):          # the fold-in has no bf16 engine
+        _dfmf.transform({('t1', 't2'): [R['t1', 't2'][0][:3]]}, {}, 't1', rank, G, S, max_iter=1, dtype='bf16',
+                        G0=G0['t1', 't1'][:3])
+
+
+def test_bf16_dfmc_masked_completion():
+    """SKF_BF16 + SKF_DFMC: zeroing and completion act on both stored copies (R and R^T, bf16)."""
+    z = golden('probe_multirel.npz')
+    R, Theta, M, types, rank = probe_graph(z)
+    Rb = {k: [nat.from_bf16_bits(nat.to_bf16_bits(m)).astype(np.float64) for m in v] for k, v in R.items()}
+    G0 = g0_from(z, 'dfmc/', types)
+    keep = {k: [m.copy() for m in v] for k, v in R.items()}
+    G, S = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=10, G0=G0, dtype='bf16')
+    Go, So = orc.dfmc(Rb, M, Theta, types, rank, max_iter=10, G0=G0)
+    for t in types:
+        assert relerr(G[t, t], Go[t, t]) < 5e-2
+    for k in R:
+        for a, b in zip(R[k], keep[k]):
+            np.testing.assert_array_equal(a, b)
+    # unmasked entries: reconstruction error close to the f64 oracle's
+    for (i, j), mats in Rb.items():
+        for l, m in enumerate(mats):
+            keepm = np.ones(m.shape, bool) if M[i, j][l] is None else ~M[i, j][l]
+            e = np.linalg.norm((m - G[i, i] @ S[i, j][l] @ G[j, j].T)[keepm])
+            eo = np.linalg.norm((m - Go[i, i] @ So[i, j][l] @ Go[j, j].T)[keepm])
+            assert abs(e - eo) < 5e-2 * eo
 
 
 def test_relation_sqerr_and_stopping_path():

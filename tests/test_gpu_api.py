@@ -40,6 +40,7 @@ def test_pipeline_and_fold_in():
     A.pipeline_and_transform(full=True)
     A.fold_in_recovers_known_rows(full=True)
     A.error_paths()
+    A.blockwise_completion()
 
 
 def test_f32_engine_reaches_the_same_fixed_point():
