@@ -99,11 +99,16 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = local % max(torch.cuda.device_count(), 1)     # (ranks may share a GPU in smoke runs)
     torch.cuda.set_device(local)
     dist = None
+    backend = os.environ.get('SKF_BENCH_BACKEND', 'nccl')   # 'gloo' only for single-GPU smoke runs
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__
     if rank == 0:
@@ -147,7 +152,7 @@ def main():
     k_ms, k_launches, k_flops = plan.get_profile()
     plan.set_profiling(False)
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
