@@ -110,7 +110,7 @@ static int pick_splits(const TileCfg& t, int M, int N, int K) {
     if (tiles >= 256) return 1;
     const int ktiles = cdiv(K, t.bk);
     int s = (int)(512 / tiles);
-    const int max_by_k = ktiles / 8 > 0 ? ktiles / 8 : 1;       // at least 8 K tiles per slice
+    const int max_by_k = ktiles / 32 > 0 ? ktiles / 32 : 1;     // at least 32 K tiles per slice (no split of c x c x c products)
     if (s > max_by_k) s = max_by_k;
     if (s > 256) s = 256;
     return s < 1 ? 1 : s;

@@ -169,6 +169,31 @@ def test_bf16_engine_against_oracle_on_bf16_rounded_relations():
                         G0=G0['t1', 't1'][:3])
 
 
+def test_bf16_engine_odd_sizes_and_wide_rank():
+    """bf16 engine on shapes that exercise every padding path: object counts that are not
+    multiples of 8 / 64 (zero-padded K), a rank above 256 (several N tiles) and a rank of 1."""
+    rs = np.random.RandomState(12)
+    n = {'a': 77, 'b': 301, 'c': 9}
+    rank = {'a': 5, 'b': 1, 'c': 3}
+    R = {('a', 'b'): [rs.rand(77, 301)], ('c', 'a'): [rs.rand(9, 77)], ('b', 'c'): [rs.rand(301, 9)]}
+    types = ['a', 'b', 'c']
+    G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.1 for t in types}
+    Rb = {k: [nat.from_bf16_bits(nat.to_bf16_bits(v[0])).astype(np.float64)] for k, v in R.items()}
+    G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=6, G0=G0, dtype='bf16')
+    Go, So = orc.dfmf(Rb, {}, types, rank, max_iter=6, G0=G0)
+    for t in types:
+        assert relerr(G[t, t], Go[t, t]) < 3e-2
+    # wide rank: 300 latent dimensions on 320 objects (N = 300 > 256 -> two column tiles)
+    R2 = {('a', 'b'): [rs.rand(320, 140)]}
+    rank2 = {'a': 300, 'b': 20}
+    G02 = {('a', 'a'): rs.rand(320, 300) + 0.1, ('b', 'b'): rs.rand(140, 20) + 0.1}
+    Rb2 = {k: [nat.from_bf16_bits(nat.to_bf16_bits(v[0])).astype(np.float64)] for k, v in R2.items()}
+    G, S = _dfmf.dfmf(R2, {}, ['a', 'b'], rank2, max_iter=2, G0=G02, dtype='bf16')
+    Go, So = orc.dfmf(Rb2, {}, ['a', 'b'], rank2, max_iter=2, G0=G02)
+    e, eo = orc.relation_errors(Rb2, G, S), orc.relation_errors(Rb2, Go, So)
+    assert abs(e['a', 'b'][0] - eo['a', 'b'][0]) < 5e-2 * eo['a', 'b'][0]
+
+
 def test_bf16_dfmc_masked_completion():
     """SKF_BF16 + SKF_DFMC: zeroing and completion act on both stored copies (R and R^T, bf16)."""
     z = golden('probe_multirel.npz')

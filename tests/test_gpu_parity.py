@@ -264,6 +264,7 @@ def test_bf16_engine_c1_and_c3_scaled():
     import test_emul_engine as E
     E.test_bf16_engine_against_oracle_on_bf16_rounded_relations()
     E.test_bf16_dfmc_masked_completion()
+    E.test_bf16_engine_odd_sizes_and_wide_rank()
     z = golden('c3_scaled.npz')
     R, G0, types, rank = c3_scaled_graph(z)
     G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=5, G0=G0, dtype='bf16')
