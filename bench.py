@@ -49,6 +49,19 @@ def alg_flops(n):
     return sum(2.0 * n[i] * n[j] * (RANKS[i] + RANKS[j]) for i, j, _ in PAIRS)
 
 
+def hbm_view(dtype, n, k_ms, k_launches):
+    """The same launches against the HBM roofline: algorithmic bytes = every relation read once per
+    contraction (2 contractions per relation); peak 8 TB/s (MI355X_MICROARCH.md)."""
+    esz = {'bf16': 2, 'f32': 4, 'f64': 8}[dtype]
+    total = 2.0 * sum(float(n[i]) * n[j] for i, j, _ in PAIRS) * esz          # per iteration
+    if not k_ms or not k_launches:
+        return None
+    iters = k_launches / (2.0 * len(PAIRS))
+    tbs = total * iters / (k_ms * 1e-3) / 1e12
+    return {'achieved': tbs, 'peak': 8.0, 'unit': 'TB/s', 'frac': tbs / 8.0,
+            'algorithmic_bytes_per_launch': total / (2.0 * len(PAIRS))}
+
+
 def cpu_baseline(seconds_budget=25.0):
     """Oracle (kind=port) on the host cores at 1/10 linear scale, scaled to the full graph."""
     from oracle import dfmf_oracle as orc
@@ -198,7 +211,8 @@ def main():
                          'launches': int(k_launches),
                          'avg_launch_ms': k_ms / k_launches if k_launches else None,
                          'alg_flops_per_launch': k_flops / k_launches if k_launches else None,
-                         'whole_iteration_frac': alg_flops(n) * args.steps / elapsed / 1e12 / peak},
+                         'whole_iteration_frac': alg_flops(n) * args.steps / elapsed / 1e12 / peak,
+                         'hbm_view': hbm_view(args.dtype, n, k_ms, k_launches)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

@@ -144,10 +144,13 @@ class TorchDeviceMemory(object):
                                'there is no CPU fallback')
         self.torch = torch
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+        # the engine works on its own stream (hipGraph capture is impossible on the legacy default
+        # stream); every hand-over to / from torch goes through a device-wide synchronize()
+        self._stream = torch.cuda.Stream(device=self.device)
 
     @property
     def stream(self):
-        return self.torch.cuda.current_stream(self.device).cuda_stream
+        return self._stream.cuda_stream
 
     def empty(self, nbytes):
         t = self.torch.empty(max(int(nbytes), 256), dtype=self.torch.uint8, device=self.device)
@@ -156,6 +159,7 @@ class TorchDeviceMemory(object):
     def from_host(self, array):
         a = np.ascontiguousarray(array)
         t = self.torch.from_numpy(a.view(np.uint8).reshape(-1)).to(self.device)
+        self.torch.cuda.synchronize(self.device)     # visible to the engine stream
         return Buffer(t.data_ptr(), a.nbytes, t)
 
     def to_host(self, buf, shape, dtype):
