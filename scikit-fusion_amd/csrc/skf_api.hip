@@ -214,9 +214,9 @@ static int pick_splits_bf16(int64_t units, int ktiles, int bm) {
 
 static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, int64_t ldb, float* C, int64_t ldc,
                           int M, int N, int Kp, int want_splits, void* part, size_t part_bytes, bool relation,
-                          hipStream_t st) {
+                          hipStream_t st, int64_t a_kstep = 64, int64_t b_kstep = 64) {
     if (M <= 0 || N <= 0) return;
-    if (Kp % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || lda < Kp || ldb < Kp)
+    if (Kp % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || (a_kstep == 64 && lda < Kp) || (b_kstep == 64 && ldb < Kp))
         SKF_FAIL(SKF_E_INVALID, "bf16 contraction: inner dimension must be padded to 64 (Kp=%d lda=%lld ldb=%lld)", Kp,
                  (long long)lda, (long long)ldb);
     if ((((uintptr_t)A) | ((uintptr_t)Bt)) & 15) SKF_FAIL(SKF_E_INVALID, "bf16 operands must be 16-byte aligned");
@@ -233,6 +233,7 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
     g.A = A; g.Bt = Bt; g.C = C; g.part = (float*)part;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.M = M; g.N = N; g.Kp = Kp;
+    g.a_kstep = a_kstep; g.b_kstep = b_kstep;
     g.k_chunk = cdiv(ktiles > 0 ? ktiles : 1, splits) * 64;
     splits = cdiv(Kp > 0 ? Kp : 1, g.k_chunk);
     dim3 grid(cdiv(N, bn), cdiv(M, bm), splits);

@@ -657,6 +657,9 @@ struct Bf16GemmArgs {
     int64_t lda, ldb, ldc;
     int M, N, Kp;          // Kp % 64 == 0
     int k_chunk;           // K range per z-slice, multiple of 64
+    int64_t a_kstep, b_kstep;   // elements between consecutive 64-wide K tiles of a row: 64 for the
+                                // row-major layout; rows*64 for the K-tile-major layout, in which the
+                                // [rows][64] slab of one K tile is contiguous (lda = ldb = 64)
 };
 
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return row * 8 + (chunk ^ (row & 7)); }
@@ -695,12 +698,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16GemmArgs g) {
 #pragma unroll
         for (int p = 0; p < A_PER; ++p) {
             const int m = bm0 + srow + 32 * p;
-            ra[p] = (m < g.M) ? *(const u32x4*)(g.A + (int64_t)m * g.lda + k0 + schunk * 8) : zero;
+            ra[p] = (m < g.M) ? *(const u32x4*)(g.A + (int64_t)m * g.lda + (int64_t)(k0 >> 6) * g.a_kstep + schunk * 8) : zero;
         }
 #pragma unroll
         for (int p = 0; p < B_PER; ++p) {
             const int n = bn0 + srow + 32 * p;
-            rb[p] = (n < g.N) ? *(const u32x4*)(g.Bt + (int64_t)n * g.ldb + k0 + schunk * 8) : zero;
+            rb[p] = (n < g.N) ? *(const u32x4*)(g.Bt + (int64_t)n * g.ldb + (int64_t)(k0 >> 6) * g.b_kstep + schunk * 8) : zero;
         }
     };
     auto store_tiles = [&]() {
@@ -827,13 +830,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
         for (int p = 0; p < A_PER; ++p) {
             const int m = bm0 + srow + 64 * p;
             const int mc = m < g.M ? m : g.M - 1;
-            ra[p] = *(const u32x4*)(g.A + (int64_t)mc * g.lda + k0 + schunk * 8);
+            ra[p] = *(const u32x4*)(g.A + (int64_t)mc * g.lda + (int64_t)(k0 >> 6) * g.a_kstep + schunk * 8);
         }
 #pragma unroll
         for (int p = 0; p < B_PER; ++p) {
             const int n = bn0 + srow + 64 * p;
             const int nc = n < g.N ? n : g.N - 1;
-            rb[p] = *(const u32x4*)(g.Bt + (int64_t)nc * g.ldb + k0 + schunk * 8);
+            rb[p] = *(const u32x4*)(g.Bt + (int64_t)nc * g.ldb + (int64_t)(k0 >> 6) * g.b_kstep + schunk * 8);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
             const int m = bm0 + row;
             const int mc = m < g.M ? m : g.M - 1;
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g.A + (int64_t)mc * g.lda + k0 + c * 8),
+                (const __attribute__((address_space(1))) void*)(g.A + (int64_t)mc * g.lda + (int64_t)(k0 >> 6) * g.a_kstep + c * 8),
                 (__attribute__((address_space(3))) void*)(Ad + blk * 64), 16, 0, 0);
         }
     };
@@ -877,7 +880,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
             const int n = bn0 + row;
             const int nc = n < g.N ? n : g.N - 1;
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + k0 + c * 8),
+                (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + (int64_t)(k0 >> 6) * g.b_kstep + c * 8),
                 (__attribute__((address_space(3))) void*)(Bd + blk * 64), 16, 0, 0);
         }
     };
@@ -1066,7 +1069,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v3_kernel(Bf16GemmArgs g) {
             const int m = bm0 + row;
             const int mc = m < g.M ? m : g.M - 1;
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g.A + (int64_t)mc * g.lda + k0 + (pc ^ (row & 7)) * 8),
+                (const __attribute__((address_space(1))) void*)(g.A + (int64_t)mc * g.lda + (int64_t)(k0 >> 6) * g.a_kstep + (pc ^ (row & 7)) * 8),
                 (__attribute__((address_space(3))) void*)(Ad + blk * 64), 16, 0, 0);
         }
     };
@@ -1079,7 +1082,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v3_kernel(Bf16GemmArgs g) {
             const int n = bn0 + row;
             const int nc = n < g.N ? n : g.N - 1;
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + k0 + (pc ^ (row & 7)) * 8),
+                (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + (int64_t)(k0 >> 6) * g.b_kstep + (pc ^ (row & 7)) * 8),
                 (__attribute__((address_space(3))) void*)(Bd + blk * 64), 16, 0, 0);
         }
     };

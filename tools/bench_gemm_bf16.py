@@ -28,8 +28,9 @@ def main():
     for name in args.shapes.split(','):
         M, N, K = SHAPES[name]
         Kp = (K + 63) // 64 * 64
-        A = fill_uniform((M, Kp), 1, 'bf16')
-        Bt = fill_uniform((N, Kp), 2, 'bf16')
+        mp, npad = (M + 255) // 256 * 256, (N + 255) // 256 * 256
+        A = fill_uniform((mp, Kp), 1, 'bf16')
+        Bt = fill_uniform((npad, Kp), 2, 'bf16')
         C = rt.mem.empty(M * N * 4)
         ws = rt.mem.empty(32 * M * N * 4)
         for tile in args.tiles.split(','):
@@ -43,10 +44,10 @@ def main():
                 run()
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+                e0.record(rt.mem._stream)
                 for _ in range(args.reps):
                     run()
-                e1.record()
+                e1.record(rt.mem._stream)
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / args.reps
                 print('%s M=%d N=%d K=%d tile=%s splits=%d : %.3f ms  %.0f TFLOP/s  (A stream %.2f TB/s)'

@@ -37,10 +37,10 @@ def main():
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 3
-            e0.record()
+            e0.record(rt.mem._stream)
             for _ in range(reps):
                 run()
-            e1.record()
+            e1.record(rt.mem._stream)
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
             print('%s %-10s M=%d N=%d K=%d : %.3f ms  %.1f TFLOP/s' % (name, label, M, N, K, ms, 2.0 * M * N * K / ms / 1e9),
