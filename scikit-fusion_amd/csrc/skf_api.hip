@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/skfusion_hip.h"
@@ -123,7 +124,19 @@ static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, 
     dim3 block(GEMM_THREADS);
     constexpr int WRB = BigWave<T>::WR, WCB = BigWave<T>::WC;
     const bool big = (t.bm == Tiles<T>::big().bm && t.bn == Tiles<T>::big().bn);
-    if (engine == SKF_ENGINE_VALU) {
+    if (g.epi == EPI_MASKED_STORE_BF16) {          // f32 operands only; never split, always the MFMA kernel
+        if constexpr (std::is_same<T, float>::value && std::is_same<TA, float>::value &&
+                      std::is_same<TB, float>::value) {
+            if (big)
+                hipLaunchKernelGGL((gemm_mfma_kernel<float, float, float, WRB, WCB, Tiles<float>::BK, 2>), grid,
+                                   block, 0, st, g);
+            else
+                hipLaunchKernelGGL((gemm_mfma_kernel<float, float, float, 1, 1, Tiles<float>::BK, 2>), grid, block,
+                                   0, st, g);
+        } else {
+            SKF_FAIL(SKF_E_INVALID, "bf16 masked store needs f32 operands");
+        }
+    } else if (engine == SKF_ENGINE_VALU) {
         hipLaunchKernelGGL((gemm_valu_kernel<T, TA, TB>), grid, block, 0, st, g);
     } else if (big && relation) {
         hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 1>), grid, block, 0, st, g);
@@ -154,9 +167,9 @@ static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void
                      hipStream_t st, bool relation = false) {
     if (g.M <= 0 || g.N <= 0) return;
     const bool is_f64 = (ty.c == SKF_F64);
-    const TileCfg t = pick_tile(is_f64, engine, g.M, g.N);
+    const TileCfg t = pick_tile(is_f64, g.epi == EPI_MASKED_STORE_BF16 ? SKF_ENGINE_MFMA : engine, g.M, g.N);
     int splits = want_splits > 0 ? want_splits : pick_splits(t, g.M, g.N, g.K);
-    if (g.epi == EPI_SQDIFF) splits = 1;
+    if (g.epi == EPI_SQDIFF || g.epi == EPI_MASKED_STORE_BF16) splits = 1;
     const size_t per = (size_t)g.M * g.N;
     const size_t part_elems = part_bytes / (is_f64 ? 8 : 4);
     if (splits > 1 && (part == nullptr || per * splits > part_elems)) {

@@ -93,12 +93,22 @@ __device__ __forceinline__ T apply_aop(T x, int aop) {
     return x;
 }
 
-template <typename T>
+// BF16OUT instantiations (gemm_mfma_kernel<.., TAG = 2>) carry only EPI_MASKED_STORE_BF16: keeping that
+// case out of the common switch keeps the f32 / f64 kernels' register allocation spill-free.
+template <typename T, bool BF16OUT = false>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int m, int n, T v) {
     T* C = (T*)g.C;
     T* C2 = (T*)g.C2;
     if (g.nan_to_num) v = nan_to_num(v);
     const int64_t i = (int64_t)m * g.ldc + n;
+    if (BF16OUT) {
+        if (g.mask[(int64_t)m * g.ldmask + n]) {
+            const uint16_t h = f32_to_bf16_rne((float)v);
+            ((uint16_t*)g.C)[i] = h;
+            ((uint16_t*)g.C2)[(int64_t)n * g.ldc2 + m] = h;
+        }
+        return;
+    }
     const int64_t i2 = (int64_t)m * g.ldc2 + n;
     switch (g.epi) {
         case EPI_STORE: C[i] = v; break;
@@ -113,13 +123,6 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int m, int n, 
             break;
         case EPI_MASKED_STORE:
             if (g.mask[(int64_t)m * g.ldmask + n]) C[i] = v;
-            break;
-        case EPI_MASKED_STORE_BF16:
-            if (g.mask[(int64_t)m * g.ldmask + n]) {
-                const uint16_t h = f32_to_bf16_rne((float)v);
-                ((uint16_t*)g.C)[i] = h;
-                ((uint16_t*)g.C2)[(int64_t)n * g.ldc2 + m] = h;
-            }
             break;
         default: break;
     }
@@ -289,7 +292,8 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS *
 // One K step:  [global loads of tile t+1 in flight]  MFMA on tile t from LDS  | barrier |
 //              registers -> LDS | barrier.
 // ------------------------------------------------------------------------------------------
-// TAG only changes the symbol name: TAG=1 instantiations are the two relation contractions
+// TAG = 2: the bf16 masked-store epilogue (DFMC completion of the bf16 R / R^T copies).
+// TAG 0 / 1 only change the symbol name: TAG=1 instantiations are the two relation contractions
 // P = R G_j and Q = R^T G_i (the only launches that read R), so that profilers list the
 // dominant kernel separately from the small n x c x c products that share the code.
 // T = arithmetic / output type (f32 or f64 MFMA); TA, TB = storage types of the operands (a f32
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
                         const T d = rv - v;
                         sq += d * d;
                     } else {
-                        epilogue_store<T>(g, m, n, v);
+                        epilogue_store<T, TAG == 2>(g, m, n, v);
                     }
                 }
             }
