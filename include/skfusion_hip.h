@@ -63,7 +63,20 @@ typedef struct {
     const uint8_t* mask;        /* DFMC only: n_row x n_col bytes, !=0 = unknown entry
                                    (M[(i,j)][l], dfmc.py:77-90); NULL = no mask */
     int64_t mask_ld;
+    /* Row-block sharding of ONE relation over several processes: this process holds
+     * rows [row_begin, row_begin + n_rows) of the relation; `data` / `mask` point at its first LOCAL
+     * row.  n_rows == 0 (zero-initialised descriptor): the whole relation is here.  A plan that
+     * lists a relation it holds no rows of sets SKF_REL_ABSENT (data may be NULL).  See skf_stage. */
+    int64_t row_begin;
+    int64_t n_rows;
+    int32_t flags;              /* SKF_REL_* */
 } skf_relation_desc;
+
+enum {
+    SKF_REL_ABSENT = 1,       /* no local rows of this relation (its backbone / Q are still kept) */
+    SKF_REL_NO_COL_SIDE = 2,  /* another process adds the column-side terms E_j, D_j of this relation */
+    SKF_REL_MASKED = 4        /* SKF_REL_ABSENT descriptors: the relation is masked where it lives */
+};
 
 typedef struct {
     int32_t type;     /* constrained object type (Theta[(i,i)][t], dfmf.py:82-85) */
@@ -130,6 +143,27 @@ int skf_iterate(skf_plan* plan, int32_t n_iters, void* stream);
 int skf_accumulate(skf_plan* plan, void* stream);
 int skf_apply_update(skf_plan* plan, void* stream);
 int skf_accumulator_range(const skf_plan* plan, size_t* offset, size_t* bytes);
+
+/* Row-block sharding: every process creates a plan with ALL object types and ALL relations, each
+ * relation carrying this process's row block (or SKF_REL_ABSENT); exactly one holder per relation
+ * leaves SKF_REL_NO_COL_SIDE clear.  One iteration is then four stages with an all-reduce(sum)
+ * over the processes of a workspace byte range between them (skf_exchange_range; the ranges have
+ * the same layout in every such plan):
+ *     skf_stage(SKF_STAGE_CONTRACT)    Gram, pinv, local P = R_blk G_j, partial Q = R_blk^T G_i[blk],
+ *                                      partial W = G_i[blk]^T P          -> reduce SKF_X_W, SKF_X_Q
+ *     skf_stage(SKF_STAGE_BACKBONE)    S = K_i W K_j; DFMC: completion of the local rows, P and
+ *                                      partial Q of masked relations     -> reduce SKF_X_QM (DFMC)
+ *     skf_stage(SKF_STAGE_ACCUMULATE)  E / D terms of the local rows, column-side and Theta terms
+ *                                                                        -> reduce SKF_X_ED
+ *     skf_stage(SKF_STAGE_UPDATE)      G <- G * sqrt(E / max(D, eps))
+ * (the +- split of _dfmf.py:256-276 is non-linear, hence Q is reduced raw, before it).
+ * skf_accumulate == the first three stages back to back (plans without row blocks);
+ * skf_iterate refuses a plan with row blocks.  skf_relation_sqerr covers the local rows. */
+enum { SKF_STAGE_CONTRACT = 0, SKF_STAGE_BACKBONE = 1, SKF_STAGE_ACCUMULATE = 2, SKF_STAGE_UPDATE = 3 };
+enum { SKF_X_W = 0, SKF_X_Q = 1, SKF_X_QM = 2, SKF_X_ED = 3 };
+int skf_stage(skf_plan* plan, int32_t stage, void* stream);
+/* dtype: SKF_F64 for SKF_X_W, the master type otherwise; bytes may be 0 (nothing to reduce). */
+int skf_exchange_range(const skf_plan* plan, int32_t which, size_t* offset, size_t* bytes, int32_t* dtype);
 
 /* sum over the relation of (R - G_i S G_j^T)^2 with the current (G, S), written as one f64 to
  * the DEVICE address `out` (reconstruction error of _dfmf.py:306-316 without materialising the

@@ -66,6 +66,50 @@ def partition_relations(rel_list, theta_list, n_obj, rank_of):
     return rel_owner, theta_owner
 
 
+def partition_rows(rel_list, theta_list, n_obj, rank_of, align=256, size=None):
+    """Balanced row-block partition ("relations and, for balance, row blocks of large
+    relations"): the relations are laid end to end, every row weighted by its contraction cost
+    n_j*(c_i+c_j), and cut into `size` stretches of equal cost at row boundaries that are multiples
+    of `align`.  A rank therefore holds at most one contiguous block of any relation.  Returns
+    (blocks, theta_owner): blocks[k] = [(rank, row_begin, n_rows), ...] covering relation k in row
+    order (the first block's rank also adds the column-side terms); every rank computes the same
+    table."""
+    if size is None:
+        _, size = world()
+    row_cost = [float(n_obj[j]) * (rank_of[i] + rank_of[j]) for i, j, _, _ in rel_list]
+    total = sum(c * n_obj[rel[0]] for c, rel in zip(row_cost, rel_list))
+    share = total / float(size) if size else 0.0
+    blocks = [[] for _ in rel_list]
+    load = [0.0] * size
+    q = 0
+    for k, (i, j, _, _) in enumerate(rel_list):
+        n_i, done = int(n_obj[i]), 0
+        while done < n_i:
+            left = n_i - done
+            room = share - load[q]
+            take = left
+            if q < size - 1 and room < left * row_cost[k]:
+                take = int(room / row_cost[k]) // align * align
+                if left - take < align:          # do not leave a sliver for the next rank
+                    take = left
+            if take <= 0:                        # this rank is full
+                q += 1
+                continue
+            blocks[k].append((q, done, take))
+            load[q] += take * row_cost[k]
+            done += take
+            if q < size - 1 and load[q] >= share - 0.5 * align * row_cost[k]:
+                q += 1
+    theta_owner = [0] * len(theta_list)
+    jobs = sorted(((2.0 * float(n_obj[i]) ** 2 * rank_of[i], k) for k, (i, _) in enumerate(theta_list)),
+                  key=lambda t: (-t[0], t[1]))
+    for cost, k in jobs:
+        r = min(range(size), key=lambda x: (load[x], x))
+        load[r] += cost
+        theta_owner[k] = r
+    return blocks, theta_owner
+
+
 def gather_backbones(local, n_rel):
     """{relation index: S} of this rank -> list of all backbones, identical on every rank."""
     return gather_runs(local, n_rel)

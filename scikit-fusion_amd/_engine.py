@@ -18,6 +18,15 @@ class DeviceMatrix(object):
     def __init__(self, buf, shape, ld=None):
         self.buf, self.shape, self.ld = buf, tuple(shape), ld if ld is not None else shape[1]
 
+    def rows(self, begin, count, itemsize):
+        """View of `count` rows from `begin` on (no copy; the parent buffer stays referenced)."""
+        return DeviceMatrix(_BufferView(self.buf, begin * self.ld * itemsize), (count, self.shape[1]), self.ld)
+
+
+class _BufferView(object):
+    def __init__(self, parent, offset):
+        self.parent, self.ptr = parent, parent.ptr + offset
+
 
 def fill_uniform(shape, seed, dtype='f32', scale=1.0, shift=0.0, runtime=None):
     """Device matrix of counter-based uniforms (bit-identical to oracle hash_uniform_matrix)."""
@@ -35,8 +44,10 @@ class DevicePlan(object):
 
     def __init__(self, obj_types, n_obj, rank, relations, thetas, variant, dtype='f64',
                  target=None, engine=None, runtime=None):
-        """relations: list of (row_type, col_type, ndarray, mask-or-None);
-        thetas: list of (type, ndarray)."""
+        """relations: list of (row_type, col_type, ndarray, mask-or-None[, block]);
+        thetas: list of (type, ndarray).  `block` (row-block sharding, `_distributed.partition_rows`)
+        = dict(row_begin, n_rows, absent, col_side, masked): data / mask then hold only the local rows
+        (None when absent)."""
         self.rt = runtime or nat.get_runtime()
         self.dtype = nat.DTYPES[dtype] if isinstance(dtype, str) else dtype
         if self.dtype not in nat.NP_DTYPE:
@@ -55,7 +66,19 @@ class DevicePlan(object):
         for k in range(len(self.types)):
             tdesc[k].n_obj, tdesc[k].rank = self.n_obj[k], self.rank[k]
         rdesc = (nat.RelationDesc * max(len(relations), 1))()
-        for k, (i, j, data, mask) in enumerate(relations):
+        for k, rel in enumerate(relations):
+            i, j, data, mask = rel[:4]
+            block = rel[4] if len(rel) > 4 else None
+            rdesc[k].row_type, rdesc[k].col_type = self.index[i], self.index[j]
+            rows_here = n_obj[i]
+            if block is not None:
+                rows_here = int(block['n_rows'])
+                rdesc[k].row_begin, rdesc[k].n_rows = int(block['row_begin']), rows_here
+                rdesc[k].flags = ((nat.SKF_REL_ABSENT if block.get('absent') else 0) |
+                                  (0 if block.get('col_side', True) else nat.SKF_REL_NO_COL_SIDE) |
+                                  (nat.SKF_REL_MASKED if block.get('masked') else 0))
+                if block.get('absent'):
+                    continue
             if isinstance(data, DeviceMatrix):
                 arr, buf, ld = data, data.buf, data.ld
             else:
@@ -65,11 +88,10 @@ class DevicePlan(object):
                 # SKF_BF16: relations are handed over as bf16 bit patterns
                 up = nat.to_bf16_bits(arr) if self.dtype == nat.SKF_BF16 else arr
                 buf, ld = mem.from_host(up), arr.shape[1]
-            if tuple(arr.shape) != (n_obj[i], n_obj[j]):
+            if tuple(arr.shape) != (rows_here, n_obj[j]):
                 raise ValueError('relation (%s,%s) dimension mismatch: %r vs object counts (%d,%d)'
-                                 % (i, j, tuple(arr.shape), n_obj[i], n_obj[j]))
+                                 % (i, j, tuple(arr.shape), rows_here, n_obj[j]))
             self._keep.append(buf)
-            rdesc[k].row_type, rdesc[k].col_type = self.index[i], self.index[j]
             rdesc[k].data, rdesc[k].ld = buf.ptr, ld
             if mask is not None:
                 m = np.ascontiguousarray(np.asarray(mask, dtype=bool).astype(np.uint8))
@@ -165,6 +187,50 @@ class DevicePlan(object):
                 self.rt.mem.synchronize()
             self.rt.call('skf_apply_update', self.handle, self.rt.mem.stream)
 
+    def _exchange_views(self):
+        """Zero-copy tensor views of the four exchange ranges (None when empty)."""
+        views = []
+        for which in (nat.SKF_X_W, nat.SKF_X_Q, nat.SKF_X_QM, nat.SKF_X_ED):
+            off, nbytes, dt = C.c_size_t(), C.c_size_t(), C.c_int32()
+            self.rt.call('skf_exchange_range', self.handle, which, C.byref(off), C.byref(nbytes), C.byref(dt))
+            views.append(self.rt.mem.as_tensor(self.ws, off.value, nbytes.value, nat.NP_DTYPE[dt.value])
+                         if nbytes.value else None)
+        return views
+
+    def stage(self, which):
+        self.rt.call('skf_stage', self.handle, int(which), self.rt.mem.stream)
+
+    def iterate_rows(self, n_iters=1, reduce=None):
+        """Iterations of a row-block-sharded run (every rank lists all relations, each with its row
+        block): four stages with an all-reduce(sum) of W and Q, of the masked relations' Q (DFMC),
+        and of E / D between them -- include/skfusion_hip.h `skf_stage`.  `reduce(tensor)` defaults
+        to torch.distributed.all_reduce (RCCL on GPUs, gloo in the CPU tests)."""
+        if reduce is None:
+            import torch.distributed as dist
+            active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+            def reduce(t):
+                if active:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        xw, xq, xqm, xed = self._exchange_views()
+        mem, call, h = self.rt.mem, self.rt.call, self.handle
+
+        def exchange(*tensors):
+            mem.synchronize()                      # the collective runs on torch's own stream
+            for t in tensors:
+                if t is not None:
+                    reduce(t)
+            mem.synchronize()
+        for _ in range(int(n_iters)):
+            call('skf_stage', h, nat.SKF_STAGE_CONTRACT, mem.stream)
+            exchange(xw, xq)
+            call('skf_stage', h, nat.SKF_STAGE_BACKBONE, mem.stream)
+            if xqm is not None:
+                exchange(xqm)
+            call('skf_stage', h, nat.SKF_STAGE_ACCUMULATE, mem.stream)
+            exchange(xed)
+            call('skf_stage', h, nat.SKF_STAGE_UPDATE, mem.stream)
+
     def relation_sqerr(self, rel):
         """sum (R - G_i S G_j^T)^2 for relation index `rel` (device reduction, one f64 D2H)."""
         self.rt.call('skf_relation_sqerr', self.handle, rel, self._scalar.ptr, self.rt.mem.stream)
@@ -192,6 +258,40 @@ class DevicePlan(object):
             self.close()
         except Exception:
             pass
+
+
+def iterate_rows_lockstep(plans, n_iters=1):
+    """Drive the row-block plans of ALL ranks from one process (same device), summing the exchange
+    ranges by hand where the ranks of a process group would all-reduce: the single-GPU / emulator
+    test vehicle of the row-block schedule."""
+    views = [p._exchange_views() for p in plans]
+
+    def exchange(*which):
+        for p in plans:
+            p.synchronize()
+        for w in which:
+            ts = [v[w] for v in views]
+            if ts[0] is None:
+                continue
+            total = ts[0].clone()
+            for t in ts[1:]:
+                total += t
+            for t in ts:
+                t.copy_(total)
+        for p in plans:
+            p.synchronize()
+    for _ in range(int(n_iters)):
+        for p in plans:
+            p.stage(nat.SKF_STAGE_CONTRACT)
+        exchange(0, 1)
+        for p in plans:
+            p.stage(nat.SKF_STAGE_BACKBONE)
+        exchange(2)
+        for p in plans:
+            p.stage(nat.SKF_STAGE_ACCUMULATE)
+        exchange(3)
+        for p in plans:
+            p.stage(nat.SKF_STAGE_UPDATE)
 
 
 def flatten_relations(R, M=None):

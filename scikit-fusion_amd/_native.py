@@ -15,6 +15,9 @@ import numpy as np
 SKF_F64, SKF_F32, SKF_BF16 = 0, 1, 2
 SKF_DFMF, SKF_DFMC, SKF_TRANSFORM = 0, 1, 2
 SKF_ENGINE_MFMA, SKF_ENGINE_VALU = 0, 1
+SKF_REL_ABSENT, SKF_REL_NO_COL_SIDE, SKF_REL_MASKED = 1, 2, 4
+SKF_STAGE_CONTRACT, SKF_STAGE_BACKBONE, SKF_STAGE_ACCUMULATE, SKF_STAGE_UPDATE = 0, 1, 2, 3
+SKF_X_W, SKF_X_Q, SKF_X_QM, SKF_X_ED = 0, 1, 2, 3
 
 DTYPES = {'f64': SKF_F64, 'f32': SKF_F32, 'bf16': SKF_BF16, 'float64': SKF_F64, 'float32': SKF_F32}
 NP_DTYPE = {SKF_F64: np.float64, SKF_F32: np.float32, SKF_BF16: np.float32}   # dtype of the masters
@@ -48,7 +51,8 @@ class TypeDesc(C.Structure):
 
 class RelationDesc(C.Structure):
     _fields_ = [('row_type', C.c_int32), ('col_type', C.c_int32), ('data', C.c_void_p),
-                ('ld', C.c_int64), ('mask', C.c_void_p), ('mask_ld', C.c_int64)]
+                ('ld', C.c_int64), ('mask', C.c_void_p), ('mask_ld', C.c_int64),
+                ('row_begin', C.c_int64), ('n_rows', C.c_int64), ('flags', C.c_int32)]
 
 
 class ThetaDesc(C.Structure):
@@ -86,6 +90,9 @@ SIGNATURES = {
     'skf_accumulate': (C.c_int, [_P, _P]),
     'skf_apply_update': (C.c_int, [_P, _P]),
     'skf_accumulator_range': (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    'skf_stage': (C.c_int, [_P, C.c_int32, _P]),
+    'skf_exchange_range': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                     C.POINTER(C.c_int32)]),
     'skf_relation_sqerr': (C.c_int, [_P, C.c_int32, _P, _P]),
     'skf_plan_set_profiling': (C.c_int, [_P, C.c_int32]),
     'skf_plan_get_profile': (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

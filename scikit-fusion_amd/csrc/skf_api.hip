@@ -374,6 +374,11 @@ struct RelState {
     Slot Rb, RTb;                  // SKF_BF16: padded bf16 copies of R and R^T
     int64_t ldrb = 0, ldrtb = 0;
     bool s_set = false;
+    // row-block sharding: this plan holds rows [r0, r0 + nr) of the relation (nr == n_i: all of it)
+    int64_t r0 = 0, nr = 0;
+    bool absent = false;           // no local rows (W, Q, S are still kept for the exchange)
+    bool masked = false;           // DFMC: the relation has a mask (here or, for an absent one, elsewhere)
+    bool col_side = true;          // this plan adds the column-side terms E_j, D_j
 };
 
 struct ThetaState {
@@ -409,6 +414,9 @@ struct skf_plan {
     size_t part_aux_bytes = 0;
     bool overlap = false;
     size_t acc_off = 0, acc_bytes = 0;     // contiguous range of all E / D accumulators
+    // row-block sharding: contiguous ranges of all W, of the Q of unmasked / of masked relations
+    bool sliced = false;
+    size_t xw_off = 0, xw_bytes = 0, xq_off = 0, xq_bytes = 0, xqm_off = 0, xqm_bytes = 0;
     // one captured iteration (hipGraph) for launch-bound graphs; replayed by skf_iterate
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t graph_stream = nullptr;
@@ -494,7 +502,7 @@ static void relation_gemm(skf_plan* p, GemmArgs g, hipStream_t st, const RelStat
             run_gemm_bf16((const uint16_t*)r->Rb.ptr, r->ldrb, (const uint16_t*)tj.GTb.ptr, tj.ldgt, (float*)g.C,
                           g.ldc, g.M, g.N, (int)r->ldrb, 0, p->part.ptr, p->part_bytes, true, st);
         else            // Q = R^T G_i :  A = stored R^T (bf16), Bt = G_i^T (bf16)
-            run_gemm_bf16((const uint16_t*)r->RTb.ptr, r->ldrtb, (const uint16_t*)ti.GTb.ptr, ti.ldgt, (float*)g.C,
+            run_gemm_bf16((const uint16_t*)r->RTb.ptr, r->ldrtb, (const uint16_t*)ti.GTb.ptr + r->r0, ti.ldgt, (float*)g.C,
                           g.ldc, g.M, g.N, (int)r->ldrtb, 0, p->part.ptr, p->part_bytes, true, st);
     } else {
         run_gemm(GemmTypes{p->mt, p->mt, p->mt}, p->engine, g, 0, p->part.ptr, p->part_bytes, st, true);
@@ -641,47 +649,68 @@ static void relation_small_terms(skf_plan* p, RelState& r, int nan_upd, int epi_
 }
 
 // Fused E/D update of one relation side (MFMA engine): E (+)= (X Sop)+ + G Bn, D (+)= (X Sop)- + G Bp
+// on the rows [G, E, D point at the first one; n of them] of type t.
 static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const void* Sop, int64_t ss_k, int64_t ss_n,
-                        TypeState& t, const void* Bn, const void* Bp, bool accumulate, int nan, hipStream_t st) {
+                        TypeState& t, const void* G, void* E, void* D, int n, const void* Bn, const void* Bp,
+                        bool accumulate, int nan, hipStream_t st) {
     SideArgs a;
-    a.X = X; a.Sop = Sop; a.G = t.G.ptr; a.Bn = Bn; a.Bp = Bp; a.E = t.E.ptr; a.D = t.D.ptr;
+    a.X = X; a.Sop = Sop; a.G = G; a.Bn = Bn; a.Bp = Bp; a.E = E; a.D = D;
     a.ldx = ldx; a.ss_k = ss_k; a.ss_n = ss_n; a.ldg = t.c; a.ldb = t.c; a.lde = t.c;
-    a.n = (int)t.n; a.c = t.c; a.k1 = k1;
+    a.n = n; a.c = t.c; a.k1 = k1;
     a.accumulate = accumulate ? 1 : 0;
     a.nan_to_num = nan;
-    const bool big = (t.n > 64 && t.c > 64);
+    const bool big = (n > 64 && t.c > 64);
     dim3 block(GEMM_THREADS);
     if (p->f64) {
         if (big) {
-            dim3 grid(cdiv(t.c, 64), cdiv(t.n, 64));
+            dim3 grid(cdiv(t.c, 64), cdiv(n, 64));
             hipLaunchKernelGGL((side_update_kernel<double, double, 2, 2, 16>), grid, block, 0, st, a);
         } else {
-            dim3 grid(cdiv(t.c, 32), cdiv(t.n, 32));
+            dim3 grid(cdiv(t.c, 32), cdiv(n, 32));
             hipLaunchKernelGGL((side_update_kernel<double, double, 1, 1, 16>), grid, block, 0, st, a);
         }
     } else {
         if (big) {
-            dim3 grid(cdiv(t.c, 128), cdiv(t.n, 128));
+            dim3 grid(cdiv(t.c, 128), cdiv(n, 128));
             hipLaunchKernelGGL((side_update_kernel<float, double, 2, 2, 16>), grid, block, 0, st, a);
         } else {
-            dim3 grid(cdiv(t.c, 64), cdiv(t.n, 64));
+            dim3 grid(cdiv(t.c, 64), cdiv(n, 64));
             hipLaunchKernelGGL((side_update_kernel<float, double, 1, 1, 16>), grid, block, 0, st, a);
         }
     }
     check_launch("side_update");
 }
 
-// E/D accumulation of one iteration: everything of the loop body except the final G update.
-// With relation sharding every rank runs this on ITS relations / constraints, the E and D
-// accumulators are then summed over the ranks (one all-reduce), and apply_update follows.
-static void accumulate_fit(skf_plan* p, hipStream_t st) {
-    const bool dfmc = (p->variant == SKF_DFMC);
-    const int nan_upd = dfmc ? 0 : 1;       // _update_G_for_Rij (_dfmc.py:127-178) has no nan_to_num
+// A view of the rows [r0, r0 + nr) of a factor-shaped matrix (G, E, D) of type t
+static inline void* rows_of(const skf_plan* p, const Slot& s, const TypeState& t, int64_t r0) {
+    return (char*)s.ptr + (size_t)r0 * t.c * p->esz;
+}
 
+static void contraction_P(skf_plan* p, RelState& r, hipStream_t st) {      // P = R_blk G_j
+    TypeState& tj = p->types[r.col];
+    GemmArgs g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, tj.c, 1, r.P.ptr, tj.c, (int)r.nr, tj.c, (int)tj.n, EPI_STORE, 0);
+    relation_gemm(p, g, st, &r, false);
+}
+
+static void contraction_Q(skf_plan* p, RelState& r, hipStream_t st) {      // Q = R_blk^T G_i[blk]
+    TypeState& ti = p->types[r.row];
+    TypeState& tj = p->types[r.col];
+    if (r.absent) {
+        SKF_HIP(hipMemsetAsync(r.Q.ptr, 0, r.Q.bytes, st));
+        return;
+    }
+    GemmArgs g = gemm_args(r.R, 1, r.ldr, rows_of(p, ti.G, ti, r.r0), ti.c, 1, r.Q.ptr, ti.c, (int)tj.n, ti.c,
+                           (int)r.nr, EPI_STORE, 0);
+    relation_gemm(p, g, st, &r, true);
+}
+
+// Stage 1 of an iteration (SKF_STAGE_CONTRACT): everything that depends on G only.
+static void stage_contract(skf_plan* p, hipStream_t st) {
+    const bool dfmc = (p->variant == SKF_DFMC);
     if (dfmc && p->first_iter) {            // _dfmc.py:287-292
         for (RelState& r : p->rels) {
             if (!r.mask) continue;
-            const int64_t rows = p->types[r.row].n, cols = p->types[r.col].n;
+            const int64_t rows = r.nr, cols = p->types[r.col].n;
             if (p->bf16) {
                 hipLaunchKernelGGL((mask_zero_kernel<uint16_t>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
                                    (uint16_t*)r.Rb.ptr, r.ldrb, r.mask, r.ldmask, rows, cols);
@@ -698,9 +727,7 @@ static void accumulate_fit(skf_plan* p, hipStream_t st) {
     }
     p->first_iter = false;
 
-    const bool fused = (p->engine == SKF_ENGINE_MFMA);
     std::vector<int> all;
-    std::vector<char> touched(p->types.size(), 0);     // E/D of the type already written this iteration
     // ---- phase A (second stream when available): Gram_i and K_i = pinv(Gram_i).  They depend
     // only on G, exactly like the relation contractions of phase B, so the two phases overlap.
     // The Gram products use the whole chip and stay on the main stream; the pseudo-inverses are
@@ -719,12 +746,73 @@ static void accumulate_fit(skf_plan* p, hipStream_t st) {
     plan_pinv(p, all, sa);
     if (p->overlap) SKF_HIP(hipEventRecord(p->ev_join, p->aux));
 
-    // ---- phase B (main stream): every product that streams a relation matrix
+    // ---- phase B (main stream): every product that streams a relation matrix, and W = G_i^T P
+    for (RelState& r : p->rels) {
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        if (r.absent) {
+            SKF_HIP(hipMemsetAsync(r.W.ptr, 0, r.W.bytes, st));
+        } else {
+            contraction_P(p, r, st);
+        }
+        if (!(dfmc && r.masked)) contraction_Q(p, r, st);     // a masked relation is completed first
+        if (!r.absent) {
+            GemmArgs g = gemm_args(rows_of(p, ti.G, ti, r.r0), 1, ti.c, r.P.ptr, tj.c, 1, r.W.ptr, tj.c, ti.c, tj.c,
+                                   (int)r.nr, EPI_STORE, 0);
+            wide_gemm(p, g, st);
+        }
+    }
+    if (p->overlap) SKF_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
+}
+
+// Stage 2 (SKF_STAGE_BACKBONE): S = K_i W K_j; DFMC: completion, then P and Q of masked relations.
+static void stage_backbone(skf_plan* p, hipStream_t st) {
+    const bool dfmc = (p->variant == SKF_DFMC);
+    for (RelState& r : p->rels) {
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        const int nr = (int)r.nr, nj = (int)tj.n, ci = ti.c, cj = tj.c;
+        GemmArgs g;
+        // T1 = K_i W ; S = T1 K_j
+        g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);
+        small_gemm(p, g, st);
+        g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);
+        small_gemm(p, g, st);
+        if (!(dfmc && r.masked)) continue;
+        if (!r.absent) {
+            // H = G_i[blk] S ; Rw[mask] = (H G_j^T)[mask] ; P = Rw G_j        (_dfmc.py:319-325)
+            g = gemm_args(rows_of(p, ti.G, ti, r.r0), ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, nr, cj, ci, EPI_STORE, 0);
+            mixed_gemm(p, g, st);
+            if (r.mask) {
+                if (p->bf16) {     // completed entries go to both stored copies (R and R^T), as bf16
+                    g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rb.ptr, r.ldrb, nr, nj, cj, EPI_MASKED_STORE_BF16, 0);
+                    g.C2 = r.RTb.ptr;
+                    g.ldc2 = r.ldrtb;
+                } else {
+                    g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rw.ptr, r.ldr, nr, nj, cj, EPI_MASKED_STORE, 0);
+                }
+                g.mask = r.mask;
+                g.ldmask = r.ldmask;
+                plan_gemm(p, g, st);
+            }
+            contraction_P(p, r, st);
+        }
+        contraction_Q(p, r, st);
+    }
+}
+
+// Stage 3 (SKF_STAGE_ACCUMULATE): the E / D sums of this plan's row blocks, column sides and constraints.
+static void stage_accumulate(skf_plan* p, hipStream_t st) {
+    const bool dfmc = (p->variant == SKF_DFMC);
+    const int nan_upd = dfmc ? 0 : 1;       // _update_G_for_Rij (_dfmc.py:127-178) has no nan_to_num
+    const bool fused = (p->engine == SKF_ENGINE_MFMA);
+    std::vector<char> touched(p->types.size(), 0);     // E/D of the type already written this iteration
     for (size_t i = 0; i < p->types.size(); ++i) {
         TypeState& t = p->types[i];
         bool has_rel = false;
         for (RelState& r : p->rels) has_rel = has_rel || r.row == (int)i || r.col == (int)i;
-        if (!fused || !has_rel) {          // the fused update overwrites E/D on first touch
+        // the fused update overwrites E/D on first touch -- of whole matrices only
+        if (!fused || !has_rel || p->sliced) {
             SKF_HIP(hipMemsetAsync(t.E.ptr, 0, t.E.bytes, st));
             SKF_HIP(hipMemsetAsync(t.D.ptr, 0, t.D.bytes, st));
             touched[i] = 1;
@@ -733,77 +821,60 @@ static void accumulate_fit(skf_plan* p, hipStream_t st) {
     for (RelState& r : p->rels) {
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
-        const int ni = (int)ti.n, nj = (int)tj.n, ci = ti.c, cj = tj.c;
-        // P = R G_j
-        GemmArgs g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
-        relation_gemm(p, g, st, &r, false);
-        if (!(dfmc && r.mask)) {           // Q = R^T G_i (a masked relation is completed first)
-            g = gemm_args(r.R, 1, r.ldr, ti.G.ptr, ci, 1, r.Q.ptr, ci, nj, ci, ni, EPI_STORE, 0);
-            relation_gemm(p, g, st, &r, true);
-        }
-    }
-    if (p->overlap) SKF_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
-
-    // ---- phase C: backbones and accumulator updates
-    for (RelState& r : p->rels) {
-        TypeState& ti = p->types[r.row];
-        TypeState& tj = p->types[r.col];
-        const int ni = (int)ti.n, nj = (int)tj.n, ci = ti.c, cj = tj.c;
+        const int nr = (int)r.nr, nj = (int)tj.n, ci = ti.c, cj = tj.c;
+        const bool row_side = !r.absent, col_side = r.col_side;
+        if (!row_side && !col_side) continue;
+        relation_small_terms(p, r, nan_upd, EPI_SPLIT_STORE, r.Bp.ptr, r.Bn.ptr, r.Dp.ptr, r.Dn.ptr, row_side, col_side, st);
+        void* Gi = rows_of(p, ti.G, ti, r.r0);
+        void* Ei = rows_of(p, ti.E, ti, r.r0);
+        void* Di = rows_of(p, ti.D, ti, r.r0);
         GemmArgs g;
-        // W = G_i^T P ; T1 = K_i W ; S = T1 K_j
-        g = gemm_args(ti.G.ptr, 1, ci, r.P.ptr, cj, 1, r.W.ptr, cj, ci, cj, ni, EPI_STORE, 0);
-        wide_gemm(p, g, st);
-        g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);
-        small_gemm(p, g, st);
-        g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);
-        small_gemm(p, g, st);
-        if (dfmc && r.mask) {
-            // H = G_i S ; Rw[mask] = (H G_j^T)[mask] ; P = Rw G_j        (_dfmc.py:319-325)
-            g = gemm_args(ti.G.ptr, ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, ni, cj, ci, EPI_STORE, 0);
-            mixed_gemm(p, g, st);
-            if (p->bf16) {         // completed entries go to both stored copies (R and R^T), as bf16
-                g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rb.ptr, r.ldrb, ni, nj, cj, EPI_MASKED_STORE_BF16, 0);
-                g.C2 = r.RTb.ptr;
-                g.ldc2 = r.ldrtb;
-            } else {
-                g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rw.ptr, r.ldr, ni, nj, cj, EPI_MASKED_STORE, 0);
-            }
-            g.mask = r.mask;
-            g.ldmask = r.ldmask;
-            plan_gemm(p, g, st);
-            g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
-            relation_gemm(p, g, st, &r, false);
-            g = gemm_args(r.R, 1, r.ldr, ti.G.ptr, ci, 1, r.Q.ptr, ci, nj, ci, ni, EPI_STORE, 0);
-            relation_gemm(p, g, st, &r, true);
-        }
-        relation_small_terms(p, r, nan_upd, EPI_SPLIT_STORE, r.Bp.ptr, r.Bn.ptr, r.Dp.ptr, r.Dn.ptr, true, true, st);
         if (fused) {
             // row side: A = P S^T (Sop(k,j) = S[j][k]);  column side: C = Q S
-            side_update(p, r.P.ptr, cj, cj, r.S.ptr, 1, cj, ti, r.Bn.ptr, r.Bp.ptr, touched[r.row] != 0, nan_upd, st);
-            touched[r.row] = 1;
-            side_update(p, r.Q.ptr, ci, ci, r.S.ptr, cj, 1, tj, r.Dn.ptr, r.Dp.ptr, touched[r.col] != 0, nan_upd, st);
-            touched[r.col] = 1;
+            if (row_side) {
+                side_update(p, r.P.ptr, cj, cj, r.S.ptr, 1, cj, ti, Gi, Ei, Di, nr, r.Bn.ptr, r.Bp.ptr,
+                            touched[r.row] != 0, nan_upd, st);
+                touched[r.row] = 1;
+            }
+            if (col_side) {
+                side_update(p, r.Q.ptr, ci, ci, r.S.ptr, cj, 1, tj, tj.G.ptr, tj.E.ptr, tj.D.ptr, nj, r.Dn.ptr, r.Dp.ptr,
+                            touched[r.col] != 0, nan_upd, st);
+                touched[r.col] = 1;
+            }
             continue;
         }
-        // E_i += (P S^T)+ ; D_i += (P S^T)-          (_dfmf.py:254-258, 278-279)
-        g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, ti.E.ptr, ci, ni, ci, cj, EPI_SPLIT_ACC, nan_upd);
-        g.C2 = ti.D.ptr;
-        mixed_gemm(p, g, st);
-        // E_i += G_i B- ; D_i += G_i B+
-        g = gemm_args(ti.G.ptr, ci, 1, r.Bn.ptr, ci, 1, ti.E.ptr, ci, ni, ci, ci, EPI_ACC, 0);
-        mixed_gemm(p, g, st);
-        g = gemm_args(ti.G.ptr, ci, 1, r.Bp.ptr, ci, 1, ti.D.ptr, ci, ni, ci, ci, EPI_ACC, 0);
-        mixed_gemm(p, g, st);
-        // E_j += (Q S)+ ; D_j += (Q S)-              (_dfmf.py:266-270, 281-282)
-        g = gemm_args(r.Q.ptr, ci, 1, r.S.ptr, cj, 1, tj.E.ptr, cj, nj, cj, ci, EPI_SPLIT_ACC, nan_upd);
-        g.C2 = tj.D.ptr;
-        mixed_gemm(p, g, st);
-        g = gemm_args(tj.G.ptr, cj, 1, r.Dn.ptr, cj, 1, tj.E.ptr, cj, nj, cj, cj, EPI_ACC, 0);
-        mixed_gemm(p, g, st);
-        g = gemm_args(tj.G.ptr, cj, 1, r.Dp.ptr, cj, 1, tj.D.ptr, cj, nj, cj, cj, EPI_ACC, 0);
-        mixed_gemm(p, g, st);
+        if (row_side) {
+            // E_i += (P S^T)+ ; D_i += (P S^T)-          (_dfmf.py:254-258, 278-279)
+            g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, Ei, ci, nr, ci, cj, EPI_SPLIT_ACC, nan_upd);
+            g.C2 = Di;
+            mixed_gemm(p, g, st);
+            // E_i += G_i B- ; D_i += G_i B+
+            g = gemm_args(Gi, ci, 1, r.Bn.ptr, ci, 1, Ei, ci, nr, ci, ci, EPI_ACC, 0);
+            mixed_gemm(p, g, st);
+            g = gemm_args(Gi, ci, 1, r.Bp.ptr, ci, 1, Di, ci, nr, ci, ci, EPI_ACC, 0);
+            mixed_gemm(p, g, st);
+        }
+        if (col_side) {
+            // E_j += (Q S)+ ; D_j += (Q S)-              (_dfmf.py:266-270, 281-282)
+            g = gemm_args(r.Q.ptr, ci, 1, r.S.ptr, cj, 1, tj.E.ptr, cj, nj, cj, ci, EPI_SPLIT_ACC, nan_upd);
+            g.C2 = tj.D.ptr;
+            mixed_gemm(p, g, st);
+            g = gemm_args(tj.G.ptr, cj, 1, r.Dn.ptr, cj, 1, tj.E.ptr, cj, nj, cj, cj, EPI_ACC, 0);
+            mixed_gemm(p, g, st);
+            g = gemm_args(tj.G.ptr, cj, 1, r.Dp.ptr, cj, 1, tj.D.ptr, cj, nj, cj, cj, EPI_ACC, 0);
+            mixed_gemm(p, g, st);
+        }
     }
     theta_terms(p, st);
+}
+
+// E/D accumulation of one iteration: everything of the loop body except the final G update.
+// With relation sharding every rank runs this on ITS relations / constraints, the E and D
+// accumulators are then summed over the ranks (one all-reduce), and apply_update follows.
+static void accumulate_fit(skf_plan* p, hipStream_t st) {
+    stage_contract(p, st);
+    stage_backbone(p, st);
+    stage_accumulate(p, st);
 }
 
 // G_i <- G_i * sqrt(E_i / max(D_i, eps)) for every type   (_dfmf.py:294-296)
@@ -963,10 +1034,22 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             if (d.row_type < 0 || d.row_type >= n_types || d.col_type < 0 || d.col_type >= n_types)
                 SKF_FAIL(SKF_E_INVALID, "relation %d: type index out of range", r);
             if (d.row_type == d.col_type) SKF_FAIL(SKF_E_INVALID, "relation %d: row type == column type (pass it as a constraint)", r);
-            if (!d.data || d.ld < p->types[d.col_type].n)
+            const bool absent = (d.flags & SKF_REL_ABSENT) != 0;
+            if (!absent && (!d.data || d.ld < p->types[d.col_type].n))
                 SKF_FAIL(SKF_E_INVALID, "relation %d: dimension mismatch (ld %lld < %lld columns)", r, (long long)d.ld,
                          (long long)p->types[d.col_type].n);
-            if (d.mask && p->variant != SKF_DFMC) SKF_FAIL(SKF_E_INVALID, "relation %d: masks need SKF_DFMC", r);
+            const int64_t n_row_type = p->types[d.row_type].n;
+            if (d.row_begin < 0 || d.n_rows < 0 || d.row_begin + d.n_rows > n_row_type)
+                SKF_FAIL(SKF_E_INVALID, "relation %d: row block [%lld, +%lld) outside the %lld objects of its row type",
+                         r, (long long)d.row_begin, (long long)d.n_rows, (long long)n_row_type);
+            const bool block = absent || (d.n_rows > 0 && d.n_rows < n_row_type) || (d.flags & SKF_REL_NO_COL_SIDE);
+            if (block && p->variant == SKF_TRANSFORM)
+                SKF_FAIL(SKF_E_INVALID, "relation %d: row blocks are for SKF_DFMF / SKF_DFMC plans", r);
+            if (block && p->bf16 && d.row_begin % 64 != 0)
+                SKF_FAIL(SKF_E_INVALID, "relation %d: SKF_BF16 row blocks must start at a multiple of 64", r);
+            if (block) p->sliced = true;
+            if ((d.mask || (d.flags & SKF_REL_MASKED)) && p->variant != SKF_DFMC)
+                SKF_FAIL(SKF_E_INVALID, "relation %d: masks need SKF_DFMC", r);
             if (d.mask && d.mask_ld < p->types[d.col_type].n) SKF_FAIL(SKF_E_INVALID, "relation %d: mask ld", r);
             if (p->variant == SKF_TRANSFORM && d.row_type != p->target && d.col_type != p->target)
                 SKF_FAIL(SKF_E_INVALID, "relation %d must include the target object type", r);
@@ -974,6 +1057,12 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             s.row = d.row_type; s.col = d.col_type;
             s.R_in = d.data; s.ld_in = d.ld; s.mask = d.mask; s.ldmask = d.mask_ld;
             s.R = d.data; s.ldr = d.ld;
+            s.absent = absent;
+            s.r0 = absent ? 0 : d.row_begin;
+            s.nr = absent ? 0 : (d.n_rows > 0 ? d.n_rows : n_row_type - d.row_begin);
+            s.col_side = (d.flags & SKF_REL_NO_COL_SIDE) == 0;
+            s.masked = d.mask != nullptr || (d.flags & SKF_REL_MASKED) != 0;
+            if (absent) { s.R_in = s.R = nullptr; s.mask = nullptr; }
         }
         p->thetas.resize(n_thetas);
         for (int t = 0; t < n_thetas; ++t) {
@@ -1029,42 +1118,58 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             }
         }
         size_t sq_elems = 1;
+        if (p->variant != SKF_TRANSFORM) {
+            // exchange ranges of row-block sharding: all W; then Q of unmasked, then of masked relations
+            p->xw_off = p->ws_bytes;
+            for (RelState& r : p->rels) add_slot(p, r.W, (size_t)p->types[r.row].c * p->types[r.col].c * 8);
+            p->xw_bytes = p->ws_bytes - p->xw_off;
+            p->xq_off = p->ws_bytes;
+            for (RelState& r : p->rels)
+                if (!r.masked) add_slot(p, r.Q, (size_t)p->types[r.col].n * p->types[r.row].c * es);
+            p->xq_bytes = p->ws_bytes - p->xq_off;
+            p->xqm_off = p->ws_bytes;
+            for (RelState& r : p->rels)
+                if (r.masked) add_slot(p, r.Q, (size_t)p->types[r.col].n * p->types[r.row].c * es);
+            p->xqm_bytes = p->ws_bytes - p->xqm_off;
+        }
         for (RelState& r : p->rels) {
             TypeState& ti = p->types[r.row];
             TypeState& tj = p->types[r.col];
             const size_t cc = (size_t)ti.c * tj.c * 8;
+            const int64_t nr = p->variant == SKF_TRANSFORM ? ti.n : r.nr;      // local rows
+            if (p->variant == SKF_TRANSFORM) { r.nr = ti.n; r.r0 = 0; }
             add_slot(p, r.S, cc);
             add_slot(p, r.U, cc);
-            add_slot(p, r.H, (size_t)ti.n * tj.c * es);
-            if (p->variant != SKF_TRANSFORM || r.row == p->target) add_slot(p, r.P, (size_t)ti.n * tj.c * es);
-            if (p->variant != SKF_TRANSFORM || r.col == p->target) add_slot(p, r.Q, (size_t)tj.n * ti.c * es);
+            if (nr > 0) add_slot(p, r.H, (size_t)nr * tj.c * es);
+            if (nr > 0 && (p->variant != SKF_TRANSFORM || r.row == p->target)) add_slot(p, r.P, (size_t)nr * tj.c * es);
+            if (p->variant == SKF_TRANSFORM && r.col == p->target) add_slot(p, r.Q, (size_t)tj.n * ti.c * es);
             if (p->variant != SKF_TRANSFORM) {
-                add_slot(p, r.W, cc);
                 add_slot(p, r.T1, cc);
                 add_slot(p, r.Bp, (size_t)ti.c * ti.c * 8);
                 add_slot(p, r.Bn, (size_t)ti.c * ti.c * 8);
                 add_slot(p, r.Dp, (size_t)tj.c * tj.c * 8);
                 add_slot(p, r.Dn, (size_t)tj.c * tj.c * 8);
-                want_part(ti.c, tj.c, (int)ti.n, true);
+                if (nr > 0) want_part(ti.c, tj.c, (int)nr, true);
             }
-            if (r.mask && !p->bf16) add_slot(p, r.Rw, (size_t)ti.n * tj.n * es);
-            if (p->bf16) {
-                r.ldrb = pad64(tj.n);
-                r.ldrtb = pad64(ti.n);
-                add_slot(p, r.Rb, (size_t)ti.n * r.ldrb * 2);
-                add_slot(p, r.RTb, (size_t)tj.n * r.ldrtb * 2);
-                size_t b1 = bf16_part_bytes((int)ti.n, tj.c, (int)r.ldrb), b2 = bf16_part_bytes((int)tj.n, ti.c, (int)r.ldrtb);
-                if (b1 > part_bytes) part_bytes = b1;
-                if (b2 > part_bytes) part_bytes = b2;
-            }
-            want_part((int)ti.n, tj.c, (int)tj.n, p->f64);
-            want_part((int)tj.n, ti.c, (int)ti.n, p->f64);
-            want_part((int)ti.n, ti.c, tj.c, p->f64);
-            want_part((int)tj.n, tj.c, ti.c, p->f64);
             want_part(ti.c, tj.c, ti.c > tj.c ? ti.c : tj.c, true);
             want_part(ti.c, ti.c, tj.c, true);
             want_part(tj.c, tj.c, ti.c, true);
-            size_t blocks = (size_t)cdiv(ti.n, 32) * cdiv(tj.n, 32);
+            if (nr <= 0) continue;
+            if (r.mask && !p->bf16) add_slot(p, r.Rw, (size_t)nr * tj.n * es);
+            if (p->bf16) {
+                r.ldrb = pad64(tj.n);
+                r.ldrtb = pad64(nr);
+                add_slot(p, r.Rb, (size_t)nr * r.ldrb * 2);
+                add_slot(p, r.RTb, (size_t)tj.n * r.ldrtb * 2);
+                size_t b1 = bf16_part_bytes((int)nr, tj.c, (int)r.ldrb), b2 = bf16_part_bytes((int)tj.n, ti.c, (int)r.ldrtb);
+                if (b1 > part_bytes) part_bytes = b1;
+                if (b2 > part_bytes) part_bytes = b2;
+            }
+            want_part((int)nr, tj.c, (int)tj.n, p->f64);
+            want_part((int)tj.n, ti.c, (int)nr, p->f64);
+            want_part((int)nr, ti.c, tj.c, p->f64);
+            want_part((int)tj.n, tj.c, ti.c, p->f64);
+            size_t blocks = (size_t)cdiv(nr, 32) * cdiv(tj.n, 32);
             if (blocks > sq_elems) sq_elems = blocks;
         }
         for (ThetaState& th : p->thetas)
@@ -1119,7 +1224,7 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
         hipStream_t st = as_stream(stream);
         for (RelState& r : p->rels) {
             if (!r.mask || p->bf16) continue;      // bf16: the padded R / R^T copies are the working set
-            const int64_t rows = p->types[r.row].n, cols = p->types[r.col].n;
+            const int64_t rows = r.nr, cols = p->types[r.col].n;
             copy2d(r.Rw.ptr, cols, r.R_in, r.ld_in, rows, cols, p->esz, st);
             r.R = r.Rw.ptr;
             r.ldr = cols;
@@ -1129,7 +1234,8 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             // it is not referenced after this call
             for (TypeState& t : p->types) SKF_HIP(hipMemsetAsync(t.GTb.ptr, 0, t.GTb.bytes, st));
             for (RelState& r : p->rels) {
-                const int64_t rows = p->types[r.row].n, cols = p->types[r.col].n;
+                if (r.absent) continue;
+                const int64_t rows = r.nr, cols = p->types[r.col].n;
                 SKF_HIP(hipMemsetAsync(r.Rb.ptr, 0, r.Rb.bytes, st));
                 SKF_HIP(hipMemsetAsync(r.RTb.ptr, 0, r.RTb.bytes, st));
                 launch_to_bf16<uint16_t>((uint16_t*)r.Rb.ptr, r.ldrb, (const uint16_t*)r.R_in, r.ld_in, rows, cols, false, st);
@@ -1237,6 +1343,7 @@ int skf_get_backbone(const skf_plan* p, int32_t rel, void* S, int64_t ld, void* 
 int skf_iterate(skf_plan* p, int32_t n_iters, void* stream) {
     return guarded([&] {
         check_bound(p);
+        if (p->sliced) SKF_FAIL(SKF_E_STATE, "a plan with row blocks iterates through skf_stage + the exchanges");
         if (n_iters < 0) SKF_FAIL(SKF_E_INVALID, "n_iters < 0");
         for (size_t i = 0; i < p->types.size(); ++i)
             if (!p->types[i].set) SKF_FAIL(SKF_E_STATE, "factor of object type %zu not set", i);
@@ -1283,6 +1390,37 @@ int skf_apply_update(skf_plan* p, void* stream) {
     });
 }
 
+int skf_stage(skf_plan* p, int32_t stage, void* stream) {
+    return guarded([&] {
+        check_bound(p);
+        if (p->variant == SKF_TRANSFORM) SKF_FAIL(SKF_E_INVALID, "skf_stage: SKF_DFMF / SKF_DFMC plans only");
+        for (size_t i = 0; i < p->types.size(); ++i)
+            if (!p->types[i].set) SKF_FAIL(SKF_E_STATE, "factor of object type %zu not set", i);
+        hipStream_t st = as_stream(stream);
+        switch (stage) {
+            case SKF_STAGE_CONTRACT: stage_contract(p, st); break;
+            case SKF_STAGE_BACKBONE: stage_backbone(p, st); break;
+            case SKF_STAGE_ACCUMULATE: stage_accumulate(p, st); break;
+            case SKF_STAGE_UPDATE: apply_update(p, st); break;
+            default: SKF_FAIL(SKF_E_INVALID, "unknown stage %d", stage);
+        }
+    });
+}
+
+int skf_exchange_range(const skf_plan* p, int32_t which, size_t* offset, size_t* bytes, int32_t* dtype) {
+    return guarded([&] {
+        if (!p || !offset || !bytes || !dtype) SKF_FAIL(SKF_E_INVALID, "null argument");
+        *dtype = p->mt;
+        switch (which) {
+            case SKF_X_W: *offset = p->xw_off; *bytes = p->xw_bytes; *dtype = SKF_F64; break;
+            case SKF_X_Q: *offset = p->xq_off; *bytes = p->xq_bytes; break;
+            case SKF_X_QM: *offset = p->xqm_off; *bytes = p->xqm_bytes; break;
+            case SKF_X_ED: *offset = p->acc_off; *bytes = p->acc_bytes; break;
+            default: SKF_FAIL(SKF_E_INVALID, "unknown exchange range %d", which);
+        }
+    });
+}
+
 int skf_accumulator_range(const skf_plan* p, size_t* offset, size_t* bytes) {
     return guarded([&] {
         if (!p || !offset || !bytes) SKF_FAIL(SKF_E_INVALID, "null argument");
@@ -1299,8 +1437,12 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
         RelState& r = p->rels[rel];
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
-        const int ni = (int)ti.n, nj = (int)tj.n, ci = ti.c, cj = tj.c;
-        GemmArgs g = gemm_args(ti.G.ptr, ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, ni, cj, ci, EPI_STORE, 0);
+        const int ni = (int)r.nr, nj = (int)tj.n, ci = ti.c, cj = tj.c;        // the local rows
+        if (r.absent) {
+            SKF_HIP(hipMemsetAsync(out, 0, sizeof(double), st));
+            return;
+        }
+        GemmArgs g = gemm_args(rows_of(p, ti.G, ti, r.r0), ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, ni, cj, ci, EPI_STORE, 0);
         mixed_gemm(p, g, st);
         g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, (void*)r.R, r.ldr, ni, nj, cj, EPI_SQDIFF, 0);
         g.C2 = p->sqpart.ptr;

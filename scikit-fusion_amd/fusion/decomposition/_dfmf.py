@@ -42,6 +42,58 @@ def _rel_index(rel_list, target):
     return hits[l]
 
 
+def row_block_plan(variant, rel_list, theta_list, obj_types, n_obj, obj_type2rank, dtype, engine, rank, size):
+    """The plan of rank `rank` of `size` in a row-block-sharded fit: all relations listed, each with
+    this rank's row block of `_distributed.partition_rows` (or marked absent)."""
+    from ..._distributed import partition_rows
+    # block boundaries: multiples of the contraction tile for big graphs; bf16 needs multiples of 64
+    align = 256 if min(n_obj.values()) >= 4096 else (64 if dtype == 'bf16' else 1)
+    blocks, theta_owner = partition_rows(rel_list, theta_list, n_obj, obj_type2rank, align=align, size=size)
+    local = []
+    for (i, j, m, mask), blk in zip(rel_list, blocks):
+        mine = [b for b in blk if b[0] == rank]
+        info = {'masked': mask is not None, 'col_side': bool(mine) and mine[0][1] == 0}
+        if not mine:
+            info.update(absent=True, row_begin=0, n_rows=0, col_side=False)
+            local.append((i, j, None, None, info))
+            continue
+        _, a, cnt = mine[0]
+        info.update(absent=False, row_begin=a, n_rows=cnt)
+        local.append((i, j, np.asarray(m)[a:a + cnt], None if mask is None else np.asarray(mask)[a:a + cnt], info))
+    return DevicePlan(obj_types, n_obj, obj_type2rank, local,
+                      [t for t, o in zip(theta_list, theta_owner) if o == rank], variant,
+                      dtype=dtype, engine=engine)
+
+
+def run_fit_rows(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
+                 random_state, dtype, G0, engine):
+    """One fit whose relations are cut into balanced ROW BLOCKS over the ranks of the process group
+    (SURVEY.md 8e): every rank lists all relations with its own row block (or none), factors are
+    replicated, and an iteration is four stages with all-reduces of W / Q, E / D in between
+    (`DevicePlan.iterate_rows`).  Every rank ends with the full (G, S)."""
+    from ..._distributed import world
+    obj_types = list(obj_types)
+    n_obj = count_objects(obj_types, R)
+    if G0 is None:
+        R_first = {k: np.asarray(v[0], dtype=float) for k, v in R.items()}
+        G0 = initialize(obj_types, n_obj, obj_type2rank, R_first, init_type, _as_rs(random_state))
+    rel_list = flatten_relations(R, M)
+    rank, size = world()
+    plan = row_block_plan(variant, rel_list, flatten_thetas(Theta), obj_types, n_obj, obj_type2rank, dtype,
+                          engine, rank, size)
+    try:
+        for t in obj_types:
+            plan.set_factor(t, G0[t, t])
+        plan.iterate_rows(max_iter)
+        G = {(t, t): plan.get_factor(t) for t in obj_types}
+        S = {}
+        for k, (i, j, _, _) in enumerate(rel_list):
+            S.setdefault((i, j), []).append(plan.get_backbone(k))
+        return G, S
+    finally:
+        plan.close()
+
+
 def run_fit_sharded(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
                     random_state, dtype, G0, engine):
     """One fit whose relations are partitioned over the ranks of the process group (one GPU
@@ -133,7 +185,7 @@ def run_fit(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
 
 def _sharded_ok(stopping, stopping_system, compute_err, callback):
     if stopping or stopping_system or compute_err or callback:
-        raise ValueError("shard='relations' does not support callback / stopping / compute_err")
+        raise ValueError("shard='relations' / 'rows' do not support callback / stopping / compute_err")
 
 
 def dfmf(R, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol",
@@ -142,10 +194,11 @@ def dfmf(R, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol
     """Data fusion by matrix factorization -- drop-in for reference ``dfmf`` (_dfmf.py:127).
     ``shard='relations'`` (with an initialised torch.distributed group) partitions the relations
     of this ONE fit over the ranks."""
-    if shard == 'relations':
+    if shard in ('relations', 'rows'):
         _sharded_ok(stopping, stopping_system, compute_err, callback)
-        return run_fit_sharded(nat.SKF_DFMF, R, None, Theta, obj_types, obj_type2rank, max_iter,
-                               init_type, random_state, dtype, G0, engine)
+        fit = run_fit_sharded if shard == 'relations' else run_fit_rows
+        return fit(nat.SKF_DFMF, R, None, Theta, obj_types, obj_type2rank, max_iter,
+                   init_type, random_state, dtype, G0, engine)
     return run_fit(nat.SKF_DFMF, R, None, Theta, obj_types, obj_type2rank, max_iter, init_type,
                    stopping, stopping_system, verbose, compute_err, callback, random_state,
                    dtype, G0, engine)

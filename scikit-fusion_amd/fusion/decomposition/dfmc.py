@@ -35,8 +35,8 @@ class Dfmc(FusionFit):
                   stopping_system=self.stopping_system, verbose=self.verbose,
                   compute_err=self.compute_err, callback=self.callback,
                   random_state=self.random_state, n_jobs=self.n_jobs, dtype=self.dtype)
-        if self.shard == 'relations':
-            store_runs(self, [_dfmc.dfmc(G0=G0[k], shard='relations', **kw) for k in range(self.n_run)])
+        if self.shard in ('relations', 'rows'):
+            store_runs(self, [_dfmc.dfmc(G0=G0[k], shard=self.shard, **kw) for k in range(self.n_run)])
             return self
         local = {k: _dfmc.dfmc(G0=G0[k], **kw) for k in my_runs(self.n_run)}
         store_runs(self, gather_runs(local, self.n_run))

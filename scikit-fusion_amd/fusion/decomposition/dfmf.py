@@ -80,8 +80,9 @@ class Dfmf(FusionFit):
     Parameters (identical to the reference): max_iter=100, init_type='random_c', n_run=1,
     stopping=None, stopping_system=None, verbose=0, compute_err=False, callback=None,
     random_state=None, n_jobs=1.  Additions: dtype='f64' | 'f32' | 'bf16' (device arithmetic),
-    shard='runs' | 'relations' (what a torch.distributed process group shares out: whole
-    restarts -- no collective -- or the relations of each restart -- one all-reduce/iteration).
+    shard='runs' | 'relations' | 'rows' (what a torch.distributed process group shares out: whole
+    restarts -- no collective; the relations of each restart -- one all-reduce per iteration; or
+    balanced row blocks of the relations -- all-reduces of W, Q and E / D per iteration).
     """
 
     def __init__(self, max_iter=100, init_type='random_c', n_run=1, stopping=None,
@@ -102,8 +103,8 @@ class Dfmf(FusionFit):
                   stopping_system=self.stopping_system, verbose=self.verbose,
                   compute_err=self.compute_err, callback=self.callback,
                   random_state=self.random_state, n_jobs=self.n_jobs, dtype=self.dtype)
-        if self.shard == 'relations':                   # all GPUs cooperate on every restart
-            store_runs(self, [_dfmf.dfmf(G0=G0[k], shard='relations', **kw) for k in range(self.n_run)])
+        if self.shard in ('relations', 'rows'):                   # all GPUs cooperate on every restart
+            store_runs(self, [_dfmf.dfmf(G0=G0[k], shard=self.shard, **kw) for k in range(self.n_run)])
             return self
         local = {k: _dfmf.dfmf(G0=G0[k], **kw)
                  for k in my_runs(self.n_run)}          # one restart per GPU when distributed

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from helpers import C5_RELATIONS as C5_REL, C5_TYPES      # noqa: E402
 
 
 def _free_port():
@@ -48,7 +50,17 @@ def _probe_sharded(shard):
     return out
 
 
-def _worker(rank, world, port, out):
+def _c5_sharded(shard='relations'):
+    """BASELINE config 5 (scaled): MovieLens-style Dfmc, its 6 relations / 3 constraints over the ranks."""
+    from helpers import golden, movielens_style_graph, g0_from
+    from skfusion_amd.fusion.decomposition import _dfmc
+    z = golden('c5_movielens_scaled.npz')
+    R, M, Theta, types, rank = movielens_style_graph()
+    G, S = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=2, G0=g0_from(z, 'dfmc/', types), shard=shard)
+    return [G[t, t] for t in types] + [S[i, j][0] for i, j, _, _ in C5_REL]
+
+
+def _worker(rank, world, port, out, what):
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, HERE)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -61,10 +73,11 @@ def _worker(rank, world, port, out):
         assert dist_world() == (rank, world)
         assert my_runs(3) == ([0, 2] if rank == 0 else [1])
         with nat.use_runtime(emulated_runtime()):
-            res = _fit()
-            res2 = _probe_sharded('relations')
-        np.savez(os.path.join(out, 'rank%d.npz' % rank), *res)
-        np.savez(os.path.join(out, 'shard%d.npz' % rank), *res2)
+            if what == 'runs':
+                np.savez(os.path.join(out, 'rank%d.npz' % rank), *_fit())
+            else:
+                np.savez(os.path.join(out, 'shard%d.npz' % rank), *_probe_sharded(what))
+                np.savez(os.path.join(out, 'c5_%d.npz' % rank), *_c5_sharded(what))
     finally:
         dist.destroy_process_group()
 
@@ -77,23 +90,25 @@ def test_restarts_sharded_over_two_gloo_ranks(tmp_path):
     with nat.use_runtime(emulated_runtime()):
         single = _fit()
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), 'runs'), nprocs=2, join=True)
     for rank in range(2):
         z = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % rank))
         for k, want in enumerate(single):
             np.testing.assert_array_equal(z['arr_%d' % k], want)
 
 
-def test_relations_sharded_over_two_gloo_ranks_match_golden(tmp_path):
-    """One fit, relations + constraints partitioned over 2 ranks, E/D all-reduced every iteration:
+@pytest.mark.parametrize('shard', ['relations', 'rows'])
+def test_one_fit_sharded_over_two_gloo_ranks_matches_golden(tmp_path, shard):
+    """One fit over 2 ranks -- whole relations + constraints partitioned (E/D all-reduced every
+    iteration), or balanced row blocks of the relations (W, Q, E/D all-reduced between the stages):
     both ranks must reproduce the reference goldens (iteration 10 of the probe graph, DFMF and
-    DFMC) to 1e-9 -- the same bar as the single-device engine."""
+    DFMC; iteration 2 of the MovieLens-style config 5) to 1e-9 -- the bar of the single-device engine."""
     import torch.multiprocessing as mp
     from emul.runtime import build
     from helpers import golden, TYPES, relerr
     build()
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), shard), nprocs=2, join=True)
     z = golden('probe_multirel.npz')
     pairs = [('t1', 't2', 0), ('t1', 't2', 1), ('t1', 't3', 0), ('t2', 't3', 0)]
     for rank in range(2):
@@ -104,3 +119,12 @@ def test_relations_sharded_over_two_gloo_ranks_match_golden(tmp_path):
                 assert relerr(arrs[v + k], z['%s/G_%s_it9' % (variant, t)]) < 1e-9
             for k, (i, j, l) in enumerate(pairs):
                 assert relerr(arrs[v + 3 + k], z['%s/S_%s_%s_%d_it9' % (variant, i, j, l)]) < 1e-9
+    # config 5 (MovieLens-style Dfmc, 6 relations + 3 constraints over 2 ranks): iteration 2 of the golden
+    z5 = golden('c5_movielens_scaled.npz')
+    for rank in range(2):
+        a = np.load(os.path.join(str(tmp_path), 'c5_%d.npz' % rank))
+        arrs = [a['arr_%d' % k] for k in range(len(a.files))]
+        for k, t in enumerate(C5_TYPES):
+            assert relerr(arrs[k], z5['dfmc/G_%s_it1' % t]) < 1e-9
+        for k, (i, j, _, _) in enumerate(C5_REL):
+            assert relerr(arrs[len(C5_TYPES) + k], z5['dfmc/S_%s_%s_0_it1' % (i, j)]) < 1e-9

@@ -85,6 +85,16 @@ def test_probe_graph_dfmc_masks_and_inputs_untouched():
             np.testing.assert_array_equal(a, b)
 
 
+def test_c5_movielens_style_dfmc_two_iterations():
+    """BASELINE config 5 (scaled): 6 relations, 98 % masked ratings, lam*I and sparse negative Theta."""
+    from helpers import movielens_style_graph
+    z = golden('c5_movielens_scaled.npz')
+    R, M, Theta, types, rank = movielens_style_graph()
+    snaps = Snapshots((0, 1))
+    _dfmc.dfmc(R, M, Theta, types, rank, max_iter=2, callback=snaps, G0=g0_from(z, 'dfmc/', types))
+    assert compare_snapshots(z, 'dfmc/', snaps.snap, 1e-9) < 1e-9
+
+
 @pytest.mark.parametrize('variant', ['dfmf', 'dfmc'])
 def test_rank_deficient_gram(variant):
     z = golden('rank_deficient.npz')
@@ -215,6 +225,67 @@ def test_bf16_dfmc_masked_completion():
             e = np.linalg.norm((m - G[i, i] @ S[i, j][l] @ G[j, j].T)[keepm])
             eo = np.linalg.norm((m - Go[i, i] @ So[i, j][l] @ Go[j, j].T)[keepm])
             assert abs(e - eo) < 5e-2 * eo
+
+
+@pytest.mark.parametrize('variant', ['dfmf', 'dfmc'])
+def test_row_block_sharding_matches_reference_golden(variant):
+    """relations cut into balanced row blocks over 2 and 3 (simulated) ranks, W / Q / E / D
+    summed between the stages: every rank reproduces iteration 10 of the reference golden."""
+    from helpers import fit_row_blocks
+    z = golden('probe_multirel.npz')
+    R, Theta, M, types, rank = probe_graph(z)
+    pairs = [('t1', 't2', 0), ('t1', 't2', 1), ('t1', 't3', 0), ('t2', 't3', 0)]
+    for size in (2, 3):
+        for G, S in fit_row_blocks(variant, R, M, Theta, types, rank, g0_from(z, variant + '/', types), 10, size):
+            for t in types:
+                assert relerr(G[t, t], z['%s/G_%s_it9' % (variant, t)]) < 1e-9
+            for i, j, l in pairs:
+                assert relerr(S[i, j][l], z['%s/S_%s_%s_%d_it9' % (variant, i, j, l)]) < 1e-9
+
+
+def test_row_block_sharding_bf16_and_abi_errors():
+    """bf16 row blocks (boundaries at multiples of 64; Q of a block contracts against a column
+    window of the stored G^T) against the single-plan bf16 engine; misuse of the staged ABI."""
+    import ctypes as C
+    from helpers import fit_row_blocks
+    from skfusion_amd._engine import DevicePlan, flatten_relations
+    rs = np.random.RandomState(4)
+    types, n, rank = ['a', 'b', 'c'], {'a': 200, 'b': 150, 'c': 70}, {'a': 6, 'b': 5, 'c': 4}
+    R = {('a', 'b'): [rs.rand(200, 150)], ('a', 'c'): [rs.rand(200, 70)], ('b', 'c'): [rs.rand(150, 70)]}
+    M = {('a', 'b'): [rs.rand(200, 150) > 0.7], ('a', 'c'): [None], ('b', 'c'): [None]}
+    G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.1 for t in types}
+    for variant in ('dfmf', 'dfmc'):
+        mod = _dfmf if variant == 'dfmf' else _dfmc
+        if variant == 'dfmf':
+            Gs, Ss = _dfmf.dfmf(R, {}, types, rank, max_iter=3, G0=G0, dtype='bf16')
+        else:
+            Gs, Ss = _dfmc.dfmc(R, M, {}, types, rank, max_iter=3, G0=G0, dtype='bf16')
+        for G, S in fit_row_blocks(variant, R, M, {}, types, rank, G0, 3, 2, dtype='bf16'):
+            for t in types:
+                assert relerr(G[t, t], Gs[t, t]) < 1e-4          # f32 partial sums in another order
+            for k in Ss:
+                assert relerr(S[k][0], Ss[k][0]) < 1e-4
+    # ABI misuse
+    rel = flatten_relations(R)
+    blk = dict(row_begin=64, n_rows=64, absent=False, col_side=False, masked=False)
+    plan = DevicePlan(types, n, rank, [(rel[0][0], rel[0][1], rel[0][2][64:128], None, blk)] + rel[1:], [],
+                      nat.SKF_DFMF, dtype='f64')
+    for t in types:
+        plan.set_factor(t, G0[t, t])
+    with pytest.raises(nat.SkfNativeError):           # a plan with row blocks has no skf_iterate
+        plan.iterate(1)
+    plan.stage(nat.SKF_STAGE_CONTRACT)
+    with pytest.raises(nat.SkfNativeError):
+        plan.stage(7)
+    plan.close()
+    bad = dict(row_begin=150, n_rows=100, absent=False, col_side=True, masked=False)
+    with pytest.raises(nat.SkfNativeError):           # block outside the row type
+        DevicePlan(types, n, rank, [(rel[0][0], rel[0][1], rel[0][2][:100], None, bad)] + rel[1:], [],
+                   nat.SKF_DFMF, dtype='f64')
+    bad = dict(row_begin=10, n_rows=64, absent=False, col_side=True, masked=False)
+    with pytest.raises(nat.SkfNativeError):           # bf16 blocks start at multiples of 64
+        DevicePlan(types, n, rank, [(rel[0][0], rel[0][1], rel[0][2][10:74], None, bad)] + rel[1:], [],
+                   nat.SKF_DFMF, dtype='bf16')
 
 
 def test_relation_sqerr_and_stopping_path():

@@ -152,6 +152,25 @@ def test_probe_graph_dfmf_and_dfmc():
     compare_snapshots(z, 'dfmc/', snaps.snap, 2e-3)
 
 
+def test_c5_movielens_style_dfmc_f64_f32_bf16():
+    """BASELINE config 5 (scaled, tests/helpers.py): f64 to 1e-9 of the reference golden over 30
+    iterations; f32 / bf16 engines judged on the known-entry and held-out RMSE of the ratings."""
+    from helpers import movielens_style_graph
+    z = golden('c5_movielens_scaled.npz')
+    R, M, Theta, types, rank = movielens_style_graph()
+    G0 = g0_from(z, 'dfmc/', types)
+    snaps = Snapshots((0, 1, 9, 29))
+    _dfmc.dfmc(R, M, Theta, types, rank, max_iter=30, callback=snaps, G0=G0)
+    compare_snapshots(z, 'dfmc/', snaps.snap, 1e-9)
+    known = ~M['user', 'movie'][0]
+    for dtype, tol in (('f32', 1e-5), ('bf16', 5e-3)):        # measured 5e-7 / 3.4e-4
+        G, S = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=30, G0=G0, dtype=dtype)
+        d = G['user', 'user'].dot(S['user', 'movie'][0]).dot(G['movie', 'movie'].T) - R['user', 'movie'][0]
+        for sel, key in ((known, 'dfmc/rmse_known'), (~known, 'dfmc/rmse_unknown')):
+            got = np.sqrt(np.mean(d[sel] ** 2))
+            assert abs(got - float(z[key])) / float(z[key]) < tol, (dtype, key, got, float(z[key]))
+
+
 @pytest.mark.parametrize('variant', ['dfmf', 'dfmc'])
 def test_rank_deficient_100_iterations(variant):
     z = golden('rank_deficient.npz')

@@ -62,6 +62,20 @@ def test_probe_multirelation_dfmc_and_inputs_untouched():
             np.testing.assert_array_equal(a, b)
 
 
+def test_c5_movielens_style_dfmc():
+    """BASELINE config 5, scaled: 6 types / 6 relations / 98 % masked ratings / 3 constraints."""
+    from helpers import movielens_style_graph
+    z = golden('c5_movielens_scaled.npz')
+    R, M, Theta, types, rank = movielens_style_graph()
+    snaps = Snapshots((0, 1, 9, 29))
+    G, S = orc.dfmc(R, M, Theta, types, rank, max_iter=30, callback=snaps, G0=g0_from(z, 'dfmc/', types))
+    compare_snapshots(z, 'dfmc/', snaps.snap, TOL)
+    known = ~M['user', 'movie'][0]
+    d = G['user', 'user'].dot(S['user', 'movie'][0]).dot(G['movie', 'movie'].T) - R['user', 'movie'][0]
+    assert abs(np.sqrt(np.mean(d[known] ** 2)) - float(z['dfmc/rmse_known'])) < 1e-10
+    assert abs(np.sqrt(np.mean(d[~known] ** 2)) - float(z['dfmc/rmse_unknown'])) < 1e-10
+
+
 @pytest.mark.parametrize('variant', ['dfmf', 'dfmc'])
 def test_rank_deficient_gram_matches_pinv_truncation(variant):
     """reference tests/test_n_run.py:14 -- rank 50 > 30 objects: pinv must truncate."""

@@ -293,6 +293,29 @@ def gen_c3_scaled():
     save('c3_scaled.npz', out)
 
 
+# ------------------------------------------------------------------ C5: MovieLens-style Dfmc
+def gen_c5():
+    """BASELINE config 5 scaled down (tests/helpers.py:movielens_style_graph): inputs are regenerated
+    from seeds, so only G0 and the reference's (G, S) snapshots / errors are stored."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import movielens_style_graph
+    R, M, Theta, types, rank = movielens_style_graph()
+    Rin = {k: [m.copy() for m in v] for k, v in R.items()}
+    out = {}
+    with Recorder(ref_dfmc, (0, 1, 9, 29)) as rec:
+        G, S = ref_dfmc.dfmc(Rin, M, Theta, types, rank, max_iter=30, init_type='random_vcol',
+                             callback=rec.callback, random_state=np.random.RandomState(5))
+    for k in R:
+        for a, b in zip(R[k], Rin[k]):
+            assert np.array_equal(a, b)
+    pack('dfmc/', rec, out, fro_errs(R, G, S))
+    known = ~M['user', 'movie'][0]
+    rec_um = G['user', 'user'].dot(S['user', 'movie'][0]).dot(G['movie', 'movie'].T)
+    out['dfmc/rmse_known'] = np.sqrt(np.mean((rec_um - R['user', 'movie'][0])[known] ** 2))
+    out['dfmc/rmse_unknown'] = np.sqrt(np.mean((rec_um - R['user', 'movie'][0])[~known] ** 2))
+    save('c5_movielens_scaled.npz', out)
+
+
 # ------------------------------------------------------------------ fill strategies (host glue)
 def gen_fill():
     """Relation.filled() of the reference (fusion_graph.py:464-545) on inputs with NaN / inf /
@@ -324,7 +347,7 @@ def gen_fill():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['c1', 'probe', 'rd', 'transform', 'dicty', 'c3s', 'fill']
+    which = sys.argv[1:] or ['c1', 'probe', 'rd', 'transform', 'dicty', 'c3s', 'c5', 'fill']
     G = S = None
     if 'c1' in which or 'transform' in which:
         G, S = gen_c1()
@@ -338,5 +361,7 @@ if __name__ == '__main__':
         gen_dicty()
     if 'c3s' in which:
         gen_c3_scaled()
+    if 'c5' in which:
+        gen_c5()
     if 'fill' in which:
         gen_fill()
