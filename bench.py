@@ -102,10 +102,11 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['f32', 'f64', 'bf16'])
     ap.add_argument('--scale', type=float, default=1.0, help='linear scale of the object counts')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--mode', default='restarts', choices=['restarts', 'relations'],
-                    help='N>1: one independent restart per GPU (weak scaling, no collective; default) or '
-                         'ONE fit with its relations partitioned over the GPUs and an RCCL all-reduce of the '
-                         'E/D accumulators per iteration (strong scaling)')
+    ap.add_argument('--mode', default='restarts', choices=['restarts', 'relations', 'rows'],
+                    help='N>1: one independent restart per GPU (weak scaling, no collective; default); or ONE fit '
+                         '(strong scaling) with whole relations partitioned over the GPUs and an RCCL all-reduce of '
+                         'the E/D accumulators per iteration (relations), or with balanced row blocks of the '
+                         'relations and all-reduces of W, Q and E/D (rows)')
     args = ap.parse_args()
 
     import torch
@@ -132,13 +133,30 @@ def main():
     from skfusion_amd._engine import DevicePlan, fill_uniform
 
     n = sizes(args.scale)
-    sharded = (args.mode == 'relations' and world > 1)
+    sharded = (args.mode in ('relations', 'rows') and world > 1)
     pairs = PAIRS
-    if sharded:                        # this rank keeps only its share of the relations
+    if sharded and args.mode == 'relations':       # this rank keeps only its share of the relations
         from skfusion_amd._distributed import partition_relations
         owner, _ = partition_relations([(i, j, None, None) for i, j, _ in PAIRS], [], n, RANKS)
         pairs = [pr for pr, o in zip(PAIRS, owner) if o == rank]
-    rels = [(i, j, fill_uniform((n[i], n[j]), s, args.dtype), None) for i, j, s in pairs]
+    if sharded and args.mode == 'rows':            # every relation listed, with this rank's row block of it
+        from skfusion_amd._distributed import partition_rows
+        blocks, _ = partition_rows([(i, j, None, None) for i, j, _ in PAIRS], [], n, RANKS,
+                                   align=256 if min(n.values()) >= 4096 else 64)
+        esz = {'bf16': 2, 'f32': 4, 'f64': 8}[args.dtype]
+        rels = []
+        for (i, j, s), blk in zip(PAIRS, blocks):
+            mine = [b for b in blk if b[0] == rank]
+            if not mine:
+                rels.append((i, j, None, None, dict(absent=True, row_begin=0, n_rows=0, col_side=False, masked=False)))
+                continue
+            _, a, cnt = mine[0]
+            full = fill_uniform((n[i], n[j]), s, args.dtype)      # same values as the unsharded run
+            rels.append((i, j, full.rows(a, cnt, esz), None,
+                         dict(absent=False, row_begin=a, n_rows=cnt, col_side=(a == 0), masked=False)))
+            del full
+    else:
+        rels = [(i, j, fill_uniform((n[i], n[j]), s, args.dtype), None) for i, j, s in pairs]
     plan = DevicePlan(TYPES, n, RANKS, rels, [], nat.SKF_DFMF, dtype=args.dtype)
     if args.dtype == 'bf16':          # the plan keeps its own padded bf16 copies of R and R^T
         del rels[:]
@@ -147,7 +165,7 @@ def main():
     for k, t in enumerate(TYPES):      # one random restart per rank: G0 seed depends on the rank
         seed = 100 + k + (0 if sharded else 10 * rank)       # sharded: replicated factors
         plan.set_factor(t, fill_uniform((n[t], RANKS[t]), seed, MASTER[args.dtype]))
-    step = plan.iterate_sharded if sharded else plan.iterate
+    step = plan.iterate if not sharded else (plan.iterate_rows if args.mode == 'rows' else plan.iterate_sharded)
 
     def sync():
         torch.cuda.synchronize()
@@ -170,8 +188,15 @@ def main():
         elapsed = float(tt.item())
 
     rmse = {}
-    for k, (i, j, _) in enumerate(pairs):
-        rmse['%s-%s' % (i, j)] = float(np.sqrt(plan.relation_sqerr(k) / (n[i] * n[j])))
+    if sharded and args.mode == 'rows':            # every rank holds the squared error of its row blocks
+        sq = torch.tensor([plan.relation_sqerr(k) for k in range(len(PAIRS))], dtype=torch.float64,
+                          device='cuda' if backend == 'nccl' else 'cpu')
+        dist.all_reduce(sq)
+        for k, (i, j, _) in enumerate(PAIRS):
+            rmse['%s-%s' % (i, j)] = float(np.sqrt(float(sq[k]) / (n[i] * n[j])))
+    else:
+        for k, (i, j, _) in enumerate(pairs):
+            rmse['%s-%s' % (i, j)] = float(np.sqrt(plan.relation_sqerr(k) / (n[i] * n[j])))
     units = 1 if sharded else world        # fits advanced per step by the whole job
 
     if rank == 0:
@@ -199,8 +224,11 @@ def main():
             'dtype': args.dtype,
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[2]: synthetic dense 3-type graph %dx%d / %dx%d / %dx%d, '
-                                   'ranks 128/256/256, Dfmf, one random restart per GPU'
-                                   % (n['t1'], n['t2'], n['t1'], n['t3'], n['t2'], n['t3']),
+                                   'ranks 128/256/256, Dfmf, %s'
+                                   % (n['t1'], n['t2'], n['t1'], n['t3'], n['t2'], n['t3'],
+                                      {'restarts': 'one random restart per GPU',
+                                       'relations': 'one fit, whole relations partitioned over the GPUs',
+                                       'rows': 'one fit, balanced row blocks of the relations over the GPUs'}[args.mode]),
                        'scale': args.scale, 'restarts': units, 'mode': args.mode,
                        'alg_flops_per_iter': alg_flops(n)},
             'rmse': rmse,

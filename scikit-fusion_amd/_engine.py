@@ -39,6 +39,20 @@ def fill_uniform(shape, seed, dtype='f32', scale=1.0, shift=0.0, runtime=None):
     return DeviceMatrix(buf, shape)
 
 
+def _all_reduce_sum(t):
+    """Sum a tensor view over the process group (RCCL for GPU tensors; a gloo group -- CPU tests,
+    single-GPU smoke runs -- stages GPU tensors through the host)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 class DevicePlan(object):
     """One (run, device) plan: relations + constraints uploaded, workspace bound."""
 
@@ -175,16 +189,14 @@ class DevicePlan(object):
         """Iterations of a relation-sharded run: this plan holds only this rank's relations;
         the E / D accumulators are summed over the ranks (one all-reduce per iteration: RCCL on
         GPUs, gloo in the CPU tests) before the replicated G update."""
-        import torch.distributed as dist
         off, nbytes = C.c_size_t(), C.c_size_t()
         self.rt.call('skf_accumulator_range', self.handle, C.byref(off), C.byref(nbytes))
         acc = self.rt.mem.as_tensor(self.ws, off.value, nbytes.value, self.np_dtype)
         for _ in range(int(n_iters)):
             self.rt.call('skf_accumulate', self.handle, self.rt.mem.stream)
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                self.rt.mem.synchronize()          # the collective runs on torch's own stream
-                dist.all_reduce(acc, op=dist.ReduceOp.SUM)
-                self.rt.mem.synchronize()
+            self.rt.mem.synchronize()              # the collective runs on torch's own stream
+            _all_reduce_sum(acc)
+            self.rt.mem.synchronize()
             self.rt.call('skf_apply_update', self.handle, self.rt.mem.stream)
 
     def _exchange_views(self):
@@ -206,12 +218,7 @@ class DevicePlan(object):
         and of E / D between them -- include/skfusion_hip.h `skf_stage`.  `reduce(tensor)` defaults
         to torch.distributed.all_reduce (RCCL on GPUs, gloo in the CPU tests)."""
         if reduce is None:
-            import torch.distributed as dist
-            active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-
-            def reduce(t):
-                if active:
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            reduce = _all_reduce_sum
         xw, xq, xqm, xed = self._exchange_views()
         mem, call, h = self.rt.mem, self.rt.call, self.handle
 

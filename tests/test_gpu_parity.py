@@ -277,6 +277,35 @@ def test_accumulate_apply_split_equals_iterate():
         assert relerr(Gc[t, t], z['dfmc/G_%s_it9' % t]) < 1e-9
 
 
+def test_row_block_sharding_c3_scaled_c5_and_probe():
+    """SURVEY.md 8e row blocks on the device: 2 / 3 / 4 simulated ranks (lockstep plans on this one
+    GPU, exchange ranges summed where RCCL would all-reduce) against the reference goldens -- the
+    scaled config 3 (f64 errors + S, f32, bf16), config 5 (MovieLens-style Dfmc) and the probe graph."""
+    import test_emul_engine as E
+    from helpers import fit_row_blocks, movielens_style_graph
+    for variant in ('dfmf', 'dfmc'):
+        E.test_row_block_sharding_matches_reference_golden(variant)
+    E.test_row_block_sharding_bf16_and_abi_errors()
+    z = golden('c3_scaled.npz')
+    R, G0, types, rank = c3_scaled_graph(z)
+    Rb = {k: [nat.from_bf16_bits(nat.to_bf16_bits(v[0])).astype(np.float64)] for k, v in R.items()}
+    for size, dtype, tol in ((3, 'f64', 1e-9), (4, 'f32', 1e-5), (2, 'bf16', 1e-2)):
+        for G, S in fit_row_blocks('dfmf', R, None, {}, types, rank, G0, 5, size, dtype=dtype):
+            e = orc.relation_errors(Rb if dtype == 'bf16' else R, G, S)
+            got = np.array([e[k][0] for k in sorted(e)])
+            assert np.abs(got - z['errs'][4]).max() / z['errs'][4].min() < tol, (size, dtype)
+            if dtype == 'f64':
+                for (i, j) in R:
+                    assert relerr(S[i, j][0], z['S_%s_%s_it4' % (i, j)]) < 1e-7
+    z5 = golden('c5_movielens_scaled.npz')
+    R, M, Theta, types, rank = movielens_style_graph()
+    for G, S in fit_row_blocks('dfmc', R, M, Theta, types, rank, g0_from(z5, 'dfmc/', types), 30, 4):
+        for t in types:
+            assert relerr(G[t, t], z5['dfmc/G_%s_it29' % t]) < 1e-9
+        for (i, j) in R:
+            assert relerr(S[i, j][0], z5['dfmc/S_%s_%s_0_it29' % (i, j)]) < 1e-9
+
+
 def test_bf16_engine_c1_and_c3_scaled():
     """SKF_BF16 engine: bf16 relation contractions.  Tolerances: reconstruction
     error within 1e-2 relative of the f64 oracle on the same (bf16-rounded) relations."""

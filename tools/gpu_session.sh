@@ -23,6 +23,13 @@ case "$step" in
     echo "== bench $dt" | tee -a "$OUT/summary.txt"
     ( time timeout 900 python bench.py --dtype $dt --steps 10 --warmup 3 ) > "$OUT/bench_$dt.log" 2>&1
     echo "bench exit $?" | tee -a "$OUT/summary.txt"; tail -4 "$OUT/bench_$dt.log" | tee -a "$OUT/summary.txt" ;;
+  dist_smoke)
+    # the torchrun paths of bench.py with 2 ranks sharing the one GPU of this box (gloo group)
+    echo "== torchrun x2 (gloo, shared GPU) restarts / relations / rows" | tee -a "$OUT/summary.txt"
+    for mode in restarts relations rows; do
+      ( SKF_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --scale 0.2 --mode $mode --no-cpu-baseline ) > "$OUT/dist_$mode.log" 2>&1
+      echo "dist $mode exit $?" | tee -a "$OUT/summary.txt"; tail -1 "$OUT/dist_$mode.log" | cut -c1-700 | tee -a "$OUT/summary.txt"
+    done ;;
   prof_*)
     dt=${step#prof_}
     echo "== rocprofv3 kernel-trace $dt" | tee -a "$OUT/summary.txt"
