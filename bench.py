@@ -157,7 +157,8 @@ def main():
             del full
     else:
         rels = [(i, j, fill_uniform((n[i], n[j]), s, args.dtype), None) for i, j, s in pairs]
-    plan = DevicePlan(TYPES, n, RANKS, rels, [], nat.SKF_DFMF, dtype=args.dtype)
+    plan = DevicePlan(TYPES, n, RANKS, rels, [], nat.SKF_DFMF, dtype=args.dtype,
+                      part=(rank, world) if sharded and args.mode == 'rows' else None)
     if args.dtype == 'bf16':          # the plan keeps its own padded bf16 copies of R and R^T
         del rels[:]
         plan._keep = []

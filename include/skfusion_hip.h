@@ -89,6 +89,11 @@ typedef struct {
     int32_t variant;     /* SKF_DFMF / SKF_DFMC / SKF_TRANSFORM */
     int32_t target_type; /* SKF_TRANSFORM: the type whose factor is folded in */
     int32_t engine;      /* SKF_ENGINE_MFMA (default) / SKF_ENGINE_VALU */
+    /* Row-block sharding only (plans whose relations carry row blocks): this process is part
+     * `part_index` of `part_count`; it adds the type-level terms E_i += G_i * sum_r B_r^-,
+     * D_i += G_i * sum_r B_r^+ (_dfmf.py:260-264,272-276,278-282 summed over the relations, which is
+     * linear in B) on its 1/part_count share of the rows of every type.  0, 0 = all rows. */
+    int32_t part_index, part_count;
 } skf_options;
 
 /* ---- plan life cycle ------------------------------------------------------------------- */

@@ -57,11 +57,11 @@ class DevicePlan(object):
     """One (run, device) plan: relations + constraints uploaded, workspace bound."""
 
     def __init__(self, obj_types, n_obj, rank, relations, thetas, variant, dtype='f64',
-                 target=None, engine=None, runtime=None):
+                 target=None, engine=None, runtime=None, part=None):
         """relations: list of (row_type, col_type, ndarray, mask-or-None[, block]);
         thetas: list of (type, ndarray).  `block` (row-block sharding, `_distributed.partition_rows`)
         = dict(row_begin, n_rows, absent, col_side, masked): data / mask then hold only the local rows
-        (None when absent)."""
+        (None when absent); `part` = (index, count) of this plan among the row-block plans."""
         self.rt = runtime or nat.get_runtime()
         self.dtype = nat.DTYPES[dtype] if isinstance(dtype, str) else dtype
         if self.dtype not in nat.NP_DTYPE:
@@ -123,7 +123,8 @@ class DevicePlan(object):
             self._keep.append(buf)
             hdesc[k].type, hdesc[k].data, hdesc[k].ld = self.index[t], buf.ptr, arr.shape[1]
         opt = nat.Options(self.dtype, variant, self.index[target] if target is not None else -1,
-                          nat.SKF_ENGINE_MFMA if engine is None else engine)
+                          nat.SKF_ENGINE_MFMA if engine is None else engine,
+                          part[0] if part else 0, part[1] if part else 0)
         self.rt.call('skf_plan_create', len(self.types), tdesc, len(relations), rdesc, len(thetas),
                      hdesc, C.byref(opt), C.byref(self.handle))
         nbytes = C.c_size_t()

@@ -61,7 +61,7 @@ class ThetaDesc(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [('dtype', C.c_int32), ('variant', C.c_int32), ('target_type', C.c_int32),
-                ('engine', C.c_int32)]
+                ('engine', C.c_int32), ('part_index', C.c_int32), ('part_count', C.c_int32)]
 
 
 class GemmDesc(C.Structure):

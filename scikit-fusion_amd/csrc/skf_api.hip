@@ -356,7 +356,9 @@ struct TypeState {
     int c = 0;
     int n_pad = 0;                 // eigen order (even)
     Slot G, E, D, Gram, K;
-    Slot Bp_tot, Bn_tot, Ec, Dc;   // SKF_TRANSFORM target only
+    Slot Bp_tot, Bn_tot;           // sum over the relations of the B / D matrices' + and - parts (c x c f64)
+    Slot Ec, Dc;                   // SKF_TRANSFORM target only
+    int64_t t0 = 0, tn = 0;        // rows whose type-level terms G (sum B) this plan adds (row-block sharding)
     Slot GTb;                      // SKF_BF16: bf16 transpose of G, [c][pad64(n)], zero padded
     int64_t ldgt = 0;
     bool set = false;
@@ -370,7 +372,7 @@ struct RelState {
     int64_t ldmask = 0;
     const void* R = nullptr;       // matrix the iteration reads (R_in or the DFMC working copy)
     int64_t ldr = 0;
-    Slot Rw, P, Q, W, T1, S, U, Bp, Bn, Dp, Dn, H;
+    Slot Rw, P, Q, W, T1, S, U, H;
     Slot Rb, RTb;                  // SKF_BF16: padded bf16 copies of R and R^T
     int64_t ldrb = 0, ldrtb = 0;
     bool s_set = false;
@@ -652,13 +654,14 @@ static void relation_small_terms(skf_plan* p, RelState& r, int nan_upd, int epi_
 // on the rows [G, E, D point at the first one; n of them] of type t.
 static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const void* Sop, int64_t ss_k, int64_t ss_n,
                         TypeState& t, const void* G, void* E, void* D, int n, const void* Bn, const void* Bp,
-                        bool accumulate, int nan, hipStream_t st) {
+                        bool phase2, bool accumulate, int nan, hipStream_t st) {
     SideArgs a;
     a.X = X; a.Sop = Sop; a.G = G; a.Bn = Bn; a.Bp = Bp; a.E = E; a.D = D;
     a.ldx = ldx; a.ss_k = ss_k; a.ss_n = ss_n; a.ldg = t.c; a.ldb = t.c; a.lde = t.c;
     a.n = n; a.c = t.c; a.k1 = k1;
     a.accumulate = accumulate ? 1 : 0;
     a.nan_to_num = nan;
+    a.phase2 = phase2 ? 1 : 0;
     const bool big = (n > 64 && t.c > 64);
     dim3 block(GEMM_THREADS);
     if (p->f64) {
@@ -802,29 +805,63 @@ static void stage_backbone(skf_plan* p, hipStream_t st) {
 }
 
 // Stage 3 (SKF_STAGE_ACCUMULATE): the E / D sums of this plan's row blocks, column sides and constraints.
+// The G_i B^-+ terms of _dfmf.py:278-282 are linear in B: they are added once per type with the
+// sums of B^+ / B^- over the relations (half the n x c x c work of adding them relation by relation).
 static void stage_accumulate(skf_plan* p, hipStream_t st) {
     const bool dfmc = (p->variant == SKF_DFMC);
     const int nan_upd = dfmc ? 0 : 1;       // _update_G_for_Rij (_dfmc.py:127-178) has no nan_to_num
     const bool fused = (p->engine == SKF_ENGINE_MFMA);
-    std::vector<char> touched(p->types.size(), 0);     // E/D of the type already written this iteration
-    for (size_t i = 0; i < p->types.size(); ++i) {
+    const size_t nt = p->types.size();
+    std::vector<char> touched(nt, 0);       // E/D of the type already written this iteration
+    std::vector<int> sides_left(nt, 0);     // E/D side products still to come for the type
+    for (RelState& r : p->rels) {
+        if (!r.absent) sides_left[r.row] += 1;
+        if (r.col_side) sides_left[r.col] += 1;
+    }
+    for (size_t i = 0; i < nt; ++i) {
         TypeState& t = p->types[i];
-        bool has_rel = false;
-        for (RelState& r : p->rels) has_rel = has_rel || r.row == (int)i || r.col == (int)i;
         // the fused update overwrites E/D on first touch -- of whole matrices only
-        if (!fused || !has_rel || p->sliced) {
+        if (!fused || sides_left[i] == 0 || p->sliced) {
             SKF_HIP(hipMemsetAsync(t.E.ptr, 0, t.E.bytes, st));
             SKF_HIP(hipMemsetAsync(t.D.ptr, 0, t.D.bytes, st));
             touched[i] = 1;
         }
+        SKF_HIP(hipMemsetAsync(t.Bp_tot.ptr, 0, t.Bp_tot.bytes, st));
+        SKF_HIP(hipMemsetAsync(t.Bn_tot.ptr, 0, t.Bn_tot.bytes, st));
     }
+    // sum_r B_r^+- per type.  A plan with row blocks lists every relation and owns a share of the rows
+    // of every type: it sums over all relations; otherwise over the plan's own relations.
+    for (RelState& r : p->rels) {
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        relation_small_terms(p, r, nan_upd, EPI_SPLIT_ACC, ti.Bp_tot.ptr, ti.Bn_tot.ptr, tj.Bp_tot.ptr, tj.Bn_tot.ptr,
+                             true, true, st);
+    }
+    // type-level term on rows [t0, t0 + tn): separately (row blocks / VALU engine), or inside the
+    // last side product of the type (fused engine on whole matrices)
+    auto type_term = [&](size_t i) {
+        TypeState& t = p->types[i];
+        if (t.tn <= 0) return;
+        void* G = rows_of(p, t.G, t, t.t0);
+        void* E = rows_of(p, t.E, t, t.t0);
+        void* D = rows_of(p, t.D, t, t.t0);
+        if (fused) {
+            side_update(p, nullptr, 0, 0, nullptr, 0, 0, t, G, E, D, (int)t.tn, t.Bn_tot.ptr, t.Bp_tot.ptr, true,
+                        touched[i] != 0, 0, st);
+        } else {
+            GemmArgs g = gemm_args(G, t.c, 1, t.Bn_tot.ptr, t.c, 1, E, t.c, (int)t.tn, t.c, t.c, EPI_ACC, 0);
+            mixed_gemm(p, g, st);
+            g = gemm_args(G, t.c, 1, t.Bp_tot.ptr, t.c, 1, D, t.c, (int)t.tn, t.c, t.c, EPI_ACC, 0);
+            mixed_gemm(p, g, st);
+        }
+        touched[i] = 1;
+    };
+    const bool fuse_type_term = fused && !p->sliced;
     for (RelState& r : p->rels) {
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
         const int nr = (int)r.nr, nj = (int)tj.n, ci = ti.c, cj = tj.c;
         const bool row_side = !r.absent, col_side = r.col_side;
-        if (!row_side && !col_side) continue;
-        relation_small_terms(p, r, nan_upd, EPI_SPLIT_STORE, r.Bp.ptr, r.Bn.ptr, r.Dp.ptr, r.Dn.ptr, row_side, col_side, st);
         void* Gi = rows_of(p, ti.G, ti, r.r0);
         void* Ei = rows_of(p, ti.E, ti, r.r0);
         void* Di = rows_of(p, ti.D, ti, r.r0);
@@ -832,13 +869,15 @@ static void stage_accumulate(skf_plan* p, hipStream_t st) {
         if (fused) {
             // row side: A = P S^T (Sop(k,j) = S[j][k]);  column side: C = Q S
             if (row_side) {
-                side_update(p, r.P.ptr, cj, cj, r.S.ptr, 1, cj, ti, Gi, Ei, Di, nr, r.Bn.ptr, r.Bp.ptr,
+                const bool last = fuse_type_term && --sides_left[r.row] == 0;
+                side_update(p, r.P.ptr, cj, cj, r.S.ptr, 1, cj, ti, Gi, Ei, Di, nr, ti.Bn_tot.ptr, ti.Bp_tot.ptr, last,
                             touched[r.row] != 0, nan_upd, st);
                 touched[r.row] = 1;
             }
             if (col_side) {
-                side_update(p, r.Q.ptr, ci, ci, r.S.ptr, cj, 1, tj, tj.G.ptr, tj.E.ptr, tj.D.ptr, nj, r.Dn.ptr, r.Dp.ptr,
-                            touched[r.col] != 0, nan_upd, st);
+                const bool last = fuse_type_term && --sides_left[r.col] == 0;
+                side_update(p, r.Q.ptr, ci, ci, r.S.ptr, cj, 1, tj, tj.G.ptr, tj.E.ptr, tj.D.ptr, nj, tj.Bn_tot.ptr,
+                            tj.Bp_tot.ptr, last, touched[r.col] != 0, nan_upd, st);
                 touched[r.col] = 1;
             }
             continue;
@@ -848,23 +887,16 @@ static void stage_accumulate(skf_plan* p, hipStream_t st) {
             g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, Ei, ci, nr, ci, cj, EPI_SPLIT_ACC, nan_upd);
             g.C2 = Di;
             mixed_gemm(p, g, st);
-            // E_i += G_i B- ; D_i += G_i B+
-            g = gemm_args(Gi, ci, 1, r.Bn.ptr, ci, 1, Ei, ci, nr, ci, ci, EPI_ACC, 0);
-            mixed_gemm(p, g, st);
-            g = gemm_args(Gi, ci, 1, r.Bp.ptr, ci, 1, Di, ci, nr, ci, ci, EPI_ACC, 0);
-            mixed_gemm(p, g, st);
         }
         if (col_side) {
             // E_j += (Q S)+ ; D_j += (Q S)-              (_dfmf.py:266-270, 281-282)
             g = gemm_args(r.Q.ptr, ci, 1, r.S.ptr, cj, 1, tj.E.ptr, cj, nj, cj, ci, EPI_SPLIT_ACC, nan_upd);
             g.C2 = tj.D.ptr;
             mixed_gemm(p, g, st);
-            g = gemm_args(tj.G.ptr, cj, 1, r.Dn.ptr, cj, 1, tj.E.ptr, cj, nj, cj, cj, EPI_ACC, 0);
-            mixed_gemm(p, g, st);
-            g = gemm_args(tj.G.ptr, cj, 1, r.Dp.ptr, cj, 1, tj.D.ptr, cj, nj, cj, cj, EPI_ACC, 0);
-            mixed_gemm(p, g, st);
         }
     }
+    if (!fuse_type_term)
+        for (size_t i = 0; i < nt; ++i) type_term(i);     // E_i += G_i sum B- ; D_i += G_i sum B+
     theta_terms(p, st);
 }
 
@@ -1027,7 +1059,21 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             p->types[i].n = types[i].n_obj;
             p->types[i].c = types[i].rank;
             p->types[i].n_pad = (types[i].rank + 1) / 2 * 2;
+            p->types[i].t0 = 0;
+            p->types[i].tn = types[i].n_obj;
+            if (opt->part_count > 1) {      // even shares of the rows, boundaries at multiples of 64
+                if (opt->part_index < 0 || opt->part_index >= opt->part_count)
+                    SKF_FAIL(SKF_E_INVALID, "part_index %d outside [0, %d)", opt->part_index, opt->part_count);
+                const int64_t per = (types[i].n_obj + opt->part_count - 1) / opt->part_count;
+                const int64_t step = (per + 63) / 64 * 64;
+                int64_t lo = step * opt->part_index, hi = lo + step;
+                if (lo > types[i].n_obj) lo = types[i].n_obj;
+                if (hi > types[i].n_obj) hi = types[i].n_obj;
+                p->types[i].t0 = lo;
+                p->types[i].tn = hi - lo;
+            }
         }
+        if (opt->part_count > 1) p->sliced = true;
         p->rels.resize(n_relations);
         for (int r = 0; r < n_relations; ++r) {
             const skf_relation_desc& d = relations[r];
@@ -1109,6 +1155,8 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             want_part(t.c, t.c, (int)t.n, true);
             if (p->variant != SKF_TRANSFORM) {
                 add_slot(p, t.K, (size_t)t.c * t.c * 8);
+                add_slot(p, t.Bp_tot, (size_t)t.c * t.c * 8);
+                add_slot(p, t.Bn_tot, (size_t)t.c * t.c * 8);
                 if (t.n_pad > maxn) maxn = t.n_pad;
             } else if (i == p->target) {
                 add_slot(p, t.Ec, (size_t)t.n * t.c * es);
@@ -1145,10 +1193,6 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             if (p->variant == SKF_TRANSFORM && r.col == p->target) add_slot(p, r.Q, (size_t)tj.n * ti.c * es);
             if (p->variant != SKF_TRANSFORM) {
                 add_slot(p, r.T1, cc);
-                add_slot(p, r.Bp, (size_t)ti.c * ti.c * 8);
-                add_slot(p, r.Bn, (size_t)ti.c * ti.c * 8);
-                add_slot(p, r.Dp, (size_t)tj.c * tj.c * 8);
-                add_slot(p, r.Dn, (size_t)tj.c * tj.c * 8);
                 if (nr > 0) want_part(ti.c, tj.c, (int)nr, true);
             }
             want_part(ti.c, tj.c, ti.c > tj.c ? ti.c : tj.c, true);

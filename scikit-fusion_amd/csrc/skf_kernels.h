@@ -427,6 +427,7 @@ struct SideArgs {
     int n, c, k1;
     int accumulate;     // 0: E/D are overwritten (first contribution of the iteration)
     int nan_to_num;     // numpy.nan_to_num on A before the split (DFMF only)
+    int phase2;         // 0: only the (X Sop) split terms; 1: also + G Bn / + G Bp   (k1 = 0: only those)
 };
 
 template <typename T, typename TB, int WR, int WC, int BK>
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
                 accD[i][j][r] = v > (T)0 ? (T)0 : -v;
             }
     // ---- phase 2: accE += G * Bn ; accD += G * Bp   (one staging of the G tile feeds both)
-    {
+    if (a.phase2) {
         const T* G = (const T*)a.G;
         const TB* Bn = (const TB*)a.Bn;
         const TB* Bp = (const TB*)a.Bp;

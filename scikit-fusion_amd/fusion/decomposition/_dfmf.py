@@ -62,7 +62,7 @@ def row_block_plan(variant, rel_list, theta_list, obj_types, n_obj, obj_type2ran
         local.append((i, j, np.asarray(m)[a:a + cnt], None if mask is None else np.asarray(mask)[a:a + cnt], info))
     return DevicePlan(obj_types, n_obj, obj_type2rank, local,
                       [t for t, o in zip(theta_list, theta_owner) if o == rank], variant,
-                      dtype=dtype, engine=engine)
+                      dtype=dtype, engine=engine, part=(rank, size))
 
 
 def run_fit_rows(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
