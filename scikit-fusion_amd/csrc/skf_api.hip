@@ -93,13 +93,17 @@ template <> struct Tiles<double> {
     static constexpr int BK = 16;
     static TileCfg big() { return {64, 128, BK}; }
     static TileCfg small() { return {32, 32, BK}; }
+    // c x c x c products of the backbone algebra (c <= 512): latency-bound -- many small tiles over
+    // the chip and few, deep K steps instead of 8 workgroups walking 16 shallow ones
+    static TileCfg deep() { return {32, 32, 64}; }
 };
 template <typename T> struct BigWave;
 template <> struct BigWave<float> { static constexpr int WR = 2, WC = 2; };     // 128 x 128
 template <> struct BigWave<double> { static constexpr int WR = 2, WC = 4; };    //  64 x 128
 
-static TileCfg pick_tile(bool is_f64, int engine, int M, int N) {
+static TileCfg pick_tile(bool is_f64, int engine, int M, int N, int K = 0, bool all_f64 = false) {
     if (engine == SKF_ENGINE_VALU) return {64, 64, 16};
+    if (all_f64 && K >= 64 && K <= 1024 && (int64_t)M * N <= 512 * 512) return Tiles<double>::deep();
     const bool big = (M > 64 && N > 64);
     if (is_f64) return big ? Tiles<double>::big() : Tiles<double>::small();
     return big ? Tiles<float>::big() : Tiles<float>::small();
@@ -138,6 +142,12 @@ static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, 
         }
     } else if (engine == SKF_ENGINE_VALU) {
         hipLaunchKernelGGL((gemm_valu_kernel<T, TA, TB>), grid, block, 0, st, g);
+    } else if (t.bk == 64 && t.bm == 32) {         // Tiles<double>::deep()
+        if constexpr (std::is_same<T, double>::value && std::is_same<TA, double>::value &&
+                      std::is_same<TB, double>::value)
+            hipLaunchKernelGGL((gemm_mfma_kernel<double, double, double, 1, 1, 64, 0>), grid, block, 0, st, g);
+        else
+            SKF_FAIL(SKF_E_INVALID, "deep tile is f64 only");
     } else if (big && relation) {
         hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 1>), grid, block, 0, st, g);
     } else if (big) {
@@ -167,7 +177,9 @@ static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void
                      hipStream_t st, bool relation = false) {
     if (g.M <= 0 || g.N <= 0) return;
     const bool is_f64 = (ty.c == SKF_F64);
-    const TileCfg t = pick_tile(is_f64, g.epi == EPI_MASKED_STORE_BF16 ? SKF_ENGINE_MFMA : engine, g.M, g.N);
+    const bool all_f64 = (ty.c == SKF_F64 && ty.a == SKF_F64 && ty.b == SKF_F64);
+    const TileCfg t = pick_tile(is_f64, g.epi == EPI_MASKED_STORE_BF16 ? SKF_ENGINE_MFMA : engine, g.M, g.N, g.K,
+                                all_f64 && want_splits <= 1);
     int splits = want_splits > 0 ? want_splits : pick_splits(t, g.M, g.N, g.K);
     if (g.epi == EPI_SQDIFF || g.epi == EPI_MASKED_STORE_BF16) splits = 1;
     const size_t per = (size_t)g.M * g.N;
