@@ -368,6 +368,7 @@ struct TypeState {
     int c = 0;
     int n_pad = 0;                 // eigen order (even)
     Slot G, E, D, Gram, K;
+    Slot Bp32, Bn32;               // f32 engines: roundings of Bp_tot / Bn_tot for the fused side update
     Slot Bp_tot, Bn_tot;           // sum over the relations of the B / D matrices' + and - parts (c x c f64)
     Slot Ec, Dc;                   // SKF_TRANSFORM target only
     int64_t t0 = 0, tn = 0;        // rows whose type-level terms G (sum B) this plan adds (row-block sharding)
@@ -385,6 +386,7 @@ struct RelState {
     const void* R = nullptr;       // matrix the iteration reads (R_in or the DFMC working copy)
     int64_t ldr = 0;
     Slot Rw, P, Q, W, T1, S, U, H;
+    Slot S32;                      // f32 engines: rounding of S for the fused side update
     Slot Rb, RTb;                  // SKF_BF16: padded bf16 copies of R and R^T
     int64_t ldrb = 0, ldrtb = 0;
     bool s_set = false;
@@ -663,7 +665,9 @@ static void relation_small_terms(skf_plan* p, RelState& r, int nan_upd, int epi_
 }
 
 // Fused E/D update of one relation side (MFMA engine): E (+)= (X Sop)+ + G Bn, D (+)= (X Sop)- + G Bp
-// on the rows [G, E, D point at the first one; n of them] of type t.
+// on the rows [G, E, D point at the first one; n of them] of type t.  Sop / Bn / Bp are c x c matrices
+// in the master type (the f32 engines pass f32 roundings of the f64 originals -- the same values
+// the f32 matrix cores would see -- so that the staged operands take half the registers).
 static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const void* Sop, int64_t ss_k, int64_t ss_n,
                         TypeState& t, const void* G, void* E, void* D, int n, const void* Bn, const void* Bp,
                         bool phase2, bool accumulate, int nan, hipStream_t st) {
@@ -687,10 +691,10 @@ static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const v
     } else {
         if (big) {
             dim3 grid(cdiv(t.c, 128), cdiv(n, 128));
-            hipLaunchKernelGGL((side_update_kernel<float, double, 2, 2, 16>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16>), grid, block, 0, st, a);
         } else {
             dim3 grid(cdiv(t.c, 64), cdiv(n, 64));
-            hipLaunchKernelGGL((side_update_kernel<float, double, 1, 1, 16>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 16>), grid, block, 0, st, a);
         }
     }
     check_launch("side_update");
@@ -849,6 +853,21 @@ static void stage_accumulate(skf_plan* p, hipStream_t st) {
         relation_small_terms(p, r, nan_upd, EPI_SPLIT_ACC, ti.Bp_tot.ptr, ti.Bn_tot.ptr, tj.Bp_tot.ptr, tj.Bn_tot.ptr,
                              true, true, st);
     }
+    // c x c operands of the fused side products in the master type
+    auto to_master = [&](const Slot& src, const Slot& dst, int rows, int cols) -> const void* {
+        if (p->f64 || !fused) return src.ptr;
+        hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid((int64_t)rows * cols)), dim3(256), 0, st,
+                           (float*)dst.ptr, (int64_t)cols, (const double*)src.ptr, (int64_t)cols, (int64_t)rows,
+                           (int64_t)cols);
+        check_launch("cast");
+        return dst.ptr;
+    };
+    std::vector<const void*> Bn_m(nt), Bp_m(nt);
+    for (size_t i = 0; i < nt; ++i) {
+        TypeState& t = p->types[i];
+        Bn_m[i] = to_master(t.Bn_tot, t.Bn32, t.c, t.c);
+        Bp_m[i] = to_master(t.Bp_tot, t.Bp32, t.c, t.c);
+    }
     // type-level term on rows [t0, t0 + tn): separately (row blocks / VALU engine), or inside the
     // last side product of the type (fused engine on whole matrices)
     auto type_term = [&](size_t i) {
@@ -858,7 +877,7 @@ static void stage_accumulate(skf_plan* p, hipStream_t st) {
         void* E = rows_of(p, t.E, t, t.t0);
         void* D = rows_of(p, t.D, t, t.t0);
         if (fused) {
-            side_update(p, nullptr, 0, 0, nullptr, 0, 0, t, G, E, D, (int)t.tn, t.Bn_tot.ptr, t.Bp_tot.ptr, true,
+            side_update(p, nullptr, 0, 0, nullptr, 0, 0, t, G, E, D, (int)t.tn, Bn_m[i], Bp_m[i], true,
                         touched[i] != 0, 0, st);
         } else {
             GemmArgs g = gemm_args(G, t.c, 1, t.Bn_tot.ptr, t.c, 1, E, t.c, (int)t.tn, t.c, t.c, EPI_ACC, 0);
@@ -880,16 +899,18 @@ static void stage_accumulate(skf_plan* p, hipStream_t st) {
         GemmArgs g;
         if (fused) {
             // row side: A = P S^T (Sop(k,j) = S[j][k]);  column side: C = Q S
+            if (!row_side && !col_side) continue;
+            const void* Sm = to_master(r.S, r.S32, ci, cj);
             if (row_side) {
                 const bool last = fuse_type_term && --sides_left[r.row] == 0;
-                side_update(p, r.P.ptr, cj, cj, r.S.ptr, 1, cj, ti, Gi, Ei, Di, nr, ti.Bn_tot.ptr, ti.Bp_tot.ptr, last,
+                side_update(p, r.P.ptr, cj, cj, Sm, 1, cj, ti, Gi, Ei, Di, nr, Bn_m[r.row], Bp_m[r.row], last,
                             touched[r.row] != 0, nan_upd, st);
                 touched[r.row] = 1;
             }
             if (col_side) {
                 const bool last = fuse_type_term && --sides_left[r.col] == 0;
-                side_update(p, r.Q.ptr, ci, ci, r.S.ptr, cj, 1, tj, tj.G.ptr, tj.E.ptr, tj.D.ptr, nj, tj.Bn_tot.ptr,
-                            tj.Bp_tot.ptr, last, touched[r.col] != 0, nan_upd, st);
+                side_update(p, r.Q.ptr, ci, ci, Sm, cj, 1, tj, tj.G.ptr, tj.E.ptr, tj.D.ptr, nj, Bn_m[r.col],
+                            Bp_m[r.col], last, touched[r.col] != 0, nan_upd, st);
                 touched[r.col] = 1;
             }
             continue;
@@ -1169,6 +1190,10 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 add_slot(p, t.K, (size_t)t.c * t.c * 8);
                 add_slot(p, t.Bp_tot, (size_t)t.c * t.c * 8);
                 add_slot(p, t.Bn_tot, (size_t)t.c * t.c * 8);
+                if (!p->f64) {
+                    add_slot(p, t.Bp32, (size_t)t.c * t.c * 4);
+                    add_slot(p, t.Bn32, (size_t)t.c * t.c * 4);
+                }
                 if (t.n_pad > maxn) maxn = t.n_pad;
             } else if (i == p->target) {
                 add_slot(p, t.Ec, (size_t)t.n * t.c * es);
@@ -1205,6 +1230,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             if (p->variant == SKF_TRANSFORM && r.col == p->target) add_slot(p, r.Q, (size_t)tj.n * ti.c * es);
             if (p->variant != SKF_TRANSFORM) {
                 add_slot(p, r.T1, cc);
+                if (!p->f64) add_slot(p, r.S32, cc / 2);
                 if (nr > 0) want_part(ti.c, tj.c, (int)nr, true);
             }
             want_part(ti.c, tj.c, ti.c > tj.c ? ti.c : tj.c, true);

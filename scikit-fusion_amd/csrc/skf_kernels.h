@@ -462,13 +462,20 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
         const bool s_kfast = (a.ss_k == 1);
         const int mx = stage_mode<T>(X, a.ldx, 1, a.n, 0, a.k1);
         const int ms = stage_mode<TB>(S, a.ss_n, a.ss_k, a.c, 0, a.k1);
+        // register prefetch of the next K tile while the current one feeds the matrix cores
+        if (a.k1 > 0) {
+            stage_load<T, BM, BK>(ra, X, a.ldx, 1, bm0, 0, a.n, a.k1, tid, mx);
+            stage_load<TB, BN, BK>(rb, S, a.ss_n, a.ss_k, bn0, 0, a.c, a.k1, tid, ms);
+        }
         for (int k0 = 0; k0 < a.k1; k0 += BK) {
-            stage_load<T, BM, BK>(ra, X, a.ldx, 1, bm0, k0, a.n, a.k1, tid, mx);
-            stage_load<TB, BN, BK>(rb, S, a.ss_n, a.ss_k, bn0, k0, a.c, a.k1, tid, ms);
             __syncthreads();
             stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.k1, AOP_NONE, tid, mx);
             stage_store<T, TB, BN, BK, LDB>(Bs, rb, s_kfast, k0, a.k1, AOP_NONE, tid, ms);
             __syncthreads();
+            if (k0 + BK < a.k1) {
+                stage_load<T, BM, BK>(ra, X, a.ldx, 1, bm0, k0 + BK, a.n, a.k1, tid, mx);
+                stage_load<TB, BN, BK>(rb, S, a.ss_n, a.ss_k, bn0, k0 + BK, a.c, a.k1, tid, ms);
+            }
 #pragma unroll
             for (int kk = 0; kk < BK; kk += MF::KT) {
                 T av[WR], bv[WC];
@@ -504,15 +511,20 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
         const int mg = stage_mode<T>(G, a.ldg, 1, a.n, 0, a.c);
         const int mbn = stage_mode<TB>(Bn, 1, a.ldb, a.c, 0, a.c);
         const int mbp = stage_mode<TB>(Bp, 1, a.ldb, a.c, 0, a.c);
+        stage_load<T, BM, BK>(ra, G, a.ldg, 1, bm0, 0, a.n, a.c, tid, mg);
+        stage_load<TB, BN, BK>(rb, Bn, 1, a.ldb, bn0, 0, a.c, a.c, tid, mbn);
+        stage_load<TB, BN, BK>(rb2, Bp, 1, a.ldb, bn0, 0, a.c, a.c, tid, mbp);
         for (int k0 = 0; k0 < a.c; k0 += BK) {
-            stage_load<T, BM, BK>(ra, G, a.ldg, 1, bm0, k0, a.n, a.c, tid, mg);
-            stage_load<TB, BN, BK>(rb, Bn, 1, a.ldb, bn0, k0, a.c, a.c, tid, mbn);
-            stage_load<TB, BN, BK>(rb2, Bp, 1, a.ldb, bn0, k0, a.c, a.c, tid, mbp);
             __syncthreads();
             stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.c, AOP_NONE, tid, mg);
             stage_store<T, TB, BN, BK, LDB>(Bs, rb, a.ldb == 1, k0, a.c, AOP_NONE, tid, mbn);
             stage_store<T, TB, BN, BK, LDB>(Bs2, rb2, a.ldb == 1, k0, a.c, AOP_NONE, tid, mbp);
             __syncthreads();
+            if (k0 + BK < a.c) {
+                stage_load<T, BM, BK>(ra, G, a.ldg, 1, bm0, k0 + BK, a.n, a.c, tid, mg);
+                stage_load<TB, BN, BK>(rb, Bn, 1, a.ldb, bn0, k0 + BK, a.c, a.c, tid, mbn);
+                stage_load<TB, BN, BK>(rb2, Bp, 1, a.ldb, bn0, k0 + BK, a.c, a.c, tid, mbp);
+            }
 #pragma unroll
             for (int kk = 0; kk < BK; kk += MF::KT) {
                 T av[WR], bv[WC], bv2[WC];
