@@ -40,26 +40,75 @@ PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6, 'bf16': 2500.0}        # MI355X dense 
 MASTER = {'f32': 'f32', 'f64': 'f64', 'bf16': 'f32'}
 
 
-def sizes(scale):
-    return {t: max(int(round(n * scale)), 64) for t, n in FULL.items()}
+# BASELINE configs[4]: MovieLens-style Dfmc -- 6 object types, 6 relations, the ratings
+# relation 98 % masked, constraints on Movie (lambda*I and a sparse negative similarity).  The dense
+# lambda*I on the 100k users (40 GB as a dense f32 matrix, as the reference would hold it) is left out.
+C5_FULL = {'user': 100000, 'movie': 40000, 'genre': 64, 'actor': 40000, 'tag': 20000, 'director': 10000}
+C5_RANKS = {'user': 128, 'movie': 256, 'genre': 16, 'actor': 128, 'tag': 64, 'director': 64}
+C5_TYPES = ['user', 'movie', 'genre', 'actor', 'tag', 'director']
+# (row, col, seed, density of the binary relation | None = ratings, masked)
+C5_PAIRS = [('user', 'movie', 50, None), ('movie', 'genre', 51, 0.15), ('movie', 'actor', 52, 0.001),
+            ('movie', 'tag', 53, 0.05), ('movie', 'director', 54, 0.001), ('user', 'tag', 55, 0.01)]
 
 
-def alg_flops(n):
-    """sum over relations of 2 * n_i * n_j * (c_i + c_j)."""
-    return sum(2.0 * n[i] * n[j] * (RANKS[i] + RANKS[j]) for i, j, _ in PAIRS)
+def sizes(scale, full=None):
+    return {t: max(int(round(n * scale)), 64) for t, n in (full or FULL).items()}
 
 
-def hbm_view(dtype, n, k_ms, k_launches):
+def c5_graph(n, dtype, masked=0.98, lam=0.01):
+    """Device-resident synthetic data of the config-5 graph (torch used as the random source and
+    elementwise plumbing; the engine only sees raw device pointers)."""
+    import torch
+    from skfusion_amd._engine import device_matrix_from_tensor as wrap
+    gen = torch.Generator(device='cuda')
+    tdt = {'bf16': torch.bfloat16, 'f32': torch.float32, 'f64': torch.float64}[dtype]
+    mdt = {'bf16': torch.float32, 'f32': torch.float32, 'f64': torch.float64}[dtype]
+    rels = []
+    for i, j, seed, dens in C5_PAIRS:
+        gen.manual_seed(seed)
+        u = torch.rand((n[i], n[j]), generator=gen, device='cuda', dtype=torch.float32)
+        if dens is None:
+            data = ((u * 10.0).floor_() + 1.0).div_(10.0).to(tdt)             # ratings 0.1 .. 1.0
+            gen.manual_seed(seed + 100)
+            mask = (torch.rand((n[i], n[j]), generator=gen, device='cuda', dtype=torch.float32) < masked).to(torch.uint8)
+            rels.append((i, j, wrap(data.contiguous()), wrap(mask.contiguous())))
+        else:
+            rels.append((i, j, wrap((u < dens).to(tdt).contiguous()), None))
+        del u
+    nm = n['movie']
+    gen.manual_seed(60)
+    sim = torch.rand((nm, nm), generator=gen, device='cuda', dtype=torch.float32) < 0.001
+    sim = (sim | sim.t()).to(mdt).mul_(-0.05)
+    sim.fill_diagonal_(0.0)
+    eye = torch.zeros((nm, nm), device='cuda', dtype=mdt)
+    eye.fill_diagonal_(lam)
+    thetas = [('movie', wrap(eye)), ('movie', wrap(sim.contiguous()))]
+    torch.cuda.synchronize()
+    return rels, thetas
+
+
+def alg_flops(n, spec=None, ranks=None):
+    """sum over relations of 2 * n_i * n_j * (c_i + c_j); a masked relation (DFMC) adds
+    its completion 2 * n_i * n_j * min(c_i, c_j)."""
+    spec = spec or [(i, j, False) for i, j, _ in PAIRS]
+    ranks = ranks or RANKS
+    return sum(2.0 * n[i] * n[j] * (ranks[i] + ranks[j] + (min(ranks[i], ranks[j]) if m else 0))
+               for i, j, m in spec)
+
+
+def hbm_view(dtype, n, k_ms, k_launches, spec=None):
     """The same launches against the HBM roofline: algorithmic bytes = every relation read once per
     contraction (2 contractions per relation); peak 8 TB/s (MI355X_MICROARCH.md)."""
     esz = {'bf16': 2, 'f32': 4, 'f64': 8}[dtype]
-    total = 2.0 * sum(float(n[i]) * n[j] for i, j, _ in PAIRS) * esz          # per iteration
+    spec = spec or [(i, j, False) for i, j, _ in PAIRS]
+    per_iter = sum(3 if m else 2 for _, _, m in spec)       # a masked relation recomputes P after completion
+    total = sum((3.0 if m else 2.0) * float(n[i]) * n[j] for i, j, m in spec) * esz     # per iteration
     if not k_ms or not k_launches:
         return None
-    iters = k_launches / (2.0 * len(PAIRS))
+    iters = k_launches / float(per_iter)
     tbs = total * iters / (k_ms * 1e-3) / 1e12
     return {'achieved': tbs, 'peak': 8.0, 'unit': 'TB/s', 'frac': tbs / 8.0,
-            'algorithmic_bytes_per_launch': total / (2.0 * len(PAIRS))}
+            'algorithmic_bytes_per_launch': total / float(per_iter)}
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -102,6 +151,9 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['f32', 'f64', 'bf16'])
     ap.add_argument('--scale', type=float, default=1.0, help='linear scale of the object counts')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='c3', choices=['c3', 'c5'],
+                    help='c3 (default): BASELINE configs[2], the metric\'s workload; c5: BASELINE configs[4], '
+                         'Dfmc on the MovieLens-style 6-relation graph with masks and constraints')
     ap.add_argument('--mode', default='restarts', choices=['restarts', 'relations', 'rows'],
                     help='N>1: one independent restart per GPU (weak scaling, no collective; default); or ONE fit '
                          '(strong scaling) with whole relations partitioned over the GPUs and an RCCL all-reduce of '
@@ -132,40 +184,62 @@ def main():
     import skfusion_amd._native as nat
     from skfusion_amd._engine import DevicePlan, fill_uniform
 
-    n = sizes(args.scale)
+    c5 = (args.workload == 'c5')
+    types, ranks_ = (C5_TYPES, C5_RANKS) if c5 else (TYPES, RANKS)
+    n = sizes(args.scale, C5_FULL if c5 else FULL)
+    variant = nat.SKF_DFMC if c5 else nat.SKF_DFMF
     sharded = (args.mode in ('relations', 'rows') and world > 1)
-    pairs = PAIRS
+    esz = {'bf16': 2, 'f32': 4, 'f64': 8}[args.dtype]
+    # the whole graph as (row, col, masked) + a maker of relation k's device matrices
+    if c5:
+        full_rels, full_thetas = c5_graph(n, args.dtype)
+        spec = [(i, j, dens is None) for i, j, _, dens in C5_PAIRS]
+
+        def make(k):
+            return full_rels[k][2], full_rels[k][3]
+    else:
+        full_thetas = []
+        spec = [(i, j, False) for i, j, _ in PAIRS]
+
+        def make(k):                   # same values whatever the sharding (counter-based generator)
+            i, j, seed = PAIRS[k]
+            return fill_uniform((n[i], n[j]), seed, args.dtype), None
+    part_rel = [(i, j, None, None) for i, j, _ in spec]
+    part_th = [(t, None) for t, _ in full_thetas]
+    local_index = list(range(len(spec)))            # global index of every relation of this plan
+    thetas = list(full_thetas)
     if sharded and args.mode == 'relations':       # this rank keeps only its share of the relations
         from skfusion_amd._distributed import partition_relations
-        owner, _ = partition_relations([(i, j, None, None) for i, j, _ in PAIRS], [], n, RANKS)
-        pairs = [pr for pr, o in zip(PAIRS, owner) if o == rank]
+        owner, th_owner = partition_relations(part_rel, part_th, n, ranks_)
+        local_index = [k for k, o in enumerate(owner) if o == rank]
+        thetas = [t for t, o in zip(full_thetas, th_owner) if o == rank]
     if sharded and args.mode == 'rows':            # every relation listed, with this rank's row block of it
         from skfusion_amd._distributed import partition_rows
-        blocks, _ = partition_rows([(i, j, None, None) for i, j, _ in PAIRS], [], n, RANKS,
-                                   align=256 if min(n.values()) >= 4096 else 64)
-        esz = {'bf16': 2, 'f32': 4, 'f64': 8}[args.dtype]
+        blocks, th_owner = partition_rows(part_rel, part_th, n, ranks_,
+                                          align=256 if min(n.values()) >= 4096 else 64)
+        thetas = [t for t, o in zip(full_thetas, th_owner) if o == rank]
         rels = []
-        for (i, j, s), blk in zip(PAIRS, blocks):
+        for k, ((i, j, masked), blk) in enumerate(zip(spec, blocks)):
             mine = [b for b in blk if b[0] == rank]
             if not mine:
-                rels.append((i, j, None, None, dict(absent=True, row_begin=0, n_rows=0, col_side=False, masked=False)))
+                rels.append((i, j, None, None, dict(absent=True, row_begin=0, n_rows=0, col_side=False, masked=masked)))
                 continue
             _, a, cnt = mine[0]
-            full = fill_uniform((n[i], n[j]), s, args.dtype)      # same values as the unsharded run
-            rels.append((i, j, full.rows(a, cnt, esz), None,
-                         dict(absent=False, row_begin=a, n_rows=cnt, col_side=(a == 0), masked=False)))
-            del full
+            data, mask = make(k)
+            rels.append((i, j, data.rows(a, cnt, esz), None if mask is None else mask.rows(a, cnt, 1),
+                         dict(absent=False, row_begin=a, n_rows=cnt, col_side=(a == 0), masked=masked)))
+            del data, mask
     else:
-        rels = [(i, j, fill_uniform((n[i], n[j]), s, args.dtype), None) for i, j, s in pairs]
-    plan = DevicePlan(TYPES, n, RANKS, rels, [], nat.SKF_DFMF, dtype=args.dtype,
+        rels = [(spec[k][0], spec[k][1]) + make(k) for k in local_index]
+    plan = DevicePlan(types, n, ranks_, rels, thetas, variant, dtype=args.dtype,
                       part=(rank, world) if sharded and args.mode == 'rows' else None)
     if args.dtype == 'bf16':          # the plan keeps its own padded bf16 copies of R and R^T
-        del rels[:]
-        plan._keep = []
+        plan.release_relation_data()
+        rels = full_rels = None
         torch.cuda.empty_cache()
-    for k, t in enumerate(TYPES):      # one random restart per rank: G0 seed depends on the rank
+    for k, t in enumerate(types):      # one random restart per rank: G0 seed depends on the rank
         seed = 100 + k + (0 if sharded else 10 * rank)       # sharded: replicated factors
-        plan.set_factor(t, fill_uniform((n[t], RANKS[t]), seed, MASTER[args.dtype]))
+        plan.set_factor(t, fill_uniform((n[t], ranks_[t]), seed, MASTER[args.dtype]))
     step = plan.iterate if not sharded else (plan.iterate_rows if args.mode == 'rows' else plan.iterate_sharded)
 
     def sync():
@@ -190,14 +264,15 @@ def main():
 
     rmse = {}
     if sharded and args.mode == 'rows':            # every rank holds the squared error of its row blocks
-        sq = torch.tensor([plan.relation_sqerr(k) for k in range(len(PAIRS))], dtype=torch.float64,
+        sq = torch.tensor([plan.relation_sqerr(k) for k in range(len(spec))], dtype=torch.float64,
                           device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(sq)
-        for k, (i, j, _) in enumerate(PAIRS):
+        for k, (i, j, _) in enumerate(spec):
             rmse['%s-%s' % (i, j)] = float(np.sqrt(float(sq[k]) / (n[i] * n[j])))
     else:
-        for k, (i, j, _) in enumerate(pairs):
-            rmse['%s-%s' % (i, j)] = float(np.sqrt(plan.relation_sqerr(k) / (n[i] * n[j])))
+        for q, k in enumerate(local_index):
+            i, j, _ = spec[k]
+            rmse['%s-%s' % (i, j)] = float(np.sqrt(plan.relation_sqerr(q) / (n[i] * n[j])))
     units = 1 if sharded else world        # fits advanced per step by the whole job
 
     if rank == 0:
@@ -205,14 +280,19 @@ def main():
         try:
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
                 t = json.load(fh).get(args.dtype)
-            if t and args.scale == 1.0:
+            if t and args.scale == 1.0 and not c5:
                 traffic = t['fetch_bytes_per_launch'] + t['write_bytes_per_launch']
         except Exception:
             traffic = None
+        how = {'restarts': 'one random restart per GPU',
+               'relations': 'one fit, whole relations partitioned over the GPUs',
+               'rows': 'one fit, balanced row blocks of the relations over the GPUs'}[args.mode]
         achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
         out = {
-            'metric': 'DFMF update iters/sec (+ reconstruction RMSE), 3-relation graph @ ranks 128/256/256',
+            'metric': ('DFMC update iters/sec (+ RMSE), MovieLens-style 6-relation graph with masks and constraints'
+                       if c5 else
+                       'DFMF update iters/sec (+ reconstruction RMSE), 3-relation graph @ ranks 128/256/256'),
             'value': units * args.steps / elapsed,
             'unit': 'iters/s',
             'n_gpus': world,
@@ -224,26 +304,27 @@ def main():
             'vs_baseline': None,
             'dtype': args.dtype,
             'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2]: synthetic dense 3-type graph %dx%d / %dx%d / %dx%d, '
-                                   'ranks 128/256/256, Dfmf, %s'
-                                   % (n['t1'], n['t2'], n['t1'], n['t3'], n['t2'], n['t3'],
-                                      {'restarts': 'one random restart per GPU',
-                                       'relations': 'one fit, whole relations partitioned over the GPUs',
-                                       'rows': 'one fit, balanced row blocks of the relations over the GPUs'}[args.mode]),
+            'config': {'workload': ('BASELINE configs[4]: Dfmc, MovieLens-style graph %s, ranks %s, ratings 98%% masked, '
+                                    'Theta_movie = [lambda*I, sparse negative similarity], %s'
+                                    % (' / '.join('%s %d' % (t, n[t]) for t in types),
+                                       '/'.join(str(ranks_[t]) for t in types), how) if c5 else
+                                    'BASELINE configs[2]: synthetic dense 3-type graph %dx%d / %dx%d / %dx%d, '
+                                    'ranks 128/256/256, Dfmf, %s'
+                                    % (n['t1'], n['t2'], n['t1'], n['t3'], n['t2'], n['t3'], how)),
                        'scale': args.scale, 'restarts': units, 'mode': args.mode,
-                       'alg_flops_per_iter': alg_flops(n)},
+                       'alg_flops_per_iter': alg_flops(n, spec, ranks_)},
             'rmse': rmse,
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic,
                          'traffic_note': 'HBM bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) measured by rocprofv3 --pmc in a separate pass, profiles/pmc_traffic.json; algorithmic = one read of the bf16 relation',
-                         'kernel': 'relation contractions P=R*G_j, Q=R^T*G_i (%s)' % ('gemm_bf16_kernel<BN,1>' if args.dtype == 'bf16' else 'gemm_mfma_kernel<..,TAG=1>'),
+                         'kernel': 'relation contractions P=R*G_j, Q=R^T*G_i (%s)' % ('gemm_bf16_v2_kernel<BN,TAG=1,..>' if args.dtype == 'bf16' else 'gemm_mfma_kernel<..,TAG=1>'),
                          'launches': int(k_launches),
                          'avg_launch_ms': k_ms / k_launches if k_launches else None,
                          'alg_flops_per_launch': k_flops / k_launches if k_launches else None,
-                         'whole_iteration_frac': alg_flops(n) * args.steps / elapsed / 1e12 / peak,
-                         'hbm_view': hbm_view(args.dtype, n, k_ms, k_launches)},
+                         'whole_iteration_frac': alg_flops(n, spec, ranks_) * args.steps / elapsed / 1e12 / peak,
+                         'hbm_view': hbm_view(args.dtype, n, k_ms, k_launches, spec)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not c5:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
     plan.close()

@@ -23,6 +23,12 @@ class DeviceMatrix(object):
         return DeviceMatrix(_BufferView(self.buf, begin * self.ld * itemsize), (count, self.shape[1]), self.ld)
 
 
+def device_matrix_from_tensor(t):
+    """Wrap a contiguous 2-D torch tensor that lives on the engine's device (no copy)."""
+    assert t.dim() == 2 and t.is_contiguous()
+    return DeviceMatrix(nat.Buffer(t.data_ptr(), t.numel() * t.element_size(), t), tuple(t.shape))
+
+
 class _BufferView(object):
     def __init__(self, parent, offset):
         self.parent, self.ptr = parent, parent.ptr + offset
@@ -73,7 +79,7 @@ class DevicePlan(object):
         self.rank = [int(rank[t]) for t in self.types]
         self.relations = relations
         self.handle = nat._P()
-        self._keep = []
+        self._keep, self._keep_rel = [], []
         mem, lib = self.rt.mem, self.rt.lib
 
         tdesc = (nat.TypeDesc * len(self.types))()
@@ -105,9 +111,14 @@ class DevicePlan(object):
             if tuple(arr.shape) != (rows_here, n_obj[j]):
                 raise ValueError('relation (%s,%s) dimension mismatch: %r vs object counts (%d,%d)'
                                  % (i, j, tuple(arr.shape), rows_here, n_obj[j]))
-            self._keep.append(buf)
+            self._keep_rel.append(buf)
             rdesc[k].data, rdesc[k].ld = buf.ptr, ld
-            if mask is not None:
+            if isinstance(mask, DeviceMatrix):           # uint8 bytes already in HBM
+                if tuple(mask.shape) != tuple(arr.shape):
+                    raise ValueError('mask shape mismatch for relation (%s,%s)' % (i, j))
+                self._keep.append(mask.buf)
+                rdesc[k].mask, rdesc[k].mask_ld = mask.buf.ptr, mask.ld
+            elif mask is not None:
                 m = np.ascontiguousarray(np.asarray(mask, dtype=bool).astype(np.uint8))
                 if m.shape != arr.shape:
                     raise ValueError('mask shape mismatch for relation (%s,%s)' % (i, j))
@@ -116,6 +127,12 @@ class DevicePlan(object):
                 rdesc[k].mask, rdesc[k].mask_ld = mbuf.ptr, m.shape[1]
         hdesc = (nat.ThetaDesc * max(len(thetas), 1))()
         for k, (t, data) in enumerate(thetas):
+            if isinstance(data, DeviceMatrix):           # master dtype, already in HBM
+                if tuple(data.shape) != (n_obj[t], n_obj[t]):
+                    raise ValueError('constraint on %s dimension mismatch' % (t,))
+                self._keep.append(data.buf)
+                hdesc[k].type, hdesc[k].data, hdesc[k].ld = self.index[t], data.buf.ptr, data.ld
+                continue
             arr = np.ascontiguousarray(data, dtype=self.np_dtype)
             if arr.shape != (n_obj[t], n_obj[t]):
                 raise ValueError('constraint on %s dimension mismatch' % (t,))
@@ -133,6 +150,12 @@ class DevicePlan(object):
         self.ws = mem.empty(nbytes.value)
         self.rt.call('skf_plan_bind_workspace', self.handle, self.ws.ptr, nbytes.value, mem.stream)
         self._scalar = mem.empty(8)
+
+    def release_relation_data(self):
+        """SKF_BF16: the relations were copied (padded, transposed) at bind time; the caller's buffers
+        are not referenced afterwards and may be dropped.  No-op for the other engines."""
+        if self.dtype == nat.SKF_BF16:
+            self._keep_rel = []
 
     # -- factors ---------------------------------------------------------------------------
     def set_factor(self, t, G):
@@ -258,7 +281,7 @@ class DevicePlan(object):
         if self.handle:
             self.rt.lib.skf_plan_destroy(self.handle)
             self.handle = nat._P()
-        self._keep = []
+        self._keep, self._keep_rel = [], []
         self.ws = None
 
     def __del__(self):

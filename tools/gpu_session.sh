@@ -23,6 +23,23 @@ case "$step" in
     echo "== bench $dt" | tee -a "$OUT/summary.txt"
     ( time timeout 900 python bench.py --dtype $dt --steps 10 --warmup 3 ) > "$OUT/bench_$dt.log" 2>&1
     echo "bench exit $?" | tee -a "$OUT/summary.txt"; tail -4 "$OUT/bench_$dt.log" | tee -a "$OUT/summary.txt" ;;
+  c5_*)
+    dt=${step#c5_}
+    echo "== bench c5 (Dfmc, MovieLens-style) $dt" | tee -a "$OUT/summary.txt"
+    ( time timeout 900 python bench.py --workload c5 --dtype $dt --steps 5 --warmup 2 ) > "$OUT/c5_$dt.log" 2>&1
+    echo "c5 exit $?" | tee -a "$OUT/summary.txt"; tail -3 "$OUT/c5_$dt.log" | cut -c1-1500 | tee -a "$OUT/summary.txt" ;;
+  c5prof_*)
+    dt=${step#c5prof_}
+    echo "== rocprofv3 kernel-trace c5 $dt" | tee -a "$OUT/summary.txt"
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/c5prof_$dt" -o prof -- python "$OLDPWD/bench.py" --workload c5 --dtype $dt --steps 3 --warmup 1 ) > "$OUT/c5prof_$dt.log" 2>&1
+    echo "rocprof exit $?" | tee -a "$OUT/summary.txt"
+    find "$OUT/c5prof_$dt" -name '*kernel_trace.csv' -size +20M -delete ;;
+  c5dist)
+    echo "== torchrun x2 (gloo, shared GPU) c5 rows / relations" | tee -a "$OUT/summary.txt"
+    for mode in relations rows; do
+      ( SKF_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --workload c5 --gpus 2 --steps 2 --warmup 1 --scale 0.1 --mode $mode ) > "$OUT/c5dist_$mode.log" 2>&1
+      echo "c5 dist $mode exit $?" | tee -a "$OUT/summary.txt"; tail -1 "$OUT/c5dist_$mode.log" | cut -c1-900 | tee -a "$OUT/summary.txt"
+    done ;;
   dist_smoke)
     # the torchrun paths of bench.py with 2 ranks sharing the one GPU of this box (gloo group)
     echo "== torchrun x2 (gloo, shared GPU) restarts / relations / rows" | tee -a "$OUT/summary.txt"
