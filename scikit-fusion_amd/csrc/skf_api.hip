@@ -387,6 +387,8 @@ struct RelState {
     int64_t ldr = 0;
     Slot Rw, P, Q, W, T1, S, U, H;
     Slot S32;                      // f32 engines: rounding of S for the fused side update
+    Slot Hb, Gb;                   // SKF_BF16 masked relation: bf16 H = G_i S and bf16 G_j (K padded to 64)
+    int64_t ldhb = 0;
     Slot Rb, RTb;                  // SKF_BF16: padded bf16 copies of R and R^T
     int64_t ldrb = 0, ldrtb = 0;
     bool s_set = false;
@@ -401,6 +403,9 @@ struct ThetaState {
     int type = 0;
     const void* data = nullptr;
     int64_t ld = 0;
+    bool has_pos = true, has_neg = true;   // non-empty halves of the +- split (found at bind time)
+    Slot Pb, Nb;                           // SKF_BF16: bf16 copies of Theta+ / Theta-, [n][pad64(n)]
+    int64_t ldb = 0;
 };
 
 }  // namespace skf
@@ -420,6 +425,7 @@ struct skf_plan {
     skf::Slot part;            // split-K partials
     size_t part_bytes = 0;
     skf::Slot eigA, eigV, eigVs, eigW, eigN, eigNorig, eigOk, sqpart;
+    skf::Slot theta_flags, theta_tmp;      // sign flags of the constraints; SKF_BF16: n x c product scratch
     int64_t eig_stride = 0;
     int eig_maxn = 0;
     size_t sq_elems = 0;
@@ -629,13 +635,26 @@ static void mult_update(skf_plan* p, TypeState& t, hipStream_t st) {
 static void theta_terms(skf_plan* p, hipStream_t st) {
     for (ThetaState& th : p->thetas) {
         TypeState& t = p->types[th.type];
-        // D += Theta+ G   (_dfmf.py:285-288);  E += Theta- G   (:289-292)
+        // D += Theta+ G   (_dfmf.py:285-288);  E += Theta- G   (:289-292); an all-zero half is skipped
+        if (p->bf16) {      // bf16 copies of the halves against the stored G^T, f32 accumulate, then added
+            for (int half = 0; half < 2; ++half) {
+                if (!(half == 0 ? th.has_pos : th.has_neg)) continue;
+                run_gemm_bf16((const uint16_t*)(half == 0 ? th.Pb.ptr : th.Nb.ptr), th.ldb, (const uint16_t*)t.GTb.ptr,
+                              t.ldgt, (float*)p->theta_tmp.ptr, t.c, (int)t.n, t.c, (int)th.ldb, 0, p->part.ptr,
+                              p->part_bytes, false, st);
+                hipLaunchKernelGGL(add_into_kernel, dim3(elem_grid(t.n * t.c)), dim3(256), 0, st,
+                                   (float*)(half == 0 ? t.D.ptr : t.E.ptr), (const float*)p->theta_tmp.ptr,
+                                   (int64_t)t.n * t.c);
+                check_launch("add_into");
+            }
+            continue;
+        }
         GemmArgs g = gemm_args(th.data, th.ld, 1, t.G.ptr, t.c, 1, t.D.ptr, t.c, (int)t.n, t.c, (int)t.n, EPI_ACC, 0);
         g.aop = AOP_POS;
-        plan_gemm(p, g, st);
+        if (th.has_pos) plan_gemm(p, g, st);
         g.C = t.E.ptr;
         g.aop = AOP_NEG;
-        plan_gemm(p, g, st);
+        if (th.has_neg) plan_gemm(p, g, st);
     }
 }
 
@@ -803,16 +822,31 @@ static void stage_backbone(skf_plan* p, hipStream_t st) {
             g = gemm_args(rows_of(p, ti.G, ti, r.r0), ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, nr, cj, ci, EPI_STORE, 0);
             mixed_gemm(p, g, st);
             if (r.mask) {
-                if (p->bf16) {     // completed entries go to both stored copies (R and R^T), as bf16
-                    g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rb.ptr, r.ldrb, nr, nj, cj, EPI_MASKED_STORE_BF16, 0);
-                    g.C2 = r.RTb.ptr;
-                    g.ldc2 = r.ldrtb;
+                const char* slow = getenv("SKF_BF16_COMPLETE_F32");      // "1": the f32 product (A/B runs)
+                if (p->bf16 && !(slow && atoi(slow) != 0)) {
+                    // completed entries go to both stored copies (R and R^T) as bf16: bf16 operands on the
+                    // matrix cores, the write-out is the bound (complete_bf16_kernel)
+                    launch_to_bf16<float>((uint16_t*)r.Hb.ptr, r.ldhb, (const float*)r.H.ptr, (int64_t)cj, nr, cj, false, st);
+                    launch_to_bf16<float>((uint16_t*)r.Gb.ptr, r.ldhb, (const float*)tj.G.ptr, (int64_t)cj, nj, cj, false, st);
+                    CompleteArgs ca;
+                    ca.A = (const uint16_t*)r.Hb.ptr; ca.Bt = (const uint16_t*)r.Gb.ptr; ca.mask = r.mask;
+                    ca.R = (uint16_t*)r.Rb.ptr; ca.RT = (uint16_t*)r.RTb.ptr;
+                    ca.lda = r.ldhb; ca.ldb = r.ldhb; ca.ldmask = r.ldmask; ca.ldr = r.ldrb; ca.ldrt = r.ldrtb;
+                    ca.M = nr; ca.N = nj; ca.Kp = (int)r.ldhb;
+                    hipLaunchKernelGGL(complete_bf16_kernel, dim3(cdiv(nj, 128), cdiv(nr, 128)), dim3(256), 0, st, ca);
+                    check_launch("complete_bf16");
                 } else {
-                    g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rw.ptr, r.ldr, nr, nj, cj, EPI_MASKED_STORE, 0);
+                    if (p->bf16) {
+                        g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rb.ptr, r.ldrb, nr, nj, cj, EPI_MASKED_STORE_BF16, 0);
+                        g.C2 = r.RTb.ptr;
+                        g.ldc2 = r.ldrtb;
+                    } else {
+                        g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rw.ptr, r.ldr, nr, nj, cj, EPI_MASKED_STORE, 0);
+                    }
+                    g.mask = r.mask;
+                    g.ldmask = r.ldmask;
+                    plan_gemm(p, g, st);
                 }
-                g.mask = r.mask;
-                g.ldmask = r.ldmask;
-                plan_gemm(p, g, st);
             }
             contraction_P(p, r, st);
         }
@@ -1238,6 +1272,11 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             want_part(tj.c, tj.c, ti.c, true);
             if (nr <= 0) continue;
             if (r.mask && !p->bf16) add_slot(p, r.Rw, (size_t)nr * tj.n * es);
+            if (p->bf16 && r.mask) {
+                r.ldhb = pad64(tj.c);
+                add_slot(p, r.Hb, (size_t)nr * r.ldhb * 2);
+                add_slot(p, r.Gb, (size_t)tj.n * r.ldhb * 2);
+            }
             if (p->bf16) {
                 r.ldrb = pad64(tj.n);
                 r.ldrtb = pad64(nr);
@@ -1254,8 +1293,21 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             size_t blocks = (size_t)cdiv(nr, 32) * cdiv(tj.n, 32);
             if (blocks > sq_elems) sq_elems = blocks;
         }
-        for (ThetaState& th : p->thetas)
-            want_part((int)p->types[th.type].n, p->types[th.type].c, (int)p->types[th.type].n, p->f64);
+        size_t theta_tmp_bytes = 0;
+        for (ThetaState& th : p->thetas) {
+            TypeState& t = p->types[th.type];
+            want_part((int)t.n, t.c, (int)t.n, p->f64);
+            if (p->bf16) {
+                th.ldb = pad64(t.n);
+                add_slot(p, th.Pb, (size_t)t.n * th.ldb * 2);
+                add_slot(p, th.Nb, (size_t)t.n * th.ldb * 2);
+                const size_t b = bf16_part_bytes((int)t.n, t.c, (int)th.ldb);
+                if (b > part_bytes) part_bytes = b;
+                if ((size_t)t.n * t.c * 4 > theta_tmp_bytes) theta_tmp_bytes = (size_t)t.n * t.c * 4;
+            }
+        }
+        if (!p->thetas.empty()) add_slot(p, p->theta_flags, p->thetas.size() * 2 * sizeof(int));
+        if (theta_tmp_bytes) add_slot(p, p->theta_tmp, theta_tmp_bytes);
         p->part_bytes = part_bytes;
         add_slot(p, p->part, part_bytes);
         size_t aux_bytes = 0;
@@ -1320,10 +1372,49 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
                 const int64_t rows = r.nr, cols = p->types[r.col].n;
                 SKF_HIP(hipMemsetAsync(r.Rb.ptr, 0, r.Rb.bytes, st));
                 SKF_HIP(hipMemsetAsync(r.RTb.ptr, 0, r.RTb.bytes, st));
+                if (r.mask) {
+                    SKF_HIP(hipMemsetAsync(r.Hb.ptr, 0, r.Hb.bytes, st));
+                    SKF_HIP(hipMemsetAsync(r.Gb.ptr, 0, r.Gb.bytes, st));
+                }
                 launch_to_bf16<uint16_t>((uint16_t*)r.Rb.ptr, r.ldrb, (const uint16_t*)r.R_in, r.ld_in, rows, cols, false, st);
                 launch_to_bf16<uint16_t>((uint16_t*)r.RTb.ptr, r.ldrtb, (const uint16_t*)r.R_in, r.ld_in, rows, cols, true, st);
                 r.R = r.Rb.ptr;
                 r.ldr = r.ldrb;
+            }
+        }
+        if (!p->thetas.empty()) {
+            // which halves of every constraint's +- split are non-empty (one device pass, read back here:
+            // bind is not on the hot path), and the bf16 engine's copies of the non-empty halves
+            SKF_HIP(hipMemsetAsync(p->theta_flags.ptr, 0, p->theta_flags.bytes, st));
+            for (size_t k = 0; k < p->thetas.size(); ++k) {
+                ThetaState& th = p->thetas[k];
+                const int64_t n = p->types[th.type].n;
+                int* fl = (int*)p->theta_flags.ptr + 2 * k;
+                if (p->f64)
+                    hipLaunchKernelGGL((sign_flags_kernel<double>), dim3(elem_grid(n * n)), dim3(256), 0, st,
+                                       (const double*)th.data, th.ld, n, n, fl);
+                else
+                    hipLaunchKernelGGL((sign_flags_kernel<float>), dim3(elem_grid(n * n)), dim3(256), 0, st,
+                                       (const float*)th.data, th.ld, n, n, fl);
+                check_launch("sign_flags");
+            }
+            std::vector<int> flags(p->thetas.size() * 2);
+            SKF_HIP(hipMemcpyAsync(flags.data(), p->theta_flags.ptr, flags.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+            SKF_HIP(hipStreamSynchronize(st));
+            for (size_t k = 0; k < p->thetas.size(); ++k) {
+                ThetaState& th = p->thetas[k];
+                th.has_pos = flags[2 * k] != 0;
+                th.has_neg = flags[2 * k + 1] != 0;
+                if (!p->bf16) continue;
+                const int64_t n = p->types[th.type].n;
+                for (int half = 0; half < 2; ++half) {
+                    if (!(half == 0 ? th.has_pos : th.has_neg)) continue;
+                    Slot& dst = half == 0 ? th.Pb : th.Nb;
+                    SKF_HIP(hipMemsetAsync(dst.ptr, 0, dst.bytes, st));
+                    hipLaunchKernelGGL(split_to_bf16_kernel, dim3(elem_grid(n * n)), dim3(256), 0, st, (uint16_t*)dst.ptr,
+                                       th.ldb, (const float*)th.data, th.ld, n, n, half == 0 ? AOP_POS : AOP_NEG);
+                    check_launch("split_to_bf16");
+                }
             }
         }
         if (p->variant != SKF_TRANSFORM) {

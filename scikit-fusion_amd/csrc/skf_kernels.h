@@ -775,6 +775,184 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 engine, DFMC completion (_dfmc.py:319-325): R[m][n] = RT[n][m] = bf16((H G_j^T)[m][n]) where
+// mask[m][n] != 0, both stored copies of the relation in one pass.  A = bf16(H) [M][lda], Bt =
+// bf16(G_j) [N][ldb] (K = c_j, zero padded to 64).  128 x 128 tile, 4 waves (64 x 64 each), main
+// loop of gemm_bf16_kernel.  The output is HBM-bound (every masked entry is written twice), so the
+// epilogue stages the tile and its mask in LDS and writes whole 16-byte chunks in BOTH
+// orientations -- along n into R and along m into RT -- reading the old chunk only when it holds
+// an unmasked entry to keep.
+// ------------------------------------------------------------------------------------------
+struct CompleteArgs {
+    const uint16_t* A;
+    const uint16_t* Bt;
+    const uint8_t* mask;
+    uint16_t* R;
+    uint16_t* RT;
+    int64_t lda, ldb, ldmask, ldr, ldrt;
+    int M, N, Kp;
+};
+
+__global__ __launch_bounds__(256) void complete_bf16_kernel(CompleteArgs g) {
+    constexpr int BM = 128, BN = 128, BK = 64;
+    constexpr int TLD = 130;                 // halfwords per staged row: 65 dwords, odd -> column reads spread
+    constexpr int MLD = 132;                 // mask bytes per staged row: 33 dwords
+    constexpr int T_BYTES = BM * TLD * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[T_BYTES + BM * MLD];
+    u32x4* As = (u32x4*)smem;                // main loop: 2 x 16 KiB of operand tiles
+    u32x4* Bs = As + BM * 8;
+    uint16_t* T = (uint16_t*)smem;           // epilogue: the tile as bf16 and its mask
+    uint8_t* Mk = smem + T_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    const int nkt = g.Kp / BK;
+    const int srow = tid >> 3, schunk = tid & 7;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[4], rb[4];
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = bm0 + srow + 32 * p;
+            ra[p] = (m < g.M) ? *(const u32x4*)(g.A + (int64_t)m * g.lda + k0 + schunk * 8) : zero;
+            const int n = bn0 + srow + 32 * p;
+            rb[p] = (n < g.N) ? *(const u32x4*)(g.Bt + (int64_t)n * g.ldb + k0 + schunk * 8) : zero;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            As[swz_chunk(srow + 32 * p, schunk)] = ra[p];
+            Bs[swz_chunk(srow + 32 * p, schunk)] = rb[p];
+        }
+    };
+    if (nkt > 0) {
+        load_tiles(0);
+        store_tiles();
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1 < nkt);
+        if (more) load_tiles((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = 4 * ks + (lane >> 4);
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) store_tiles();
+        __syncthreads();
+    }
+
+    // ---- epilogue.  (the last barrier of the loop already separates the operand tiles from T / Mk)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                T[(wm0 + i * 16 + 4 * (lane >> 4) + r) * TLD + wn0 + j * 16 + (lane & 15)] = f32_to_bf16_rne(acc[i][j][r]);
+    // mask tile, zero outside the matrix (those positions are never written)
+    const bool mvec = ((g.ldmask & 15) == 0) && ((((uintptr_t)g.mask) & 15) == 0);
+    for (int i = tid; i < BM * 8; i += 256) {
+        const int r = i >> 3, c16 = (i & 7) * 16;
+        const int m = bm0 + r, n = bn0 + c16;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (m < g.M && n < g.N) {
+            const uint8_t* src = g.mask + (int64_t)m * g.ldmask + n;
+            if (mvec && n + 16 <= g.N) {
+                const u32x4 v = *(const u32x4*)src;
+                w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
+            } else {
+                for (int q = 0; q < 16; ++q)
+                    if (n + q < g.N && src[q]) w[q >> 2] |= 1u << (8 * (q & 3));
+            }
+        }
+        uint32_t* dst = (uint32_t*)(Mk + r * MLD + c16);
+        dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3];
+    }
+    __syncthreads();
+    // pass 1: 8 consecutive columns of one row -> R (row-major copy)
+    for (int i = tid; i < BM * 16; i += 256) {
+        const int r = i >> 4, c0 = (i & 15) * 8;
+        const int m = bm0 + r;
+        if (m >= g.M) continue;
+        const uint32_t* mk = (const uint32_t*)(Mk + r * MLD + c0);
+        const uint32_t m0 = mk[0], m1 = mk[1];
+        if ((m0 | m1) == 0u) continue;
+        const uint32_t* tv = (const uint32_t*)(T + r * TLD + c0);          // 4-byte aligned (TLD, c0 even)
+        u32x4 v = {tv[0], tv[1], tv[2], tv[3]};
+        u32x4* dst = (u32x4*)(g.R + (int64_t)m * g.ldr + bn0 + c0);
+        uint32_t keep = 0u;        // bit q set: element q is known (mask byte 0) and keeps its old value
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t byte = ((q < 4 ? m0 : m1) >> (8 * (q & 3))) & 0xFFu;
+            if (!byte) keep |= 1u << q;
+        }
+        if (keep) {
+            const u32x4 old = *dst;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (keep & (1u << q)) {
+                    const uint32_t sh = 16 * (q & 1), msk = 0xFFFFu << sh;
+                    v[q >> 1] = (v[q >> 1] & ~msk) | (old[q >> 1] & msk);
+                }
+        }
+        *dst = v;
+    }
+    // pass 2: 8 consecutive rows of one column -> RT (stored transpose)
+    for (int i = tid; i < BN * 16; i += 256) {
+        const int c = i >> 4, r0 = (i & 15) * 8;
+        const int n = bn0 + c;
+        if (n >= g.N) continue;
+        uint32_t keep = 0u, any = 0u;
+        uint16_t e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            e[q] = T[(r0 + q) * TLD + c];
+            if (Mk[(r0 + q) * MLD + c]) any = 1u;
+            else keep |= 1u << q;
+        }
+        if (!any) continue;
+        u32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (uint32_t)e[2 * q] | ((uint32_t)e[2 * q + 1] << 16);
+        u32x4* dst = (u32x4*)(g.RT + (int64_t)n * g.ldrt + bm0 + r0);
+        if (keep) {
+            const u32x4 old = *dst;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (keep & (1u << q)) {
+                    const uint32_t sh = 16 * (q & 1), msk = 0xFFFFu << sh;
+                    v[q >> 1] = (v[q >> 1] & ~msk) | (old[q >> 1] & msk);
+                }
+        }
+        *dst = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // bf16 relation contraction, second generation: 256 x BN block tile, 512 threads = 8 waves
 // (4 x 2, wave tile 64 x BN/2), K tile 64, LDS double-buffered in dynamic shared memory
 // (2 x (256+BN) x 128 B = 128 KiB at BN = 256) so that one barrier per K tile suffices:
@@ -1328,16 +1506,64 @@ __global__ __launch_bounds__(256) void mask_zero_kernel(T* __restrict__ R, int64
     }
 }
 
-// bf16 engine, DFMC iteration 0: the stored transpose gets the same zeros, RT[c][r] = 0 where mask[r][c]
+// bf16 engine, DFMC iteration 0: the stored transpose gets the same zeros, RT[c][r] = 0 where mask[r][c].
+// 64 x 64 tiles through LDS: the mask is read along its rows, R^T written along its rows.
 __global__ __launch_bounds__(256) void mask_zero_transposed_kernel(uint16_t* __restrict__ RT, int64_t ldrt,
                                                                    const uint8_t* __restrict__ mask, int64_t ldm,
                                                                    int64_t rows, int64_t cols) {
+    __shared__ uint8_t tile[64][65];
+    const int64_t tiles_c = (cols + 63) / 64, tiles = ((rows + 63) / 64) * tiles_c;
+    const int tid = threadIdx.x;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+        for (int i = tid; i < 4096; i += 256) {
+            const int rr = i >> 6, cc = i & 63;
+            tile[rr][cc] = (r0 + rr < rows && c0 + cc < cols) ? mask[(r0 + rr) * ldm + c0 + cc] : (uint8_t)0;
+        }
+        __syncthreads();
+        for (int i = tid; i < 4096; i += 256) {
+            const int cc = i >> 6, rr = i & 63;
+            if (tile[rr][cc]) RT[(c0 + cc) * ldrt + r0 + rr] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// flags[0] |= any(Theta > 0), flags[1] |= any(Theta < 0): the all-zero half of a constraint's +- split
+// (_dfmf.py:203-208) is never multiplied (e.g. a non-positive similarity has Theta+ == 0)
+template <typename T>
+__global__ __launch_bounds__(256) void sign_flags_kernel(const T* __restrict__ src, int64_t ld, int64_t rows,
+                                                         int64_t cols, int* __restrict__ flags) {
+    const int64_t total = rows * cols;
+    bool pos = false, neg = false;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const T v = src[(e / cols) * ld + e % cols];
+        pos = pos || v > (T)0;
+        neg = neg || v < (T)0;
+    }
+    if (pos) flags[0] = 1;          // benign race: every writer stores the same value
+    if (neg) flags[1] = 1;
+}
+
+// bf16 engine: dst = bf16(max(src, 0)) (aop = AOP_POS) or bf16(max(-src, 0)) (AOP_NEG); dst is pre-zeroed
+__global__ __launch_bounds__(256) void split_to_bf16_kernel(uint16_t* __restrict__ dst, int64_t ldd,
+                                                            const float* __restrict__ src, int64_t lds,
+                                                            int64_t rows, int64_t cols, int aop) {
     const int64_t total = rows * cols;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / cols, c = e % cols;
-        if (mask[r * ldm + c]) RT[c * ldrt + r] = 0;
+        dst[r * ldd + c] = f32_to_bf16_rne(apply_aop(src[r * lds + c], aop));
     }
+}
+
+// dst += src  (n x c, both row-major with leading dimension c)
+__global__ __launch_bounds__(256) void add_into_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                       int64_t total) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x)
+        dst[e] += src[e];
 }
 
 // ------------------------------------------------------------------------------------------

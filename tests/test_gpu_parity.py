@@ -306,6 +306,11 @@ def test_row_block_sharding_c3_scaled_c5_and_probe():
             assert relerr(S[i, j][0], z5['dfmc/S_%s_%s_0_it29' % (i, j)]) < 1e-9
 
 
+def test_bf16_completion_kernel(monkeypatch):
+    import test_emul_engine as E
+    E.test_bf16_completion_kernel_against_f32_product(monkeypatch)
+
+
 def test_bf16_engine_c1_and_c3_scaled():
     """SKF_BF16 engine: bf16 relation contractions.  Tolerances: reconstruction
     error within 1e-2 relative of the f64 oracle on the same (bf16-rounded) relations."""
