@@ -1,0 +1,72 @@
+"""Host-side pieces of bench.py and of the sharding tables (no GPU, no library): the algorithmic
+work of BASELINE config 3, the HBM view, and the partitioners' invariants."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                                   # noqa: E402
+import skfusion_amd                                            # noqa: E402,F401
+from skfusion_amd._distributed import partition_rows, partition_relations   # noqa: E402
+
+
+def test_algorithmic_work_of_config_3_and_5():
+    assert bench.alg_flops(bench.FULL) == pytest.approx(9.472e12, rel=1e-12)
+    n = bench.sizes(0.1)
+    assert n == {'t1': 5000, 't2': 10000, 't3': 4000}
+    assert bench.alg_flops(n) / bench.alg_flops(bench.FULL) == pytest.approx(0.01)
+    v = bench.hbm_view('bf16', bench.FULL, 12.0, 6)          # one iteration = 6 launches, 12 ms
+    assert v['algorithmic_bytes_per_launch'] * 6 == pytest.approx(2 * 1.1e10 * 2)  # every R twice, 2 B
+    assert v['achieved'] == pytest.approx(44e9 / 12e-3 / 1e12)
+    spec = [(i, j, d is None) for i, j, _, d in bench.C5_PAIRS]
+    n5 = bench.sizes(1.0, bench.C5_FULL)
+    base = sum(2.0 * n5[i] * n5[j] * (bench.C5_RANKS[i] + bench.C5_RANKS[j]) for i, j, _ in spec)
+    extra = 2.0 * n5['user'] * n5['movie'] * min(bench.C5_RANKS['user'], bench.C5_RANKS['movie'])
+    assert bench.alg_flops(n5, spec, bench.C5_RANKS) == pytest.approx(base + extra)
+
+
+@pytest.mark.parametrize('size', [1, 2, 3, 4, 5, 8, 16])
+@pytest.mark.parametrize('graph', ['c3', 'c5', 'tiny'])
+def test_row_partition_covers_every_row_once_and_balances(size, graph):
+    if graph == 'c3':
+        n, c, align = bench.FULL, bench.RANKS, 256
+        rel = [(i, j, None, None) for i, j, _ in bench.PAIRS]
+    elif graph == 'c5':
+        n, c, align = bench.C5_FULL, bench.C5_RANKS, 256
+        rel = [(i, j, None, None) for i, j, _, _ in bench.C5_PAIRS]
+    else:
+        n, c, align = {'a': 12, 'b': 9, 'c': 7}, {'a': 4, 'b': 3, 'c': 2}, 1
+        rel = [('a', 'b', None, None), ('a', 'c', None, None), ('b', 'c', None, None)]
+    thetas = [(rel[0][0], None)]
+    blocks, th_owner = partition_rows(rel, thetas, n, c, align=align, size=size)
+    load = np.zeros(size)
+    for (i, j, _, _), blk in zip(rel, blocks):
+        pos, seen = 0, set()
+        for q, a, cnt in blk:
+            assert a == pos and cnt > 0 and 0 <= q < size      # contiguous, in row order
+            assert q not in seen                                 # at most one block per rank and relation
+            seen.add(q)
+            assert a % align == 0
+            pos += cnt
+            load[q] += cnt * n[j] * (c[i] + c[j])
+        assert pos == n[i]                                       # every row exactly once
+        assert blk[0][1] == 0                                    # the first block owns the column side
+    assert 0 <= th_owner[0] < size
+    if graph != 'tiny' and size <= 8:
+        assert load.max() <= 1.08 * load.sum() / size           # config 3 on 8 GPUs: 1.033
+
+
+def test_relation_partition_is_deterministic_and_complete():
+    rel = [(i, j, None, None) for i, j, _ in bench.PAIRS]
+    import skfusion_amd._distributed as D
+    saved = D.world
+    try:
+        D.world = lambda: (0, 2)
+        a = partition_relations(rel, [('t1', None)], bench.FULL, bench.RANKS)
+        b = partition_relations(rel, [('t1', None)], bench.FULL, bench.RANKS)
+    finally:
+        D.world = saved
+    assert a == b and sorted(set(a[0])) == [0, 1] and len(a[0]) == 3
