@@ -151,6 +151,10 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['f32', 'f64', 'bf16'])
     ap.add_argument('--scale', type=float, default=1.0, help='linear scale of the object counts')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--data', default='uniform', choices=['uniform', 'planted'],
+                    help='c3 only. uniform (default): iid U[0,1) entries as in the reference README (RMSE floor '
+                         'sqrt(1/12) at any modest rank); planted: R_ij = G*_i S*_ij G*_j^T / mean + 0.01 U, on which '
+                         'the RMSE discriminates (SURVEY.md 8d)')
     ap.add_argument('--workload', default='c3', choices=['c3', 'c5'],
                     help='c3 (default): BASELINE configs[2], the metric\'s workload; c5: BASELINE configs[4], '
                          'Dfmc on the MovieLens-style 6-relation graph with masks and constraints')
@@ -201,9 +205,30 @@ def main():
         full_thetas = []
         spec = [(i, j, False) for i, j, _ in PAIRS]
 
+        planted = {}
+
         def make(k):                   # same values whatever the sharding (counter-based generator)
             i, j, seed = PAIRS[k]
-            return fill_uniform((n[i], n[j]), seed, args.dtype), None
+            if args.data == 'uniform':
+                return fill_uniform((n[i], n[j]), seed, args.dtype), None
+            # planted low-rank structure + 1 % noise (torch as the random source / data plumbing only)
+            from skfusion_amd._engine import device_matrix_from_tensor as wrap
+            gen = torch.Generator(device='cuda')
+            for q, t in enumerate(types):
+                if t not in planted:
+                    gen.manual_seed(200 + q)
+                    planted[t] = torch.rand((n[t], ranks_[t]), generator=gen, device='cuda')
+            gen.manual_seed(300 + seed)
+            S = torch.rand((ranks_[i], ranks_[j]), generator=gen, device='cuda')
+            Rm = (planted[i] @ S) @ planted[j].t()
+            Rm.div_(Rm.mean())
+            for r0 in range(0, n[i], 8192):          # noise in row chunks (no second full-size temporary)
+                blk = Rm[r0:r0 + 8192]
+                blk.add_(torch.rand(blk.shape, generator=gen, device='cuda'), alpha=0.01)
+            tdt = {'bf16': torch.bfloat16, 'f32': torch.float32, 'f64': torch.float64}[args.dtype]
+            out = wrap(Rm.to(tdt).contiguous())
+            torch.cuda.synchronize()
+            return out, None
     part_rel = [(i, j, None, None) for i, j, _ in spec]
     part_th = [(t, None) for t, _ in full_thetas]
     local_index = list(range(len(spec)))            # global index of every relation of this plan
@@ -303,7 +328,7 @@ def main():
             'scaling': 'strong' if sharded else 'weak',
             'vs_baseline': None,
             'dtype': args.dtype,
-            'data': 'synthetic',
+            'data': 'synthetic' if (c5 or args.data == 'uniform') else 'synthetic-planted (rank-structured + 1% noise; RMSE floor 0.0029)',
             'config': {'workload': ('BASELINE configs[4]: Dfmc, MovieLens-style graph %s, ranks %s, ratings 98%% masked, '
                                     'Theta_movie = [lambda*I, sparse negative similarity], %s'
                                     % (' / '.join('%s %d' % (t, n[t]) for t in types),

@@ -149,7 +149,25 @@ static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, 
         else
             SKF_FAIL(SKF_E_INVALID, "deep tile is f64 only");
     } else if (big && relation) {
-        hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 1>), grid, block, 0, st, g);
+        // f32 relation contractions P = R G_j (A along K, B along its rows) and Q = R^T G_i (both along
+        // their rows) with 16-byte aligned operands: kernels with compile-time staging modes
+        bool fixed = false;
+        if constexpr (std::is_same<T, float>::value && std::is_same<TA, float>::value && std::is_same<TB, float>::value) {
+            auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+            const bool b_rows = g.sb_n == 1 && g.sb_k % 4 == 0 && g.N % 4 == 0 && al(g.B);
+            const bool k_ok = g.K % 4 == 0 && g.k_chunk % 4 == 0;
+            if (b_rows && al(g.A) && g.sa_k == 1 && g.sa_m % 4 == 0 && k_ok) {
+                hipLaunchKernelGGL((gemm_mfma_kernel<float, float, float, 2, 2, 32, 1, STAGE_VEC_K | (STAGE_VEC_R << 2)>),
+                                   grid, block, 0, st, g);
+                fixed = true;
+            } else if (b_rows && al(g.A) && g.sa_m == 1 && g.sa_k % 4 == 0 && g.M % 4 == 0) {
+                hipLaunchKernelGGL((gemm_mfma_kernel<float, float, float, 2, 2, 32, 1, STAGE_VEC_R | (STAGE_VEC_R << 2)>),
+                                   grid, block, 0, st, g);
+                fixed = true;
+            }
+        }
+        if (!fixed)
+            hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 1>), grid, block, 0, st, g);
     } else if (big) {
         hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 0>), grid, block, 0, st, g);
     } else {
@@ -710,7 +728,21 @@ static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const v
     } else {
         if (big) {
             dim3 grid(cdiv(t.c, 128), cdiv(n, 128));
-            hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16>), grid, block, 0, st, a);
+            // the two operand layouts of the iteration with everything 16-byte aligned get kernels whose
+            // staging modes are compile-time constants (SKF_SIDE_FM); anything else the generic one
+            auto al = [](const void* q) { return q == nullptr || (((uintptr_t)q) & 15) == 0; };
+            const bool vec = al(X) && al(Sop) && al(G) && al(Bn) && al(Bp) && t.c % 4 == 0 && k1 % 4 == 0 &&
+                             ldx % 4 == 0 && (k1 == 0 || (ss_k == 1 ? ss_n % 4 == 0 : (ss_n == 1 && ss_k % 4 == 0)));
+            if (vec && (k1 == 0 || ss_k == 1))
+                hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16, SKF_SIDE_FM(STAGE_VEC_K, STAGE_VEC_K,
+                                                                                           STAGE_VEC_K, STAGE_VEC_R)>),
+                                   grid, block, 0, st, a);
+            else if (vec)
+                hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16, SKF_SIDE_FM(STAGE_VEC_K, STAGE_VEC_R,
+                                                                                           STAGE_VEC_K, STAGE_VEC_R)>),
+                                   grid, block, 0, st, a);
+            else
+                hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16>), grid, block, 0, st, a);
         } else {
             dim3 grid(cdiv(t.c, 64), cdiv(n, 64));
             hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 16>), grid, block, 0, st, a);

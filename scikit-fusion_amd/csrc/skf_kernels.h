@@ -301,7 +301,8 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS *
 // engine; an f64 backbone feeding an f32 contraction is narrowed the same way).
 // (f32: at least 2 waves per SIMD, i.e. <= 256 registers per lane -- left alone the compiler
 // spreads the unrolled staging code over 277 registers and halves the occupancy)
-template <typename T, typename TA, typename TB, int WR, int WC, int BK, int TAG>
+// FM >= 0: compile-time staging modes (bits 0-1 operand A, 2-3 operand B), conditions checked by the host.
+template <typename T, typename TA, typename TB, int WR, int WC, int BK, int TAG, int FM = -1>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) {
     typedef Mfma<T> MF;
     constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
@@ -330,8 +331,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
     TA ra[BM * BK / GEMM_THREADS];
     TB rb[BN * BK / GEMM_THREADS];
     const int nkt = (kz1 - kz0 + BK - 1) / BK;
-    const int ma = stage_mode<TA>(A, g.sa_m, g.sa_k, g.M, kz0, kz1);
-    const int mb = stage_mode<TB>(B, g.sb_n, g.sb_k, g.N, kz0, kz1);
+    const int ma = FM >= 0 ? (FM & 3) : stage_mode<TA>(A, g.sa_m, g.sa_k, g.M, kz0, kz1);
+    const int mb = FM >= 0 ? ((FM >> 2) & 3) : stage_mode<TB>(B, g.sb_n, g.sb_k, g.N, kz0, kz1);
     if (nkt > 0) {
         stage_load<TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, kz0, g.M, kz1, tid, ma);
         stage_load<TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, kz0, g.N, kz1, tid, mb);
@@ -430,7 +431,11 @@ struct SideArgs {
     int phase2;         // 0: only the (X Sop) split terms; 1: also + G Bn / + G Bp   (k1 = 0: only those)
 };
 
-template <typename T, typename TB, int WR, int WC, int BK>
+// FM >= 0: the staging modes are compile-time constants (bits 0-1 X, 2-3 Sop, 4-5 G, 6-7 Bn/Bp; the
+// host checked the alignment conditions of stage_mode): one staging path per operand instead of
+// three keeps the hoisted address arithmetic out of the register budget.  FM = -1: run-time modes.
+#define SKF_SIDE_FM(mx, ms, mg, mb) ((mx) | ((ms) << 2) | ((mg) << 4) | ((mb) << 6))
+template <typename T, typename TB, int WR, int WC, int BK, int FM = -1>
 __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_update_kernel(SideArgs a) {
     typedef Mfma<T> MF;
     constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
@@ -460,8 +465,8 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
         const T* X = (const T*)a.X;
         const TB* S = (const TB*)a.Sop;
         const bool s_kfast = (a.ss_k == 1);
-        const int mx = stage_mode<T>(X, a.ldx, 1, a.n, 0, a.k1);
-        const int ms = stage_mode<TB>(S, a.ss_n, a.ss_k, a.c, 0, a.k1);
+        const int mx = FM >= 0 ? (FM & 3) : stage_mode<T>(X, a.ldx, 1, a.n, 0, a.k1);
+        const int ms = FM >= 0 ? ((FM >> 2) & 3) : stage_mode<TB>(S, a.ss_n, a.ss_k, a.c, 0, a.k1);
         // register prefetch of the next K tile while the current one feeds the matrix cores
         if (a.k1 > 0) {
             stage_load<T, BM, BK>(ra, X, a.ldx, 1, bm0, 0, a.n, a.k1, tid, mx);
@@ -508,9 +513,9 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
         const T* G = (const T*)a.G;
         const TB* Bn = (const TB*)a.Bn;
         const TB* Bp = (const TB*)a.Bp;
-        const int mg = stage_mode<T>(G, a.ldg, 1, a.n, 0, a.c);
-        const int mbn = stage_mode<TB>(Bn, 1, a.ldb, a.c, 0, a.c);
-        const int mbp = stage_mode<TB>(Bp, 1, a.ldb, a.c, 0, a.c);
+        const int mg = FM >= 0 ? ((FM >> 4) & 3) : stage_mode<T>(G, a.ldg, 1, a.n, 0, a.c);
+        const int mbn = FM >= 0 ? ((FM >> 6) & 3) : stage_mode<TB>(Bn, 1, a.ldb, a.c, 0, a.c);
+        const int mbp = FM >= 0 ? ((FM >> 6) & 3) : stage_mode<TB>(Bp, 1, a.ldb, a.c, 0, a.c);
         stage_load<T, BM, BK>(ra, G, a.ldg, 1, bm0, 0, a.n, a.c, tid, mg);
         stage_load<TB, BN, BK>(rb, Bn, 1, a.ldb, bn0, 0, a.c, a.c, tid, mbn);
         stage_load<TB, BN, BK>(rb2, Bp, 1, a.ldb, bn0, 0, a.c, a.c, tid, mbp);

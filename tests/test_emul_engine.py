@@ -319,6 +319,27 @@ def test_bf16_completion_kernel_against_f32_product(monkeypatch):
     assert abs(e - eo) < 2e-2 * eo
 
 
+def test_fixed_staging_mode_kernels_f32_and_bf16():
+    """Ranks above 64 and multiples of 4 with 16-byte aligned operands select the kernels whose staging
+    modes are compile-time constants (f32 relation contractions P / Q, both layouts of the fused side
+    update): f32 and bf16 engines against the oracle, object counts that leave row / K tails."""
+    rs = np.random.RandomState(21)
+    types, n, rank = ['a', 'b'], {'a': 132, 'b': 148}, {'a': 68, 'b': 72}
+    R = {('a', 'b'): [rs.rand(132, 148)]}
+    G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.1 for t in types}
+    Go, So = orc.dfmf(R, {}, types, rank, max_iter=2, G0=G0)
+    G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=2, G0=G0, dtype='f32')
+    for t in types:
+        assert relerr(G[t, t], Go[t, t]) < 1e-4
+    e, eo = orc.relation_errors(R, G, S), orc.relation_errors(R, Go, So)
+    assert abs(e['a', 'b'][0] - eo['a', 'b'][0]) < 1e-5 * eo['a', 'b'][0]
+    Rb = {k: [nat.from_bf16_bits(nat.to_bf16_bits(v[0])).astype(np.float64)] for k, v in R.items()}
+    Gob, Sob = orc.dfmf(Rb, {}, types, rank, max_iter=2, G0=G0)
+    Gb, Sb = _dfmf.dfmf(R, {}, types, rank, max_iter=2, G0=G0, dtype='bf16')
+    for t in types:
+        assert relerr(Gb[t, t], Gob[t, t]) < 2e-2
+
+
 def test_relation_sqerr_and_stopping_path():
     R, types, rank = readme_graph()
     z = golden('c1_readme_dfmf.npz')
