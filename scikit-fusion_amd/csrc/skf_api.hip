@@ -169,7 +169,21 @@ static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, 
         if (!fixed)
             hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 1>), grid, block, 0, st, g);
     } else if (big) {
-        hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 0>), grid, block, 0, st, g);
+        // Gram = G^T G and W = G_i^T P of the f32 / bf16 engines (f32 operands read along their rows,
+        // f64 arithmetic): compile-time staging modes when everything is 16-byte aligned
+        bool fixed = false;
+        if constexpr (std::is_same<T, double>::value && std::is_same<TA, float>::value && std::is_same<TB, float>::value) {
+            auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+            if (al(g.A) && al(g.B) && g.sa_m == 1 && g.sb_n == 1 && g.sa_k % 4 == 0 && g.sb_k % 4 == 0 &&
+                g.M % 4 == 0 && g.N % 4 == 0) {
+                hipLaunchKernelGGL((gemm_mfma_kernel<double, float, float, WRB, WCB, Tiles<double>::BK, 0,
+                                                     STAGE_VEC_R | (STAGE_VEC_R << 2)>),
+                                   grid, block, 0, st, g);
+                fixed = true;
+            }
+        }
+        if (!fixed)
+            hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 0>), grid, block, 0, st, g);
     } else {
         hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, 1, 1, Tiles<T>::BK, 0>), grid, block, 0, st, g);
     }
