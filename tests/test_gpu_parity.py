@@ -306,6 +306,20 @@ def test_row_block_sharding_c3_scaled_c5_and_probe():
             assert relerr(S[i, j][0], z5['dfmc/S_%s_%s_0_it29' % (i, j)]) < 1e-9
 
 
+def test_graph_replay_matches_golden(monkeypatch):
+    """SKF_GRAPH=1: iterations 2..n of skf_iterate replay one captured hipGraph (opt-in; a capture
+    failure falls back to eager launches): same iterates as the golden either way."""
+    monkeypatch.setenv('SKF_GRAPH', '1')
+    z = golden('probe_multirel.npz')
+    R, Theta, M, types, rank = probe_graph(z)
+    G, S = _dfmf.dfmf(R, Theta, types, rank, max_iter=30, G0=g0_from(z, 'dfmf/', types))
+    for t in types:
+        assert relerr(G[t, t], z['dfmf/G_%s_it29' % t]) < 1e-9
+    Gc, Sc = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=30, G0=g0_from(z, 'dfmc/', types), dtype='bf16')
+    for t in types:
+        assert np.isfinite(Gc[t, t]).all()
+
+
 def test_bf16_completion_kernel(monkeypatch):
     import test_emul_engine as E
     E.test_bf16_completion_kernel_against_f32_product(monkeypatch)
