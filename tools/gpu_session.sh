@@ -63,7 +63,7 @@ case "$step" in
     echo "pmc fetch exit $?" | tee -a "$OUT/summary.txt"
     ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE -d "$OLDPWD/$OUT/pmc_write_$dt" -o pmc -- python "$OLDPWD/bench.py" --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline ) > "$OUT/pmc_write_$dt.log" 2>&1
     echo "pmc write exit $?" | tee -a "$OUT/summary.txt"
-    python tools/pmc_summary.py "$OUT/pmc_fetch_$dt" "$OUT/pmc_write_$dt" 2>&1 | tee -a "$OUT/summary.txt"
+    python tools/pmc_summary.py "$OUT/pmc_fetch_$dt/pmc_results.db" "$OUT/pmc_write_$dt/pmc_results.db" 2>&1 | tee -a "$OUT/summary.txt"
     find "$OUT" -name '*counter_collection.csv' -size +20M -delete ;;
 esac
 done
