@@ -729,7 +729,7 @@ static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const v
     a.accumulate = accumulate ? 1 : 0;
     a.nan_to_num = nan;
     a.phase2 = phase2 ? 1 : 0;
-    const bool big = (n > 64 && t.c > 64);
+    bool big = (n > 64 && t.c > 64);
     dim3 block(GEMM_THREADS);
     if (p->f64) {
         if (big) {
@@ -740,26 +740,39 @@ static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const v
             hipLaunchKernelGGL((side_update_kernel<double, double, 1, 1, 16>), grid, block, 0, st, a);
         }
     } else {
+        // 128 x 128 tiles run 2 workgroups per CU, 64 x 64 tiles 6: take the shape whose last round of
+        // workgroups is fuller (the small tile re-reads its operands twice as often: it has to win by 10 %)
+        static const int force = [] { const char* e = getenv("SKF_SIDE_TILE"); return e ? atoi(e) : 0; }();
+        if (big) {
+            auto eff = [](int64_t wgs, int64_t slots) { return (double)wgs / (double)((wgs + slots - 1) / slots * slots); };
+            const double e_big = eff((int64_t)cdiv(t.c, 128) * cdiv(n, 128), 512);
+            const double e_small = eff((int64_t)cdiv(t.c, 64) * cdiv(n, 64), 1536);
+            if (force == 64 || (force == 0 && e_small > 1.10 * e_big)) big = false;
+        }
+        // the two operand layouts of the iteration with everything 16-byte aligned get kernels whose
+        // staging modes are compile-time constants (SKF_SIDE_FM); anything else the generic one
+        auto al = [](const void* q) { return q == nullptr || (((uintptr_t)q) & 15) == 0; };
+        const bool vec = al(X) && al(Sop) && al(G) && al(Bn) && al(Bp) && t.c % 4 == 0 && k1 % 4 == 0 &&
+                         ldx % 4 == 0 && (k1 == 0 || (ss_k == 1 ? ss_n % 4 == 0 : (ss_n == 1 && ss_k % 4 == 0)));
+        const bool k_major = (k1 == 0 || ss_k == 1);
+        constexpr int FM_K = SKF_SIDE_FM(STAGE_VEC_K, STAGE_VEC_K, STAGE_VEC_K, STAGE_VEC_R);
+        constexpr int FM_R = SKF_SIDE_FM(STAGE_VEC_K, STAGE_VEC_R, STAGE_VEC_K, STAGE_VEC_R);
         if (big) {
             dim3 grid(cdiv(t.c, 128), cdiv(n, 128));
-            // the two operand layouts of the iteration with everything 16-byte aligned get kernels whose
-            // staging modes are compile-time constants (SKF_SIDE_FM); anything else the generic one
-            auto al = [](const void* q) { return q == nullptr || (((uintptr_t)q) & 15) == 0; };
-            const bool vec = al(X) && al(Sop) && al(G) && al(Bn) && al(Bp) && t.c % 4 == 0 && k1 % 4 == 0 &&
-                             ldx % 4 == 0 && (k1 == 0 || (ss_k == 1 ? ss_n % 4 == 0 : (ss_n == 1 && ss_k % 4 == 0)));
-            if (vec && (k1 == 0 || ss_k == 1))
-                hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16, SKF_SIDE_FM(STAGE_VEC_K, STAGE_VEC_K,
-                                                                                           STAGE_VEC_K, STAGE_VEC_R)>),
-                                   grid, block, 0, st, a);
+            if (vec && k_major)
+                hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16, FM_K>), grid, block, 0, st, a);
             else if (vec)
-                hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16, SKF_SIDE_FM(STAGE_VEC_K, STAGE_VEC_R,
-                                                                                           STAGE_VEC_K, STAGE_VEC_R)>),
-                                   grid, block, 0, st, a);
+                hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16, FM_R>), grid, block, 0, st, a);
             else
                 hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16>), grid, block, 0, st, a);
         } else {
             dim3 grid(cdiv(t.c, 64), cdiv(n, 64));
-            hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 16>), grid, block, 0, st, a);
+            if (vec && k_major && n > 64 && t.c >= 64)
+                hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 16, FM_K>), grid, block, 0, st, a);
+            else if (vec && n > 64 && t.c >= 64)
+                hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 16, FM_R>), grid, block, 0, st, a);
+            else
+                hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 16>), grid, block, 0, st, a);
         }
     }
     check_launch("side_update");
