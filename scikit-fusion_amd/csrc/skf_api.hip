@@ -740,21 +740,19 @@ static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const v
             hipLaunchKernelGGL((side_update_kernel<double, double, 1, 1, 16>), grid, block, 0, st, a);
         }
     } else {
-        // 128 x 128 tiles run 2 workgroups per CU, 64 x 64 tiles 6: take the shape whose last round of
-        // workgroups is fuller (the small tile re-reads its operands twice as often: it has to win by 10 %)
-        static const int force = [] { const char* e = getenv("SKF_SIDE_TILE"); return e ? atoi(e) : 0; }();
-        if (big) {
-            auto eff = [](int64_t wgs, int64_t slots) { return (double)wgs / (double)((wgs + slots - 1) / slots * slots); };
-            const double e_big = eff((int64_t)cdiv(t.c, 128) * cdiv(n, 128), 512);
-            const double e_small = eff((int64_t)cdiv(t.c, 64) * cdiv(n, 64), 1536);
-            if (force == 64 || (force == 0 && e_small > 1.10 * e_big)) big = false;
-        }
+        const char* fe = getenv("SKF_SIDE_TILE");           // 64 / 128 force a tile shape (A/B runs, tests)
+        const int force = fe ? atoi(fe) : 0;
+        const char* be = getenv("SKF_SIDE_BK");             // 32: deeper K tile for the 64 x 64 kernels
+        const bool bk32 = be && atoi(be) == 32;
         // the two operand layouts of the iteration with everything 16-byte aligned get kernels whose
         // staging modes are compile-time constants (SKF_SIDE_FM); anything else the generic one
         auto al = [](const void* q) { return q == nullptr || (((uintptr_t)q) & 15) == 0; };
         const bool vec = al(X) && al(Sop) && al(G) && al(Bn) && al(Bp) && t.c % 4 == 0 && k1 % 4 == 0 &&
                          ldx % 4 == 0 && (k1 == 0 || (ss_k == 1 ? ss_n % 4 == 0 : (ss_n == 1 && ss_k % 4 == 0)));
         const bool k_major = (k1 == 0 || ss_k == 1);
+        // measured at config 3 (rocprof, all six launches): the 64 x 64 fixed-mode kernels (78 VGPRs, 6
+        // workgroups per CU) beat the 128 x 128 ones (182 VGPRs, 2 per CU): 0.98 vs 1.30 ms per iteration
+        if (big && force != 128 && (vec || force == 64)) big = false;
         constexpr int FM_K = SKF_SIDE_FM(STAGE_VEC_K, STAGE_VEC_K, STAGE_VEC_K, STAGE_VEC_R);
         constexpr int FM_R = SKF_SIDE_FM(STAGE_VEC_K, STAGE_VEC_R, STAGE_VEC_K, STAGE_VEC_R);
         if (big) {
@@ -767,7 +765,11 @@ static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const v
                 hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16>), grid, block, 0, st, a);
         } else {
             dim3 grid(cdiv(t.c, 64), cdiv(n, 64));
-            if (vec && k_major && n > 64 && t.c >= 64)
+            if (vec && k_major && n > 64 && t.c >= 64 && bk32)
+                hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 32, FM_K>), grid, block, 0, st, a);
+            else if (vec && n > 64 && t.c >= 64 && bk32)
+                hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 32, FM_R>), grid, block, 0, st, a);
+            else if (vec && k_major && n > 64 && t.c >= 64)
                 hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 16, FM_K>), grid, block, 0, st, a);
             else if (vec && n > 64 && t.c >= 64)
                 hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 16, FM_R>), grid, block, 0, st, a);

@@ -319,10 +319,14 @@ def test_bf16_completion_kernel_against_f32_product(monkeypatch):
     assert abs(e - eo) < 2e-2 * eo
 
 
-def test_fixed_staging_mode_kernels_f32_and_bf16():
-    """Ranks above 64 and multiples of 4 with 16-byte aligned operands select the kernels whose staging
+@pytest.mark.parametrize('tile', ['', '128'])
+def test_fixed_staging_mode_kernels_f32_and_bf16(monkeypatch, tile):
+    """(SKF_SIDE_TILE=128 keeps the 128 x 128 side-update kernels under test; default is 64 x 64.)
+    Ranks above 64 and multiples of 4 with 16-byte aligned operands select the kernels whose staging
     modes are compile-time constants (f32 relation contractions P / Q, both layouts of the fused side
     update): f32 and bf16 engines against the oracle, object counts that leave row / K tails."""
+    if tile:
+        monkeypatch.setenv('SKF_SIDE_TILE', tile)
     rs = np.random.RandomState(21)
     types, n, rank = ['a', 'b'], {'a': 132, 'b': 148}, {'a': 68, 'b': 72}
     R = {('a', 'b'): [rs.rand(132, 148)]}

@@ -58,8 +58,8 @@ case "$step" in
     find "$OUT/prof_$dt" -name '*kernel_trace.csv' -size +20M -delete ;;
   sidetile)
     # A/B of the side-update tile shape: rocprof kernel stats with 64 x 64 tiles forced
-    echo "== rocprofv3 kernel-trace bf16, SKF_SIDE_TILE=64" | tee -a "$OUT/summary.txt"
-    ( cd /tmp && SKF_SIDE_TILE=64 timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_side64" -o prof -- python "$OLDPWD/bench.py" --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline ) > "$OUT/prof_side64.log" 2>&1
+    echo "== rocprofv3 kernel-trace bf16, SKF_SIDE_BK=32" | tee -a "$OUT/summary.txt"
+    ( cd /tmp && SKF_SIDE_BK=32 timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_side64" -o prof -- python "$OLDPWD/bench.py" --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline ) > "$OUT/prof_side64.log" 2>&1
     echo "rocprof exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/prof_side64.log" | cut -c1-300 | tee -a "$OUT/summary.txt"
     find "$OUT/prof_side64" -name '*kernel_trace.csv' -size +20M -delete ;;
   pmc_*)
