@@ -59,6 +59,32 @@ def _all_reduce_sum(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
+def _exchange(mem, tensors, reduce=None):
+    """All-reduce(sum) the given workspace views between two stages of a sharded iteration.
+    RCCL: issued on the engine's own stream (stream order replaces host synchronisation).  gloo
+    (CPU tests, single-GPU smoke runs) or a caller-supplied `reduce`: bracketed by device syncs."""
+    import os
+    tensors = [t for t in tensors if t is not None]
+    if not tensors:
+        return
+    if reduce is None:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size() <= 1 and not os.environ.get('SKF_FORCE_COLLECTIVES'):
+            return
+        if tensors[0].is_cuda and dist.get_backend() != 'gloo' and hasattr(mem, 'stream_scope'):
+            with mem.stream_scope():
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return
+        reduce = _all_reduce_sum
+    mem.synchronize()
+    for t in tensors:
+        reduce(t)
+    mem.synchronize()
+
+
 class DevicePlan(object):
     """One (run, device) plan: relations + constraints uploaded, workspace bound."""
 
@@ -218,9 +244,7 @@ class DevicePlan(object):
         acc = self.rt.mem.as_tensor(self.ws, off.value, nbytes.value, self.np_dtype)
         for _ in range(int(n_iters)):
             self.rt.call('skf_accumulate', self.handle, self.rt.mem.stream)
-            self.rt.mem.synchronize()              # the collective runs on torch's own stream
-            _all_reduce_sum(acc)
-            self.rt.mem.synchronize()
+            _exchange(self.rt.mem, [acc])
             self.rt.call('skf_apply_update', self.handle, self.rt.mem.stream)
 
     def _exchange_views(self):
@@ -241,17 +265,11 @@ class DevicePlan(object):
         block): four stages with an all-reduce(sum) of W and Q, of the masked relations' Q (DFMC),
         and of E / D between them -- include/skfusion_hip.h `skf_stage`.  `reduce(tensor)` defaults
         to torch.distributed.all_reduce (RCCL on GPUs, gloo in the CPU tests)."""
-        if reduce is None:
-            reduce = _all_reduce_sum
         xw, xq, xqm, xed = self._exchange_views()
         mem, call, h = self.rt.mem, self.rt.call, self.handle
 
         def exchange(*tensors):
-            mem.synchronize()                      # the collective runs on torch's own stream
-            for t in tensors:
-                if t is not None:
-                    reduce(t)
-            mem.synchronize()
+            _exchange(mem, tensors, reduce)
         for _ in range(int(n_iters)):
             call('skf_stage', h, nat.SKF_STAGE_CONTRACT, mem.stream)
             exchange(xw, xq)

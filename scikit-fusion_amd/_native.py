@@ -177,6 +177,12 @@ class TorchDeviceMemory(object):
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
 
+    def stream_scope(self):
+        """Context in which torch (RCCL collectives) works on the engine's stream: a collective issued
+        inside is ordered after the engine's kernels and before the ones launched next -- no host
+        synchronisation on the data path."""
+        return self.torch.cuda.stream(self._stream)
+
     def as_tensor(self, buf, offset, nbytes, np_dtype):
         """Zero-copy torch view of a byte range of a device buffer (for RCCL collectives)."""
         tdt = {np.dtype(np.float32): self.torch.float32, np.dtype(np.float64): self.torch.float64}[np.dtype(np_dtype)]

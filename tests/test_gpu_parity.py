@@ -306,6 +306,38 @@ def test_row_block_sharding_c3_scaled_c5_and_probe():
             assert relerr(S[i, j][0], z5['dfmc/S_%s_%s_0_it29' % (i, j)]) < 1e-9
 
 
+def test_rccl_stream_ordered_exchanges_single_rank(monkeypatch):
+    """The RCCL path of the sharded iterations (collectives issued on the engine's stream, no host
+    synchronisation between the stages) with a one-rank nccl group on this box's GPU: the all-reduces
+    are identities, the iterates must equal the golden.  (Real multi-rank runs: gloo tests on CPU,
+    the driver's multi-GPU bench.)"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    try:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                                device_id=torch.device('cuda', torch.cuda.current_device()))
+    except Exception as exc:                                  # pragma: no cover
+        pytest.skip('no one-rank RCCL group on this box: %r' % (exc,))
+    try:
+        monkeypatch.setenv('SKF_FORCE_COLLECTIVES', '1')
+        z = golden('probe_multirel.npz')
+        R, Theta, M, types, rank = probe_graph(z)
+        for shard in ('relations', 'rows'):
+            G, S = _dfmf.dfmf(R, Theta, types, rank, max_iter=10, G0=g0_from(z, 'dfmf/', types), shard=shard)
+            for t in types:
+                assert relerr(G[t, t], z['dfmf/G_%s_it9' % t]) < 1e-9
+            Gc, Sc = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=10, G0=g0_from(z, 'dfmc/', types), shard=shard)
+            for t in types:
+                assert relerr(Gc[t, t], z['dfmc/G_%s_it9' % t]) < 1e-9
+    finally:
+        dist.destroy_process_group()
+
+
 def test_graph_replay_matches_golden(monkeypatch):
     """SKF_GRAPH=1: iterations 2..n of skf_iterate replay one captured hipGraph (opt-in; a capture
     failure falls back to eager launches): same iterates as the golden either way."""
