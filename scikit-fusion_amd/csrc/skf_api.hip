@@ -471,6 +471,8 @@ struct skf_plan {
     // row-block sharding: contiguous ranges of all W, of the Q of unmasked / of masked relations
     bool sliced = false;
     size_t xw_off = 0, xw_bytes = 0, xq_off = 0, xq_bytes = 0, xqm_off = 0, xqm_bytes = 0;
+    size_t btot_off = 0, btot_bytes = 0;   // contiguous range of every type's Bp_tot / Bn_tot
+    void* ws_base = nullptr;
     // one captured iteration (hipGraph) for launch-bound graphs; replayed by skf_iterate
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t graph_stream = nullptr;
@@ -586,7 +588,10 @@ static double chol_rel_threshold() {
 // Cholesky fast path: the LDS-blocked kernel up to order CHOLB_MAXN, the plain one beyond
 static void launch_chol(const EighArgs& e, int batch, int max_order, hipStream_t st) {
     const char* f = getenv("SKF_CHOL_UNBLOCKED");
-    if (max_order <= CHOLB_MAXN && !(f && atoi(f) != 0)) {
+    const char* nos = getenv("SKF_CHOL_NO_SMALL");          // "1": skip the one-wave kernel (A/B runs, tests)
+    if (max_order <= CHOLS_MAXN && !(nos && atoi(nos) != 0) && !(f && atoi(f) != 0)) {
+        hipLaunchKernelGGL(chol_inverse_small_kernel, dim3((unsigned)batch), dim3(64), 0, st, e, chol_rel_threshold());
+    } else if (max_order <= CHOLB_MAXN && !(f && atoi(f) != 0)) {
         size_t wave_tiles = (size_t)(EIGH_THREADS / 64) * CHOLB_NB * (CHOLB_NB + 1);
         size_t panel = (size_t)CHOLB_NB * max_order;
         size_t smem = ((size_t)CHOLB_NB * (CHOLB_NB + 1) + (panel > wave_tiles ? panel : wave_tiles)) * sizeof(double);
@@ -609,13 +614,32 @@ static void launch_chol(const EighArgs& e, int batch, int max_order, hipStream_t
 static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st) {
     if (which.empty()) return;
     const int64_t stride = p->eig_stride;
-    for (size_t b = 0; b < which.size(); ++b) {
-        const TypeState& t = p->types[which[b]];
-        double* A = (double*)p->eigA.ptr + (int64_t)b * stride;
-        const int total = t.n_pad * t.n_pad;
-        hipLaunchKernelGGL((eigh_pack_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, A, t.n_pad,
-                           (const double*)t.Gram.ptr, (int64_t)t.c, t.c);
+    const int nb = (int)which.size();
+    const bool batched = nb <= PINV_MAXB;       // one launch for all types (pointers travel as kernel arguments)
+    PinvBatch pb;
+    int max_pad = 2, max_c = 1;
+    if (batched) {
+        for (int b = 0; b < nb; ++b) {
+            const TypeState& t = p->types[which[b]];
+            pb.gram[b] = (const double*)t.Gram.ptr;
+            pb.K[b] = (double*)t.K.ptr;
+            pb.c[b] = t.c;
+            pb.n_pad[b] = t.n_pad;
+            if (t.n_pad > max_pad) max_pad = t.n_pad;
+            if (t.c > max_c) max_c = t.c;
+        }
+        hipLaunchKernelGGL(eigh_pack_batched_kernel, dim3(elem_grid((int64_t)max_pad * max_pad), nb), dim3(256), 0, st, pb,
+                           (double*)p->eigA.ptr, stride);
         check_launch("eigh_pack");
+    } else {
+        for (size_t b = 0; b < which.size(); ++b) {
+            const TypeState& t = p->types[which[b]];
+            double* A = (double*)p->eigA.ptr + (int64_t)b * stride;
+            const int total = t.n_pad * t.n_pad;
+            hipLaunchKernelGGL((eigh_pack_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, A, t.n_pad,
+                               (const double*)t.Gram.ptr, (int64_t)t.c, t.c);
+            check_launch("eigh_pack");
+        }
     }
     EighArgs e;
     e.A = (double*)p->eigA.ptr; e.V = (double*)p->eigV.ptr; e.Vs = (double*)p->eigVs.ptr;
@@ -625,24 +649,36 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
     e.max_sweeps = 30;
     // fast path (Cholesky inverse) with an on-device verdict; the Jacobi eigen-solver only does
     // work for the matrices the fast path rejected -- no host round trip either way
-    launch_chol(e, (int)which.size(), p->eig_maxn, st);
-    for (size_t b = 0; b < which.size(); ++b) {
-        const TypeState& t = p->types[which[b]];
-        const double* X = (const double*)p->eigV.ptr + (int64_t)b * stride;
-        hipLaunchKernelGGL((chol_unpack_kernel<double>), dim3(elem_grid(t.c * t.c)), dim3(256), 0, st,
-                           (double*)t.K.ptr, (int64_t)t.c, X, t.n_pad, t.c, (const int*)p->eigOk.ptr + b);
+    launch_chol(e, nb, p->eig_maxn, st);
+    if (batched) {
+        hipLaunchKernelGGL(chol_unpack_batched_kernel, dim3(elem_grid((int64_t)max_c * max_c), nb), dim3(256), 0, st, pb,
+                           (const double*)p->eigV.ptr, stride, (const int*)p->eigOk.ptr);
         check_launch("chol_unpack");
+    } else {
+        for (size_t b = 0; b < which.size(); ++b) {
+            const TypeState& t = p->types[which[b]];
+            const double* X = (const double*)p->eigV.ptr + (int64_t)b * stride;
+            hipLaunchKernelGGL((chol_unpack_kernel<double>), dim3(elem_grid(t.c * t.c)), dim3(256), 0, st,
+                               (double*)t.K.ptr, (int64_t)t.c, X, t.n_pad, t.c, (const int*)p->eigOk.ptr + b);
+            check_launch("chol_unpack");
+        }
     }
     hipLaunchKernelGGL(jacobi_eigh_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), 0, st, e);
     check_launch("jacobi_eigh");
-    for (size_t b = 0; b < which.size(); ++b) {
-        const TypeState& t = p->types[which[b]];
-        const double* Vs = (const double*)p->eigVs.ptr + (int64_t)b * stride;
-        const double* V = (const double*)p->eigV.ptr + (int64_t)b * stride;
-        const int total = t.c * t.c;
-        hipLaunchKernelGGL((eigh_unpack_pinv_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st,
-                           (double*)t.K.ptr, (int64_t)t.c, Vs, V, t.n_pad, t.c, (const int*)p->eigOk.ptr + b);
+    if (batched) {
+        hipLaunchKernelGGL(eigh_unpack_pinv_batched_kernel, dim3(elem_grid((int64_t)max_c * max_c), nb), dim3(256), 0, st, pb,
+                           (const double*)p->eigVs.ptr, (const double*)p->eigV.ptr, stride, (const int*)p->eigOk.ptr);
         check_launch("eigh_unpack");
+    } else {
+        for (size_t b = 0; b < which.size(); ++b) {
+            const TypeState& t = p->types[which[b]];
+            const double* Vs = (const double*)p->eigVs.ptr + (int64_t)b * stride;
+            const double* V = (const double*)p->eigV.ptr + (int64_t)b * stride;
+            const int total = t.c * t.c;
+            hipLaunchKernelGGL((eigh_unpack_pinv_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st,
+                               (double*)t.K.ptr, (int64_t)t.c, Vs, V, t.n_pad, t.c, (const int*)p->eigOk.ptr + b);
+            check_launch("eigh_unpack");
+        }
     }
 }
 
@@ -937,9 +973,8 @@ static void stage_accumulate(skf_plan* p, hipStream_t st) {
             SKF_HIP(hipMemsetAsync(t.D.ptr, 0, t.D.bytes, st));
             touched[i] = 1;
         }
-        SKF_HIP(hipMemsetAsync(t.Bp_tot.ptr, 0, t.Bp_tot.bytes, st));
-        SKF_HIP(hipMemsetAsync(t.Bn_tot.ptr, 0, t.Bn_tot.bytes, st));
     }
+    SKF_HIP(hipMemsetAsync((char*)p->ws_base + p->btot_off, 0, p->btot_bytes, st));
     // sum_r B_r^+- per type.  A plan with row blocks lists every relation and owns a share of the rows
     // of every type: it sums over all relations; otherwise over the plan's own relations.
     for (RelState& r : p->rels) {
@@ -1283,8 +1318,6 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             want_part(t.c, t.c, (int)t.n, true);
             if (p->variant != SKF_TRANSFORM) {
                 add_slot(p, t.K, (size_t)t.c * t.c * 8);
-                add_slot(p, t.Bp_tot, (size_t)t.c * t.c * 8);
-                add_slot(p, t.Bn_tot, (size_t)t.c * t.c * 8);
                 if (!p->f64) {
                     add_slot(p, t.Bp32, (size_t)t.c * t.c * 4);
                     add_slot(p, t.Bn32, (size_t)t.c * t.c * 4);
@@ -1299,6 +1332,13 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         }
         size_t sq_elems = 1;
         if (p->variant != SKF_TRANSFORM) {
+            // the per-type sums of B+ / B- form one range: one memset per iteration clears them all
+            p->btot_off = p->ws_bytes;
+            for (TypeState& t : p->types) {
+                add_slot(p, t.Bp_tot, (size_t)t.c * t.c * 8);
+                add_slot(p, t.Bn_tot, (size_t)t.c * t.c * 8);
+            }
+            p->btot_bytes = p->ws_bytes - p->btot_off;
             // exchange ranges of row-block sharding: all W; then Q of unmasked, then of masked relations
             p->xw_off = p->ws_bytes;
             for (RelState& r : p->rels) add_slot(p, r.W, (size_t)p->types[r.row].c * p->types[r.col].c * 8);
@@ -1416,6 +1456,7 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
         if (bytes < p->ws_bytes) SKF_FAIL(SKF_E_WORKSPACE, "workspace %zu B < required %zu B", bytes, p->ws_bytes);
         if (((uintptr_t)ws & 255) != 0) SKF_FAIL(SKF_E_WORKSPACE, "workspace must be 256-byte aligned");
         for (Slot* s : p->slots) s->ptr = (char*)ws + s->off;
+        p->ws_base = ws;
         hipStream_t st = as_stream(stream);
         for (RelState& r : p->rels) {
             if (!r.mask || p->bf16) continue;      // bf16: the padded R / R^T copies are the working set
