@@ -901,18 +901,47 @@ static void stage_contract(skf_plan* p, hipStream_t st) {
 }
 
 // Stage 2 (SKF_STAGE_BACKBONE): S = K_i W K_j; DFMC: completion, then P and Q of masked relations.
+// every rank <= SMALLC: the c x c chains run in the one-workgroup kernels (SKF_NO_SMALL_CHAIN=1: off)
+static bool small_chain(const skf_plan* p) {
+    const char* off = getenv("SKF_NO_SMALL_CHAIN");
+    if (off && atoi(off) != 0) return false;
+    for (const TypeState& t : p->types)
+        if (t.c > SMALLC) return false;
+    return true;
+}
+
 static void stage_backbone(skf_plan* p, hipStream_t st) {
     const bool dfmc = (p->variant == SKF_DFMC);
+    const bool chain = small_chain(p);
+    if (chain) {
+        for (size_t k0 = 0; k0 < p->rels.size(); k0 += CHAIN_MAXB) {
+            BackboneBatch bb;
+            int nb = 0;
+            for (size_t k = k0; k < p->rels.size() && nb < CHAIN_MAXB; ++k, ++nb) {
+                RelState& r = p->rels[k];
+                bb.Ki[nb] = (const double*)p->types[r.row].K.ptr;
+                bb.Kj[nb] = (const double*)p->types[r.col].K.ptr;
+                bb.W[nb] = (const double*)r.W.ptr;
+                bb.S[nb] = (double*)r.S.ptr;
+                bb.ci[nb] = p->types[r.row].c;
+                bb.cj[nb] = p->types[r.col].c;
+            }
+            hipLaunchKernelGGL(backbone_small_kernel, dim3(nb), dim3(256), 0, st, bb);
+            check_launch("backbone_small");
+        }
+    }
     for (RelState& r : p->rels) {
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
         const int nr = (int)r.nr, nj = (int)tj.n, ci = ti.c, cj = tj.c;
         GemmArgs g;
-        // T1 = K_i W ; S = T1 K_j
-        g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);
-        small_gemm(p, g, st);
-        g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);
-        small_gemm(p, g, st);
+        if (!chain) {
+            // T1 = K_i W ; S = T1 K_j
+            g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);
+            small_gemm(p, g, st);
+            g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);
+            small_gemm(p, g, st);
+        }
         if (!(dfmc && r.masked)) continue;
         if (!r.absent) {
             // H = G_i[blk] S ; Rw[mask] = (H G_j^T)[mask] ; P = Rw G_j        (_dfmc.py:319-325)
@@ -977,26 +1006,61 @@ static void stage_accumulate(skf_plan* p, hipStream_t st) {
     SKF_HIP(hipMemsetAsync((char*)p->ws_base + p->btot_off, 0, p->btot_bytes, st));
     // sum_r B_r^+- per type.  A plan with row blocks lists every relation and owns a share of the rows
     // of every type: it sums over all relations; otherwise over the plan's own relations.
+    const bool chain = small_chain(p);
     for (RelState& r : p->rels) {
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
+        if (chain) {
+            BTermsArgs ba;
+            ba.S = (const double*)r.S.ptr; ba.Gram_i = (const double*)ti.Gram.ptr; ba.Gram_j = (const double*)tj.Gram.ptr;
+            ba.Bp_i = (double*)ti.Bp_tot.ptr; ba.Bn_i = (double*)ti.Bn_tot.ptr;
+            ba.Bp_j = (double*)tj.Bp_tot.ptr; ba.Bn_j = (double*)tj.Bn_tot.ptr;
+            ba.ci = ti.c; ba.cj = tj.c; ba.nan_to_num = nan_upd;
+            hipLaunchKernelGGL(bterms_small_kernel, dim3(1), dim3(256), 0, st, ba);
+            check_launch("bterms_small");
+            continue;
+        }
         relation_small_terms(p, r, nan_upd, EPI_SPLIT_ACC, ti.Bp_tot.ptr, ti.Bn_tot.ptr, tj.Bp_tot.ptr, tj.Bn_tot.ptr,
                              true, true, st);
     }
-    // c x c operands of the fused side products in the master type
-    auto to_master = [&](const Slot& src, const Slot& dst, int rows, int cols) -> const void* {
-        if (p->f64 || !fused) return src.ptr;
-        hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid((int64_t)rows * cols)), dim3(256), 0, st,
-                           (float*)dst.ptr, (int64_t)cols, (const double*)src.ptr, (int64_t)cols, (int64_t)rows,
-                           (int64_t)cols);
-        check_launch("cast");
-        return dst.ptr;
-    };
-    std::vector<const void*> Bn_m(nt), Bp_m(nt);
-    for (size_t i = 0; i < nt; ++i) {
-        TypeState& t = p->types[i];
-        Bn_m[i] = to_master(t.Bn_tot, t.Bn32, t.c, t.c);
-        Bp_m[i] = to_master(t.Bp_tot, t.Bp32, t.c, t.c);
+    // c x c operands of the fused side products in the master type: the f32 engines round S of every
+    // relation with a side here and sum B+- of every type in ONE batched launch
+    std::vector<const void*> Bn_m(nt), Bp_m(nt), S_m(p->rels.size());
+    {
+        const bool cast = !p->f64 && fused;
+        CastBatch cb;
+        int ne = 0, max_count = 1;
+        bool overflow = false;
+        auto add = [&](const Slot& src, const Slot& dst, int count) -> const void* {
+            if (!cast) return src.ptr;
+            if (ne >= CAST_MAXB) {                   // very large graphs: one launch per matrix
+                overflow = true;
+                hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid(count)), dim3(256), 0, st, (float*)dst.ptr,
+                                   (int64_t)count, (const double*)src.ptr, (int64_t)count, (int64_t)1, (int64_t)count);
+                check_launch("cast");
+                return dst.ptr;
+            }
+            cb.src[ne] = (const double*)src.ptr;
+            cb.dst[ne] = (float*)dst.ptr;
+            cb.count[ne] = count;
+            if (count > max_count) max_count = count;
+            ++ne;
+            return dst.ptr;
+        };
+        for (size_t i = 0; i < nt; ++i) {
+            TypeState& t = p->types[i];
+            Bn_m[i] = add(t.Bn_tot, t.Bn32, t.c * t.c);
+            Bp_m[i] = add(t.Bp_tot, t.Bp32, t.c * t.c);
+        }
+        for (size_t k = 0; k < p->rels.size(); ++k) {
+            RelState& r = p->rels[k];
+            S_m[k] = (!r.absent || r.col_side) ? add(r.S, r.S32, p->types[r.row].c * p->types[r.col].c) : r.S.ptr;
+        }
+        (void)overflow;
+        if (cast && ne > 0) {
+            hipLaunchKernelGGL(cast_batched_kernel, dim3(elem_grid(max_count), ne), dim3(256), 0, st, cb);
+            check_launch("cast_batched");
+        }
     }
     // type-level term on rows [t0, t0 + tn): separately (row blocks / VALU engine), or inside the
     // last side product of the type (fused engine on whole matrices)
@@ -1018,7 +1082,8 @@ static void stage_accumulate(skf_plan* p, hipStream_t st) {
         touched[i] = 1;
     };
     const bool fuse_type_term = fused && !p->sliced;
-    for (RelState& r : p->rels) {
+    for (size_t rk = 0; rk < p->rels.size(); ++rk) {
+        RelState& r = p->rels[rk];
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
         const int nr = (int)r.nr, nj = (int)tj.n, ci = ti.c, cj = tj.c;
@@ -1030,7 +1095,7 @@ static void stage_accumulate(skf_plan* p, hipStream_t st) {
         if (fused) {
             // row side: A = P S^T (Sop(k,j) = S[j][k]);  column side: C = Q S
             if (!row_side && !col_side) continue;
-            const void* Sm = to_master(r.S, r.S32, ci, cj);
+            const void* Sm = S_m[rk];
             if (row_side) {
                 const bool last = fuse_type_term && --sides_left[r.row] == 0;
                 side_update(p, r.P.ptr, cj, cj, Sm, 1, cj, ti, Gi, Ei, Di, nr, Bn_m[r.row], Bp_m[r.row], last,

@@ -2122,6 +2122,110 @@ __global__ __launch_bounds__(256) void eigh_unpack_pinv_kernel(T* __restrict__ K
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Small ranks (every c <= 64: the reference's own examples).  The c x c algebra of a relation is
+// a chain of tiny dependent products; as separate launches they dominate the iteration of a small
+// graph.  Two kernels, one workgroup per relation, intermediates in LDS, f64 throughout:
+//   backbone_small_kernel   T1 = K_i W ; S = nan_to_num(T1 K_j)                (all relations, one launch)
+//   bterms_small_kernel     B = (S Gram_j) S^T, D = S^T (Gram_i S) -> += into the +- sums of the row /
+//                           column type (one launch per relation: the sums are shared between relations)
+// ------------------------------------------------------------------------------------------
+constexpr int SMALLC = 64;
+constexpr int CHAIN_MAXB = 16;
+struct BackboneBatch {
+    const double* Ki[CHAIN_MAXB];
+    const double* Kj[CHAIN_MAXB];
+    const double* W[CHAIN_MAXB];
+    double* S[CHAIN_MAXB];
+    int ci[CHAIN_MAXB], cj[CHAIN_MAXB];
+};
+
+__global__ __launch_bounds__(256) void backbone_small_kernel(BackboneBatch bb) {
+    __shared__ double T1[SMALLC * (SMALLC + 1)];
+    const int b = blockIdx.x, ci = bb.ci[b], cj = bb.cj[b];
+    const double* __restrict__ Ki = bb.Ki[b];
+    const double* __restrict__ Kj = bb.Kj[b];
+    const double* __restrict__ W = bb.W[b];
+    double* __restrict__ S = bb.S[b];
+    for (int e = threadIdx.x; e < ci * cj; e += blockDim.x) {
+        const int a = e / cj, c = e % cj;
+        double s = 0.0;
+        for (int k = 0; k < ci; ++k) s += Ki[a * ci + k] * W[k * cj + c];
+        T1[a * (SMALLC + 1) + c] = s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ci * cj; e += blockDim.x) {
+        const int a = e / cj, c = e % cj;
+        double s = 0.0;
+        for (int k = 0; k < cj; ++k) s += T1[a * (SMALLC + 1) + k] * Kj[k * cj + c];
+        S[a * cj + c] = nan_to_num(s);
+    }
+}
+
+struct BTermsArgs {
+    const double* S;        // ci x cj
+    const double* Gram_i;   // ci x ci
+    const double* Gram_j;   // cj x cj
+    double* Bp_i;           // += max(B, 0), ci x ci     (row type)
+    double* Bn_i;           // += max(-B, 0)
+    double* Bp_j;           // += max(D, 0), cj x cj     (column type)
+    double* Bn_j;
+    int ci, cj, nan_to_num;
+};
+
+__global__ __launch_bounds__(256) void bterms_small_kernel(BTermsArgs a) {
+    __shared__ double U[SMALLC * (SMALLC + 1)];
+    const int ci = a.ci, cj = a.cj;
+    const double* __restrict__ S = a.S;
+    // U = S Gram_j ; B = U S^T                                   (tmp2 of _dfmf.py:260)
+    for (int e = threadIdx.x; e < ci * cj; e += blockDim.x) {
+        const int r = e / cj, c = e % cj;
+        double s = 0.0;
+        for (int k = 0; k < cj; ++k) s += S[r * cj + k] * a.Gram_j[k * cj + c];
+        U[r * (SMALLC + 1) + c] = s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ci * ci; e += blockDim.x) {
+        const int r = e / ci, c = e % ci;
+        double s = 0.0;
+        for (int k = 0; k < cj; ++k) s += U[r * (SMALLC + 1) + k] * S[c * cj + k];
+        if (a.nan_to_num) s = nan_to_num(s);
+        a.Bp_i[e] += s > 0.0 ? s : 0.0;
+        a.Bn_i[e] += s > 0.0 ? 0.0 : -s;
+    }
+    __syncthreads();
+    // U = Gram_i S ; D = S^T U                                   (tmp5 of _dfmf.py:272)
+    for (int e = threadIdx.x; e < ci * cj; e += blockDim.x) {
+        const int r = e / cj, c = e % cj;
+        double s = 0.0;
+        for (int k = 0; k < ci; ++k) s += a.Gram_i[r * ci + k] * S[k * cj + c];
+        U[r * (SMALLC + 1) + c] = s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cj * cj; e += blockDim.x) {
+        const int r = e / cj, c = e % cj;
+        double s = 0.0;
+        for (int k = 0; k < ci; ++k) s += S[k * cj + r] * U[k * (SMALLC + 1) + c];
+        if (a.nan_to_num) s = nan_to_num(s);
+        a.Bp_j[e] += s > 0.0 ? s : 0.0;
+        a.Bn_j[e] += s > 0.0 ? 0.0 : -s;
+    }
+}
+
+// f32 engines: f32 roundings of several small f64 matrices in one launch (blockIdx.y = entry)
+constexpr int CAST_MAXB = 32;
+struct CastBatch {
+    const double* src[CAST_MAXB];
+    float* dst[CAST_MAXB];
+    int count[CAST_MAXB];
+};
+__global__ __launch_bounds__(256) void cast_batched_kernel(CastBatch cb) {
+    const int b = blockIdx.y;
+    const double* __restrict__ src = cb.src[b];
+    float* __restrict__ dst = cb.dst[b];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < cb.count[b]; e += gridDim.x * blockDim.x) dst[e] = (float)src[e];
+}
+
 // Batched forms for the plan (blockIdx.y = matrix): the per-type pack / unpack launches of one
 // pseudo-inverse pass collapse into one launch each -- on small graphs an iteration is bounded by
 // the number of dependent launches, not by their work.

@@ -18,8 +18,14 @@ def emul():
         yield rt
 
 
+@pytest.mark.parametrize('small_chain', ['on', 'off'])
 @pytest.mark.parametrize('engine', [nat.SKF_ENGINE_MFMA, nat.SKF_ENGINE_VALU])
-def test_c1_readme_f64_matches_reference_golden(engine):
+def test_c1_readme_f64_matches_reference_golden(engine, small_chain, monkeypatch):
+    """(small_chain off: the c x c algebra through the generic GEMM launches and the blocked Cholesky
+    inverse, as for ranks above 64; on: the one-workgroup kernels for small ranks.)"""
+    if small_chain == 'off':
+        monkeypatch.setenv('SKF_NO_SMALL_CHAIN', '1')
+        monkeypatch.setenv('SKF_CHOL_NO_SMALL', '1')
     z = golden('c1_readme_dfmf.npz')
     R, types, rank = readme_graph()
     snaps = Snapshots((0, 1, 9))
