@@ -926,7 +926,20 @@ static void stage_backbone(skf_plan* p, hipStream_t st) {
                 bb.ci[nb] = p->types[r.row].c;
                 bb.cj[nb] = p->types[r.col].c;
             }
-            hipLaunchKernelGGL(backbone_small_kernel, dim3(nb), dim3(256), 0, st, bb);
+            size_t smem = 0;
+            for (int q = 0; q < nb; ++q) {
+                const size_t need = ((size_t)bb.ci[q] * bb.ci[q] + 2 * (size_t)bb.ci[q] * bb.cj[q] + (size_t)bb.cj[q] * bb.cj[q]) * 8;
+                if (need > smem) smem = need;
+            }
+            static bool attr = false;
+            if (!attr) {
+                SKF_HIP(hipFuncSetAttribute((const void*)backbone_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            4 * SMALLC * SMALLC * 8));
+                SKF_HIP(hipFuncSetAttribute((const void*)bterms_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            4 * SMALLC * SMALLC * 8));
+                attr = true;
+            }
+            hipLaunchKernelGGL(backbone_small_kernel, dim3(nb), dim3(256), smem, st, bb);
             check_launch("backbone_small");
         }
     }
@@ -1016,7 +1029,8 @@ static void stage_accumulate(skf_plan* p, hipStream_t st) {
             ba.Bp_i = (double*)ti.Bp_tot.ptr; ba.Bn_i = (double*)ti.Bn_tot.ptr;
             ba.Bp_j = (double*)tj.Bp_tot.ptr; ba.Bn_j = (double*)tj.Bn_tot.ptr;
             ba.ci = ti.c; ba.cj = tj.c; ba.nan_to_num = nan_upd;
-            hipLaunchKernelGGL(bterms_small_kernel, dim3(1), dim3(256), 0, st, ba);
+            const size_t smem = ((size_t)ti.c * ti.c + 2 * (size_t)ti.c * tj.c + (size_t)tj.c * tj.c) * 8;
+            hipLaunchKernelGGL(bterms_small_kernel, dim3(1), dim3(256), smem, st, ba);
             check_launch("bterms_small");
             continue;
         }

@@ -2140,25 +2140,32 @@ struct BackboneBatch {
     int ci[CHAIN_MAXB], cj[CHAIN_MAXB];
 };
 
+// dynamic LDS: Ki (ci x ci) | W, then T1 (ci x cj) | Kj (cj x cj) | T1 -- operands are staged with
+// coalesced loads first: the dot products then run on LDS latency, not on L2 round trips
 __global__ __launch_bounds__(256) void backbone_small_kernel(BackboneBatch bb) {
-    __shared__ double T1[SMALLC * (SMALLC + 1)];
+    HIP_DYNAMIC_SHARED(double, sm)
     const int b = blockIdx.x, ci = bb.ci[b], cj = bb.cj[b];
-    const double* __restrict__ Ki = bb.Ki[b];
-    const double* __restrict__ Kj = bb.Kj[b];
-    const double* __restrict__ W = bb.W[b];
-    double* __restrict__ S = bb.S[b];
-    for (int e = threadIdx.x; e < ci * cj; e += blockDim.x) {
-        const int a = e / cj, c = e % cj;
-        double s = 0.0;
-        for (int k = 0; k < ci; ++k) s += Ki[a * ci + k] * W[k * cj + c];
-        T1[a * (SMALLC + 1) + c] = s;
-    }
+    double* Ki = sm;
+    double* W = Ki + ci * ci;
+    double* Kj = W + ci * cj;
+    double* T1 = Kj + cj * cj;
+    for (int e = threadIdx.x; e < ci * ci; e += blockDim.x) Ki[e] = bb.Ki[b][e];
+    for (int e = threadIdx.x; e < ci * cj; e += blockDim.x) W[e] = bb.W[b][e];
+    for (int e = threadIdx.x; e < cj * cj; e += blockDim.x) Kj[e] = bb.Kj[b][e];
     __syncthreads();
     for (int e = threadIdx.x; e < ci * cj; e += blockDim.x) {
         const int a = e / cj, c = e % cj;
         double s = 0.0;
-        for (int k = 0; k < cj; ++k) s += T1[a * (SMALLC + 1) + k] * Kj[k * cj + c];
-        S[a * cj + c] = nan_to_num(s);
+        for (int k = 0; k < ci; ++k) s += Ki[a * ci + k] * W[k * cj + c];
+        T1[e] = s;
+    }
+    __syncthreads();
+    double* __restrict__ S = bb.S[b];
+    for (int e = threadIdx.x; e < ci * cj; e += blockDim.x) {
+        const int a = e / cj, c = e % cj;
+        double s = 0.0;
+        for (int k = 0; k < cj; ++k) s += T1[a * cj + k] * Kj[k * cj + c];
+        S[e] = nan_to_num(s);
     }
 }
 
@@ -2173,22 +2180,30 @@ struct BTermsArgs {
     int ci, cj, nan_to_num;
 };
 
+// dynamic LDS: S (ci x cj) | Gram_i (ci x ci) | Gram_j (cj x cj) | U (ci x cj)
 __global__ __launch_bounds__(256) void bterms_small_kernel(BTermsArgs a) {
-    __shared__ double U[SMALLC * (SMALLC + 1)];
+    HIP_DYNAMIC_SHARED(double, sm)
     const int ci = a.ci, cj = a.cj;
-    const double* __restrict__ S = a.S;
+    double* S = sm;
+    double* Gi = S + ci * cj;
+    double* Gj = Gi + ci * ci;
+    double* U = Gj + cj * cj;
+    for (int e = threadIdx.x; e < ci * cj; e += blockDim.x) S[e] = a.S[e];
+    for (int e = threadIdx.x; e < ci * ci; e += blockDim.x) Gi[e] = a.Gram_i[e];
+    for (int e = threadIdx.x; e < cj * cj; e += blockDim.x) Gj[e] = a.Gram_j[e];
+    __syncthreads();
     // U = S Gram_j ; B = U S^T                                   (tmp2 of _dfmf.py:260)
     for (int e = threadIdx.x; e < ci * cj; e += blockDim.x) {
         const int r = e / cj, c = e % cj;
         double s = 0.0;
-        for (int k = 0; k < cj; ++k) s += S[r * cj + k] * a.Gram_j[k * cj + c];
-        U[r * (SMALLC + 1) + c] = s;
+        for (int k = 0; k < cj; ++k) s += S[r * cj + k] * Gj[k * cj + c];
+        U[e] = s;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < ci * ci; e += blockDim.x) {
         const int r = e / ci, c = e % ci;
         double s = 0.0;
-        for (int k = 0; k < cj; ++k) s += U[r * (SMALLC + 1) + k] * S[c * cj + k];
+        for (int k = 0; k < cj; ++k) s += U[r * cj + k] * S[c * cj + k];
         if (a.nan_to_num) s = nan_to_num(s);
         a.Bp_i[e] += s > 0.0 ? s : 0.0;
         a.Bn_i[e] += s > 0.0 ? 0.0 : -s;
@@ -2198,14 +2213,14 @@ __global__ __launch_bounds__(256) void bterms_small_kernel(BTermsArgs a) {
     for (int e = threadIdx.x; e < ci * cj; e += blockDim.x) {
         const int r = e / cj, c = e % cj;
         double s = 0.0;
-        for (int k = 0; k < ci; ++k) s += a.Gram_i[r * ci + k] * S[k * cj + c];
-        U[r * (SMALLC + 1) + c] = s;
+        for (int k = 0; k < ci; ++k) s += Gi[r * ci + k] * S[k * cj + c];
+        U[e] = s;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < cj * cj; e += blockDim.x) {
         const int r = e / cj, c = e % cj;
         double s = 0.0;
-        for (int k = 0; k < ci; ++k) s += S[k * cj + r] * U[k * (SMALLC + 1) + c];
+        for (int k = 0; k < ci; ++k) s += S[k * cj + r] * U[k * cj + c];
         if (a.nan_to_num) s = nan_to_num(s);
         a.Bp_j[e] += s > 0.0 ? s : 0.0;
         a.Bn_j[e] += s > 0.0 ? 0.0 : -s;
