@@ -111,7 +111,9 @@ SIGNATURES = {
 
 
 def load_library(path=LIB_PATH):
-    """dlopen the C-ABI library and attach the prototypes of every declared entry point."""
+    """dlopen the C-ABI library and attach the prototypes of every declared entry point.
+    (SKF_LIB_PATH overrides the in-tree build: A/B runs of experimental builds.)"""
+    path = os.environ.get('SKF_LIB_PATH', path)
     if not os.path.exists(path):
         raise ImportError(
             '%s not found at %s -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
