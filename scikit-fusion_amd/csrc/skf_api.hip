@@ -242,7 +242,10 @@ static inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
 
 // K slices for the bf16 contraction: equal work units over the 256 CUs (x resident workgroups)
 // finish in ceil(units/slots) rounds; pick the split that wastes the least of the last round,
-// charging a little for the partial-sum traffic of every extra slice.
+// charging every extra slice for its partial-sum traffic.  The charge is empirical (config 3, A/B
+// runs of SKF_BF16_SPLIT_PENALTY = 0.002 ... 1.0): 0.05-0.07 is best -- e.g. 196 row tiles run
+// UNSPLIT on 196 of the 256 CUs as fast as 5 slices on all of them (the memory system, not the
+// number of busy CUs, bounds the kernel), while 157 and 391 tiles gain from 3 slices.
 // rows per workgroup of the bf16 contraction: the 256-row double-buffered kernel for large
 // problems, the 128-row kernel otherwise (SKF_BF16_TILE=128 / 256 forces one, for A/B runs)
 static int bf16_block_rows(int M) {
@@ -254,13 +257,17 @@ static int bf16_block_rows(int M) {
 
 static int pick_splits_bf16(int64_t units, int ktiles, int bm) {
     const double slots = 256.0 * (bm == 256 ? 1.0 : 2.0);     // resident workgroups on 256 CUs
+    static const double penalty = [] {                         // cost of one more K slice (partial-sum traffic)
+        const char* e = getenv("SKF_BF16_SPLIT_PENALTY");
+        return e ? atof(e) : 0.06;
+    }();
     int best = 1;
     double best_eff = -1.0;
     for (int s = 1; s <= 32; ++s) {
         if (s > 1 && ktiles / s < 8) break;
         const double w = (double)units * s / slots;
         const double rounds = (double)(int64_t)(w + 0.999999);
-        const double eff = w / (rounds < 1.0 ? 1.0 : rounds) - 0.008 * (s - 1);
+        const double eff = w / (rounds < 1.0 ? 1.0 : rounds) - penalty * (s - 1);
         if (eff > best_eff + 1e-9) {
             best_eff = eff;
             best = s;

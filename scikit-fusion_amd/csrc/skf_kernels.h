@@ -986,6 +986,12 @@ __device__ __forceinline__ int swz_chunk32(int row, int chunk) { return row * 8 
 #ifndef SKF_A_AUX
 #define SKF_A_AUX 2
 #endif
+#ifndef SKF_B_AUX
+#define SKF_B_AUX 0
+#endif
+#ifndef SKF_MFMA_PRIO
+#define SKF_MFMA_PRIO 0
+#endif
 template <int BN, int TAG, bool MF32, bool GLDS, int NSTAGE>
 __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     constexpr int BM = 256, BK = 64;
@@ -1087,7 +1093,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
             const int nc = n < g.N ? n : g.N - 1;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + (int64_t)(k0 >> 6) * g.b_kstep + c * 8),
-                (__attribute__((address_space(3))) void*)(Bd + blk * 64), 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(Bd + blk * 64), 16, 0, SKF_B_AUX);
         }
     };
 
@@ -1165,6 +1171,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                         acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc32[i][j], 0, 0, 0);
             }
         } else {
+            if (SKF_MFMA_PRIO) __builtin_amdgcn_s_setprio(SKF_MFMA_PRIO);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int chunk = 4 * ks + (lane >> 4);
@@ -1181,6 +1188,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                     for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+            if (SKF_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
         }
         if constexpr (NSTAGE == 3) {
             // tile kt+1 must have landed; tile kt+2 (if it was issued) may stay in flight.

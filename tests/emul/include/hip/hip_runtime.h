@@ -303,6 +303,7 @@ inline unsigned long long __ballot(int pred) {
 }
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
+inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
 // LDS-DMA: destination = the FIRST lane's LDS pointer + lane * size (wave-linear), source per lane
 template <class PS, class PD>
