@@ -248,15 +248,17 @@ static inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
 // number of busy CUs, bounds the kernel), while 157 and 391 tiles gain from 3 slices.
 // rows per workgroup of the bf16 contraction: the 256-row double-buffered kernel for large
 // problems, the 128-row kernel otherwise (SKF_BF16_TILE=128 / 256 forces one, for A/B runs)
-static int bf16_block_rows(int M) {
+static int bf16_block_rows(int M, int N = 256) {
     const char* f = getenv("SKF_BF16_TILE");
     if (f && atoi(f) == 128) return 128;
     if (f && atoi(f) == 256) return 256;
+    const char* t = getenv("SKF_BF16_TALL");           // "1": 384 x 256 / 512 x 128 tiles (gemm_bf16_tall_kernel)
+    if (t && (atoi(t) == 2 || (atoi(t) == 1 && M >= 4096))) return N > 128 ? 384 : 512;      // "2": any M (tests)
     return M >= 4096 ? 256 : 128;
 }
 
 static int pick_splits_bf16(int64_t units, int ktiles, int bm) {
-    const double slots = 256.0 * (bm == 256 ? 1.0 : 2.0);     // resident workgroups on 256 CUs
+    const double slots = 256.0 * (bm >= 256 ? 1.0 : 2.0);     // resident workgroups on 256 CUs
     static const double penalty = [] {                         // cost of one more K slice (partial-sum traffic)
         const char* e = getenv("SKF_BF16_SPLIT_PENALTY");
         return e ? atof(e) : 0.06;
@@ -285,7 +287,7 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
                  (long long)lda, (long long)ldb);
     if ((((uintptr_t)A) | ((uintptr_t)Bt)) & 15) SKF_FAIL(SKF_E_INVALID, "bf16 operands must be 16-byte aligned");
     const int bn = (N <= 128) ? 128 : 256;
-    const int bm = bf16_block_rows(M);
+    const int bm = bf16_block_rows(M, N);
     const int ktiles = Kp / 64;
     const int64_t units = (int64_t)cdiv(M, bm) * cdiv(N, bn);
     int splits = want_splits > 0 ? want_splits : pick_splits_bf16(units, ktiles, bm);
@@ -301,7 +303,25 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
     g.k_chunk = cdiv(ktiles > 0 ? ktiles : 1, splits) * 64;
     splits = cdiv(Kp > 0 ? Kp : 1, g.k_chunk);
     dim3 grid(cdiv(N, bn), cdiv(M, bm), splits);
-    if (bm == 256) {
+    if (bm > 256) {
+        // tall tiles: the whole LDS as a 2-deep ring of both operands
+        const int smem = 2 * (bm + bn) * 8 * 16;
+#define SKF_TALL_LAUNCH(BN_, NW_, TAG_)                                                                           \
+    do {                                                                                                          \
+        static bool attr_ = false;                                                                                \
+        if (!attr_) {                                                                                             \
+            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tall_kernel<BN_, NW_, TAG_>,                       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (32 * NW_ + BN_) * 8 * 16)); \
+            attr_ = true;                                                                                         \
+        }                                                                                                         \
+        hipLaunchKernelGGL((gemm_bf16_tall_kernel<BN_, NW_, TAG_>), grid, dim3(NW_ * 64), smem, st, g);           \
+    } while (0)
+        if (bm == 384 && relation) SKF_TALL_LAUNCH(256, 12, 1);
+        else if (bm == 384) SKF_TALL_LAUNCH(256, 12, 0);
+        else if (relation) SKF_TALL_LAUNCH(128, 16, 1);
+        else SKF_TALL_LAUNCH(128, 16, 0);
+#undef SKF_TALL_LAUNCH
+    } else if (bm == 256) {
         // 256 x BN tile, LDS double buffer in dynamic shared memory (> 64 KiB needs the attribute)
         dim3 block(512);
         const char* mf = getenv("SKF_BF16_MFMA");          // "32" selects the 32x32x16 flavour
@@ -376,7 +396,9 @@ static size_t bf16_part_bytes(int M, int N, int Kp) {
     // worst case over the two tile heights (the choice can be overridden at run time)
     const int s1 = pick_splits_bf16((int64_t)cdiv(M, 128) * cdiv(N, bn), Kp / 64, 128);
     const int s2 = pick_splits_bf16((int64_t)cdiv(M, 256) * cdiv(N, bn), Kp / 64, 256);
-    const int s = s1 > s2 ? s1 : s2;
+    const int s3 = pick_splits_bf16((int64_t)cdiv(M, N > 128 ? 384 : 512) * cdiv(N, bn), Kp / 64, 512);
+    const int s12 = s1 > s2 ? s1 : s2;
+    const int s = s12 > s3 ? s12 : s3;
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 

@@ -1237,6 +1237,119 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 relation contraction, "tall" tiles.  Finding (A/B runs at config 3): the v2 kernel runs as fast
+// on 196 of the 256 CUs as on all of them -- what bounds it is the traffic into the L1s (relation
+// tile from HBM + the G^T tile every workgroup re-reads from L2), not the number of busy CUs.  The
+// G^T share is 1/BM per flop, so taller tiles cut it: NW waves (NW/2 x 2, wave tile 64 x BN/2) own
+// a (32 NW) x BN tile --  384 x 256 with 12 waves (3 per SIMD), 512 x 128 with 16 waves -- and the
+// whole LDS holds a 2-deep ring of both operands (LDS-DMA, nt policy on the relation stream).
+//     [DMA tile t+1]  MFMA on tile t  | vmcnt(0) | barrier
+// Same operand contract / swizzle / epilogue as gemm_bf16_v2_kernel.
+// ------------------------------------------------------------------------------------------
+template <int BN, int NW, int TAG>
+__global__ __launch_bounds__(NW * 64) void gemm_bf16_tall_kernel(Bf16GemmArgs g) {
+    constexpr int BM = 32 * NW, BK = 64;
+    constexpr int WN = BN / 2;
+    constexpr int NJ = WN / 16;
+    constexpr int ASZ = BM * 8, BSZ = BN * 8;                   // u32x4 entries per buffer
+    HIP_DYNAMIC_SHARED(u32x4, smem)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * WN;
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    const int kz0 = blockIdx.z * g.k_chunk;
+    const int kz1 = (kz0 + g.k_chunk < g.Kp) ? kz0 + g.k_chunk : g.Kp;
+    const int nkt = (kz1 - kz0) / BK;
+    const int rr = lane >> 3, pc = lane & 7;
+
+    f32x4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    auto dma_A = [&](int k0, int buf) {
+        u32x4* Ad = smem + buf * ASZ;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {                      // BM / 8 row blocks over NW waves = 4 each
+            const int blk = wave * 4 + p;
+            const int row = blk * 8 + rr;
+            const int m = bm0 + row;
+            const int mc = m < g.M ? m : g.M - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g.A + (int64_t)mc * g.lda + (int64_t)(k0 >> 6) * g.a_kstep + (pc ^ (row & 7)) * 8),
+                (__attribute__((address_space(3))) void*)(Ad + blk * 64), 16, 0, SKF_A_AUX);
+        }
+    };
+    auto dma_B = [&](int k0, int buf) {
+        u32x4* Bd = smem + 2 * ASZ + buf * BSZ;
+        for (int blk = wave; blk < BN / 8; blk += NW) {
+            const int row = blk * 8 + rr;
+            const int n = bn0 + row;
+            const int nc = n < g.N ? n : g.N - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + (int64_t)(k0 >> 6) * g.b_kstep + (pc ^ (row & 7)) * 8),
+                (__attribute__((address_space(3))) void*)(Bd + blk * 64), 16, 0, 0);
+        }
+    };
+
+    if (nkt > 0) {
+        dma_A(kz0, 0);
+        dma_B(kz0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the LDS-DMA has landed
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) {
+            dma_A(kz0 + (kt + 1) * BK, cur ^ 1);
+            dma_B(kz0 + (kt + 1) * BK, cur ^ 1);
+        }
+        const u32x4* As = smem + cur * ASZ;
+        const u32x4* Bs = smem + 2 * ASZ + cur * BSZ;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = 4 * ks + (lane >> 4);
+            bf16x8 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
+            constexpr int JB = (NW == 12) ? 2 : 4;          // B fragments per group (register budget: 3 waves/SIMD)
+#pragma unroll
+            for (int jh = 0; jh < NJ; jh += JB) {
+                bf16x8 b[JB];
+#pragma unroll
+                for (int j = 0; j < JB; ++j)
+                    b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + (jh + j) * 16 + (lane & 15), chunk)]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < JB; ++j)
+                        acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][jh + j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0): next tile landed, reads done
+        __syncthreads();
+    }
+
+    float* out = (gridDim.z > 1) ? g.part + (int64_t)blockIdx.z * g.M * g.N : g.C;
+    const int64_t ldo = (gridDim.z > 1) ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = bm0 + wm0 + i * 16 + 4 * (lane >> 4) + r;
+                const int n = bn0 + wn0 + j * 16 + (lane & 15);
+                if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc[i][j][r];
+            }
+}
+
+// ------------------------------------------------------------------------------------------
 // bf16 relation contraction, third generation = the v2 LDS-DMA ring kernel with the fragment
 // reads software-pipelined by half a K tile.  Two fragment register sets alternate:
 //     [ds_read F1 = second half of tile t ]  MFMA on F0 (first half of tile t)

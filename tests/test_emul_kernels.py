@@ -179,6 +179,19 @@ def test_gemm_bf16_contraction(rt, shape):
             os.environ.pop('SKF_BF16_PIPE', None)
 
 
+@pytest.mark.parametrize('shape', [(257, 128, 200), (100, 256, 129), (700, 300, 130), (1030, 64, 70)])
+def test_gemm_bf16_tall_tiles(rt, shape, monkeypatch):
+    """gemm_bf16_tall_kernel: 384 x 256 tiles (12 waves) for N > 128, 512 x 128 tiles (16 waves) otherwise;
+    row / column / K tails, several row and column tiles, split-K."""
+    monkeypatch.setenv('SKF_BF16_TALL', '2')
+    M, N, K = shape
+    rs = np.random.RandomState(M + N + K)
+    A, B = rs.randn(M, K), rs.randn(K, N)
+    for splits in (0, 1, 2):
+        got, want = run_gemm_bf16(rt, A, B, splits)
+        assert relerr(got, want) < 2e-6, splits
+
+
 def test_to_bf16_and_transpose(rt):
     rs = np.random.RandomState(2)
     X = rs.randn(70, 45)
