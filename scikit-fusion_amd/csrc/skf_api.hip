@@ -254,6 +254,8 @@ static int bf16_block_rows(int M, int N = 256) {
     if (f && atoi(f) == 256) return 256;
     const char* t = getenv("SKF_BF16_TALL");           // "1": 384 x 256 / 512 x 128 tiles (gemm_bf16_tall_kernel)
     if (t && (atoi(t) == 2 || (atoi(t) == 1 && M >= 4096))) return N > 128 ? 384 : 512;      // "2": any M (tests)
+    if (t && atoi(t) == 3 && M >= 4096 && N <= 128) return 512;                              // "3" / "4": one shape only
+    if (t && atoi(t) == 4 && M >= 4096 && N > 128) return 384;
     return M >= 4096 ? 256 : 128;
 }
 
