@@ -899,12 +899,21 @@ static void stage_contract(skf_plan* p, hipStream_t st) {
     // The Gram products use the whole chip and stay on the main stream; the pseudo-inverses are
     // three single-workgroup kernels with a long serial chain: they go to the second stream and
     // run underneath the relation contractions.
+    // SKF_GRAM_AUX=1 (experiment): the Gram products go to the second stream too, next to the first
+    // contraction (which leaves CUs idle when its row tiles do not fill the chip)
+    const char* ga = getenv("SKF_GRAM_AUX");
+    const bool gram_aux = p->overlap && ga && atoi(ga) != 0;
+    hipStream_t sa = st;
+    if (p->overlap && gram_aux) {
+        SKF_HIP(hipEventRecord(p->ev_fork, st));
+        SKF_HIP(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
+        sa = p->aux;
+    }
     for (size_t i = 0; i < p->types.size(); ++i) {
-        gram(p, p->types[i], 1, st, false);
+        gram(p, p->types[i], 1, gram_aux ? sa : st, gram_aux);
         all.push_back((int)i);
     }
-    hipStream_t sa = st;
-    if (p->overlap) {
+    if (p->overlap && !gram_aux) {
         SKF_HIP(hipEventRecord(p->ev_fork, st));
         SKF_HIP(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
         sa = p->aux;
