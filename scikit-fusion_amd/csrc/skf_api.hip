@@ -919,6 +919,23 @@ static void stage_contract(skf_plan* p, hipStream_t st) {
         sa = p->aux;
     }
     plan_pinv(p, all, sa);
+    if (const char* dbg = getenv("SKF_DEBUG_PINV"); dbg && atoi(dbg) != 0) {
+        // diagnostics: verdict of the Cholesky fast path and the diagonal range of every Gram matrix
+        SKF_HIP(hipStreamSynchronize(sa));
+        std::vector<int> ok(p->types.size());
+        SKF_HIP(hipMemcpy(ok.data(), p->eigOk.ptr, ok.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < p->types.size(); ++i) {
+            const TypeState& t = p->types[i];
+            std::vector<double> gm((size_t)t.c * t.c);
+            SKF_HIP(hipMemcpy(gm.data(), t.Gram.ptr, gm.size() * 8, hipMemcpyDeviceToHost));
+            double lo = 1e300, hi = 0.0;
+            for (int k = 0; k < t.c; ++k) {
+                lo = gm[(size_t)k * t.c + k] < lo ? gm[(size_t)k * t.c + k] : lo;
+                hi = gm[(size_t)k * t.c + k] > hi ? gm[(size_t)k * t.c + k] : hi;
+            }
+            fprintf(stderr, "[skf pinv] type %zu c=%d chol_ok=%d diag min %.3e max %.3e\n", i, t.c, ok[i], lo, hi);
+        }
+    }
     if (p->overlap) SKF_HIP(hipEventRecord(p->ev_join, p->aux));
 
     // ---- phase B (main stream): every product that streams a relation matrix, and W = G_i^T P

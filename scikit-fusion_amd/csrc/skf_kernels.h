@@ -788,6 +788,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16GemmArgs g) {
 // orientations -- along n into R and along m into RT -- reading the old chunk only when it holds
 // an unmasked entry to keep.
 // ------------------------------------------------------------------------------------------
+// -DSKF_COMPLETE_NT=1: non-temporal stores of the completed chunks / loads of the mask (experiment)
+#ifndef SKF_COMPLETE_NT
+#define SKF_COMPLETE_NT 0
+#endif
 struct CompleteArgs {
     const uint16_t* A;
     const uint16_t* Bt;
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(256) void complete_bf16_kernel(CompleteArgs g) {
         if (m < g.M && n < g.N) {
             const uint8_t* src = g.mask + (int64_t)m * g.ldmask + n;
             if (mvec && n + 16 <= g.N) {
-                const u32x4 v = *(const u32x4*)src;
+                const u32x4 v = SKF_COMPLETE_NT ? __builtin_nontemporal_load((const u32x4*)src) : *(const u32x4*)src;
                 w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
             } else {
                 for (int q = 0; q < 16; ++q)
@@ -924,7 +928,7 @@ __global__ __launch_bounds__(256) void complete_bf16_kernel(CompleteArgs g) {
                     v[q >> 1] = (v[q >> 1] & ~msk) | (old[q >> 1] & msk);
                 }
         }
-        *dst = v;
+        if (SKF_COMPLETE_NT) __builtin_nontemporal_store(v, dst); else *dst = v;
     }
     // pass 2: 8 consecutive rows of one column -> RT (stored transpose)
     for (int i = tid; i < BN * 16; i += 256) {
@@ -953,7 +957,7 @@ __global__ __launch_bounds__(256) void complete_bf16_kernel(CompleteArgs g) {
                     v[q >> 1] = (v[q >> 1] & ~msk) | (old[q >> 1] & msk);
                 }
         }
-        *dst = v;
+        if (SKF_COMPLETE_NT) __builtin_nontemporal_store(v, dst); else *dst = v;
     }
 }
 
