@@ -166,6 +166,21 @@ static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, 
                 fixed = true;
             }
         }
+        if constexpr (std::is_same<T, double>::value && std::is_same<TA, double>::value && std::is_same<TB, double>::value) {
+            // the same two layouts in the f64 engine (16-byte vectors = 2 doubles)
+            auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+            const bool b_rows = g.sb_n == 1 && g.sb_k % 2 == 0 && g.N % 2 == 0 && al(g.B);
+            const bool k_ok = g.K % 2 == 0 && g.k_chunk % 2 == 0;
+            if (b_rows && al(g.A) && g.sa_k == 1 && g.sa_m % 2 == 0 && k_ok) {
+                hipLaunchKernelGGL((gemm_mfma_kernel<double, double, double, WRB, WCB, Tiles<double>::BK, 1,
+                                                     STAGE_VEC_K | (STAGE_VEC_R << 2)>), grid, block, 0, st, g);
+                fixed = true;
+            } else if (b_rows && al(g.A) && g.sa_m == 1 && g.sa_k % 2 == 0 && g.M % 2 == 0) {
+                hipLaunchKernelGGL((gemm_mfma_kernel<double, double, double, WRB, WCB, Tiles<double>::BK, 1,
+                                                     STAGE_VEC_R | (STAGE_VEC_R << 2)>), grid, block, 0, st, g);
+                fixed = true;
+            }
+        }
         if (!fixed)
             hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 1>), grid, block, 0, st, g);
     } else if (big) {
