@@ -135,6 +135,12 @@ int skf_get_backbone(const skf_plan* plan, int32_t rel, void* S, int64_t ld, voi
  * and get_factor the factors AFTER it -- the same generation mismatch the reference returns
  * (_dfmf.py:239 vs :295, return :327). */
 int skf_iterate(skf_plan* plan, int32_t n_iters, void* stream);
+/* enable != 0: iterations 2..n of skf_iterate replay ONE captured hipGraph (a single host call per
+ * iteration instead of one per kernel).  Off by default -- a single fit is bound by kernel time --
+ * and switched on for restarts that run CONCURRENTLY on several streams of one GPU, where the
+ * host-side launch rate of one thread is the limit (the reference's n_jobs over n_run restarts,
+ * dfmf.py:87-95).  A failed capture falls back to eager launches. */
+int skf_plan_set_graph(skf_plan* plan, int32_t enable);
 
 /* The same iteration in two halves, for runs whose relations are partitioned over several GPUs
  * (one process and one plan per GPU, each plan holding ALL object types but only its share of

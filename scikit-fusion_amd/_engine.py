@@ -89,12 +89,16 @@ class DevicePlan(object):
     """One (run, device) plan: relations + constraints uploaded, workspace bound."""
 
     def __init__(self, obj_types, n_obj, rank, relations, thetas, variant, dtype='f64',
-                 target=None, engine=None, runtime=None, part=None):
+                 target=None, engine=None, runtime=None, part=None, stream=None):
         """relations: list of (row_type, col_type, ndarray, mask-or-None[, block]);
         thetas: list of (type, ndarray).  `block` (row-block sharding, `_distributed.partition_rows`)
         = dict(row_begin, n_rows, absent, col_side, masked): data / mask then hold only the local rows
         (None when absent); `part` = (index, count) of this plan among the row-block plans."""
         self.rt = runtime or nat.get_runtime()
+        # `stream`: (raw handle, keep-alive) of a stream of its own for this plan (concurrent restarts);
+        # default: the runtime's engine stream
+        self._own_stream = stream
+        self.stream = stream[0] if stream is not None else self.rt.mem.stream
         self.dtype = nat.DTYPES[dtype] if isinstance(dtype, str) else dtype
         if self.dtype not in nat.NP_DTYPE:
             raise ValueError('unsupported engine dtype %r' % (dtype,))
@@ -174,7 +178,7 @@ class DevicePlan(object):
         self.rt.call('skf_plan_workspace_bytes', self.handle, C.byref(nbytes))
         self.workspace_bytes = nbytes.value
         self.ws = mem.empty(nbytes.value)
-        self.rt.call('skf_plan_bind_workspace', self.handle, self.ws.ptr, nbytes.value, mem.stream)
+        self.rt.call('skf_plan_bind_workspace', self.handle, self.ws.ptr, nbytes.value, self.stream)
         self._scalar = mem.empty(8)
 
     def release_relation_data(self):
@@ -189,7 +193,7 @@ class DevicePlan(object):
         if isinstance(G, DeviceMatrix):
             if G.shape != (self.n_obj[k], self.rank[k]):
                 raise ValueError('factor of %s has shape %r' % (t, G.shape))
-            self.rt.call('skf_set_factor', self.handle, k, G.buf.ptr, G.ld, self.rt.mem.stream)
+            self.rt.call('skf_set_factor', self.handle, k, G.buf.ptr, G.ld, self.stream)
             self.rt.mem.synchronize()
             return
         arr = np.ascontiguousarray(G, dtype=self.np_dtype)
@@ -197,14 +201,14 @@ class DevicePlan(object):
             raise ValueError('factor of %s has shape %r, expected %r'
                              % (t, arr.shape, (self.n_obj[k], self.rank[k])))
         buf = self.rt.mem.from_host(arr)
-        self.rt.call('skf_set_factor', self.handle, k, buf.ptr, arr.shape[1], self.rt.mem.stream)
+        self.rt.call('skf_set_factor', self.handle, k, buf.ptr, arr.shape[1], self.stream)
         self.rt.mem.synchronize()
 
     def get_factor(self, t):
         k = self.index[t]
         shape = (self.n_obj[k], self.rank[k])
         buf = self.rt.mem.empty(shape[0] * shape[1] * np.dtype(self.np_dtype).itemsize)
-        self.rt.call('skf_get_factor', self.handle, k, buf.ptr, shape[1], self.rt.mem.stream)
+        self.rt.call('skf_get_factor', self.handle, k, buf.ptr, shape[1], self.stream)
         self.rt.mem.synchronize()
         return self.rt.mem.to_host(buf, shape, self.np_dtype).astype(np.float64)
 
@@ -218,19 +222,23 @@ class DevicePlan(object):
         if arr.shape != shape:
             raise ValueError('backbone %d has shape %r, expected %r' % (rel, arr.shape, shape))
         buf = self.rt.mem.from_host(arr)
-        self.rt.call('skf_set_backbone', self.handle, rel, buf.ptr, shape[1], self.rt.mem.stream)
+        self.rt.call('skf_set_backbone', self.handle, rel, buf.ptr, shape[1], self.stream)
         self.rt.mem.synchronize()
 
     def get_backbone(self, rel):
         shape = self._backbone_shape(rel)
         buf = self.rt.mem.empty(shape[0] * shape[1] * np.dtype(self.np_dtype).itemsize)
-        self.rt.call('skf_get_backbone', self.handle, rel, buf.ptr, shape[1], self.rt.mem.stream)
+        self.rt.call('skf_get_backbone', self.handle, rel, buf.ptr, shape[1], self.stream)
         self.rt.mem.synchronize()
         return self.rt.mem.to_host(buf, shape, self.np_dtype).astype(np.float64)
 
+    def set_graph(self, enable=True):
+        """Replay one captured hipGraph per iteration (concurrent restarts: include/skfusion_hip.h)."""
+        self.rt.call('skf_plan_set_graph', self.handle, 1 if enable else 0)
+
     # -- the loop --------------------------------------------------------------------------
     def iterate(self, n_iters=1):
-        self.rt.call('skf_iterate', self.handle, int(n_iters), self.rt.mem.stream)
+        self.rt.call('skf_iterate', self.handle, int(n_iters), self.stream)
 
     def synchronize(self):
         self.rt.mem.synchronize()
@@ -243,9 +251,9 @@ class DevicePlan(object):
         self.rt.call('skf_accumulator_range', self.handle, C.byref(off), C.byref(nbytes))
         acc = self.rt.mem.as_tensor(self.ws, off.value, nbytes.value, self.np_dtype)
         for _ in range(int(n_iters)):
-            self.rt.call('skf_accumulate', self.handle, self.rt.mem.stream)
+            self.rt.call('skf_accumulate', self.handle, self.stream)
             _exchange(self.rt.mem, [acc])
-            self.rt.call('skf_apply_update', self.handle, self.rt.mem.stream)
+            self.rt.call('skf_apply_update', self.handle, self.stream)
 
     def _exchange_views(self):
         """Zero-copy tensor views of the four exchange ranges (None when empty)."""
@@ -258,7 +266,7 @@ class DevicePlan(object):
         return views
 
     def stage(self, which):
-        self.rt.call('skf_stage', self.handle, int(which), self.rt.mem.stream)
+        self.rt.call('skf_stage', self.handle, int(which), self.stream)
 
     def iterate_rows(self, n_iters=1, reduce=None):
         """Iterations of a row-block-sharded run (every rank lists all relations, each with its row
@@ -271,18 +279,18 @@ class DevicePlan(object):
         def exchange(*tensors):
             _exchange(mem, tensors, reduce)
         for _ in range(int(n_iters)):
-            call('skf_stage', h, nat.SKF_STAGE_CONTRACT, mem.stream)
+            call('skf_stage', h, nat.SKF_STAGE_CONTRACT, self.stream)
             exchange(xw, xq)
-            call('skf_stage', h, nat.SKF_STAGE_BACKBONE, mem.stream)
+            call('skf_stage', h, nat.SKF_STAGE_BACKBONE, self.stream)
             if xqm is not None:
                 exchange(xqm)
-            call('skf_stage', h, nat.SKF_STAGE_ACCUMULATE, mem.stream)
+            call('skf_stage', h, nat.SKF_STAGE_ACCUMULATE, self.stream)
             exchange(xed)
-            call('skf_stage', h, nat.SKF_STAGE_UPDATE, mem.stream)
+            call('skf_stage', h, nat.SKF_STAGE_UPDATE, self.stream)
 
     def relation_sqerr(self, rel):
         """sum (R - G_i S G_j^T)^2 for relation index `rel` (device reduction, one f64 D2H)."""
-        self.rt.call('skf_relation_sqerr', self.handle, rel, self._scalar.ptr, self.rt.mem.stream)
+        self.rt.call('skf_relation_sqerr', self.handle, rel, self._scalar.ptr, self.stream)
         self.rt.mem.synchronize()
         return float(self.rt.mem.to_host(self._scalar, (1,), np.float64)[0])
 
@@ -307,6 +315,31 @@ class DevicePlan(object):
             self.close()
         except Exception:
             pass
+
+
+def upload_graph(rel_list, theta_list, dtype, runtime=None):
+    """Relations / masks / constraints to HBM ONCE, as DeviceMatrix entries that any number of plans can
+    share (concurrent restarts of one graph): same conversions as DevicePlan applies to host arrays."""
+    rt = runtime or nat.get_runtime()
+    code = nat.DTYPES[dtype] if isinstance(dtype, str) else dtype
+    npd = nat.NP_DTYPE[code]
+    rels, thetas = [], []
+    for rel in rel_list:
+        i, j, data, mask = rel[:4]
+        if not isinstance(data, DeviceMatrix):
+            arr = np.ascontiguousarray(data, dtype=npd)
+            up = nat.to_bf16_bits(arr) if code == nat.SKF_BF16 else arr
+            data = DeviceMatrix(rt.mem.from_host(up), arr.shape)
+        if mask is not None and not isinstance(mask, DeviceMatrix):
+            m = np.ascontiguousarray(np.asarray(mask, dtype=bool).astype(np.uint8))
+            mask = DeviceMatrix(rt.mem.from_host(m), m.shape)
+        rels.append((i, j, data, mask) + tuple(rel[4:]))
+    for t, data in theta_list:
+        if not isinstance(data, DeviceMatrix):
+            arr = np.ascontiguousarray(data, dtype=npd)
+            data = DeviceMatrix(rt.mem.from_host(arr), arr.shape)
+        thetas.append((t, data))
+    return rels, thetas
 
 
 def iterate_rows_lockstep(plans, n_iters=1):

@@ -87,6 +87,7 @@ SIGNATURES = {
     'skf_set_backbone': (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
     'skf_get_backbone': (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
     'skf_iterate': (C.c_int, [_P, C.c_int32, _P]),
+    'skf_plan_set_graph': (C.c_int, [_P, C.c_int32]),
     'skf_accumulate': (C.c_int, [_P, _P]),
     'skf_apply_update': (C.c_int, [_P, _P]),
     'skf_accumulator_range': (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
@@ -178,6 +179,11 @@ class TorchDeviceMemory(object):
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
+
+    def new_stream(self):
+        """A further stream for a plan that runs concurrently with others (raw handle, keep-alive object)."""
+        s = self.torch.cuda.Stream(device=self.device)
+        return s.cuda_stream, s
 
     def stream_scope(self):
         """Context in which torch (RCCL collectives) works on the engine's stream: a collective issued

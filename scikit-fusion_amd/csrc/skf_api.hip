@@ -523,6 +523,7 @@ struct skf_plan {
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t graph_stream = nullptr;
     bool graph_failed = false;
+    bool graph_on = false;                 // skf_plan_set_graph
     // optional hipEvent timing of the relation contractions (skf_plan_set_profiling)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
@@ -1241,7 +1242,7 @@ static bool use_graph(skf_plan* p, hipStream_t st, int n_iters) {
     // opt-in (SKF_GRAPH=1): measured on dicty (50 launches / 0.5 ms iteration) the replay is not
     // faster than the asynchronous eager launches -- the iteration is bound by kernel time
     const char* on = getenv("SKF_GRAPH");
-    return on && atoi(on) != 0;
+    return p->graph_on || (on && atoi(on) != 0);
 }
 
 // Record one iteration into a hipGraph (the second-stream fork/join becomes graph edges).
@@ -1795,6 +1796,13 @@ int skf_iterate(skf_plan* p, int32_t n_iters, void* stream) {
             }
             for (; it < n_iters; ++it) iterate_fit(p, st);
         }
+    });
+}
+
+int skf_plan_set_graph(skf_plan* p, int32_t enable) {
+    return guarded([&] {
+        if (!p) SKF_FAIL(SKF_E_INVALID, "null plan");
+        p->graph_on = enable != 0;
     });
 }
 

@@ -127,6 +127,47 @@ def run_fit_sharded(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, in
         plan.close()
 
 
+def run_fits_concurrent(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, dtype, G0_list, engine,
+                        n_streams):
+    """The restarts of ONE graph on one GPU, `n_streams` of them at a time, each on a HIP stream of its own
+    -- the reference's `n_jobs` over `n_run` (joblib workers, dfmf.py:87-95) for graphs too small to
+    fill the chip: a single fit is then a chain of dependent few-microsecond launches, and several
+    chains interleave on the device.  The graph is uploaded once and shared; every plan replays one
+    captured hipGraph per iteration so that one host thread can feed all streams.  Returns
+    [(G, S)] in run order; results are identical to sequential runs (each plan is deterministic)."""
+    from ..._engine import upload_graph
+    obj_types = list(obj_types)
+    n_obj = count_objects(obj_types, R)
+    rt = nat.get_runtime()
+    rel_list, theta_list = upload_graph(flatten_relations(R, M), flatten_thetas(Theta), dtype, rt)
+    own_streams = hasattr(rt.mem, 'new_stream')
+    out = []
+    for k0 in range(0, len(G0_list), max(int(n_streams), 1)):
+        plans = []
+        try:
+            for G0 in G0_list[k0:k0 + max(int(n_streams), 1)]:
+                plan = DevicePlan(obj_types, n_obj, obj_type2rank, rel_list, theta_list, variant, dtype=dtype,
+                                  engine=engine, stream=rt.mem.new_stream() if own_streams else None)
+                plans.append(plan)
+                for t in obj_types:
+                    plan.set_factor(t, G0[t, t])
+                if own_streams:
+                    plan.set_graph(True)
+            for plan in plans:
+                plan.iterate(max_iter)              # asynchronous: the streams run side by side
+            rt.mem.synchronize()
+            for plan in plans:
+                G = {(t, t): plan.get_factor(t) for t in obj_types}
+                S = {}
+                for k, rel in enumerate(rel_list):
+                    S.setdefault((rel[0], rel[1]), []).append(plan.get_backbone(k))
+                out.append((G, S))
+        finally:
+            for plan in plans:
+                plan.close()
+    return out
+
+
 def run_fit(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type, stopping,
             stopping_system, verbose, compute_err, callback, random_state, dtype, G0, engine):
     """Shared driver of dfmf / dfmc: the body of the reference loops (_dfmf.py:212-322,

@@ -7,7 +7,7 @@ import numpy as np
 from ..base import FusionFit
 from . import _dfmc
 from ..._distributed import my_runs, gather_runs
-from .dfmf import graph_matrices, store_runs, initial_factors, _random_state
+from .dfmf import graph_matrices, store_runs, initial_factors, _random_state, concurrent_streams
 
 __all__ = ['Dfmc']
 
@@ -37,6 +37,13 @@ class Dfmc(FusionFit):
                   random_state=self.random_state, n_jobs=self.n_jobs, dtype=self.dtype)
         if self.shard in ('relations', 'rows'):
             store_runs(self, [_dfmc.dfmc(G0=G0[k], shard=self.shard, **kw) for k in range(self.n_run)])
+            return self
+        n_streams = concurrent_streams(self)
+        if n_streams:                                   # n_jobs restarts side by side on this GPU
+            from ... import _native as nat
+            from ._dfmf import run_fits_concurrent
+            store_runs(self, run_fits_concurrent(nat.SKF_DFMC, R, M, Theta, object_types, rank, self.max_iter,
+                                                 self.dtype, G0, None, n_streams))
             return self
         local = {k: _dfmc.dfmc(G0=G0[k], **kw) for k in my_runs(self.n_run)}
         store_runs(self, gather_runs(local, self.n_run))

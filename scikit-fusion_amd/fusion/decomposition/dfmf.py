@@ -60,6 +60,23 @@ def initial_factors(R, object_types, rank, init_type, random_state, n_run):
             for _ in range(n_run)]
 
 
+def concurrent_streams(fuser):
+    """`n_jobs` -> how many of the `n_run` restarts share this GPU concurrently, each on a stream of
+    its own (0: one after the other).  The reference hands the restarts to `n_jobs` joblib workers
+    (dfmf.py:87-95); here they stay in one process.  Only the plain loop qualifies (no callback /
+    stopping / error logging, which need the host every iteration), and a process group shares
+    the restarts out over the GPUs instead."""
+    from ..._distributed import world
+    if fuser.n_run < 2 or fuser.callback or fuser.stopping or fuser.stopping_system or fuser.compute_err:
+        return 0
+    if fuser.shard != 'runs' or world()[1] > 1:
+        return 0
+    nj = fuser.n_jobs
+    if nj is None or nj in (0, 1):
+        return 0
+    return min(fuser.n_run, 16 if nj < 0 else int(nj), 16)
+
+
 def store_runs(fuser, runs):
     """(G, S) per run -> factors_[object_type][run], backbones_[relation][run]
     (dfmf.py:97-105)."""
@@ -79,7 +96,8 @@ class Dfmf(FusionFit):
 
     Parameters (identical to the reference): max_iter=100, init_type='random_c', n_run=1,
     stopping=None, stopping_system=None, verbose=0, compute_err=False, callback=None,
-    random_state=None, n_jobs=1.  Additions: dtype='f64' | 'f32' | 'bf16' (device arithmetic),
+    random_state=None, n_jobs=1 (here: that many restarts run concurrently on streams of one GPU;
+    results do not depend on it).  Additions: dtype='f64' | 'f32' | 'bf16' (device arithmetic),
     shard='runs' | 'relations' | 'rows' (what a torch.distributed process group shares out: whole
     restarts -- no collective; the relations of each restart -- one all-reduce per iteration; or
     balanced row blocks of the relations -- all-reduces of W, Q and E / D per iteration).
@@ -105,6 +123,12 @@ class Dfmf(FusionFit):
                   random_state=self.random_state, n_jobs=self.n_jobs, dtype=self.dtype)
         if self.shard in ('relations', 'rows'):                   # all GPUs cooperate on every restart
             store_runs(self, [_dfmf.dfmf(G0=G0[k], shard=self.shard, **kw) for k in range(self.n_run)])
+            return self
+        n_streams = concurrent_streams(self)
+        if n_streams:                                   # n_jobs restarts side by side on this GPU
+            from ... import _native as nat
+            store_runs(self, _dfmf.run_fits_concurrent(nat.SKF_DFMF, R, None, Theta, object_types, rank,
+                                                       self.max_iter, self.dtype, G0, None, n_streams))
             return self
         local = {k: _dfmf.dfmf(G0=G0[k], **kw)
                  for k in my_runs(self.n_run)}          # one restart per GPU when distributed

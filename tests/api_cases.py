@@ -184,3 +184,24 @@ def error_paths():
         except DataFusionError:
             pass
     assert 'Dfmf(max_iter=1' in repr(fuser)
+
+
+def n_jobs_concurrent_restarts_equal_sequential(cls):
+    """n_jobs > 1: the restarts run on streams of their own (one uploaded graph, one captured hipGraph per
+    plan); every run must equal the one-after-the-other result bit for bit."""
+    rs = np.random.RandomState(5)
+    t1, t2, t3 = ObjectType('A', 6), ObjectType('B', 5), ObjectType('C', 4)
+    R12 = rs.rand(40, 30)
+    if cls is Dfmc:
+        R12 = np.ma.masked_array(R12, mask=rs.rand(40, 30) > 0.8)
+    rels = [Relation(R12, t1, t2), Relation(rs.rand(40, 20), t1, t3),
+            Relation(rs.rand(30, 20), t2, t3), Relation(-0.02 * (rs.rand(30, 30) > 0.9), t2, t2)]
+    graph = FusionGraph(rels)
+    seq = cls(max_iter=8, n_run=5, random_state=3, n_jobs=1).fuse(graph)
+    par = cls(max_iter=8, n_run=5, random_state=3, n_jobs=3).fuse(graph)
+    for t in (t1, t2, t3):
+        for a, b in zip(seq.factor(t), par.factor(t)):
+            np.testing.assert_array_equal(a, b)
+    for r in rels[:3]:
+        for a, b in zip(seq.backbone(r), par.backbone(r)):
+            np.testing.assert_array_equal(a, b)

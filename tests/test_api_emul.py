@@ -41,3 +41,8 @@ def test_pipeline_transform_chain_and_errors():
     A.pipeline_and_transform(full=False)
     A.error_paths()
     A.blockwise_completion()
+
+
+@pytest.mark.parametrize('cls', [Dfmf, Dfmc])
+def test_n_jobs_concurrent_restarts(cls):
+    A.n_jobs_concurrent_restarts_equal_sequential(cls)

@@ -52,3 +52,8 @@ def test_f32_engine_reaches_the_same_fixed_point():
     rel = Relation(R12, t1, t2)
     fuser = Dfmf(init_type='random', random_state=rnds, dtype='f32').fuse(FusionGraph([rel]))
     np.testing.assert_almost_equal(fuser.complete(rel), R12, decimal=4)
+
+
+@pytest.mark.parametrize('cls', [Dfmf, Dfmc])
+def test_n_jobs_concurrent_restarts(cls):
+    A.n_jobs_concurrent_restarts_equal_sequential(cls)

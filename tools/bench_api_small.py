@@ -24,6 +24,13 @@ def main():
         dt = (time.perf_counter() - t0) / 5
         print('README graph, Dfmf(max_iter=100, dtype=%s).fuse: %.1f ms per fit (%.3f ms per iteration incl. host set-up)'
               % (dtype, dt * 1e3, dt * 10))
+    for n_jobs in (1, 2, 5, 10):
+        fusion.Dfmf(max_iter=5, n_run=10, n_jobs=n_jobs, random_state=0).fuse(graph)     # warm-up
+        t0 = time.perf_counter()
+        fusion.Dfmf(max_iter=100, n_run=10, n_jobs=n_jobs, random_state=0).fuse(graph)
+        dt = time.perf_counter() - t0
+        print('README graph, Dfmf(max_iter=100, n_run=10, n_jobs=%d).fuse: %.1f ms (%.1f ms per restart)'
+              % (n_jobs, dt * 1e3, dt * 100))
     R = {('a', 'b'): [R12], ('a', 'c'): [R13], ('b', 'c'): [R23]}
     t0 = time.perf_counter()
     orc.dfmf(R, {}, ['a', 'b', 'c'], {'a': 10, 'b': 20, 'c': 30}, max_iter=100, init_type='random_c',
