@@ -132,8 +132,8 @@ def run_fits_concurrent(variant, R, M, Theta, obj_types, obj_type2rank, max_iter
     """The restarts of ONE graph on one GPU, `n_streams` of them at a time, each on a HIP stream of its own
     -- the reference's `n_jobs` over `n_run` (joblib workers, dfmf.py:87-95) for graphs too small to
     fill the chip: a single fit is then a chain of dependent few-microsecond launches, and several
-    chains interleave on the device.  The graph is uploaded once and shared; every plan replays one
-    captured hipGraph per iteration so that one host thread can feed all streams.  Returns
+    chains interleave on the device.  The graph is uploaded once and shared; one host thread per
+    stream issues the launches.  Returns
     [(G, S)] in run order; results are identical to sequential runs (each plan is deterministic)."""
     from ..._engine import upload_graph
     obj_types = list(obj_types)
@@ -151,10 +151,27 @@ def run_fits_concurrent(variant, R, M, Theta, obj_types, obj_type2rank, max_iter
                 plans.append(plan)
                 for t in obj_types:
                     plan.set_factor(t, G0[t, t])
-                if own_streams:
-                    plan.set_graph(True)
-            for plan in plans:
-                plan.iterate(max_iter)              # asynchronous: the streams run side by side
+            if own_streams and len(plans) > 1:
+                # one host thread per stream feeds the launches (ctypes releases the GIL inside skf_iterate;
+                # a plan is only ever touched by its own thread); the streams run side by side
+                import threading
+                errors = []
+
+                def drive(plan):
+                    try:
+                        plan.iterate(max_iter)
+                    except Exception as exc:          # surfaced after the join
+                        errors.append(exc)
+                threads = [threading.Thread(target=drive, args=(plan,)) for plan in plans]
+                for th in threads:
+                    th.start()
+                for th in threads:
+                    th.join()
+                if errors:
+                    raise errors[0]
+            else:
+                for plan in plans:
+                    plan.iterate(max_iter)
             rt.mem.synchronize()
             for plan in plans:
                 G = {(t, t): plan.get_factor(t) for t in obj_types}
