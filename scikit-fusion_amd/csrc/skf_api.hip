@@ -1294,7 +1294,7 @@ static void prepare_transform(skf_plan* p, hipStream_t st) {
         const int ni = (int)ti.n, nj = (int)tj.n, ci = ti.c, cj = tj.c;
         if (r.row == p->target) {             // _dfmf.py:392-405
             GemmArgs g = gemm_args(r.R, r.ldr, 1, tj.G.ptr, cj, 1, r.P.ptr, cj, ni, cj, nj, EPI_STORE, 0);
-            relation_gemm(p, g, st);
+            relation_gemm(p, g, st, &r, false);
             g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, tt.Ec.ptr, ci, ni, ci, cj, EPI_SPLIT_ACC, 0);
             g.C2 = tt.Dc.ptr;
             mixed_gemm(p, g, st);
@@ -1302,7 +1302,7 @@ static void prepare_transform(skf_plan* p, hipStream_t st) {
                                  false, st);
         } else {                              // _dfmf.py:407-419
             GemmArgs g = gemm_args(r.R, 1, r.ldr, ti.G.ptr, ci, 1, r.Q.ptr, ci, nj, ci, ni, EPI_STORE, 0);
-            relation_gemm(p, g, st);
+            relation_gemm(p, g, st, &r, true);
             g = gemm_args(r.Q.ptr, ci, 1, r.S.ptr, cj, 1, tt.Ec.ptr, cj, nj, cj, ci, EPI_SPLIT_ACC, 0);
             g.C2 = tt.Dc.ptr;
             mixed_gemm(p, g, st);
@@ -1324,6 +1324,7 @@ static void iterate_transform(skf_plan* p, hipStream_t st) {
     mixed_gemm(p, g, st);
     theta_terms(p, st);
     mult_update(p, tt, st);
+    if (!p->thetas.empty()) refresh_gt(p, tt, st);      // SKF_BF16: the constraint products read the stored G^T
 }
 
 }  // namespace skf
@@ -1347,8 +1348,6 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             SKF_FAIL(SKF_E_INVALID, "bad relation / constraint arrays");
         if (opt->dtype != SKF_F64 && opt->dtype != SKF_F32 && opt->dtype != SKF_BF16)
             SKF_FAIL(SKF_E_INVALID, "unknown dtype %d", opt->dtype);
-        if (opt->dtype == SKF_BF16 && opt->variant == SKF_TRANSFORM)
-            SKF_FAIL(SKF_E_INVALID, "SKF_BF16 is implemented for SKF_DFMF / SKF_DFMC (use SKF_F32 for the fold-in)");
         if (opt->dtype == SKF_BF16 && opt->engine != SKF_ENGINE_MFMA)
             SKF_FAIL(SKF_E_INVALID, "SKF_BF16 needs the MFMA engine");
         if (opt->variant < SKF_DFMF || opt->variant > SKF_TRANSFORM) SKF_FAIL(SKF_E_INVALID, "bad variant");

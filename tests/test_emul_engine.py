@@ -138,6 +138,11 @@ def test_transform_fold_in(init):
     Gi32 = _dfmf.transform(Rn, {('t1', 't1'): [z['theta_t1']]}, 't1', rank, G, S, max_iter=100,
                            G0=z[init + '/G0'], dtype='f32')
     assert relerr(Gi32, z['%s/G_it99' % init]) < 1e-4
+    # bf16 engine: bf16 new relations / constraint halves / frozen G^T in the one-off contractions,
+    # f32 masters (measured 2.0e-3 .. 2.1e-3 against the f64 golden)
+    Gib = _dfmf.transform(Rn, {('t1', 't1'): [z['theta_t1']]}, 't1', rank, G, S, max_iter=100,
+                          G0=z[init + '/G0'], dtype='bf16')
+    assert relerr(Gib, z['%s/G_it99' % init]) < 1e-2
 
 
 def test_c2_dicty_first_iteration_f64():
@@ -180,9 +185,6 @@ def test_bf16_engine_against_oracle_on_bf16_rounded_relations():
         want = np.linalg.norm(Rb[i, j][0] - Gd[i, i] @ plan.get_backbone(k) @ Gd[j, j].T) ** 2
         assert abs(plan.relation_sqerr(k) - want) < 1e-4 * want
     plan.close()
-    with pytest.raises(nat.SkfNativeError):          # the fold-in has no bf16 engine
-        _dfmf.transform({('t1', 't2'): [R['t1', 't2'][0][:3]]}, {}, 't1', rank, G, S, max_iter=1, dtype='bf16',
-                        G0=G0['t1', 't1'][:3])
 
 
 def test_bf16_engine_odd_sizes_and_wide_rank():
