@@ -18,14 +18,15 @@ def main():
     n = {'t1': n_new, 't2': 100000, 't3': 40000}
     rank = {'t1': 128, 't2': 256, 't3': 256}
     types = ['t1', 't2', 't3']
-    for dtype in ('f32', 'f64'):
+    for dtype in ('bf16', 'f32', 'f64'):
+        master = 'f32' if dtype == 'bf16' else dtype
         rels = [('t1', 't2', fill_uniform((n['t1'], n['t2']), 0, dtype), None),
                 ('t1', 't3', fill_uniform((n['t1'], n['t3']), 1, dtype), None)]
         plan = DevicePlan(types, n, rank, rels, [], nat.SKF_TRANSFORM, dtype=dtype, target='t1')
         for k, t in enumerate(types):
-            plan.set_factor(t, fill_uniform((n[t], rank[t]), 100 + k, dtype))
+            plan.set_factor(t, fill_uniform((n[t], rank[t]), 100 + k, master))
         for k, (i, j) in enumerate((('t1', 't2'), ('t1', 't3'))):
-            S = fill_uniform((rank[i], rank[j]), 200 + k, dtype, scale=1e-3)
+            S = fill_uniform((rank[i], rank[j]), 200 + k, master, scale=1e-3)
             plan.rt.call('skf_set_backbone', plan.handle, k, S.buf.ptr, S.ld, plan.rt.mem.stream)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
