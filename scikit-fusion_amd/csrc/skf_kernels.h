@@ -1880,6 +1880,15 @@ __global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) {
 // severely ill-conditioned Gram matrices, reference tests/test_n_run.py:14).
 // Scratch: L lives in e.Vs, X in e.V (both are only written by the Jacobi path afterwards).
 // ------------------------------------------------------------------------------------------
+// Pivot test of the fast path.  Cholesky is invariant under diagonal scaling, so a pivot is judged
+// against ITS OWN diagonal entry: p_k / a_kk = sin^2 of the angle between factor column k and the span
+// of the columns before it -- below rel_thr the columns are (nearly) dependent and the exact
+// pseudo-inverse semantics of the eigen path are needed.  A mere difference in scale between the
+// columns (a latent dimension 1e-5 times smaller than the largest) stays on the fast path; only
+// a diagonal entry so small that scipy.linalg.pinv's cut-off (n * eps * sigma_max, sigma_max <= n *
+// max diag) could truncate its direction is handed to the eigen path.
+__device__ __forceinline__ double chol_diag_floor(int n) { return (double)n * (double)n * 2.220446049250313e-16; }
+
 __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_kernel(EighArgs e, double rel_thr) {
     __shared__ double col[EIGH_MAXN];
     __shared__ double red[EIGH_THREADS / 64];
@@ -1910,11 +1919,12 @@ __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_kernel(EighArgs e, 
         s_max = s;
     }
     __syncthreads();
-    const double thr = rel_thr * s_max;
+    const double floor_ = chol_diag_floor(n) * s_max;
 
     for (int k = 0; k < n; ++k) {
         const double piv = L[k * ld + k];
-        if (!(piv > thr) || !(piv > 0.0)) {          // uniform: every thread reads the same word
+        const double akk = A[k * ld + k];
+        if (!(akk > floor_) || !(piv > rel_thr * akk) || !(piv > 0.0)) {   // uniform: every thread reads the same words
             if (tid == 0) e.chol_ok[b] = 0;
             return;
         }
@@ -1981,12 +1991,13 @@ __global__ __launch_bounds__(64) void chol_inverse_small_kernel(EighArgs e, doub
         mx = fabs(M[i * LD + i]);
     }
     for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
-    const double thr = rel_thr * mx;
+    const double floor_ = chol_diag_floor(n) * mx;
     __syncthreads();
 
     for (int k = 0; k < n; ++k) {
         const double piv = M[k * LD + k];
-        if (!(piv > thr) || !(piv > 0.0)) {          // uniform
+        const double akk = A[k * ld + k];
+        if (!(akk > floor_) || !(piv > rel_thr * akk) || !(piv > 0.0)) {   // uniform
             if (i == 0) e.chol_ok[b] = 0;
             return;
         }
@@ -2066,7 +2077,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_blocked_kernel(Eigh
         s_max = s;
     }
     __syncthreads();
-    const double thr = rel_thr * s_max;
+    const double floor_ = chol_diag_floor(n) * s_max;
 
     // ---------------- factorisation
     for (int kb = 0; kb < n; kb += NB) {
@@ -2079,7 +2090,8 @@ __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_blocked_kernel(Eigh
         __syncthreads();
         for (int k = 0; k < nb; ++k) {
             const double piv = D[k * (NB + 1) + k];
-            if (!(piv > thr) || !(piv > 0.0)) {          // uniform: same LDS word for every thread
+            const double akk = A[(kb + k) * ld + kb + k];
+            if (!(akk > floor_) || !(piv > rel_thr * akk) || !(piv > 0.0)) {   // uniform: same words for every thread
                 if (tid == 0) e.chol_ok[b] = 0;
                 return;
             }

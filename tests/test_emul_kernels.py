@@ -257,6 +257,31 @@ def test_pinv_rank_deficient_truncates_like_scipy(rt):
     assert np.isfinite(got32).all()
 
 
+@pytest.mark.parametrize('n', [12, 40, 70])
+def test_pinv_badly_scaled_columns_match_scipy(rt, n):
+    """Latent dimensions of very different scale (column norms down to 1e-5 of the largest: diagonal of
+    the Gram matrix spread over 1e-10) but independent: the pivot test of the Cholesky fast path is
+    relative to each pivot's own diagonal, so these stay on it; scipy inverts them too (sigma_min /
+    sigma_max ~ 1e-10 is far above its cut-off).  Compared in the equilibrated metric."""
+    import os
+    import scipy.linalg as spla
+    rs = np.random.RandomState(n)
+    scale = 10.0 ** (-5.0 * rs.rand(n))
+    scale[0], scale[-1] = 1.0, 1e-5
+    G = rs.rand(6 * n, n) * scale
+    A = G.T @ G
+    want = spla.pinv(A)
+    d = np.sqrt(np.diag(A))
+    for env in ({}, {'SKF_CHOL_NO_SMALL': '1'}, {'SKF_CHOL_UNBLOCKED': '1'}):
+        os.environ.update(env)
+        try:
+            got = run_pinv(rt, nat.SKF_F64, A)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert relerr(got * np.outer(d, d), want * np.outer(d, d)) < 1e-8, env
+
+
 def test_pinv_zero_and_diagonal(rt):
     got = run_pinv(rt, nat.SKF_F64, np.zeros((6, 6)))
     assert (got == 0).all()
