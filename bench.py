@@ -19,6 +19,15 @@ The JSON line also carries
                  hipEvent duration inside the timed region; bound = matrix cores of the dtype.
   cpu_baseline : the NumPy oracle (reference operation order, fp64, all host cores) timed on a
                  bounded 1/10-linear-scale sample of the same graph and scaled to full size.
+
+Options beyond the driver's contract (defaults = the metric's configuration):
+  --dtype bf16|f32|f64      engine (default bf16, the configuration the metric is quoted on)
+  --mode restarts|relations|rows   N > 1: independent restarts (default, weak scaling) or ONE fit
+                            sharded by whole relations / balanced row blocks (strong scaling,
+                            RCCL all-reduces between the stages)
+  --workload c3|c5          c5 = BASELINE configs[4]: Dfmc, MovieLens-style 6-relation graph
+  --data uniform|planted    planted: rank-structured relations + 1 % noise (RMSE discriminates)
+  --scale x                 linear scale of the object counts (smoke runs)
 """
 import argparse
 import json
