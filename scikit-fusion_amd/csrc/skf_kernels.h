@@ -1747,6 +1747,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) {
     __shared__ int pp[EIGH_MAXN / 2], qq[EIGH_MAXN / 2];
     __shared__ double red[EIGH_THREADS / 64];
     __shared__ double s_off, s_diag;
+    __shared__ int s_rot;                     // some pair rotated in the current sweep
     const int b = blockIdx.x;
     if (e.chol_ok[b]) return;                 // uniform: fast path already inverted this matrix
     const int n = e.n[b];
@@ -1797,9 +1798,11 @@ __global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) {
             double s = 0.0;
             for (int i = 0; i < nt / 64; ++i) s += red[i];
             s_diag = s;
+            s_rot = 0;
         }
         __syncthreads();
         if (s_off <= 1e-30 * s_diag || s_off == 0.0) break;       // uniform across the block
+        const double s_dnorm = sqrt(s_diag);
 
         for (int round = 0; round < n - 1; ++round) {
             // phase 1: rotation angles of the n/2 disjoint pairs
@@ -1808,11 +1811,18 @@ __global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) {
                 jacobi_pair(round, k, n, p, q);
                 const double app = A[p * n + p], aqq = A[q * n + q], apq = A[p * n + q];
                 double c = 1.0, s = 0.0;
-                if (apq != 0.0) {
+                // threshold Jacobi: an off-diagonal entry below 1e-2 * eps of the diagonal's norm is left
+                // alone.  That is 100x under the absolute accuracy eps * ||A|| of the LAPACK SVD behind
+                // scipy.linalg.pinv and far under the cut-off n * eps * sigma_max; it is what lets a
+                // rank-deficient Gram matrix converge: its null-space block consists of rounding noise
+                // at eps * ||A|| that cyclic rotations never bring to exactly zero (30 sweeps before,
+                // now the usual 8-10).  Pairs that do not rotate move no data.
+                if (apq != 0.0 && fabs(apq) > 2.2e-18 * s_dnorm) {
                     const double tau = (aqq - app) / (2.0 * apq);
                     const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
                     c = 1.0 / sqrt(1.0 + t * t);
                     s = t * c;
+                    if (s != 0.0) s_rot = 1;      // benign race: every writer stores 1
                 }
                 cs[k] = c; sn[k] = s; pp[k] = p; qq[k] = q;
             }
@@ -1822,6 +1832,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) {
                 const int r = idx / half, k = idx % half;
                 const int p = pp[k], q = qq[k];
                 const double c = cs[k], s = sn[k];
+                if (s == 0.0) continue;
                 const double arp = A[r * n + p], arq = A[r * n + q];
                 A[r * n + p] = c * arp - s * arq;
                 A[r * n + q] = s * arp + c * arq;
@@ -1835,12 +1846,14 @@ __global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) {
                 const int k = idx / n, col = idx % n;
                 const int p = pp[k], q = qq[k];
                 const double c = cs[k], s = sn[k];
+                if (s == 0.0) continue;
                 const double apc = A[p * n + col], aqc = A[q * n + col];
                 A[p * n + col] = c * apc - s * aqc;
                 A[q * n + col] = s * apc + c * aqc;
             }
             __syncthreads();
         }
+        if (!s_rot) break;                       // a whole sweep without a rotation: converged (uniform)
     }
 
     // eigenvalues, cut-off, scaled eigenvectors
