@@ -346,7 +346,7 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
         const char* gl = getenv("SKF_BF16_GLDS");          // "0" selects register staging
         const bool glds = !(gl && atoi(gl) == 0);
         const char* sg = getenv("SKF_BF16_STAGES");        // "2" disables the 3-stage ring (BN = 128)
-        const bool three = glds && !mf32 && !(sg && atoi(sg) == 2);
+        const bool three = glds && !(sg && atoi(sg) == 2);
 #define SKF_V2_LAUNCH(BN_, TAG_, MF_, GL_, NS_)                                                                   \
     do {                                                                                                          \
         const int smem_ = (NS_ * 256 + ((NS_ == 3 && BN_ == 256) ? 2 : NS_) * BN_) * 8 * 16;                      \
@@ -382,6 +382,8 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
         else if (pipe && bn == 128) SKF_V3_LAUNCH(128, 0);
         else if (pipe && relation) SKF_V3_LAUNCH(256, 1);
         else if (pipe) SKF_V3_LAUNCH(256, 0);
+        else if (three && mf32 && bn == 128) SKF_V2_LAUNCH(128, 0, true, true, 3);
+        else if (three && mf32) SKF_V2_LAUNCH(256, 0, true, true, 3);
         else if (three && bn == 128 && relation) SKF_V2_LAUNCH(128, 1, false, true, 3);
         else if (three && bn == 128) SKF_V2_LAUNCH(128, 0, false, true, 3);
         else if (three && relation) SKF_V2_LAUNCH(256, 1, false, true, 3);

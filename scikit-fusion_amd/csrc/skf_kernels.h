@@ -996,6 +996,24 @@ __device__ __forceinline__ int swz_chunk32(int row, int chunk) { return row * 8 
 #ifndef SKF_MFMA_PRIO
 #define SKF_MFMA_PRIO 0
 #endif
+// 1: LDS-DMA pieces issued between the MFMA groups; 3: + fragments of the second K half read up front
+#ifndef SKF_V2_SCHED
+#define SKF_V2_SCHED 0
+#endif
+// bound-finding probe builds (tools/probe_bounds.sh; never defined in the product build):
+//   SKF_PROBE_NOMFMA  the K loop only moves tiles (LDS-DMA, waits, barriers)      -> ingest-only time
+//   SKF_PROBE_NODMA_A / SKF_PROBE_NODMA_B  the loop re-uses the tiles of the prologue -> time without
+//                     the relation stream / without the G^T stream
+#if defined(SKF_PROBE_NODMA_A)
+#define SKF_PROBE_A(x) (void)0
+#else
+#define SKF_PROBE_A(x) x
+#endif
+#if defined(SKF_PROBE_NODMA_B)
+#define SKF_PROBE_B(x) (void)0
+#else
+#define SKF_PROBE_B(x) x
+#endif
 template <int BN, int TAG, bool MF32, bool GLDS, int NSTAGE>
 __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     constexpr int BM = 256, BK = 64;
@@ -1101,6 +1119,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
         }
     };
 
+    auto dma_A1 = [&](int k0, int buf, int p) {           // piece p of dma_A
+        u32x4* Ad = smem + buf * ASZ;
+        const int blk = wave * (BM / 64) + p;
+        const int row = blk * 8 + rr;
+        const int c = MF32 ? (pc ^ ((row >> 1) & 7)) : (pc ^ (row & 7));
+        const int m = bm0 + row;
+        const int mc = m < g.M ? m : g.M - 1;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(g.A + (int64_t)mc * g.lda + (int64_t)(k0 >> 6) * g.a_kstep + c * 8),
+            (__attribute__((address_space(3))) void*)(Ad + blk * 64), 16, 0, SKF_A_AUX);
+    };
+    auto dma_B1 = [&](int k0, int buf, int p) {           // piece p of dma_B
+        u32x4* Bd = smem + AST * ASZ + buf * BSZ;
+        const int blk = wave * (BN / 64) + p;
+        const int row = blk * 8 + rr;
+        const int c = MF32 ? (pc ^ ((row >> 1) & 7)) : (pc ^ (row & 7));
+        const int n = bn0 + row;
+        const int nc = n < g.N ? n : g.N - 1;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + (int64_t)(k0 >> 6) * g.b_kstep + c * 8),
+            (__attribute__((address_space(3))) void*)(Bd + blk * 64), 16, 0, SKF_B_AUX);
+    };
+
     constexpr int PWA = BM / 64, PWB = BN / 64;          // LDS-DMA instructions per wave and K tile
     // instructions allowed to stay outstanding when the NEXT tile must be complete
     constexpr int KEEP = (BST == 3) ? (PWA + PWB) : PWA;
@@ -1136,16 +1177,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
         const int cur = kt % AST;
         const int curb = kt % BST;
         const bool more = (kt + 1 < nkt);
-        if constexpr (NSTAGE == 3) {
+        if constexpr (NSTAGE == 3 && SKF_V2_SCHED != 0 && !MF32) {
+            // the pieces are issued between the MFMA groups below
+        } else if constexpr (NSTAGE == 3) {
             // every buffer refilled here was last read in iteration kt-1 and released by its barrier
             if constexpr (BST == 3) {
                 if (kt + 2 < nkt) {
-                    dma_A(kz0 + (kt + 2) * BK, (kt + 2) % 3);
-                    dma_B(kz0 + (kt + 2) * BK, (kt + 2) % 3);
+                    SKF_PROBE_A(dma_A(kz0 + (kt + 2) * BK, (kt + 2) % 3));
+                    SKF_PROBE_B(dma_B(kz0 + (kt + 2) * BK, (kt + 2) % 3));
                 }
             } else {
-                if (more) dma_B(kz0 + (kt + 1) * BK, (kt + 1) & 1);          // B first ...
-                if (kt + 2 < nkt) dma_A(kz0 + (kt + 2) * BK, (kt + 2) % 3);  // ... newest = A(kt+2)
+                if (more) SKF_PROBE_B(dma_B(kz0 + (kt + 1) * BK, (kt + 1) & 1));          // B first ...
+                if (kt + 2 < nkt) SKF_PROBE_A(dma_A(kz0 + (kt + 2) * BK, (kt + 2) % 3));  // ... newest = A(kt+2)
             }
         } else if (more) {
             if constexpr (GLDS) {
@@ -1176,6 +1219,60 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
             }
         } else {
             if (SKF_MFMA_PRIO) __builtin_amdgcn_s_setprio(SKF_MFMA_PRIO);
+#ifndef SKF_PROBE_NOMFMA
+            if constexpr (NSTAGE == 3 && SKF_V2_SCHED != 0) {
+                // scheduled form: the LDS-DMA pieces of the tiles in flight are issued BETWEEN the groups of
+                // MFMAs (one piece per 16-row block of the wave tile) instead of in one burst after the
+                // barrier, and (SKF_V2_SCHED & 2) the fragments of the second K half are read before the
+                // MFMAs of the first.  Order of the pieces: every B piece of tile kt+1 before the first A
+                // piece of tile kt+2 (BST == 2), so that the counted vmcnt below still means "tile kt+1 landed".
+                constexpr int NPIECE = PWA + PWB;
+                auto piece = [&](int q) {
+                    if (q >= NPIECE) return;
+                    if constexpr (BST == 3) {
+                        if (kt + 2 < nkt) {
+                            if (q < PWA) dma_A1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q);
+                            else dma_B1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q - PWA);
+                        }
+                    } else {
+                        if (q < PWB) {
+                            if (more) dma_B1(kz0 + (kt + 1) * BK, (kt + 1) & 1, q);
+                        } else if (kt + 2 < nkt) {
+                            dma_A1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q - PWB);
+                        }
+                    }
+                };
+                bf16x8 a[2][4], b[2][NJ];
+                auto read_frags = [&](int ks) {
+                    const int chunk = 4 * ks + (lane >> 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        a[ks][i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        b[ks][j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
+                };
+                read_frags(0);
+                if constexpr ((SKF_V2_SCHED & 6) == 2) read_frags(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if constexpr ((SKF_V2_SCHED & 2) == 0) {
+                        if (ks == 1) read_frags(1);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(ks * 4 + i);
+                        if constexpr ((SKF_V2_SCHED & 6) == 6) {
+                            if (ks == 0 && i == 0) read_frags(1);      // lands under the next 3 groups
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int chunk = 4 * ks + (lane >> 4);
@@ -1192,6 +1289,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                     for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+            }
+#endif
             if (SKF_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
         }
         if constexpr (NSTAGE == 3) {

@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--shapes', default='P12,Q12')
     ap.add_argument('--tiles', default='128,256')
     ap.add_argument('--splits', default='0')
+    ap.add_argument('--zero', action='store_true', help='all-zero operands (power / DVFS probe)')
     args = ap.parse_args()
     import torch
     import skfusion_amd._native as nat
@@ -31,6 +32,9 @@ def main():
         mp, npad = (M + 255) // 256 * 256, (N + 255) // 256 * 256
         A = fill_uniform((mp, Kp), 1, 'bf16')
         Bt = fill_uniform((npad, Kp), 2, 'bf16')
+        if args.zero:
+            A = fill_uniform((mp, Kp), 1, 'bf16', scale=0.0)
+            Bt = fill_uniform((npad, Kp), 2, 'bf16', scale=0.0)
         C = rt.mem.empty(M * N * 4)
         ws = rt.mem.empty(32 * M * N * 4)
         for tile in args.tiles.split(','):
@@ -50,7 +54,7 @@ def main():
                 e1.record(rt.mem._stream)
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / args.reps
-                print('%s M=%d N=%d K=%d tile=%s splits=%d : %.3f ms  %.0f TFLOP/s  (A stream %.2f TB/s)'
+                print(('zero ' if args.zero else '') + '%s M=%d N=%d K=%d tile=%s splits=%d : %.3f ms  %.0f TFLOP/s  (A stream %.2f TB/s)'
                       % (name, M, N, K, tile, sp, ms, 2.0 * M * N * K / ms / 1e9, M * Kp * 2 / ms / 1e9), flush=True)
 
 

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Builds probe variants of the library (compile-time switches of skf_kernels.h) next to the product build:
+#   tools/build_probe_libs.sh name:-Dflag[,-Dflag...] ...
+cd "$(dirname "$0")/.."
+for spec in "$@"; do
+  name=${spec%%:*}; flags=${spec#*:}; [ "$flags" = "$spec" ] && flags=""
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I include ${flags//,/ } scikit-fusion_amd/csrc/skf_api.hip -o scikit-fusion_amd/lib/libskf_$name.so &
+done
+wait
+ls -la scikit-fusion_amd/lib/
