@@ -57,11 +57,17 @@ typedef struct {
 typedef struct {
     int32_t row_type, col_type; /* indices into the type array; row_type != col_type */
     const void* data;           /* n_row x n_col, engine dtype (R[(i,j)][l], dfmf.py:82-85);
-                                   SKF_BF16: bf16 (uint16) data, copied (padded + transposed)
-                                   at bind time and not referenced afterwards */
+                                   SKF_BF16: bf16 (uint16) data, copied ONCE into a zero-padded
+                                   row-major layout at bind time (both contractions read that
+                                   one copy) and not referenced afterwards */
     int64_t ld;
-    const uint8_t* mask;        /* DFMC only: n_row x n_col bytes, !=0 = unknown entry
-                                   (M[(i,j)][l], dfmc.py:77-90); NULL = no mask */
+    const uint8_t* mask;        /* DFMC only (M[(i,j)][l], dfmc.py:77-90); NULL = no mask.
+                                   Default: n_row x n_col BYTES, !=0 = unknown entry, mask_ld in
+                                   bytes = entries.  SKF_REL_MASK_BITS: packed, one BIT per entry
+                                   (bit (c & 7) of byte mask[r * mask_ld + (c >> 3)], 1 = unknown),
+                                   mask_ld = bytes per row >= ceil(n_col / 8).  Either form is
+                                   converted to the engine's packed layout at bind time and not
+                                   referenced afterwards: an iteration reads 1 bit per entry */
     int64_t mask_ld;
     /* Row-block sharding of ONE relation over several processes: this process holds
      * rows [row_begin, row_begin + n_rows) of the relation; `data` / `mask` point at its first LOCAL
@@ -75,7 +81,8 @@ typedef struct {
 enum {
     SKF_REL_ABSENT = 1,       /* no local rows of this relation (its backbone / Q are still kept) */
     SKF_REL_NO_COL_SIDE = 2,  /* another process adds the column-side terms E_j, D_j of this relation */
-    SKF_REL_MASKED = 4        /* SKF_REL_ABSENT descriptors: the relation is masked where it lives */
+    SKF_REL_MASKED = 4,       /* SKF_REL_ABSENT descriptors: the relation is masked where it lives */
+    SKF_REL_MASK_BITS = 8     /* `mask` is packed, one bit per entry (see skf_relation_desc.mask) */
 };
 
 typedef struct {
@@ -178,7 +185,8 @@ int skf_exchange_range(const skf_plan* plan, int32_t which, size_t* offset, size
 
 /* sum over the relation of (R - G_i S G_j^T)^2 with the current (G, S), written as one f64 to
  * the DEVICE address `out` (reconstruction error of _dfmf.py:306-316 without materialising the
- * n_i x n_j product).  For DFMC the working copy (completed entries) is used. */
+ * n_i x n_j product).  For DFMC the working copy (completed entries) is used.  SKF_BF16: one pass
+ * over the stored bf16 relation, bf16-rounded G_i S and G_j on the matrix cores, f32 residual. */
 int skf_relation_sqerr(skf_plan* plan, int32_t rel, double* out, void* stream);
 
 /* Optional hipEvent timing of the two contractions that stream a relation matrix
@@ -217,6 +225,15 @@ int skf_gemm(int32_t dtype, int32_t engine, const skf_gemm_desc* desc, void* wor
 int skf_gemm_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, float* C, int64_t ldc,
                   int32_t M, int32_t N, int32_t Kp, int32_t splits, void* workspace,
                   size_t workspace_bytes, void* stream);
+
+/* The transposed-A form of the same contraction, C[M x N] (f32) = A[Kp x M]^T * Bt[N x Kp]^T: A is
+ * row-major [Kp][lda] with the OUTPUT rows along its columns (lda >= M, lda % 8 == 0, rows zero-filled
+ * up to Kp % 64 == 0).  This is Q = R^T G_i read from the row-major relation itself: the A tile lands in
+ * LDS as stored and the fragments are read transposed (ds_read_b64_tr_b16) -- no stored R^T
+ * (reference _dfmf.py:266 multiplies the strided view R.T the same way, without a copy). */
+int skf_gemm_bf16_tn(const void* A, int64_t lda, const void* Bt, int64_t ldb, float* C, int64_t ldc,
+                     int32_t M, int32_t N, int32_t Kp, int32_t splits, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* dst (bf16, ld ldd) = round-to-nearest-even(src) or its transpose; src dtype SKF_F64 / SKF_F32 /
  * SKF_BF16.  Padding columns of dst are left untouched (zero them beforehand). */

@@ -23,6 +23,23 @@ class DeviceMatrix(object):
         return DeviceMatrix(_BufferView(self.buf, begin * self.ld * itemsize), (count, self.shape[1]), self.ld)
 
 
+class PackedMask(object):
+    """A DFMC mask in HBM as packed bits: bit (c & 7) of byte [r * ld + (c >> 3)], 1 = unknown entry
+    (SKF_REL_MASK_BITS, include/skfusion_hip.h)."""
+
+    def __init__(self, buf, shape, ld):
+        self.buf, self.shape, self.ld = buf, tuple(shape), ld
+
+
+def pack_mask(mask, mem):
+    """Boolean host mask -> PackedMask (1/8 of the bytes cross PCIe; the engine reads one bit per entry)."""
+    m = np.asarray(mask, dtype=bool)
+    if m.ndim != 2:
+        raise ValueError('mask is not a matrix')
+    bits = np.ascontiguousarray(np.packbits(m, axis=1, bitorder='little'))
+    return PackedMask(mem.from_host(bits), m.shape, bits.shape[1])
+
+
 def device_matrix_from_tensor(t):
     """Wrap a contiguous 2-D torch tensor that lives on the engine's device (no copy)."""
     assert t.dim() == 2 and t.is_contiguous()
@@ -143,18 +160,24 @@ class DevicePlan(object):
                                  % (i, j, tuple(arr.shape), rows_here, n_obj[j]))
             self._keep_rel.append(buf)
             rdesc[k].data, rdesc[k].ld = buf.ptr, ld
-            if isinstance(mask, DeviceMatrix):           # uint8 bytes already in HBM
+            if isinstance(mask, PackedMask):             # packed bits already in HBM (upload_graph)
                 if tuple(mask.shape) != tuple(arr.shape):
                     raise ValueError('mask shape mismatch for relation (%s,%s)' % (i, j))
-                self._keep.append(mask.buf)
+                self._keep_rel.append(mask.buf)
+                rdesc[k].mask, rdesc[k].mask_ld = mask.buf.ptr, mask.ld
+                rdesc[k].flags |= nat.SKF_REL_MASK_BITS
+            elif isinstance(mask, DeviceMatrix):         # uint8 bytes already in HBM (device-generated data)
+                if tuple(mask.shape) != tuple(arr.shape):
+                    raise ValueError('mask shape mismatch for relation (%s,%s)' % (i, j))
+                self._keep_rel.append(mask.buf)
                 rdesc[k].mask, rdesc[k].mask_ld = mask.buf.ptr, mask.ld
             elif mask is not None:
-                m = np.ascontiguousarray(np.asarray(mask, dtype=bool).astype(np.uint8))
-                if m.shape != arr.shape:
+                pm = pack_mask(mask, mem)
+                if pm.shape != arr.shape:
                     raise ValueError('mask shape mismatch for relation (%s,%s)' % (i, j))
-                mbuf = mem.from_host(m)
-                self._keep.append(mbuf)
-                rdesc[k].mask, rdesc[k].mask_ld = mbuf.ptr, m.shape[1]
+                self._keep_rel.append(pm.buf)
+                rdesc[k].mask, rdesc[k].mask_ld = pm.buf.ptr, pm.ld
+                rdesc[k].flags |= nat.SKF_REL_MASK_BITS
         hdesc = (nat.ThetaDesc * max(len(thetas), 1))()
         for k, (t, data) in enumerate(thetas):
             if isinstance(data, DeviceMatrix):           # master dtype, already in HBM
@@ -182,8 +205,9 @@ class DevicePlan(object):
         self._scalar = mem.empty(8)
 
     def release_relation_data(self):
-        """SKF_BF16: the relations were copied (padded, transposed) at bind time; the caller's buffers
-        are not referenced afterwards and may be dropped.  No-op for the other engines."""
+        """SKF_BF16: the relations (and every engine's masks) were copied into the engine's own layout at
+        bind time; the caller's buffers are not referenced afterwards and may be dropped.  The f32 / f64
+        engines keep reading unmasked relations in place: no-op for them."""
         if self.dtype == nat.SKF_BF16:
             self._keep_rel = []
 
@@ -330,9 +354,8 @@ def upload_graph(rel_list, theta_list, dtype, runtime=None):
             arr = np.ascontiguousarray(data, dtype=npd)
             up = nat.to_bf16_bits(arr) if code == nat.SKF_BF16 else arr
             data = DeviceMatrix(rt.mem.from_host(up), arr.shape)
-        if mask is not None and not isinstance(mask, DeviceMatrix):
-            m = np.ascontiguousarray(np.asarray(mask, dtype=bool).astype(np.uint8))
-            mask = DeviceMatrix(rt.mem.from_host(m), m.shape)
+        if mask is not None and not isinstance(mask, (DeviceMatrix, PackedMask)):
+            mask = pack_mask(mask, rt.mem)
         rels.append((i, j, data, mask) + tuple(rel[4:]))
     for t, data in theta_list:
         if not isinstance(data, DeviceMatrix):

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -128,19 +129,7 @@ static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, 
     dim3 block(GEMM_THREADS);
     constexpr int WRB = BigWave<T>::WR, WCB = BigWave<T>::WC;
     const bool big = (t.bm == Tiles<T>::big().bm && t.bn == Tiles<T>::big().bn);
-    if (g.epi == EPI_MASKED_STORE_BF16) {          // f32 operands only; never split, always the MFMA kernel
-        if constexpr (std::is_same<T, float>::value && std::is_same<TA, float>::value &&
-                      std::is_same<TB, float>::value) {
-            if (big)
-                hipLaunchKernelGGL((gemm_mfma_kernel<float, float, float, WRB, WCB, Tiles<float>::BK, 2>), grid,
-                                   block, 0, st, g);
-            else
-                hipLaunchKernelGGL((gemm_mfma_kernel<float, float, float, 1, 1, Tiles<float>::BK, 2>), grid, block,
-                                   0, st, g);
-        } else {
-            SKF_FAIL(SKF_E_INVALID, "bf16 masked store needs f32 operands");
-        }
-    } else if (engine == SKF_ENGINE_VALU) {
+    if (engine == SKF_ENGINE_VALU) {
         hipLaunchKernelGGL((gemm_valu_kernel<T, TA, TB>), grid, block, 0, st, g);
     } else if (t.bk == 64 && t.bm == 32) {         // Tiles<double>::deep()
         if constexpr (std::is_same<T, double>::value && std::is_same<TA, double>::value &&
@@ -225,10 +214,9 @@ static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void
     if (g.M <= 0 || g.N <= 0) return;
     const bool is_f64 = (ty.c == SKF_F64);
     const bool all_f64 = (ty.c == SKF_F64 && ty.a == SKF_F64 && ty.b == SKF_F64);
-    const TileCfg t = pick_tile(is_f64, g.epi == EPI_MASKED_STORE_BF16 ? SKF_ENGINE_MFMA : engine, g.M, g.N, g.K,
-                                all_f64 && want_splits <= 1);
+    const TileCfg t = pick_tile(is_f64, engine, g.M, g.N, g.K, all_f64 && want_splits <= 1);
     int splits = want_splits > 0 ? want_splits : pick_splits(t, g.M, g.N, g.K);
-    if (g.epi == EPI_SQDIFF || g.epi == EPI_MASKED_STORE_BF16) splits = 1;
+    if (g.epi == EPI_SQDIFF) splits = 1;
     const size_t per = (size_t)g.M * g.N;
     const size_t part_elems = part_bytes / (is_f64 ? 8 : 4);
     if (splits > 1 && (part == nullptr || per * splits > part_elems)) {
@@ -258,28 +246,10 @@ static inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
 // K slices for the bf16 contraction: equal work units over the 256 CUs (x resident workgroups)
 // finish in ceil(units/slots) rounds; pick the split that wastes the least of the last round,
 // charging every extra slice for its partial-sum traffic.  The charge is empirical (config 3, A/B
-// runs of SKF_BF16_SPLIT_PENALTY = 0.002 ... 1.0): 0.05-0.07 is best -- e.g. 196 row tiles run
-// UNSPLIT on 196 of the 256 CUs as fast as 5 slices on all of them (the memory system, not the
-// number of busy CUs, bounds the kernel), while 157 and 391 tiles gain from 3 slices.
-// rows per workgroup of the bf16 contraction: the 256-row double-buffered kernel for large
-// problems, the 128-row kernel otherwise (SKF_BF16_TILE=128 / 256 forces one, for A/B runs)
-static int bf16_block_rows(int M, int N = 256) {
-    const char* f = getenv("SKF_BF16_TILE");
-    if (f && atoi(f) == 128) return 128;
-    if (f && atoi(f) == 256) return 256;
-    const char* t = getenv("SKF_BF16_TALL");           // "1": 384 x 256 / 512 x 128 tiles (gemm_bf16_tall_kernel)
-    if (t && (atoi(t) == 2 || (atoi(t) == 1 && M >= 4096))) return N > 128 ? 384 : 512;      // "2": any M (tests)
-    if (t && atoi(t) == 3 && M >= 4096 && N <= 128) return 512;                              // "3" / "4": one shape only
-    if (t && atoi(t) == 4 && M >= 4096 && N > 128) return 384;
-    return M >= 4096 ? 256 : 128;
-}
-
+// runs 0.002 ... 1.0 inside the whole iteration): 0.05-0.07 is best.
 static int pick_splits_bf16(int64_t units, int ktiles, int bm) {
     const double slots = 256.0 * (bm >= 256 ? 1.0 : 2.0);     // resident workgroups on 256 CUs
-    static const double penalty = [] {                         // cost of one more K slice (partial-sum traffic)
-        const char* e = getenv("SKF_BF16_SPLIT_PENALTY");
-        return e ? atof(e) : 0.06;
-    }();
+    const double penalty = 0.06;                               // cost of one more K slice (partial-sum traffic)
     int best = 1;
     double best_eff = -1.0;
     for (int s = 1; s <= 32; ++s) {
@@ -295,16 +265,31 @@ static int pick_splits_bf16(int64_t units, int ktiles, int bm) {
     return best;
 }
 
+// rows per workgroup of the bf16 contraction: the 256-row LDS-DMA kernel for large problems and for
+// every transposed-A product, the 128-row register-staged kernel for small P-type products
+static int bf16_block_rows(int M, bool at) { return (at || M >= 4096) ? 256 : 128; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and process, safe against the
+// concurrent host threads of run_fits_concurrent (one plan per thread)
+template <class K>
+static void allow_dynamic_lds(std::once_flag& once, K kernel, int bytes) {
+    hipError_t err = hipSuccess;
+    std::call_once(once, [&] { err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+    if (err != hipSuccess) SKF_FAIL(SKF_E_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
+}
+
+// C[M x N] (f32) = op(A) * Bt^T, bf16 operands:  at == false: A is [M][lda] (K contiguous);
+// at == true: A is [Kp][lda] row-major with the OUTPUT rows along its columns (lda >= M, rows zero-padded to Kp)
 static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, int64_t ldb, float* C, int64_t ldc,
                           int M, int N, int Kp, int want_splits, void* part, size_t part_bytes, bool relation,
-                          hipStream_t st, int64_t a_kstep = 64, int64_t b_kstep = 64) {
+                          hipStream_t st, bool at = false) {
     if (M <= 0 || N <= 0) return;
-    if (Kp % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || (a_kstep == 64 && lda < Kp) || (b_kstep == 64 && ldb < Kp))
+    if (Kp % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || (!at && lda < Kp) || (at && lda < M) || ldb < Kp)
         SKF_FAIL(SKF_E_INVALID, "bf16 contraction: inner dimension must be padded to 64 (Kp=%d lda=%lld ldb=%lld)", Kp,
                  (long long)lda, (long long)ldb);
     if ((((uintptr_t)A) | ((uintptr_t)Bt)) & 15) SKF_FAIL(SKF_E_INVALID, "bf16 operands must be 16-byte aligned");
     const int bn = (N <= 128) ? 128 : 256;
-    const int bm = bf16_block_rows(M, N);
+    const int bm = bf16_block_rows(M, at);
     const int ktiles = Kp / 64;
     const int64_t units = (int64_t)cdiv(M, bm) * cdiv(N, bn);
     int splits = want_splits > 0 ? want_splits : pick_splits_bf16(units, ktiles, bm);
@@ -316,90 +301,30 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
     g.A = A; g.Bt = Bt; g.C = C; g.part = (float*)part;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.M = M; g.N = N; g.Kp = Kp;
-    g.a_kstep = a_kstep; g.b_kstep = b_kstep;
+    g.a_kstep = 64; g.b_kstep = 64;
     g.k_chunk = cdiv(ktiles > 0 ? ktiles : 1, splits) * 64;
     splits = cdiv(Kp > 0 ? Kp : 1, g.k_chunk);
     dim3 grid(cdiv(N, bn), cdiv(M, bm), splits);
-    if (bm > 256) {
-        // tall tiles: the whole LDS as a 2-deep ring of both operands
-        const int smem = 2 * (bm + bn) * 8 * 16;
-#define SKF_TALL_LAUNCH(BN_, NW_, TAG_)                                                                           \
-    do {                                                                                                          \
-        static bool attr_ = false;                                                                                \
-        if (!attr_) {                                                                                             \
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_tall_kernel<BN_, NW_, TAG_>,                       \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (32 * NW_ + BN_) * 8 * 16)); \
-            attr_ = true;                                                                                         \
-        }                                                                                                         \
-        hipLaunchKernelGGL((gemm_bf16_tall_kernel<BN_, NW_, TAG_>), grid, dim3(NW_ * 64), smem, st, g);           \
-    } while (0)
-        if (bm == 384 && relation) SKF_TALL_LAUNCH(256, 12, 1);
-        else if (bm == 384) SKF_TALL_LAUNCH(256, 12, 0);
-        else if (relation) SKF_TALL_LAUNCH(128, 16, 1);
-        else SKF_TALL_LAUNCH(128, 16, 0);
-#undef SKF_TALL_LAUNCH
-    } else if (bm == 256) {
-        // 256 x BN tile, LDS double buffer in dynamic shared memory (> 64 KiB needs the attribute)
-        dim3 block(512);
-        const char* mf = getenv("SKF_BF16_MFMA");          // "32" selects the 32x32x16 flavour
-        const bool mf32 = (mf && atoi(mf) == 32);           // (measured 7 % slower than 16x16x32 here)
-        const char* gl = getenv("SKF_BF16_GLDS");          // "0" selects register staging
-        const bool glds = !(gl && atoi(gl) == 0);
-        const char* sg = getenv("SKF_BF16_STAGES");        // "2" disables the 3-stage ring (BN = 128)
-        const bool three = glds && !(sg && atoi(sg) == 2);
-#define SKF_V2_LAUNCH(BN_, TAG_, MF_, GL_, NS_)                                                                   \
-    do {                                                                                                          \
-        const int smem_ = (NS_ * 256 + ((NS_ == 3 && BN_ == 256) ? 2 : NS_) * BN_) * 8 * 16;                      \
-        static bool attr_ = false;                                                                                \
-        if (!attr_) {                                                                                             \
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<BN_, TAG_, MF_, GL_, NS_>,               \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_));                      \
-            attr_ = true;                                                                                         \
-        }                                                                                                         \
-        hipLaunchKernelGGL((gemm_bf16_v2_kernel<BN_, TAG_, MF_, GL_, NS_>), grid, block, smem_, st, g);           \
-    } while (0)
-#define SKF_V2_PICK(BN_, TAG_)                                         \
-    do {                                                               \
-        if (mf32 && glds) SKF_V2_LAUNCH(BN_, TAG_, true, true, 2);     \
-        else if (mf32) SKF_V2_LAUNCH(BN_, TAG_, true, false, 2);       \
-        else if (glds) SKF_V2_LAUNCH(BN_, TAG_, false, true, 2);       \
-        else SKF_V2_LAUNCH(BN_, TAG_, false, false, 2);                \
-    } while (0)
-        const char* pp = getenv("SKF_BF16_PIPE");          // "1" enables the half-tile fragment pipeline
-        const bool pipe = three && (pp && atoi(pp) == 1);   // (v3: measured equal to v2, kept for A/B runs)
-#define SKF_V3_LAUNCH(BN_, TAG_)                                                                                  \
+    if (bm == 256) {
+        // 256 x BN tile, LDS rings in dynamic shared memory (> 64 KiB needs the attribute)
+#define SKF_V2_LAUNCH(BN_, TAG_, AT_)                                                                             \
     do {                                                                                                          \
         const int smem_ = (3 * 256 + ((BN_ == 256) ? 2 : 3) * BN_) * 8 * 16;                                      \
-        static bool attr_ = false;                                                                                \
-        if (!attr_) {                                                                                             \
-            SKF_HIP(hipFuncSetAttribute((const void*)gemm_bf16_v3_kernel<BN_, TAG_>,                              \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_));                      \
-            attr_ = true;                                                                                         \
-        }                                                                                                         \
-        hipLaunchKernelGGL((gemm_bf16_v3_kernel<BN_, TAG_>), grid, block, smem_, st, g);                          \
+        static std::once_flag once_;                                                                              \
+        allow_dynamic_lds(once_, gemm_bf16_v2_kernel<BN_, TAG_, AT_>, smem_);                                     \
+        hipLaunchKernelGGL((gemm_bf16_v2_kernel<BN_, TAG_, AT_>), grid, dim3(512), smem_, st, g);                 \
     } while (0)
-        if (pipe && bn == 128 && relation) SKF_V3_LAUNCH(128, 1);
-        else if (pipe && bn == 128) SKF_V3_LAUNCH(128, 0);
-        else if (pipe && relation) SKF_V3_LAUNCH(256, 1);
-        else if (pipe) SKF_V3_LAUNCH(256, 0);
-        else if (three && mf32 && bn == 128) SKF_V2_LAUNCH(128, 0, true, true, 3);
-        else if (three && mf32) SKF_V2_LAUNCH(256, 0, true, true, 3);
-        else if (three && bn == 128 && relation) SKF_V2_LAUNCH(128, 1, false, true, 3);
-        else if (three && bn == 128) SKF_V2_LAUNCH(128, 0, false, true, 3);
-        else if (three && relation) SKF_V2_LAUNCH(256, 1, false, true, 3);
-        else if (three) SKF_V2_LAUNCH(256, 0, false, true, 3);
-        else if (bn == 128 && relation) SKF_V2_PICK(128, 1);
-        else if (bn == 128) SKF_V2_PICK(128, 0);
-        else if (relation) SKF_V2_PICK(256, 1);
-        else SKF_V2_PICK(256, 0);
-#undef SKF_V3_LAUNCH
-#undef SKF_V2_PICK
+        if (at) {
+            if (bn == 128) SKF_V2_LAUNCH(128, 1, true);
+            else SKF_V2_LAUNCH(256, 1, true);
+        } else if (bn == 128 && relation) SKF_V2_LAUNCH(128, 1, false);
+        else if (bn == 128) SKF_V2_LAUNCH(128, 0, false);
+        else if (relation) SKF_V2_LAUNCH(256, 1, false);
+        else SKF_V2_LAUNCH(256, 0, false);
 #undef SKF_V2_LAUNCH
     } else {
         dim3 block(256);
-        if (bn == 128 && relation) hipLaunchKernelGGL((gemm_bf16_kernel<128, 1>), grid, block, 0, st, g);
-        else if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, 0>), grid, block, 0, st, g);
-        else if (relation) hipLaunchKernelGGL((gemm_bf16_kernel<256, 1>), grid, block, 0, st, g);
+        if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, 0>), grid, block, 0, st, g);
         else hipLaunchKernelGGL((gemm_bf16_kernel<256, 0>), grid, block, 0, st, g);
     }
     check_launch("gemm_bf16");
@@ -410,14 +335,10 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
     }
 }
 
-static size_t bf16_part_bytes(int M, int N, int Kp) {
+static size_t bf16_part_bytes(int M, int N, int Kp, bool at) {
     const int bn = (N <= 128) ? 128 : 256;
-    // worst case over the two tile heights (the choice can be overridden at run time)
-    const int s1 = pick_splits_bf16((int64_t)cdiv(M, 128) * cdiv(N, bn), Kp / 64, 128);
-    const int s2 = pick_splits_bf16((int64_t)cdiv(M, 256) * cdiv(N, bn), Kp / 64, 256);
-    const int s3 = pick_splits_bf16((int64_t)cdiv(M, N > 128 ? 384 : 512) * cdiv(N, bn), Kp / 64, 512);
-    const int s12 = s1 > s2 ? s1 : s2;
-    const int s = s12 > s3 ? s12 : s3;
+    const int bm = bf16_block_rows(M, at);
+    const int s = pick_splits_bf16((int64_t)cdiv(M, bm) * cdiv(N, bn), Kp / 64, bm);
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
@@ -467,10 +388,14 @@ struct RelState {
     int64_t ldr = 0;
     Slot Rw, P, Q, W, T1, S, U, H;
     Slot S32;                      // f32 engines: rounding of S for the fused side update
-    Slot Hb, Gb;                   // SKF_BF16 masked relation: bf16 H = G_i S and bf16 G_j (K padded to 64)
+    Slot Hb, Gb;                   // SKF_BF16: bf16 H = G_i S and bf16 G_j (K padded to 64) for the completion / residual tiles
     int64_t ldhb = 0;
-    Slot Rb, RTb;                  // SKF_BF16: padded bf16 copies of R and R^T
-    int64_t ldrb = 0, ldrtb = 0;
+    Slot Rb;                       // SKF_BF16: the ONE stored copy of the relation, bf16 [pad64(nr)][pad64(n_j)], zero padded
+    int64_t ldrb = 0;
+    int64_t kq = 0;                // pad64(nr): inner dimension of Q = R^T G_i (padding rows of Rb are zero)
+    Slot Mb;                       // DFMC: the mask as packed bits, [nr][ldmb bytes], bit (n & 7) of byte n >> 3
+    int64_t ldmb = 0;
+    bool mask_is_bits = false;     // the caller's mask is already packed (SKF_REL_MASK_BITS)
     bool s_set = false;
     // row-block sharding: this plan holds rows [r0, r0 + nr) of the relation (nr == n_i: all of it)
     int64_t r0 = 0, nr = 0;
@@ -606,9 +531,9 @@ static void relation_gemm(skf_plan* p, GemmArgs g, hipStream_t st, const RelStat
         if (!is_q)      // P = R G_j :  A = R (bf16), Bt = G_j^T (bf16)
             run_gemm_bf16((const uint16_t*)r->Rb.ptr, r->ldrb, (const uint16_t*)tj.GTb.ptr, tj.ldgt, (float*)g.C,
                           g.ldc, g.M, g.N, (int)r->ldrb, 0, p->part.ptr, p->part_bytes, true, st);
-        else            // Q = R^T G_i :  A = stored R^T (bf16), Bt = G_i^T (bf16)
-            run_gemm_bf16((const uint16_t*)r->RTb.ptr, r->ldrtb, (const uint16_t*)ti.GTb.ptr + r->r0, ti.ldgt, (float*)g.C,
-                          g.ldc, g.M, g.N, (int)r->ldrtb, 0, p->part.ptr, p->part_bytes, true, st);
+        else            // Q = R^T G_i :  A = the same row-major R read transposed out of LDS, Bt = G_i^T (bf16)
+            run_gemm_bf16((const uint16_t*)r->Rb.ptr, r->ldrb, (const uint16_t*)ti.GTb.ptr + r->r0, ti.ldgt, (float*)g.C,
+                          g.ldc, g.M, g.N, (int)r->kq, 0, p->part.ptr, p->part_bytes, true, st, true);
     } else {
         run_gemm(GemmTypes{p->mt, p->mt, p->mt}, p->engine, g, 0, p->part.ptr, p->part_bytes, st, true);
     }
@@ -895,17 +820,15 @@ static void stage_contract(skf_plan* p, hipStream_t st) {
         for (RelState& r : p->rels) {
             if (!r.mask) continue;
             const int64_t rows = r.nr, cols = p->types[r.col].n;
-            if (p->bf16) {
+            if (p->bf16)
                 hipLaunchKernelGGL((mask_zero_kernel<uint16_t>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
-                                   (uint16_t*)r.Rb.ptr, r.ldrb, r.mask, r.ldmask, rows, cols);
-                hipLaunchKernelGGL(mask_zero_transposed_kernel, dim3(elem_grid(rows * cols)), dim3(256), 0, st,
-                                   (uint16_t*)r.RTb.ptr, r.ldrtb, r.mask, r.ldmask, rows, cols);
-            } else if (p->f64)
+                                   (uint16_t*)r.Rb.ptr, r.ldrb, (const uint8_t*)r.Mb.ptr, r.ldmb, rows, cols);
+            else if (p->f64)
                 hipLaunchKernelGGL((mask_zero_kernel<double>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
-                                   (double*)r.Rw.ptr, r.ldr, r.mask, r.ldmask, rows, cols);
+                                   (double*)r.Rw.ptr, r.ldr, (const uint8_t*)r.Mb.ptr, r.ldmb, rows, cols);
             else
                 hipLaunchKernelGGL((mask_zero_kernel<float>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
-                                   (float*)r.Rw.ptr, r.ldr, r.mask, r.ldmask, rows, cols);
+                                   (float*)r.Rw.ptr, r.ldr, (const uint8_t*)r.Mb.ptr, r.ldmb, rows, cols);
             check_launch("mask_zero");
         }
     }
@@ -975,6 +898,26 @@ static void stage_contract(skf_plan* p, hipStream_t st) {
     if (p->overlap) SKF_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
 }
 
+// SKF_BF16: one elementwise pass over the stored relation against its reconstruction H G_j^T (r.H = G_i S must
+// be current): DFMC completion of the unknown entries, or the squared residual into p->sqpart (one f64 per tile)
+static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t st) {
+    TypeState& tj = p->types[r.col];
+    const int nr = (int)r.nr, nj = (int)tj.n, cj = tj.c;
+    launch_to_bf16<float>((uint16_t*)r.Hb.ptr, r.ldhb, (const float*)r.H.ptr, (int64_t)cj, nr, cj, false, st);
+    launch_to_bf16<float>((uint16_t*)r.Gb.ptr, r.ldhb, (const float*)tj.G.ptr, (int64_t)cj, nj, cj, false, st);
+    TileEpiArgs ta;
+    ta.A = (const uint16_t*)r.Hb.ptr; ta.Bt = (const uint16_t*)r.Gb.ptr; ta.R = (uint16_t*)r.Rb.ptr;
+    ta.mbits = (const uint8_t*)r.Mb.ptr; ta.part = (double*)p->sqpart.ptr;
+    ta.lda = r.ldhb; ta.ldb = r.ldhb; ta.ldr = r.ldrb; ta.ldmb = r.ldmb;
+    ta.M = nr; ta.N = nj; ta.Kp = (int)r.ldhb;
+    dim3 grid(cdiv(nj, 128), cdiv(nr, 128));
+    if (mode == MODE_COMPLETE)
+        hipLaunchKernelGGL((tile_epilogue_bf16_kernel<MODE_COMPLETE>), grid, dim3(256), 0, st, ta);
+    else
+        hipLaunchKernelGGL((tile_epilogue_bf16_kernel<MODE_SQERR>), grid, dim3(256), 0, st, ta);
+    check_launch("tile_epilogue_bf16");
+}
+
 // Stage 2 (SKF_STAGE_BACKBONE): S = K_i W K_j; DFMC: completion, then P and Q of masked relations.
 // every rank <= SMALLC: the c x c chains run in the one-workgroup kernels (SKF_NO_SMALL_CHAIN=1: off)
 static bool small_chain(const skf_plan* p) {
@@ -1036,29 +979,15 @@ static void stage_backbone(skf_plan* p, hipStream_t st) {
             g = gemm_args(rows_of(p, ti.G, ti, r.r0), ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, nr, cj, ci, EPI_STORE, 0);
             mixed_gemm(p, g, st);
             if (r.mask) {
-                const char* slow = getenv("SKF_BF16_COMPLETE_F32");      // "1": the f32 product (A/B runs)
-                if (p->bf16 && !(slow && atoi(slow) != 0)) {
-                    // completed entries go to both stored copies (R and R^T) as bf16: bf16 operands on the
-                    // matrix cores, the write-out is the bound (complete_bf16_kernel)
-                    launch_to_bf16<float>((uint16_t*)r.Hb.ptr, r.ldhb, (const float*)r.H.ptr, (int64_t)cj, nr, cj, false, st);
-                    launch_to_bf16<float>((uint16_t*)r.Gb.ptr, r.ldhb, (const float*)tj.G.ptr, (int64_t)cj, nj, cj, false, st);
-                    CompleteArgs ca;
-                    ca.A = (const uint16_t*)r.Hb.ptr; ca.Bt = (const uint16_t*)r.Gb.ptr; ca.mask = r.mask;
-                    ca.R = (uint16_t*)r.Rb.ptr; ca.RT = (uint16_t*)r.RTb.ptr;
-                    ca.lda = r.ldhb; ca.ldb = r.ldhb; ca.ldmask = r.ldmask; ca.ldr = r.ldrb; ca.ldrt = r.ldrtb;
-                    ca.M = nr; ca.N = nj; ca.Kp = (int)r.ldhb;
-                    hipLaunchKernelGGL(complete_bf16_kernel, dim3(cdiv(nj, 128), cdiv(nr, 128)), dim3(256), 0, st, ca);
-                    check_launch("complete_bf16");
+                if (p->bf16) {
+                    // completed entries go to the one stored copy as bf16: bf16 operands on the matrix cores,
+                    // the write-out is the bound (tile_epilogue_bf16_kernel<MODE_COMPLETE>)
+                    launch_tile_epilogue(p, r, MODE_COMPLETE, st);
                 } else {
-                    if (p->bf16) {
-                        g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rb.ptr, r.ldrb, nr, nj, cj, EPI_MASKED_STORE_BF16, 0);
-                        g.C2 = r.RTb.ptr;
-                        g.ldc2 = r.ldrtb;
-                    } else {
-                        g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rw.ptr, r.ldr, nr, nj, cj, EPI_MASKED_STORE, 0);
-                    }
-                    g.mask = r.mask;
-                    g.ldmask = r.ldmask;
+                    g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rw.ptr, r.ldr, nr, nj, cj, EPI_MASKED_STORE, 0);
+                    g.mask = (const uint8_t*)r.Mb.ptr;
+                    g.ldmask = r.ldmb;
+                    g.mask_bits = 1;
                     plan_gemm(p, g, st);
                 }
             }
@@ -1412,12 +1341,14 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             if (block) p->sliced = true;
             if ((d.mask || (d.flags & SKF_REL_MASKED)) && p->variant != SKF_DFMC)
                 SKF_FAIL(SKF_E_INVALID, "relation %d: masks need SKF_DFMC", r);
-            if (d.mask && d.mask_ld < p->types[d.col_type].n) SKF_FAIL(SKF_E_INVALID, "relation %d: mask ld", r);
+            if (d.mask && d.mask_ld < ((d.flags & SKF_REL_MASK_BITS) ? (p->types[d.col_type].n + 7) / 8 : p->types[d.col_type].n))
+                SKF_FAIL(SKF_E_INVALID, "relation %d: mask ld", r);
             if (p->variant == SKF_TRANSFORM && d.row_type != p->target && d.col_type != p->target)
                 SKF_FAIL(SKF_E_INVALID, "relation %d must include the target object type", r);
             RelState& s = p->rels[r];
             s.row = d.row_type; s.col = d.col_type;
             s.R_in = d.data; s.ld_in = d.ld; s.mask = d.mask; s.ldmask = d.mask_ld;
+            s.mask_is_bits = (d.flags & SKF_REL_MASK_BITS) != 0;
             s.R = d.data; s.ldr = d.ld;
             s.absent = absent;
             s.r0 = absent ? 0 : d.row_begin;
@@ -1526,17 +1457,20 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             want_part(tj.c, tj.c, ti.c, true);
             if (nr <= 0) continue;
             if (r.mask && !p->bf16) add_slot(p, r.Rw, (size_t)nr * tj.n * es);
-            if (p->bf16 && r.mask) {
+            if (r.mask) {
+                r.ldmb = (tj.n + 127) / 128 * 16;               // bytes per packed mask row: whole 128-column tiles
+                add_slot(p, r.Mb, (size_t)nr * r.ldmb);
+            }
+            if (p->bf16 && p->variant != SKF_TRANSFORM) {       // completion / residual tiles
                 r.ldhb = pad64(tj.c);
                 add_slot(p, r.Hb, (size_t)nr * r.ldhb * 2);
                 add_slot(p, r.Gb, (size_t)tj.n * r.ldhb * 2);
             }
             if (p->bf16) {
                 r.ldrb = pad64(tj.n);
-                r.ldrtb = pad64(nr);
-                add_slot(p, r.Rb, (size_t)nr * r.ldrb * 2);
-                add_slot(p, r.RTb, (size_t)tj.n * r.ldrtb * 2);
-                size_t b1 = bf16_part_bytes((int)nr, tj.c, (int)r.ldrb), b2 = bf16_part_bytes((int)tj.n, ti.c, (int)r.ldrtb);
+                r.kq = pad64(nr);
+                add_slot(p, r.Rb, (size_t)r.kq * r.ldrb * 2);
+                size_t b1 = bf16_part_bytes((int)nr, tj.c, (int)r.ldrb, false), b2 = bf16_part_bytes((int)tj.n, ti.c, (int)r.kq, true);
                 if (b1 > part_bytes) part_bytes = b1;
                 if (b2 > part_bytes) part_bytes = b2;
             }
@@ -1544,7 +1478,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             want_part((int)tj.n, ti.c, (int)nr, p->f64);
             want_part((int)nr, ti.c, tj.c, p->f64);
             want_part((int)tj.n, tj.c, ti.c, p->f64);
-            size_t blocks = (size_t)cdiv(nr, 32) * cdiv(tj.n, 32);
+            size_t blocks = (size_t)cdiv(nr, 32) * cdiv(tj.n, 32);           // smallest tile any engine uses
             if (blocks > sq_elems) sq_elems = blocks;
         }
         size_t theta_tmp_bytes = 0;
@@ -1555,7 +1489,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 th.ldb = pad64(t.n);
                 add_slot(p, th.Pb, (size_t)t.n * th.ldb * 2);
                 add_slot(p, th.Nb, (size_t)t.n * th.ldb * 2);
-                const size_t b = bf16_part_bytes((int)t.n, t.c, (int)th.ldb);
+                const size_t b = bf16_part_bytes((int)t.n, t.c, (int)th.ldb, false);
                 if (b > part_bytes) part_bytes = b;
                 if ((size_t)t.n * t.c * 4 > theta_tmp_bytes) theta_tmp_bytes = (size_t)t.n * t.c * 4;
             }
@@ -1573,7 +1507,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         p->part_aux_bytes = aux_bytes;
         add_slot(p, p->part_aux, aux_bytes);
         p->sq_elems = sq_elems;
-        add_slot(p, p->sqpart, sq_elems * es);
+        add_slot(p, p->sqpart, sq_elems * 8);
         if (p->variant != SKF_TRANSFORM) {
             p->eig_maxn = maxn;
             p->eig_stride = (int64_t)maxn * maxn;
@@ -1612,27 +1546,38 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
         p->ws_base = ws;
         hipStream_t st = as_stream(stream);
         for (RelState& r : p->rels) {
-            if (!r.mask || p->bf16) continue;      // bf16: the padded R / R^T copies are the working set
+            if (!r.mask) continue;
+            // the mask in the engine's layout: one bit per entry, rows padded to whole 128-column tiles.
+            // The caller's mask (bytes or bits) is not referenced after this call.
             const int64_t rows = r.nr, cols = p->types[r.col].n;
+            if (r.mask_is_bits) {
+                SKF_HIP(hipMemsetAsync(r.Mb.ptr, 0, r.Mb.bytes, st));
+                hipLaunchKernelGGL(copy_mask_bits_kernel, dim3(elem_grid(rows * ((cols + 7) / 8))), dim3(256), 0, st,
+                                   (uint8_t*)r.Mb.ptr, r.ldmb, r.mask, r.ldmask, rows, cols);
+            } else {
+                hipLaunchKernelGGL(pack_mask_kernel, dim3(elem_grid(rows * r.ldmb)), dim3(256), 0, st, (uint8_t*)r.Mb.ptr,
+                                   r.ldmb, r.mask, r.ldmask, rows, cols);
+            }
+            check_launch("pack_mask");
+            if (p->bf16) continue;                 // bf16: the padded copy below is the working set
             copy2d(r.Rw.ptr, cols, r.R_in, r.ld_in, rows, cols, p->esz, st);
             r.R = r.Rw.ptr;
             r.ldr = cols;
         }
         if (p->bf16) {
-            // the caller's bf16 relation is copied into a zero-padded layout and transposed once;
-            // it is not referenced after this call
+            // the caller's bf16 relation is copied ONCE into a zero-padded row-major layout (rows to a multiple of
+            // 64: the inner dimension of Q = R^T G_i; columns to a multiple of 64: the inner dimension of
+            // P = R G_j); it is not referenced after this call
             for (TypeState& t : p->types) SKF_HIP(hipMemsetAsync(t.GTb.ptr, 0, t.GTb.bytes, st));
             for (RelState& r : p->rels) {
                 if (r.absent) continue;
                 const int64_t rows = r.nr, cols = p->types[r.col].n;
                 SKF_HIP(hipMemsetAsync(r.Rb.ptr, 0, r.Rb.bytes, st));
-                SKF_HIP(hipMemsetAsync(r.RTb.ptr, 0, r.RTb.bytes, st));
-                if (r.mask) {
+                if (r.Hb.bytes) {
                     SKF_HIP(hipMemsetAsync(r.Hb.ptr, 0, r.Hb.bytes, st));
                     SKF_HIP(hipMemsetAsync(r.Gb.ptr, 0, r.Gb.bytes, st));
                 }
                 launch_to_bf16<uint16_t>((uint16_t*)r.Rb.ptr, r.ldrb, (const uint16_t*)r.R_in, r.ld_in, rows, cols, false, st);
-                launch_to_bf16<uint16_t>((uint16_t*)r.RTb.ptr, r.ldrtb, (const uint16_t*)r.R_in, r.ld_in, rows, cols, true, st);
                 r.R = r.Rb.ptr;
                 r.ldr = r.ldrb;
             }
@@ -1879,11 +1824,21 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
         }
         GemmArgs g = gemm_args(rows_of(p, ti.G, ti, r.r0), ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, ni, cj, ci, EPI_STORE, 0);
         mixed_gemm(p, g, st);
+        if (p->bf16) {
+            // one pass over the stored bf16 relation: bf16 H and G_j on the matrix cores, f32 residual
+            launch_tile_epilogue(p, r, MODE_SQERR, st);
+            hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(1), dim3(256), 0, st, (const double*)p->sqpart.ptr,
+                               cdiv(ni, 128) * cdiv(nj, 128), out);
+            check_launch("sum_partials");
+            return;
+        }
         g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, (void*)r.R, r.ldr, ni, nj, cj, EPI_SQDIFF, 0);
         g.C2 = p->sqpart.ptr;
-        g.c_bf16 = p->bf16 ? 1 : 0;
-        const TileCfg t = pick_tile(p->f64, p->engine, ni, nj);
+        // one partial per workgroup of the tile run_gemm picks for THIS product (an all-f64 product of a small
+        // relation with 64 <= c_j <= 1024 runs on the deep 32 x 32 tile)
+        const TileCfg t = pick_tile(p->f64, p->engine, ni, nj, cj, p->f64);
         const int blocks = cdiv(ni, t.bm) * cdiv(nj, t.bn);
+        if ((size_t)blocks > p->sq_elems) SKF_FAIL(SKF_E_STATE, "residual partials: %d tiles > %zu slots", blocks, p->sq_elems);
         plan_gemm(p, g, st);
         if (p->f64)
             hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(1), dim3(256), 0, st, (const double*)p->sqpart.ptr,
@@ -1949,6 +1904,15 @@ int skf_gemm_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, float
         if (!A || !Bt || !C || M < 0 || N < 0 || Kp < 0 || ldc < N) SKF_FAIL(SKF_E_INVALID, "bad argument");
         run_gemm_bf16((const uint16_t*)A, lda, (const uint16_t*)Bt, ldb, C, ldc, M, N, Kp, splits, workspace,
                       workspace_bytes, false, as_stream(stream));
+    });
+}
+
+int skf_gemm_bf16_tn(const void* A, int64_t lda, const void* Bt, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
+                     int32_t Kp, int32_t splits, void* workspace, size_t workspace_bytes, void* stream) {
+    return guarded([&] {
+        if (!A || !Bt || !C || M < 0 || N < 0 || Kp < 0 || ldc < N) SKF_FAIL(SKF_E_INVALID, "bad argument");
+        run_gemm_bf16((const uint16_t*)A, lda, (const uint16_t*)Bt, ldb, C, ldc, M, N, Kp, splits, workspace,
+                      workspace_bytes, false, as_stream(stream), true);
     });
 }
 

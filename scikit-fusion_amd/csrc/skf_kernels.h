@@ -36,8 +36,7 @@ enum Epi {
     EPI_SPLIT_STORE = 2,   // C  = max(v,0) ; C2  = max(-v,0)
     EPI_SPLIT_ACC = 3,     // C += max(v,0) ; C2 += max(-v,0)       (_dfmf.py:256-258,278-282)
     EPI_MASKED_STORE = 4,  // C  = v where mask != 0                (_dfmc.py:319-325)
-    EPI_SQDIFF = 5,        // per-workgroup partial of sum (C - v)^2 -> C2[block]  (C untouched)
-    EPI_MASKED_STORE_BF16 = 6   // bf16 engine: C[m][n] = C2[n][m] = bf16(v) where mask != 0 (R and R^T copies)
+    EPI_SQDIFF = 5         // per-workgroup partial of sum (C - v)^2 -> C2[block]  (C untouched)
 };
 
 struct GemmArgs {
@@ -45,7 +44,8 @@ struct GemmArgs {
     const void* B;
     void* C;
     void* C2;
-    const uint8_t* mask;     // EPI_MASKED_STORE: byte mask, same shape as C, leading dim ldmask
+    const uint8_t* mask;     // EPI_MASKED_STORE: same shape as C; one byte per entry (leading dim ldmask), or -- mask_bits
+                             // -- one BIT per entry: bit (n & 7) of byte mask[m * ldmask + (n >> 3)], ldmask in bytes
     void* part;              // split-K partials [gridDim.z][M][N] (used when gridDim.z > 1)
     int64_t sa_m, sa_k;      // A(m,k) = A[m*sa_m + k*sa_k]
     int64_t sb_k, sb_n;      // B(k,n) = B[k*sb_k + n*sb_n]
@@ -54,7 +54,13 @@ struct GemmArgs {
     int k_chunk;             // K range handled by one z-slice
     int aop, epi, nan_to_num;
     int c_bf16;              // EPI_SQDIFF: the matrix behind C is stored as bf16
+    int mask_bits;           // EPI_MASKED_STORE: the mask is packed (the engine's own masks always are)
 };
+
+__device__ __forceinline__ bool mask_test(const GemmArgs& g, int m, int n) {
+    if (g.mask_bits) return (g.mask[(int64_t)m * g.ldmask + (n >> 3)] >> (n & 7)) & 1;
+    return g.mask[(int64_t)m * g.ldmask + n] != 0;
+}
 
 // ------------------------------------------------------------------------------------------
 // small device helpers
@@ -93,22 +99,12 @@ __device__ __forceinline__ T apply_aop(T x, int aop) {
     return x;
 }
 
-// BF16OUT instantiations (gemm_mfma_kernel<.., TAG = 2>) carry only EPI_MASKED_STORE_BF16: keeping that
-// case out of the common switch keeps the f32 / f64 kernels' register allocation spill-free.
-template <typename T, bool BF16OUT = false>
+template <typename T>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int m, int n, T v) {
     T* C = (T*)g.C;
     T* C2 = (T*)g.C2;
     if (g.nan_to_num) v = nan_to_num(v);
     const int64_t i = (int64_t)m * g.ldc + n;
-    if (BF16OUT) {
-        if (g.mask[(int64_t)m * g.ldmask + n]) {
-            const uint16_t h = f32_to_bf16_rne((float)v);
-            ((uint16_t*)g.C)[i] = h;
-            ((uint16_t*)g.C2)[(int64_t)n * g.ldc2 + m] = h;
-        }
-        return;
-    }
     const int64_t i2 = (int64_t)m * g.ldc2 + n;
     switch (g.epi) {
         case EPI_STORE: C[i] = v; break;
@@ -122,7 +118,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int m, int n, 
             C2[i2] += v > (T)0 ? (T)0 : -v;
             break;
         case EPI_MASKED_STORE:
-            if (g.mask[(int64_t)m * g.ldmask + n]) C[i] = v;
+            if (mask_test(g, m, n)) C[i] = v;
             break;
         default: break;
     }
@@ -292,7 +288,6 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS *
 // One K step:  [global loads of tile t+1 in flight]  MFMA on tile t from LDS  | barrier |
 //              registers -> LDS | barrier.
 // ------------------------------------------------------------------------------------------
-// TAG = 2: the bf16 masked-store epilogue (DFMC completion of the bf16 R / R^T copies).
 // TAG 0 / 1 only change the symbol name: TAG=1 instantiations are the two relation contractions
 // P = R G_j and Q = R^T G_i (the only launches that read R), so that profilers list the
 // dominant kernel separately from the small n x c x c products that share the code.
@@ -389,7 +384,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
                         const T d = rv - v;
                         sq += d * d;
                     } else {
-                        epilogue_store<T, TAG == 2>(g, m, n, v);
+                        epilogue_store<T>(g, m, n, v);
                     }
                 }
             }
@@ -780,38 +775,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 engine, DFMC completion (_dfmc.py:319-325): R[m][n] = RT[n][m] = bf16((H G_j^T)[m][n]) where
-// mask[m][n] != 0, both stored copies of the relation in one pass.  A = bf16(H) [M][lda], Bt =
-// bf16(G_j) [N][ldb] (K = c_j, zero padded to 64).  128 x 128 tile, 4 waves (64 x 64 each), main
-// loop of gemm_bf16_kernel.  The output is HBM-bound (every masked entry is written twice), so the
-// epilogue stages the tile and its mask in LDS and writes whole 16-byte chunks in BOTH
-// orientations -- along n into R and along m into RT -- reading the old chunk only when it holds
-// an unmasked entry to keep.
+// bf16 engine, the two passes that touch a relation ELEMENTWISE against its reconstruction
+// T = H G_j^T  (H = G_i S; A = bf16(H) [M][lda], Bt = bf16(G_j) [N][ldb], K = c_j zero padded to 64):
+//   MODE_COMPLETE  DFMC completion (_dfmc.py:319-325): R[m][n] = bf16(T[m][n]) where the mask bit is set --
+//                  the ONE stored copy of the relation, every unknown entry written once
+//   MODE_SQERR     per-workgroup partial of sum (R - T)^2 (f32 product against the stored bf16 entries;
+//                  the residual of _dfmf.py:306-316 / compute_err without materialising n_i x n_j)
+// 128 x 128 tile, 4 waves (64 x 64 each), main loop of gemm_bf16_kernel (at most 4 K tiles: the pass is
+// bound by the relation's bytes, not by the product).  COMPLETE stages the tile as bf16 in LDS and writes
+// whole 16-byte chunks along the rows of R, reading the old chunk only when it holds a known entry to keep
+// (the mask is one BIT per entry: 16 bytes per tile row).  SQERR stages the R tile in LDS (coalesced
+// 16-byte loads) and every lane compares its accumulator elements with it.
 // ------------------------------------------------------------------------------------------
-// -DSKF_COMPLETE_NT=1: non-temporal stores of the completed chunks / loads of the mask (experiment)
-#ifndef SKF_COMPLETE_NT
-#define SKF_COMPLETE_NT 0
-#endif
-struct CompleteArgs {
+enum { MODE_COMPLETE = 0, MODE_SQERR = 1 };
+struct TileEpiArgs {
     const uint16_t* A;
     const uint16_t* Bt;
-    const uint8_t* mask;
-    uint16_t* R;
-    uint16_t* RT;
-    int64_t lda, ldb, ldmask, ldr, ldrt;
+    uint16_t* R;             // [M][ldr] bf16, ldr % 8 == 0
+    const uint8_t* mbits;    // COMPLETE: packed mask [M][ldmb bytes], ldmb % 16 == 0, bits >= N are zero
+    double* part;            // SQERR: one partial per workgroup (blockIdx.y * gridDim.x + blockIdx.x)
+    int64_t lda, ldb, ldr, ldmb;
     int M, N, Kp;
 };
 
-__global__ __launch_bounds__(256) void complete_bf16_kernel(CompleteArgs g) {
+template <int MODE>
+__global__ __launch_bounds__(256) void tile_epilogue_bf16_kernel(TileEpiArgs g) {
     constexpr int BM = 128, BN = 128, BK = 64;
-    constexpr int TLD = 130;                 // halfwords per staged row: 65 dwords, odd -> column reads spread
-    constexpr int MLD = 132;                 // mask bytes per staged row: 33 dwords
-    constexpr int T_BYTES = BM * TLD * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[T_BYTES + BM * MLD];
+    constexpr int TLD = 136;                 // halfwords per staged row (272 B: 16-byte aligned rows, odd multiple of 16 B)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BM * TLD * 2];
     u32x4* As = (u32x4*)smem;                // main loop: 2 x 16 KiB of operand tiles
     u32x4* Bs = As + BM * 8;
-    uint16_t* T = (uint16_t*)smem;           // epilogue: the tile as bf16 and its mask
-    uint8_t* Mk = smem + T_BYTES;
+    uint16_t* T = (uint16_t*)smem;           // epilogue: the product tile (COMPLETE) / the R tile (SQERR) as bf16
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -874,133 +868,111 @@ __global__ __launch_bounds__(256) void complete_bf16_kernel(CompleteArgs g) {
         if (more) store_tiles();
         __syncthreads();
     }
+    // (the last barrier of the loop already separates the operand tiles from T)
 
-    // ---- epilogue.  (the last barrier of the loop already separates the operand tiles from T / Mk)
+    if constexpr (MODE == MODE_COMPLETE) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                T[(wm0 + i * 16 + 4 * (lane >> 4) + r) * TLD + wn0 + j * 16 + (lane & 15)] = f32_to_bf16_rne(acc[i][j][r]);
-    // mask tile, zero outside the matrix (those positions are never written)
-    const bool mvec = ((g.ldmask & 15) == 0) && ((((uintptr_t)g.mask) & 15) == 0);
-    for (int i = tid; i < BM * 8; i += 256) {
-        const int r = i >> 3, c16 = (i & 7) * 16;
-        const int m = bm0 + r, n = bn0 + c16;
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
-        if (m < g.M && n < g.N) {
-            const uint8_t* src = g.mask + (int64_t)m * g.ldmask + n;
-            if (mvec && n + 16 <= g.N) {
-                const u32x4 v = SKF_COMPLETE_NT ? __builtin_nontemporal_load((const u32x4*)src) : *(const u32x4*)src;
-                w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
-            } else {
-                for (int q = 0; q < 16; ++q)
-                    if (n + q < g.N && src[q]) w[q >> 2] |= 1u << (8 * (q & 3));
+                for (int r = 0; r < 4; ++r)
+                    T[(wm0 + i * 16 + 4 * (lane >> 4) + r) * TLD + wn0 + j * 16 + (lane & 15)] = f32_to_bf16_rne(acc[i][j][r]);
+        __syncthreads();
+        // 8 consecutive columns of one row per item: 16 lanes cover the 256 contiguous bytes of a tile row
+        for (int i = tid; i < BM * 16; i += 256) {
+            const int r = i >> 4, c = i & 15;
+            const int m = bm0 + r;
+            if (m >= g.M) continue;
+            const int64_t mb_off = (int64_t)m * g.ldmb + (bn0 >> 3) + c;
+            if ((int64_t)(bn0 >> 3) + c >= g.ldmb) continue;
+            const uint32_t mb = g.mbits[mb_off];          // bit q: column bn0 + 8c + q is unknown (completed)
+            if (mb == 0u) continue;
+            u32x4 v = *(const u32x4*)(T + r * TLD + c * 8);
+            u32x4* dst = (u32x4*)(g.R + (int64_t)m * g.ldr + bn0 + c * 8);
+            if (mb != 0xFFu) {
+                const u32x4 old = *dst;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (!(mb & (1u << q))) {
+                        const uint32_t sh = 16 * (q & 1), msk = 0xFFFFu << sh;
+                        v[q >> 1] = (v[q >> 1] & ~msk) | (old[q >> 1] & msk);
+                    }
             }
+            *dst = v;
         }
-        uint32_t* dst = (uint32_t*)(Mk + r * MLD + c16);
-        dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3];
-    }
-    __syncthreads();
-    // pass 1: 8 consecutive columns of one row -> R (row-major copy)
-    for (int i = tid; i < BM * 16; i += 256) {
-        const int r = i >> 4, c0 = (i & 15) * 8;
-        const int m = bm0 + r;
-        if (m >= g.M) continue;
-        const uint32_t* mk = (const uint32_t*)(Mk + r * MLD + c0);
-        const uint32_t m0 = mk[0], m1 = mk[1];
-        if ((m0 | m1) == 0u) continue;
-        const uint32_t* tv = (const uint32_t*)(T + r * TLD + c0);          // 4-byte aligned (TLD, c0 even)
-        u32x4 v = {tv[0], tv[1], tv[2], tv[3]};
-        u32x4* dst = (u32x4*)(g.R + (int64_t)m * g.ldr + bn0 + c0);
-        uint32_t keep = 0u;        // bit q set: element q is known (mask byte 0) and keeps its old value
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t byte = ((q < 4 ? m0 : m1) >> (8 * (q & 3))) & 0xFFu;
-            if (!byte) keep |= 1u << q;
+    } else {
+        // R tile -> LDS (zero outside the stored matrix: the product is zero there as well)
+        for (int i = tid; i < BM * 16; i += 256) {
+            const int r = i >> 4, c = i & 15;
+            const int m = bm0 + r;
+            const int64_t col = (int64_t)bn0 + c * 8;
+            u32x4 v = zero;
+            if (m < g.M && col + 8 <= g.ldr) v = *(const u32x4*)(g.R + (int64_t)m * g.ldr + col);
+            *(u32x4*)(T + r * TLD + c * 8) = v;
         }
-        if (keep) {
-            const u32x4 old = *dst;
+        __syncthreads();
+        float s = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (keep & (1u << q)) {
-                    const uint32_t sh = 16 * (q & 1), msk = 0xFFFFu << sh;
-                    v[q >> 1] = (v[q >> 1] & ~msk) | (old[q >> 1] & msk);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ml = wm0 + i * 16 + 4 * (lane >> 4) + r, nl = wn0 + j * 16 + (lane & 15);
+                    if (bm0 + ml < g.M && bn0 + nl < g.N) {
+                        const float d = bf16_to_f32(T[ml * TLD + nl]) - acc[i][j][r];
+                        s += d * d;
+                    }
                 }
-        }
-        if (SKF_COMPLETE_NT) __builtin_nontemporal_store(v, dst); else *dst = v;
-    }
-    // pass 2: 8 consecutive rows of one column -> RT (stored transpose)
-    for (int i = tid; i < BN * 16; i += 256) {
-        const int c = i >> 4, r0 = (i & 15) * 8;
-        const int n = bn0 + c;
-        if (n >= g.N) continue;
-        uint32_t keep = 0u, any = 0u;
-        uint16_t e[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            e[q] = T[(r0 + q) * TLD + c];
-            if (Mk[(r0 + q) * MLD + c]) any = 1u;
-            else keep |= 1u << q;
-        }
-        if (!any) continue;
-        u32x4 v;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = (uint32_t)e[2 * q] | ((uint32_t)e[2 * q + 1] << 16);
-        u32x4* dst = (u32x4*)(g.RT + (int64_t)n * g.ldrt + bm0 + r0);
-        if (keep) {
-            const u32x4 old = *dst;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (keep & (1u << q)) {
-                    const uint32_t sh = 16 * (q & 1), msk = 0xFFFFu << sh;
-                    v[q >> 1] = (v[q >> 1] & ~msk) | (old[q >> 1] & msk);
-                }
-        }
-        if (SKF_COMPLETE_NT) __builtin_nontemporal_store(v, dst); else *dst = v;
+        double ws = wave_sum((double)s);
+        __shared__ double wsum[4];
+        if (lane == 0) wsum[wave] = ws;
+        __syncthreads();
+        if (tid == 0) g.part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 relation contraction, second generation: 256 x BN block tile, 512 threads = 8 waves
-// (4 x 2, wave tile 64 x BN/2), K tile 64, LDS double-buffered in dynamic shared memory
-// (2 x (256+BN) x 128 B = 128 KiB at BN = 256) so that one barrier per K tile suffices:
-//     [global loads of tile t+1 -> registers]  MFMA on LDS[t&1]  registers -> LDS[(t+1)&1]  barrier
-// Same operand contract, fragment layout and swizzle as gemm_bf16_kernel; twice the rows per
-// workgroup halves the L2 traffic of the shared G^T operand per flop.
+// bf16 relation contraction, the kernel of the two products that stream a relation:
+//     AT = false:  C[M x N] (f32) = A[M x Kp] * Bt[N x Kp]^T      P = R G_j     (A = R,   K-contiguous rows)
+//     AT = true :  C[M x N] (f32) = A[Kp x M]^T * Bt[N x Kp]^T    Q = R^T G_i   (A = the SAME row-major R:
+//                  its rows are the contraction index, its columns the output rows -- no stored transpose)
+// 256 x BN block tile, 512 threads = 8 waves (4 x 2, wave tile 64 x BN/2), K tile 64,
+// v_mfma_f32_16x16x32_bf16 (lane l holds A[row = l&15][k = 8*(l>>4) .. +7]).
+//
+// Tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction moves 1 KiB into a
+// wave-LINEAR LDS range, so the bank swizzle is applied to the per-lane SOURCE address); no staging
+// registers, no ds_write pass.  The A operand (the relation, streamed from HBM, nt policy) lives in a ring
+// of three 32 KiB buffers -- two of its K tiles are in flight while one is consumed; the B operand (G^T,
+// served by L2) has three buffers at BN = 128 and two at BN = 256 (3 x 32 + 2 x 32 KiB = the whole LDS) and
+// is issued BEFORE the A tile, so that a COUNTED s_waitcnt vmcnt(PWA) leaves exactly the newest A tile
+// outstanding.  The workgroup meets at a raw s_barrier (__syncthreads() would drain every LDS-DMA).
+// The DMA instructions of a K step are issued BETWEEN the wave's groups of MFMAs (one piece per 16-row
+// block), not in a burst behind the barrier: +3 % (profiles/r02_contraction_bounds.txt, sched1).
+//
+// LDS images
+//   AT = false: A tile [256 rows][64 k] and B tile [BN rows][64 k], 128-byte rows, 16-byte chunk index
+//               XOR-swizzled by (row & 7): conflict-free ds_read_b128 fragment reads.
+//   AT = true : A tile [64 k][256 m], 512-byte rows (one wave instruction = two k rows); a fragment is two
+//               ds_read_b64_tr_b16 (lane i of a 16-lane group, element j <- the halfword that lane
+//               4j + (i>>2) addresses, its element i&3: each group reads a [4 k][16 m] block and every lane
+//               leaves with the 4 k values of ITS m).  Chunk pairs (32 bytes = the 16 m of one group) are
+//               XOR-swizzled by ((k & 3) | ((k >> 3) & 1) << 2): the 8 k rows a half-wave touches fall
+//               into 8 different 32-byte bank slots.
+// Kp % 64 == 0 and the padding is zero-filled by the engine (AT: padding ROWS of A), so there is no K tail.
+// Rows / columns past the end are clamped into the matrix (no divergent branches around the loads): they
+// only feed accumulator rows / columns >= M / N, which are never stored.
 // ------------------------------------------------------------------------------------------
-// swizzle of the 32x32x16 flavour: fragment rows come 32 at a time, chunk ^ ((row >> 1) & 7) is
-// conflict-free for the 16-lane service groups of ds_read_b128 in that pattern
-__device__ __forceinline__ int swz_chunk32(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
-
-// MF32 = true: v_mfma_f32_32x32x16_bf16 (lane l: A[row = l&31][k = 8*(l>>5) .. +7], 16 f32
-// results per lane) -- half the MFMA instructions of the 16x16x32 flavour for the same tile.
-// GLDS = true: the tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB = 8 swizzled
-// rows per wave instruction; the swizzle is applied to the per-lane SOURCE address because the
-// LDS destination of a wave instruction is linear), no staging registers, no ds_write pass.
-// NSTAGE = 3 (LDS-DMA only): the A operand (the relation, streamed from HBM) lives in a ring of
-// three 32 KiB buffers, so two of its K tiles are in flight while one is consumed.  The B
-// operand (G^T, served by L2) has three buffers at BN = 128 (3 x 48 KiB in total) and two at
-// BN = 256 (3 x 32 + 2 x 32 KiB = the whole 160 KiB LDS); it is issued BEFORE the A tile so
-// that a COUNTED s_waitcnt vmcnt(PW_A) leaves exactly the newest A tile outstanding.  The
-// workgroup meets at a raw s_barrier: __syncthreads() would drain every LDS-DMA (vmcnt(0)).
 // cache policy of the relation stream (aux operand of global_load_lds): 2 = nt, the tile is read once
-// and never again by this or any other workgroup.  Measured at config 3, three alternating runs each:
-// 72.9 it/s without the hint, 74.2 with nt, 74.6 with sc0|nt (-DSKF_A_AUX=n builds other policies).
+// and never again by this or any other workgroup (+2 %; on the G^T stream nt measured -7 %).
 #ifndef SKF_A_AUX
 #define SKF_A_AUX 2
 #endif
 #ifndef SKF_B_AUX
 #define SKF_B_AUX 0
 #endif
-#ifndef SKF_MFMA_PRIO
-#define SKF_MFMA_PRIO 0
-#endif
-// 1: LDS-DMA pieces issued between the MFMA groups; 3: + fragments of the second K half read up front
-#ifndef SKF_V2_SCHED
-#define SKF_V2_SCHED 0
-#endif
-// bound-finding probe builds (tools/probe_bounds.sh; never defined in the product build):
+// bound-finding probe builds (tools/probe_*.sh; never defined in the product build):
 //   SKF_PROBE_NOMFMA  the K loop only moves tiles (LDS-DMA, waits, barriers)      -> ingest-only time
 //   SKF_PROBE_NODMA_A / SKF_PROBE_NODMA_B  the loop re-uses the tiles of the prologue -> time without
 //                     the relation stream / without the G^T stream
@@ -1014,17 +986,23 @@ __device__ __forceinline__ int swz_chunk32(int row, int chunk) { return row * 8 
 #else
 #define SKF_PROBE_B(x) x
 #endif
-template <int BN, int TAG, bool MF32, bool GLDS, int NSTAGE>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// swizzle key of a k row of the transposed A image (AT)
+__device__ __forceinline__ int at_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+template <int BN, int TAG, bool AT>
 __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     constexpr int BM = 256, BK = 64;
     constexpr int WN = BN / 2;
-    constexpr int NJ = WN / 16;             // 16-wide column blocks (16x16x32 flavour)
-    constexpr int NJ32 = WN / 32;           // 32-wide column blocks (32x32x16 flavour)
-    constexpr int A_PER = BM / 64;          // 512 threads cover 64 rows x 8 chunks per pass
-    constexpr int B_PER = BN / 64;
-    constexpr int AST = NSTAGE;                                  // A ring depth
-    constexpr int BST = (NSTAGE == 3 && BN == 256) ? 2 : NSTAGE;  // B ring depth
+    constexpr int NJ = WN / 16;             // 16-wide column blocks per wave
+    constexpr int AST = 3;                                       // A ring depth
+    constexpr int BST = (BN == 256) ? 2 : 3;                     // B ring depth
     constexpr int ASZ = BM * 8, BSZ = BN * 8;                   // u32x4 entries per buffer
+    constexpr int PWA = BM / 64, PWB = BN / 64;                 // LDS-DMA instructions per wave and K tile
+    // instructions allowed to stay outstanding when the NEXT tile must be complete
+    constexpr int KEEP = (BST == 3) ? (PWA + PWB) : PWA;
     HIP_DYNAMIC_SHARED(u32x4, smem)
 
     const int tid = threadIdx.x;
@@ -1034,69 +1012,32 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     const int kz0 = blockIdx.z * g.k_chunk;
     const int kz1 = (kz0 + g.k_chunk < g.Kp) ? kz0 + g.k_chunk : g.Kp;
     const int nkt = (kz1 - kz0) / BK;
-    const int srow = tid >> 3, schunk = tid & 7;
 
-    f32x4 acc[MF32 ? 1 : 4][MF32 ? 1 : NJ];
-    f32x16 acc32[MF32 ? 2 : 1][MF32 ? NJ32 : 1];
-    if constexpr (MF32) {
+    f32x4 acc[4][NJ];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ32; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-    }
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[A_PER], rb[B_PER];
-
-    // rows past the end are clamped to the last valid row (no divergent branches around the loads,
-    // no select that would force a wait on the load): they only feed accumulator rows / columns
-    // >= M / N, which are never stored
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int p = 0; p < A_PER; ++p) {
-            const int m = bm0 + srow + 64 * p;
-            const int mc = m < g.M ? m : g.M - 1;
-            ra[p] = *(const u32x4*)(g.A + (int64_t)mc * g.lda + (int64_t)(k0 >> 6) * g.a_kstep + schunk * 8);
-        }
-#pragma unroll
-        for (int p = 0; p < B_PER; ++p) {
-            const int n = bn0 + srow + 64 * p;
-            const int nc = n < g.N ? n : g.N - 1;
-            rb[p] = *(const u32x4*)(g.Bt + (int64_t)nc * g.ldb + (int64_t)(k0 >> 6) * g.b_kstep + schunk * 8);
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        u32x4* As = smem + buf * ASZ;
-        u32x4* Bs = smem + AST * ASZ + buf * BSZ;
-#pragma unroll
-        for (int p = 0; p < A_PER; ++p) {
-            const int r = srow + 64 * p;
-            As[MF32 ? swz_chunk32(r, schunk) : swz_chunk(r, schunk)] = ra[p];
-        }
-#pragma unroll
-        for (int p = 0; p < B_PER; ++p) {
-            const int r = srow + 64 * p;
-            Bs[MF32 ? swz_chunk32(r, schunk) : swz_chunk(r, schunk)] = rb[p];
-        }
-    };
-
-    // direct global -> LDS copy of one K tile of A / B: wave w fills 8-row blocks w*NBLK .. +NBLK-1
+    // piece p of the direct global -> LDS copy of one K tile: wave w fills the 1 KiB blocks w*PW .. +PW-1
     const int rr = lane >> 3, pc = lane & 7;
-    auto dma_A = [&](int k0, int buf) {
+    auto dma_A1 = [&](int k0, int buf, int p) {
         u32x4* Ad = smem + buf * ASZ;
-#pragma unroll
-        for (int p = 0; p < BM / 64; ++p) {
-            const int blk = wave * (BM / 64) + p;
+        const int blk = wave * PWA + p;
+        if constexpr (AT) {
+            // block = k rows 2*blk, 2*blk+1 of the [64 k][256 m] image; lane -> (k row, physical chunk)
+            const int kr = 2 * blk + (lane >> 5);
+            const int c = (lane & 31) ^ (at_key(kr) << 1);             // logical 16-byte chunk (8 m)
+            int64_t col = (int64_t)bm0 + c * 8;
+            if (col > g.lda - 8) col = g.lda - 8;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g.A + (int64_t)(k0 + kr) * g.lda + col),
+                (__attribute__((address_space(3))) void*)(Ad + blk * 64), 16, 0, SKF_A_AUX);
+        } else {
             const int row = blk * 8 + rr;
-            const int c = MF32 ? (pc ^ ((row >> 1) & 7)) : (pc ^ (row & 7));
+            const int c = pc ^ (row & 7);
             const int m = bm0 + row;
             const int mc = m < g.M ? m : g.M - 1;
             __builtin_amdgcn_global_load_lds(
@@ -1104,434 +1045,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                 (__attribute__((address_space(3))) void*)(Ad + blk * 64), 16, 0, SKF_A_AUX);
         }
     };
-    auto dma_B = [&](int k0, int buf) {
+    auto dma_B1 = [&](int k0, int buf, int p) {
         u32x4* Bd = smem + AST * ASZ + buf * BSZ;
-#pragma unroll
-        for (int p = 0; p < BN / 64; ++p) {
-            const int blk = wave * (BN / 64) + p;
-            const int row = blk * 8 + rr;
-            const int c = MF32 ? (pc ^ ((row >> 1) & 7)) : (pc ^ (row & 7));
-            const int n = bn0 + row;
-            const int nc = n < g.N ? n : g.N - 1;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + (int64_t)(k0 >> 6) * g.b_kstep + c * 8),
-                (__attribute__((address_space(3))) void*)(Bd + blk * 64), 16, 0, SKF_B_AUX);
-        }
-    };
-
-    auto dma_A1 = [&](int k0, int buf, int p) {           // piece p of dma_A
-        u32x4* Ad = smem + buf * ASZ;
-        const int blk = wave * (BM / 64) + p;
+        const int blk = wave * PWB + p;
         const int row = blk * 8 + rr;
-        const int c = MF32 ? (pc ^ ((row >> 1) & 7)) : (pc ^ (row & 7));
-        const int m = bm0 + row;
-        const int mc = m < g.M ? m : g.M - 1;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(g.A + (int64_t)mc * g.lda + (int64_t)(k0 >> 6) * g.a_kstep + c * 8),
-            (__attribute__((address_space(3))) void*)(Ad + blk * 64), 16, 0, SKF_A_AUX);
-    };
-    auto dma_B1 = [&](int k0, int buf, int p) {           // piece p of dma_B
-        u32x4* Bd = smem + AST * ASZ + buf * BSZ;
-        const int blk = wave * (BN / 64) + p;
-        const int row = blk * 8 + rr;
-        const int c = MF32 ? (pc ^ ((row >> 1) & 7)) : (pc ^ (row & 7));
+        const int c = pc ^ (row & 7);
         const int n = bn0 + row;
         const int nc = n < g.N ? n : g.N - 1;
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + (int64_t)(k0 >> 6) * g.b_kstep + c * 8),
             (__attribute__((address_space(3))) void*)(Bd + blk * 64), 16, 0, SKF_B_AUX);
     };
-
-    constexpr int PWA = BM / 64, PWB = BN / 64;          // LDS-DMA instructions per wave and K tile
-    // instructions allowed to stay outstanding when the NEXT tile must be complete
-    constexpr int KEEP = (BST == 3) ? (PWA + PWB) : PWA;
-    static_assert(NSTAGE == 2 || (NSTAGE == 3 && GLDS), "3 stages need the LDS-DMA path");
-    if (nkt > 0) {
-        if constexpr (GLDS) {
-            dma_A(kz0, 0);
-            dma_B(kz0, 0);
-            if constexpr (NSTAGE == 3) {
-                if (nkt > 1) {
-                    dma_A(kz0 + BK, 1);
-                    if constexpr (BST == 3) dma_B(kz0 + BK, 1);
-                    __builtin_amdgcn_s_waitcnt(0x0F70 | KEEP);    // tile 0 has landed
-                } else {
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
-                }
-            } else {
-                __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the LDS-DMA has landed
-            }
-        } else {
-            load_tiles(kz0);
-            store_tiles(0);
-        }
-    }
-    if constexpr (NSTAGE == 3) {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    } else {
-        __syncthreads();
-    }
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt % AST;
-        const int curb = kt % BST;
-        const bool more = (kt + 1 < nkt);
-        if constexpr (NSTAGE == 3 && SKF_V2_SCHED != 0 && !MF32) {
-            // the pieces are issued between the MFMA groups below
-        } else if constexpr (NSTAGE == 3) {
-            // every buffer refilled here was last read in iteration kt-1 and released by its barrier
-            if constexpr (BST == 3) {
-                if (kt + 2 < nkt) {
-                    SKF_PROBE_A(dma_A(kz0 + (kt + 2) * BK, (kt + 2) % 3));
-                    SKF_PROBE_B(dma_B(kz0 + (kt + 2) * BK, (kt + 2) % 3));
-                }
-            } else {
-                if (more) SKF_PROBE_B(dma_B(kz0 + (kt + 1) * BK, (kt + 1) & 1));          // B first ...
-                if (kt + 2 < nkt) SKF_PROBE_A(dma_A(kz0 + (kt + 2) * BK, (kt + 2) % 3));  // ... newest = A(kt+2)
-            }
-        } else if (more) {
-            if constexpr (GLDS) {
-                dma_A(kz0 + (kt + 1) * BK, cur ^ 1);
-                dma_B(kz0 + (kt + 1) * BK, cur ^ 1);
-            } else {
-                load_tiles(kz0 + (kt + 1) * BK);
-            }
-        }
-        const u32x4* As = smem + cur * ASZ;
-        const u32x4* Bs = smem + AST * ASZ + curb * BSZ;
-        if constexpr (MF32) {
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                const int chunk = 2 * kq + (lane >> 5);
-                bf16x8 a[2], b[NJ32];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk32(wm0 + i * 32 + (lane & 31), chunk)]);
-#pragma unroll
-                for (int j = 0; j < NJ32; ++j)
-                    b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk32(wn0 + j * 32 + (lane & 31), chunk)]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ32; ++j)
-                        acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc32[i][j], 0, 0, 0);
-            }
-        } else {
-            if (SKF_MFMA_PRIO) __builtin_amdgcn_s_setprio(SKF_MFMA_PRIO);
-#ifndef SKF_PROBE_NOMFMA
-            if constexpr (NSTAGE == 3 && SKF_V2_SCHED != 0) {
-                // scheduled form: the LDS-DMA pieces of the tiles in flight are issued BETWEEN the groups of
-                // MFMAs (one piece per 16-row block of the wave tile) instead of in one burst after the
-                // barrier, and (SKF_V2_SCHED & 2) the fragments of the second K half are read before the
-                // MFMAs of the first.  Order of the pieces: every B piece of tile kt+1 before the first A
-                // piece of tile kt+2 (BST == 2), so that the counted vmcnt below still means "tile kt+1 landed".
-                constexpr int NPIECE = PWA + PWB;
-                auto piece = [&](int q) {
-                    if (q >= NPIECE) return;
-                    if constexpr (BST == 3) {
-                        if (kt + 2 < nkt) {
-                            if (q < PWA) dma_A1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q);
-                            else dma_B1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q - PWA);
-                        }
-                    } else {
-                        if (q < PWB) {
-                            if (more) dma_B1(kz0 + (kt + 1) * BK, (kt + 1) & 1, q);
-                        } else if (kt + 2 < nkt) {
-                            dma_A1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q - PWB);
-                        }
-                    }
-                };
-                bf16x8 a[2][4], b[2][NJ];
-                auto read_frags = [&](int ks) {
-                    const int chunk = 4 * ks + (lane >> 4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        a[ks][i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        b[ks][j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
-                };
-                read_frags(0);
-                if constexpr ((SKF_V2_SCHED & 6) == 2) read_frags(1);
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    if constexpr ((SKF_V2_SCHED & 2) == 0) {
-                        if (ks == 1) read_frags(1);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        piece(ks * 4 + i);
-                        if constexpr ((SKF_V2_SCHED & 6) == 6) {
-                            if (ks == 0 && i == 0) read_frags(1);      // lands under the next 3 groups
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            } else {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int chunk = 4 * ks + (lane >> 4);
-                bf16x8 a[4], b[NJ];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-            }
-#endif
-            if (SKF_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
-        }
-        if constexpr (NSTAGE == 3) {
-            // tile kt+1 must have landed; tile kt+2 (if it was issued) may stay in flight.
-            // lgkmcnt(0): this wave's fragment reads of buffer `cur` are done before it is refilled.
-            if (kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0070 | KEEP);
-            else __builtin_amdgcn_s_waitcnt(0x0070);
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        } else {
-            if constexpr (GLDS) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) before the barrier publishes the tile
-            } else {
-                if (more) store_tiles(cur ^ 1);
-            }
-            __syncthreads();
-        }
-    }
-
-    float* out = (gridDim.z > 1) ? g.part + (int64_t)blockIdx.z * g.M * g.N : g.C;
-    const int64_t ldo = (gridDim.z > 1) ? g.N : g.ldc;
-    if constexpr (MF32) {
-        // D reg r of a 32 x 32 tile -> row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane & 31
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ32; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = bm0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int n = bn0 + wn0 + j * 32 + (lane & 31);
-                    if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc32[i][j][r];
-                }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = bm0 + wm0 + i * 16 + 4 * (lane >> 4) + r;
-                    const int n = bn0 + wn0 + j * 16 + (lane & 15);
-                    if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc[i][j][r];
-                }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// bf16 relation contraction, "tall" tiles.  Finding (A/B runs at config 3): the v2 kernel runs as fast
-// on 196 of the 256 CUs as on all of them -- what bounds it is the traffic into the L1s (relation
-// tile from HBM + the G^T tile every workgroup re-reads from L2), not the number of busy CUs.  The
-// G^T share is 1/BM per flop, so taller tiles cut it: NW waves (NW/2 x 2, wave tile 64 x BN/2) own
-// a (32 NW) x BN tile --  384 x 256 with 12 waves (3 per SIMD), 512 x 128 with 16 waves -- and the
-// whole LDS holds a 2-deep ring of both operands (LDS-DMA, nt policy on the relation stream).
-//     [DMA tile t+1]  MFMA on tile t  | vmcnt(0) | barrier
-// Same operand contract / swizzle / epilogue as gemm_bf16_v2_kernel.
-// ------------------------------------------------------------------------------------------
-template <int BN, int NW, int TAG>
-__global__ __launch_bounds__(NW * 64) void gemm_bf16_tall_kernel(Bf16GemmArgs g) {
-    constexpr int BM = 32 * NW, BK = 64;
-    constexpr int WN = BN / 2;
-    constexpr int NJ = WN / 16;
-    constexpr int ASZ = BM * 8, BSZ = BN * 8;                   // u32x4 entries per buffer
-    HIP_DYNAMIC_SHARED(u32x4, smem)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * WN;
-    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
-    const int kz0 = blockIdx.z * g.k_chunk;
-    const int kz1 = (kz0 + g.k_chunk < g.Kp) ? kz0 + g.k_chunk : g.Kp;
-    const int nkt = (kz1 - kz0) / BK;
-    const int rr = lane >> 3, pc = lane & 7;
-
-    f32x4 acc[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
     auto dma_A = [&](int k0, int buf) {
-        u32x4* Ad = smem + buf * ASZ;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {                      // BM / 8 row blocks over NW waves = 4 each
-            const int blk = wave * 4 + p;
-            const int row = blk * 8 + rr;
-            const int m = bm0 + row;
-            const int mc = m < g.M ? m : g.M - 1;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g.A + (int64_t)mc * g.lda + (int64_t)(k0 >> 6) * g.a_kstep + (pc ^ (row & 7)) * 8),
-                (__attribute__((address_space(3))) void*)(Ad + blk * 64), 16, 0, SKF_A_AUX);
-        }
+        for (int p = 0; p < PWA; ++p) dma_A1(k0, buf, p);
     };
     auto dma_B = [&](int k0, int buf) {
-        u32x4* Bd = smem + 2 * ASZ + buf * BSZ;
-        for (int blk = wave; blk < BN / 8; blk += NW) {
-            const int row = blk * 8 + rr;
-            const int n = bn0 + row;
-            const int nc = n < g.N ? n : g.N - 1;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + (int64_t)(k0 >> 6) * g.b_kstep + (pc ^ (row & 7)) * 8),
-                (__attribute__((address_space(3))) void*)(Bd + blk * 64), 16, 0, 0);
-        }
-    };
-
-    if (nkt > 0) {
-        dma_A(kz0, 0);
-        dma_B(kz0, 0);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the LDS-DMA has landed
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) {
-            dma_A(kz0 + (kt + 1) * BK, cur ^ 1);
-            dma_B(kz0 + (kt + 1) * BK, cur ^ 1);
-        }
-        const u32x4* As = smem + cur * ASZ;
-        const u32x4* Bs = smem + 2 * ASZ + cur * BSZ;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = 4 * ks + (lane >> 4);
-            bf16x8 a[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
-            constexpr int JB = (NW == 12) ? 2 : 4;          // B fragments per group (register budget: 3 waves/SIMD)
-#pragma unroll
-            for (int jh = 0; jh < NJ; jh += JB) {
-                bf16x8 b[JB];
-#pragma unroll
-                for (int j = 0; j < JB; ++j)
-                    b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + (jh + j) * 16 + (lane & 15), chunk)]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < JB; ++j)
-                        acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][jh + j], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0): next tile landed, reads done
-        __syncthreads();
-    }
-
-    float* out = (gridDim.z > 1) ? g.part + (int64_t)blockIdx.z * g.M * g.N : g.C;
-    const int64_t ldo = (gridDim.z > 1) ? g.N : g.ldc;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = bm0 + wm0 + i * 16 + 4 * (lane >> 4) + r;
-                const int n = bn0 + wn0 + j * 16 + (lane & 15);
-                if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc[i][j][r];
-            }
-}
-
-// ------------------------------------------------------------------------------------------
-// bf16 relation contraction, third generation = the v2 LDS-DMA ring kernel with the fragment
-// reads software-pipelined by half a K tile.  Two fragment register sets alternate:
-//     [ds_read F1 = second half of tile t ]  MFMA on F0 (first half of tile t)
-//     wait (F1 here, tile t+1 landed) ; s_barrier          <- tile t's buffers are free from here
-//     [ds_read F0 = first half of tile t+1]  MFMA on F1
-// so every MFMA block starts on registers that were loaded during the previous block and the
-// only bubble left per K tile is the barrier itself.
-// ------------------------------------------------------------------------------------------
-template <int BN, int TAG>
-__global__ __launch_bounds__(512) void gemm_bf16_v3_kernel(Bf16GemmArgs g) {
-    constexpr int BM = 256, BK = 64;
-    constexpr int WN = BN / 2;
-    constexpr int NJ = WN / 16;
-    constexpr int AST = 3;
-    constexpr int BST = (BN == 256) ? 2 : 3;
-    constexpr int ASZ = BM * 8, BSZ = BN * 8;
-    constexpr int PWA = BM / 64, PWB = BN / 64;
-    constexpr int KEEP = (BST == 3) ? (PWA + PWB) : PWA;
-    HIP_DYNAMIC_SHARED(u32x4, smem)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * WN;
-    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
-    const int kz0 = blockIdx.z * g.k_chunk;
-    const int kz1 = (kz0 + g.k_chunk < g.Kp) ? kz0 + g.k_chunk : g.Kp;
-    const int nkt = (kz1 - kz0) / BK;
-    const int rr = lane >> 3, pc = lane & 7;
-
-    f32x4 acc[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
-    auto dma_A = [&](int k0, int buf) {
-        u32x4* Ad = smem + buf * ASZ;
-#pragma unroll
-        for (int p = 0; p < PWA; ++p) {
-            const int blk = wave * PWA + p;
-            const int row = blk * 8 + rr;
-            const int m = bm0 + row;
-            const int mc = m < g.M ? m : g.M - 1;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g.A + (int64_t)mc * g.lda + (int64_t)(k0 >> 6) * g.a_kstep + (pc ^ (row & 7)) * 8),
-                (__attribute__((address_space(3))) void*)(Ad + blk * 64), 16, 0, 0);
-        }
-    };
-    auto dma_B = [&](int k0, int buf) {
-        u32x4* Bd = smem + AST * ASZ + buf * BSZ;
-#pragma unroll
-        for (int p = 0; p < PWB; ++p) {
-            const int blk = wave * PWB + p;
-            const int row = blk * 8 + rr;
-            const int n = bn0 + row;
-            const int nc = n < g.N ? n : g.N - 1;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g.Bt + (int64_t)nc * g.ldb + (int64_t)(k0 >> 6) * g.b_kstep + (pc ^ (row & 7)) * 8),
-                (__attribute__((address_space(3))) void*)(Bd + blk * 64), 16, 0, 0);
-        }
-    };
-    bf16x8 a0[4], b0[NJ], a1[4], b1[NJ];
-    auto read_frags = [&](bf16x8 (&a)[4], bf16x8 (&b)[NJ], int kt, int ks) {
-        const u32x4* As = smem + (kt % AST) * ASZ;
-        const u32x4* Bs = smem + AST * ASZ + (kt % BST) * BSZ;
-        const int chunk = 4 * ks + (lane >> 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
-    };
-    auto mma_block = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[NJ]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int p = 0; p < PWB; ++p) dma_B1(k0, buf, p);
     };
 
     if (nkt > 0) {
@@ -1540,7 +1071,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v3_kernel(Bf16GemmArgs g) {
         if (nkt > 1) {
             dma_A(kz0 + BK, 1);
             if constexpr (BST == 3) dma_B(kz0 + BK, 1);
-            __builtin_amdgcn_s_waitcnt(0x0F70 | KEEP);
+            __builtin_amdgcn_s_waitcnt(0x0F70 | KEEP);    // tile 0 has landed
         } else {
             __builtin_amdgcn_s_waitcnt(0x0F70);
         }
@@ -1548,35 +1079,85 @@ __global__ __launch_bounds__(512) void gemm_bf16_v3_kernel(Bf16GemmArgs g) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (nkt > 0) read_frags(a0, b0, 0, 0);
 
     for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt % AST;
+        const int curb = kt % BST;
         const bool more = (kt + 1 < nkt);
-        if constexpr (BST == 3) {
-            if (kt + 2 < nkt) {
-                dma_A(kz0 + (kt + 2) * BK, (kt + 2) % 3);
-                dma_B(kz0 + (kt + 2) * BK, (kt + 2) % 3);
+        // every buffer refilled in this step was last read in step kt-1 and released by its barrier.
+        // BST == 2: every B piece of tile kt+1 goes out before the first A piece of tile kt+2
+        auto piece = [&](int q) {
+            if (q >= PWA + PWB) return;
+            if constexpr (BST == 3) {
+                if (kt + 2 < nkt) {
+                    if (q < PWA) SKF_PROBE_A(dma_A1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q));
+                    else SKF_PROBE_B(dma_B1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q - PWA));
+                }
+            } else {
+                if (q < PWB) {
+                    if (more) SKF_PROBE_B(dma_B1(kz0 + (kt + 1) * BK, (kt + 1) & 1, q));
+                } else if (kt + 2 < nkt) {
+                    SKF_PROBE_A(dma_A1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q - PWB));
+                }
             }
-        } else {
-            if (more) dma_B(kz0 + (kt + 1) * BK, (kt + 1) & 1);
-            if (kt + 2 < nkt) dma_A(kz0 + (kt + 2) * BK, (kt + 2) % 3);
+        };
+        const u32x4* As = smem + cur * ASZ;
+        const u32x4* Bs = smem + AST * ASZ + curb * BSZ;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], b[NJ];
+#ifndef SKF_PROBE_NOMFMA
+            if constexpr (AT) {
+                const unsigned char* Ab = (const unsigned char*)As;
+                const int i16 = lane & 15, grp = lane >> 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = ((wm0 + i * 16) >> 3) + ((i16 & 3) >> 1);        // logical chunk of this lane's 4 m
+                    s16x4 h[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int kr = ks * 32 + 8 * grp + 4 * hh + (i16 >> 2);
+                        const unsigned char* ptr = Ab + kr * 512 + ((c ^ (at_key(kr) << 1)) << 4) + ((i16 & 1) << 3);
+                        h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
+                    }
+                    const s16x8 v = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+                    a[i] = __builtin_bit_cast(bf16x8, v);
+                }
+            } else {
+                const int chunk = 4 * ks + (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
+            }
+            {
+                const int chunk = 4 * ks + (lane >> 4);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
+            }
+#endif
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#ifndef SKF_PROBE_NOMFMA
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                piece(ks * 4 + i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        read_frags(a1, b1, kt, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_block(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        // F1 has arrived (lgkmcnt 0) -> this wave no longer reads tile kt; tile kt+1 has landed
+        // tile kt+1 must have landed; tile kt+2 (if it was issued) may stay in flight.
+        // lgkmcnt(0): this wave's fragment reads of buffer `cur` are done before it is refilled.
         if (kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0070 | KEEP);
         else __builtin_amdgcn_s_waitcnt(0x0070);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (more) read_frags(a0, b0, kt + 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_block(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
     }
 
+    // D reg r of a 16 x 16 tile -> row = 4*(lane>>4) + r, col = lane & 15
     float* out = (gridDim.z > 1) ? g.part + (int64_t)blockIdx.z * g.M * g.N : g.C;
     const int64_t ldo = (gridDim.z > 1) ? g.N : g.ldc;
 #pragma unroll
@@ -1728,39 +1309,48 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(uint16_t* __rest
     }
 }
 
-// DFMC iteration 0: R[mask] = 0   (_dfmc.py:287-292)
+// DFMC iteration 0: R[mask] = 0   (_dfmc.py:287-292); the mask is packed, one bit per entry
 template <typename T>
 __global__ __launch_bounds__(256) void mask_zero_kernel(T* __restrict__ R, int64_t ldr,
-                                                        const uint8_t* __restrict__ mask, int64_t ldm,
+                                                        const uint8_t* __restrict__ mbits, int64_t ldmb,
                                                         int64_t rows, int64_t cols) {
     const int64_t total = rows * cols;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / cols, c = e % cols;
-        if (mask[r * ldm + c]) R[r * ldr + c] = (T)0;
+        if ((mbits[r * ldmb + (c >> 3)] >> (c & 7)) & 1) R[r * ldr + c] = (T)0;
     }
 }
 
-// bf16 engine, DFMC iteration 0: the stored transpose gets the same zeros, RT[c][r] = 0 where mask[r][c].
-// 64 x 64 tiles through LDS: the mask is read along its rows, R^T written along its rows.
-__global__ __launch_bounds__(256) void mask_zero_transposed_kernel(uint16_t* __restrict__ RT, int64_t ldrt,
-                                                                   const uint8_t* __restrict__ mask, int64_t ldm,
-                                                                   int64_t rows, int64_t cols) {
-    __shared__ uint8_t tile[64][65];
-    const int64_t tiles_c = (cols + 63) / 64, tiles = ((rows + 63) / 64) * tiles_c;
-    const int tid = threadIdx.x;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const int64_t r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
-        for (int i = tid; i < 4096; i += 256) {
-            const int rr = i >> 6, cc = i & 63;
-            tile[rr][cc] = (r0 + rr < rows && c0 + cc < cols) ? mask[(r0 + rr) * ldm + c0 + cc] : (uint8_t)0;
-        }
-        __syncthreads();
-        for (int i = tid; i < 4096; i += 256) {
-            const int cc = i >> 6, rr = i & 63;
-            if (tile[rr][cc]) RT[(c0 + cc) * ldrt + r0 + rr] = 0;
-        }
-        __syncthreads();
+// mask bytes (one per entry, != 0 = unknown) -> packed bits [rows][ldmb bytes]; bits / bytes past `cols` are zero
+__global__ __launch_bounds__(256) void pack_mask_kernel(uint8_t* __restrict__ dst, int64_t ldmb,
+                                                        const uint8_t* __restrict__ src, int64_t lds,
+                                                        int64_t rows, int64_t cols) {
+    const int64_t total = rows * ldmb;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / ldmb, b = e % ldmb;
+        uint32_t v = 0u;
+        const uint8_t* p = src + r * lds + b * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (b * 8 + q < cols && p[q]) v |= 1u << q;
+        dst[e] = (uint8_t)v;
+    }
+}
+
+// packed mask rows copied into the engine's layout (bytes past the source row are zeroed by the caller)
+__global__ __launch_bounds__(256) void copy_mask_bits_kernel(uint8_t* __restrict__ dst, int64_t ldmb,
+                                                             const uint8_t* __restrict__ src, int64_t lds,
+                                                             int64_t rows, int64_t cols) {
+    const int64_t nb = (cols + 7) / 8, total = rows * nb;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / nb, b = e % nb;
+        uint32_t v = src[r * lds + b];
+        const int64_t left = cols - b * 8;
+        if (left < 8) v &= (1u << left) - 1u;
+        dst[r * ldmb + b] = (uint8_t)v;
     }
 }
 

@@ -313,6 +313,29 @@ inline void __builtin_amdgcn_global_load_lds(PS src, PD dst, unsigned size, int 
     memcpy(base + (size_t)simt::lane_id() * size, (const unsigned char*)(uintptr_t)src + offset, size);
     simt::wave_sync();
 }
+// ds_read_b64_tr_b16 (gfx950; lane map measured on the hardware by tools/probe/tr_probe.hip): every lane
+// addresses 4 consecutive halfwords; lane i of a 16-lane group, element j <- the halfword that lane
+// 4*j + (i >> 2) of the same group addresses, its element i & 3 (a [4][16] block leaves transposed).
+typedef short simt_s16x4 __attribute__((ext_vector_type(4)));
+template <class P>
+inline simt_s16x4 __builtin_amdgcn_ds_read_tr16_b64_v4i16(P ptr) {
+    if (((uintptr_t)ptr) & 7) simt::die("ds_read_b64_tr_b16: address not 8-byte aligned");
+    simt_s16x4 mine;
+    memcpy(&mine, (const void*)(uintptr_t)ptr, sizeof mine);
+    simt::WaveSync& ws = simt::my_wave();
+    const int l = simt::lane_id();
+    memcpy(ws.xchg[l], &mine, sizeof mine);
+    simt::wave_sync();
+    simt_s16x4 r;
+    const int grp = l & ~15, i = l & 15;
+    for (int j = 0; j < 4; ++j) {
+        simt_s16x4 other;
+        memcpy(&other, ws.xchg[grp + 4 * j + (i >> 2)], sizeof other);
+        r[j] = other[i & 3];
+    }
+    simt::wave_sync();
+    return r;
+}
 inline void __builtin_amdgcn_fence(int, const char*) {}
 inline void __builtin_amdgcn_wave_barrier() { simt::wave_sync(); }
 inline void __builtin_amdgcn_s_barrier() { simt::block_barrier(); }

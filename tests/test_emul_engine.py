@@ -182,8 +182,14 @@ def test_bf16_engine_against_oracle_on_bf16_rounded_relations():
     plan.iterate(2)
     Gd = {(t, t): plan.get_factor(t) for t in types}
     for k, (i, j, Rm, _) in enumerate(rel):
-        want = np.linalg.norm(Rb[i, j][0] - Gd[i, i] @ plan.get_backbone(k) @ Gd[j, j].T) ** 2
-        assert abs(plan.relation_sqerr(k) - want) < 1e-4 * want
+        # the residual pass multiplies bf16-rounded H = G_i S and G_j on the matrix cores (f32 accumulate)
+        rb = lambda x: nat.from_bf16_bits(nat.to_bf16_bits(x.astype(np.float32))).astype(np.float64)
+        H = Gd[i, i] @ plan.get_backbone(k)
+        want_b = np.linalg.norm(Rb[i, j][0] - rb(H) @ rb(Gd[j, j]).T) ** 2
+        want = np.linalg.norm(Rb[i, j][0] - H @ Gd[j, j].T) ** 2
+        got = plan.relation_sqerr(k)
+        assert abs(got - want_b) < 2e-5 * want_b
+        assert abs(got - want) < 2e-3 * want
     plan.close()
 
 
@@ -296,11 +302,13 @@ def test_row_block_sharding_bf16_and_abi_errors():
                    nat.SKF_DFMF, dtype='bf16')
 
 
-def test_bf16_completion_kernel_against_f32_product(monkeypatch):
-    """complete_bf16_kernel (bf16 H, G_j on the matrix cores; R and R^T written in 16-byte chunks
-    with the known entries blended back) against the f32 product + per-element masked store, on
-    shapes that are not multiples of the 128 x 128 tile / of 8, with a misaligned mask pitch."""
-    from skfusion_amd._engine import DevicePlan, flatten_relations
+def test_bf16_completion_kernel_against_f32_engine():
+    """tile_epilogue_bf16_kernel<MODE_COMPLETE> (bf16 H, G_j on the matrix cores; the one stored copy of
+    R written in 16-byte chunks with the known entries blended back; the mask as packed bits) against the
+    f32 engine's per-element masked store on the bf16-rounded relation, on shapes that are not multiples of
+    the 128 x 128 tile / of 8.  The mask arrives once as host booleans (packed on the host,
+    SKF_REL_MASK_BITS) and once as device bytes (packed by the library at bind time)."""
+    from skfusion_amd._engine import DevicePlan, DeviceMatrix, flatten_relations
     rs = np.random.RandomState(9)
     types, n, rank = ['a', 'b'], {'a': 203, 'b': 157}, {'a': 7, 'b': 5}
     R = {('a', 'b'): [rs.rand(203, 157)]}
@@ -309,22 +317,56 @@ def test_bf16_completion_kernel_against_f32_product(monkeypatch):
     mask[6, :] = False
     mask[:, 11] = True
     G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.1 for t in types}
-    out = {}
-    for slow in ('1', '0'):
-        monkeypatch.setenv('SKF_BF16_COMPLETE_F32', slow)
-        G, S = _dfmc.dfmc(R, {('a', 'b'): [mask]}, {}, types, rank, max_iter=3, G0=G0, dtype='bf16')
-        out[slow] = (G, S)
-    for t in types:                                   # measured 2.5e-4 / 4.3e-4 (G), 3.4e-3 (S)
-        assert relerr(out['0'][0][t, t], out['1'][0][t, t]) < 2e-3
-    assert relerr(out['0'][1]['a', 'b'][0], out['1'][1]['a', 'b'][0]) < 2e-2
-    # the stored copies stay consistent with each other and the known entries are untouched:
-    # reconstruction error on the known entries equals the oracle's on the bf16-rounded relation
     Rb = {k: [nat.from_bf16_bits(nat.to_bf16_bits(v[0])).astype(np.float64)] for k, v in R.items()}
+    Gf, Sf = _dfmc.dfmc(Rb, {('a', 'b'): [mask]}, {}, types, rank, max_iter=3, G0=G0, dtype='f32')
+    G, S = _dfmc.dfmc(R, {('a', 'b'): [mask]}, {}, types, rank, max_iter=3, G0=G0, dtype='bf16')
+    for t in types:                                   # measured 2.5e-4 / 4.3e-4 (G), 3.4e-3 (S) in round 1
+        assert relerr(G[t, t], Gf[t, t]) < 2e-3
+    assert relerr(S['a', 'b'][0], Sf['a', 'b'][0]) < 2e-2
+    # the known entries are untouched: reconstruction error on them equals the oracle's
     Go, So = orc.dfmc(Rb, {('a', 'b'): [mask]}, {}, types, rank, max_iter=3, G0=G0)
-    G, S = out['0']
     e = np.linalg.norm((Rb['a', 'b'][0] - G['a', 'a'] @ S['a', 'b'][0] @ G['b', 'b'].T)[~mask])
     eo = np.linalg.norm((Rb['a', 'b'][0] - Go['a', 'a'] @ So['a', 'b'][0] @ Go['b', 'b'].T)[~mask])
     assert abs(e - eo) < 2e-2 * eo
+    # byte mask in device memory with a pitch that is no multiple of 8: bit-identical factors
+    rt = nat.get_runtime()
+    pitch = 163
+    mb = np.zeros((203, pitch), np.uint8)
+    mb[:, :157] = mask
+    dev_mask = DeviceMatrix(rt.mem.from_host(mb), (203, 157), pitch)
+    plans = []
+    for m in (mask, dev_mask):
+        plan = DevicePlan(types, n, rank, [('a', 'b', R['a', 'b'][0], m)], [], nat.SKF_DFMC, dtype='bf16')
+        for t in types:
+            plan.set_factor(t, G0[t, t])
+        plan.iterate(3)
+        plans.append([plan.get_factor(t) for t in types])
+        plan.close()
+    for x, y in zip(*plans):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_relation_sqerr_counts_the_partials_of_the_tile_it_launches():
+    """Regression (round-1 advisor finding): an all-f64 residual product of a small relation with
+    64 <= c_j <= 1024 runs on the deep 32 x 32 tile; the sum must cover one partial per workgroup of
+    THAT tile.  100 x 140 relation, ranks 8 / 64 (and 70 / 96), all three engines."""
+    from skfusion_amd._engine import DevicePlan
+    rs = np.random.RandomState(31)
+    for ranks in ((8, 64), (70, 96)):
+        types, n, rank = ['a', 'b'], {'a': 100, 'b': 140}, {'a': ranks[0], 'b': ranks[1]}
+        Rm = rs.rand(100, 140)
+        G0 = {t: rs.rand(n[t], rank[t]) + 0.1 for t in types}
+        for dtype, tol in (('f64', 1e-9), ('f32', 1e-5), ('bf16', 5e-3)):
+            plan = DevicePlan(types, n, rank, [('a', 'b', Rm, None)], [], nat.SKF_DFMF, dtype=dtype)
+            for t in types:
+                plan.set_factor(t, G0[t])
+            plan.iterate(2)
+            Gd = {t: plan.get_factor(t) for t in types}
+            Rref = nat.from_bf16_bits(nat.to_bf16_bits(Rm)).astype(np.float64) if dtype == 'bf16' else Rm
+            want = np.linalg.norm(Rref - Gd['a'] @ plan.get_backbone(0) @ Gd['b'].T) ** 2
+            got = plan.relation_sqerr(0)
+            assert abs(got - want) < tol * want, (ranks, dtype, got, want)
+            plan.close()
 
 
 @pytest.mark.parametrize('tile', ['', '128'])

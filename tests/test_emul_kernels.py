@@ -38,7 +38,7 @@ def run_gemm(rt, dtype, engine, A, B, transA=False, transB=False, aop=0, epi=0, 
     d.aop, d.epi, d.nan_to_num, d.splits = aop, epi, nan, splits
     d.a_dtype, d.b_dtype = a_dtype, b_dtype
     keep = None
-    if mask is not None:
+    if mask is not None:                    # the stand-alone operator takes one byte per entry
         keep = mem.from_host(np.ascontiguousarray(mask, dtype=np.uint8))
         d.mask, d.ldmask = keep.ptr, N
     ws = mem.empty(64 * M * N * 8 + 256)
@@ -152,43 +152,49 @@ def run_gemm_bf16(rt, A, B, splits=0):
 
 
 @pytest.mark.parametrize('shape', [(1, 1, 1), (16, 16, 32), (128, 128, 64), (130, 100, 70), (257, 128, 200),
-                                   (100, 256, 129), (200, 200, 500), (129, 300, 64)])
+                                   (100, 256, 129), (200, 200, 500), (129, 300, 64),
+                                   (4100, 128, 70), (4200, 256, 200), (4097, 300, 64)])
 def test_gemm_bf16_contraction(rt, shape):
-    """Both workgroup shapes: 128-row single-buffered and 256-row double-buffered kernels."""
-    import os
+    """Both workgroup shapes: the 128-row register-staged kernel (M < 4096) and the 256-row LDS-DMA
+    kernel with its 3-deep ring and scheduled DMA pieces (M >= 4096); row / column / K tails, split-K."""
     M, N, K = shape
     rs = np.random.RandomState(M + N + K)
     A, B = rs.randn(M, K), rs.randn(K, N)           # asymmetric operands
-    for tile, mf, gl, st, pipe in (('128', '16', '1', '3', '1'), ('256', '32', '1', '2', '1'), ('256', '16', '1', '3', '1'),
-                                   ('256', '16', '1', '3', '0'), ('256', '16', '1', '2', '1'), ('256', '16', '0', '2', '1'),
-                                   ('256', '32', '0', '2', '1')):
-        os.environ['SKF_BF16_TILE'] = tile
-        os.environ['SKF_BF16_PIPE'] = pipe
-        os.environ['SKF_BF16_MFMA'] = mf
-        os.environ['SKF_BF16_GLDS'] = gl
-        os.environ['SKF_BF16_STAGES'] = st
-        try:
-            for splits in (0, 1, 3):
-                got, want = run_gemm_bf16(rt, A, B, splits)
-                assert relerr(got, want) < 2e-6, (tile, mf, gl, st, pipe, splits)   # exact products, f32 accumulation
-        finally:
-            os.environ.pop('SKF_BF16_TILE', None)
-            os.environ.pop('SKF_BF16_MFMA', None)
-            os.environ.pop('SKF_BF16_GLDS', None)
-            os.environ.pop('SKF_BF16_STAGES', None)
-            os.environ.pop('SKF_BF16_PIPE', None)
-
-
-@pytest.mark.parametrize('shape', [(257, 128, 200), (100, 256, 129), (700, 300, 130), (1030, 64, 70)])
-def test_gemm_bf16_tall_tiles(rt, shape, monkeypatch):
-    """gemm_bf16_tall_kernel: 384 x 256 tiles (12 waves) for N > 128, 512 x 128 tiles (16 waves) otherwise;
-    row / column / K tails, several row and column tiles, split-K."""
-    monkeypatch.setenv('SKF_BF16_TALL', '2')
-    M, N, K = shape
-    rs = np.random.RandomState(M + N + K)
-    A, B = rs.randn(M, K), rs.randn(K, N)
-    for splits in (0, 1, 2):
+    for splits in ((0, 1, 3) if M < 4096 else (0, 2)):
         got, want = run_gemm_bf16(rt, A, B, splits)
+        assert relerr(got, want) < 2e-6, splits     # exact products, f32 accumulation
+
+
+def run_gemm_bf16_tn(rt, R, G, splits=0):
+    """Q = R^T @ G through skf_gemm_bf16_tn: R (K x M, row-major, the relation as stored) is read
+    transposed out of LDS; G (K x N) is passed as the stored transpose G^T."""
+    K, M = R.shape
+    N = G.shape[1]
+    Kp = (K + 63) // 64 * 64
+    lda = (M + 63) // 64 * 64
+    Rb = np.zeros((Kp, lda), np.uint16)
+    Rb[:K, :M] = nat.to_bf16_bits(R)
+    Gt = np.zeros((N, Kp), np.uint16)
+    Gt[:, :K] = nat.to_bf16_bits(G.T)
+    a, b = rt.mem.from_host(Rb), rt.mem.from_host(Gt)
+    c = rt.mem.empty(M * N * 4)
+    ws = rt.mem.empty(40 * M * N * 4 + 256)
+    rt.call('skf_gemm_bf16_tn', a.ptr, lda, b.ptr, Kp, c.ptr, N, M, N, Kp, splits, ws.ptr, ws.nbytes, None)
+    got = rt.mem.to_host(c, (M, N), np.float32)
+    want = nat.from_bf16_bits(Rb[:K, :M]).astype(np.float64).T @ nat.from_bf16_bits(Gt[:, :K]).astype(np.float64).T
+    return got, want
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1), (16, 16, 32), (64, 128, 64), (100, 130, 70), (200, 257, 128),
+                                   (129, 100, 256), (500, 200, 200), (64, 129, 300), (300, 520, 100)])
+def test_gemm_bf16_transposed_a(rt, shape):
+    """Q = R^T G_i from the row-major relation: LDS-DMA of [64 k][256 m] tiles, ds_read_b64_tr_b16 fragments
+    (emulated with the lane map measured on the hardware); K x M x N with tails everywhere, split-K."""
+    K, M, N = shape
+    rs = np.random.RandomState(M + N + K)
+    R, G = rs.randn(K, M), rs.randn(K, N)           # asymmetric: a transposed or mis-swizzled read cannot pass
+    for splits in (0, 1, 2):
+        got, want = run_gemm_bf16_tn(rt, R, G, splits)
         assert relerr(got, want) < 2e-6, splits
 
 

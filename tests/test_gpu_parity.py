@@ -80,6 +80,13 @@ def test_gemm_bf16_contraction(rt, shape):
     K.test_gemm_bf16_contraction(rt, shape)
 
 
+@pytest.mark.parametrize('shape', [(1, 1, 1), (16, 16, 32), (100, 130, 70), (200, 257, 128), (129, 100, 256),
+                                   (64, 129, 300), (300, 520, 100), (10000, 3000, 256), (6000, 4097, 128)])
+def test_gemm_bf16_transposed_a(rt, shape):
+    """Q = R^T G_i read from the row-major relation (ds_read_b64_tr_b16 fragments) on the hardware."""
+    K.test_gemm_bf16_transposed_a(rt, shape)
+
+
 def test_to_bf16(rt):
     K.test_to_bf16_and_transpose(rt)
 

@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--shapes', default='P12,Q12')
     ap.add_argument('--tiles', default='128,256')
     ap.add_argument('--splits', default='0')
+    ap.add_argument('--tn', action='store_true', help='transposed-A form (skf_gemm_bf16_tn): A = the row-major relation [K][M]')
     ap.add_argument('--zero', action='store_true', help='all-zero operands (power / DVFS probe)')
     args = ap.parse_args()
     import torch
@@ -37,14 +38,20 @@ def main():
             Bt = fill_uniform((npad, Kp), 2, 'bf16', scale=0.0)
         C = rt.mem.empty(M * N * 4)
         ws = rt.mem.empty(32 * M * N * 4)
+        if args.tn:
+            lda = (M + 63) // 64 * 64
+            A = fill_uniform((Kp, lda), 1, 'bf16', scale=0.0 if args.zero else 1.0)
         for tile in args.tiles.split(','):
-            os.environ['SKF_BF16_TILE'] = tile
             for sp in args.splits.split(','):
                 sp = int(sp)
 
                 def run():
-                    rt.call('skf_gemm_bf16', A.buf.ptr, Kp, Bt.buf.ptr, Kp, C.ptr, N, M, N, Kp, sp, ws.ptr,
-                            ws.nbytes, rt.mem.stream)
+                    if args.tn:
+                        rt.call('skf_gemm_bf16_tn', A.buf.ptr, lda, Bt.buf.ptr, Kp, C.ptr, N, M, N, Kp, sp, ws.ptr,
+                                ws.nbytes, rt.mem.stream)
+                    else:
+                        rt.call('skf_gemm_bf16', A.buf.ptr, Kp, Bt.buf.ptr, Kp, C.ptr, N, M, N, Kp, sp, ws.ptr,
+                                ws.nbytes, rt.mem.stream)
                 run()
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -54,7 +61,7 @@ def main():
                 e1.record(rt.mem._stream)
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / args.reps
-                print(('zero ' if args.zero else '') + '%s M=%d N=%d K=%d tile=%s splits=%d : %.3f ms  %.0f TFLOP/s  (A stream %.2f TB/s)'
+                print(('zero ' if args.zero else '') + ('tn ' if args.tn else '') + '%s M=%d N=%d K=%d tile=%s splits=%d : %.3f ms  %.0f TFLOP/s  (A stream %.2f TB/s)'
                       % (name, M, N, K, tile, sp, ms, 2.0 * M * N * K / ms / 1e9, M * Kp * 2 / ms / 1e9), flush=True)
 
 
