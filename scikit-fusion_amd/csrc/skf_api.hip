@@ -569,12 +569,9 @@ static void launch_chol(const EighArgs& e, int batch, int max_order, hipStream_t
         size_t wave_tiles = (size_t)(EIGH_THREADS / 64) * CHOLB_NB * (CHOLB_NB + 1);
         size_t panel = (size_t)CHOLB_NB * max_order;
         size_t smem = ((size_t)CHOLB_NB * (CHOLB_NB + 1) + (panel > wave_tiles ? panel : wave_tiles)) * sizeof(double);
-        static bool attr_done = false;
-        if (!attr_done) {
-            SKF_HIP(hipFuncSetAttribute((const void*)chol_inverse_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(((size_t)CHOLB_NB * (CHOLB_NB + 1) + (size_t)CHOLB_NB * CHOLB_MAXN) * sizeof(double))));
-            attr_done = true;
-        }
+        static std::once_flag once;
+        allow_dynamic_lds(once, chol_inverse_blocked_kernel,
+                          (int)(((size_t)CHOLB_NB * (CHOLB_NB + 1) + (size_t)CHOLB_NB * CHOLB_MAXN) * sizeof(double)));
         hipLaunchKernelGGL(chol_inverse_blocked_kernel, dim3((unsigned)batch), dim3(EIGH_THREADS), smem, st, e,
                            chol_rel_threshold());
     } else {
@@ -949,14 +946,9 @@ static void stage_backbone(skf_plan* p, hipStream_t st) {
                 const size_t need = ((size_t)bb.ci[q] * bb.ci[q] + 2 * (size_t)bb.ci[q] * bb.cj[q] + (size_t)bb.cj[q] * bb.cj[q]) * 8;
                 if (need > smem) smem = need;
             }
-            static bool attr = false;
-            if (!attr) {
-                SKF_HIP(hipFuncSetAttribute((const void*)backbone_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            4 * SMALLC * SMALLC * 8));
-                SKF_HIP(hipFuncSetAttribute((const void*)bterms_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            4 * SMALLC * SMALLC * 8));
-                attr = true;
-            }
+            static std::once_flag once_bb, once_bt;
+            allow_dynamic_lds(once_bb, backbone_small_kernel, 4 * SMALLC * SMALLC * 8);
+            allow_dynamic_lds(once_bt, bterms_small_kernel, 4 * SMALLC * SMALLC * 8);
             hipLaunchKernelGGL(backbone_small_kernel, dim3(nb), dim3(256), smem, st, bb);
             check_launch("backbone_small");
         }

@@ -989,6 +989,28 @@ __global__ __launch_bounds__(256) void tile_epilogue_bf16_kernel(TileEpiArgs g) 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+// ds_read_b64_tr_b16 with an immediate byte offset.  Issued as inline assembly: the compiler's waitcnt pass
+// treats the builtin form as a possible reader of every LDS-DMA in flight and puts s_waitcnt vmcnt(0) in
+// front of it (which serialises the ring); it knows nothing about this form, so the results are claimed
+// with lds_tr_wait() -- lgkmcnt(0) tied to the result registers -- before the first use.
+// (tests/emul defines SKF_HOST_EMULATOR: the host emulator models the instruction behind the builtin's name.)
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_read_tr16_b64(const unsigned char* p) {
+#ifdef SKF_HOST_EMULATOR
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + OFF));
+#else
+    s16x4 r;
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+#endif
+}
+__device__ __forceinline__ void lds_tr_wait(s16x4& a, s16x4& b, s16x4& c, s16x4& d, s16x4& e, s16x4& f, s16x4& g, s16x4& h) {
+#ifndef SKF_HOST_EMULATOR
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+#endif
+}
+
 // swizzle key of a k row of the transposed A image (AT)
 __device__ __forceinline__ int at_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
@@ -1107,20 +1129,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a[4], b[NJ];
 #ifndef SKF_PROBE_NOMFMA
+            {   // B fragments first: the transposed A reads below end in an lgkmcnt(0) that covers both
+                const int chunk = 4 * ks + (lane >> 4);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
+            }
             if constexpr (AT) {
                 const unsigned char* Ab = (const unsigned char*)As;
                 const int i16 = lane & 15, grp = lane >> 4;
+                // k rows kr (first half) and kr + 4 (second half, same swizzle key: +2048 bytes)
+                const int kr = ks * 32 + 8 * grp + (i16 >> 2);
+                s16x4 h[4][2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int c = ((wm0 + i * 16) >> 3) + ((i16 & 3) >> 1);        // logical chunk of this lane's 4 m
-                    s16x4 h[2];
+                    const unsigned char* ptr = Ab + kr * 512 + ((c ^ (at_key(kr) << 1)) << 4) + ((i16 & 1) << 3);
+                    h[i][0] = lds_read_tr16_b64<0>(ptr);
+                    h[i][1] = lds_read_tr16_b64<2048>(ptr);
+                }
+                lds_tr_wait(h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]);
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const int kr = ks * 32 + 8 * grp + 4 * hh + (i16 >> 2);
-                        const unsigned char* ptr = Ab + kr * 512 + ((c ^ (at_key(kr) << 1)) << 4) + ((i16 & 1) << 3);
-                        h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
-                    }
-                    const s16x8 v = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+                for (int i = 0; i < 4; ++i) {
+                    const s16x8 v = {h[i][0][0], h[i][0][1], h[i][0][2], h[i][0][3], h[i][1][0], h[i][1][1], h[i][1][2], h[i][1][3]};
                     a[i] = __builtin_bit_cast(bf16x8, v);
                 }
             } else {
@@ -1128,12 +1159,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
-            }
-            {
-                const int chunk = 4 * ks + (lane >> 4);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
             }
 #endif
 #pragma unroll

@@ -22,6 +22,7 @@
 // that a forward order hides).
 // =====================================================================================
 #pragma once
+#define SKF_HOST_EMULATOR 1
 #include <ucontext.h>
 #include <cmath>
 #include <cstdint>

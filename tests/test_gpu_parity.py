@@ -387,9 +387,10 @@ def test_graph_replay_matches_golden(monkeypatch):
         assert np.isfinite(Gc[t, t]).all()
 
 
-def test_bf16_completion_kernel(monkeypatch):
+def test_bf16_completion_kernel_and_residual_pass():
     import test_emul_engine as E
-    E.test_bf16_completion_kernel_against_f32_product(monkeypatch)
+    E.test_bf16_completion_kernel_against_f32_engine()
+    E.test_relation_sqerr_counts_the_partials_of_the_tile_it_launches()
 
 
 def test_bf16_engine_c1_and_c3_scaled():

@@ -1,0 +1,46 @@
+#!/bin/bash
+# Round-2 GPU session: tools/gpu_round2.sh <out-name> <step>...   outputs -> gpurun_out/<out-name>/
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out/$1; shift
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+for step in "$@"; do
+case "$step" in
+  smoke)
+    ( time python __graft_entry__.py --smoke ) > "$OUT/smoke.log" 2>&1; echo "smoke exit $?" | tee -a "$OUT/summary.txt"; tail -2 "$OUT/smoke.log" | tee -a "$OUT/summary.txt" ;;
+  tests)
+    ( time timeout 1500 python -m pytest tests -m gpu -q -x --durations=10 ) > "$OUT/pytest.log" 2>&1
+    echo "pytest exit $?" | tee -a "$OUT/summary.txt"; tail -25 "$OUT/pytest.log" | tee -a "$OUT/summary.txt" ;;
+  tests_all)
+    ( time timeout 1500 python -m pytest tests -m gpu -q --durations=10 ) > "$OUT/pytest.log" 2>&1
+    echo "pytest exit $?" | tee -a "$OUT/summary.txt"; tail -40 "$OUT/pytest.log" | tee -a "$OUT/summary.txt" ;;
+  tnbench)
+    for a in "" "--tn"; do python tools/bench_gemm_bf16.py --shapes Q12,Q13,Q23 --tiles 256 --reps 10 $a 2>&1 | grep -v -e Warning -e amdgpu.ids | tee -a "$OUT/tnbench.txt"; done ;;
+  bench_*)
+    dt=${step#bench_}
+    ( time timeout 900 python bench.py --dtype $dt --steps 20 --warmup 3 --no-cpu-baseline ) > "$OUT/bench_$dt.log" 2>&1
+    echo "bench $dt exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/bench_$dt.log" | cut -c1-600 | tee -a "$OUT/summary.txt" ;;
+  fullbench)
+    ( time timeout 1200 python bench.py ) > "$OUT/bench_full.log" 2>&1
+    echo "bench exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/bench_full.log" | tee -a "$OUT/summary.txt" ;;
+  c5_*)
+    dt=${step#c5_}
+    ( time timeout 900 python bench.py --workload c5 --dtype $dt --steps 10 --warmup 2 --no-cpu-baseline ) > "$OUT/c5_$dt.log" 2>&1
+    echo "c5 $dt exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/c5_$dt.log" | cut -c1-900 | tee -a "$OUT/summary.txt" ;;
+  prof_*)
+    dt=${step#prof_}
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_$dt" -o prof -- python "$OLDPWD/bench.py" --dtype $dt --steps 5 --warmup 2 --no-cpu-baseline ) > "$OUT/prof_$dt.log" 2>&1
+    echo "rocprof $dt exit $?" | tee -a "$OUT/summary.txt"
+    f=$(find "$OUT/prof_$dt" -name '*kernel_stats.csv' | head -1)
+    [ -n "$f" ] && head -30 "$f" | tee -a "$OUT/summary.txt"
+    find "$OUT/prof_$dt" -name '*kernel_trace.csv' -size +20M -delete; find "$OUT/prof_$dt" -name '*.db' -size +20M -delete ;;
+  c5prof_*)
+    dt=${step#c5prof_}
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/c5prof_$dt" -o prof -- python "$OLDPWD/bench.py" --workload c5 --dtype $dt --steps 3 --warmup 1 --no-cpu-baseline ) > "$OUT/c5prof_$dt.log" 2>&1
+    echo "rocprof c5 $dt exit $?" | tee -a "$OUT/summary.txt"
+    f=$(find "$OUT/c5prof_$dt" -name '*kernel_stats.csv' | head -1)
+    [ -n "$f" ] && head -30 "$f" | tee -a "$OUT/summary.txt"
+    find "$OUT/c5prof_$dt" -name '*kernel_trace.csv' -size +20M -delete; find "$OUT/c5prof_$dt" -name '*.db' -size +20M -delete ;;
+esac
+done
