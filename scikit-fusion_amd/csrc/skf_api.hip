@@ -298,6 +298,7 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
     if (splits < 1) splits = 1;
     if (splits > ktiles) splits = ktiles > 0 ? ktiles : 1;
     Bf16GemmArgs g;
+    memset(&g, 0, sizeof g);
     g.A = A; g.Bt = Bt; g.C = C; g.part = (float*)part;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.M = M; g.N = N; g.Kp = Kp;
@@ -396,6 +397,9 @@ struct RelState {
     Slot Mb;                       // DFMC: the mask as packed bits, [nr][ldmb bytes], bit (n & 7) of byte n >> 3
     int64_t ldmb = 0;
     bool mask_is_bits = false;     // the caller's mask is already packed (SKF_REL_MASK_BITS)
+    Slot Kcnt, Koff, Klist;        // SKF_BF16 masked relation: known entries per 256 x 256 tile (counts, offsets, entries)
+    size_t kcap = 0;               // capacity of Klist in entries
+    bool use_klist = false;        // the lists fit: the completion writes whole tiles and never reads R back
     bool s_set = false;
     // row-block sharding: this plan holds rows [r0, r0 + nr) of the relation (nr == n_i: all of it)
     int64_t r0 = 0, nr = 0;
@@ -897,21 +901,37 @@ static void stage_contract(skf_plan* p, hipStream_t st) {
 
 // SKF_BF16: one elementwise pass over the stored relation against its reconstruction H G_j^T (r.H = G_i S must
 // be current): DFMC completion of the unknown entries, or the squared residual into p->sqpart (one f64 per tile)
+enum { MODE_COMPLETE = 0, MODE_SQERR = 1 };
 static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t st) {
     TypeState& tj = p->types[r.col];
     const int nr = (int)r.nr, nj = (int)tj.n, cj = tj.c;
     launch_to_bf16<float>((uint16_t*)r.Hb.ptr, r.ldhb, (const float*)r.H.ptr, (int64_t)cj, nr, cj, false, st);
     launch_to_bf16<float>((uint16_t*)r.Gb.ptr, r.ldhb, (const float*)tj.G.ptr, (int64_t)cj, nj, cj, false, st);
-    TileEpiArgs ta;
-    ta.A = (const uint16_t*)r.Hb.ptr; ta.Bt = (const uint16_t*)r.Gb.ptr; ta.R = (uint16_t*)r.Rb.ptr;
-    ta.mbits = (const uint8_t*)r.Mb.ptr; ta.part = (double*)p->sqpart.ptr;
-    ta.lda = r.ldhb; ta.ldb = r.ldhb; ta.ldr = r.ldrb; ta.ldmb = r.ldmb;
-    ta.M = nr; ta.N = nj; ta.Kp = (int)r.ldhb;
-    dim3 grid(cdiv(nj, 128), cdiv(nr, 128));
-    if (mode == MODE_COMPLETE)
-        hipLaunchKernelGGL((tile_epilogue_bf16_kernel<MODE_COMPLETE>), grid, dim3(256), 0, st, ta);
-    else
-        hipLaunchKernelGGL((tile_epilogue_bf16_kernel<MODE_SQERR>), grid, dim3(256), 0, st, ta);
+    Bf16GemmArgs g;
+    memset(&g, 0, sizeof g);
+    // transposed product: tile rows = relation columns (A = bf16 G_j), tile columns = relation rows (Bt = bf16 H)
+    g.A = (const uint16_t*)r.Gb.ptr; g.Bt = (const uint16_t*)r.Hb.ptr;
+    g.lda = r.ldhb; g.ldb = r.ldhb;
+    g.M = nj; g.N = nr; g.Kp = (int)r.ldhb; g.k_chunk = (int)r.ldhb;
+    g.a_kstep = 64; g.b_kstep = 64;
+    g.R = (uint16_t*)r.Rb.ptr; g.ldr = r.ldrb;
+    g.mbits = (const uint8_t*)r.Mb.ptr; g.ldmb = r.ldmb;
+    g.sq = (double*)p->sqpart.ptr;
+    if (mode == MODE_COMPLETE && r.use_klist) {
+        g.koff = (const uint32_t*)r.Koff.ptr;
+        g.klist = (const uint32_t*)r.Klist.ptr;
+    }
+    dim3 grid(cdiv(nr, 256), cdiv(nj, 256));
+    const int smem = (3 * 256 + 2 * 256) * 8 * 16;
+    if (mode == MODE_COMPLETE) {
+        static std::once_flag once;
+        allow_dynamic_lds(once, gemm_bf16_v2_kernel<256, 0, false, EPI_T_COMPLETE>, smem);
+        hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0, false, EPI_T_COMPLETE>), grid, dim3(512), smem, st, g);
+    } else {
+        static std::once_flag once;
+        allow_dynamic_lds(once, gemm_bf16_v2_kernel<256, 0, false, EPI_T_SQERR>, smem);
+        hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0, false, EPI_T_SQERR>), grid, dim3(512), smem, st, g);
+    }
     check_launch("tile_epilogue_bf16");
 }
 
@@ -973,7 +993,7 @@ static void stage_backbone(skf_plan* p, hipStream_t st) {
             if (r.mask) {
                 if (p->bf16) {
                     // completed entries go to the one stored copy as bf16: bf16 operands on the matrix cores,
-                    // the write-out is the bound (tile_epilogue_bf16_kernel<MODE_COMPLETE>)
+                    // the write-out is the bound (gemm_bf16_v2_kernel<.., EPI_T_COMPLETE>)
                     launch_tile_epilogue(p, r, MODE_COMPLETE, st);
                 } else {
                     g = gemm_args(r.H.ptr, cj, 1, tj.G.ptr, 1, cj, r.Rw.ptr, r.ldr, nr, nj, cj, EPI_MASKED_STORE, 0);
@@ -1453,6 +1473,15 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 r.ldmb = (tj.n + 127) / 128 * 16;               // bytes per packed mask row: whole 128-column tiles
                 add_slot(p, r.Mb, (size_t)nr * r.ldmb);
             }
+            if (p->bf16 && r.mask) {
+                // known entries as compact per-tile lists, up to 1/8 of the relation (beyond that the completion
+                // blends through the mask): 4 bytes per entry = at most a quarter of the bf16 relation's bytes
+                const size_t tiles = (size_t)cdiv(nr, 256) * cdiv(tj.n, 256);
+                r.kcap = (size_t)nr * tj.n / 8 + 4096;
+                add_slot(p, r.Kcnt, tiles * 4);
+                add_slot(p, r.Koff, (tiles + 1) * 4);
+                add_slot(p, r.Klist, r.kcap * 4);
+            }
             if (p->bf16 && p->variant != SKF_TRANSFORM) {       // completion / residual tiles
                 r.ldhb = pad64(tj.c);
                 add_slot(p, r.Hb, (size_t)nr * r.ldhb * 2);
@@ -1551,7 +1580,33 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
                                    r.ldmb, r.mask, r.ldmask, rows, cols);
             }
             check_launch("pack_mask");
-            if (p->bf16) continue;                 // bf16: the padded copy below is the working set
+            if (p->bf16) {
+                // known entries of every 256 x 256 tile as a compact list (count, prefix sum on the host, fill)
+                const int tx = cdiv(rows, 256), ty = cdiv(cols, 256);
+                const size_t tiles = (size_t)tx * ty;
+                KnownArgs ka;
+                ka.mbits = (const uint8_t*)r.Mb.ptr; ka.ldmb = r.ldmb;
+                ka.Rin = (const uint16_t*)r.R_in; ka.ldin = r.ld_in;
+                ka.rows = (int)rows; ka.cols = (int)cols;
+                ka.counts = (uint32_t*)r.Kcnt.ptr; ka.off = nullptr; ka.list = nullptr;
+                hipLaunchKernelGGL(known_entries_kernel, dim3(tx, ty), dim3(256), 0, st, ka);
+                check_launch("known_entries(count)");
+                std::vector<uint32_t> cnt(tiles), off(tiles + 1);
+                SKF_HIP(hipMemcpyAsync(cnt.data(), r.Kcnt.ptr, tiles * 4, hipMemcpyDeviceToHost, st));
+                SKF_HIP(hipStreamSynchronize(st));
+                uint64_t tot = 0;
+                for (size_t t = 0; t < tiles; ++t) { off[t] = (uint32_t)tot; tot += cnt[t]; }
+                off[tiles] = (uint32_t)tot;
+                r.use_klist = tot <= r.kcap && tot < 0xFFFFFFFFull;
+                if (r.use_klist) {
+                    SKF_HIP(hipMemcpyAsync(r.Koff.ptr, off.data(), (tiles + 1) * 4, hipMemcpyHostToDevice, st));
+                    ka.off = (const uint32_t*)r.Koff.ptr; ka.list = (uint32_t*)r.Klist.ptr;
+                    hipLaunchKernelGGL(known_entries_kernel, dim3(tx, ty), dim3(256), 0, st, ka);
+                    check_launch("known_entries(fill)");
+                    SKF_HIP(hipStreamSynchronize(st));          // `off` dies here; bind is not on the hot path
+                }
+                continue;                          // bf16: the padded copy below is the working set
+            }
             copy2d(r.Rw.ptr, cols, r.R_in, r.ld_in, rows, cols, p->esz, st);
             r.R = r.Rw.ptr;
             r.ldr = cols;
@@ -1820,7 +1875,7 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
             // one pass over the stored bf16 relation: bf16 H and G_j on the matrix cores, f32 residual
             launch_tile_epilogue(p, r, MODE_SQERR, st);
             hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(1), dim3(256), 0, st, (const double*)p->sqpart.ptr,
-                               cdiv(ni, 128) * cdiv(nj, 128), out);
+                               cdiv(ni, 256) * cdiv(nj, 256), out);
             check_launch("sum_partials");
             return;
         }

@@ -677,7 +677,21 @@ struct Bf16GemmArgs {
     int64_t a_kstep, b_kstep;   // elements between consecutive 64-wide K tiles of a row: 64 for the
                                 // row-major layout; rows*64 for the K-tile-major layout, in which the
                                 // [rows][64] slab of one K tile is contiguous (lda = ldb = 64)
+    // elementwise epilogues against a stored bf16 relation (gemm_bf16_v2_kernel<.., EPI_T_*>: the product is
+    // taken transposed there -- M = relation columns, N = relation rows)
+    uint16_t* R;                // [N][ldr] bf16, ldr % 8 == 0
+    int64_t ldr;
+    const uint8_t* mbits;       // EPI_T_COMPLETE: packed mask [N][ldmb bytes], ldmb % 16 == 0, bits >= M are zero
+    int64_t ldmb;
+    double* sq;                 // EPI_T_SQERR: one partial per workgroup (blockIdx.y * gridDim.x + blockIdx.x)
+    // EPI_T_COMPLETE with the known entries of every 256 x 256 tile as a compact list (known_fill_kernel):
+    // entries koff[t] .. koff[t+1]-1 of klist belong to tile t = blockIdx.y * gridDim.x + blockIdx.x, each
+    // (m_loc * 256 + n_loc) | bf16 value << 16.  klist == nullptr: blend through the mask instead.
+    const uint32_t* koff;
+    const uint32_t* klist;
 };
+// epilogue of gemm_bf16_v2_kernel: store the f32 tile | DFMC completion | squared residual
+enum { EPI_T_STORE = 0, EPI_T_COMPLETE = 1, EPI_T_SQERR = 2 };
 
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return row * 8 + (chunk ^ (row & 7)); }
 
@@ -775,165 +789,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 engine, the two passes that touch a relation ELEMENTWISE against its reconstruction
-// T = H G_j^T  (H = G_i S; A = bf16(H) [M][lda], Bt = bf16(G_j) [N][ldb], K = c_j zero padded to 64):
-//   MODE_COMPLETE  DFMC completion (_dfmc.py:319-325): R[m][n] = bf16(T[m][n]) where the mask bit is set --
-//                  the ONE stored copy of the relation, every unknown entry written once
-//   MODE_SQERR     per-workgroup partial of sum (R - T)^2 (f32 product against the stored bf16 entries;
-//                  the residual of _dfmf.py:306-316 / compute_err without materialising n_i x n_j)
-// 128 x 128 tile, 4 waves (64 x 64 each), main loop of gemm_bf16_kernel (at most 4 K tiles: the pass is
-// bound by the relation's bytes, not by the product).  COMPLETE stages the tile as bf16 in LDS and writes
-// whole 16-byte chunks along the rows of R, reading the old chunk only when it holds a known entry to keep
-// (the mask is one BIT per entry: 16 bytes per tile row).  SQERR stages the R tile in LDS (coalesced
-// 16-byte loads) and every lane compares its accumulator elements with it.
-// ------------------------------------------------------------------------------------------
-enum { MODE_COMPLETE = 0, MODE_SQERR = 1 };
-struct TileEpiArgs {
-    const uint16_t* A;
-    const uint16_t* Bt;
-    uint16_t* R;             // [M][ldr] bf16, ldr % 8 == 0
-    const uint8_t* mbits;    // COMPLETE: packed mask [M][ldmb bytes], ldmb % 16 == 0, bits >= N are zero
-    double* part;            // SQERR: one partial per workgroup (blockIdx.y * gridDim.x + blockIdx.x)
-    int64_t lda, ldb, ldr, ldmb;
-    int M, N, Kp;
-};
-
-template <int MODE>
-__global__ __launch_bounds__(256) void tile_epilogue_bf16_kernel(TileEpiArgs g) {
-    constexpr int BM = 128, BN = 128, BK = 64;
-    constexpr int TLD = 136;                 // halfwords per staged row (272 B: 16-byte aligned rows, odd multiple of 16 B)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[BM * TLD * 2];
-    u32x4* As = (u32x4*)smem;                // main loop: 2 x 16 KiB of operand tiles
-    u32x4* Bs = As + BM * 8;
-    uint16_t* T = (uint16_t*)smem;           // epilogue: the product tile (COMPLETE) / the R tile (SQERR) as bf16
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
-    const int nkt = g.Kp / BK;
-    const int srow = tid >> 3, schunk = tid & 7;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
-    u32x4 ra[4], rb[4];
-    const u32x4 zero = {0u, 0u, 0u, 0u};
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int m = bm0 + srow + 32 * p;
-            ra[p] = (m < g.M) ? *(const u32x4*)(g.A + (int64_t)m * g.lda + k0 + schunk * 8) : zero;
-            const int n = bn0 + srow + 32 * p;
-            rb[p] = (n < g.N) ? *(const u32x4*)(g.Bt + (int64_t)n * g.ldb + k0 + schunk * 8) : zero;
-        }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            As[swz_chunk(srow + 32 * p, schunk)] = ra[p];
-            Bs[swz_chunk(srow + 32 * p, schunk)] = rb[p];
-        }
-    };
-    if (nkt > 0) {
-        load_tiles(0);
-        store_tiles();
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = (kt + 1 < nkt);
-        if (more) load_tiles((kt + 1) * BK);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = 4 * ks + (lane >> 4);
-            bf16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-        if (more) store_tiles();
-        __syncthreads();
-    }
-    // (the last barrier of the loop already separates the operand tiles from T)
-
-    if constexpr (MODE == MODE_COMPLETE) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    T[(wm0 + i * 16 + 4 * (lane >> 4) + r) * TLD + wn0 + j * 16 + (lane & 15)] = f32_to_bf16_rne(acc[i][j][r]);
-        __syncthreads();
-        // 8 consecutive columns of one row per item: 16 lanes cover the 256 contiguous bytes of a tile row
-        for (int i = tid; i < BM * 16; i += 256) {
-            const int r = i >> 4, c = i & 15;
-            const int m = bm0 + r;
-            if (m >= g.M) continue;
-            const int64_t mb_off = (int64_t)m * g.ldmb + (bn0 >> 3) + c;
-            if ((int64_t)(bn0 >> 3) + c >= g.ldmb) continue;
-            const uint32_t mb = g.mbits[mb_off];          // bit q: column bn0 + 8c + q is unknown (completed)
-            if (mb == 0u) continue;
-            u32x4 v = *(const u32x4*)(T + r * TLD + c * 8);
-            u32x4* dst = (u32x4*)(g.R + (int64_t)m * g.ldr + bn0 + c * 8);
-            if (mb != 0xFFu) {
-                const u32x4 old = *dst;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (!(mb & (1u << q))) {
-                        const uint32_t sh = 16 * (q & 1), msk = 0xFFFFu << sh;
-                        v[q >> 1] = (v[q >> 1] & ~msk) | (old[q >> 1] & msk);
-                    }
-            }
-            *dst = v;
-        }
-    } else {
-        // R tile -> LDS (zero outside the stored matrix: the product is zero there as well)
-        for (int i = tid; i < BM * 16; i += 256) {
-            const int r = i >> 4, c = i & 15;
-            const int m = bm0 + r;
-            const int64_t col = (int64_t)bn0 + c * 8;
-            u32x4 v = zero;
-            if (m < g.M && col + 8 <= g.ldr) v = *(const u32x4*)(g.R + (int64_t)m * g.ldr + col);
-            *(u32x4*)(T + r * TLD + c * 8) = v;
-        }
-        __syncthreads();
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ml = wm0 + i * 16 + 4 * (lane >> 4) + r, nl = wn0 + j * 16 + (lane & 15);
-                    if (bm0 + ml < g.M && bn0 + nl < g.N) {
-                        const float d = bf16_to_f32(T[ml * TLD + nl]) - acc[i][j][r];
-                        s += d * d;
-                    }
-                }
-        double ws = wave_sum((double)s);
-        __shared__ double wsum[4];
-        if (lane == 0) wsum[wave] = ws;
-        __syncthreads();
-        if (tid == 0) g.part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // bf16 relation contraction, the kernel of the two products that stream a relation:
 //     AT = false:  C[M x N] (f32) = A[M x Kp] * Bt[N x Kp]^T      P = R G_j     (A = R,   K-contiguous rows)
 //     AT = true :  C[M x N] (f32) = A[Kp x M]^T * Bt[N x Kp]^T    Q = R^T G_i   (A = the SAME row-major R:
@@ -1014,8 +869,9 @@ __device__ __forceinline__ void lds_tr_wait(s16x4& a, s16x4& b, s16x4& c, s16x4&
 // swizzle key of a k row of the transposed A image (AT)
 __device__ __forceinline__ int at_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
-template <int BN, int TAG, bool AT>
+template <int BN, int TAG, bool AT, int EPI = EPI_T_STORE>
 __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
+    static_assert(EPI == EPI_T_STORE || (BN == 256 && !AT), "the elementwise epilogues use the 256 x 256 P-form tile");
     constexpr int BM = 256, BK = 64;
     constexpr int WN = BN / 2;
     constexpr int NJ = WN / 16;             // 16-wide column blocks per wave
@@ -1183,18 +1039,144 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     }
 
     // D reg r of a 16 x 16 tile -> row = 4*(lane>>4) + r, col = lane & 15
-    float* out = (gridDim.z > 1) ? g.part + (int64_t)blockIdx.z * g.M * g.N : g.C;
-    const int64_t ldo = (gridDim.z > 1) ? g.N : g.ldc;
+    if constexpr (EPI == EPI_T_STORE) {
+        float* out = (gridDim.z > 1) ? g.part + (int64_t)blockIdx.z * g.M * g.N : g.C;
+        const int64_t ldo = (gridDim.z > 1) ? g.N : g.ldc;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = bm0 + wm0 + i * 16 + 4 * (lane >> 4) + r;
-                const int n = bn0 + wn0 + j * 16 + (lane & 15);
-                if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int m = bm0 + wm0 + i * 16 + 4 * (lane >> 4) + r;
+                    const int n = bn0 + wn0 + j * 16 + (lane & 15);
+                    if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc[i][j][r];
+                }
+    } else {
+        // The passes that touch a relation ELEMENTWISE against its reconstruction T = H G_j^T (K = c_j: a handful
+        // of K tiles -- the pass is bound by the relation's bytes).  The product is taken TRANSPOSED: the kernel's
+        // A operand is bf16(G_j) (tile rows = relation COLUMNS n), its Bt operand bf16(H) (tile columns = relation
+        // ROWS m), so that the four accumulator elements of a lane are four CONSECUTIVE columns of one relation row:
+        //   EPI_T_COMPLETE  DFMC completion (_dfmc.py:319-325): R[m][n] = bf16(T[m][n]) where the mask bit is set;
+        //                   the tile is staged as bf16 in LDS (one 8-byte store per 16 x 16 block and lane) and written
+        //                   as whole 16-byte chunks along the rows of R, the old chunk being read only when it holds
+        //                   a known entry to keep
+        //   EPI_T_SQERR     partial of sum (R - T)^2: the R tile is staged in LDS with coalesced 16-byte loads and
+        //                   every lane compares its accumulator elements with it (f32 product, stored bf16 entries)
+        // (the last barrier of the K loop has released the operand rings: the whole LDS is free)
+        constexpr int TLD = BM + 8;              // halfwords per staged relation row: 528 B (16-byte aligned rows)
+        constexpr int CH = BM / 8;               // 16-byte chunks per staged row
+        uint16_t* T = (uint16_t*)smem;           // T[m_loc][n_loc], m_loc < BN (relation rows), n_loc < BM (relation columns)
+        const int rel_rows = g.N, rel_cols = g.M, row0 = bn0, col0 = bm0;
+        if constexpr (EPI == EPI_T_COMPLETE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int nl = wm0 + i * 16 + 4 * (lane >> 4), ml = wn0 + j * 16 + (lane & 15);
+                    const uint32_t lo = (uint32_t)f32_to_bf16_rne(acc[i][j][0]) | ((uint32_t)f32_to_bf16_rne(acc[i][j][1]) << 16);
+                    const uint32_t hi = (uint32_t)f32_to_bf16_rne(acc[i][j][2]) | ((uint32_t)f32_to_bf16_rne(acc[i][j][3]) << 16);
+                    uint32_t* dst = (uint32_t*)(T + ml * TLD + nl);
+                    dst[0] = lo; dst[1] = hi;
+                }
+            __syncthreads();
+            constexpr int NIT = BN * CH / 512;
+            if (g.klist != nullptr) {
+                // Known entries of this tile from their compact list straight into the staged tile, then EVERY chunk
+                // is written out: full-line streaming stores, no read of the old relation, no mask traffic
+                // (at 2 % known entries the blend below reads 3 of 4 lines of R back).
+                const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+                const uint32_t k0 = g.koff[tile], k1 = g.koff[tile + 1];
+                for (uint32_t k = k0 + tid; k < k1; k += 512) {
+                    const uint32_t e = g.klist[k];
+                    T[((e >> 8) & 0xFFu) * TLD + (e & 0xFFu)] = (uint16_t)(e >> 16);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < NIT; ++q) {
+                    const int it = tid + q * 512;
+                    const int r = it / CH, c = it % CH;
+                    const int left = rel_cols - (col0 + c * 8);           // columns of this chunk inside the relation
+                    if (row0 + r >= rel_rows || left <= 0) continue;
+                    u32x4 v = *(const u32x4*)(T + r * TLD + c * 8);
+                    if (left < 8) {                                       // padding columns of R stay zero
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (e >= left) v[e >> 1] &= ~(0xFFFFu << (16 * (e & 1)));
+                    }
+                    *(u32x4*)(g.R + (int64_t)(row0 + r) * g.ldr + col0 + c * 8) = v;
+                }
+            } else {
+            // item = 8 consecutive columns of one relation row; 32 lanes cover the 512 contiguous bytes of a tile row.
+            // All mask bytes of the thread first (independent loads, one wait), then the stores.
+            uint32_t mb[NIT];
+#pragma unroll
+            for (int q = 0; q < NIT; ++q) {
+                const int it = tid + q * 512;
+                const int r = it / CH, c = it % CH;
+                const int m = row0 + r;
+                const bool in = m < rel_rows && (int64_t)(col0 >> 3) + c < g.ldmb;
+                mb[q] = in ? g.mbits[(int64_t)m * g.ldmb + (col0 >> 3) + c] : 0u;   // bit b: column col0 + 8c + b is unknown
             }
+#pragma unroll
+            for (int q = 0; q < NIT; ++q) {
+                if (mb[q] == 0u) continue;
+                const int it = tid + q * 512;
+                const int r = it / CH, c = it % CH;
+                u32x4 v = *(const u32x4*)(T + r * TLD + c * 8);
+                u32x4* dst = (u32x4*)(g.R + (int64_t)(row0 + r) * g.ldr + col0 + c * 8);
+                if (mb[q] != 0xFFu) {
+                    const u32x4 old = *dst;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (!(mb[q] & (1u << e))) {
+                            const uint32_t sh = 16 * (e & 1), msk = 0xFFFFu << sh;
+                            v[e >> 1] = (v[e >> 1] & ~msk) | (old[e >> 1] & msk);
+                        }
+                }
+                *dst = v;
+            }
+            }
+        } else {
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            for (int it = tid; it < BN * CH; it += 512) {       // zero outside the stored matrix: never compared
+                const int r = it / CH, c = it % CH;
+                const int m = row0 + r;
+                const int64_t col = (int64_t)col0 + c * 8;
+                u32x4 v = zero;
+                if (m < rel_rows && col + 8 <= g.ldr) v = *(const u32x4*)(g.R + (int64_t)m * g.ldr + col);
+                *(u32x4*)(T + r * TLD + c * 8) = v;
+            }
+            __syncthreads();
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int nl = wm0 + i * 16 + 4 * (lane >> 4), ml = wn0 + j * 16 + (lane & 15);
+                    const uint32_t* src = (const uint32_t*)(T + ml * TLD + nl);
+                    const uint32_t lo = src[0], hi = src[1];
+                    const float rv[4] = {bf16_to_f32((uint16_t)(lo & 0xFFFFu)), bf16_to_f32((uint16_t)(lo >> 16)),
+                                         bf16_to_f32((uint16_t)(hi & 0xFFFFu)), bf16_to_f32((uint16_t)(hi >> 16))};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (row0 + ml < rel_rows && col0 + nl + r < rel_cols) {
+                            const float d = rv[r] - acc[i][j][r];
+                            sacc += d * d;
+                        }
+                }
+            const double ws = wave_sum((double)sacc);
+            __syncthreads();                     // every wave is done with T: its first bytes carry the wave sums now
+            double* wsum = (double*)smem;
+            if (lane == 0) wsum[wave] = ws;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = 0.0;
+                for (int w = 0; w < 8; ++w) tot += wsum[w];
+                g.sq[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+            }
+        }
+    }
 }
 
 // split-K second stage of the bf16 contraction: C = sum_z part[z]  (fixed order)
@@ -1376,6 +1358,55 @@ __global__ __launch_bounds__(256) void copy_mask_bits_kernel(uint8_t* __restrict
         const int64_t left = cols - b * 8;
         if (left < 8) v &= (1u << left) - 1u;
         dst[r * ldmb + b] = (uint8_t)v;
+    }
+}
+
+// Known entries of a masked bf16 relation per 256 x 256 tile (the tile grid of gemm_bf16_v2_kernel<.., EPI_T_COMPLETE>:
+// blockIdx.x = tile of relation ROWS, blockIdx.y = tile of relation COLUMNS, t = blockIdx.y * gridDim.x + blockIdx.x).
+// Pass 0 (list == nullptr) counts them into counts[t]; after the host's prefix sum pass 1 writes the entries
+// (m_loc * 256 + n_loc) | bf16 value << 16 of tile t to list[off[t] ...] (order inside a tile is irrelevant).
+struct KnownArgs {
+    const uint8_t* mbits;    // packed mask [rows][ldmb], 1 = unknown; bits past `cols` are zero
+    int64_t ldmb;
+    const uint16_t* Rin;     // the caller's bf16 relation [rows][ldin]
+    int64_t ldin;
+    int rows, cols;
+    uint32_t* counts;
+    const uint32_t* off;
+    uint32_t* list;
+};
+__global__ __launch_bounds__(256) void known_entries_kernel(KnownArgs a) {
+    __shared__ uint32_t cnt;
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * 256, col0 = blockIdx.y * 256;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tid == 0) cnt = 0u;
+    __syncthreads();
+    const uint32_t base = a.list ? a.off[tile] : 0u;
+    uint32_t mine = 0u;
+    for (int it = tid; it < 256 * 8; it += 256) {          // (row, 32-column word) items
+        const int r = it >> 3, w = it & 7;
+        const int m = row0 + r, c0 = col0 + 32 * w;
+        if (m >= a.rows || c0 >= a.cols || (int64_t)(c0 >> 3) + 4 > a.ldmb) continue;
+        const uint32_t word = *(const uint32_t*)(a.mbits + (int64_t)m * a.ldmb + (c0 >> 3));
+        const int nvalid = a.cols - c0 < 32 ? a.cols - c0 : 32;
+        uint32_t known = ~word & (nvalid == 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u));
+        if (!a.list) {
+            mine += (uint32_t)__popc(known);
+            continue;
+        }
+        while (known) {
+            const int b = __ffs(known) - 1;
+            known &= known - 1u;
+            const uint32_t pos = atomicAdd(&cnt, 1u);
+            const uint32_t val = a.Rin[(int64_t)m * a.ldin + c0 + b];
+            a.list[base + pos] = (uint32_t)(r * 256 + 32 * w + b) | (val << 16);
+        }
+    }
+    if (!a.list) {
+        atomicAdd(&cnt, mine);
+        __syncthreads();
+        if (tid == 0) a.counts[tile] = cnt;
     }
 }
 

@@ -304,6 +304,8 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}

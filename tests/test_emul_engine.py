@@ -302,8 +302,11 @@ def test_row_block_sharding_bf16_and_abi_errors():
                    nat.SKF_DFMF, dtype='bf16')
 
 
-def test_bf16_completion_kernel_against_f32_engine():
-    """tile_epilogue_bf16_kernel<MODE_COMPLETE> (bf16 H, G_j on the matrix cores; the one stored copy of
+@pytest.mark.parametrize('known', [0.6, 0.04])
+def test_bf16_completion_kernel_against_f32_engine(known):
+    """(known = 0.04: the known entries travel as compact per-tile lists and the completion writes whole tiles;
+    0.6: more than 1/8 known, the completion blends through the mask.)
+    gemm_bf16_v2_kernel<.., EPI_T_COMPLETE> (bf16 H, G_j on the matrix cores; the one stored copy of
     R written in 16-byte chunks with the known entries blended back; the mask as packed bits) against the
     f32 engine's per-element masked store on the bf16-rounded relation, on shapes that are not multiples of
     the 128 x 128 tile / of 8.  The mask arrives once as host booleans (packed on the host,
@@ -312,7 +315,7 @@ def test_bf16_completion_kernel_against_f32_engine():
     rs = np.random.RandomState(9)
     types, n, rank = ['a', 'b'], {'a': 203, 'b': 157}, {'a': 7, 'b': 5}
     R = {('a', 'b'): [rs.rand(203, 157)]}
-    mask = rs.rand(203, 157) > 0.4
+    mask = rs.rand(203, 157) > known
     mask[5, :] = True            # a fully unknown row, a fully known row, a fully unknown column
     mask[6, :] = False
     mask[:, 11] = True

@@ -389,7 +389,8 @@ def test_graph_replay_matches_golden(monkeypatch):
 
 def test_bf16_completion_kernel_and_residual_pass():
     import test_emul_engine as E
-    E.test_bf16_completion_kernel_against_f32_engine()
+    for known in (0.6, 0.04):
+        E.test_bf16_completion_kernel_against_f32_engine(known)
     E.test_relation_sqerr_counts_the_partials_of_the_tile_it_launches()
 
 
