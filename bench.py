@@ -13,10 +13,23 @@ every rank runs an independent random restart of the same graph (BASELINE config
 joblib n_run loop of reference dfmf.py:87-95): no data-path collective, weak scaling,
 value = N * K / max-over-ranks time.
 
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches itself under
+torch.distributed.run (one rank per GPU); under a launcher it checks WORLD_SIZE == --gpus.
+
 The JSON line also carries
-  roofline     : the dominant kernel = the relation contractions P = R G_j, Q = R^T G_i;
-                 achieved = their algorithmic flops (2*n_i*n_j*c per launch) / their summed
-                 hipEvent duration inside the timed region; bound = matrix cores of the dtype.
+  roofline     : the dominant kernel = the relation contractions P = R G_j, Q = R^T G_i, timed with
+                 hipEvents on the launch stream inside the timed region.  SURVEY.md 8(d) defines the
+                 algorithmic work of an iteration as ONE read of every relation and
+                 sum 2 n_i n_j (c_i + c_j) flops: 430 flop/B in bf16, above the 312 flop/B ridge.  The
+                 engine reads every relation once per contraction, i.e. TWICE per iteration (a fused
+                 P+Q pass has to spill one of the two outputs as partial sums, which costs more than
+                 the second read): 215 flop/B as scheduled, below the ridge -> bound = "hbm".
+                 achieved = algorithmic bytes per launch / average launch time; `traffic` = the bytes
+                 one launch is SCHEDULED to move from HBM (relation once, G^T once per XCD, output),
+                 not a counter reading (PMC passes: profiles/); `mfma` and `hbm_scheduled` give the
+                 other two views of the same launches.
+  engines      : short runs (3 steps) of the f32 and f64 engines on the same graph (the reference's
+                 own arithmetic is f64), default single-GPU run only.
   cpu_baseline : the NumPy oracle (reference operation order, fp64, all host cores) timed on a
                  bounded 1/10-linear-scale sample of the same graph and scaled to full size.
 
@@ -101,6 +114,35 @@ def c5_graph(n, dtype, masked=0.98, lam=0.01):
     return rels, thetas
 
 
+def c3_relation(k, n, dtype, data='uniform', cache=None):
+    """Relation k of the config-3 graph in HBM.  uniform: iid U[0,1) from the counter-based generator shared with
+    the oracle (regenerable on the host, element by element).  planted: R_ij = G*_i S*_ij G*_j^T / mean + 0.01 U
+    (torch as the random source / data plumbing only) -- noise floor 0.01 / sqrt(12) = 0.0029."""
+    from skfusion_amd._engine import fill_uniform
+    i, j, seed = PAIRS[k]
+    if data == 'uniform':
+        return fill_uniform((n[i], n[j]), seed, dtype)
+    import torch
+    from skfusion_amd._engine import device_matrix_from_tensor as wrap
+    cache = cache if cache is not None else {}
+    gen = torch.Generator(device='cuda')
+    for q, t in enumerate(TYPES):
+        if t not in cache:
+            gen.manual_seed(200 + q)
+            cache[t] = torch.rand((n[t], RANKS[t]), generator=gen, device='cuda')
+    gen.manual_seed(300 + seed)
+    S = torch.rand((RANKS[i], RANKS[j]), generator=gen, device='cuda')
+    Rm = (cache[i] @ S) @ cache[j].t()
+    Rm.div_(Rm.mean())
+    for r0 in range(0, n[i], 8192):          # noise in row chunks (no second full-size temporary)
+        blk = Rm[r0:r0 + 8192]
+        blk.add_(torch.rand(blk.shape, generator=gen, device='cuda'), alpha=0.01)
+    tdt = {'bf16': torch.bfloat16, 'f32': torch.float32, 'f64': torch.float64}[dtype]
+    out = wrap(Rm.to(tdt).contiguous())
+    torch.cuda.synchronize()
+    return out
+
+
 def alg_flops(n, spec=None, ranks=None):
     """sum over relations of 2 * n_i * n_j * (c_i + c_j); a masked relation (DFMC) adds
     its completion 2 * n_i * n_j * min(c_i, c_j)."""
@@ -110,19 +152,63 @@ def alg_flops(n, spec=None, ranks=None):
                for i, j, m in spec)
 
 
-def hbm_view(dtype, n, k_ms, k_launches, spec=None):
-    """The same launches against the HBM roofline: algorithmic bytes = every relation read once per
-    contraction (2 contractions per relation); peak 8 TB/s (MI355X_MICROARCH.md)."""
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable with a float4 copy)
+RIDGE = {'bf16': 2500e12 / 8e12, 'f32': 157.3e12 / 8e12, 'f64': 78.6e12 / 8e12}     # flop per HBM byte
+
+
+def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, elapsed):
+    """SURVEY.md 8(d) accounting of the relation-contraction launches (see the module docstring)."""
     esz = {'bf16': 2, 'f32': 4, 'f64': 8}[dtype]
-    spec = spec or [(i, j, False) for i, j, _ in PAIRS]
-    per_iter = sum(3 if m else 2 for _, _, m in spec)       # a masked relation recomputes P after completion
-    total = sum((3.0 if m else 2.0) * float(n[i]) * n[j] for i, j, m in spec) * esz     # per iteration
+    msz = 4 if dtype != 'f64' else 8                       # master type of P / Q
+    gsz = 2 if dtype == 'bf16' else msz                    # factor operand of the contraction
+    per_iter = sum(3 if m else 2 for _, _, m in spec)      # a masked relation recomputes P after completion
+    alg_bytes_iter = sum(float(n[i]) * n[j] for i, j, _ in spec) * esz            # ONE read of every relation
+    sched_iter = 0.0                                                               # what the launches move from HBM
+    for i, j, m in spec:
+        rel = float(n[i]) * n[j] * esz
+        p_launch = rel + 8.0 * n[j] * ranks[j] * gsz + float(n[i]) * ranks[j] * msz   # P: R + G_j^T per XCD + P
+        q_launch = rel + 8.0 * n[i] * ranks[i] * gsz + float(n[j]) * ranks[i] * msz   # Q: R + G_i^T per XCD + Q
+        sched_iter += (2 if m else 1) * p_launch + q_launch
+    flops_iter = alg_flops(n, spec, ranks)
+    peak_tf = PEAK_TFLOPS[dtype]
+    rec = {'kernel': 'relation contractions P=R*G_j, Q=R^T*G_i (%s)'
+                     % ('gemm_bf16_v2_kernel<BN,TAG=1,AT>' if dtype == 'bf16' else 'gemm_mfma_kernel<..,TAG=1>'),
+           'launches': int(k_launches), 'launches_per_iter': per_iter,
+           'avg_launch_ms': k_ms / k_launches if k_launches else None,
+           'alg_bytes_per_iter': alg_bytes_iter, 'alg_flops_per_iter': flops_iter,
+           'intensity_algorithmic': flops_iter / alg_bytes_iter,
+           'intensity_scheduled': flops_iter / sched_iter, 'ridge': RIDGE[dtype]}
+    bound = 'hbm' if flops_iter / sched_iter < RIDGE[dtype] else 'mfma'
     if not k_ms or not k_launches:
-        return None
+        rec.update({'bound': bound, 'achieved': None, 'peak': None, 'unit': None, 'frac': None, 'traffic': None})
+        return rec
+    sec = k_ms * 1e-3
     iters = k_launches / float(per_iter)
-    tbs = total * iters / (k_ms * 1e-3) / 1e12
-    return {'achieved': tbs, 'peak': 8.0, 'unit': 'TB/s', 'frac': tbs / 8.0,
-            'algorithmic_bytes_per_launch': total / float(per_iter)}
+    mfma_tf = k_flops / sec / 1e12
+    alg_gbs = alg_bytes_iter * iters / sec / 1e9
+    sched_gbs = sched_iter * iters / sec / 1e9
+    rec['mfma'] = {'achieved': mfma_tf, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': mfma_tf / peak_tf}
+    rec['hbm_scheduled'] = {'achieved': sched_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': sched_gbs / HBM_PEAK_GBS}
+    rec['traffic'] = sched_iter / per_iter
+    rec['traffic_kind'] = 'scheduled bytes per launch (relation once per contraction + G^T once per XCD + output), not a counter; rocprofv3 --pmc passes: profiles/'
+    rec['traffic_ratio'] = sched_iter / alg_bytes_iter
+    rec['alg_bytes_per_launch'] = alg_bytes_iter / per_iter
+    if bound == 'hbm':
+        rec.update({'bound': 'hbm', 'achieved': alg_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_gbs / HBM_PEAK_GBS})
+    else:
+        rec.update({'bound': 'mfma', 'achieved': mfma_tf, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': mfma_tf / peak_tf})
+    rec['whole_iteration'] = {'mfma_frac': flops_iter * steps / elapsed / 1e12 / peak_tf,
+                              'hbm_algorithmic_frac': alg_bytes_iter * steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                              'hbm_scheduled_frac': sched_iter * steps / elapsed / 1e9 / HBM_PEAK_GBS}
+    return rec
+
+
+def host_info():
+    try:
+        ram = os.sysconf('SC_PHYS_PAGES') * os.sysconf('SC_PAGE_SIZE') / 2.0 ** 30
+    except (ValueError, OSError, AttributeError):
+        ram = None
+    return {'cpu_count': os.cpu_count(), 'ram_gib': ram}
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -149,7 +235,12 @@ def cpu_baseline(seconds_budget=25.0):
         threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count()
+    host = host_info()
     return {'value': sample_ips * ratio, 'unit': 'iters/s', 'cores': int(threads), 'kind': 'port',
+            'host_cpu_count': host['cpu_count'], 'host_ram_gib': host['ram_gib'], 'projection': True,
+            'why_a_projection': 'the bench contract bounds the CPU leg to ~10-30 s: at full size the fp64 relations '
+                                'are 88 GB and one reference-order iteration is 1.5e13 flop (tens of seconds on this '
+                                'host) before the host-side data generation',
             'sample': '%d oracle iterations (NumPy fp64, reference op order) at 1/10 linear scale '
                       '(%dx%d / %dx%d / %dx%d, ranks 128/256/256) = %.3f it/s measured, scaled by the '
                       'n_i*n_j work ratio %.4f to the full graph; os.cpu_count()=%d'
@@ -177,11 +268,23 @@ def main():
                          '(strong scaling) with whole relations partitioned over the GPUs and an RCCL all-reduce of '
                          'the E/D accumulators per iteration (relations), or with balanced row blocks of the '
                          'relations and all-reduces of W, Q and E/D (rows)')
+    ap.add_argument('--no-engines', action='store_true', help='skip the short f32 / f64 runs of the default record')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # self-launch: one rank per GPU under torch.distributed.run (RCCL over xGMI; 127.0.0.1 rendezvous)
+        import subprocess
+        port = os.environ.get('MASTER_PORT', str(29500 + os.getpid() % 2000))
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let --gpus N '
+                         'launch itself)' % (args.gpus, world))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     local = local % max(torch.cuda.device_count(), 1)     # (ranks may share a GPU in smoke runs)
     torch.cuda.set_device(local)
@@ -205,129 +308,112 @@ def main():
     c5 = (args.workload == 'c5')
     types, ranks_ = (C5_TYPES, C5_RANKS) if c5 else (TYPES, RANKS)
     n = sizes(args.scale, C5_FULL if c5 else FULL)
-    variant = nat.SKF_DFMC if c5 else nat.SKF_DFMF
     sharded = (args.mode in ('relations', 'rows') and world > 1)
-    esz = {'bf16': 2, 'f32': 4, 'f64': 8}[args.dtype]
-    # the whole graph as (row, col, masked) + a maker of relation k's device matrices
-    if c5:
-        full_rels, full_thetas = c5_graph(n, args.dtype)
-        spec = [(i, j, dens is None) for i, j, _, dens in C5_PAIRS]
+    spec = ([(i, j, dens is None) for i, j, _, dens in C5_PAIRS] if c5 else [(i, j, False) for i, j, _ in PAIRS])
 
-        def make(k):
-            return full_rels[k][2], full_rels[k][3]
-    else:
-        full_thetas = []
-        spec = [(i, j, False) for i, j, _ in PAIRS]
+    def run_once(dtype, steps, warmup):
+        """One engine on the workload: returns (elapsed s, contraction ms, launches, flops, rmse dict)."""
+        variant = nat.SKF_DFMC if c5 else nat.SKF_DFMF
+        esz = {'bf16': 2, 'f32': 4, 'f64': 8}[dtype]
+        # the whole graph as (row, col, masked) + a maker of relation k's device matrices
+        if c5:
+            full_rels, full_thetas = c5_graph(n, dtype)
+            spec = [(i, j, dens is None) for i, j, _, dens in C5_PAIRS]
 
-        planted = {}
+            def make(k):
+                return full_rels[k][2], full_rels[k][3]
+        else:
+            full_thetas = []
+            spec = [(i, j, False) for i, j, _ in PAIRS]
 
-        def make(k):                   # same values whatever the sharding (counter-based generator)
-            i, j, seed = PAIRS[k]
-            if args.data == 'uniform':
-                return fill_uniform((n[i], n[j]), seed, args.dtype), None
-            # planted low-rank structure + 1 % noise (torch as the random source / data plumbing only)
-            from skfusion_amd._engine import device_matrix_from_tensor as wrap
-            gen = torch.Generator(device='cuda')
-            for q, t in enumerate(types):
-                if t not in planted:
-                    gen.manual_seed(200 + q)
-                    planted[t] = torch.rand((n[t], ranks_[t]), generator=gen, device='cuda')
-            gen.manual_seed(300 + seed)
-            S = torch.rand((ranks_[i], ranks_[j]), generator=gen, device='cuda')
-            Rm = (planted[i] @ S) @ planted[j].t()
-            Rm.div_(Rm.mean())
-            for r0 in range(0, n[i], 8192):          # noise in row chunks (no second full-size temporary)
-                blk = Rm[r0:r0 + 8192]
-                blk.add_(torch.rand(blk.shape, generator=gen, device='cuda'), alpha=0.01)
-            tdt = {'bf16': torch.bfloat16, 'f32': torch.float32, 'f64': torch.float64}[args.dtype]
-            out = wrap(Rm.to(tdt).contiguous())
+            planted = {}
+
+            def make(k):                   # same values whatever the sharding (counter-based generator)
+                return c3_relation(k, n, dtype, args.data, planted), None
+        part_rel = [(i, j, None, None) for i, j, _ in spec]
+        part_th = [(t, None) for t, _ in full_thetas]
+        local_index = list(range(len(spec)))            # global index of every relation of this plan
+        thetas = list(full_thetas)
+        if sharded and args.mode == 'relations':       # this rank keeps only its share of the relations
+            from skfusion_amd._distributed import partition_relations
+            owner, th_owner = partition_relations(part_rel, part_th, n, ranks_)
+            local_index = [k for k, o in enumerate(owner) if o == rank]
+            thetas = [t for t, o in zip(full_thetas, th_owner) if o == rank]
+        if sharded and args.mode == 'rows':            # every relation listed, with this rank's row block of it
+            from skfusion_amd._distributed import partition_rows
+            blocks, th_owner = partition_rows(part_rel, part_th, n, ranks_,
+                                              align=256 if min(n.values()) >= 4096 else 64)
+            thetas = [t for t, o in zip(full_thetas, th_owner) if o == rank]
+            rels = []
+            for k, ((i, j, masked), blk) in enumerate(zip(spec, blocks)):
+                mine = [b for b in blk if b[0] == rank]
+                if not mine:
+                    rels.append((i, j, None, None, dict(absent=True, row_begin=0, n_rows=0, col_side=False, masked=masked)))
+                    continue
+                _, a, cnt = mine[0]
+                data, mask = make(k)
+                rels.append((i, j, data.rows(a, cnt, esz), None if mask is None else mask.rows(a, cnt, 1),
+                             dict(absent=False, row_begin=a, n_rows=cnt, col_side=(a == 0), masked=masked)))
+                del data, mask
+        else:
+            rels = [(spec[k][0], spec[k][1]) + make(k) for k in local_index]
+        plan = DevicePlan(types, n, ranks_, rels, thetas, variant, dtype=dtype,
+                          part=(rank, world) if sharded and args.mode == 'rows' else None)
+        if dtype == 'bf16':          # the plan keeps its own padded bf16 copies of R and R^T
+            plan.release_relation_data()
+            rels = full_rels = None
+            torch.cuda.empty_cache()
+        for k, t in enumerate(types):      # one random restart per rank: G0 seed depends on the rank
+            seed = 100 + k + (0 if sharded else 10 * rank)       # sharded: replicated factors
+            plan.set_factor(t, fill_uniform((n[t], ranks_[t]), seed, MASTER[dtype]))
+        step = plan.iterate if not sharded else (plan.iterate_rows if args.mode == 'rows' else plan.iterate_sharded)
+
+        def sync():
             torch.cuda.synchronize()
-            return out, None
-    part_rel = [(i, j, None, None) for i, j, _ in spec]
-    part_th = [(t, None) for t, _ in full_thetas]
-    local_index = list(range(len(spec)))            # global index of every relation of this plan
-    thetas = list(full_thetas)
-    if sharded and args.mode == 'relations':       # this rank keeps only its share of the relations
-        from skfusion_amd._distributed import partition_relations
-        owner, th_owner = partition_relations(part_rel, part_th, n, ranks_)
-        local_index = [k for k, o in enumerate(owner) if o == rank]
-        thetas = [t for t, o in zip(full_thetas, th_owner) if o == rank]
-    if sharded and args.mode == 'rows':            # every relation listed, with this rank's row block of it
-        from skfusion_amd._distributed import partition_rows
-        blocks, th_owner = partition_rows(part_rel, part_th, n, ranks_,
-                                          align=256 if min(n.values()) >= 4096 else 64)
-        thetas = [t for t, o in zip(full_thetas, th_owner) if o == rank]
-        rels = []
-        for k, ((i, j, masked), blk) in enumerate(zip(spec, blocks)):
-            mine = [b for b in blk if b[0] == rank]
-            if not mine:
-                rels.append((i, j, None, None, dict(absent=True, row_begin=0, n_rows=0, col_side=False, masked=masked)))
-                continue
-            _, a, cnt = mine[0]
-            data, mask = make(k)
-            rels.append((i, j, data.rows(a, cnt, esz), None if mask is None else mask.rows(a, cnt, 1),
-                         dict(absent=False, row_begin=a, n_rows=cnt, col_side=(a == 0), masked=masked)))
-            del data, mask
-    else:
-        rels = [(spec[k][0], spec[k][1]) + make(k) for k in local_index]
-    plan = DevicePlan(types, n, ranks_, rels, thetas, variant, dtype=args.dtype,
-                      part=(rank, world) if sharded and args.mode == 'rows' else None)
-    if args.dtype == 'bf16':          # the plan keeps its own padded bf16 copies of R and R^T
-        plan.release_relation_data()
-        rels = full_rels = None
-        torch.cuda.empty_cache()
-    for k, t in enumerate(types):      # one random restart per rank: G0 seed depends on the rank
-        seed = 100 + k + (0 if sharded else 10 * rank)       # sharded: replicated factors
-        plan.set_factor(t, fill_uniform((n[t], ranks_[t]), seed, MASTER[args.dtype]))
-    step = plan.iterate if not sharded else (plan.iterate_rows if args.mode == 'rows' else plan.iterate_sharded)
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
 
-    def sync():
-        torch.cuda.synchronize()
+        step(warmup)
+        sync()
+        plan.set_profiling(True)
+        t0 = time.perf_counter()
+        step(steps)
+        sync()
+        elapsed = time.perf_counter() - t0
+        k_ms, k_launches, k_flops = plan.get_profile()
+        plan.set_profiling(False)
         if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+            tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
 
-    step(args.warmup)
-    sync()
-    plan.set_profiling(True)
-    t0 = time.perf_counter()
-    step(args.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    k_ms, k_launches, k_flops = plan.get_profile()
-    plan.set_profiling(False)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        rmse = {}
+        if sharded and args.mode == 'rows':            # every rank holds the squared error of its row blocks
+            sq = torch.tensor([plan.relation_sqerr(k) for k in range(len(spec))], dtype=torch.float64,
+                              device='cuda' if backend == 'nccl' else 'cpu')
+            dist.all_reduce(sq)
+            for k, (i, j, _) in enumerate(spec):
+                rmse['%s-%s' % (i, j)] = float(np.sqrt(float(sq[k]) / (n[i] * n[j])))
+        else:
+            for q, k in enumerate(local_index):
+                i, j, _ = spec[k]
+                rmse['%s-%s' % (i, j)] = float(np.sqrt(plan.relation_sqerr(q) / (n[i] * n[j])))
+        units = 1 if sharded else world        # fits advanced per step by the whole job
 
-    rmse = {}
-    if sharded and args.mode == 'rows':            # every rank holds the squared error of its row blocks
-        sq = torch.tensor([plan.relation_sqerr(k) for k in range(len(spec))], dtype=torch.float64,
-                          device='cuda' if backend == 'nccl' else 'cpu')
-        dist.all_reduce(sq)
-        for k, (i, j, _) in enumerate(spec):
-            rmse['%s-%s' % (i, j)] = float(np.sqrt(float(sq[k]) / (n[i] * n[j])))
-    else:
-        for q, k in enumerate(local_index):
-            i, j, _ = spec[k]
-            rmse['%s-%s' % (i, j)] = float(np.sqrt(plan.relation_sqerr(q) / (n[i] * n[j])))
+        plan.close()
+        del plan
+        torch.cuda.empty_cache()
+        return elapsed, k_ms, k_launches, k_flops, rmse
+
+    elapsed, k_ms, k_launches, k_flops, rmse = run_once(args.dtype, args.steps, args.warmup)
     units = 1 if sharded else world        # fits advanced per step by the whole job
 
     if rank == 0:
-        traffic = None          # HBM bytes per launch from the separate PMC passes (profiles/)
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
-                t = json.load(fh).get(args.dtype)
-            if t and args.scale == 1.0 and not c5:
-                traffic = t['fetch_bytes_per_launch'] + t['write_bytes_per_launch']
-        except Exception:
-            traffic = None
         how = {'restarts': 'one random restart per GPU',
                'relations': 'one fit, whole relations partitioned over the GPUs',
                'rows': 'one fit, balanced row blocks of the relations over the GPUs'}[args.mode]
-        achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
-        peak = PEAK_TFLOPS[args.dtype]
+        roof = roofline_record(args.dtype, n, ranks_, spec, k_ms, k_launches, k_flops, args.steps, elapsed)
         out = {
             'metric': ('DFMC update iters/sec (+ RMSE), MovieLens-style 6-relation graph with masks and constraints'
                        if c5 else
@@ -353,20 +439,27 @@ def main():
                        'scale': args.scale, 'restarts': units, 'mode': args.mode,
                        'alg_flops_per_iter': alg_flops(n, spec, ranks_)},
             'rmse': rmse,
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic,
-                         'traffic_note': 'HBM bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) measured by rocprofv3 --pmc in a separate pass, profiles/pmc_traffic.json; algorithmic = one read of the bf16 relation',
-                         'kernel': 'relation contractions P=R*G_j, Q=R^T*G_i (%s)' % ('gemm_bf16_v2_kernel<BN,TAG=1,..>' if args.dtype == 'bf16' else 'gemm_mfma_kernel<..,TAG=1>'),
-                         'launches': int(k_launches),
-                         'avg_launch_ms': k_ms / k_launches if k_launches else None,
-                         'alg_flops_per_launch': k_flops / k_launches if k_launches else None,
-                         'whole_iteration_frac': alg_flops(n, spec, ranks_) * args.steps / elapsed / 1e12 / peak,
-                         'hbm_view': hbm_view(args.dtype, n, k_ms, k_launches, spec)},
+            'roofline': roof,
+            'mfma_frac': (roof.get('mfma') or {}).get('frac'),
+            'hbm_frac': roof.get('frac') if roof.get('bound') == 'hbm' else (roof.get('hbm_scheduled') or {}).get('frac'),
+            'host': host_info(),
         }
+    if world == 1 and not c5 and not args.no_engines and args.scale == 1.0 and args.data == 'uniform':
+        # the reference computes in f64: short runs of the f32 and f64 engines on the same graph
+        engines = {}
+        for dt in ('f32', 'f64'):
+            if dt == args.dtype:
+                continue
+            e_s, e_ms, e_l, e_fl, e_rmse = run_once(dt, 3, 1)
+            r = roofline_record(dt, n, ranks_, spec, e_ms, e_l, e_fl, 3, e_s)
+            engines[dt] = {'value': 3 / e_s, 'unit': 'iters/s', 'steps': 3, 'warmup': 1, 'ms_per_step': e_s / 3 * 1e3,
+                           'rmse': e_rmse, 'bound': r['bound'], 'achieved': r['achieved'], 'peak': r['peak'],
+                           'unit_roofline': r['unit'], 'frac': r['frac'], 'mfma_frac': (r.get('mfma') or {}).get('frac')}
+        out['engines'] = engines
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not c5:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    plan.close()
     if dist is not None:
         dist.destroy_process_group()
 

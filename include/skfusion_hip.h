@@ -189,6 +189,11 @@ int skf_exchange_range(const skf_plan* plan, int32_t which, size_t* offset, size
  * over the stored bf16 relation, bf16-rounded G_i S and G_j on the matrix cores, f32 residual. */
 int skf_relation_sqerr(skf_plan* plan, int32_t rel, double* out, void* stream);
 
+/* The two contraction results the LAST iteration left in the workspace, for verification at sizes where the
+ * host cannot recompute them: which = 0: P = R G_j (local rows x rank_col), 1: Q = R^T G_i (n_col x rank_row),
+ * both from the factors BEFORE that iteration's update (like the backbone), master dtype, copied to `dst`. */
+int skf_get_contraction(const skf_plan* plan, int32_t rel, int32_t which, void* dst, int64_t ld, void* stream);
+
 /* Optional hipEvent timing of the two contractions that stream a relation matrix
  * (P = R G_j, Q = R^T G_i -- the dominant kernel).  get_profile synchronises on the recorded
  * events, returns the summed duration [ms], the number of launches and their algorithmic flops

@@ -364,5 +364,16 @@ def hash_uniform(seed, start, count):
     return (z >> np.uint64(40)).astype(np.float64) * (1.0 / 16777216.0)
 
 
+def hash_uniform_at(seed, index):
+    """The same generator at arbitrary linear element indices (rows / columns of a matrix too large to build)."""
+    with np.errstate(over='ignore'):
+        z = np.uint64(seed) * _GOLDEN + np.asarray(index, dtype=np.uint64)
+        z = z + _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(40)).astype(np.float64) * (1.0 / 16777216.0)
+
+
 def hash_uniform_matrix(seed, n_rows, n_cols):
     return hash_uniform(seed, 0, n_rows * n_cols).reshape(n_rows, n_cols)

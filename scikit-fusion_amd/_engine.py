@@ -256,6 +256,18 @@ class DevicePlan(object):
         self.rt.mem.synchronize()
         return self.rt.mem.to_host(buf, shape, self.np_dtype).astype(np.float64)
 
+    def get_contraction(self, rel, which, rows=None):
+        """P = R G_j (which=0) or Q = R^T G_i (which=1) as the last iteration left it (verification accessor)."""
+        i, j = self.relations[rel][0], self.relations[rel][1]
+        if which == 0:
+            shape = (rows if rows is not None else self.n_obj[self.index[i]], self.rank[self.index[j]])
+        else:
+            shape = (self.n_obj[self.index[j]], self.rank[self.index[i]])
+        buf = self.rt.mem.empty(shape[0] * shape[1] * np.dtype(self.np_dtype).itemsize)
+        self.rt.call('skf_get_contraction', self.handle, rel, which, buf.ptr, shape[1], self.stream)
+        self.rt.mem.synchronize()
+        return self.rt.mem.to_host(buf, shape, self.np_dtype)
+
     def set_graph(self, enable=True):
         """Replay one captured hipGraph per iteration (concurrent restarts: include/skfusion_hip.h)."""
         self.rt.call('skf_plan_set_graph', self.handle, 1 if enable else 0)

@@ -95,6 +95,7 @@ SIGNATURES = {
     'skf_exchange_range': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                      C.POINTER(C.c_int32)]),
     'skf_relation_sqerr': (C.c_int, [_P, C.c_int32, _P, _P]),
+    'skf_get_contraction': (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     'skf_plan_set_profiling': (C.c_int, [_P, C.c_int32]),
     'skf_plan_get_profile': (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'skf_gemm': (C.c_int, [C.c_int32, C.c_int32, C.POINTER(GemmDesc), _P, C.c_size_t, _P]),

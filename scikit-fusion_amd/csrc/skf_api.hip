@@ -1897,6 +1897,22 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
     });
 }
 
+int skf_get_contraction(const skf_plan* p, int32_t rel, int32_t which, void* dst, int64_t ld, void* stream) {
+    return guarded([&] {
+        check_bound(p);
+        if (rel < 0 || rel >= (int)p->rels.size() || !dst || (which != 0 && which != 1))
+            SKF_FAIL(SKF_E_INVALID, "bad relation index / selector / pointer");
+        const RelState& r = p->rels[rel];
+        const TypeState& ti = p->types[r.row];
+        const TypeState& tj = p->types[r.col];
+        const Slot& src = which == 0 ? r.P : r.Q;
+        const int64_t rows = which == 0 ? r.nr : tj.n, cols = which == 0 ? tj.c : ti.c;
+        if (!src.ptr || rows <= 0) SKF_FAIL(SKF_E_STATE, "relation %d keeps no %s here", rel, which == 0 ? "P" : "Q");
+        if (ld < cols) SKF_FAIL(SKF_E_INVALID, "ld too small");
+        copy2d(dst, ld, src.ptr, cols, rows, cols, p->esz, as_stream(stream));
+    });
+}
+
 int skf_plan_set_profiling(skf_plan* p, int32_t enable) {
     return guarded([&] {
         if (!p) SKF_FAIL(SKF_E_INVALID, "null plan");

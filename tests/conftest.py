@@ -8,3 +8,22 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Measured deviations of the parity tests next to their bounds (tests/helpers.py `within`)."""
+    try:
+        import helpers
+    except Exception:
+        return
+    if not helpers.DEVIATIONS:
+        return
+    out = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'test_deviations.txt'), 'w') as fh:
+            fh.write('%-90s %12s %12s %8s\n' % ('check', 'measured', 'bound', 'bound/m'))
+            for what, v, b in helpers.DEVIATIONS:
+                fh.write('%-90s %12.3e %12.3e %8.1f\n' % (what[:90], v, b, b / v if v > 0 else float('inf')))
+    except OSError:
+        pass

@@ -178,3 +178,17 @@ def fit_row_blocks(variant, R, M, Theta, types, rank, G0, max_iter, size, dtype=
     finally:
         for p in plans:
             p.close()
+
+
+# ---- measured deviations -------------------------------------------------------------------------------
+# `within(value, bound, what)` asserts value < bound and records (what, value, bound); conftest writes the
+# records of a session to gpurun_out/test_deviations.txt, so the bounds in the GPU tests can be kept at a
+# small multiple of what the hardware actually measures (and the measured figure quoted next to them).
+DEVIATIONS = []
+
+
+def within(value, bound, what):
+    value = float(value)
+    DEVIATIONS.append((what, value, float(bound)))
+    assert value < bound, '%s: measured %.3e, bound %.3e' % (what, value, bound)
+    return value

@@ -1,5 +1,6 @@
 """Host-side pieces of bench.py and of the sharding tables (no GPU, no library): the algorithmic
-work of BASELINE config 3, the HBM view, and the partitioners' invariants."""
+work of BASELINE config 3, the roofline record, the self-launch of `--gpus N`, and the
+partitioners' invariants."""
 import os
 import sys
 
@@ -18,9 +19,20 @@ def test_algorithmic_work_of_config_3_and_5():
     n = bench.sizes(0.1)
     assert n == {'t1': 5000, 't2': 10000, 't3': 4000}
     assert bench.alg_flops(n) / bench.alg_flops(bench.FULL) == pytest.approx(0.01)
-    v = bench.hbm_view('bf16', bench.FULL, 12.0, 6)          # one iteration = 6 launches, 12 ms
-    assert v['algorithmic_bytes_per_launch'] * 6 == pytest.approx(2 * 1.1e10 * 2)  # every R twice, 2 B
-    assert v['achieved'] == pytest.approx(44e9 / 12e-3 / 1e12)
+    # algorithmic bytes = ONE read of every relation per iteration (22 GB in bf16); the engine
+    # schedules two (one per contraction) -> 215 flop/B, below the 312 flop/B ridge: the HBM roof binds
+    spec3 = [(i, j, False) for i, j, _ in bench.PAIRS]
+    r = bench.roofline_record('bf16', bench.FULL, bench.RANKS, spec3, 12.0, 6, 9.472e12, 1, 0.015)
+    assert r['alg_bytes_per_iter'] == pytest.approx(1.1e10 * 2)
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert r['achieved'] == pytest.approx(22e9 / 12e-3 / 1e9)                      # one iteration = 6 launches, 12 ms
+    assert r['frac'] == pytest.approx(r['achieved'] / 8000.0)
+    assert 2.0 < r['traffic_ratio'] < 2.2 and r['traffic'] * 6 == pytest.approx(r['traffic_ratio'] * 22e9)
+    assert r['intensity_algorithmic'] == pytest.approx(9.472e12 / 22e9) and r['intensity_scheduled'] < r['ridge']
+    assert r['mfma']['achieved'] == pytest.approx(9.472e12 / 12e-3 / 1e12) and r['mfma']['peak'] == 2500.0
+    assert r['whole_iteration']['mfma_frac'] == pytest.approx(9.472e12 / 0.015 / 1e12 / 2500.0)
+    r64 = bench.roofline_record('f64', bench.FULL, bench.RANKS, spec3, 180.0, 6, 9.472e12, 1, 0.19)
+    assert r64['bound'] == 'mfma' and r64['unit'] == 'TFLOP/s'                    # 54 flop/B scheduled > 9.8 flop/B ridge
     spec = [(i, j, d is None) for i, j, _, d in bench.C5_PAIRS]
     n5 = bench.sizes(1.0, bench.C5_FULL)
     base = sum(2.0 * n5[i] * n5[j] * (bench.C5_RANKS[i] + bench.C5_RANKS[j]) for i, j, _ in spec)
@@ -70,3 +82,25 @@ def test_relation_partition_is_deterministic_and_complete():
     finally:
         D.world = saved
     assert a == b and sorted(set(a[0])) == [0, 1] and len(a[0]) == 3
+
+
+def test_bench_gpus_n_launches_itself_and_checks_the_world_size(monkeypatch):
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run with one
+    rank per GPU; under a launcher WORLD_SIZE must equal --gpus (round-1 finding: --gpus was never read)."""
+    import subprocess
+    calls = []
+    monkeypatch.setattr(subprocess, 'call', lambda cmd: calls.append(cmd) or 0)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2', '--steps', '3', '--scale', '0.2'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(calls) == 1
+    cmd = calls[0]
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '2' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-6:] == ['--gpus', '2', '--steps', '3', '--scale', '0.2'] and cmd[-7].endswith('bench.py')
+    # under a launcher: a mismatch is refused before any GPU work
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert 'WORLD_SIZE=4' in str(e.value.code)
