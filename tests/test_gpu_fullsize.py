@@ -147,7 +147,10 @@ def test_full_size_planted_structure_is_recovered(dtype):
     G = {t: plan.get_factor(t) for t in TYPES}
     for k, (i, j, _) in enumerate(bench.PAIRS):
         rmse = np.sqrt(plan.relation_sqerr(k) / (float(N[i]) * N[j]))
-        within(rmse / floor, 1.5, 'full size %s planted: RMSE / noise floor of relation %d after %d iterations'
+        # measured f32 1.14 / 1.36 / 1.14, bf16 1.31 / 1.50 / 1.31 of the floor, unchanged between 60 and 100
+        # iterations (the bf16 rounding of R ~ 1 alone lifts the floor to 1.27; a fit that lost a K slice, a tile or a
+        # +- term stays above 10)
+        within(rmse / floor, 1.6, 'full size %s planted: RMSE / noise floor of relation %d after %d iterations'
                % (dtype, k, iters))
         rows, Rrows = sample[k]
         host = np.sqrt(np.mean((Rrows - G[i][rows] @ plan.get_backbone(k) @ G[j].T) ** 2))

@@ -1,8 +1,12 @@
 """Parity tests proper: the HIP engine on a real MI355X, called through the C ABI
 (libskfusion_hip.so), against the golden vectors of the reference and the CPU oracle.
-Run with `pytest -m gpu`.  Tolerances: f64 <= 1e-9 relative on (G, S) vs the
-goldens; f32 <= 1e-4 on G / 1e-3 on S after 30 iterations and <= 1e-5 relative on the
-per-relation reconstruction error."""
+Run with `pytest -m gpu`.  Tolerances: the bounds marked `within(...)` are at most ~5x the deviation
+measured on the hardware (quoted next to them; every session writes measured vs bound to
+gpurun_out/test_deviations.txt -> profiles/).  f64 vs the goldens of the reference: 1e-9 after 100
+iterations on the README graph (measured <= 2.2e-10; SURVEY.md 8d's 1e-10 holds for the `random`
+initialiser and at iterations 1-10, the ill-conditioned column-mean initialisers drift to 2e-10 by
+iteration 100), 5e-9 on dicty (cond 4e5), 2e-11 on the scaled config 5; f32 <= 1e-4 on G / 1e-3 on S
+after 30 iterations and <= 1e-5 relative on the per-relation reconstruction error."""
 import numpy as np
 import pytest
 
@@ -11,7 +15,7 @@ from skfusion_amd.fusion.decomposition import _dfmf, _dfmc
 from skfusion_amd._engine import DevicePlan, fill_uniform
 from oracle import dfmf_oracle as orc
 from helpers import (golden, readme_graph, probe_graph, rank_deficient_graph, dicty_graph,
-                     c3_scaled_graph, g0_from, Snapshots, compare_snapshots, relerr, TYPES)
+                     c3_scaled_graph, g0_from, Snapshots, compare_snapshots, relerr, within, TYPES)
 import test_emul_kernels as K
 
 pytestmark = pytest.mark.gpu
@@ -99,7 +103,7 @@ def test_c1_readme_100_iterations_f64(init):
     snaps = Snapshots((0, 1, 9, 99))
     G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=100, callback=snaps,
                       G0=g0_from(z, init + '/', types), dtype='f64')
-    compare_snapshots(z, init + '/', snaps.snap, 1e-9)
+    within(compare_snapshots(z, init + '/', snaps.snap, 1e-9), 1e-9, 'c1 f64 %s: (G, S) at iterations 1/2/10/100 vs golden' % init)   # measured 5.5e-13 / 2.2e-10 / 3.6e-11
     errs = orc.relation_errors(R, G, S)
     for (i, j), e in errs.items():
         assert relerr(e, z['%s/err_%s_%s' % (init, i, j)]) < 1e-9
@@ -168,14 +172,14 @@ def test_c5_movielens_style_dfmc_f64_f32_bf16():
     G0 = g0_from(z, 'dfmc/', types)
     snaps = Snapshots((0, 1, 9, 29))
     _dfmc.dfmc(R, M, Theta, types, rank, max_iter=30, callback=snaps, G0=G0)
-    compare_snapshots(z, 'dfmc/', snaps.snap, 1e-9)
+    within(compare_snapshots(z, 'dfmc/', snaps.snap, 2e-11), 2e-11, 'c5 scaled f64: (G, S) over 30 iterations vs golden')   # measured 3.6e-12
     known = ~M['user', 'movie'][0]
-    for dtype, tol in (('f32', 1e-5), ('bf16', 5e-3)):        # measured 5e-7 / 3.4e-4
+    for dtype, tol in (('f32', 4e-6), ('bf16', 5e-3)):        # measured 8.0e-7 / 9.8e-4 (round 2, MI355X)
         G, S = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=30, G0=G0, dtype=dtype)
         d = G['user', 'user'].dot(S['user', 'movie'][0]).dot(G['movie', 'movie'].T) - R['user', 'movie'][0]
         for sel, key in ((known, 'dfmc/rmse_known'), (~known, 'dfmc/rmse_unknown')):
             got = np.sqrt(np.mean(d[sel] ** 2))
-            assert abs(got - float(z[key])) / float(z[key]) < tol, (dtype, key, got, float(z[key]))
+            within(abs(got - float(z[key])) / float(z[key]), tol, 'c5 scaled %s: %s vs reference golden' % (dtype, key))
 
 
 @pytest.mark.parametrize('variant', ['dfmf', 'dfmc'])
@@ -189,7 +193,7 @@ def test_rank_deficient_100_iterations(variant):
     else:
         G, S = _dfmc.dfmc(R, {k: [None] for k in R}, {}, types, rank, max_iter=100,
                           callback=snaps, G0=G0)
-    compare_snapshots(z, variant + '/', snaps.snap, 1e-7)
+    within(compare_snapshots(z, variant + '/', snaps.snap, 1e-10), 1e-10, 'rank-deficient f64 %s: (G, S) vs golden' % variant)   # measured 9.1e-12
     assert all(np.isfinite(v).all() for v in G.values())
     errs = orc.relation_errors(R, G, S)
     for (i, j), e in errs.items():
@@ -212,10 +216,10 @@ def test_transform_fold_in(init):
         assert relerr(snaps[it], z['%s/G_it%d' % (init, it)]) < 1e-9
     Gi32 = _dfmf.transform(Rn, {('t1', 't1'): [z['theta_t1']]}, 't1', rank, G, S, max_iter=100,
                            G0=z[init + '/G0'], dtype='f32')
-    assert relerr(Gi32, z['%s/G_it99' % init]) < 1e-4
+    within(relerr(Gi32, z['%s/G_it99' % init]), 1e-5, 'fold-in f32 %s: G after 100 iterations vs golden' % init)
     Gib = _dfmf.transform(Rn, {('t1', 't1'): [z['theta_t1']]}, 't1', rank, G, S, max_iter=100,
                           G0=z[init + '/G0'], dtype='bf16')
-    assert relerr(Gib, z['%s/G_it99' % init]) < 1e-2          # measured 2e-3
+    within(relerr(Gib, z['%s/G_it99' % init]), 1e-2, 'fold-in bf16 %s: G after 100 iterations vs golden' % init)   # measured 2.1e-3 (f32: 2.0e-6)
 
 
 def test_c2_dicty_dfmf_100_iterations_f64_and_f32():
@@ -225,7 +229,7 @@ def test_c2_dicty_dfmf_100_iterations_f64_and_f32():
     G0 = g0_from(z, 'dfmf/', types)
     snaps = Snapshots((0, 9, 99))
     G, S = _dfmf.dfmf(R, Theta, types, rank, max_iter=100, callback=snaps, G0=G0, dtype='f64')
-    compare_snapshots(z, 'dfmf/', snaps.snap, 1e-8)
+    within(compare_snapshots(z, 'dfmf/', snaps.snap, 5e-9), 5e-9, 'dicty f64 dfmf: (G, S) at iterations 1/10/100 vs golden')   # measured 9.7e-10 (cond(G0^T G0) = 4e5)
     errs = orc.relation_errors(R, G, S)
     for (i, j), e in errs.items():
         assert relerr(e, z['dfmf/err_%s_%s' % (i, j)]) < 1e-9
@@ -247,7 +251,7 @@ def test_c2_dicty_dfmc_row_block_mask():
     snaps = Snapshots((0, 9, 29))
     G, S = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=30, callback=snaps,
                       G0=g0_from(z, 'dfmf/', types))
-    compare_snapshots(z, 'dfmc/', snaps.snap, 1e-8)
+    within(compare_snapshots(z, 'dfmc/', snaps.snap, 5e-9), 5e-9, 'dicty f64 dfmc: (G, S) vs golden')   # measured 6.1e-10
     assert relerr(G['gene', 'gene'][:256], z['dfmc/G_gene_final_rows']) < 1e-8
 
 
@@ -407,10 +411,10 @@ def test_bf16_engine_c1_and_c3_scaled():
     Rb = {k: [nat.from_bf16_bits(nat.to_bf16_bits(v[0])).astype(np.float64)] for k, v in R.items()}
     e = orc.relation_errors(Rb, G, S)
     got = np.array([e[k][0] for k in sorted(e)])
-    assert np.abs(got - z['errs'][4]).max() / z['errs'][4].min() < 1e-2
+    within(np.abs(got - z['errs'][4]).max() / z['errs'][4].min(), 7e-5, 'c3 scaled bf16: reconstruction error vs f64 golden')   # measured 1.4e-5
     Gf, Sf = _dfmf.dfmf(R, {}, types, rank, max_iter=5, G0=G0, dtype='f32')
     for t in types:
-        assert relerr(G[t, t], Gf[t, t]) < 2e-2
+        within(relerr(G[t, t], Gf[t, t]), 2e-2, 'c3 scaled bf16: G_%s vs the f32 engine after 5 iterations' % t)   # measured 1.7e-4 / 9.8e-4 / 4.6e-3
 
 
 def test_device_side_error_and_generated_data_match_oracle(rt):
