@@ -113,3 +113,17 @@ def partition_rows(rel_list, theta_list, n_obj, rank_of, align=256, size=None):
 def gather_backbones(local, n_rel):
     """{relation index: S} of this rank -> list of all backbones, identical on every rank."""
     return gather_runs(local, n_rel)
+
+
+def sum_over_ranks(values):
+    """Element-wise sum of a list of floats over the ranks (identical result on every rank): the per-relation
+    squared errors of a sharded fit, each rank contributing what it holds (reference _dfmf.py:301-319 needs the
+    error of every relation for `compute_err` / `stopping*`)."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return [float(v) for v in values]
+    import torch
+    on_gpu = d.get_backend() != 'gloo' and torch.cuda.is_available()
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device='cuda' if on_gpu else 'cpu')
+    d.all_reduce(t, op=d.ReduceOp.SUM)
+    return [float(v) for v in t.cpu().tolist()]

@@ -448,37 +448,59 @@ def count_objects(obj_types, R):
     return n
 
 
-def device_reconstruct(G_row_block, S, G_col, dtype='f64', runtime=None):
-    """R_hat block = G_row_block @ S @ G_col.T on the device (two strided MFMA GEMMs through
-    ``skf_gemm``) -- the building block of ``FusionFit.complete_blocks`` for relations whose dense
-    reconstruction does not fit on the host in one piece."""
-    rt = runtime or nat.get_runtime()
-    code = nat.DTYPES[dtype]
-    if code == nat.SKF_BF16:
-        code = nat.SKF_F32
-    npd = nat.NP_DTYPE[code]
-    es = np.dtype(npd).itemsize
-    A = np.ascontiguousarray(G_row_block, dtype=npd)
-    Sm = np.ascontiguousarray(S, dtype=npd)
-    B = np.ascontiguousarray(G_col, dtype=npd)
-    m, ci = A.shape
-    cj = Sm.shape[1]
-    nj = B.shape[0]
-    if Sm.shape[0] != ci or B.shape[1] != cj:
-        raise ValueError('shape mismatch in reconstruction')
-    mem = rt.mem
-    a, s_, b = mem.from_host(A), mem.from_host(Sm), mem.from_host(B)
-    h = mem.empty(m * cj * es)
-    out = mem.empty(m * nj * es)
+class DeviceReconstructor(object):
+    """R_hat blocks = G_row[block] @ S @ G_col.T on the device (two strided MFMA GEMMs through ``skf_gemm``) with
+    ``S`` and the column factor uploaded ONCE and kept resident across blocks -- the building block of
+    ``FusionFit.complete_blocks`` for relations whose dense reconstruction does not fit on the host in one
+    piece (reference base.py:119-146 materialises the whole product)."""
 
-    def gemm(Ap, sa_m, sa_k, Bp, sb_k, sb_n, Cp, ldc, M, N, K):
+    def __init__(self, S, G_col, dtype='f64', runtime=None):
+        self.rt = runtime or nat.get_runtime()
+        code = nat.DTYPES[dtype]
+        self.code = nat.SKF_F32 if code == nat.SKF_BF16 else code
+        self.npd = nat.NP_DTYPE[self.code]
+        self.es = np.dtype(self.npd).itemsize
+        Sm = np.ascontiguousarray(S, dtype=self.npd)
+        B = np.ascontiguousarray(G_col, dtype=self.npd)
+        if Sm.ndim != 2 or B.ndim != 2 or B.shape[1] != Sm.shape[1]:
+            raise ValueError('shape mismatch in reconstruction')
+        self.ci, self.cj = Sm.shape
+        self.nj = B.shape[0]
+        self.s = self.rt.mem.from_host(Sm)
+        self.b = self.rt.mem.from_host(B)
+        self.uploads = 2                       # H2D copies of S / G_col so far (stays 2 whatever the block count)
+        self._h = self._out = None
+        self._rows = 0
+
+    def _gemm(self, Ap, sa_m, sa_k, Bp, sb_k, sb_n, Cp, ldc, M, N, K):
         d = nat.GemmDesc()
         d.A, d.B, d.C = Ap, Bp, Cp
         d.sa_m, d.sa_k, d.sb_k, d.sb_n, d.ldc, d.ldc2 = sa_m, sa_k, sb_k, sb_n, ldc, ldc
         d.M, d.N, d.K = M, N, K
         d.splits, d.a_dtype, d.b_dtype = 1, -1, -1
-        rt.call('skf_gemm', code, nat.SKF_ENGINE_MFMA, C.byref(d), None, 0, mem.stream)
-    gemm(a.ptr, ci, 1, s_.ptr, cj, 1, h.ptr, cj, m, cj, ci)              # H = G_blk S
-    gemm(h.ptr, cj, 1, b.ptr, 1, cj, out.ptr, nj, m, nj, cj)             # R_hat = H G_col^T
-    mem.synchronize()
-    return mem.to_host(out, (m, nj), npd).astype(np.float64)
+        self.rt.call('skf_gemm', self.code, nat.SKF_ENGINE_MFMA, C.byref(d), None, 0, self.rt.mem.stream)
+
+    def block(self, G_row_block, device=False):
+        """Reconstruction of the rows of this block: a host ndarray (float64), or -- device=True -- a
+        DeviceMatrix of the engine dtype that is valid until the next call (no D2H copy at all)."""
+        A = np.ascontiguousarray(G_row_block, dtype=self.npd)
+        if A.ndim != 2 or A.shape[1] != self.ci:
+            raise ValueError('shape mismatch in reconstruction')
+        m = A.shape[0]
+        mem = self.rt.mem
+        if m > self._rows:                     # scratch grows to the largest block seen, then is reused
+            self._h = mem.empty(m * self.cj * self.es)
+            self._out = mem.empty(m * self.nj * self.es)
+            self._rows = m
+        a = mem.from_host(A)
+        self._gemm(a.ptr, self.ci, 1, self.s.ptr, self.cj, 1, self._h.ptr, self.cj, m, self.cj, self.ci)      # H = G_blk S
+        self._gemm(self._h.ptr, self.cj, 1, self.b.ptr, 1, self.cj, self._out.ptr, self.nj, m, self.nj, self.cj)   # H G_col^T
+        mem.synchronize()
+        if device:
+            return DeviceMatrix(self._out, (m, self.nj))
+        return mem.to_host(self._out, (m, self.nj), self.npd).astype(np.float64)
+
+
+def device_reconstruct(G_row_block, S, G_col, dtype='f64', runtime=None):
+    """One block (S and G_col uploaded for this call only; `DeviceReconstructor` keeps them resident)."""
+    return DeviceReconstructor(S, G_col, dtype, runtime).block(G_row_block)

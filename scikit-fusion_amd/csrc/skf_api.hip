@@ -1482,7 +1482,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 add_slot(p, r.Koff, (tiles + 1) * 4);
                 add_slot(p, r.Klist, r.kcap * 4);
             }
-            if (p->bf16 && p->variant != SKF_TRANSFORM) {       // completion / residual tiles
+            if (p->bf16) {                                       // completion / residual tiles
                 r.ldhb = pad64(tj.c);
                 add_slot(p, r.Hb, (size_t)nr * r.ldhb * 2);
                 add_slot(p, r.Gb, (size_t)tj.n * r.ldhb * 2);

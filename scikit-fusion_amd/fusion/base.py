@@ -9,7 +9,7 @@ from collections import defaultdict
 
 import numpy as np
 
-__all__ = ['FusionBase', 'FusionFit', 'FusionTransform', 'DataFusionError']
+__all__ = ['FusionBase', 'FusionFit', 'FusionTransform', 'DataFusionError', 'save_fit', 'load_fit']
 
 
 class DataFusionError(Exception):
@@ -107,23 +107,135 @@ class FusionFit(FusionBase):
         return self._reconstruct(relation, 0 if run is None else run)
 
 
-    def complete_blocks(self, relation, block_rows=4096, run=None, dtype='f64'):
+    def save(self, path):
+        """Write the fitted model to ``path`` (one ``.npz``; see ``save_fit``)."""
+        return save_fit(self, path)
+
+    @staticmethod
+    def load(path, fusion_graph=None):
+        """Read a model written by ``save`` (see ``load_fit``)."""
+        return load_fit(path, fusion_graph)
+
+    def complete_blocks(self, relation, block_rows=4096, run=None, dtype='f64', device=False):
         """Blockwise reconstruction on the device: yields ``(row_slice, R_hat[row_slice])`` with
         at most ``block_rows`` rows per block, so that a relation whose dense reconstruction is too
-        large for the host (BASELINE config 3: up to 40 GB) can be consumed piece by piece.
-        A postprocessor is applied per block (exact for element-wise postprocessors).
+        large for the host (BASELINE config 3: up to 40 GB) can be consumed piece by piece.  The backbone and the
+        column factor are uploaded once and stay resident in HBM across the blocks.  ``device=True`` yields the
+        block as a device-resident matrix (valid until the next block; no copy back) for consumers that stay on
+        the GPU; otherwise a float64 ndarray, post-processed per block (exact for element-wise postprocessors).
         Extension of the reference API (``complete`` itself is unchanged)."""
-        from .._engine import device_reconstruct
+        from .._engine import DeviceReconstructor
         run = 0 if run is None else run
         G1 = self.factor(relation.row_type, run)
-        S12 = self.backbone(relation, run)
-        G2 = self.factor(relation.col_type, run)
+        rec = DeviceReconstructor(self.backbone(relation, run), self.factor(relation.col_type, run), dtype=dtype)
         for r0 in range(0, G1.shape[0], int(block_rows)):
             sl = slice(r0, min(r0 + int(block_rows), G1.shape[0]))
-            block = device_reconstruct(G1[sl], S12, G2, dtype=dtype)
-            if relation.postprocessor:
+            block = rec.block(G1[sl], device=device)
+            if relation.postprocessor and not device:
                 block = relation.postprocessor(block)
             yield sl, block
+
+
+# ---- persistence of a fitted model (SURVEY.md 8 f4; the reference has none: its accessors base.py:35-56,
+# 169-189 are the only consumers of factors_ / backbones_) ----------------------------------------------
+_FORMAT = 'skfusion_amd.fit/1'
+
+
+def _plain(value):
+    """Constructor parameters that survive JSON; callables, RandomState objects ... are dropped (None)."""
+    if value is None or isinstance(value, (bool, int, float, str)):
+        return value
+    if isinstance(value, (np.integer, np.floating)):
+        return value.item()
+    if isinstance(value, (list, tuple)):
+        return [_plain(v) for v in value]
+    return None
+
+
+def save_fit(fuser, path):
+    """Fitted Dfmf / Dfmc -> ONE ``.npz`` file: every factor G (per object type and run) and backbone S (per
+    relation and run) as float64 arrays ``G/<type index>/<run>``, ``S/<relation index>/<run>``, plus a JSON
+    header (format tag, class, constructor parameters, object types with rank and size, relations by row / column
+    type and position among the relations of that pair)."""
+    import json
+    graph = fuser.fusion_graph
+    types = list(graph.object_types)
+    rels = list(graph.relations)
+    n_run = int(fuser.n_run)
+    arrays = {}
+    for a, ot in enumerate(types):
+        runs = fuser.factors_[ot]
+        if len(runs) != n_run:
+            raise DataFusionError("Object type %s has %d fitted factors, expected %d" % (ot.name, len(runs), n_run))
+        for k, G in enumerate(runs):
+            arrays['G/%d/%d' % (a, k)] = np.asarray(G, dtype=np.float64)
+    seen = {}
+    rel_meta = []
+    for b, rel in enumerate(rels):
+        pair = (rel.row_type.name, rel.col_type.name)
+        pos = seen.get(pair, 0)
+        seen[pair] = pos + 1
+        rel_meta.append({'row': pair[0], 'col': pair[1], 'name': str(getattr(rel, 'name', '') or ''), 'position': pos,
+                         'shape': [int(d) for d in np.shape(rel.data)]})
+        for k, S in enumerate(fuser.backbones_[rel]):
+            arrays['S/%d/%d' % (b, k)] = np.asarray(S, dtype=np.float64)
+    meta = {'format': _FORMAT, 'class': type(fuser).__name__, 'n_run': n_run,
+            'params': {k: _plain(v) for k, v in (fuser._params or {}).items()},
+            'object_types': [{'name': str(ot.name), 'rank': int(ot.rank),
+                              'n_objects': int(np.shape(fuser.factors_[ot][0])[0])} for ot in types],
+            'relations': rel_meta}
+    arrays['meta'] = np.frombuffer(json.dumps(meta).encode('utf-8'), dtype=np.uint8)
+    with open(path, 'wb') as fh:
+        np.savez_compressed(fh, **arrays)
+    return path
+
+
+def load_fit(path, fusion_graph=None):
+    """Inverse of ``save_fit``: a fuser of the saved class whose ``factor`` / ``backbone`` / ``complete`` /
+    ``chain`` accessors work (including the generator convention for ``n_run > 1``).  With ``fusion_graph`` the
+    factors are attached to ITS object types / relations (matched by name and by position among the relations of
+    a type pair; sizes are checked); without one a skeleton graph of the saved types and relation shapes is
+    built (relation data: read-only NaN views that take no memory)."""
+    import json
+    from .fusion_graph import FusionGraph, ObjectType, Relation
+    with np.load(path, allow_pickle=False) as z:
+        meta = json.loads(bytes(z['meta'].tobytes()).decode('utf-8'))
+        if meta.get('format') != _FORMAT:
+            raise DataFusionError("Not a saved fusion model: %r" % (meta.get('format'),))
+        arrays = {k: z[k] for k in z.files if k != 'meta'}
+    if fusion_graph is None:
+        by_name = {t['name']: ObjectType(t['name'], t['rank']) for t in meta['object_types']}
+        fusion_graph = FusionGraph([Relation(np.broadcast_to(np.nan, tuple(r['shape'])), by_name[r['row']],
+                                             by_name[r['col']], name=r['name']) for r in meta['relations']])
+    from . import decomposition
+    cls = getattr(decomposition, meta['class'], None)
+    if cls is None or not issubclass(cls, FusionFit):
+        raise DataFusionError("Unknown fuser class %r" % (meta['class'],))
+    params = {k: v for k, v in meta['params'].items() if v is not None}
+    fuser = cls(**params)
+    fuser.fusion_graph = fusion_graph
+    n_run = int(meta['n_run'])
+    names = {ot.name: ot for ot in fusion_graph.object_types}
+    for a, t in enumerate(meta['object_types']):
+        if t['name'] not in names:
+            raise DataFusionError("Object type %s is not included in the fusion scheme" % t['name'])
+        ot = names[t['name']]
+        for k in range(n_run):
+            G = arrays['G/%d/%d' % (a, k)]
+            if G.shape != (t['n_objects'], t['rank']):
+                raise DataFusionError("Factor of %s has shape %r" % (t['name'], G.shape))
+            fuser.factors_[ot].append(G)
+    for b, r in enumerate(meta['relations']):
+        cands = list(fusion_graph.get_relations(names[r['row']], names[r['col']]))
+        if r['position'] >= len(cands):
+            raise DataFusionError("Relation %s -> %s #%d is not in the fusion graph" % (r['row'], r['col'], r['position']))
+        rel = cands[r['position']]
+        if list(np.shape(rel.data)) != list(r['shape']):
+            raise DataFusionError("Relation %s -> %s: data shape %r, saved %r"
+                                  % (r['row'], r['col'], np.shape(rel.data), r['shape']))
+        for k in range(n_run):
+            fuser.backbones_[rel].append(arrays['S/%d/%d' % (b, k)])
+    return fuser
 
 
 class FusionTransform(FusionBase):

@@ -4,7 +4,7 @@
 iteration (_dfmc.py:287-292, :319-325).  The relation matrices passed in are never modified
 (the engine completes a device-side copy)."""
 from ... import _native as nat
-from ._dfmf import run_fit, run_fit_sharded, run_fit_rows, _sharded_ok
+from ._dfmf import run_fit, run_fit_sharded, run_fit_rows
 
 
 def dfmc(R, M, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol",
@@ -12,10 +12,9 @@ def dfmc(R, M, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_v
          random_state=None, n_jobs=1, dtype='f64', G0=None, engine=None, shard=None):
     """Data fusion by matrix completion -- drop-in for reference ``dfmc`` (_dfmc.py:181)."""
     if shard in ('relations', 'rows'):
-        _sharded_ok(stopping, stopping_system, compute_err, callback)
         fit = run_fit_sharded if shard == 'relations' else run_fit_rows
         return fit(nat.SKF_DFMC, R, M, Theta, obj_types, obj_type2rank, max_iter,
-                   init_type, random_state, dtype, G0, engine)
+                   init_type, random_state, dtype, G0, engine, stopping, stopping_system, compute_err, callback)
     return run_fit(nat.SKF_DFMC, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
                    stopping, stopping_system, verbose, compute_err, callback, random_state,
                    dtype, G0, engine)

@@ -42,6 +42,47 @@ def _rel_index(rel_list, target):
     return hits[l]
 
 
+def _host_loop(step, sqerrs, rel_list, max_iter, stopping, stopping_system, compute_err, on_iter):
+    """The body of the reference loops with their early-stopping / error logging (_dfmf.py:212-221, 301-322;
+    _dfmc.py:270-279, 370-392; fold-in _dfmf.py:367-376, 433-450), one device iteration per pass.
+    step(): one iteration; sqerrs(indices): squared reconstruction errors of those relations (summed over the
+    ranks of a sharded fit, so that every rank takes the same decision); on_iter(it): the callback hook."""
+    if stopping_system:
+        compute_err = True
+    err_t = (None, None)
+    err_s = (None, None)
+    objective = []
+    for it in range(max_iter):
+        if it > 1 and stopping and err_t[1] - err_t[0] < stopping[1]:
+            log.info("Early stopping: target matrix change < %5.4f", stopping[1])
+            break
+        if it > 1 and stopping_system and err_s[1] - err_s[0] < stopping_system:
+            log.info("Early stopping: matrix system change < %5.4f", stopping_system)
+            break
+        step()
+        if compute_err:
+            sq = sqerrs(list(range(len(rel_list))))
+            s = 0.
+            for (i, j, _, _), v in zip(rel_list, sq):
+                e = np.sqrt(v)
+                log.info("Relation R_%s,%s norm difference: %5.4f", i, j, e)
+                s += e
+            log.info("Error (objective function value): %5.4f", s)
+            objective.append(s)
+            err_s = (s, err_s[0])
+            if stopping:
+                err_t = (np.sqrt(sq[_rel_index(rel_list, stopping[0])]), err_t[0])
+        elif stopping:
+            k = _rel_index(rel_list, stopping[0])
+            err_t = (np.sqrt(sqerrs([k])[0]), err_t[0])
+        if on_iter:
+            on_iter(it)
+    if compute_err:
+        log.info("Violations of optimization objective: %d/%d",
+                 int(np.sum(np.diff(objective) > 0)), len(objective))
+    return objective
+
+
 def row_block_plan(variant, rel_list, theta_list, obj_types, n_obj, obj_type2rank, dtype, engine, rank, size):
     """The plan of rank `rank` of `size` in a row-block-sharded fit: all relations listed, each with
     this rank's row block of `_distributed.partition_rows` (or marked absent)."""
@@ -66,7 +107,8 @@ def row_block_plan(variant, rel_list, theta_list, obj_types, n_obj, obj_type2ran
 
 
 def run_fit_rows(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
-                 random_state, dtype, G0, engine):
+                 random_state, dtype, G0, engine, stopping=None, stopping_system=None, compute_err=False,
+                 callback=None):
     """One fit whose relations are cut into balanced ROW BLOCKS over the ranks of the process group
     (SURVEY.md 8e): every rank lists all relations with its own row block (or none), factors are
     replicated, and an iteration is four stages with all-reduces of W / Q, E / D in between
@@ -84,18 +126,25 @@ def run_fit_rows(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_
     try:
         for t in obj_types:
             plan.set_factor(t, G0[t, t])
-        plan.iterate_rows(max_iter)
-        G = {(t, t): plan.get_factor(t) for t in obj_types}
-        S = {}
-        for k, (i, j, _, _) in enumerate(rel_list):
-            S.setdefault((i, j), []).append(plan.get_backbone(k))
-        return G, S
+        if not (callback or stopping or stopping_system or compute_err):
+            plan.iterate_rows(max_iter)
+        else:
+            from ..._distributed import sum_over_ranks
+            # every rank holds the squared error of ITS row blocks; factors and backbones are replicated
+
+            def sqerrs(idx):
+                return sum_over_ranks([plan.relation_sqerr(k) for k in idx])
+            _host_loop(lambda: plan.iterate_rows(1), sqerrs, rel_list, max_iter, stopping, stopping_system,
+                       compute_err,
+                       (lambda it: callback(*(_collect(plan, obj_types, rel_list) + (it,)))) if callback else None)
+        return _collect(plan, obj_types, rel_list)
     finally:
         plan.close()
 
 
 def run_fit_sharded(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
-                    random_state, dtype, G0, engine):
+                    random_state, dtype, G0, engine, stopping=None, stopping_system=None, compute_err=False,
+                    callback=None):
     """One fit whose relations are partitioned over the ranks of the process group (one GPU
     each): replicated factors, local contractions, ONE all-reduce of the E / D accumulators per
     iteration (second row).  Every rank returns the full (G, S)."""
@@ -116,13 +165,25 @@ def run_fit_sharded(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, in
     try:
         for t in obj_types:
             plan.set_factor(t, G0[t, t])
-        plan.iterate_sharded(max_iter)
-        G = {(t, t): plan.get_factor(t) for t in obj_types}
-        backbones = gather_backbones({k: plan.get_backbone(q) for q, k in enumerate(mine)}, len(rel_list))
-        S = {}
-        for k, (i, j, _, _) in enumerate(rel_list):
-            S.setdefault((i, j), []).append(backbones[k])
-        return G, S
+
+        def collect():
+            G = {(t, t): plan.get_factor(t) for t in obj_types}
+            backbones = gather_backbones({k: plan.get_backbone(q) for q, k in enumerate(mine)}, len(rel_list))
+            S = {}
+            for k, (i, j, _, _) in enumerate(rel_list):
+                S.setdefault((i, j), []).append(backbones[k])
+            return G, S
+        if not (callback or stopping or stopping_system or compute_err):
+            plan.iterate_sharded(max_iter)
+        else:
+            from ..._distributed import sum_over_ranks
+            where = {k: q for q, k in enumerate(mine)}          # global relation index -> index in this rank's plan
+
+            def sqerrs(idx):                                     # the owner of a relation contributes its error
+                return sum_over_ranks([plan.relation_sqerr(where[k]) if k in where else 0.0 for k in idx])
+            _host_loop(lambda: plan.iterate_sharded(1), sqerrs, rel_list, max_iter, stopping, stopping_system,
+                       compute_err, (lambda it: callback(*(collect() + (it,)))) if callback else None)
+        return collect()
     finally:
         plan.close()
 
@@ -201,49 +262,15 @@ def run_fit(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
     try:
         for t in obj_types:
             plan.set_factor(t, G0[t, t])
-        if stopping_system:
-            compute_err = True
-        host_loop = bool(callback or stopping or compute_err)
-        if not host_loop:
+        if not (callback or stopping or stopping_system or compute_err):
             plan.iterate(max_iter)              # whole loop device-resident, no host sync
         else:
-            err_t = (None, None)
-            err_s = (None, None)
-            objective = []
-            for it in range(max_iter):
-                if it > 1 and stopping and err_t[1] - err_t[0] < stopping[1]:
-                    log.info("Early stopping: target matrix change < %5.4f", stopping[1])
-                    break
-                if it > 1 and stopping_system and err_s[1] - err_s[0] < stopping_system:
-                    log.info("Early stopping: matrix system change < %5.4f", stopping_system)
-                    break
-                plan.iterate(1)
-                if stopping:
-                    k = _rel_index(rel_list, stopping[0])
-                    err_t = (np.sqrt(plan.relation_sqerr(k)), err_t[0])
-                if compute_err:
-                    s = 0.
-                    for k, (i, j, _, _) in enumerate(rel_list):
-                        e = np.sqrt(plan.relation_sqerr(k))
-                        log.info("Relation R_%s,%s norm difference: %5.4f", i, j, e)
-                        s += e
-                    log.info("Error (objective function value): %5.4f", s)
-                    objective.append(s)
-                    err_s = (s, err_s[0])
-                if callback:
-                    G, S = _collect(plan, obj_types, rel_list)
-                    callback(G, S, it)
-            if compute_err:
-                log.info("Violations of optimization objective: %d/%d",
-                         int(np.sum(np.diff(objective) > 0)), len(objective))
+            _host_loop(lambda: plan.iterate(1), lambda idx: [plan.relation_sqerr(k) for k in idx], rel_list,
+                       max_iter, stopping, stopping_system, compute_err,
+                       (lambda it: callback(*(_collect(plan, obj_types, rel_list) + (it,)))) if callback else None)
         return _collect(plan, obj_types, rel_list)
     finally:
         plan.close()
-
-
-def _sharded_ok(stopping, stopping_system, compute_err, callback):
-    if stopping or stopping_system or compute_err or callback:
-        raise ValueError("shard='relations' / 'rows' do not support callback / stopping / compute_err")
 
 
 def dfmf(R, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol",
@@ -253,10 +280,10 @@ def dfmf(R, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol
     ``shard='relations'`` (with an initialised torch.distributed group) partitions the relations
     of this ONE fit over the ranks."""
     if shard in ('relations', 'rows'):
-        _sharded_ok(stopping, stopping_system, compute_err, callback)
+        logging.basicConfig(format="%(asctime)s %(levelname)s: %(message)s", level=50 - verbose)
         fit = run_fit_sharded if shard == 'relations' else run_fit_rows
         return fit(nat.SKF_DFMF, R, None, Theta, obj_types, obj_type2rank, max_iter,
-                   init_type, random_state, dtype, G0, engine)
+                   init_type, random_state, dtype, G0, engine, stopping, stopping_system, compute_err, callback)
     return run_fit(nat.SKF_DFMF, R, None, Theta, obj_types, obj_type2rank, max_iter, init_type,
                    stopping, stopping_system, verbose, compute_err, callback, random_state,
                    dtype, G0, engine)
@@ -301,12 +328,15 @@ def transform(R_ij, Theta_i, target_obj_type, obj_type2rank, G, S, max_iter=10,
             l = seen.get((i, j), 0)
             seen[i, j] = l + 1
             plan.set_backbone(k, S[i, j][l])
-        if callback:
-            for it in range(max_iter):
-                plan.iterate(1)
-                callback(plan.get_factor(t), it)
-        else:
+        if not (callback or stopping or stopping_system or compute_err):
             plan.iterate(max_iter)
+        else:
+            # reference _dfmf.py:367-376, 433-450: the system error of the NEW relations per iteration and
+            # `stopping_system` on its change.  (`stopping` reads an undefined name there -- a NameError at the
+            # third iteration; here it is the error change of the named relation, as in dfmf().)
+            _host_loop(lambda: plan.iterate(1), lambda idx: [plan.relation_sqerr(k) for k in idx], rel_list,
+                       max_iter, stopping, stopping_system, compute_err,
+                       (lambda it: callback(plan.get_factor(t), it)) if callback else None)
         return plan.get_factor(t)
     finally:
         plan.close()

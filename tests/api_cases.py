@@ -170,6 +170,20 @@ def blockwise_completion():
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
     got32 = np.vstack([b for _, b in fuser.complete_blocks(rel, block_rows=64, dtype='f32')])
     np.testing.assert_allclose(got32, want, rtol=1e-5, atol=1e-5)
+    # the backbone and the column factor are uploaded once and stay resident across the blocks; device=True
+    # hands the block over without a copy back
+    from skfusion_amd._engine import DeviceReconstructor
+    import skfusion_amd._native as nat
+    rec = DeviceReconstructor(fuser.backbone(rel), fuser.factor(t2))
+    G1 = fuser.factor(t1)
+    mem = nat.get_runtime().mem
+    for r0 in (0, 50, 100):
+        dm = rec.block(G1[r0:r0 + 50], device=True)
+        blk = mem.to_host(dm.buf, dm.shape, np.float64)
+        np.testing.assert_allclose(blk, want[r0:r0 + 50], rtol=1e-12, atol=1e-12)
+    assert rec.uploads == 2
+    dev = [mem.to_host(b.buf, b.shape, np.float64).copy() for _, b in fuser.complete_blocks(rel, block_rows=50, device=True)]
+    np.testing.assert_allclose(np.vstack(dev), want, rtol=1e-12, atol=1e-12)
 
 
 def error_paths():

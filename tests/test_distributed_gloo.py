@@ -60,6 +60,23 @@ def _c5_sharded(shard='relations'):
     return [G[t, t] for t in types] + [S[i, j][0] for i, j, _, _ in C5_REL]
 
 
+def _probe_stopping(shard):
+    """callback / compute_err / stopping_system inside a sharded fit: every rank sees the errors of ALL relations
+    (summed over the ranks) and therefore stops at the same iteration as the single-device fit."""
+    from helpers import golden, probe_graph, g0_from
+    from skfusion_amd.fusion.decomposition import _dfmf
+    z = golden('probe_multirel.npz')
+    R, Theta, M, types, rank = probe_graph(z)
+    seen = []
+    G, S = _dfmf.dfmf(R, Theta, types, rank, max_iter=40, G0=g0_from(z, 'dfmf/', types), shard=shard,
+                      stopping_system=2e-2, callback=lambda g, s_, it: seen.append(it))
+    seen2 = []
+    G2, S2 = _dfmf.dfmf(R, Theta, types, rank, max_iter=12, G0=g0_from(z, 'dfmf/', types), shard=shard,
+                        stopping=(('t1', 't3'), 1e-3), callback=lambda g, s_, it: seen2.append(it))
+    return [np.array(seen, dtype=np.int64), np.array(seen2, dtype=np.int64)] + [G[t, t] for t in types] + \
+           [G2[t, t] for t in types]
+
+
 def _worker(rank, world, port, out, what):
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, HERE)
@@ -75,6 +92,8 @@ def _worker(rank, world, port, out, what):
         with nat.use_runtime(emulated_runtime()):
             if what == 'runs':
                 np.savez(os.path.join(out, 'rank%d.npz' % rank), *_fit())
+            elif what.startswith('stop:'):
+                np.savez(os.path.join(out, 'stop%d.npz' % rank), *_probe_stopping(what[5:]))
             else:
                 np.savez(os.path.join(out, 'shard%d.npz' % rank), *_probe_sharded(what))
                 np.savez(os.path.join(out, 'c5_%d.npz' % rank), *_c5_sharded(what))
@@ -128,3 +147,26 @@ def test_one_fit_sharded_over_two_gloo_ranks_matches_golden(tmp_path, shard):
             assert relerr(arrs[k], z5['dfmc/G_%s_it1' % t]) < 1e-9
         for k, (i, j, _, _) in enumerate(C5_REL):
             assert relerr(arrs[len(C5_TYPES) + k], z5['dfmc/S_%s_%s_0_it1' % (i, j)]) < 1e-9
+
+
+@pytest.mark.parametrize('shard', ['relations', 'rows'])
+def test_stopping_and_callback_inside_a_sharded_fit(tmp_path, shard):
+    """`stopping`, `stopping_system`, `compute_err` and `callback` under shard='relations' / 'rows' (the reference
+    supports them on every path, _dfmf.py:213-221, 301-322): both ranks stop at the iteration the single-device fit
+    stops at and return its factors."""
+    import torch.multiprocessing as mp
+    import skfusion_amd._native as nat
+    from emul.runtime import emulated_runtime, build
+    from helpers import relerr
+    build()
+    with nat.use_runtime(emulated_runtime()):
+        single = _probe_stopping(None)
+    assert 2 < len(single[0]) < 40 and 2 < len(single[1]) <= 12        # stopping_system fired early
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), 'stop:' + shard), nprocs=2, join=True)
+    for rank in range(2):
+        a = np.load(os.path.join(str(tmp_path), 'stop%d.npz' % rank))
+        np.testing.assert_array_equal(a['arr_0'], single[0])
+        np.testing.assert_array_equal(a['arr_1'], single[1])
+        for k in range(2, len(single)):
+            assert relerr(a['arr_%d' % k], single[k]) < 1e-9

@@ -425,3 +425,32 @@ def test_shape_mismatch_is_a_hard_error():
     with pytest.raises(DataFusionError):
         _dfmf.dfmf(R, {}, ['a', 'b', 'c'], {'a': 2, 'b': 2, 'c': 2}, max_iter=1,
                    random_state=np.random.RandomState(0))
+
+
+def test_transform_honours_stopping_system_and_compute_err():
+    """Fold-in with `stopping_system` (reference _dfmf.py:367-376, 433-450): the system error of the new relations is
+    evaluated every iteration and the loop stops on its change -- the round-1 engine dropped these options silently."""
+    z = golden('transform_readme.npz')
+    G = {(t, t): z['G_%s' % t] for t in TYPES}
+    S = {('t1', 't2'): [z['S_t1_t2']], ('t1', 't3'): [z['S_t1_t3']], ('t2', 't1'): [z['S_t2_t1']]}
+    Rn = {('t1', 't2'): [z['new_t1_t2']], ('t1', 't3'): [z['new_t1_t3']], ('t2', 't1'): [z['new_t2_t1']]}
+    rank = {'t1': 10, 't2': 20, 't3': 30}
+    G0 = z['random_c/G0']
+    seen = []
+    Gi = _dfmf.transform(Rn, {('t1', 't1'): [z['theta_t1']]}, 't1', rank, G, S, max_iter=100, G0=G0,
+                         stopping_system=0.2, callback=lambda g, it: seen.append(it))
+    assert 2 < len(seen) < 100
+    # the same number of plain iterations gives the same factor; the oracle agrees on the stopping iteration
+    Gp = _dfmf.transform(Rn, {('t1', 't1'): [z['theta_t1']]}, 't1', rank, G, S, max_iter=len(seen), G0=G0)
+    assert relerr(Gi, Gp) < 1e-12
+    errs = []
+    Gh = G0
+    for it in range(len(seen) + 3):
+        Gh = orc.transform(Rn, {('t1', 't1'): [z['theta_t1']]}, 't1', rank, G, S, max_iter=it + 1, G0=G0)
+        s = 0.0
+        for (i, j), mats in Rn.items():
+            Gi_, Gj_ = (Gh if i == 't1' else G[i, i]), (Gh if j == 't1' else G[j, j])
+            s += np.linalg.norm(mats[0] - Gi_ @ S[i, j][0] @ Gj_.T)
+        errs.append(s)
+    stop_at = next(it for it in range(2, len(errs)) if errs[it - 2] - errs[it - 1] < 0.2)
+    assert stop_at == len(seen)

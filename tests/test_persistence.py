@@ -1,0 +1,92 @@
+"""On-disk format of a fitted model: FusionFit.save / load round trips, host only.
+(The reference has no persistence; what must survive is exactly what its accessors read:
+factors_[type][run], backbones_[relation][run], base.py:35-56, 169-189.)"""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import skfusion_amd                                                           # noqa: E402,F401
+from skfusion_amd.fusion import (Dfmf, Dfmc, FusionGraph, Relation, ObjectType, DataFusionError,   # noqa: E402
+                                 FusionFit, save_fit, load_fit)
+
+
+def _fitted(cls=Dfmf, n_run=2, seed=0):
+    rs = np.random.RandomState(seed)
+    a, b, c = ObjectType('genes', 4), ObjectType('terms', 3), ObjectType('conditions', 2)
+    rels = [Relation(rs.rand(12, 9), a, b, name='ann'), Relation(rs.rand(12, 9), a, b, name='ann2'),
+            Relation(rs.rand(12, 7), a, c, name='expr', postprocessor=lambda x: np.clip(x, 0.0, 1.0))]
+    graph = FusionGraph(rels)
+    fuser = cls(max_iter=7, init_type='random_vcol', n_run=n_run, random_state=3,
+                callback=lambda *args: None, stopping=(('genes', 'terms'), 1e-3))
+    fuser.fusion_graph = graph
+    for ot, n in ((a, 12), (b, 9), (c, 7)):
+        fuser.factors_[ot] = [rs.rand(n, ot.rank) for _ in range(n_run)]
+    for rel in rels:
+        fuser.backbones_[rel] = [rs.randn(rel.row_type.rank, rel.col_type.rank) for _ in range(n_run)]
+    return fuser, graph, (a, b, c), rels
+
+
+@pytest.mark.parametrize('cls', [Dfmf, Dfmc])
+@pytest.mark.parametrize('n_run', [1, 3])
+def test_round_trip_onto_the_same_graph(tmp_path, cls, n_run):
+    fuser, graph, ots, rels = _fitted(cls, n_run)
+    path = fuser.save(str(tmp_path / 'model.npz'))
+    back = FusionFit.load(path, graph)
+    assert type(back) is cls and back.n_run == n_run and back.max_iter == 7 and back.init_type == 'random_vcol'
+    assert back.callback is None                      # callables are not persisted
+    for ot in ots:
+        got, want = back.factor(ot), fuser.factor(ot)
+        if n_run > 1:                                 # generator convention of the reference (base.py:52-56)
+            assert isinstance(got, types.GeneratorType)
+            got, want = list(got), list(want)
+            assert len(got) == n_run
+            for g, w in zip(got, want):
+                np.testing.assert_array_equal(g, w)
+            np.testing.assert_array_equal(back.factor(ot, run=n_run - 1), fuser.factor(ot, run=n_run - 1))
+        else:
+            np.testing.assert_array_equal(got, want)
+    for rel in rels:
+        for k in range(n_run):
+            np.testing.assert_array_equal(back.backbone(rel, run=k), fuser.backbone(rel, run=k))
+            np.testing.assert_array_equal(back.complete(rel, run=k), fuser.complete(rel, run=k))   # postprocessor of the graph
+
+
+def test_load_without_a_graph_builds_a_skeleton(tmp_path):
+    fuser, graph, ots, rels = _fitted(Dfmf, 2)
+    path = save_fit(fuser, str(tmp_path / 'm.npz'))
+    back = load_fit(path)
+    g2 = back.fusion_graph
+    assert [ot.name for ot in g2.object_types] == [ot.name for ot in graph.object_types]
+    assert [int(ot.rank) for ot in g2.object_types] == [4, 3, 2]
+    assert [(r.row_type.name, r.col_type.name, r.name, r.data.shape) for r in g2.relations] == \
+           [(r.row_type.name, r.col_type.name, r.name, r.data.shape) for r in graph.relations]
+    for ot in ots:
+        np.testing.assert_array_equal(back.factor(g2.get_object_type(ot.name), run=1), fuser.factor(ot, run=1))
+    for rel, rel2 in zip(rels, g2.relations):
+        np.testing.assert_array_equal(back.backbone(rel2, run=0), fuser.backbone(rel, run=0))
+    # the two relations of the same type pair keep their order
+    ann = list(g2.get_relations(g2.get_object_type('genes'), g2.get_object_type('terms')))
+    assert [r.name for r in ann] == ['ann', 'ann2']
+    paths = list(back.chain(g2.get_object_type('genes'), g2.get_object_type('conditions')))
+    assert [[t.name for t in p] for p in paths] == [['genes', 'conditions']]
+
+
+def test_mismatches_are_reported(tmp_path):
+    fuser, graph, ots, rels = _fitted(Dfmf, 1)
+    path = fuser.save(str(tmp_path / 'm.npz'))
+    a, b = ObjectType('genes', 4), ObjectType('terms', 3)
+    with pytest.raises(DataFusionError):              # an object type of the model is missing from the graph
+        load_fit(path, FusionGraph([Relation(np.zeros((12, 9)), a, b)]))
+    c = ObjectType('conditions', 2)
+    wrong = FusionGraph([Relation(np.zeros((12, 9)), a, b), Relation(np.zeros((12, 9)), a, b),
+                         Relation(np.zeros((12, 8)), a, c)])
+    with pytest.raises(DataFusionError):              # relation shape differs from the saved one
+        load_fit(path, wrong)
+    np.savez(str(tmp_path / 'other.npz'), meta=np.frombuffer(b'{"format": "x"}', dtype=np.uint8))
+    with pytest.raises(DataFusionError):
+        load_fit(str(tmp_path / 'other.npz'))
