@@ -454,3 +454,32 @@ def test_transform_honours_stopping_system_and_compute_err():
         errs.append(s)
     stop_at = next(it for it in range(2, len(errs)) if errs[it - 2] - errs[it - 1] < 0.2)
     assert stop_at == len(seen)
+
+
+def test_relation_pipelined_schedule_matches_the_staged_one_and_the_oracle(monkeypatch):
+    """DFMF with every rank above 64 runs the relation-pipelined schedule (contractions on the main stream, each
+    relation's backbone / B terms / side products on the second stream underneath the next relation's
+    contractions, relations walked most-expensive first).  Same arithmetic as the staged schedule
+    (SKF_NO_PIPELINE=1): f64 agrees with it and with the oracle to 1e-10, f32 / bf16 to their engine tolerances."""
+    rs = np.random.RandomState(5)
+    types = ['a', 'b', 'c']
+    n = {'a': 90, 'b': 140, 'c': 75}
+    rank = {'a': 66, 'b': 80, 'c': 70}
+    R = {('a', 'b'): [rs.rand(90, 140)], ('a', 'c'): [rs.rand(90, 75) - 0.3], ('b', 'c'): [rs.rand(140, 75)],
+         ('c', 'a'): [rs.rand(75, 90)]}
+    G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.05 for t in types}
+    Go, So = orc.dfmf(R, {}, types, rank, max_iter=4, G0=G0)
+    out = {}
+    for mode in ('pipelined', 'staged'):
+        if mode == 'staged':
+            monkeypatch.setenv('SKF_NO_PIPELINE', '1')
+        for dtype in ('f64', 'f32', 'bf16'):
+            out[mode, dtype] = _dfmf.dfmf(R, {}, types, rank, max_iter=4, G0=G0, dtype=dtype)
+    for t in types:
+        assert relerr(out['pipelined', 'f64'][0][t, t], Go[t, t]) < 1e-10
+        assert relerr(out['pipelined', 'f64'][0][t, t], out['staged', 'f64'][0][t, t]) < 1e-12
+        assert relerr(out['pipelined', 'f32'][0][t, t], out['staged', 'f32'][0][t, t]) < 1e-5
+        assert relerr(out['pipelined', 'bf16'][0][t, t], out['staged', 'bf16'][0][t, t]) < 1e-5
+        assert relerr(out['pipelined', 'f32'][0][t, t], Go[t, t]) < 1e-4
+    for k in So:
+        assert relerr(out['pipelined', 'f64'][1][k][0], So[k][0]) < 1e-10
