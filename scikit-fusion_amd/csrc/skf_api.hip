@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -246,10 +247,13 @@ static inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
 // K slices for the bf16 contraction: equal work units over the 256 CUs (x resident workgroups)
 // finish in ceil(units/slots) rounds; pick the split that wastes the least of the last round,
 // charging every extra slice for its partial-sum traffic.  The charge is empirical (config 3, A/B
-// runs 0.002 ... 1.0 inside the whole iteration): 0.05-0.07 is best.
+// runs 0.002 ... 1.0 inside the whole iteration; round 2 with the scheduled DMA pieces: 0.04 +0.7 % over 0.06).
 static int pick_splits_bf16(int64_t units, int ktiles, int bm) {
     const double slots = 256.0 * (bm >= 256 ? 1.0 : 2.0);     // resident workgroups on 256 CUs
-    const double penalty = 0.06;                               // cost of one more K slice (partial-sum traffic)
+#ifndef SKF_SPLIT_PENALTY
+#define SKF_SPLIT_PENALTY 0.04
+#endif
+    const double penalty = SKF_SPLIT_PENALTY;                  // cost of one more K slice (partial-sum traffic)
     int best = 1;
     double best_eff = -1.0;
     for (int s = 1; s <= 32; ++s) {
@@ -444,6 +448,8 @@ struct skf_plan {
     skf::Slot part_aux;
     size_t part_aux_bytes = 0;
     bool overlap = false;
+    bool pipeline = true;                  // relation-pipelined schedule of the DFMF iteration (SKF_NO_PIPELINE=1 at bind: off)
+    std::vector<hipEvent_t> ev_rel;        // one event per relation: its contractions are done
     size_t acc_off = 0, acc_bytes = 0;     // contiguous range of all E / D accumulators
     // row-block sharding: contiguous ranges of all W, of the Q of unmasked / of masked relations
     bool sliced = false;
@@ -463,6 +469,7 @@ struct skf_plan {
     int64_t prof_launches = 0;
     ~skf_plan() {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_rel) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (aux) (void)hipStreamDestroy(aux);
@@ -1175,7 +1182,138 @@ static void apply_update(skf_plan* p, hipStream_t st) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The same DFMF iteration as stage_contract + stage_backbone + stage_accumulate, scheduled as a pipeline over
+// the relations (whole, unmasked relations; every rank between 65 and 512; MFMA engine): the main stream runs
+// nothing but the Gram products and the contractions P_r, Q_r, W_r; everything that follows a relation's
+// contractions -- S_r = K_i W_r K_j, the B / D terms, the roundings, its two side products -- runs on the second
+// stream UNDERNEATH the contractions of the next relation (those launches leave 60 of the 256 CUs idle when their
+// 196 row tiles run unsplit, and every launch has a tail).  Only the last relation's small work, the type-level
+// terms G (sum B) and the update itself remain exposed.  Arithmetic and results are those of the staged schedule;
+// only the order in which the relations add into E / D differs (relations are walked cheapest-last).
+// ------------------------------------------------------------------------------------------
+static bool can_pipeline(const skf_plan* p) {
+    if (!p->overlap || p->sliced || p->variant != SKF_DFMF || p->engine != SKF_ENGINE_MFMA || !p->pipeline) return false;
+    if (p->rels.empty() || p->rels.size() > 64 || !p->thetas.empty()) return false;   // (constraint products share the split-K scratch)
+    for (const TypeState& t : p->types)
+        if (t.c <= SMALLC || t.c > 512) return false;
+    for (const RelState& r : p->rels)
+        if (r.absent || r.masked) return false;
+    return true;
+}
+
+static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
+    const size_t nt = p->types.size(), nr = p->rels.size();
+    hipStream_t ax = p->aux;
+    const int nan_upd = 1;                                   // DFMF: nan_to_num on the A/B/C/D terms (_dfmf.py:254-276)
+    p->first_iter = false;
+    if (p->ev_rel.size() < nr) {
+        const size_t old = p->ev_rel.size();
+        p->ev_rel.resize(nr);
+        for (size_t k = old; k < nr; ++k) SKF_HIP(hipEventCreateWithFlags(&p->ev_rel[k], hipEventDisableTiming));
+    }
+    // order of the relations: most expensive first, so that the exposed tail belongs to the cheapest one
+    std::vector<size_t> order(nr);
+    for (size_t k = 0; k < nr; ++k) order[k] = k;
+    auto cost = [&](size_t k) {
+        const RelState& r = p->rels[k];
+        return (double)r.nr * (double)p->types[r.col].n * (p->types[r.row].c + p->types[r.col].c);
+    };
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost(a) > cost(b); });
+
+    // ---- main: Gram matrices; second stream: their pseudo-inverses, then the cleared B sums.
+    // (Measured, profiles/r02_pipeline_ab.txt: with the Gram products and W = G_i^T P on the second stream as well the
+    // contractions slow down by as much as those kernels take -- they are whole-chip launches and any co-resident
+    // workgroup takes a CU from them; what the pipeline can hide is what fits on the 60 CUs the unsplit 196-tile
+    // launches leave idle and in the launch tails: +1.5 % it/s.)
+    std::vector<int> all;
+    for (size_t i = 0; i < nt; ++i) {
+        gram(p, p->types[i], 1, st);
+        all.push_back((int)i);
+    }
+    SKF_HIP(hipEventRecord(p->ev_fork, st));
+    SKF_HIP(hipStreamWaitEvent(ax, p->ev_fork, 0));
+    plan_pinv(p, all, ax);
+    SKF_HIP(hipMemsetAsync((char*)p->ws_base + p->btot_off, 0, p->btot_bytes, ax));
+
+    std::vector<char> touched(nt, 0);
+    std::vector<int> rels_left(nt, 0);           // relations of the type still to come: its sum of B is complete at 0
+    for (const RelState& r : p->rels) {
+        rels_left[r.row] += 1;
+        rels_left[r.col] += 1;
+    }
+    // type-level terms E_i += G_i sum B-, D_i += G_i sum B+ as soon as the last relation of the type is through
+    auto type_term = [&](size_t i) {
+        TypeState& t = p->types[i];
+        const void* Bn = t.Bn_tot.ptr;
+        const void* Bp = t.Bp_tot.ptr;
+        if (!p->f64) {
+            const int cc = t.c * t.c;
+            hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid(cc)), dim3(256), 0, ax, (float*)t.Bn32.ptr,
+                               (int64_t)cc, (const double*)t.Bn_tot.ptr, (int64_t)cc, (int64_t)1, (int64_t)cc);
+            hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid(cc)), dim3(256), 0, ax, (float*)t.Bp32.ptr,
+                               (int64_t)cc, (const double*)t.Bp_tot.ptr, (int64_t)cc, (int64_t)1, (int64_t)cc);
+            check_launch("cast");
+            Bn = t.Bn32.ptr;
+            Bp = t.Bp32.ptr;
+        }
+        if (!touched[i]) {                        // a type without relations here: E = D = 0 before the term is added
+            SKF_HIP(hipMemsetAsync(t.E.ptr, 0, t.E.bytes, ax));
+            SKF_HIP(hipMemsetAsync(t.D.ptr, 0, t.D.bytes, ax));
+            touched[i] = 1;
+        }
+        side_update(p, nullptr, 0, 0, nullptr, 0, 0, t, t.G.ptr, t.E.ptr, t.D.ptr, (int)t.n, Bn, Bp, true, true, 0, ax);
+    };
+    for (size_t q = 0; q < nr; ++q) {
+        RelState& r = p->rels[order[q]];
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        const int ni = (int)r.nr, nj = (int)tj.n, ci = ti.c, cj = tj.c;
+        // ---- main stream: the products that stream the relation, and W = G_i^T P
+        contraction_P(p, r, st);
+        contraction_Q(p, r, st);
+        GemmArgs g = gemm_args(ti.G.ptr, 1, ci, r.P.ptr, cj, 1, r.W.ptr, cj, ci, cj, ni, EPI_STORE, 0);
+        wide_gemm(p, g, st);
+        SKF_HIP(hipEventRecord(p->ev_rel[q], st));
+        // ---- second stream: everything else of this relation
+        SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[q], 0));
+        g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);       // T1 = K_i W
+        small_gemm(p, g, ax);
+        g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);       // S = T1 K_j
+        small_gemm(p, g, ax);
+        relation_small_terms(p, r, nan_upd, EPI_SPLIT_ACC, ti.Bp_tot.ptr, ti.Bn_tot.ptr, tj.Bp_tot.ptr, tj.Bn_tot.ptr,
+                             true, true, ax);
+        const void* Sm = r.S.ptr;
+        if (!p->f64) {
+            hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid((int64_t)ci * cj)), dim3(256), 0, ax,
+                               (float*)r.S32.ptr, (int64_t)cj, (const double*)r.S.ptr, (int64_t)cj, (int64_t)ci, (int64_t)cj);
+            check_launch("cast");
+            Sm = r.S32.ptr;
+        }
+        // row side: E_i (+)= (P S^T)+, D_i (+)= (P S^T)-;  column side: E_j (+)= (Q S)+, D_j (+)= (Q S)-
+        side_update(p, r.P.ptr, cj, cj, Sm, 1, cj, ti, ti.G.ptr, ti.E.ptr, ti.D.ptr, ni, nullptr, nullptr, false,
+                    touched[r.row] != 0, nan_upd, ax);
+        touched[r.row] = 1;
+        side_update(p, r.Q.ptr, ci, ci, Sm, cj, 1, tj, tj.G.ptr, tj.E.ptr, tj.D.ptr, nj, nullptr, nullptr, false,
+                    touched[r.col] != 0, nan_upd, ax);
+        touched[r.col] = 1;
+        if (--rels_left[r.row] == 0) type_term(r.row);
+        if (--rels_left[r.col] == 0) type_term(r.col);
+    }
+    for (size_t i = 0; i < nt; ++i)
+        if (rels_left[i] == 0 && !touched[i]) type_term(i);          // types without relations in this plan
+    theta_terms(p, ax);
+    SKF_HIP(hipEventRecord(p->ev_join, ax));
+    SKF_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
+    apply_update(p, st);
+}
+
 static void iterate_fit(skf_plan* p, hipStream_t st) {
+    if (can_pipeline(p)) {
+        iterate_fit_pipelined(p, st);
+        return;
+    }
     accumulate_fit(p, st);
     apply_update(p, st);
 }
@@ -1525,6 +1663,12 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             size_t need = (size_t)pick_splits(tc, t.c, t.c, (int)t.n) * (size_t)t.c * t.c * 8;
             if (need > aux_bytes) aux_bytes = need;
         }
+        for (RelState& r : p->rels) {          // W = G_i^T P on the second stream (pipelined schedule)
+            const int ci = p->types[r.row].c, cj = p->types[r.col].c;
+            TileCfg tc = pick_tile(true, p->engine, ci, cj);
+            size_t need = (size_t)pick_splits(tc, ci, cj, (int)r.nr) * (size_t)ci * cj * 8;
+            if (need > aux_bytes) aux_bytes = need;
+        }
         p->part_aux_bytes = aux_bytes;
         add_slot(p, p->part_aux, aux_bytes);
         p->sq_elems = sq_elems;
@@ -1677,6 +1821,8 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
         if (p->variant != SKF_TRANSFORM && !p->aux) {
             const char* no = getenv("SKF_NO_OVERLAP");
             if (!(no && atoi(no) != 0)) {
+                const char* np = getenv("SKF_NO_PIPELINE");       // A/B runs and tests: the staged schedule
+                p->pipeline = !(np && atoi(np) != 0);
                 SKF_HIP(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
                 SKF_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
                 SKF_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));

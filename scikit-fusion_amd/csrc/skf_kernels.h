@@ -824,6 +824,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16GemmArgs g) {
 #ifndef SKF_A_AUX
 #define SKF_A_AUX 2
 #endif
+// (An alternative LDS image of the transposed-A tile -- [k/4][m/16] blocks of [4 k][16 m], every 16-lane group of a
+// ds_read_b64_tr_b16 reading one contiguous 128-byte block -- measured equal within 1 %: the XOR-swizzled rows are
+// not bank-conflict bound; profiles/r02_contraction_bounds.txt.)
 #ifndef SKF_B_AUX
 #define SKF_B_AUX 0
 #endif
