@@ -570,6 +570,13 @@ static double chol_rel_threshold() {
     return 1e-8;
 }
 
+// lower edge of the deflation's gap test; SKF_PINV_JACOBI=1 (tests) disables the deflation as well
+static double deflation_lo() {
+    const char* f = getenv("SKF_PINV_JACOBI");
+    if (f && atoi(f) != 0) return 1e300;
+    return 1e-10;
+}
+
 // Cholesky fast path: the LDS-blocked kernel up to order CHOLB_MAXN, the plain one beyond
 static void launch_chol(const EighArgs& e, int batch, int max_order, hipStream_t st) {
     const char* f = getenv("SKF_CHOL_UNBLOCKED");
@@ -645,6 +652,10 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
             check_launch("chol_unpack");
         }
     }
+    // a rank-deficient Gram matrix with a clear spectral gap: rank-revealing deflation (pchol_pinv_kernel); what it
+    // declines goes to the eigen-solver with the exact singular-value cut-off
+    hipLaunchKernelGGL(pchol_pinv_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), 0, st, e, deflation_lo(), 1e-7);
+    check_launch("pchol_pinv");
     hipLaunchKernelGGL(jacobi_eigh_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), 0, st, e);
     check_launch("jacobi_eigh");
     if (batched) {
@@ -2187,6 +2198,8 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
             hipLaunchKernelGGL((chol_unpack_kernel<float>), dim3(elem_grid(tot2)), dim3(256), 0, st, (float*)K, ldk,
                                eV, np, n, eOk);
         check_launch("chol_unpack");
+        hipLaunchKernelGGL(pchol_pinv_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, e, deflation_lo(), 1e-7);
+        check_launch("pchol_pinv");
         hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, e);
         check_launch("jacobi_eigh");
         if (dtype == SKF_F64)

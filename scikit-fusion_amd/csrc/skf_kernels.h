@@ -1468,7 +1468,8 @@ struct EighArgs {
     int64_t wstride;
     const int* n;     // per-matrix (padded, even) order
     const int* n_orig;
-    int* chol_ok;     // per matrix: 1 = the Cholesky fast path produced the inverse (Jacobi skips)
+    int* chol_ok;     // per matrix: 1 = the Cholesky fast path produced the inverse, 2 = the rank-revealing deflation
+                      // did (result in the eigen format Vs, V); 0 = left to the Jacobi eigen-solver
     int max_sweeps;
 };
 
@@ -1986,12 +1987,154 @@ __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_blocked_kernel(Eigh
     if (tid == 0) e.chol_ok[b] = 1;
 }
 
+// ------------------------------------------------------------------------------------------
+// Rank-revealing deflation: the pseudo-inverse of a symmetric positive SEMI-definite matrix the Cholesky fast
+// path rejected (a rank-deficient Gram matrix: duplicate or zero latent columns, rank > objects -- the case of
+// reference tests/test_n_run.py:14), without an eigen-decomposition:
+//   1. Cholesky with complete diagonal pivoting, stopped when the largest remaining diagonal entry falls below
+//      lo * d_max:   A = L L^T + (remainder <= n * lo * d_max),  L: n x r, r = numerical rank
+//   2. A^+ = Y Y^T with Y = L (L^T L)^-1  (exact for a matrix of rank r): B = L^T L (r x r, positive definite),
+//      its Cholesky factor, and one forward + backward substitution per row of L.
+// scipy.linalg.pinv (reference _dfmf.py:232) cuts singular values <= n * eps * sigma_max instead.  The two agree
+// to rounding when the spectrum has a GAP between the kept part and rounding noise, which the kernel checks on
+// the pivots it is given: no accepted pivot below hi * d_max (lo = 1e-10, hi = 1e-7 relative to the largest
+// diagonal entry).  A pivot inside (lo, hi) * d_max -- a genuinely ill-conditioned matrix -- leaves chol_ok = 0 and
+// the Jacobi eigen-solver applies the exact cut-off.  One workgroup per matrix; 1.1 ms instead of 216 ms for a
+// rank-128 matrix of order 256 (tools/bench_pinv.py).  Result in the eigen format: Vs = V = Y (row-major, zero
+// padded), so that eigh_unpack_pinv forms K = Vs V^T.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, double lo, double hi) {
+    __shared__ double d[EIGH_MAXN];            // remaining diagonal; < 0: the index has been a pivot
+    __shared__ double rowk[EIGH_MAXN];         // row of L of the current pivot (its first k entries)
+    __shared__ double red_v[EIGH_THREADS / 64];
+    __shared__ int red_i[EIGH_THREADS / 64];
+    __shared__ double s_val;
+    __shared__ int s_idx, s_fail;
+    const int b = blockIdx.x;
+    if (e.chol_ok[b] || !(lo < 1.0)) return;   // uniform: the fast path inverted this matrix / deflation switched off
+    const int n = e.n[b];
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const double* A = e.A + (int64_t)b * e.stride;
+    double* Lt = e.V + (int64_t)b * e.stride;      // Lt[k * n + i] = L[i][k]   (column k contiguous over the rows)
+    double* W = e.Vs + (int64_t)b * e.stride;      // B = L^T L, then its Cholesky factor (r x r, row-major, ld n)
+
+    for (int i = tid; i < n; i += nt) d[i] = A[(int64_t)i * n + i];
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    double dmax0 = 0.0, last = 0.0;
+    int r = 0;
+    for (int k = 0; k < n; ++k) {
+        // ---- pivot = the largest remaining diagonal entry
+        double bv = -1.0;
+        int bi = -1;
+        for (int i = tid; i < n; i += nt)
+            if (d[i] > bv) { bv = d[i]; bi = i; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double v = red_v[0];
+            int ix = red_i[0];
+            for (int w = 1; w < EIGH_THREADS / 64; ++w)
+                if (red_v[w] > v || (red_v[w] == v && red_i[w] >= 0 && (ix < 0 || red_i[w] < ix))) { v = red_v[w]; ix = red_i[w]; }
+            s_val = v;
+            s_idx = ix;
+        }
+        __syncthreads();
+        const double pv = s_val;
+        const int piv = s_idx;
+        if (k == 0) dmax0 = pv;
+        if (piv < 0 || !(pv > lo * dmax0) || !(pv > 0.0)) break;          // uniform: everything left is noise
+        last = pv;
+        r = k + 1;
+        const double lkk = sqrt(pv);
+        for (int j = tid; j < k; j += nt) rowk[j] = Lt[(int64_t)j * n + piv];
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) {
+            double v;
+            if (i == piv) {
+                v = lkk;
+            } else if (d[i] < 0.0) {
+                v = 0.0;                                                   // an earlier pivot: above the diagonal
+            } else {
+                double sacc = A[(int64_t)i * n + piv];
+                for (int j = 0; j < k; ++j) sacc -= Lt[(int64_t)j * n + i] * rowk[j];
+                v = sacc / lkk;
+                const double nd = d[i] - v * v;
+                d[i] = nd > 0.0 ? nd : 0.0;
+            }
+            Lt[(int64_t)k * n + i] = v;
+        }
+        __syncthreads();
+        if (tid == 0) d[piv] = -1.0;
+        __syncthreads();
+    }
+    if (r > 0 && last < hi * dmax0) return;    // uniform: a pivot in the ambiguous band -> exact cut-off (Jacobi)
+
+    // ---- B = L^T L   (r x r)
+    for (int idx = tid; idx < r * r; idx += nt) {
+        const int a = idx / r, c = idx % r;
+        if (c > a) continue;
+        double sacc = 0.0;
+        for (int i = 0; i < n; ++i) sacc += Lt[(int64_t)a * n + i] * Lt[(int64_t)c * n + i];
+        W[(int64_t)a * n + c] = sacc;
+        W[(int64_t)c * n + a] = sacc;
+    }
+    __syncthreads();
+    // ---- Cholesky of B in place (lower triangle), right-looking
+    for (int k = 0; k < r; ++k) {
+        const double pk = W[(int64_t)k * n + k];
+        if (!(pk > 0.0)) {
+            if (tid == 0) s_fail = 1;
+        }
+        __syncthreads();
+        if (s_fail) return;                    // uniform (A is untouched: the eigen-solver takes over)
+        const double ck = sqrt(pk);
+        for (int i = k + 1 + tid; i < r; i += nt) W[(int64_t)i * n + k] /= ck;
+        __syncthreads();
+        if (tid == 0) W[(int64_t)k * n + k] = ck;
+        const int m = r - k - 1;
+        for (int idx = tid; idx < m * m; idx += nt) {
+            const int i = k + 1 + idx / m, j = k + 1 + idx % m;
+            if (j <= i) W[(int64_t)i * n + j] -= W[(int64_t)i * n + k] * W[(int64_t)j * n + k];
+        }
+        __syncthreads();
+    }
+    // ---- Y = L B^-1: per row i of L solve C z = l_i, C^T y = z, in place in column i of Lt
+    for (int i = tid; i < n; i += nt) {
+        for (int k = 0; k < r; ++k) {
+            double sacc = Lt[(int64_t)k * n + i];
+            for (int j = 0; j < k; ++j) sacc -= W[(int64_t)k * n + j] * Lt[(int64_t)j * n + i];
+            Lt[(int64_t)k * n + i] = sacc / W[(int64_t)k * n + k];
+        }
+        for (int k = r - 1; k >= 0; --k) {
+            double sacc = Lt[(int64_t)k * n + i];
+            for (int j = k + 1; j < r; ++j) sacc -= W[(int64_t)j * n + k] * Lt[(int64_t)j * n + i];
+            Lt[(int64_t)k * n + i] = sacc / W[(int64_t)k * n + k];
+        }
+    }
+    __syncthreads();
+    // ---- eigen format: Vs = V = Y row-major, zero padded   (W is free now; Lt is read before it is overwritten)
+    for (int idx = tid; idx < n * n; idx += nt) {
+        const int i = idx / n, k = idx % n;
+        W[idx] = k < r ? Lt[(int64_t)k * n + i] : 0.0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += nt) Lt[idx] = W[idx];
+    if (tid == 0) e.chol_ok[b] = 2;
+}
+
 // K(r,c) = sum_{k >= max(r,c)} X(k,r) X(k,c)   (inverse from the inverted Cholesky factor)
 template <typename T>
 __global__ __launch_bounds__(256) void chol_unpack_kernel(T* __restrict__ K, int64_t ldk,
                                                           const double* __restrict__ X, int ld, int n,
                                                           const int* __restrict__ chol_ok) {
-    if (!chol_ok[0]) return;
+    if (chol_ok[0] != 1) return;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
         const int r = idx / n, c = idx % n;
         double s = 0.0;
@@ -2017,7 +2160,7 @@ __global__ __launch_bounds__(256) void eigh_unpack_pinv_kernel(T* __restrict__ K
                                                                const double* __restrict__ Vs,
                                                                const double* __restrict__ V, int n_pad, int n,
                                                                const int* __restrict__ chol_ok) {
-    if (chol_ok[0]) return;
+    if (chol_ok[0] == 1) return;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += gridDim.x * blockDim.x) {
         const int r = idx / n, c = idx % n;
         double s = 0.0;
@@ -2168,7 +2311,7 @@ __global__ __launch_bounds__(256) void eigh_pack_batched_kernel(PinvBatch pb, do
 __global__ __launch_bounds__(256) void chol_unpack_batched_kernel(PinvBatch pb, const double* __restrict__ Xall,
                                                                   int64_t stride, const int* __restrict__ chol_ok) {
     const int b = blockIdx.y;
-    if (!chol_ok[b]) return;
+    if (chol_ok[b] != 1) return;
     const int n = pb.c[b], ld = pb.n_pad[b];
     const double* X = Xall + (int64_t)b * stride;
     double* K = pb.K[b];
@@ -2184,7 +2327,7 @@ __global__ __launch_bounds__(256) void eigh_unpack_pinv_batched_kernel(PinvBatch
                                                                        const double* __restrict__ VAll, int64_t stride,
                                                                        const int* __restrict__ chol_ok) {
     const int b = blockIdx.y;
-    if (chol_ok[b]) return;
+    if (chol_ok[b] == 1) return;
     const int n = pb.c[b], n_pad = pb.n_pad[b];
     const double* Vs = VsAll + (int64_t)b * stride;
     const double* V = VAll + (int64_t)b * stride;

@@ -263,6 +263,40 @@ def test_pinv_rank_deficient_truncates_like_scipy(rt):
     assert np.isfinite(got32).all()
 
 
+@pytest.mark.parametrize('n,rank', [(50, 30), (96, 40), (130, 65), (33, 1)])
+def test_pinv_deflation_matches_scipy_and_the_eigen_path(rt, n, rank, monkeypatch):
+    """A rank-deficient Gram matrix with a clear spectral gap goes through the rank-revealing deflation
+    (pivoted Cholesky, A^+ = Y Y^T with Y = L (L^T L)^-1): same result as scipy.linalg.pinv and as the Jacobi
+    eigen path with its exact cut-off (SKF_PINV_JACOBI=1), duplicate columns included."""
+    import scipy.linalg as spla
+    rs = np.random.RandomState(n + rank)
+    G = rs.rand(rank, n)
+    G[:, n // 2] = G[:, 1]                       # an exactly duplicated latent column
+    A = G.T @ G
+    want = spla.pinv(A)
+    got = run_pinv(rt, nat.SKF_F64, A)
+    assert relerr(got, want) < 1e-8
+    monkeypatch.setenv('SKF_PINV_JACOBI', '1')
+    exact = run_pinv(rt, nat.SKF_F64, A)
+    assert relerr(got, exact) < 1e-8
+
+
+def test_pinv_ambiguous_spectrum_falls_back_to_the_exact_cut_off(rt):
+    """A singular value inside the deflation's gap band (1e-10 .. 1e-7 of the largest) is neither noise nor safely
+    invertible by a pivot rule: the deflation declines and the eigen path applies scipy's cut-off (which keeps
+    it: 1e-8 is far above n * eps)."""
+    import scipy.linalg as spla
+    rs = np.random.RandomState(4)
+    Qm, _ = np.linalg.qr(rs.randn(24, 24))
+    w = np.array([1.0] * 10 + [1e-8] * 2 + [0.0] * 12)
+    A = (Qm * w) @ Qm.T
+    A = 0.5 * (A + A.T)
+    got = run_pinv(rt, nat.SKF_F64, A)
+    want = spla.pinv(A)
+    assert np.abs(got).max() > 1e7                # the 1e-8 directions were inverted, not dropped
+    assert relerr(got, want) < 1e-6
+
+
 @pytest.mark.parametrize('n', [12, 40, 70])
 def test_pinv_badly_scaled_columns_match_scipy(rt, n):
     """Latent dimensions of very different scale (column norms down to 1e-5 of the largest: diagonal of
