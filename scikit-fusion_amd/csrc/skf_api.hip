@@ -654,7 +654,11 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
     }
     // a rank-deficient Gram matrix with a clear spectral gap: rank-revealing deflation (pchol_pinv_kernel); what it
     // declines goes to the eigen-solver with the exact singular-value cut-off
-    hipLaunchKernelGGL(pchol_pinv_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), 0, st, e, deflation_lo(), 1e-7);
+    {
+        static std::once_flag once;
+        allow_dynamic_lds(once, pchol_pinv_kernel, PCHOL_LDS_BYTES);
+    }
+    hipLaunchKernelGGL(pchol_pinv_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), PCHOL_LDS_BYTES, st, e, deflation_lo(), 1e-7);
     check_launch("pchol_pinv");
     hipLaunchKernelGGL(jacobi_eigh_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), 0, st, e);
     check_launch("jacobi_eigh");
@@ -2198,7 +2202,11 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
             hipLaunchKernelGGL((chol_unpack_kernel<float>), dim3(elem_grid(tot2)), dim3(256), 0, st, (float*)K, ldk,
                                eV, np, n, eOk);
         check_launch("chol_unpack");
-        hipLaunchKernelGGL(pchol_pinv_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, e, deflation_lo(), 1e-7);
+        {
+            static std::once_flag once;
+            allow_dynamic_lds(once, pchol_pinv_kernel, PCHOL_LDS_BYTES);
+        }
+        hipLaunchKernelGGL(pchol_pinv_kernel, dim3(1), dim3(EIGH_THREADS), PCHOL_LDS_BYTES, st, e, deflation_lo(), 1e-7);
         check_launch("pchol_pinv");
         hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, e);
         check_launch("jacobi_eigh");

@@ -2003,6 +2003,8 @@ __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_blocked_kernel(Eigh
 // rank-128 matrix of order 256 (tools/bench_pinv.py).  Result in the eigen format: Vs = V = Y (row-major, zero
 // padded), so that eigh_unpack_pinv forms K = Vs V^T.
 // ------------------------------------------------------------------------------------------
+constexpr int PCHOL_LDS_R = 176;           // packed r (r + 1) / 2 doubles of the small factor fit the dynamic LDS up to this rank
+constexpr int PCHOL_LDS_BYTES = PCHOL_LDS_R * (PCHOL_LDS_R + 1) / 2 * 8;
 __global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, double lo, double hi) {
     __shared__ double d[EIGH_MAXN];            // remaining diagonal; < 0: the index has been a pivot
     __shared__ double rowk[EIGH_MAXN];         // row of L of the current pivot (its first k entries)
@@ -2076,46 +2078,67 @@ __global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, do
     }
     if (r > 0 && last < hi * dmax0) return;    // uniform: a pivot in the ambiguous band -> exact cut-off (Jacobi)
 
-    // ---- B = L^T L   (r x r)
-    for (int idx = tid; idx < r * r; idx += nt) {
-        const int a = idx / r, c = idx % r;
-        if (c > a) continue;
+    // ---- B = L^T L (r x r, lower triangle, packed: element (a, c <= a) at a (a + 1) / 2 + c) -- in LDS when it fits
+    // (r <= PCHOL_LDS_R), else in the Vs scratch.  One wave per element: the lanes split the rows (coalesced) and meet
+    // in a wave reduction.
+    HIP_DYNAMIC_SHARED(double, Cs)
+    const bool in_lds = r <= PCHOL_LDS_R;
+    double* Cp = in_lds ? Cs : W;
+    const int nel = r * (r + 1) / 2;
+    for (int el = wave; el < nel; el += EIGH_THREADS / 64) {
+        int a = (int)((sqrt(8.0 * el + 1.0) - 1.0) * 0.5);
+        while ((a + 1) * (a + 2) / 2 <= el) ++a;
+        while (a * (a + 1) / 2 > el) --a;
+        const int c = el - a * (a + 1) / 2;
         double sacc = 0.0;
-        for (int i = 0; i < n; ++i) sacc += Lt[(int64_t)a * n + i] * Lt[(int64_t)c * n + i];
-        W[(int64_t)a * n + c] = sacc;
-        W[(int64_t)c * n + a] = sacc;
+        for (int i = lane; i < n; i += 64) sacc += Lt[(int64_t)a * n + i] * Lt[(int64_t)c * n + i];
+        sacc = wave_sum(sacc);
+        if (lane == 0) Cp[el] = sacc;
     }
     __syncthreads();
-    // ---- Cholesky of B in place (lower triangle), right-looking
+    // ---- Cholesky of B in place, right-looking
     for (int k = 0; k < r; ++k) {
-        const double pk = W[(int64_t)k * n + k];
+        const int kk = k * (k + 1) / 2;
+        const double pk = Cp[kk + k];
         if (!(pk > 0.0)) {
             if (tid == 0) s_fail = 1;
         }
         __syncthreads();
         if (s_fail) return;                    // uniform (A is untouched: the eigen-solver takes over)
         const double ck = sqrt(pk);
-        for (int i = k + 1 + tid; i < r; i += nt) W[(int64_t)i * n + k] /= ck;
+        for (int i = k + 1 + tid; i < r; i += nt) Cp[i * (i + 1) / 2 + k] /= ck;
         __syncthreads();
-        if (tid == 0) W[(int64_t)k * n + k] = ck;
+        if (tid == 0) Cp[kk + k] = ck;
         const int m = r - k - 1;
         for (int idx = tid; idx < m * m; idx += nt) {
             const int i = k + 1 + idx / m, j = k + 1 + idx % m;
-            if (j <= i) W[(int64_t)i * n + j] -= W[(int64_t)i * n + k] * W[(int64_t)j * n + k];
+            if (j <= i) Cp[i * (i + 1) / 2 + j] -= Cp[i * (i + 1) / 2 + k] * Cp[j * (j + 1) / 2 + k];
         }
         __syncthreads();
     }
-    // ---- Y = L B^-1: per row i of L solve C z = l_i, C^T y = z, in place in column i of Lt
+    // ---- Y = L B^-1: per row i of L solve C z = l_i, C^T y = z, in place in column i of Lt (coalesced over i;
+    // the factor is read uniformly: LDS broadcast)
     for (int i = tid; i < n; i += nt) {
         for (int k = 0; k < r; ++k) {
-            double sacc = Lt[(int64_t)k * n + i];
-            for (int j = 0; j < k; ++j) sacc -= W[(int64_t)k * n + j] * Lt[(int64_t)j * n + i];
-            Lt[(int64_t)k * n + i] = sacc / W[(int64_t)k * n + k];
+            const int kk = k * (k + 1) / 2;
+            double s0 = Lt[(int64_t)k * n + i], s1 = 0.0;
+            int j = 0;
+            for (; j + 1 < k; j += 2) {
+                s0 -= Cp[kk + j] * Lt[(int64_t)j * n + i];
+                s1 -= Cp[kk + j + 1] * Lt[(int64_t)(j + 1) * n + i];
+            }
+            if (j < k) s0 -= Cp[kk + j] * Lt[(int64_t)j * n + i];
+            Lt[(int64_t)k * n + i] = (s0 + s1) / Cp[kk + k];
         }
         for (int k = r - 1; k >= 0; --k) {
-            double sacc = Lt[(int64_t)k * n + i];
-            for (int j = k + 1; j < r; ++j) sacc -= W[(int64_t)j * n + k] * Lt[(int64_t)j * n + i];
-            Lt[(int64_t)k * n + i] = sacc / W[(int64_t)k * n + k];
+            double s0 = Lt[(int64_t)k * n + i], s1 = 0.0;
+            int j = k + 1;
+            for (; j + 1 < r; j += 2) {
+                s0 -= Cp[j * (j + 1) / 2 + k] * Lt[(int64_t)j * n + i];
+                s1 -= Cp[(j + 1) * (j + 2) / 2 + k] * Lt[(int64_t)(j + 1) * n + i];
+            }
+            if (j < r) s0 -= Cp[j * (j + 1) / 2 + k] * Lt[(int64_t)j * n + i];
+            Lt[(int64_t)k * n + i] = (s0 + s1) / Cp[k * (k + 1) / 2 + k];
         }
     }
     __syncthreads();

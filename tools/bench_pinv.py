@@ -1,4 +1,5 @@
-"""Time skf_pinv_sym on the GPU: full-rank (Cholesky fast path) and rank-deficient (eigen path)
+"""Time skf_pinv_sym on the GPU: full-rank (Cholesky fast path) and rank-deficient (rank-revealing deflation;
+SKF_PINV_JACOBI=1: the Jacobi eigen path)
 Gram matrices of order n.    python tools/bench_pinv.py [n ...]"""
 import ctypes as C
 import os
