@@ -255,6 +255,17 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
 int skf_fill_uniform(int32_t dtype, void* dst, int64_t rows, int64_t cols, int64_t ld,
                      uint64_t seed, double scale, double shift, void* stream);
 
+/* Relation.filled() on the device (reference fusion_graph.py:464-510): every UNKNOWN entry of `data` (rows x cols,
+ * SKF_F64 / SKF_F32, in place) -- not finite, or flagged in the optional byte mask -- is replaced by the mean of the
+ * known entries of the whole matrix (strategy 0, 'mean'), of its row (1, 'row_mean') or column (2, 'col_mean'; rows /
+ * columns without a known entry take the overall mean), or by `value` (3, a constant).  numpy.nanmean semantics: NaN
+ * and masked entries are skipped, +-inf take part in the means.  Whether the mask survives the fill is the host
+ * layer's business (it does for 'mean' and constants, not for the row / column means: fusion_graph.py:475-489). */
+int skf_fill_unknown_workspace_bytes(int64_t rows, int64_t cols, size_t* bytes);
+int skf_fill_unknown(int32_t dtype, void* data, int64_t ld, int64_t rows, int64_t cols, const uint8_t* mask,
+                     int64_t mask_ld, int32_t strategy, double value, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
 /* dst(r,c) = (dst_dtype) src(r,c), dtypes SKF_F64 / SKF_F32 */
 int skf_cast(int32_t dst_dtype, void* dst, int64_t ldd, int32_t src_dtype, const void* src,
              int64_t lds, int64_t rows, int64_t cols, void* stream);

@@ -62,6 +62,42 @@ def fill_uniform(shape, seed, dtype='f32', scale=1.0, shift=0.0, runtime=None):
     return DeviceMatrix(buf, shape)
 
 
+_FILL = {'mean': 0, 'row_mean': 1, 'col_mean': 2, 'const': 3}
+
+
+def fill_unknown_device(data, mask, strategy, value=0.0, dtype='f64', runtime=None):
+    """Host matrix (NaN / inf / masked entries unknown) -> DeviceMatrix of the engine dtype with the unknown entries
+    imputed on the device (reference Relation.filled(), fusion_graph.py:464-510).  SKF_BF16: filled in f32, then
+    rounded to bf16 on the device."""
+    rt = runtime or nat.get_runtime()
+    code = nat.DTYPES[dtype]
+    work = nat.SKF_F32 if code == nat.SKF_BF16 else code
+    npd = nat.NP_DTYPE[work]
+    arr = np.ascontiguousarray(data, dtype=npd)
+    if arr.ndim != 2:
+        raise ValueError('relation data is not a matrix')
+    rows, cols = arr.shape
+    buf = rt.mem.from_host(arr)
+    mbuf, mld = None, 0
+    if mask is not None:
+        m = np.ascontiguousarray(np.asarray(mask, dtype=bool).astype(np.uint8))
+        if m.shape != arr.shape:
+            raise ValueError('mask shape mismatch')
+        mbuf, mld = rt.mem.from_host(m), cols
+    need = C.c_size_t()
+    rt.call('skf_fill_unknown_workspace_bytes', rows, cols, C.byref(need))
+    ws = rt.mem.empty(need.value)
+    rt.call('skf_fill_unknown', work, buf.ptr, cols, rows, cols, mbuf.ptr if mbuf is not None else None, mld,
+            _FILL[strategy], float(value), ws.ptr, need.value, rt.mem.stream)
+    if code == nat.SKF_BF16:
+        out = rt.mem.empty(rows * cols * 2)
+        rt.call('skf_to_bf16', out.ptr, cols, work, buf.ptr, cols, rows, cols, 0, rt.mem.stream)
+        rt.mem.synchronize()
+        return DeviceMatrix(out, (rows, cols))
+    rt.mem.synchronize()
+    return DeviceMatrix(buf, (rows, cols))
+
+
 def _all_reduce_sum(t):
     """Sum a tensor view over the process group (RCCL for GPU tensors; a gloo group -- CPU tests,
     single-GPU smoke runs -- stages GPU tensors through the host)."""

@@ -108,6 +108,9 @@ SIGNATURES = {
     'skf_pinv_sym': (C.c_int, [C.c_int32, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
     'skf_fill_uniform': (C.c_int, [C.c_int32, _P, C.c_int64, C.c_int64, C.c_int64, C.c_uint64,
                                    C.c_double, C.c_double, _P]),
+    'skf_fill_unknown_workspace_bytes': (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
+    'skf_fill_unknown': (C.c_int, [C.c_int32, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int32, C.c_double,
+                                   _P, C.c_size_t, _P]),
     'skf_cast': (C.c_int, [C.c_int32, _P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int64, C.c_int64, _P]),
     'skf_last_error': (C.c_char_p, []),
     'skf_version': (C.c_char_p, []),

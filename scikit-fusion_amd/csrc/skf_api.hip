@@ -2241,6 +2241,51 @@ int skf_fill_uniform(int32_t dtype, void* dst, int64_t rows, int64_t cols, int64
     });
 }
 
+int skf_fill_unknown_workspace_bytes(int64_t rows, int64_t cols, size_t* bytes) {
+    return guarded([&] {
+        if (rows < 0 || cols < 0 || !bytes) SKF_FAIL(SKF_E_INVALID, "bad argument");
+        *bytes = (size_t)(2 * rows + 2 * cols + 2) * sizeof(double);
+    });
+}
+
+int skf_fill_unknown(int32_t dtype, void* data, int64_t ld, int64_t rows, int64_t cols, const uint8_t* mask, int64_t mask_ld,
+                     int32_t strategy, double value, void* workspace, size_t workspace_bytes, void* stream) {
+    return guarded([&] {
+        if (!data || rows < 0 || cols < 0 || ld < cols || (mask && mask_ld < cols)) SKF_FAIL(SKF_E_INVALID, "bad argument");
+        if (dtype != SKF_F64 && dtype != SKF_F32) SKF_FAIL(SKF_E_INVALID, "skf_fill_unknown: dtype must be SKF_F64 / SKF_F32");
+        if (strategy < FILL_MEAN || strategy > FILL_CONST) SKF_FAIL(SKF_E_INVALID, "unknown fill strategy %d", strategy);
+        size_t need = 0;
+        skf_fill_unknown_workspace_bytes(rows, cols, &need);
+        if (!workspace || workspace_bytes < need) SKF_FAIL(SKF_E_WORKSPACE, "fill workspace too small / null");
+        if (rows == 0 || cols == 0) return;
+        hipStream_t st = as_stream(stream);
+        double* stats = (double*)workspace;
+        const int rgrid = (int)((rows + 3) / 4 < 2048 ? ((rows + 3) / 4 > 0 ? (rows + 3) / 4 : 1) : 2048);     // 4 waves per workgroup
+        if (dtype == SKF_F64) {
+            double* X = (double*)data;
+            if (strategy != FILL_CONST) {
+                hipLaunchKernelGGL((fill_row_stats_kernel<double>), dim3(rgrid), dim3(256), 0, st, X, ld, rows, cols, mask, mask_ld, stats);
+                if (strategy == FILL_COL_MEAN)
+                    hipLaunchKernelGGL((fill_col_stats_kernel<double>), dim3(elem_grid(cols)), dim3(256), 0, st, X, ld, rows, cols, mask, mask_ld, stats);
+                hipLaunchKernelGGL(fill_total_kernel, dim3(1), dim3(256), 0, st, rows, cols, stats);
+            }
+            hipLaunchKernelGGL((fill_apply_kernel<double>), dim3(elem_grid(rows * cols)), dim3(256), 0, st, X, ld, rows, cols, mask,
+                               mask_ld, stats, strategy, value);
+        } else {
+            float* X = (float*)data;
+            if (strategy != FILL_CONST) {
+                hipLaunchKernelGGL((fill_row_stats_kernel<float>), dim3(rgrid), dim3(256), 0, st, X, ld, rows, cols, mask, mask_ld, stats);
+                if (strategy == FILL_COL_MEAN)
+                    hipLaunchKernelGGL((fill_col_stats_kernel<float>), dim3(elem_grid(cols)), dim3(256), 0, st, X, ld, rows, cols, mask, mask_ld, stats);
+                hipLaunchKernelGGL(fill_total_kernel, dim3(1), dim3(256), 0, st, rows, cols, stats);
+            }
+            hipLaunchKernelGGL((fill_apply_kernel<float>), dim3(elem_grid(rows * cols)), dim3(256), 0, st, X, ld, rows, cols, mask,
+                               mask_ld, stats, strategy, value);
+        }
+        check_launch("fill_unknown");
+    });
+}
+
 int skf_cast(int32_t dst_dtype, void* dst, int64_t ldd, int32_t src_dtype, const void* src, int64_t lds, int64_t rows,
              int64_t cols, void* stream) {
     return guarded([&] {

@@ -1413,6 +1413,92 @@ __global__ __launch_bounds__(256) void known_entries_kernel(KnownArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fill strategies of Relation.filled() on the device (reference fusion_graph.py:464-510): an entry is UNKNOWN when
+// it is not finite or masked; it is replaced by the mean of the known entries (numpy.nanmean semantics: NaN and
+// masked entries are skipped, +-inf take part and make the mean infinite) of the whole matrix, of its row or of
+// its column -- a row / column without any known entry takes the overall mean -- or by a constant.
+// Statistics in f64: stats[0..rows) row sums, [rows..2 rows) row counts, then column sums / counts, then the
+// total sum and count.  Fixed summation order (no float atomics): run-to-run deterministic.
+// ------------------------------------------------------------------------------------------
+enum { FILL_MEAN = 0, FILL_ROW_MEAN = 1, FILL_COL_MEAN = 2, FILL_CONST = 3 };
+
+template <typename T>
+__device__ __forceinline__ bool fill_known(T v, const uint8_t* mask, int64_t ldm, int64_t r, int64_t c) {
+    if (mask && mask[r * ldm + c]) return false;
+    return v == v;                               // NaN is skipped; +-inf is a value for the means (numpy.nanmean)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fill_row_stats_kernel(const T* __restrict__ X, int64_t ld, int64_t rows, int64_t cols,
+                                                             const uint8_t* __restrict__ mask, int64_t ldm,
+                                                             double* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        double s = 0.0, n = 0.0;
+        for (int64_t c = lane; c < cols; c += 64) {
+            const T v = X[r * ld + c];
+            if (fill_known(v, mask, ldm, r, c)) { s += (double)v; n += 1.0; }
+        }
+        s = wave_sum(s);
+        n = wave_sum(n);
+        if (lane == 0) { stats[r] = s; stats[rows + r] = n; }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fill_col_stats_kernel(const T* __restrict__ X, int64_t ld, int64_t rows, int64_t cols,
+                                                             const uint8_t* __restrict__ mask, int64_t ldm,
+                                                             double* __restrict__ stats) {
+    double* cs = stats + 2 * rows;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += (int64_t)gridDim.x * blockDim.x) {
+        double s = 0.0, n = 0.0;
+        for (int64_t r = 0; r < rows; ++r) {
+            const T v = X[r * ld + c];
+            if (fill_known(v, mask, ldm, r, c)) { s += (double)v; n += 1.0; }
+        }
+        cs[c] = s;
+        cs[cols + c] = n;
+    }
+}
+
+// total sum / count from the row statistics (one workgroup, fixed order)
+__global__ __launch_bounds__(256) void fill_total_kernel(int64_t rows, int64_t cols, double* __restrict__ stats) {
+    __shared__ double ps[256], pn[256];
+    double s = 0.0, n = 0.0;
+    for (int64_t r = threadIdx.x; r < rows; r += 256) { s += stats[r]; n += stats[rows + r]; }
+    ps[threadIdx.x] = s;
+    pn[threadIdx.x] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0, tn = 0.0;
+        for (int k = 0; k < 256; ++k) { ts += ps[k]; tn += pn[k]; }
+        stats[2 * rows + 2 * cols] = ts;
+        stats[2 * rows + 2 * cols + 1] = tn;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fill_apply_kernel(T* __restrict__ X, int64_t ld, int64_t rows, int64_t cols,
+                                                         const uint8_t* __restrict__ mask, int64_t ldm,
+                                                         const double* __restrict__ stats, int strategy, double value) {
+    const int64_t total = rows * cols;
+    const double ts = stats[2 * rows + 2 * cols], tn = stats[2 * rows + 2 * cols + 1];
+    const double overall = ts / tn;              // 0 / 0 = NaN when nothing is known, as numpy.nanmean
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / cols, c = e % cols;
+        const T v = X[r * ld + c];
+        const bool unknown = (mask && mask[r * ldm + c]) || !(v - v == (T)0);      // masked, NaN or +-inf
+        if (!unknown) continue;
+        double f = value;
+        if (strategy == FILL_MEAN) f = overall;
+        else if (strategy == FILL_ROW_MEAN) f = stats[rows + r] > 0.0 ? stats[r] / stats[rows + r] : overall;
+        else if (strategy == FILL_COL_MEAN) f = stats[2 * rows + cols + c] > 0.0 ? stats[2 * rows + c] / stats[2 * rows + cols + c] : overall;
+        X[r * ld + c] = (T)f;
+    }
+}
+
 // flags[0] |= any(Theta > 0), flags[1] |= any(Theta < 0): the all-zero half of a constraint's +- split
 // (_dfmf.py:203-208) is never multiplied (e.g. a non-positive similarity has Theta+ == 0)
 template <typename T>

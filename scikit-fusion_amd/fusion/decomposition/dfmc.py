@@ -7,7 +7,8 @@ import numpy as np
 from ..base import FusionFit
 from . import _dfmc
 from ..._distributed import my_runs, gather_runs
-from .dfmf import graph_matrices, store_runs, initial_factors, _random_state, concurrent_streams
+from .dfmf import (graph_matrices, store_runs, initial_factors, _random_state, concurrent_streams,
+                   device_fill_dtype)
 
 __all__ = ['Dfmc']
 
@@ -19,7 +20,7 @@ class Dfmc(FusionFit):
 
     def __init__(self, max_iter=100, init_type='random_c', n_run=1, stopping=None,
                  stopping_system=None, verbose=0, compute_err=False, callback=None,
-                 random_state=None, n_jobs=1, dtype='f64', shard='runs'):
+                 random_state=None, n_jobs=1, dtype='f64', shard='runs', device_fill=False):
         super(Dfmc, self).__init__()
         self._set_params(vars())
 
@@ -28,7 +29,7 @@ class Dfmc(FusionFit):
         self.random_state = _random_state(self.random_state)
         object_types = list(fusion_graph.object_types)
         rank = {ot: int(ot.rank) for ot in object_types}
-        R, Theta, M = graph_matrices(fusion_graph, with_masks=True)
+        R, Theta, M = graph_matrices(fusion_graph, with_masks=True, device_dtype=device_fill_dtype(self))
         G0 = initial_factors(R, object_types, rank, self.init_type, self.random_state, self.n_run)
         kw = dict(R=R, M=M, Theta=Theta, obj_types=object_types, obj_type2rank=rank,
                   max_iter=self.max_iter, init_type=self.init_type, stopping=self.stopping,

@@ -24,22 +24,27 @@ def _random_state(obj):
     return obj if isinstance(obj, np.random.RandomState) else np.random.RandomState(obj)
 
 
-def graph_matrices(fusion_graph, with_masks=False):
+def graph_matrices(fusion_graph, with_masks=False, device_dtype=None):
     """FusionGraph -> (R, Theta[, M]) dictionaries in the reference's walking order
     (dfmf.py:70-85, dfmc.py:70-93): pairs from product(object_types, repeat=2), each relation
     filled, then preprocessed; relations between two different types go to R, same-type
     relations are constraints (Theta).  For a masked result the raw ``.data`` is used and,
-    with ``with_masks``, the mask is kept as the completion mask."""
+    with ``with_masks``, the mask is kept as the completion mask.
+    ``device_dtype``: relations (not constraints) without a preprocessor are filled ON THE DEVICE and enter the
+    dictionaries as device-resident matrices of that engine dtype (``Relation.filled_device``)."""
     R, Theta, M = {}, {}, {}
     for row_type, col_type in product(fusion_graph.object_types, repeat=2):
         for relation in fusion_graph.get_relations(row_type, col_type):
-            data = relation.filled()
-            if relation.preprocessor:
-                data = relation.preprocessor(data)
             mask = None
-            if np.ma.is_masked(data):
-                mask = data.mask
-                data = data.data
+            if device_dtype and not relation.preprocessor and relation.row_type != relation.col_type:
+                data, mask = relation.filled_device(device_dtype)
+            else:
+                data = relation.filled()
+                if relation.preprocessor:
+                    data = relation.preprocessor(data)
+                if np.ma.is_masked(data):
+                    mask = data.mask
+                    data = data.data
             key = (relation.row_type, relation.col_type)
             if relation.row_type != relation.col_type:
                 R.setdefault(key, []).append(data)
@@ -55,9 +60,19 @@ def initial_factors(R, object_types, rank, init_type, random_state, n_run):
     n_jobs=1).  Every rank draws all of them so that the result of run k does not depend on how
     many GPUs share the work."""
     n_obj = count_objects(object_types, R)
-    R_first = {k: np.asarray(v[0], dtype=float) for k, v in R.items()}
+    # ('random' never reads the relations: they may live on the device already, `device_fill`)
+    R_first = {} if init_type == 'random' else {k: np.asarray(v[0], dtype=float) for k, v in R.items()}
     return [initialize(object_types, n_obj, rank, R_first, init_type, random_state)
             for _ in range(n_run)]
+
+
+def device_fill_dtype(fuser):
+    """The engine dtype when the fill strategies of the relations may run on the device: asked for
+    (`device_fill=True`), whole relations on this process (shard='runs'), and an initialiser that does not read the
+    filled values on the host ('random'; the column-mean initialisers `random_c` / `random_vcol` do)."""
+    if getattr(fuser, 'device_fill', False) and fuser.shard == 'runs' and fuser.init_type == 'random':
+        return fuser.dtype
+    return None
 
 
 def concurrent_streams(fuser):
@@ -105,7 +120,7 @@ class Dfmf(FusionFit):
 
     def __init__(self, max_iter=100, init_type='random_c', n_run=1, stopping=None,
                  stopping_system=None, verbose=0, compute_err=False, callback=None,
-                 random_state=None, n_jobs=1, dtype='f64', shard='runs'):
+                 random_state=None, n_jobs=1, dtype='f64', shard='runs', device_fill=False):
         super(Dfmf, self).__init__()
         self._set_params(vars())
 
@@ -114,7 +129,7 @@ class Dfmf(FusionFit):
         self.random_state = _random_state(self.random_state)
         object_types = list(fusion_graph.object_types)
         rank = {ot: int(ot.rank) for ot in object_types}
-        R, Theta = graph_matrices(fusion_graph)
+        R, Theta = graph_matrices(fusion_graph, device_dtype=device_fill_dtype(self))
         G0 = initial_factors(R, object_types, rank, self.init_type, self.random_state, self.n_run)
         kw = dict(R=R, Theta=Theta, obj_types=object_types, obj_type2rank=rank,
                   max_iter=self.max_iter, init_type=self.init_type, stopping=self.stopping,

@@ -119,6 +119,24 @@ class Relation(object):
             return fill_const(self.data, self.fill_value)
         return _FILLERS[self.fill_value](self.data)
 
+    def filled_device(self, dtype='f64', runtime=None):
+        """``filled()`` on the device: the raw matrix (and its mask) are uploaded once and the unknown entries are
+        imputed in HBM (``skf_fill_unknown``); returns ``(DeviceMatrix in the engine dtype, mask or None)`` where
+        the mask is what ``filled()`` would leave on the result -- kept by 'mean' and constants, dropped by
+        'row_mean' / 'col_mean' (reference fusion_graph.py:475-489 under NumPy's masked-assignment rules)."""
+        from .._engine import fill_unknown_device
+        x = self.data
+        mask = np.ma.getmaskarray(x) if np.ma.isMaskedArray(x) and np.ma.is_masked(x) else None
+        if isinstance(self.fill_value, Number):
+            strategy, value = 'const', float(self.fill_value)
+        else:
+            if self.fill_value not in _FILLERS:
+                raise KeyError(self.fill_value)
+            strategy, value = self.fill_value, 0.0
+        dm = fill_unknown_device(np.ma.getdata(x), mask, strategy, value, dtype, runtime)
+        keeps_mask = strategy in ('mean', 'const')
+        return dm, (mask if (mask is not None and keeps_mask) else None)
+
     def __contains__(self, obj_type):
         return obj_type == self.row_type or obj_type == self.col_type
 

@@ -186,6 +186,51 @@ def blockwise_completion():
     np.testing.assert_allclose(np.vstack(dev), want, rtol=1e-12, atol=1e-12)
 
 
+def device_fill_strategies():
+    """Relation.filled() on the device (skf_fill_unknown) against the reference outputs pinned in
+    tests/golden/fill_strategies.npz -- values to 1e-13 (the summation order of the means differs from NumPy's
+    pairwise sums), infinities and the survival of the mask exactly -- and inside Dfmf / Dfmc(device_fill=True)."""
+    import warnings
+    import skfusion_amd._native as nat
+    from helpers import golden
+    z = golden('fill_strategies.npz')
+    mem = nat.get_runtime().mem
+    for tag in ('masked', 'plain', 'finite'):
+        if tag == 'plain':
+            arr = z['plain'].copy()
+        else:
+            arr = np.ma.MaskedArray(z[tag + '_data'].copy(), mask=z[tag + '_mask'].copy())
+        for fv in ('mean', 'row_mean', 'col_mean', 0.5):
+            rel = Relation(arr, ObjectType('a'), ObjectType('b'), fill_value=fv)
+            for dtype, npd, tol in (('f64', np.float64, 1e-13), ('f32', np.float32, 1e-6)):
+                dm, mask = rel.filled_device(dtype)
+                got = mem.to_host(dm.buf, dm.shape, npd).astype(np.float64)
+                key = '%s/%s' % (tag, fv)
+                want = z[key + '/data']
+                fin = np.isfinite(want)
+                np.testing.assert_array_equal(np.isfinite(got), fin)
+                np.testing.assert_array_equal(got[~fin], want[~fin])              # +-inf exactly
+                np.testing.assert_allclose(got[fin], want[fin], rtol=tol, atol=0)
+                assert (mask is not None) == bool(z[key + '/is_masked'])
+                if mask is not None:
+                    np.testing.assert_array_equal(mask, z[key + '/mask'])
+    # inside a fit: the device-filled graph gives the factors of the host-filled one
+    rs = np.random.RandomState(8)
+    t1, t2, t3 = ObjectType('type1', 4), ObjectType('type2', 3), ObjectType('type3', 2)
+    A = rs.rand(30, 20)
+    A[rs.rand(30, 20) < 0.1] = np.nan
+    B = np.ma.masked_greater(rs.rand(30, 12), 0.8)
+    for cls in (Dfmf, Dfmc):
+        fits = []
+        for dev in (False, True):
+            g = FusionGraph([Relation(A.copy(), t1, t2, fill_value='row_mean'), Relation(B.copy(), t1, t3, fill_value=0.3)])
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                fits.append(cls(max_iter=5, init_type='random', random_state=4, device_fill=dev).fuse(g))
+        for t in (t1, t2, t3):
+            np.testing.assert_allclose(fits[1].factor(t), fits[0].factor(t), rtol=1e-10, atol=1e-12)
+
+
 def error_paths():
     t1, t2, t9 = ObjectType('type1', 2), ObjectType('type2', 2), ObjectType('nine', 2)
     rel = Relation(np.random.RandomState(0).rand(5, 3), t1, t2)

@@ -46,3 +46,7 @@ def test_pipeline_transform_chain_and_errors():
 @pytest.mark.parametrize('cls', [Dfmf, Dfmc])
 def test_n_jobs_concurrent_restarts(cls):
     A.n_jobs_concurrent_restarts_equal_sequential(cls)
+
+
+def test_fill_strategies_on_the_device():
+    A.device_fill_strategies()

@@ -57,3 +57,7 @@ def test_f32_engine_reaches_the_same_fixed_point():
 @pytest.mark.parametrize('cls', [Dfmf, Dfmc])
 def test_n_jobs_concurrent_restarts(cls):
     A.n_jobs_concurrent_restarts_equal_sequential(cls)
+
+
+def test_fill_strategies_on_the_device():
+    A.device_fill_strategies()
