@@ -95,7 +95,9 @@ def c5_graph(n, dtype, masked=0.98, lam=0.01):
             mask = (torch.rand((n[i], n[j]), generator=gen, device='cuda', dtype=torch.float32) < masked).to(torch.uint8)
             rels.append((i, j, wrap(data.contiguous()), wrap(mask.contiguous())))
         else:
-            rels.append((i, j, wrap((u < dens).to(tdt).contiguous()), None))
+            dm = wrap((u < dens).to(tdt).contiguous())
+            dm.binary = True                       # 0 / 1 relation: the bf16 engine keeps it as a bitmap (SKF_REL_BINARY)
+            rels.append((i, j, dm, None))
         del u
     nm = n['movie']
     gen.manual_seed(60)

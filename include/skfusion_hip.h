@@ -82,7 +82,12 @@ enum {
     SKF_REL_ABSENT = 1,       /* no local rows of this relation (its backbone / Q are still kept) */
     SKF_REL_NO_COL_SIDE = 2,  /* another process adds the column-side terms E_j, D_j of this relation */
     SKF_REL_MASKED = 4,       /* SKF_REL_ABSENT descriptors: the relation is masked where it lives */
-    SKF_REL_MASK_BITS = 8     /* `mask` is packed, one bit per entry (see skf_relation_desc.mask) */
+    SKF_REL_MASK_BITS = 8,    /* `mask` is packed, one bit per entry (see skf_relation_desc.mask) */
+    SKF_REL_BINARY = 16       /* every entry is 0 or 1 (checked at bind time; "movie has genre", "user tagged").
+                                 SKF_BF16 keeps such a relation as a BITMAP -- 1 bit instead of a bf16 per entry
+                                 in HBM and on the way to the matrix cores, where it is expanded to bf16 0 / 1 in
+                                 LDS: the same products as the dense form, bit for bit.  Ignored for masked
+                                 relations and by the f32 / f64 engines. */
 };
 
 typedef struct {
@@ -239,6 +244,14 @@ int skf_gemm_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, float
 int skf_gemm_bf16_tn(const void* A, int64_t lda, const void* Bt, int64_t ldb, float* C, int64_t ldc,
                      int32_t M, int32_t N, int32_t Kp, int32_t splits, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/* The same two contractions with a BINARY A operand stored as a bitmap (SKF_REL_BINARY): bit (c & 7) of byte
+ * A[r * lda_bytes + (c >> 3)] is entry (r, c), lda_bytes a multiple of 8, padding bits zero.
+ * transposed == 0: C[M x N] = A[M x Kp] * Bt^T (rows of the bitmap = output rows);
+ * transposed != 0: C[M x N] = A[Kp x M]^T * Bt^T (rows of the bitmap = the contraction index, zero rows up to Kp). */
+int skf_gemm_bits(const void* A, int64_t lda_bytes, const void* Bt, int64_t ldb, float* C, int64_t ldc,
+                  int32_t M, int32_t N, int32_t Kp, int32_t transposed, int32_t splits, void* workspace,
+                  size_t workspace_bytes, void* stream);
 
 /* dst (bf16, ld ldd) = round-to-nearest-even(src) or its transpose; src dtype SKF_F64 / SKF_F32 /
  * SKF_BF16.  Padding columns of dst are left untouched (zero them beforehand). */

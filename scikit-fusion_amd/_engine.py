@@ -15,12 +15,14 @@ class DeviceMatrix(object):
     """A row-major matrix that already lives in HBM (engine dtype), e.g. synthetic benchmark
     data generated on the device with ``fill_uniform``."""
 
-    def __init__(self, buf, shape, ld=None):
+    def __init__(self, buf, shape, ld=None, binary=False):
         self.buf, self.shape, self.ld = buf, tuple(shape), ld if ld is not None else shape[1]
+        self.binary = bool(binary)      # the caller's promise that every entry is 0 or 1 (SKF_REL_BINARY; checked at bind)
 
     def rows(self, begin, count, itemsize):
         """View of `count` rows from `begin` on (no copy; the parent buffer stays referenced)."""
-        return DeviceMatrix(_BufferView(self.buf, begin * self.ld * itemsize), (count, self.shape[1]), self.ld)
+        return DeviceMatrix(_BufferView(self.buf, begin * self.ld * itemsize), (count, self.shape[1]), self.ld,
+                            self.binary)
 
 
 class PackedMask(object):
@@ -184,10 +186,15 @@ class DevicePlan(object):
                     continue
             if isinstance(data, DeviceMatrix):
                 arr, buf, ld = data, data.buf, data.ld
+                if data.binary and mask is None and self.dtype == nat.SKF_BF16:
+                    rdesc[k].flags |= nat.SKF_REL_BINARY
             else:
                 arr = np.ascontiguousarray(data, dtype=self.np_dtype)
                 if arr.ndim != 2:
                     raise ValueError('relation %d is not a matrix' % k)
+                # SKF_BF16: a 0 / 1 relation is kept as a bitmap on the device (1/16 of the bytes per iteration)
+                if self.dtype == nat.SKF_BF16 and mask is None and arr.size and bool(((arr == 0) | (arr == 1)).all()):
+                    rdesc[k].flags |= nat.SKF_REL_BINARY
                 # SKF_BF16: relations are handed over as bf16 bit patterns
                 up = nat.to_bf16_bits(arr) if self.dtype == nat.SKF_BF16 else arr
                 buf, ld = mem.from_host(up), arr.shape[1]
@@ -401,7 +408,8 @@ def upload_graph(rel_list, theta_list, dtype, runtime=None):
         if not isinstance(data, DeviceMatrix):
             arr = np.ascontiguousarray(data, dtype=npd)
             up = nat.to_bf16_bits(arr) if code == nat.SKF_BF16 else arr
-            data = DeviceMatrix(rt.mem.from_host(up), arr.shape)
+            binary = code == nat.SKF_BF16 and mask is None and arr.size and bool(((arr == 0) | (arr == 1)).all())
+            data = DeviceMatrix(rt.mem.from_host(up), arr.shape, binary=binary)
         if mask is not None and not isinstance(mask, (DeviceMatrix, PackedMask)):
             mask = pack_mask(mask, rt.mem)
         rels.append((i, j, data, mask) + tuple(rel[4:]))

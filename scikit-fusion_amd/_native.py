@@ -15,7 +15,7 @@ import numpy as np
 SKF_F64, SKF_F32, SKF_BF16 = 0, 1, 2
 SKF_DFMF, SKF_DFMC, SKF_TRANSFORM = 0, 1, 2
 SKF_ENGINE_MFMA, SKF_ENGINE_VALU = 0, 1
-SKF_REL_ABSENT, SKF_REL_NO_COL_SIDE, SKF_REL_MASKED, SKF_REL_MASK_BITS = 1, 2, 4, 8
+SKF_REL_ABSENT, SKF_REL_NO_COL_SIDE, SKF_REL_MASKED, SKF_REL_MASK_BITS, SKF_REL_BINARY = 1, 2, 4, 8, 16
 SKF_STAGE_CONTRACT, SKF_STAGE_BACKBONE, SKF_STAGE_ACCUMULATE, SKF_STAGE_UPDATE = 0, 1, 2, 3
 SKF_X_W, SKF_X_Q, SKF_X_QM, SKF_X_ED = 0, 1, 2, 3
 
@@ -102,6 +102,8 @@ SIGNATURES = {
     'skf_gemm_bf16': (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                C.c_int32, _P, C.c_size_t, _P]),
     'skf_gemm_bf16_tn': (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_int32, _P, C.c_size_t, _P]),
+    'skf_gemm_bits': (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                C.c_int32, _P, C.c_size_t, _P]),
     'skf_to_bf16': (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _P]),
     'skf_pinv_sym_workspace_bytes': (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),

@@ -286,14 +286,16 @@ static void allow_dynamic_lds(std::once_flag& once, K kernel, int bytes) {
 // at == true: A is [Kp][lda] row-major with the OUTPUT rows along its columns (lda >= M, rows zero-padded to Kp)
 static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, int64_t ldb, float* C, int64_t ldc,
                           int M, int N, int Kp, int want_splits, void* part, size_t part_bytes, bool relation,
-                          hipStream_t st, bool at = false) {
+                          hipStream_t st, bool at = false, bool abits = false) {
     if (M <= 0 || N <= 0) return;
-    if (Kp % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || (!at && lda < Kp) || (at && lda < M) || ldb < Kp)
+    // abits: A is the bitmap of a binary relation, lda its row pitch in bytes (8 entries per byte)
+    const int64_t a_cols = abits ? lda * 8 : lda;
+    if (Kp % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || (!at && a_cols < Kp) || (at && a_cols < M) || ldb < Kp)
         SKF_FAIL(SKF_E_INVALID, "bf16 contraction: inner dimension must be padded to 64 (Kp=%d lda=%lld ldb=%lld)", Kp,
                  (long long)lda, (long long)ldb);
     if ((((uintptr_t)A) | ((uintptr_t)Bt)) & 15) SKF_FAIL(SKF_E_INVALID, "bf16 operands must be 16-byte aligned");
     const int bn = (N <= 128) ? 128 : 256;
-    const int bm = bf16_block_rows(M, at);
+    const int bm = bf16_block_rows(M, at || abits);
     const int ktiles = Kp / 64;
     const int64_t units = (int64_t)cdiv(M, bm) * cdiv(N, bn);
     int splits = want_splits > 0 ? want_splits : pick_splits_bf16(units, ktiles, bm);
@@ -319,7 +321,19 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
         allow_dynamic_lds(once_, gemm_bf16_v2_kernel<BN_, TAG_, AT_>, smem_);                                     \
         hipLaunchKernelGGL((gemm_bf16_v2_kernel<BN_, TAG_, AT_>), grid, dim3(512), smem_, st, g);                 \
     } while (0)
-        if (at) {
+#define SKF_V2_LAUNCH_BITS(BN_, AT_)                                                                              \
+    do {                                                                                                          \
+        const int smem_ = (3 * 256 + ((BN_ == 256) ? 2 : 3) * BN_) * 8 * 16;                                      \
+        static std::once_flag once_;                                                                              \
+        allow_dynamic_lds(once_, gemm_bf16_v2_kernel<BN_, 1, AT_, EPI_T_STORE, true>, smem_);                     \
+        hipLaunchKernelGGL((gemm_bf16_v2_kernel<BN_, 1, AT_, EPI_T_STORE, true>), grid, dim3(512), smem_, st, g); \
+    } while (0)
+        if (abits) {
+            if (at && bn == 128) SKF_V2_LAUNCH_BITS(128, true);
+            else if (at) SKF_V2_LAUNCH_BITS(256, true);
+            else if (bn == 128) SKF_V2_LAUNCH_BITS(128, false);
+            else SKF_V2_LAUNCH_BITS(256, false);
+        } else if (at) {
             if (bn == 128) SKF_V2_LAUNCH(128, 1, true);
             else SKF_V2_LAUNCH(256, 1, true);
         } else if (bn == 128 && relation) SKF_V2_LAUNCH(128, 1, false);
@@ -327,6 +341,7 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
         else if (relation) SKF_V2_LAUNCH(256, 1, false);
         else SKF_V2_LAUNCH(256, 0, false);
 #undef SKF_V2_LAUNCH
+#undef SKF_V2_LAUNCH_BITS
     } else {
         dim3 block(256);
         if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, 0>), grid, block, 0, st, g);
@@ -340,7 +355,7 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
     }
 }
 
-static size_t bf16_part_bytes(int M, int N, int Kp, bool at) {
+static size_t bf16_part_bytes(int M, int N, int Kp, bool at) {      // (a bitmap operand always takes the 256-row kernel)
     const int bn = (N <= 128) ? 128 : 256;
     const int bm = bf16_block_rows(M, at);
     const int s = pick_splits_bf16((int64_t)cdiv(M, bm) * cdiv(N, bn), Kp / 64, bm);
@@ -398,6 +413,9 @@ struct RelState {
     Slot Rb;                       // SKF_BF16: the ONE stored copy of the relation, bf16 [pad64(nr)][pad64(n_j)], zero padded
     int64_t ldrb = 0;
     int64_t kq = 0;                // pad64(nr): inner dimension of Q = R^T G_i (padding rows of Rb are zero)
+    bool binary = false;           // SKF_BF16 + SKF_REL_BINARY: the relation is stored as a bitmap (Bb) instead of Rb
+    Slot Bb;                       // bitmap [pad64(nr)][ldbb bytes], bit (c & 7) of byte c >> 3; padding zero
+    int64_t ldbb = 0;
     Slot Mb;                       // DFMC: the mask as packed bits, [nr][ldmb bytes], bit (n & 7) of byte n >> 3
     int64_t ldmb = 0;
     bool mask_is_bits = false;     // the caller's mask is already packed (SKF_REL_MASK_BITS)
@@ -539,7 +557,14 @@ static void relation_gemm(skf_plan* p, GemmArgs g, hipStream_t st, const RelStat
     if (p->bf16) {
         const TypeState& ti = p->types[r->row];
         const TypeState& tj = p->types[r->col];
-        if (!is_q)      // P = R G_j :  A = R (bf16), Bt = G_j^T (bf16)
+        if (r->binary) {        // the relation as a bitmap: 1/16 of the bytes, expanded to bf16 0 / 1 on the way into LDS
+            if (!is_q)
+                run_gemm_bf16((const uint16_t*)r->Bb.ptr, r->ldbb, (const uint16_t*)tj.GTb.ptr, tj.ldgt, (float*)g.C,
+                              g.ldc, g.M, g.N, (int)r->ldrb, 0, p->part.ptr, p->part_bytes, true, st, false, true);
+            else
+                run_gemm_bf16((const uint16_t*)r->Bb.ptr, r->ldbb, (const uint16_t*)ti.GTb.ptr + r->r0, ti.ldgt, (float*)g.C,
+                              g.ldc, g.M, g.N, (int)r->kq, 0, p->part.ptr, p->part_bytes, true, st, true, true);
+        } else if (!is_q)      // P = R G_j :  A = R (bf16), Bt = G_j^T (bf16)
             run_gemm_bf16((const uint16_t*)r->Rb.ptr, r->ldrb, (const uint16_t*)tj.GTb.ptr, tj.ldgt, (float*)g.C,
                           g.ldc, g.M, g.N, (int)r->ldrb, 0, p->part.ptr, p->part_bytes, true, st);
         else            // Q = R^T G_i :  A = the same row-major R read transposed out of LDS, Bt = G_i^T (bf16)
@@ -937,6 +962,7 @@ static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t
     g.M = nj; g.N = nr; g.Kp = (int)r.ldhb; g.k_chunk = (int)r.ldhb;
     g.a_kstep = 64; g.b_kstep = 64;
     g.R = (uint16_t*)r.Rb.ptr; g.ldr = r.ldrb;
+    if (r.binary) { g.Rbits = (const uint8_t*)r.Bb.ptr; g.ldrbits = r.ldbb; }
     g.mbits = (const uint8_t*)r.Mb.ptr; g.ldmb = r.ldmb;
     g.sq = (double*)p->sqpart.ptr;
     if (mode == MODE_COMPLETE && r.use_klist) {
@@ -1514,6 +1540,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             s.row = d.row_type; s.col = d.col_type;
             s.R_in = d.data; s.ld_in = d.ld; s.mask = d.mask; s.ldmask = d.mask_ld;
             s.mask_is_bits = (d.flags & SKF_REL_MASK_BITS) != 0;
+            s.binary = p->bf16 && (d.flags & SKF_REL_BINARY) != 0 && !d.mask && !absent;
             s.R = d.data; s.ldr = d.ld;
             s.absent = absent;
             s.r0 = absent ? 0 : d.row_begin;
@@ -1643,8 +1670,13 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             if (p->bf16) {
                 r.ldrb = pad64(tj.n);
                 r.kq = pad64(nr);
-                add_slot(p, r.Rb, (size_t)r.kq * r.ldrb * 2);
-                size_t b1 = bf16_part_bytes((int)nr, tj.c, (int)r.ldrb, false), b2 = bf16_part_bytes((int)tj.n, ti.c, (int)r.kq, true);
+                if (r.binary) {
+                    r.ldbb = r.ldrb / 8;
+                    add_slot(p, r.Bb, (size_t)r.kq * r.ldbb);
+                } else {
+                    add_slot(p, r.Rb, (size_t)r.kq * r.ldrb * 2);
+                }
+                size_t b1 = bf16_part_bytes((int)nr, tj.c, (int)r.ldrb, r.binary), b2 = bf16_part_bytes((int)tj.n, ti.c, (int)r.kq, true);
                 if (b1 > part_bytes) part_bytes = b1;
                 if (b2 > part_bytes) part_bytes = b2;
             }
@@ -1778,6 +1810,24 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             for (RelState& r : p->rels) {
                 if (r.absent) continue;
                 const int64_t rows = r.nr, cols = p->types[r.col].n;
+                if (r.binary) {
+                    int* bad = (int*)p->sqpart.ptr;                  // (scratch word; bind is not on the hot path)
+                    SKF_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
+                    hipLaunchKernelGGL(pack_binary_kernel, dim3(elem_grid(r.kq * r.ldbb)), dim3(256), 0, st, (uint8_t*)r.Bb.ptr,
+                                       r.ldbb, r.kq, (const uint16_t*)r.R_in, r.ld_in, rows, cols, bad);
+                    check_launch("pack_binary");
+                    int hbad = 0;
+                    SKF_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+                    SKF_HIP(hipStreamSynchronize(st));
+                    if (hbad) SKF_FAIL(SKF_E_INVALID, "a relation flagged SKF_REL_BINARY holds an entry that is neither 0 nor 1");
+                    if (r.Hb.bytes) {
+                        SKF_HIP(hipMemsetAsync(r.Hb.ptr, 0, r.Hb.bytes, st));
+                        SKF_HIP(hipMemsetAsync(r.Gb.ptr, 0, r.Gb.bytes, st));
+                    }
+                    r.R = r.Bb.ptr;
+                    r.ldr = r.ldrb;
+                    continue;
+                }
                 SKF_HIP(hipMemsetAsync(r.Rb.ptr, 0, r.Rb.bytes, st));
                 if (r.Hb.bytes) {
                     SKF_HIP(hipMemsetAsync(r.Hb.ptr, 0, r.Hb.bytes, st));
@@ -2137,6 +2187,15 @@ int skf_gemm_bf16_tn(const void* A, int64_t lda, const void* Bt, int64_t ldb, fl
         if (!A || !Bt || !C || M < 0 || N < 0 || Kp < 0 || ldc < N) SKF_FAIL(SKF_E_INVALID, "bad argument");
         run_gemm_bf16((const uint16_t*)A, lda, (const uint16_t*)Bt, ldb, C, ldc, M, N, Kp, splits, workspace,
                       workspace_bytes, false, as_stream(stream), true);
+    });
+}
+
+int skf_gemm_bits(const void* A, int64_t lda_bytes, const void* Bt, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
+                  int32_t Kp, int32_t transposed, int32_t splits, void* workspace, size_t workspace_bytes, void* stream) {
+    return guarded([&] {
+        if (!A || !Bt || !C || M < 0 || N < 0 || Kp < 0 || ldc < N) SKF_FAIL(SKF_E_INVALID, "bad argument");
+        run_gemm_bf16((const uint16_t*)A, lda_bytes, (const uint16_t*)Bt, ldb, C, ldc, M, N, Kp, splits, workspace,
+                      workspace_bytes, false, as_stream(stream), transposed != 0, true);
     });
 }
 

@@ -689,6 +689,9 @@ struct Bf16GemmArgs {
     // (m_loc * 256 + n_loc) | bf16 value << 16.  klist == nullptr: blend through the mask instead.
     const uint32_t* koff;
     const uint32_t* klist;
+    // EPI_T_SQERR of a binary relation stored as a bitmap (ABITS): bit (n & 7) of Rbits[m * ldrbits + (n >> 3)] = R[m][n]
+    const uint8_t* Rbits;
+    int64_t ldrbits;
 };
 // epilogue of gemm_bf16_v2_kernel: store the f32 tile | DFMC completion | squared residual
 enum { EPI_T_STORE = 0, EPI_T_COMPLETE = 1, EPI_T_SQERR = 2 };
@@ -872,7 +875,20 @@ __device__ __forceinline__ void lds_tr_wait(s16x4& a, s16x4& b, s16x4& c, s16x4&
 // swizzle key of a k row of the transposed A image (AT)
 __device__ __forceinline__ int at_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
-template <int BN, int TAG, bool AT, int EPI = EPI_T_STORE>
+// ABITS: the A operand is a BINARY relation stored as a bitmap (1 bit per entry instead of a bf16: 1/16 of the
+// bytes from HBM): g.A points at the bitmap, g.lda is its row pitch in BYTES (a multiple of 8); a row of the bitmap
+// is a row of the relation, bit (c & 7) of byte c >> 3.  Every thread fetches the 32 bits of its quarter row of the
+// NEXT-but-two tile into a register, and expands them into bf16 0 / 1 in the LDS image of the tile (the same swizzled
+// images as the LDS-DMA path, so fragment reads and MFMAs are unchanged) in the slots between the MFMA groups.
+__device__ __forceinline__ u32x4 bits_to_bf16x8(uint32_t byte) {
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        v[j] = ((byte >> (2 * j)) & 1u) * 0x3F80u | ((byte >> (2 * j + 1)) & 1u) * 0x3F800000u;
+    return v;
+}
+
+template <int BN, int TAG, bool AT, int EPI = EPI_T_STORE, bool ABITS = false>
 __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     static_assert(EPI == EPI_T_STORE || (BN == 256 && !AT), "the elementwise epilogues use the 256 x 256 P-form tile");
     constexpr int BM = 256, BK = 64;
@@ -883,7 +899,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     constexpr int ASZ = BM * 8, BSZ = BN * 8;                   // u32x4 entries per buffer
     constexpr int PWA = BM / 64, PWB = BN / 64;                 // LDS-DMA instructions per wave and K tile
     // instructions allowed to stay outstanding when the NEXT tile must be complete
-    constexpr int KEEP = (BST == 3) ? (PWA + PWB) : PWA;
+    constexpr int KEEP = ABITS ? ((BST == 3) ? PWB : 0) : ((BST == 3) ? (PWA + PWB) : PWA);
     HIP_DYNAMIC_SHARED(u32x4, smem)
 
     const int tid = threadIdx.x;
@@ -946,15 +962,57 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
         for (int p = 0; p < PWB; ++p) dma_B1(k0, buf, p);
     };
 
-    if (nkt > 0) {
-        dma_A(kz0, 0);
-        dma_B(kz0, 0);
-        if (nkt > 1) {
-            dma_A(kz0 + BK, 1);
-            if constexpr (BST == 3) dma_B(kz0 + BK, 1);
-            __builtin_amdgcn_s_waitcnt(0x0F70 | KEEP);    // tile 0 has landed
+    // ABITS: this thread's 32 bits of a tile -- P form: row tid >> 1, k half tid & 1; Q form: k row tid >> 3, 32 columns
+    const uint8_t* Abits = (const uint8_t*)g.A;
+    auto load_bits = [&](int k0) -> uint32_t {
+        if constexpr (AT) {
+            int64_t off = (int64_t)(bm0 >> 3) + 4 * (tid & 7);
+            if (off > g.lda - 4) off = g.lda - 4;
+            return *(const uint32_t*)(Abits + (int64_t)(k0 + (tid >> 3)) * g.lda + off);
         } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);
+            const int m = bm0 + (tid >> 1);
+            const int mc = m < g.M ? m : g.M - 1;
+            return *(const uint32_t*)(Abits + (int64_t)mc * g.lda + (k0 >> 3) + 4 * (tid & 1));
+        }
+    };
+    auto expand_bits = [&](uint32_t w, int buf, int q) {       // chunk q (8 entries) of the thread's 32
+        u32x4* Ad = smem + buf * ASZ;
+        const u32x4 v = bits_to_bf16x8((w >> (8 * q)) & 0xFFu);
+        if constexpr (AT) {
+            const int kr = tid >> 3, c = 4 * (tid & 7) + q;
+            Ad[kr * 32 + (c ^ (at_key(kr) << 1))] = v;
+        } else {
+            Ad[swz_chunk(tid >> 1, 4 * (tid & 1) + q)] = v;
+        }
+    };
+    uint32_t wnext = 0u;
+    if (nkt > 0) {
+        if constexpr (ABITS) {
+            uint32_t w = load_bits(kz0);
+            dma_B(kz0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) expand_bits(w, 0, q);
+            if (nkt > 1) {
+                w = load_bits(kz0 + BK);
+                if constexpr (BST == 3) dma_B(kz0 + BK, 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) expand_bits(w, 1, q);
+            }
+            if (nkt > 2) wnext = load_bits(kz0 + 2 * BK);
+            // tile 0 complete: its B pieces landed (only B(1) and the bits of tile 2 may still be in flight), every LDS write done
+            if (nkt > 2) __builtin_amdgcn_s_waitcnt(0x0070 | ((BST == 3 ? PWB : 0) + 1));
+            else if (nkt > 1) __builtin_amdgcn_s_waitcnt(0x0070 | (BST == 3 ? PWB : 0));
+            else __builtin_amdgcn_s_waitcnt(0x0070);
+        } else {
+            dma_A(kz0, 0);
+            dma_B(kz0, 0);
+            if (nkt > 1) {
+                dma_A(kz0 + BK, 1);
+                if constexpr (BST == 3) dma_B(kz0 + BK, 1);
+                __builtin_amdgcn_s_waitcnt(0x0F70 | KEEP);    // tile 0 has landed
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
         }
     }
     asm volatile("" ::: "memory");
@@ -969,6 +1027,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
         // BST == 2: every B piece of tile kt+1 goes out before the first A piece of tile kt+2
         auto piece = [&](int q) {
             if (q >= PWA + PWB) return;
+            if constexpr (ABITS) {
+                // A slots: one 16-byte chunk of tile kt+2 expanded per slot, then the bits of tile kt+3 are fetched;
+                // B slots as below (BST == 2: the B pieces of tile kt+1 first, so that the bits load is the newest)
+                const bool a_slot = (BST == 3) ? (q < PWA) : (q >= PWB);
+                const int qa = (BST == 3) ? q : q - PWB;
+                if (a_slot) {
+                    if (kt + 2 < nkt) expand_bits(wnext, (kt + 2) % 3, qa);
+                    if (qa == PWA - 1 && kt + 3 < nkt) wnext = load_bits(kz0 + (kt + 3) * BK);
+                } else if constexpr (BST == 3) {
+                    if (kt + 2 < nkt) dma_B1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q - PWA);
+                } else {
+                    if (more) dma_B1(kz0 + (kt + 1) * BK, (kt + 1) & 1, q);
+                }
+                return;
+            }
             if constexpr (BST == 3) {
                 if (kt + 2 < nkt) {
                     if (q < PWA) SKF_PROBE_A(dma_A1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q));
@@ -1034,8 +1107,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
         }
         // tile kt+1 must have landed; tile kt+2 (if it was issued) may stay in flight.
         // lgkmcnt(0): this wave's fragment reads of buffer `cur` are done before it is refilled.
-        if (kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0070 | KEEP);
-        else __builtin_amdgcn_s_waitcnt(0x0070);
+        if constexpr (ABITS) {
+            // allowed in flight: the B pieces of tile kt+2 (BST == 3) and the bits of tile kt+3
+            if (kt + 3 < nkt) __builtin_amdgcn_s_waitcnt(0x0070 | (KEEP + 1));
+            else if (kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0070 | KEEP);
+            else __builtin_amdgcn_s_waitcnt(0x0070);
+        } else {
+            if (kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0070 | KEEP);
+            else __builtin_amdgcn_s_waitcnt(0x0070);
+        }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1147,7 +1227,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                 const int m = row0 + r;
                 const int64_t col = (int64_t)col0 + c * 8;
                 u32x4 v = zero;
-                if (m < rel_rows && col + 8 <= g.ldr) v = *(const u32x4*)(g.R + (int64_t)m * g.ldr + col);
+                if (g.Rbits != nullptr) {
+                    if (m < rel_rows && (col >> 3) < g.ldrbits) v = bits_to_bf16x8(g.Rbits[(int64_t)m * g.ldrbits + (col >> 3)]);
+                } else if (m < rel_rows && col + 8 <= g.ldr) {
+                    v = *(const u32x4*)(g.R + (int64_t)m * g.ldr + col);
+                }
                 *(u32x4*)(T + r * TLD + c * 8) = v;
             }
             __syncthreads();
@@ -1362,6 +1446,31 @@ __global__ __launch_bounds__(256) void copy_mask_bits_kernel(uint8_t* __restrict
         if (left < 8) v &= (1u << left) - 1u;
         dst[r * ldmb + b] = (uint8_t)v;
     }
+}
+
+// A binary relation (every entry 0 or 1, e.g. "movie has genre") as a bitmap: bit (c & 7) of dst[r * ldb + (c >> 3)] =
+// (src[r][c] == 1); rows and bytes of the padding are zero.  *bad is set when an entry is neither 0 nor 1.
+__global__ __launch_bounds__(256) void pack_binary_kernel(uint8_t* __restrict__ dst, int64_t ldb, int64_t rows_pad,
+                                                          const uint16_t* __restrict__ src, int64_t lds,
+                                                          int64_t rows, int64_t cols, int* __restrict__ bad) {
+    const int64_t total = rows_pad * ldb;
+    int wrong = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / ldb, b = e % ldb;
+        uint32_t v = 0u;
+        if (r < rows) {
+            const uint16_t* p = src + r * lds + b * 8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (b * 8 + q < cols) {
+                    const uint16_t h = p[q];
+                    if (h == 0x3F80u) v |= 1u << q;
+                    else if (h != 0u && h != 0x8000u) wrong = 1;
+                }
+        }
+        dst[e] = (uint8_t)v;
+    }
+    if (wrong) *bad = 1;
 }
 
 // Known entries of a masked bf16 relation per 256 x 256 tile (the tile grid of gemm_bf16_v2_kernel<.., EPI_T_COMPLETE>:

@@ -198,6 +198,50 @@ def test_gemm_bf16_transposed_a(rt, shape):
         assert relerr(got, want) < 2e-6, splits
 
 
+def run_gemm_bits(rt, Rb, G, transposed, splits=0):
+    """Binary relation Rb (0 / 1) as a bitmap through skf_gemm_bits: P = Rb @ G (transposed=0, Rb is M x K) or
+    Q = Rb^T @ G (transposed=1, Rb is K x M)."""
+    rows, cols = Rb.shape
+    ldb_bytes = (cols + 63) // 64 * 8
+    rows_pad = (rows + 63) // 64 * 64
+    bits = np.zeros((rows_pad, ldb_bytes), np.uint8)
+    bits[:rows, :(cols + 7) // 8] = np.packbits(Rb.astype(bool), axis=1, bitorder='little')
+    if transposed:
+        K, M = rows, cols
+        Kp = rows_pad
+    else:
+        M, K = rows, cols
+        Kp = ldb_bytes * 8
+    N = G.shape[1]
+    Gt = np.zeros((N, Kp), np.uint16)
+    Gt[:, :K] = nat.to_bf16_bits(G.T)
+    a, b = rt.mem.from_host(bits), rt.mem.from_host(Gt)
+    c = rt.mem.empty(M * N * 4)
+    ws = rt.mem.empty(40 * M * N * 4 + 256)
+    rt.call('skf_gemm_bits', a.ptr, ldb_bytes, b.ptr, Kp, c.ptr, N, M, N, Kp, 1 if transposed else 0, splits,
+            ws.ptr, ws.nbytes, None)
+    got = rt.mem.to_host(c, (M, N), np.float32)
+    Gr = nat.from_bf16_bits(Gt[:, :K]).astype(np.float64).T
+    want = (Rb.T if transposed else Rb).astype(np.float64) @ Gr
+    return got, want
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1), (70, 100, 130), (128, 200, 257), (256, 129, 100), (200, 500, 200),
+                                   (300, 64, 129), (100, 300, 520)])
+@pytest.mark.parametrize('transposed', [0, 1])
+def test_gemm_bits_binary_relation_as_a_bitmap(rt, shape, transposed):
+    """A 0 / 1 relation stored as one bit per entry, expanded to bf16 in LDS between the MFMA groups: both
+    contractions (rows of the bitmap as output rows, or as the contraction index with transposed fragment
+    reads), N <= 128 and N > 128 (3- and 2-deep G^T rings), tails everywhere, split-K."""
+    N, rows, cols = shape
+    rs = np.random.RandomState(rows + cols + N + transposed)
+    Rb = (rs.rand(rows, cols) < 0.3).astype(np.float64)
+    G = rs.randn(rows if transposed else cols, N)
+    for splits in (0, 1, 2):
+        got, want = run_gemm_bits(rt, Rb, G, transposed, splits)
+        assert relerr(got, want) < 2e-6, splits
+
+
 def test_to_bf16_and_transpose(rt):
     rs = np.random.RandomState(2)
     X = rs.randn(70, 45)

@@ -91,6 +91,18 @@ def test_gemm_bf16_transposed_a(rt, shape):
     K.test_gemm_bf16_transposed_a(rt, shape)
 
 
+@pytest.mark.parametrize('shape', [(1, 1, 1), (70, 100, 130), (128, 200, 257), (256, 129, 100), (300, 64, 129),
+                                   (100, 300, 520), (256, 3000, 10000), (128, 6000, 4097)])
+@pytest.mark.parametrize('transposed', [0, 1])
+def test_gemm_bits_binary_relation_as_a_bitmap(rt, shape, transposed):
+    K.test_gemm_bits_binary_relation_as_a_bitmap(rt, shape, transposed)
+
+
+def test_binary_relations_as_bitmaps_in_the_engine():
+    import test_emul_engine as E
+    E.test_binary_relations_as_bitmaps_give_the_dense_results_bit_for_bit()
+
+
 def test_to_bf16(rt):
     K.test_to_bf16_and_transpose(rt)
 
