@@ -379,6 +379,35 @@ static void launch_to_bf16(uint16_t* dst, int64_t ldd, const TS* src, int64_t ld
 // ------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------
+// Test / A-B switches from the environment.  A plan reads them ONCE, when its workspace is bound (skf::Switches::read);
+// no launch path calls getenv.  Defaults are the measured best.
+struct Switches {
+    bool pinv_jacobi = false;      // SKF_PINV_JACOBI=1     every pseudo-inverse through the Jacobi eigen-solver
+    bool chol_unblocked = false;   // SKF_CHOL_UNBLOCKED=1  plain (unblocked) Cholesky inverse
+    bool chol_no_small = false;    // SKF_CHOL_NO_SMALL=1   no one-wave kernel for orders <= 64
+    bool no_small_chain = false;   // SKF_NO_SMALL_CHAIN=1  general c x c launches instead of the one-workgroup chains
+    bool debug_pinv = false;       // SKF_DEBUG_PINV=1      per iteration: verdict of the fast path (stderr; synchronises)
+    bool graph = false;            // SKF_GRAPH=1           hipGraph replay of the iteration
+    bool no_overlap = false;       // SKF_NO_OVERLAP=1      no second stream
+    bool no_pipeline = false;      // SKF_NO_PIPELINE=1     staged schedule instead of the relation pipeline
+    int side_tile = 0;             // SKF_SIDE_TILE=64|128  tile shape of the fused side update
+    static Switches read() {
+        auto on = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
+        Switches w;
+        w.pinv_jacobi = on("SKF_PINV_JACOBI");
+        w.chol_unblocked = on("SKF_CHOL_UNBLOCKED");
+        w.chol_no_small = on("SKF_CHOL_NO_SMALL");
+        w.no_small_chain = on("SKF_NO_SMALL_CHAIN");
+        w.debug_pinv = on("SKF_DEBUG_PINV");
+        w.graph = on("SKF_GRAPH");
+        w.no_overlap = on("SKF_NO_OVERLAP");
+        w.no_pipeline = on("SKF_NO_PIPELINE");
+        const char* st = getenv("SKF_SIDE_TILE");
+        w.side_tile = st ? atoi(st) : 0;
+        return w;
+    }
+};
+
 struct Slot {            // a workspace sub-allocation
     size_t off = 0, bytes = 0;
     void* ptr = nullptr;
@@ -465,6 +494,7 @@ struct skf_plan {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     skf::Slot part_aux;
     size_t part_aux_bytes = 0;
+    skf::Switches sw;                      // read once in skf_plan_bind_workspace
     bool overlap = false;
     bool pipeline = true;                  // relation-pipelined schedule of the DFMF iteration (SKF_NO_PIPELINE=1 at bind: off)
     std::vector<hipEvent_t> ev_rel;        // one event per relation: its contractions are done
@@ -586,29 +616,17 @@ static void refresh_gt(skf_plan* p, TypeState& t, hipStream_t st) {
     launch_to_bf16<float>((uint16_t*)t.GTb.ptr, t.ldgt, (const float*)t.G.ptr, (int64_t)t.c, t.n, (int64_t)t.c, true, st);
 }
 
-// Relative pivot threshold of the Cholesky fast path: below it the Gram matrix goes to the
-// eigen-solver, which applies the exact singular-value cut-off.  SKF_PINV_JACOBI=1 forces the
-// eigen path (tests).
-static double chol_rel_threshold() {
-    const char* f = getenv("SKF_PINV_JACOBI");
-    if (f && atoi(f) != 0) return 1e300;
-    return 1e-8;
-}
-
-// lower edge of the deflation's gap test; SKF_PINV_JACOBI=1 (tests) disables the deflation as well
-static double deflation_lo() {
-    const char* f = getenv("SKF_PINV_JACOBI");
-    if (f && atoi(f) != 0) return 1e300;
-    return 1e-10;
-}
+// Relative pivot threshold of the Cholesky fast path: below it the Gram matrix goes to the deflation / the
+// eigen-solver.  SKF_PINV_JACOBI=1 forces the eigen path with its exact singular-value cut-off (tests).
+static double chol_rel_threshold(const Switches& sw) { return sw.pinv_jacobi ? 1e300 : 1e-8; }
+// lower edge of the deflation's gap test
+static double deflation_lo(const Switches& sw) { return sw.pinv_jacobi ? 1e300 : 1e-10; }
 
 // Cholesky fast path: the LDS-blocked kernel up to order CHOLB_MAXN, the plain one beyond
-static void launch_chol(const EighArgs& e, int batch, int max_order, hipStream_t st) {
-    const char* f = getenv("SKF_CHOL_UNBLOCKED");
-    const char* nos = getenv("SKF_CHOL_NO_SMALL");          // "1": skip the one-wave kernel (A/B runs, tests)
-    if (max_order <= CHOLS_MAXN && !(nos && atoi(nos) != 0) && !(f && atoi(f) != 0)) {
-        hipLaunchKernelGGL(chol_inverse_small_kernel, dim3((unsigned)batch), dim3(64), 0, st, e, chol_rel_threshold());
-    } else if (max_order <= CHOLB_MAXN && !(f && atoi(f) != 0)) {
+static void launch_chol(const Switches& sw, const EighArgs& e, int batch, int max_order, hipStream_t st) {
+    if (max_order <= CHOLS_MAXN && !sw.chol_no_small && !sw.chol_unblocked) {
+        hipLaunchKernelGGL(chol_inverse_small_kernel, dim3((unsigned)batch), dim3(64), 0, st, e, chol_rel_threshold(sw));
+    } else if (max_order <= CHOLB_MAXN && !sw.chol_unblocked) {
         size_t wave_tiles = (size_t)(EIGH_THREADS / 64) * CHOLB_NB * (CHOLB_NB + 1);
         size_t panel = (size_t)CHOLB_NB * max_order;
         size_t smem = ((size_t)CHOLB_NB * (CHOLB_NB + 1) + (panel > wave_tiles ? panel : wave_tiles)) * sizeof(double);
@@ -616,9 +634,9 @@ static void launch_chol(const EighArgs& e, int batch, int max_order, hipStream_t
         allow_dynamic_lds(once, chol_inverse_blocked_kernel,
                           (int)(((size_t)CHOLB_NB * (CHOLB_NB + 1) + (size_t)CHOLB_NB * CHOLB_MAXN) * sizeof(double)));
         hipLaunchKernelGGL(chol_inverse_blocked_kernel, dim3((unsigned)batch), dim3(EIGH_THREADS), smem, st, e,
-                           chol_rel_threshold());
+                           chol_rel_threshold(sw));
     } else {
-        hipLaunchKernelGGL(chol_inverse_kernel, dim3((unsigned)batch), dim3(EIGH_THREADS), 0, st, e, chol_rel_threshold());
+        hipLaunchKernelGGL(chol_inverse_kernel, dim3((unsigned)batch), dim3(EIGH_THREADS), 0, st, e, chol_rel_threshold(sw));
     }
     check_launch("chol_inverse");
 }
@@ -663,7 +681,7 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
     e.max_sweeps = 30;
     // fast path (Cholesky inverse) with an on-device verdict; the Jacobi eigen-solver only does
     // work for the matrices the fast path rejected -- no host round trip either way
-    launch_chol(e, nb, p->eig_maxn, st);
+    launch_chol(p->sw, e, nb, p->eig_maxn, st);
     if (batched) {
         hipLaunchKernelGGL(chol_unpack_batched_kernel, dim3(elem_grid((int64_t)max_c * max_c), nb), dim3(256), 0, st, pb,
                            (const double*)p->eigV.ptr, stride, (const int*)p->eigOk.ptr);
@@ -683,7 +701,7 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
         static std::once_flag once;
         allow_dynamic_lds(once, pchol_pinv_kernel, PCHOL_LDS_BYTES);
     }
-    hipLaunchKernelGGL(pchol_pinv_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), PCHOL_LDS_BYTES, st, e, deflation_lo(), 1e-7);
+    hipLaunchKernelGGL(pchol_pinv_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), PCHOL_LDS_BYTES, st, e, deflation_lo(p->sw), 1e-7);
     check_launch("pchol_pinv");
     hipLaunchKernelGGL(jacobi_eigh_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), 0, st, e);
     check_launch("jacobi_eigh");
@@ -798,10 +816,7 @@ static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const v
             hipLaunchKernelGGL((side_update_kernel<double, double, 1, 1, 16>), grid, block, 0, st, a);
         }
     } else {
-        const char* fe = getenv("SKF_SIDE_TILE");           // 64 / 128 force a tile shape (A/B runs, tests)
-        const int force = fe ? atoi(fe) : 0;
-        const char* be = getenv("SKF_SIDE_BK");             // 32: deeper K tile for the 64 x 64 kernels
-        const bool bk32 = be && atoi(be) == 32;
+        const int force = p->sw.side_tile;                   // 64 / 128 force a tile shape (A/B runs, tests)
         // the two operand layouts of the iteration with everything 16-byte aligned get kernels whose
         // staging modes are compile-time constants (SKF_SIDE_FM); anything else the generic one
         auto al = [](const void* q) { return q == nullptr || (((uintptr_t)q) & 15) == 0; };
@@ -823,11 +838,7 @@ static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const v
                 hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16>), grid, block, 0, st, a);
         } else {
             dim3 grid(cdiv(t.c, 64), cdiv(n, 64));
-            if (vec && k_major && n > 64 && t.c >= 64 && bk32)
-                hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 32, FM_K>), grid, block, 0, st, a);
-            else if (vec && n > 64 && t.c >= 64 && bk32)
-                hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 32, FM_R>), grid, block, 0, st, a);
-            else if (vec && k_major && n > 64 && t.c >= 64)
+            if (vec && k_major && n > 64 && t.c >= 64)
                 hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 16, FM_K>), grid, block, 0, st, a);
             else if (vec && n > 64 && t.c >= 64)
                 hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 16, FM_R>), grid, block, 0, st, a);
@@ -888,27 +899,20 @@ static void stage_contract(skf_plan* p, hipStream_t st) {
     // The Gram products use the whole chip and stay on the main stream; the pseudo-inverses are
     // three single-workgroup kernels with a long serial chain: they go to the second stream and
     // run underneath the relation contractions.
-    // SKF_GRAM_AUX=1 (experiment): the Gram products go to the second stream too, next to the first
-    // contraction (which leaves CUs idle when its row tiles do not fill the chip)
-    const char* ga = getenv("SKF_GRAM_AUX");
-    const bool gram_aux = p->overlap && ga && atoi(ga) != 0;
+    // (Round 1 / 2 A-B: with the Gram products on the second stream as well the contractions slow down by what those
+    // kernels take -- profiles/r02_pipeline_ab.txt.)
     hipStream_t sa = st;
-    if (p->overlap && gram_aux) {
-        SKF_HIP(hipEventRecord(p->ev_fork, st));
-        SKF_HIP(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
-        sa = p->aux;
-    }
     for (size_t i = 0; i < p->types.size(); ++i) {
-        gram(p, p->types[i], 1, gram_aux ? sa : st, gram_aux);
+        gram(p, p->types[i], 1, st);
         all.push_back((int)i);
     }
-    if (p->overlap && !gram_aux) {
+    if (p->overlap) {
         SKF_HIP(hipEventRecord(p->ev_fork, st));
         SKF_HIP(hipStreamWaitEvent(p->aux, p->ev_fork, 0));
         sa = p->aux;
     }
     plan_pinv(p, all, sa);
-    if (const char* dbg = getenv("SKF_DEBUG_PINV"); dbg && atoi(dbg) != 0) {
+    if (p->sw.debug_pinv) {
         // diagnostics: verdict of the Cholesky fast path and the diagonal range of every Gram matrix
         SKF_HIP(hipStreamSynchronize(sa));
         std::vector<int> ok(p->types.size());
@@ -986,8 +990,7 @@ static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t
 // Stage 2 (SKF_STAGE_BACKBONE): S = K_i W K_j; DFMC: completion, then P and Q of masked relations.
 // every rank <= SMALLC: the c x c chains run in the one-workgroup kernels (SKF_NO_SMALL_CHAIN=1: off)
 static bool small_chain(const skf_plan* p) {
-    const char* off = getenv("SKF_NO_SMALL_CHAIN");
-    if (off && atoi(off) != 0) return false;
+    if (p->sw.no_small_chain) return false;
     for (const TypeState& t : p->types)
         if (t.c > SMALLC) return false;
     return true;
@@ -1363,8 +1366,7 @@ static bool use_graph(skf_plan* p, hipStream_t st, int n_iters) {
     if (st == nullptr || p->profiling || p->graph_failed || n_iters < 4) return false;
     // opt-in (SKF_GRAPH=1): measured on dicty (50 launches / 0.5 ms iteration) the replay is not
     // faster than the asynchronous eager launches -- the iteration is bound by kernel time
-    const char* on = getenv("SKF_GRAPH");
-    return p->graph_on || (on && atoi(on) != 0);
+    return p->graph_on || p->sw.graph;
 }
 
 // Record one iteration into a hipGraph (the second-stream fork/join becomes graph edges).
@@ -1756,6 +1758,7 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
         if (((uintptr_t)ws & 255) != 0) SKF_FAIL(SKF_E_WORKSPACE, "workspace must be 256-byte aligned");
         for (Slot* s : p->slots) s->ptr = (char*)ws + s->off;
         p->ws_base = ws;
+        p->sw = Switches::read();          // the only place a plan looks at the environment
         hipStream_t st = as_stream(stream);
         for (RelState& r : p->rels) {
             if (!r.mask) continue;
@@ -1883,11 +1886,9 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             SKF_HIP(hipMemcpyAsync(p->eigNorig.ptr, n_orig.data(), n_orig.size() * sizeof(int), hipMemcpyHostToDevice, st));
             SKF_HIP(hipStreamSynchronize(st));     // the host vectors die here; bind is not on the hot path
         }
+        p->pipeline = !p->sw.no_pipeline;
         if (p->variant != SKF_TRANSFORM && !p->aux) {
-            const char* no = getenv("SKF_NO_OVERLAP");
-            if (!(no && atoi(no) != 0)) {
-                const char* np = getenv("SKF_NO_PIPELINE");       // A/B runs and tests: the staged schedule
-                p->pipeline = !(np && atoi(np) != 0);
+            if (!p->sw.no_overlap) {
                 SKF_HIP(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
                 SKF_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
                 SKF_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
@@ -2253,7 +2254,8 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
         e.A = eA; e.V = eV; e.Vs = eVs; e.w = eW; e.stride = (int64_t)np * np; e.wstride = np;
         e.n = eN; e.n_orig = eNo; e.chol_ok = eOk; e.max_sweeps = 30;
         const int tot2 = n * n;
-        launch_chol(e, 1, np, st);
+        const Switches sw = Switches::read();          // stand-alone operator: no plan to hold them
+        launch_chol(sw, e, 1, np, st);
         if (dtype == SKF_F64)
             hipLaunchKernelGGL((chol_unpack_kernel<double>), dim3(elem_grid(tot2)), dim3(256), 0, st, (double*)K, ldk,
                                eV, np, n, eOk);
@@ -2265,7 +2267,7 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
             static std::once_flag once;
             allow_dynamic_lds(once, pchol_pinv_kernel, PCHOL_LDS_BYTES);
         }
-        hipLaunchKernelGGL(pchol_pinv_kernel, dim3(1), dim3(EIGH_THREADS), PCHOL_LDS_BYTES, st, e, deflation_lo(), 1e-7);
+        hipLaunchKernelGGL(pchol_pinv_kernel, dim3(1), dim3(EIGH_THREADS), PCHOL_LDS_BYTES, st, e, deflation_lo(sw), 1e-7);
         check_launch("pchol_pinv");
         hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, e);
         check_launch("jacobi_eigh");
