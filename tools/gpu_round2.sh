@@ -21,6 +21,15 @@ case "$step" in
     dt=${step#bench_}
     ( time timeout 900 python bench.py --dtype $dt --steps 20 --warmup 3 --no-cpu-baseline ) > "$OUT/bench_$dt.log" 2>&1
     echo "bench $dt exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/bench_$dt.log" | cut -c1-600 | tee -a "$OUT/summary.txt" ;;
+  dist_smoke)
+    # `bench.py --gpus 2` launches itself (torch.distributed.run, one rank per GPU); on this one-GPU box the two
+    # ranks share GPU 0 over a gloo group: all three multi-GPU modes end to end
+    for mode in restarts relations rows; do
+      ( SKF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --scale 0.2 --mode $mode --no-cpu-baseline --no-engines ) > "$OUT/dist_$mode.log" 2>&1
+      echo "dist $mode exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/dist_$mode.log" | cut -c1-260 | tee -a "$OUT/summary.txt"
+    done
+    ( SKF_BENCH_BACKEND=gloo timeout 600 python bench.py --workload c5 --gpus 2 --steps 2 --warmup 1 --scale 0.1 --mode rows --no-cpu-baseline ) > "$OUT/dist_c5_rows.log" 2>&1
+    echo "dist c5 rows exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/dist_c5_rows.log" | cut -c1-260 | tee -a "$OUT/summary.txt" ;;
   fullbench)
     ( time timeout 1200 python bench.py ) > "$OUT/bench_full.log" 2>&1
     echo "bench exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/bench_full.log" | tee -a "$OUT/summary.txt" ;;
