@@ -701,7 +701,12 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
         static std::once_flag once;
         allow_dynamic_lds(once, pchol_pinv_kernel, PCHOL_LDS_BYTES);
     }
-    hipLaunchKernelGGL(pchol_pinv_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), PCHOL_LDS_BYTES, st, e, deflation_lo(p->sw), 1e-7);
+    {   // dynamic LDS for the packed factor of L^T L, sized by the largest order of this plan (a no-op launch still has
+        // to find a CU with that much LDS free, so small graphs reserve little)
+        const int lr = p->eig_maxn < PCHOL_LDS_R ? p->eig_maxn : PCHOL_LDS_R;
+        hipLaunchKernelGGL(pchol_pinv_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), (size_t)lr * (lr + 1) / 2 * 8, st, e,
+                           deflation_lo(p->sw), 1e-7, lr);
+    }
     check_launch("pchol_pinv");
     hipLaunchKernelGGL(jacobi_eigh_kernel, dim3((unsigned)which.size()), dim3(EIGH_THREADS), 0, st, e);
     check_launch("jacobi_eigh");
@@ -2267,7 +2272,8 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
             static std::once_flag once;
             allow_dynamic_lds(once, pchol_pinv_kernel, PCHOL_LDS_BYTES);
         }
-        hipLaunchKernelGGL(pchol_pinv_kernel, dim3(1), dim3(EIGH_THREADS), PCHOL_LDS_BYTES, st, e, deflation_lo(sw), 1e-7);
+        const int lr = np < PCHOL_LDS_R ? np : PCHOL_LDS_R;
+        hipLaunchKernelGGL(pchol_pinv_kernel, dim3(1), dim3(EIGH_THREADS), (size_t)lr * (lr + 1) / 2 * 8, st, e, deflation_lo(sw), 1e-7, lr);
         check_launch("pchol_pinv");
         hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, e);
         check_launch("jacobi_eigh");

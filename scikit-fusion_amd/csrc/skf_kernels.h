@@ -2200,7 +2200,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_blocked_kernel(Eigh
 // ------------------------------------------------------------------------------------------
 constexpr int PCHOL_LDS_R = 176;           // packed r (r + 1) / 2 doubles of the small factor fit the dynamic LDS up to this rank
 constexpr int PCHOL_LDS_BYTES = PCHOL_LDS_R * (PCHOL_LDS_R + 1) / 2 * 8;
-__global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, double lo, double hi) {
+__global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, double lo, double hi, int lds_rank) {
     __shared__ double d[EIGH_MAXN];            // remaining diagonal; < 0: the index has been a pivot
     __shared__ double rowk[EIGH_MAXN];         // row of L of the current pivot (its first k entries)
     __shared__ double red_v[EIGH_THREADS / 64];
@@ -2277,7 +2277,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, do
     // (r <= PCHOL_LDS_R), else in the Vs scratch.  One wave per element: the lanes split the rows (coalesced) and meet
     // in a wave reduction.
     HIP_DYNAMIC_SHARED(double, Cs)
-    const bool in_lds = r <= PCHOL_LDS_R;
+    const bool in_lds = r <= lds_rank;          // the launch reserved lds_rank (lds_rank + 1) / 2 doubles of dynamic LDS
     double* Cp = in_lds ? Cs : W;
     const int nel = r * (r + 1) / 2;
     for (int el = wave; el < nel; el += EIGH_THREADS / 64) {
