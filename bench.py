@@ -113,6 +113,8 @@ def c5_graph(n, dtype, masked=0.98, lam=0.01):
     eye = torch.zeros((nm, nm), device='cuda', dtype=mdt)
     eye.fill_diagonal_(lam)
     thetas = [('movie', wrap(eye)), ('movie', wrap(sim.contiguous()))]
+    thetas[0][1].nnz = nm                                     # sparse constraints: the engine keeps them as CSR
+    thetas[1][1].nnz = int((sim != 0).sum().item())
     torch.cuda.synchronize()
     return rels, thetas
 

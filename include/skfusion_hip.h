@@ -92,8 +92,13 @@ enum {
 
 typedef struct {
     int32_t type;     /* constrained object type (Theta[(i,i)][t], dfmf.py:82-85) */
-    const void* data; /* n_i x n_i, engine dtype */
+    const void* data; /* n_i x n_i, engine dtype (SKF_BF16: f32), dense row-major */
     int64_t ld;
+    int64_t nnz;      /* 0: multiply it as a dense matrix, as the reference does (_dfmf.py:284-292).  > 0: an upper
+                         bound on its non-zero entries -- the engine then keeps the constraint as CSR (built on the
+                         device at bind time, `data` is not referenced afterwards) and D_i += Theta+ G_i,
+                         E_i += Theta- G_i become ONE sparse pass in the master precision.  Accepted up to
+                         n_i * n_i / 16; a bound that turns out too small is an error at bind time. */
 } skf_theta_desc;
 
 typedef struct {

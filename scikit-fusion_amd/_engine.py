@@ -18,6 +18,7 @@ class DeviceMatrix(object):
     def __init__(self, buf, shape, ld=None, binary=False):
         self.buf, self.shape, self.ld = buf, tuple(shape), ld if ld is not None else shape[1]
         self.binary = bool(binary)      # the caller's promise that every entry is 0 or 1 (SKF_REL_BINARY; checked at bind)
+        self.nnz = 0                    # constraints: an upper bound on the non-zero entries (0 = unknown / dense)
 
     def rows(self, begin, count, itemsize):
         """View of `count` rows from `begin` on (no copy; the parent buffer stays referenced)."""
@@ -62,6 +63,13 @@ def fill_uniform(shape, seed, dtype='f32', scale=1.0, shift=0.0, runtime=None):
     rt.call('skf_fill_uniform', code, buf.ptr, shape[0], shape[1], shape[1], int(seed),
             float(scale), float(shift), rt.mem.stream)
     return DeviceMatrix(buf, shape)
+
+
+def _sparse_bound(nnz, n):
+    """skf_theta_desc.nnz for a constraint with `nnz` non-zeros: the count itself when the matrix is sparse enough for
+    the CSR path (<= n*n/16), 0 (dense product, as the reference) otherwise or when unknown."""
+    nnz = int(nnz or 0)
+    return max(nnz, 1) if 0 < nnz <= (int(n) * int(n)) // 16 else 0
 
 
 _FILL = {'mean': 0, 'row_mean': 1, 'col_mean': 2, 'const': 3}
@@ -228,6 +236,7 @@ class DevicePlan(object):
                     raise ValueError('constraint on %s dimension mismatch' % (t,))
                 self._keep.append(data.buf)
                 hdesc[k].type, hdesc[k].data, hdesc[k].ld = self.index[t], data.buf.ptr, data.ld
+                hdesc[k].nnz = _sparse_bound(getattr(data, 'nnz', 0), n_obj[t])
                 continue
             arr = np.ascontiguousarray(data, dtype=self.np_dtype)
             if arr.shape != (n_obj[t], n_obj[t]):
@@ -235,6 +244,8 @@ class DevicePlan(object):
             buf = mem.from_host(arr)
             self._keep.append(buf)
             hdesc[k].type, hdesc[k].data, hdesc[k].ld = self.index[t], buf.ptr, arr.shape[1]
+            # a sparse constraint (lambda I, a few must-link pairs per object, dicty's ppi) is kept as CSR on the device
+            hdesc[k].nnz = _sparse_bound(int(np.count_nonzero(arr)), n_obj[t])
         opt = nat.Options(self.dtype, variant, self.index[target] if target is not None else -1,
                           nat.SKF_ENGINE_MFMA if engine is None else engine,
                           part[0] if part else 0, part[1] if part else 0)

@@ -56,7 +56,7 @@ class RelationDesc(C.Structure):
 
 
 class ThetaDesc(C.Structure):
-    _fields_ = [('type', C.c_int32), ('data', C.c_void_p), ('ld', C.c_int64)]
+    _fields_ = [('type', C.c_int32), ('data', C.c_void_p), ('ld', C.c_int64), ('nnz', C.c_int64)]
 
 
 class Options(C.Structure):

@@ -466,6 +466,10 @@ struct ThetaState {
     bool has_pos = true, has_neg = true;   // non-empty halves of the +- split (found at bind time)
     Slot Pb, Nb;                           // SKF_BF16: bf16 copies of Theta+ / Theta-, [n][pad64(n)]
     int64_t ldb = 0;
+    // sparse form (skf_theta_desc.nnz > 0): CSR in the master type, built at bind time
+    bool sparse = false;
+    int64_t nnz_cap = 0, nnz = 0;
+    Slot Rp, Ci, Vv, Cnt;                  // rowptr (n + 1, int64), column indices (int32), values, per-row counts
 };
 
 }  // namespace skf
@@ -749,6 +753,20 @@ static void theta_terms(skf_plan* p, hipStream_t st) {
     for (ThetaState& th : p->thetas) {
         TypeState& t = p->types[th.type];
         // D += Theta+ G   (_dfmf.py:285-288);  E += Theta- G   (:289-292); an all-zero half is skipped
+        if (th.sparse) {    // both halves in one pass over the CSR form, master precision
+            if (th.nnz == 0) continue;
+            const int grid = (int)((t.n + 3) / 4 < 2048 ? (t.n + 3) / 4 : 2048);
+            if (p->f64)
+                hipLaunchKernelGGL((theta_spmm_kernel<double>), dim3(grid), dim3(256), 0, st, (const int64_t*)th.Rp.ptr,
+                                   (const int*)th.Ci.ptr, (const double*)th.Vv.ptr, (const double*)t.G.ptr, (double*)t.E.ptr,
+                                   (double*)t.D.ptr, t.n, t.c);
+            else
+                hipLaunchKernelGGL((theta_spmm_kernel<float>), dim3(grid), dim3(256), 0, st, (const int64_t*)th.Rp.ptr,
+                                   (const int*)th.Ci.ptr, (const float*)th.Vv.ptr, (const float*)t.G.ptr, (float*)t.E.ptr,
+                                   (float*)t.D.ptr, t.n, t.c);
+            check_launch("theta_spmm");
+            continue;
+        }
         if (p->bf16) {      // bf16 copies of the halves against the stored G^T, f32 accumulate, then added
             for (int half = 0; half < 2; ++half) {
                 if (!(half == 0 ? th.has_pos : th.has_neg)) continue;
@@ -1244,7 +1262,9 @@ static void apply_update(skf_plan* p, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 static bool can_pipeline(const skf_plan* p) {
     if (!p->overlap || p->sliced || p->variant != SKF_DFMF || p->engine != SKF_ENGINE_MFMA || !p->pipeline) return false;
-    if (p->rels.empty() || p->rels.size() > 64 || !p->thetas.empty()) return false;   // (constraint products share the split-K scratch)
+    if (p->rels.empty() || p->rels.size() > 64) return false;
+    for (const ThetaState& th : p->thetas)
+        if (!th.sparse) return false;            // (dense constraint products share the split-K scratch of the main stream)
     for (const TypeState& t : p->types)
         if (t.c <= SMALLC || t.c > 512) return false;
     for (const RelState& r : p->rels)
@@ -1566,6 +1586,12 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             p->thetas[t].type = thetas[t].type;
             p->thetas[t].data = thetas[t].data;
             p->thetas[t].ld = thetas[t].ld;
+            const int64_t nn = p->types[thetas[t].type].n;
+            if (thetas[t].nnz < 0) SKF_FAIL(SKF_E_INVALID, "constraint %d: negative non-zero bound", t);
+            if (thetas[t].nnz > 0 && thetas[t].nnz <= nn * nn / 16) {
+                p->thetas[t].sparse = true;
+                p->thetas[t].nnz_cap = thetas[t].nnz;
+            }
         }
         // ---- workspace layout: n-sized buffers in the master type, every c x c matrix in f64
         const size_t es = p->esz;
@@ -1697,6 +1723,13 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         size_t theta_tmp_bytes = 0;
         for (ThetaState& th : p->thetas) {
             TypeState& t = p->types[th.type];
+            if (th.sparse) {
+                add_slot(p, th.Cnt, (size_t)t.n * sizeof(int));
+                add_slot(p, th.Rp, (size_t)(t.n + 1) * sizeof(int64_t));
+                add_slot(p, th.Ci, (size_t)th.nnz_cap * sizeof(int));
+                add_slot(p, th.Vv, (size_t)th.nnz_cap * es);
+                continue;
+            }
             want_part((int)t.n, t.c, (int)t.n, p->f64);
             if (p->bf16) {
                 th.ldb = pad64(t.n);
@@ -1846,12 +1879,44 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
                 r.ldr = r.ldrb;
             }
         }
+        for (ThetaState& th : p->thetas) {
+            if (!th.sparse) continue;
+            // CSR of a sparse constraint: per-row counts on the device, prefix sum on the host, fill on the device
+            const int64_t n = p->types[th.type].n;
+            const int grid = (int)((n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048);
+            if (p->f64)
+                hipLaunchKernelGGL((theta_row_count_kernel<double>), dim3(grid), dim3(256), 0, st, (const double*)th.data, th.ld, n, (int*)th.Cnt.ptr);
+            else
+                hipLaunchKernelGGL((theta_row_count_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)th.data, th.ld, n, (int*)th.Cnt.ptr);
+            check_launch("theta_row_count");
+            std::vector<int> cnt((size_t)n);
+            SKF_HIP(hipMemcpyAsync(cnt.data(), th.Cnt.ptr, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
+            SKF_HIP(hipStreamSynchronize(st));
+            std::vector<int64_t> rp((size_t)n + 1);
+            int64_t tot = 0;
+            for (int64_t r = 0; r < n; ++r) { rp[(size_t)r] = tot; tot += cnt[(size_t)r]; }
+            rp[(size_t)n] = tot;
+            if (tot > th.nnz_cap)
+                SKF_FAIL(SKF_E_INVALID, "constraint on type %d holds %lld non-zeros, more than the bound %lld given in skf_theta_desc.nnz",
+                         th.type, (long long)tot, (long long)th.nnz_cap);
+            th.nnz = tot;
+            SKF_HIP(hipMemcpyAsync(th.Rp.ptr, rp.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            if (p->f64)
+                hipLaunchKernelGGL((theta_csr_fill_kernel<double>), dim3(grid), dim3(256), 0, st, (const double*)th.data, th.ld, n,
+                                   (const int64_t*)th.Rp.ptr, (int*)th.Ci.ptr, (double*)th.Vv.ptr);
+            else
+                hipLaunchKernelGGL((theta_csr_fill_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)th.data, th.ld, n,
+                                   (const int64_t*)th.Rp.ptr, (int*)th.Ci.ptr, (float*)th.Vv.ptr);
+            check_launch("theta_csr_fill");
+            SKF_HIP(hipStreamSynchronize(st));          // `rp` dies here; bind is not on the hot path
+        }
         if (!p->thetas.empty()) {
             // which halves of every constraint's +- split are non-empty (one device pass, read back here:
             // bind is not on the hot path), and the bf16 engine's copies of the non-empty halves
             SKF_HIP(hipMemsetAsync(p->theta_flags.ptr, 0, p->theta_flags.bytes, st));
             for (size_t k = 0; k < p->thetas.size(); ++k) {
                 ThetaState& th = p->thetas[k];
+                if (th.sparse) continue;
                 const int64_t n = p->types[th.type].n;
                 int* fl = (int*)p->theta_flags.ptr + 2 * k;
                 if (p->f64)
@@ -1867,6 +1932,7 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             SKF_HIP(hipStreamSynchronize(st));
             for (size_t k = 0; k < p->thetas.size(); ++k) {
                 ThetaState& th = p->thetas[k];
+                if (th.sparse) continue;
                 th.has_pos = flags[2 * k] != 0;
                 th.has_neg = flags[2 * k + 1] != 0;
                 if (!p->bf16) continue;

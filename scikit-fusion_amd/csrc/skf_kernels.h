@@ -1608,6 +1608,76 @@ __global__ __launch_bounds__(256) void fill_apply_kernel(T* __restrict__ X, int6
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Sparse constraints.  A constraint matrix Theta (n x n) is usually sparse -- lambda I, a handful of must-link /
+// cannot-link pairs per object, dicty's 3 % dense ppi -- while the reference multiplies it as a dense matrix
+// (_dfmf.py:284-292: D_i += Theta+ G_i, E_i += Theta- G_i).  With a non-zero bound from the caller
+// (skf_theta_desc.nnz) the engine keeps it as CSR, built on the device at bind time (count, host prefix sum, fill),
+// and the two products become one pass: a wave per row walks the row's non-zeros, gathers the rows of G and adds
+// v G[k] to D (v > 0) or -v G[k] to E (v < 0).  Same arithmetic as the dense split; fixed order within a row.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void theta_row_count_kernel(const T* __restrict__ X, int64_t ld, int64_t n,
+                                                              int* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n; r += nwaves) {
+        int cnt = 0;
+        for (int64_t c = lane; c < n; c += 64) cnt += (X[r * ld + c] != (T)0) ? 1 : 0;
+        cnt = wave_sum(cnt);
+        if (lane == 0) counts[r] = cnt;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void theta_csr_fill_kernel(const T* __restrict__ X, int64_t ld, int64_t n,
+                                                             const int64_t* __restrict__ rowptr, int* __restrict__ cols,
+                                                             T* __restrict__ vals) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n; r += nwaves) {
+        int64_t base = rowptr[r];
+        for (int64_t c0 = 0; c0 < n; c0 += 64) {
+            const int64_t c = c0 + lane;
+            const T v = c < n ? X[r * ld + c] : (T)0;
+            const bool nz = v != (T)0;
+            const unsigned long long m = __ballot(nz ? 1 : 0);
+            if (nz) {
+                const int before = __popcll(m & ((1ull << lane) - 1ull));
+                cols[base + before] = (int)c;
+                vals[base + before] = v;
+            }
+            base += __popcll(m);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void theta_spmm_kernel(const int64_t* __restrict__ rowptr, const int* __restrict__ cols,
+                                                         const T* __restrict__ vals, const T* __restrict__ G,
+                                                         T* __restrict__ E, T* __restrict__ D, int64_t n, int c) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n; r += nwaves) {
+        const int64_t a = rowptr[r], b = rowptr[r + 1];
+        if (a == b) continue;
+        for (int j0 = 0; j0 < c; j0 += 64) {
+            const int j = j0 + lane;
+            T e = (T)0, d = (T)0;
+            for (int64_t q = a; q < b; ++q) {
+                const T v = vals[q];
+                const T g = j < c ? G[(int64_t)cols[q] * c + j] : (T)0;
+                if (v > (T)0) d += v * g;
+                else e -= v * g;
+            }
+            if (j < c) {
+                E[r * c + j] += e;
+                D[r * c + j] += d;
+            }
+        }
+    }
+}
+
 // flags[0] |= any(Theta > 0), flags[1] |= any(Theta < 0): the all-zero half of a constraint's +- split
 // (_dfmf.py:203-208) is never multiplied (e.g. a non-positive similarity has Theta+ == 0)
 template <typename T>

@@ -522,3 +522,50 @@ def test_binary_relations_as_bitmaps_give_the_dense_results_bit_for_bit():
     bad = DeviceMatrix(rt.mem.from_host(nat.to_bf16_bits(Rum.astype(np.float32))), Rum.shape, binary=True)
     with pytest.raises(nat.SkfNativeError):
         DevicePlan(types, n, rank, [('u', 'm', bad, None), ('m', 'a', Rma, None)], [], nat.SKF_DFMF, dtype='bf16')
+
+
+@pytest.mark.parametrize('dtype,wide', [('f64', False), ('f64', True), ('bf16', False)])
+def test_sparse_constraints_as_csr_give_the_dense_product(dtype, wide):
+    """A constraint with few non-zeros (skf_theta_desc.nnz) is compacted to CSR on the device and applied as a
+    row-gather product with the same +- split as the dense form (reference _dfmf.py:276-283): same factors as the
+    dense product to summation order, on the staged schedule and (every rank > 64, DFMF) under the relation
+    pipeline; a bound below the true count is refused at bind time."""
+    from skfusion_amd._engine import DevicePlan, DeviceMatrix
+    rs = np.random.RandomState(23)
+    types = ['a', 'b']
+    n = {'a': 130, 'b': 110}
+    rank = {'a': 66, 'b': 70} if wide else {'a': 9, 'b': 6}
+    R = rs.rand(130, 110)
+    T1 = np.where(rs.rand(130, 130) < 0.03, rs.randn(130, 130), 0.0)       # must-link (-) and cannot-link (+)
+    T1 = T1 + T1.T
+    T2 = 0.5 * np.eye(130)
+    T3 = np.where(rs.rand(110, 110) < 0.02, -1.0, 0.0)
+    T3[7, :] = 0.0                                                          # an empty row
+    G0 = {t: rs.rand(n[t], rank[t]) + 0.05 for t in types}
+    rt = nat.get_runtime()
+    npd = np.float64 if dtype == 'f64' else np.float32
+    out = {}
+    for mode in ('sparse', 'dense'):
+        thetas = []
+        for t, T in (('a', T1), ('a', T2), ('b', T3)):
+            dm = DeviceMatrix(rt.mem.from_host(np.ascontiguousarray(T, dtype=npd)), T.shape)
+            dm.nnz = int(np.count_nonzero(T)) if mode == 'sparse' else 0
+            thetas.append((t, dm))
+        plan = DevicePlan(types, n, rank, [('a', 'b', R, None)], thetas, nat.SKF_DFMF, dtype=dtype)
+        for t in types:
+            plan.set_factor(t, G0[t])
+        plan.iterate(3)
+        out[mode] = [plan.get_factor(t) for t in types]
+        plan.close()
+    # SKF_BF16: the dense form rounds Theta and G to bf16 for the matrix cores, the CSR form works on the f32 masters
+    tol = 1e-12 if dtype == 'f64' else 5e-3
+    for a, b in zip(out['sparse'], out['dense']):
+        assert relerr(a, b) < tol
+    Go, _ = orc.dfmf({('a', 'b'): [R]}, {('a', 'a'): [T1, T2], ('b', 'b'): [T3]}, types, rank, max_iter=3,
+                     G0={(t, t): G0[t] for t in types})
+    for k, t in enumerate(types):
+        assert relerr(out['sparse'][k], Go[t, t]) < (1e-10 if dtype == 'f64' else 2e-2)
+    low = DeviceMatrix(rt.mem.from_host(np.ascontiguousarray(T1, dtype=npd)), T1.shape)
+    low.nnz = int(np.count_nonzero(T1)) - 1
+    with pytest.raises(nat.SkfNativeError):
+        DevicePlan(types, n, rank, [('a', 'b', R, None)], [('a', low)], nat.SKF_DFMF, dtype=dtype)

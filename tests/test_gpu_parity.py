@@ -12,7 +12,7 @@ import pytest
 
 import skfusion_amd._native as nat
 from skfusion_amd.fusion.decomposition import _dfmf, _dfmc
-from skfusion_amd._engine import DevicePlan, fill_uniform
+from skfusion_amd._engine import DevicePlan, DeviceMatrix, fill_uniform
 from oracle import dfmf_oracle as orc
 from helpers import (golden, readme_graph, probe_graph, rank_deficient_graph, dicty_graph,
                      c3_scaled_graph, g0_from, Snapshots, compare_snapshots, relerr, within, TYPES)
@@ -101,6 +101,43 @@ def test_gemm_bits_binary_relation_as_a_bitmap(rt, shape, transposed):
 def test_binary_relations_as_bitmaps_in_the_engine():
     import test_emul_engine as E
     E.test_binary_relations_as_bitmaps_give_the_dense_results_bit_for_bit()
+
+
+@pytest.mark.parametrize('dtype,wide', [('f64', False), ('f64', True), ('bf16', False)])
+def test_sparse_constraints_in_the_engine(dtype, wide):
+    import test_emul_engine as E
+    E.test_sparse_constraints_as_csr_give_the_dense_product(dtype, wide)
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_sparse_constraints_at_8000_objects(dtype):
+    """8000 x 8000 constraints (lambda I and 0.4 % similarity pairs of both signs, as config 5's) on a 6000 x 8000
+    relation: CSR path (non-zero bound given) against the dense product on the same device-resident data."""
+    import torch
+    rs = np.random.RandomState(5)
+    n, rank = {'u': 6000, 'm': 8000}, {'u': 40, 'm': 96}
+    sim = np.where(rs.rand(8000, 8000) < 0.004, rs.randn(8000, 8000), 0.0)
+    eye = 0.01 * np.eye(8000)
+    R = rs.rand(6000, 8000)
+    npd = np.float64 if dtype == 'f64' else np.float32
+    mem = nat.get_runtime().mem
+    out = {}
+    for mode in ('sparse', 'dense'):
+        thetas = []
+        for T in (eye, sim):
+            dm = DeviceMatrix(mem.from_host(np.ascontiguousarray(T, dtype=npd)), T.shape)
+            dm.nnz = int(np.count_nonzero(T)) if mode == 'sparse' else 0
+            thetas.append(('m', dm))
+        plan = DevicePlan(['u', 'm'], n, rank, [('u', 'm', R, None)], thetas, nat.SKF_DFMF, dtype=dtype)
+        for k, t in enumerate(['u', 'm']):
+            plan.set_factor(t, fill_uniform((n[t], rank[t]), 100 + k, dtype))
+        plan.iterate(5)
+        out[mode] = [plan.get_factor(t) for t in ('u', 'm')]
+        plan.close()
+        del thetas
+        torch.cuda.empty_cache()
+    for a, b in zip(out['sparse'], out['dense']):
+        within(relerr(a, b), 5e-12 if dtype == 'f64' else 2e-5, 'sparse vs dense constraints at 8000 objects, %s' % dtype)
 
 
 def test_to_bf16(rt):
