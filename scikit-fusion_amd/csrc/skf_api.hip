@@ -349,7 +349,7 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
     }
     check_launch("gemm_bf16");
     if (splits > 1) {
-        hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3(elem_grid((int64_t)M * N)), dim3(256), 0, st, C, ldc,
+        hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3(elem_grid(((int64_t)M * N + 3) / 4)), dim3(256), 0, st, C, ldc,
                            (const float*)part, M, N, splits);
         check_launch("bf16_splitk_reduce");
     }
@@ -1277,10 +1277,10 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
     hipStream_t ax = p->aux;
     const int nan_upd = 1;                                   // DFMF: nan_to_num on the A/B/C/D terms (_dfmf.py:254-276)
     p->first_iter = false;
-    if (p->ev_rel.size() < nr) {
+    if (p->ev_rel.size() < 2 * nr) {              // per relation: P and W done | Q done
         const size_t old = p->ev_rel.size();
-        p->ev_rel.resize(nr);
-        for (size_t k = old; k < nr; ++k) SKF_HIP(hipEventCreateWithFlags(&p->ev_rel[k], hipEventDisableTiming));
+        p->ev_rel.resize(2 * nr);
+        for (size_t k = old; k < 2 * nr; ++k) SKF_HIP(hipEventCreateWithFlags(&p->ev_rel[k], hipEventDisableTiming));
     }
     // order of the relations: most expensive first, so that the exposed tail belongs to the cheapest one
     std::vector<size_t> order(nr);
@@ -1339,14 +1339,17 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
         const int ni = (int)r.nr, nj = (int)tj.n, ci = ti.c, cj = tj.c;
-        // ---- main stream: the products that stream the relation, and W = G_i^T P
+        // ---- main stream: the products that stream the relation, and W = G_i^T P.  W goes out between P and Q: the
+        // backbone chain and the row side of the relation then run underneath its OWN Q (for the last relation the
+        // exposed tail is the column side only)
         contraction_P(p, r, st);
-        contraction_Q(p, r, st);
         GemmArgs g = gemm_args(ti.G.ptr, 1, ci, r.P.ptr, cj, 1, r.W.ptr, cj, ci, cj, ni, EPI_STORE, 0);
         wide_gemm(p, g, st);
-        SKF_HIP(hipEventRecord(p->ev_rel[q], st));
+        SKF_HIP(hipEventRecord(p->ev_rel[2 * q], st));
+        contraction_Q(p, r, st);
+        SKF_HIP(hipEventRecord(p->ev_rel[2 * q + 1], st));
         // ---- second stream: everything else of this relation
-        SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[q], 0));
+        SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[2 * q], 0));
         g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);       // T1 = K_i W
         small_gemm(p, g, ax);
         g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);       // S = T1 K_j
@@ -1364,6 +1367,7 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         side_update(p, r.P.ptr, cj, cj, Sm, 1, cj, ti, ti.G.ptr, ti.E.ptr, ti.D.ptr, ni, nullptr, nullptr, false,
                     touched[r.row] != 0, nan_upd, ax);
         touched[r.row] = 1;
+        SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[2 * q + 1], 0));
         side_update(p, r.Q.ptr, ci, ci, Sm, cj, 1, tj, tj.G.ptr, tj.E.ptr, tj.D.ptr, nj, nullptr, nullptr, false,
                     touched[r.col] != 0, nan_upd, ax);
         touched[r.col] = 1;

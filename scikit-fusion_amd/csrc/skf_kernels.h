@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 namespace skf {
 
@@ -872,6 +873,72 @@ __device__ __forceinline__ void lds_tr_wait(s16x4& a, s16x4& b, s16x4& c, s16x4&
 #endif
 }
 
+
+// ds_read_b128 in the same inline-assembly form (the fragment pipeline of gemm_bf16_v2_kernel counts its own
+// outstanding LDS reads: lds_wait<N>() = s_waitcnt lgkmcnt(N) tied to the registers it releases)
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128(const unsigned char* p) {
+#ifdef SKF_HOST_EMULATOR
+    return *(const u32x4*)(p + OFF);
+#else
+    u32x4 r;
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+#endif
+}
+template <int CNT, typename T>
+__device__ __forceinline__ void lds_wait(T& x) {
+#ifndef SKF_HOST_EMULATOR
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(CNT));
+#endif
+}
+template <int CNT, typename T, typename U>
+__device__ __forceinline__ void lds_wait(T& x, U& y) {
+#ifndef SKF_HOST_EMULATOR
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(CNT));
+#endif
+}
+// the register holds a value that an earlier lds_wait has released: ties its consumers behind that wait
+template <typename T>
+__device__ __forceinline__ void lds_claim(T& x) {
+#ifndef SKF_HOST_EMULATOR
+    asm volatile("" : "+v"(x));
+#endif
+}
+// the bitmap loads and expansion stores of the ABITS flavour, in the same form (vm_wait<N>() = s_waitcnt vmcnt(N))
+__device__ __forceinline__ uint32_t global_load_u32(const void* p) {
+#ifdef SKF_HOST_EMULATOR
+    return *(const uint32_t*)p;
+#else
+    uint32_t r;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+#endif
+}
+template <int CNT>
+__device__ __forceinline__ void vm_wait(uint32_t& x) {
+#ifndef SKF_HOST_EMULATOR
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(CNT));
+#endif
+}
+__device__ __forceinline__ void lds_write_b128(u32x4* p, u32x4 v) {
+#ifdef SKF_HOST_EMULATOR
+    *p = v;
+#else
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)p;
+    asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(v) : "memory");
+#endif
+}
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
 // swizzle key of a k row of the transposed A image (AT)
 __device__ __forceinline__ int at_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
@@ -968,11 +1035,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
         if constexpr (AT) {
             int64_t off = (int64_t)(bm0 >> 3) + 4 * (tid & 7);
             if (off > g.lda - 4) off = g.lda - 4;
-            return *(const uint32_t*)(Abits + (int64_t)(k0 + (tid >> 3)) * g.lda + off);
+            return global_load_u32(Abits + (int64_t)(k0 + (tid >> 3)) * g.lda + off);
         } else {
             const int m = bm0 + (tid >> 1);
             const int mc = m < g.M ? m : g.M - 1;
-            return *(const uint32_t*)(Abits + (int64_t)mc * g.lda + (k0 >> 3) + 4 * (tid & 1));
+            return global_load_u32(Abits + (int64_t)mc * g.lda + (k0 >> 3) + 4 * (tid & 1));
         }
     };
     auto expand_bits = [&](uint32_t w, int buf, int q) {       // chunk q (8 entries) of the thread's 32
@@ -980,145 +1047,220 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
         const u32x4 v = bits_to_bf16x8((w >> (8 * q)) & 0xFFu);
         if constexpr (AT) {
             const int kr = tid >> 3, c = 4 * (tid & 7) + q;
-            Ad[kr * 32 + (c ^ (at_key(kr) << 1))] = v;
+            lds_write_b128(Ad + kr * 32 + (c ^ (at_key(kr) << 1)), v);
         } else {
-            Ad[swz_chunk(tid >> 1, 4 * (tid & 1) + q)] = v;
+            lds_write_b128(Ad + swz_chunk(tid >> 1, 4 * (tid & 1) + q), v);
         }
     };
-    uint32_t wnext = 0u;
-    if (nkt > 0) {
-        if constexpr (ABITS) {
-            uint32_t w = load_bits(kz0);
-            dma_B(kz0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) expand_bits(w, 0, q);
-            if (nkt > 1) {
-                w = load_bits(kz0 + BK);
-                if constexpr (BST == 3) dma_B(kz0 + BK, 1);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) expand_bits(w, 1, q);
-            }
-            if (nkt > 2) wnext = load_bits(kz0 + 2 * BK);
-            // tile 0 complete: its B pieces landed (only B(1) and the bits of tile 2 may still be in flight), every LDS write done
-            if (nkt > 2) __builtin_amdgcn_s_waitcnt(0x0070 | ((BST == 3 ? PWB : 0) + 1));
-            else if (nkt > 1) __builtin_amdgcn_s_waitcnt(0x0070 | (BST == 3 ? PWB : 0));
-            else __builtin_amdgcn_s_waitcnt(0x0070);
-        } else {
-            dma_A(kz0, 0);
-            dma_B(kz0, 0);
-            if (nkt > 1) {
-                dma_A(kz0 + BK, 1);
-                if constexpr (BST == 3) dma_B(kz0 + BK, 1);
-                __builtin_amdgcn_s_waitcnt(0x0F70 | KEEP);    // tile 0 has landed
-            } else {
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-            }
-        }
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt % AST;
-        const int curb = kt % BST;
-        const bool more = (kt + 1 < nkt);
-        // every buffer refilled in this step was last read in step kt-1 and released by its barrier.
-        // BST == 2: every B piece of tile kt+1 goes out before the first A piece of tile kt+2
-        auto piece = [&](int q) {
-            if (q >= PWA + PWB) return;
-            if constexpr (ABITS) {
-                // A slots: one 16-byte chunk of tile kt+2 expanded per slot, then the bits of tile kt+3 are fetched;
-                // B slots as below (BST == 2: the B pieces of tile kt+1 first, so that the bits load is the newest)
-                const bool a_slot = (BST == 3) ? (q < PWA) : (q >= PWB);
-                const int qa = (BST == 3) ? q : q - PWB;
-                if (a_slot) {
-                    if (kt + 2 < nkt) expand_bits(wnext, (kt + 2) % 3, qa);
-                    if (qa == PWA - 1 && kt + 3 < nkt) wnext = load_bits(kz0 + (kt + 3) * BK);
-                } else if constexpr (BST == 3) {
-                    if (kt + 2 < nkt) dma_B1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q - PWA);
-                } else {
-                    if (more) dma_B1(kz0 + (kt + 1) * BK, (kt + 1) & 1, q);
-                }
-                return;
-            }
-            if constexpr (BST == 3) {
-                if (kt + 2 < nkt) {
-                    if (q < PWA) SKF_PROBE_A(dma_A1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q));
-                    else SKF_PROBE_B(dma_B1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q - PWA));
-                }
-            } else {
-                if (q < PWB) {
-                    if (more) SKF_PROBE_B(dma_B1(kz0 + (kt + 1) * BK, (kt + 1) & 1, q));
-                } else if (kt + 2 < nkt) {
-                    SKF_PROBE_A(dma_A1(kz0 + (kt + 2) * BK, (kt + 2) % 3, q - PWB));
-                }
-            }
-        };
-        const u32x4* As = smem + cur * ASZ;
-        const u32x4* Bs = smem + AST * ASZ + curb * BSZ;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[4], b[NJ];
-#ifndef SKF_PROBE_NOMFMA
-            {   // B fragments first: the transposed A reads below end in an lgkmcnt(0) that covers both
-                const int chunk = 4 * ks + (lane >> 4);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    b[j] = __builtin_bit_cast(bf16x8, Bs[swz_chunk(wn0 + j * 16 + (lane & 15), chunk)]);
-            }
-            if constexpr (AT) {
-                const unsigned char* Ab = (const unsigned char*)As;
-                const int i16 = lane & 15, grp = lane >> 4;
-                // k rows kr (first half) and kr + 4 (second half, same swizzle key: +2048 bytes)
-                const int kr = ks * 32 + 8 * grp + (i16 >> 2);
-                s16x4 h[4][2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = ((wm0 + i * 16) >> 3) + ((i16 & 3) >> 1);        // logical chunk of this lane's 4 m
-                    const unsigned char* ptr = Ab + kr * 512 + ((c ^ (at_key(kr) << 1)) << 4) + ((i16 & 1) << 3);
-                    h[i][0] = lds_read_tr16_b64<0>(ptr);
-                    h[i][1] = lds_read_tr16_b64<2048>(ptr);
-                }
-                lds_tr_wait(h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const s16x8 v = {h[i][0][0], h[i][0][1], h[i][0][2], h[i][0][3], h[i][1][0], h[i][1][1], h[i][1][2], h[i][1][3]};
-                    a[i] = __builtin_bit_cast(bf16x8, v);
-                }
-            } else {
-                const int chunk = 4 * ks + (lane >> 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    a[i] = __builtin_bit_cast(bf16x8, As[swz_chunk(wm0 + i * 16 + (lane & 15), chunk)]);
-            }
-#endif
+    {
+        // ---- fragment-pipelined K loop --------------------------------------------------------------------------
+        // A K tile is consumed in two PHASES (k steps of 32).  While the matrix cores work through the phase's
+        // fragments column by column (4 MFMAs per 16-wide column of the wave's sub-tile), the fragments of the NEXT
+        // phase are read into the registers the MFMAs have just released: B fragment j+1 behind column j (one spare
+        // register set), the four A fragments behind their last MFMA in the last column.  The reads are inline
+        // assembly and the loop counts its own lgkmcnt: next phase's first column waits for A fragment i with
+        // exactly the later reads outstanding; every other column starts without a wait.  (Round 2, before:
+        // all 12 ds_read_b128 of a k step, s_waitcnt lgkmcnt(0), then 32 MFMAs -- with the 8 waves of the workgroup
+        // released by the same barrier the LDS needs ~400 cycles for that burst, twice per K tile, against 2048
+        // cycles of MFMA work per SIMD.)
+        // The workgroup meets ONCE per K tile, between the two phases: by then every wave holds the tile's last
+        // fragments in registers, so the B buffer of the tile (all B reads complete: lgkmcnt below) is refilled in
+        // phase 1 and the A buffer in phase 0 of the next tile (its last reads were issued before this barrier and
+        // have a whole phase to drain before the first DMA piece into the buffer is even issued).
+        //   phase 0 of tile kt: MFMAs of (kt, k step 0) | reads (kt, k step 1)   | DMA A(kt+2) -> ring slot (kt+2) % 3
+        //   s_waitcnt vmcnt: tile kt+1 landed (only A(kt+2) may be in flight); s_barrier
+        //   phase 1 of tile kt: MFMAs of (kt, k step 1) | reads (kt+1, k step 0) | DMA B(kt+2) -> ring slot (kt+2) % BST
+        constexpr int APH = AT ? 2 : 1;                                  // LDS reads per A fragment
+        constexpr int MIDW = ((APH * 4) << 8) | 0x0070;                  // lgkmcnt: only the 4 A fragments may be in flight
+        const unsigned char* smem_b = (const unsigned char*)smem;
+        const int l15 = lane & 15, grp = lane >> 4;
+        int aoff[2] = {0, 0}, boff[2], atoff[4] = {0, 0, 0, 0};
+        if constexpr (AT) {
+            // k rows kr (first half of the fragment) and kr + 4 (+2048 bytes); k step 1 = +32 rows = +16384 bytes
+            const int kr0 = 8 * grp + (l15 >> 2);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-#ifndef SKF_PROBE_NOMFMA
+                const int c = ((wm0 + i * 16) >> 3) + ((l15 & 3) >> 1);
+                atoff[i] = kr0 * 512 + ((c ^ (at_key(kr0) << 1)) << 4) + ((l15 & 1) << 3);
+            }
+        } else {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) aoff[ks] = swz_chunk(wm0 + l15, 4 * ks + grp) * 16;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) boff[ks] = swz_chunk(wn0 + l15, 4 * ks + grp) * 16;
+
+        u32x4 fa[4], fb[NJ];
+        s16x4 fh[4][2];
+        auto issue_a = [&](auto ic, auto ksc, const unsigned char* abuf, u32x4& a, s16x4(&h)[2]) {
+            constexpr int i = decltype(ic)::value, ks = decltype(ksc)::value;
+            if constexpr (AT) {
+                h[0] = lds_read_tr16_b64<ks * 16384>(abuf + atoff[i]);
+                h[1] = lds_read_tr16_b64<ks * 16384 + 2048>(abuf + atoff[i]);
+            } else {
+                a = lds_read_b128<i * 2048>(abuf + aoff[ks]);
+            }
+        };
+        auto slot = [&](auto ksc, auto sc, int kt) {
+            constexpr int ks = decltype(ksc)::value, sidx = decltype(sc)::value;
+            if (kt + 2 >= nkt) return;
+            const int k2 = kz0 + (kt + 2) * BK;
+            if constexpr (ks == 0) {
+                if constexpr (!ABITS) SKF_PROBE_A(dma_A1(k2, (kt + 2) % AST, sidx));
+            } else if constexpr (sidx < PWB) {
+                SKF_PROBE_B(dma_B1(k2, (kt + 2) % BST, sidx));
+            }
+        };
+        // ABITS, phase 0: chunk q of the bits of tile kt+2 (in wcur since the previous tile) goes into ring slot
+        // (kt+2) % 3 behind column min(q, NJ-2) -- every expansion write precedes the phase's A fragment reads, so the
+        // lgkmcnt bookkeeping of the fragments is the same with and without them -- then the bits of tile kt+3 are
+        // fetched.  Loads and stores are inline assembly like the fragment reads (the compiler's own waitcnt pass put
+        // s_waitcnt vmcnt(0) -- every LDS-DMA in flight -- in front of each ds_write of the round-2 loop).
+        // Past the end of the K range the writes still go out (stale bits into a ring slot nobody reads again).
+        uint32_t wcur = 0u;
+        auto expand_chunk = [&](auto qc, int kt) {
+            constexpr int q = decltype(qc)::value;
+            if constexpr (q == 0) {
+                // behind the bits load: the B pieces of tile kt+1 (phase 1 of the previous tile)
+                if (kt + 2 < nkt) vm_wait<PWB>(wcur);
+            }
+            expand_bits(wcur, (kt + 2) % AST, q);
+            if constexpr (q == 3) {
+                if (kt + 3 < nkt) wcur = load_bits(kz0 + (kt + 3) * BK);
+            }
+        };
+        auto phase = [&](auto ksc, int kt) {
+            constexpr int ks = decltype(ksc)::value;
+            using NKS = std::integral_constant<int, (ks ^ 1)>;
+            const int tn = kt + ks;                                      // the tile this phase reads fragments of
+            const unsigned char* abuf = smem_b + (tn % AST) * (ASZ * 16);
+            const unsigned char* pb = smem_b + (AST * ASZ + (tn % BST) * BSZ) * 16 + boff[ks ^ 1];
+            u32x4 na[4], nb[NJ];
+            s16x4 nh[4][2];
+            nb[0] = lds_read_b128<0>(pb);
+            static_for<NJ>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                static_for<4>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (j == 0) {
+                        // in flight behind A fragment i: the later A fragments and this phase's first B read
+                        if constexpr (AT) {
+                            lds_wait<APH * (3 - i) + 1>(fh[i][0], fh[i][1]);
+                            const s16x8 v = {fh[i][0][0], fh[i][0][1], fh[i][0][2], fh[i][0][3],
+                                             fh[i][1][0], fh[i][1][1], fh[i][1][2], fh[i][1][3]};
+                            fa[i] = __builtin_bit_cast(u32x4, v);
+                        } else {
+                            lds_wait<APH * (3 - i) + 1>(fa[i]);
+                        }
+                        if constexpr (i == 0) {                          // every B fragment is older than A fragment 0
+#pragma unroll
+                            for (int q = 0; q < NJ; ++q) lds_claim(fb[q]);
+                        }
+                    }
+#ifndef SKF_PROBE_NOMFMA
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                        __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
 #endif
+                    if constexpr (j == 0) __builtin_amdgcn_sched_barrier(0);    // (keeps MFMA i between waits i and i+1)
+                    if constexpr (j == NJ - 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_a(ic, NKS{}, abuf, na[i], nh[i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                if constexpr (j + 1 < NJ) nb[j + 1] = lds_read_b128<(j + 1) * 2048>(pb);
+                if constexpr (ABITS && ks == 0) {
+                    if constexpr (j < 4 && j <= NJ - 2) expand_chunk(jc, kt);
+                    if constexpr (NJ == 4 && j == 2) expand_chunk(std::integral_constant<int, 3>{}, kt);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                piece(ks * 4 + i);
-                __builtin_amdgcn_sched_barrier(0);
+                constexpr int CPS = NJ / 4;                              // columns per DMA slot (4 slots per phase)
+                if constexpr ((j + 1) % CPS == 0) {
+                    slot(ksc, std::integral_constant<int, (j + 1) / CPS - 1>{}, kt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = na[i];
+                fh[i][0] = nh[i][0];
+                fh[i][1] = nh[i][1];
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = nb[j];
+        };
+
+        if (nkt > 0) {
+            if constexpr (ABITS) {
+                // tiles 0 and 1 expanded before the loop (once per workgroup: plain vmcnt(0)), the bits of tile 2 in wcur
+                uint32_t w0 = load_bits(kz0), w1 = 0u;
+                dma_B(kz0, 0);
+                if (nkt > 1) {
+                    w1 = load_bits(kz0 + BK);
+                    dma_B(kz0 + BK, 1);
+                }
+                if (nkt > 2) wcur = load_bits(kz0 + 2 * BK);
+                vm_wait<0>(w0);
+                vm_wait<0>(w1);
+                vm_wait<0>(wcur);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) expand_bits(w0, 0, q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) expand_bits(w1, 1, q);
+                __builtin_amdgcn_s_waitcnt(0x0070);
+            } else {
+                dma_A(kz0, 0);
+                dma_B(kz0, 0);
+                if (nkt > 1) {
+                    dma_A(kz0 + BK, 1);
+                    dma_B(kz0 + BK, 1);
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | (PWA + PWB));    // tile 0 has landed
+                } else {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {   // fragments of (tile 0, k step 0), in the order every phase issues them: B 0 .. NJ-1, A 0 .. 3
+                const unsigned char* pb0 = smem_b + AST * ASZ * 16 + boff[0];
+                static_for<NJ>([&](auto jc) { fb[decltype(jc)::value] = lds_read_b128<decltype(jc)::value * 2048>(pb0); });
+                static_for<4>([&](auto ic) {
+                    issue_a(ic, std::integral_constant<int, 0>{}, smem_b, fa[decltype(ic)::value], fh[decltype(ic)::value]);
+                });
+            }
+            for (int kt = 0; kt < nkt; ++kt) {
+                phase(std::integral_constant<int, 0>{}, kt);
+                if constexpr (ABITS) {           // B(kt+1) landed; behind it only the bits load of tile kt+3
+                    if (kt + 3 < nkt) __builtin_amdgcn_s_waitcnt(MIDW | 1);
+                    else __builtin_amdgcn_s_waitcnt(MIDW);
+                } else {
+                    if (kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(MIDW | PWA);
+                    else __builtin_amdgcn_s_waitcnt(MIDW);
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                phase(std::integral_constant<int, 1>{}, kt);
+            }
+            // the reads of the phase past the end (never consumed) must not land in registers that are live again
+            if constexpr (AT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lds_wait<0>(fh[i][0], fh[i][1]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lds_wait<0>(fa[i]);
+            }
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) lds_claim(fb[q]);
+            if constexpr (ABITS) vm_wait<0>(wcur);
+            if constexpr (EPI != EPI_T_STORE) {                          // the epilogues below stage their tile in the rings
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
             }
         }
-        // tile kt+1 must have landed; tile kt+2 (if it was issued) may stay in flight.
-        // lgkmcnt(0): this wave's fragment reads of buffer `cur` are done before it is refilled.
-        if constexpr (ABITS) {
-            // allowed in flight: the B pieces of tile kt+2 (BST == 3) and the bits of tile kt+3
-            if (kt + 3 < nkt) __builtin_amdgcn_s_waitcnt(0x0070 | (KEEP + 1));
-            else if (kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0070 | KEEP);
-            else __builtin_amdgcn_s_waitcnt(0x0070);
-        } else {
-            if (kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0070 | KEEP);
-            else __builtin_amdgcn_s_waitcnt(0x0070);
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
     }
 
     // D reg r of a 16 x 16 tile -> row = 4*(lane>>4) + r, col = lane & 15
@@ -1175,13 +1317,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                     T[((e >> 8) & 0xFFu) * TLD + (e & 0xFFu)] = (uint16_t)(e >> 16);
                 }
                 __syncthreads();
+                u32x4 tv[NIT];                   // all chunks of the thread out of LDS first (one wait), then the stores
+#pragma unroll
+                for (int q = 0; q < NIT; ++q) {
+                    const int it = tid + q * 512;
+                    tv[q] = *(const u32x4*)(T + (it / CH) * TLD + (it % CH) * 8);
+                }
 #pragma unroll
                 for (int q = 0; q < NIT; ++q) {
                     const int it = tid + q * 512;
                     const int r = it / CH, c = it % CH;
                     const int left = rel_cols - (col0 + c * 8);           // columns of this chunk inside the relation
                     if (row0 + r >= rel_rows || left <= 0) continue;
-                    u32x4 v = *(const u32x4*)(T + r * TLD + c * 8);
+                    u32x4 v = tv[q];
                     if (left < 8) {                                       // padding columns of R stay zero
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
@@ -1271,6 +1419,25 @@ __global__ __launch_bounds__(256) void bf16_splitk_reduce_kernel(float* __restri
                                                                  const float* __restrict__ part, int M, int N,
                                                                  int splits) {
     const int64_t total = (int64_t)M * N;
+    if (ldc == N && (total & 3) == 0) {
+        // the contraction outputs (P, Q: ldc == N): 16 bytes per lane, the slices of a step loaded together
+        const int64_t nv = total >> 2;
+        const f32x4* p4 = (const f32x4*)part;
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nv; e += (int64_t)gridDim.x * blockDim.x) {
+            f32x4 v = __builtin_nontemporal_load(p4 + e);
+            int z = 1;
+            for (; z + 3 < splits; z += 4) {
+                const f32x4 a = __builtin_nontemporal_load(p4 + (int64_t)z * nv + e);
+                const f32x4 b = __builtin_nontemporal_load(p4 + (int64_t)(z + 1) * nv + e);
+                const f32x4 c = __builtin_nontemporal_load(p4 + (int64_t)(z + 2) * nv + e);
+                const f32x4 d = __builtin_nontemporal_load(p4 + (int64_t)(z + 3) * nv + e);
+                v += a; v += b; v += c; v += d;
+            }
+            for (; z < splits; ++z) v += __builtin_nontemporal_load(p4 + (int64_t)z * nv + e);
+            ((f32x4*)C)[e] = v;
+        }
+        return;
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         float v = 0.f;
