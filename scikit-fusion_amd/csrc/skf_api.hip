@@ -958,13 +958,21 @@ static void stage_contract(skf_plan* p, hipStream_t st) {
     for (RelState& r : p->rels) {
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
+        // A masked DFMC relation is contracted twice per iteration: here, before its completion, only
+        // W = G_i^T R G_j is needed (_dfmc.py:311-314), and the narrower factor does it -- with c_i < c_j as
+        // W = (R^T G_i)^T G_j (config 5, user x movie: rank 128 instead of 256 through the 8 GB relation).
+        const bool w_by_q = dfmc && r.masked && ti.c < tj.c;
         if (r.absent) {
             SKF_HIP(hipMemsetAsync(r.W.ptr, 0, r.W.bytes, st));
+        } else if (w_by_q) {
+            contraction_Q(p, r, st);
+            GemmArgs g = gemm_args(r.Q.ptr, 1, ti.c, tj.G.ptr, tj.c, 1, r.W.ptr, tj.c, ti.c, tj.c, (int)tj.n, EPI_STORE, 0);
+            wide_gemm(p, g, st);
         } else {
             contraction_P(p, r, st);
         }
         if (!(dfmc && r.masked)) contraction_Q(p, r, st);     // a masked relation is completed first
-        if (!r.absent) {
+        if (!r.absent && !w_by_q) {
             GemmArgs g = gemm_args(rows_of(p, ti.G, ti, r.r0), 1, ti.c, r.P.ptr, tj.c, 1, r.W.ptr, tj.c, ti.c, tj.c,
                                    (int)r.nr, EPI_STORE, 0);
             wide_gemm(p, g, st);
