@@ -244,25 +244,22 @@ static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void
 // ---- bf16 relation contraction --------------------------------------------------------------
 static inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
 
-// K slices for the bf16 contraction: equal work units over the 256 CUs (x resident workgroups)
-// finish in ceil(units/slots) rounds; pick the split that wastes the least of the last round,
-// charging every extra slice for its partial-sum traffic.  The charge is empirical (config 3, A/B
-// runs 0.002 ... 1.0 inside the whole iteration; round 2 with the scheduled DMA pieces: 0.04 +0.7 % over 0.06).
-static int pick_splits_bf16(int64_t units, int ktiles, int bm) {
+// K slices for the bf16 contraction.  Time model of a launch (microseconds): the workgroups run in
+// ceil(units * s / slots) rounds of (K tiles per slice + 3 tiles of prologue / epilogue) x 1.5 us, and s > 1 slices
+// write and re-read s partial copies of the output at ~3 TB/s.  On config 3 it picks what the A/B runs of rounds 1 / 2
+// picked (5 / 3 / 3 / 3 slices for P12 / Q12 / P23 / Q23); a product with a handful of output tiles (config 5,
+// genre x movie: ONE 256 x 256 tile over K = 40000, 0.96 ms in one workgroup before) is cut into up to 64 slices.
+static int pick_splits_bf16(int64_t units, int ktiles, int bm, int64_t out_elems) {
     const double slots = 256.0 * (bm >= 256 ? 1.0 : 2.0);     // resident workgroups on 256 CUs
-#ifndef SKF_SPLIT_PENALTY
-#define SKF_SPLIT_PENALTY 0.04
-#endif
-    const double penalty = SKF_SPLIT_PENALTY;                  // cost of one more K slice (partial-sum traffic)
+    const double per_slice_us = (double)out_elems * 8.0 / 3.0e6;
     int best = 1;
-    double best_eff = -1.0;
-    for (int s = 1; s <= 32; ++s) {
-        if (s > 1 && ktiles / s < 8) break;
-        const double w = (double)units * s / slots;
-        const double rounds = (double)(int64_t)(w + 0.999999);
-        const double eff = w / (rounds < 1.0 ? 1.0 : rounds) - penalty * (s - 1);
-        if (eff > best_eff + 1e-9) {
-            best_eff = eff;
+    double best_t = 1e300;
+    for (int s = 1; s <= 64; ++s) {
+        if (s > 1 && ktiles / s < 4) break;
+        const double rounds = (double)(int64_t)((double)units * s / slots + 0.999999);
+        const double t = (rounds < 1.0 ? 1.0 : rounds) * ((ktiles + s - 1) / s + 3) * 1.5 + (s > 1 ? s * per_slice_us : 0.0);
+        if (t < best_t * (1.0 - 1e-9)) {
+            best_t = t;
             best = s;
         }
     }
@@ -298,7 +295,7 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
     const int bm = bf16_block_rows(M, at || abits);
     const int ktiles = Kp / 64;
     const int64_t units = (int64_t)cdiv(M, bm) * cdiv(N, bn);
-    int splits = want_splits > 0 ? want_splits : pick_splits_bf16(units, ktiles, bm);
+    int splits = want_splits > 0 ? want_splits : pick_splits_bf16(units, ktiles, bm, (int64_t)M * N);
     const size_t per = (size_t)M * N * sizeof(float);
     if (splits > 1 && (!part || per * splits > part_bytes)) splits = part ? (int)(part_bytes / per) : 1;
     if (splits < 1) splits = 1;
@@ -358,7 +355,7 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
 static size_t bf16_part_bytes(int M, int N, int Kp, bool at) {      // (a bitmap operand always takes the 256-row kernel)
     const int bn = (N <= 128) ? 128 : 256;
     const int bm = bf16_block_rows(M, at);
-    const int s = pick_splits_bf16((int64_t)cdiv(M, bm) * cdiv(N, bn), Kp / 64, bm);
+    const int s = pick_splits_bf16((int64_t)cdiv(M, bm) * cdiv(N, bn), Kp / 64, bm, (int64_t)M * N);
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 

@@ -972,10 +972,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * WN;
-    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
     const int kz0 = blockIdx.z * g.k_chunk;
     const int kz1 = (kz0 + g.k_chunk < g.Kp) ? kz0 + g.k_chunk : g.Kp;
     const int nkt = (kz1 - kz0) / BK;
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;     // EPI_T_*: index of the tile in koff / sq
+
+    // EPI_T_COMPLETE: the first known entries of the tile (3 per thread: 1536 of on average 1300) travel while the K loop runs
+    constexpr int KPF = 3;
+    uint32_t kq0 = 0u, kq1 = 0u, kpre[KPF] = {0u, 0u, 0u};
+    if constexpr (EPI == EPI_T_COMPLETE) {
+        if (g.klist != nullptr) {
+            kq0 = g.koff[tile];
+            kq1 = g.koff[tile + 1];
+#pragma unroll
+            for (int q = 0; q < KPF; ++q) {
+                const uint32_t k = kq0 + tid + q * 512;
+                if (k < kq1) kpre[q] = __builtin_nontemporal_load(g.klist + k);
+            }
+        }
+    }
 
     f32x4 acc[4][NJ];
 #pragma unroll
@@ -1310,22 +1326,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                 // Known entries of this tile from their compact list straight into the staged tile, then EVERY chunk
                 // is written out: full-line streaming stores, no read of the old relation, no mask traffic
                 // (at 2 % known entries the blend below reads 3 of 4 lines of R back).
-                const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-                const uint32_t k0 = g.koff[tile], k1 = g.koff[tile + 1];
-                for (uint32_t k = k0 + tid; k < k1; k += 512) {
+#pragma unroll
+                for (int q = 0; q < KPF; ++q)
+                    if (kq0 + tid + q * 512 < kq1) T[((kpre[q] >> 8) & 0xFFu) * TLD + (kpre[q] & 0xFFu)] = (uint16_t)(kpre[q] >> 16);
+                for (uint32_t k = kq0 + tid + KPF * 512; k < kq1; k += 512) {
                     const uint32_t e = g.klist[k];
                     T[((e >> 8) & 0xFFu) * TLD + (e & 0xFFu)] = (uint16_t)(e >> 16);
                 }
                 __syncthreads();
-                u32x4 tv[NIT];                   // all chunks of the thread out of LDS first (one wait), then the stores
+                constexpr int NB = 8;            // chunks out of LDS per batch (one wait), then their stores
+                static_assert(NIT % NB == 0, "write-out batches");
 #pragma unroll
-                for (int q = 0; q < NIT; ++q) {
-                    const int it = tid + q * 512;
+                for (int q0 = 0; q0 < NIT; q0 += NB) {
+                u32x4 tv[NB];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    const int it = tid + (q0 + q) * 512;
                     tv[q] = *(const u32x4*)(T + (it / CH) * TLD + (it % CH) * 8);
                 }
 #pragma unroll
-                for (int q = 0; q < NIT; ++q) {
-                    const int it = tid + q * 512;
+                for (int q = 0; q < NB; ++q) {
+                    const int it = tid + (q0 + q) * 512;
                     const int r = it / CH, c = it % CH;
                     const int left = rel_cols - (col0 + c * 8);           // columns of this chunk inside the relation
                     if (row0 + r >= rel_rows || left <= 0) continue;
@@ -1335,7 +1356,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                         for (int e = 0; e < 8; ++e)
                             if (e >= left) v[e >> 1] &= ~(0xFFFFu << (16 * (e & 1)));
                     }
+#ifndef SKF_PROBE_NOSTORE
                     *(u32x4*)(g.R + (int64_t)(row0 + r) * g.ldr + col0 + c * 8) = v;
+#else
+                    if (v[0] == 0x12345678u) *(u32x4*)(g.R + (int64_t)(row0 + r) * g.ldr + col0 + c * 8) = v;
+#endif
+                }
                 }
             } else {
             // item = 8 consecutive columns of one relation row; 32 lanes cover the 512 contiguous bytes of a tile row.
@@ -1408,7 +1434,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
             if (tid == 0) {
                 double tot = 0.0;
                 for (int w = 0; w < 8; ++w) tot += wsum[w];
-                g.sq[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+                g.sq[tile] = tot;
             }
         }
     }
