@@ -194,8 +194,12 @@ static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, 
     }
     check_launch("gemm");
     if (splits > 1) {
-        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(elem_grid((int64_t)g.M * g.N)), dim3(256), 0, st,
-                           g, splits);
+        if (splits >= 8)
+            hipLaunchKernelGGL((splitk_reduce_z16_kernel<T>), dim3(elem_grid((int64_t)g.M * g.N * 16)), dim3(256), 0, st,
+                               g, splits);
+        else
+            hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(elem_grid((int64_t)g.M * g.N)), dim3(256), 0, st,
+                               g, splits);
         check_launch("splitk_reduce");
     }
 }

@@ -1485,6 +1485,40 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int spli
     }
 }
 
+// the same for MANY slices of a small output (wide c x c products: Gram, W = G_i^T P -- up to 250 slices)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_z16_kernel(GemmArgs g, int splits) {
+    // 16 elements per workgroup pass, 16 threads per element: thread (zl, el) sums the slices zl, zl + 16, ... (four
+    // loads in flight), the 16 sums of an element are added in the order zl = 0 .. 15.  (One thread per element walked
+    // up to 250 slices of a wide c x c product one load at a time: 75 us for 16 000 outputs.)
+    __shared__ T red[16][17];
+    const int64_t total = (int64_t)g.M * g.N;
+    const T* part = (const T*)g.part;
+    const int zl = threadIdx.x >> 4, el = threadIdx.x & 15;
+    for (int64_t e0 = (int64_t)blockIdx.x * 16; e0 < total; e0 += (int64_t)gridDim.x * 16) {
+        const int64_t e = e0 + el;
+        T v = (T)0;
+        if (e < total) {
+            int z = zl;
+            for (; z + 48 < splits; z += 64) {
+                const T a = part[(int64_t)z * total + e], b = part[(int64_t)(z + 16) * total + e];
+                const T c = part[(int64_t)(z + 32) * total + e], d = part[(int64_t)(z + 48) * total + e];
+                v += a; v += b; v += c; v += d;
+            }
+            for (; z < splits; z += 16) v += part[(int64_t)z * total + e];
+        }
+        red[zl][el] = v;
+        __syncthreads();
+        if (zl == 0 && e < total) {
+            T t = red[0][el];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) t += red[q][el];
+            epilogue_store<T>(g, (int)(e / g.N), (int)(e % g.N), t);
+        }
+        __syncthreads();
+    }
+}
+
 // out[0] = sum_k part[k] in f64, fixed order (single workgroup)
 template <typename T>
 __global__ __launch_bounds__(256) void sum_partials_kernel(const T* __restrict__ part, int n, double* out) {
