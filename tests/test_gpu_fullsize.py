@@ -79,13 +79,15 @@ def test_one_full_size_iteration_against_host_regenerated_rows(dtype):
         rows = idx[i]
         Rrows = np.stack([orc.hash_uniform(seed, int(r) * nj, nj) for r in rows])
         want = _round(Rrows, dtype) @ Gop[j]
-        # measured (MI355X): 3.4e-7 .. 1.8e-6 bf16, 3.1e-6 .. 5.3e-6 f32 (f32 accumulation over 40k-100k terms)
-        within(relerr(P[k][rows], want), 2e-5, 'full size %s: P rows of relation %d vs host-regenerated R' % (dtype, k))
+        # measured (MI355X): 1.9e-7 .. 5.3e-7 bf16 (exact products of bf16 operands), 3.1e-6 .. 5.3e-6 f32 (f32
+        # accumulation over 40k-100k terms)
+        tol_pq = 2.5e-6 if dtype == 'bf16' else 2e-5
+        within(relerr(P[k][rows], want), tol_pq, 'full size %s: P rows of relation %d vs host-regenerated R' % (dtype, k))
         cols = idx[j]
         allr = np.arange(ni, dtype=np.uint64) * np.uint64(nj)
         Rcols = np.stack([orc.hash_uniform_at(seed, allr + np.uint64(c)) for c in cols])    # [sample][n_i]
         want = _round(Rcols, dtype) @ Gop[i]
-        within(relerr(Q[k][cols], want), 2e-5, 'full size %s: Q rows of relation %d vs host-regenerated R' % (dtype, k))
+        within(relerr(Q[k][cols], want), tol_pq, 'full size %s: Q rows of relation %d vs host-regenerated R' % (dtype, k))
 
     # ---- the backbone from the full P (reference _dfmf.py:228-239), f64 on the host
     Gram = {t: G2[t].T @ G2[t] for t in TYPES}
@@ -93,7 +95,7 @@ def test_one_full_size_iteration_against_host_regenerated_rows(dtype):
     for k, (i, j, _) in enumerate(bench.PAIRS):
         want = Kinv[i] @ (G2[i].T @ P[k]) @ Kinv[j]
         # measured 2.5e-8 (f64 c x c algebra on both sides; Cholesky inverse vs scipy's SVD pinv)
-        within(relerr(S[k], want), 2e-7, 'full size %s: backbone of relation %d vs host K_i (G_i^T P) K_j' % (dtype, k))
+        within(relerr(S[k], want), 1e-7, 'full size %s: backbone of relation %d vs host K_i (G_i^T P) K_j' % (dtype, k))
 
     # ---- the multiplicative update of sampled factor rows (reference _dfmf.py:254-296)
     Bp = {t: np.zeros((RANK[t], RANK[t])) for t in TYPES}
@@ -117,7 +119,7 @@ def test_one_full_size_iteration_against_host_regenerated_rows(dtype):
                 E += pos(Cm); Dn += neg(Cm)
         want = G2[t][rows] * np.sqrt(E / np.maximum(Dn, eps))
         # measured 1.3e-7 .. 1.5e-7 (f32 side products and update)
-        within(relerr(G3[t][rows], want), 1e-6, 'full size %s: updated rows of G_%s vs host update' % (dtype, t))
+        within(relerr(G3[t][rows], want), 6e-7, 'full size %s: updated rows of G_%s vs host update' % (dtype, t))
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'f32'])
@@ -155,7 +157,8 @@ def test_full_size_planted_structure_is_recovered(dtype):
         rows, Rrows = sample[k]
         host = np.sqrt(np.mean((Rrows - G[i][rows] @ plan.get_backbone(k) @ G[j].T) ** 2))
         # the backbone belongs to the factors before the last update (reference _dfmf.py:239 vs :295), as in
-        # the device's own residual; 384 of the rows (the per-row residual varies: 96 rows measured 0.1-2.9 %)
-        within(abs(host - rmse) / rmse, 0.03, 'full size %s planted: device RMSE vs host RMSE on sampled rows, relation %d'
+        # the device's own residual; 384 of the rows (the per-row residual varies: 96 rows measured 0.1-2.9 %,
+        # 384 rows 0.003-0.31 %)
+        within(abs(host - rmse) / rmse, 0.012, 'full size %s planted: device RMSE vs host RMSE on sampled rows, relation %d'
                % (dtype, k))
     plan.close()
