@@ -803,12 +803,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16GemmArgs g) {
 // Tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction moves 1 KiB into a
 // wave-LINEAR LDS range, so the bank swizzle is applied to the per-lane SOURCE address); no staging
 // registers, no ds_write pass.  The A operand (the relation, streamed from HBM, nt policy) lives in a ring
-// of three 32 KiB buffers -- two of its K tiles are in flight while one is consumed; the B operand (G^T,
-// served by L2) has three buffers at BN = 128 and two at BN = 256 (3 x 32 + 2 x 32 KiB = the whole LDS) and
-// is issued BEFORE the A tile, so that a COUNTED s_waitcnt vmcnt(PWA) leaves exactly the newest A tile
-// outstanding.  The workgroup meets at a raw s_barrier (__syncthreads() would drain every LDS-DMA).
-// The DMA instructions of a K step are issued BETWEEN the wave's groups of MFMAs (one piece per 16-row
-// block), not in a burst behind the barrier: +3 % (profiles/r02_contraction_bounds.txt, sched1).
+// of three 32 KiB buffers, the B operand (G^T, served by L2) in three buffers at BN = 128 and two at BN = 256
+// (3 x 32 + 2 x 32 KiB = the whole LDS).  The DMA instructions are issued one at a time in slots BETWEEN the
+// wave's groups of MFMAs, never in a burst behind a barrier (+3 %, profiles/r02_contraction_bounds.txt).
+//
+// K loop (round 2, second half): a K tile is consumed in two phases of 32 k.  The fragments of the NEXT phase are
+// read while the matrix cores work through the current one -- into the registers the MFMAs have just released,
+// plus one spare B fragment -- by inline-assembly ds_read_b128 / ds_read_b64_tr_b16 whose lgkmcnt the loop counts
+// itself (the compiler's waitcnt pass knows nothing of them, so no s_waitcnt it would place can serialise the
+// LDS-DMA ring).  The workgroup meets at ONE raw s_barrier per K tile, between the phases, behind a counted
+// s_waitcnt vmcnt(PWA) that leaves exactly the newest A tile in flight (__syncthreads() would drain every
+// LDS-DMA).  Before: 12 fragment reads, lgkmcnt(0), 32 MFMAs, twice per K tile, all 8 waves bursting at the LDS
+// together: MFMA busy 57 -> 61 %, P12 2.56 -> 2.39 ms, compute-only probe 1.85 -> 1.57 ms.
+// ABITS (bitmap operand): the bits of a tile are fetched by an inline-assembly global load two tiles ahead and
+// expanded to bf16 0 / 1 into the A ring by inline-assembly ds_write_b128 in the same slots; every vmcnt / lgkmcnt
+// of that path is counted by hand for the same reason.
 //
 // LDS images
 //   AT = false: A tile [256 rows][64 k] and B tile [BN rows][64 k], 128-byte rows, 16-byte chunk index
@@ -965,8 +974,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     constexpr int BST = (BN == 256) ? 2 : 3;                     // B ring depth
     constexpr int ASZ = BM * 8, BSZ = BN * 8;                   // u32x4 entries per buffer
     constexpr int PWA = BM / 64, PWB = BN / 64;                 // LDS-DMA instructions per wave and K tile
-    // instructions allowed to stay outstanding when the NEXT tile must be complete
-    constexpr int KEEP = ABITS ? ((BST == 3) ? PWB : 0) : ((BST == 3) ? (PWA + PWB) : PWA);
     HIP_DYNAMIC_SHARED(u32x4, smem)
 
     const int tid = threadIdx.x;
