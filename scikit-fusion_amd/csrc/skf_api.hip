@@ -262,7 +262,7 @@ static int pick_splits_bf16(int64_t units, int ktiles, int bm, int64_t out_elems
         if (s > 1 && ktiles / s < 4) break;
         const double rounds = (double)(int64_t)((double)units * s / slots + 0.999999);
         const double t = (rounds < 1.0 ? 1.0 : rounds) * ((ktiles + s - 1) / s + 3) * 1.5 + (s > 1 ? s * per_slice_us : 0.0);
-        if (t < best_t * (1.0 - 1e-9)) {
+        if (t < best_t * 0.97) {                                 // more slices only for a clear gain (HBM-bound launches have none)
             best_t = t;
             best = s;
         }
@@ -345,8 +345,8 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
 #undef SKF_V2_LAUNCH_BITS
     } else {
         dim3 block(256);
-        if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, 0>), grid, block, 0, st, g);
-        else hipLaunchKernelGGL((gemm_bf16_kernel<256, 0>), grid, block, 0, st, g);
+        if (bn == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, 0>), grid, block, (128 + 128) * 128, st, g);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<256, 0>), grid, block, (128 + 256) * 128, st, g);
     }
     check_launch("gemm_bf16");
     if (splits > 1) {
@@ -392,6 +392,7 @@ struct Switches {
     bool no_overlap = false;       // SKF_NO_OVERLAP=1      no second stream
     bool no_pipeline = false;      // SKF_NO_PIPELINE=1     staged schedule instead of the relation pipeline
     int side_tile = 0;             // SKF_SIDE_TILE=64|128  tile shape of the fused side update
+    int epi_tile = 128;            // SKF_EPI_TILE=256      completion / residual passes on the 256 x 256 tile (one workgroup per CU)
     static Switches read() {
         auto on = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
         Switches w;
@@ -405,6 +406,8 @@ struct Switches {
         w.no_pipeline = on("SKF_NO_PIPELINE");
         const char* st = getenv("SKF_SIDE_TILE");
         w.side_tile = st ? atoi(st) : 0;
+        const char* et = getenv("SKF_EPI_TILE");
+        w.epi_tile = (et && atoi(et) == 256) ? 256 : 128;
         return w;
     }
 };
@@ -1004,6 +1007,22 @@ static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t
     if (mode == MODE_COMPLETE && r.use_klist) {
         g.koff = (const uint32_t*)r.Koff.ptr;
         g.klist = (const uint32_t*)r.Klist.ptr;
+    }
+    if (p->sw.epi_tile == 128) {
+        // 128 relation columns x 256 relation rows per workgroup, 256 threads, 68 KiB of LDS: two workgroups per CU
+        dim3 grid(cdiv(nr, 256), cdiv(nj, 128));
+        const int smem = 256 * (128 + 8) * 2;
+        if (mode == MODE_COMPLETE) {
+            static std::once_flag once;
+            allow_dynamic_lds(once, gemm_bf16_kernel<256, 0, EPI_T_COMPLETE>, smem);
+            hipLaunchKernelGGL((gemm_bf16_kernel<256, 0, EPI_T_COMPLETE>), grid, dim3(256), smem, st, g);
+        } else {
+            static std::once_flag once;
+            allow_dynamic_lds(once, gemm_bf16_kernel<256, 0, EPI_T_SQERR>, smem);
+            hipLaunchKernelGGL((gemm_bf16_kernel<256, 0, EPI_T_SQERR>), grid, dim3(256), smem, st, g);
+        }
+        check_launch("tile_epilogue_bf16");
+        return;
     }
     dim3 grid(cdiv(nr, 256), cdiv(nj, 256));
     const int smem = (3 * 256 + 2 * 256) * 8 * 16;
@@ -1702,7 +1721,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             if (p->bf16 && r.mask) {
                 // known entries as compact per-tile lists, up to 1/8 of the relation (beyond that the completion
                 // blends through the mask): 4 bytes per entry = at most a quarter of the bf16 relation's bytes
-                const size_t tiles = (size_t)cdiv(nr, 256) * cdiv(tj.n, 256);
+                const size_t tiles = (size_t)cdiv(nr, 256) * cdiv(tj.n, 128);     // (128-column tiles: the finer grid)
                 r.kcap = (size_t)nr * tj.n / 8 + 4096;
                 add_slot(p, r.Kcnt, tiles * 4);
                 add_slot(p, r.Koff, (tiles + 1) * 4);
@@ -1826,13 +1845,15 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             }
             check_launch("pack_mask");
             if (p->bf16) {
-                // known entries of every 256 x 256 tile as a compact list (count, prefix sum on the host, fill)
-                const int tx = cdiv(rows, 256), ty = cdiv(cols, 256);
+                // known entries of every tile of the completion pass (256 rows x epi_tile columns) as a compact list
+                // (count, prefix sum on the host, fill)
+                const int tx = cdiv(rows, 256), ty = cdiv(cols, p->sw.epi_tile);
                 const size_t tiles = (size_t)tx * ty;
                 KnownArgs ka;
                 ka.mbits = (const uint8_t*)r.Mb.ptr; ka.ldmb = r.ldmb;
                 ka.Rin = (const uint16_t*)r.R_in; ka.ldin = r.ld_in;
                 ka.rows = (int)rows; ka.cols = (int)cols;
+                ka.tile_cols = p->sw.epi_tile;
                 ka.counts = (uint32_t*)r.Kcnt.ptr; ka.off = nullptr; ka.list = nullptr;
                 hipLaunchKernelGGL(known_entries_kernel, dim3(tx, ty), dim3(256), 0, st, ka);
                 check_launch("known_entries(count)");
@@ -2171,7 +2192,7 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
             // one pass over the stored bf16 relation: bf16 H and G_j on the matrix cores, f32 residual
             launch_tile_epilogue(p, r, MODE_SQERR, st);
             hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(1), dim3(256), 0, st, (const double*)p->sqpart.ptr,
-                               cdiv(ni, 256) * cdiv(nj, 256), out);
+                               cdiv(ni, 256) * cdiv(nj, p->sw.epi_tile), out);
             check_launch("sum_partials");
             return;
         }

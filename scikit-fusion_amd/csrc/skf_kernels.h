@@ -699,24 +699,40 @@ enum { EPI_T_STORE = 0, EPI_T_COMPLETE = 1, EPI_T_SQERR = 2 };
 
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return row * 8 + (chunk ^ (row & 7)); }
 
-template <int BN, int TAG>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16GemmArgs g) {
+constexpr int KPF = 3;       // known entries per thread that EPI_T_COMPLETE fetches before the K loop of its tile
+template <int NTHR>
+__device__ __forceinline__ void bf16_tile_prefetch_known(const Bf16GemmArgs& g, int tile, uint32_t& kq0, uint32_t& kq1,
+                                                         uint32_t (&kpre)[KPF]);
+template <int EPI, int BM, int BN, int NTHR, int NJ>
+__device__ __forceinline__ void bf16_tile_epilogue(const Bf16GemmArgs& g, f32x4 (&acc)[4][NJ], u32x4* smem, int bm0, int bn0,
+                                                   int tile, uint32_t kq0, uint32_t kq1, const uint32_t (&kpre)[KPF]);
+
+// 128 x BN tile, 4 waves, register-staged double buffering.  EPI_T_STORE: the P-type products of small problems.
+// EPI_T_COMPLETE / EPI_T_SQERR: the elementwise passes over a stored relation (see bf16_tile_epilogue) -- their K loop is
+// a handful of tiles and the phases of a tile (operand latency, MFMAs, staging, write-out) are serial inside a workgroup;
+// with 70 KiB of LDS and 256 threads TWO workgroups share a CU and one's write-out runs under the other's K loop.
+template <int BN, int TAG, int EPI = EPI_T_STORE>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
     constexpr int BM = 128, BK = 64;
     constexpr int WN = BN / 2;              // wave tile 64 x WN
     constexpr int NJ = WN / 16;             // 16-wide column blocks per wave
     constexpr int A_PER = BM * 8 / 256;     // 16-byte chunks per thread and tile
     constexpr int B_PER = BN * 8 / 256;
-    __shared__ u32x4 As[BM * 8];
-    __shared__ u32x4 Bs[BN * 8];
+    HIP_DYNAMIC_SHARED(u32x4, smem)          // (BM + BN) * 128 bytes of operand tiles; EPI_T_*: >= BN * (BM + 8) * 2 for the staged tile
+    u32x4* As = smem;
+    u32x4* Bs = smem + BM * 8;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * WN;
     const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;     // EPI_T_*: index of the tile in koff / sq
     const int kz0 = blockIdx.z * g.k_chunk;
     const int kz1 = (kz0 + g.k_chunk < g.Kp) ? kz0 + g.k_chunk : g.Kp;
     const int nkt = (kz1 - kz0) / BK;
     const int srow = tid >> 3, schunk = tid & 7;        // staging: 8 lanes per 128-byte row
+    uint32_t kq0 = 0u, kq1 = 0u, kpre[KPF] = {0u, 0u, 0u};
+    if constexpr (EPI == EPI_T_COMPLETE) bf16_tile_prefetch_known<256>(g, tile, kq0, kq1, kpre);
 
     f32x4 acc[4][NJ];
 #pragma unroll
@@ -777,6 +793,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Bf16GemmArgs g) {
         __syncthreads();
     }
 
+    if constexpr (EPI != EPI_T_STORE) {
+        // (the loop's last __syncthreads() has released the operand tiles: the staged tile may overwrite them)
+        bf16_tile_epilogue<EPI, BM, BN, 256, NJ>(g, acc, smem, bm0, bn0, tile, kq0, kq1, kpre);
+        return;
+    }
     // epilogue: D reg r of a 16 x 16 tile -> row = 4*(lane>>4) + r, col = lane & 15
     float* out = (gridDim.z > 1) ? g.part + (int64_t)blockIdx.z * g.M * g.N : g.C;
     const int64_t ldo = (gridDim.z > 1) ? g.N : g.ldc;
@@ -964,6 +985,177 @@ __device__ __forceinline__ u32x4 bits_to_bf16x8(uint32_t byte) {
     return v;
 }
 
+template <int NTHR>
+__device__ __forceinline__ void bf16_tile_prefetch_known(const Bf16GemmArgs& g, int tile, uint32_t& kq0, uint32_t& kq1,
+                                                         uint32_t (&kpre)[KPF]) {
+    kq0 = kq1 = 0u;
+#pragma unroll
+    for (int q = 0; q < KPF; ++q) kpre[q] = 0u;
+    if (g.klist != nullptr) {
+        kq0 = g.koff[tile];
+        kq1 = g.koff[tile + 1];
+#pragma unroll
+        for (int q = 0; q < KPF; ++q) {
+            const uint32_t k = kq0 + threadIdx.x + q * NTHR;
+            if (k < kq1) kpre[q] = __builtin_nontemporal_load(g.klist + k);
+        }
+    }
+}
+
+// Elementwise epilogues of the bf16 tile kernels (gemm_bf16_v2_kernel: BM = 256, 512 threads; gemm_bf16_kernel:
+// BM = 128, 256 threads -- two workgroups per CU, so that one tile's write-out runs under the other's K loop).
+// BM = tile rows = relation COLUMNS, BN = tile columns = relation ROWS; waves as (wave >> 1) x (wave & 1) of 64 x BN/2.
+template <int EPI, int BM, int BN, int NTHR, int NJ>
+__device__ __forceinline__ void bf16_tile_epilogue(const Bf16GemmArgs& g, f32x4 (&acc)[4][NJ], u32x4* smem, int bm0, int bn0,
+                                                   int tile, uint32_t kq0, uint32_t kq1, const uint32_t (&kpre)[KPF]) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * (BN / 2);
+    // The passes that touch a relation ELEMENTWISE against its reconstruction T = H G_j^T (K = c_j: a handful
+    // of K tiles -- the pass is bound by the relation's bytes).  The product is taken TRANSPOSED: the kernel's
+    // A operand is bf16(G_j) (tile rows = relation COLUMNS n), its Bt operand bf16(H) (tile columns = relation
+    // ROWS m), so that the four accumulator elements of a lane are four CONSECUTIVE columns of one relation row:
+    //   EPI_T_COMPLETE  DFMC completion (_dfmc.py:319-325): R[m][n] = bf16(T[m][n]) where the mask bit is set;
+    //                   the tile is staged as bf16 in LDS (one 8-byte store per 16 x 16 block and lane) and written
+    //                   as whole 16-byte chunks along the rows of R, the old chunk being read only when it holds
+    //                   a known entry to keep
+    //   EPI_T_SQERR     partial of sum (R - T)^2: the R tile is staged in LDS with coalesced 16-byte loads and
+    //                   every lane compares its accumulator elements with it (f32 product, stored bf16 entries)
+    // (the last barrier of the K loop has released the operand rings: the whole LDS is free)
+    constexpr int TLD = BM + 8;              // halfwords per staged relation row: 528 B (16-byte aligned rows)
+    constexpr int CH = BM / 8;               // 16-byte chunks per staged row
+    uint16_t* T = (uint16_t*)smem;           // T[m_loc][n_loc], m_loc < BN (relation rows), n_loc < BM (relation columns)
+    const int rel_rows = g.N, rel_cols = g.M, row0 = bn0, col0 = bm0;
+    if constexpr (EPI == EPI_T_COMPLETE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nl = wm0 + i * 16 + 4 * (lane >> 4), ml = wn0 + j * 16 + (lane & 15);
+                const uint32_t lo = (uint32_t)f32_to_bf16_rne(acc[i][j][0]) | ((uint32_t)f32_to_bf16_rne(acc[i][j][1]) << 16);
+                const uint32_t hi = (uint32_t)f32_to_bf16_rne(acc[i][j][2]) | ((uint32_t)f32_to_bf16_rne(acc[i][j][3]) << 16);
+                uint32_t* dst = (uint32_t*)(T + ml * TLD + nl);
+                dst[0] = lo; dst[1] = hi;
+            }
+        __syncthreads();
+        constexpr int NIT = BN * CH / NTHR;
+        if (g.klist != nullptr) {
+            // Known entries of this tile from their compact list straight into the staged tile, then EVERY chunk
+            // is written out: full-line streaming stores, no read of the old relation, no mask traffic
+            // (at 2 % known entries the blend below reads 3 of 4 lines of R back).
+#pragma unroll
+            for (int q = 0; q < KPF; ++q)
+                if (kq0 + tid + q * NTHR < kq1) T[((kpre[q] >> 8) & 0xFFu) * TLD + (kpre[q] & 0xFFu)] = (uint16_t)(kpre[q] >> 16);
+            for (uint32_t k = kq0 + tid + KPF * NTHR; k < kq1; k += NTHR) {
+                const uint32_t e = g.klist[k];
+                T[((e >> 8) & 0xFFu) * TLD + (e & 0xFFu)] = (uint16_t)(e >> 16);
+            }
+            __syncthreads();
+            constexpr int NB = 8;            // chunks out of LDS per batch (one wait), then their stores
+            static_assert(NIT % NB == 0, "write-out batches");
+#pragma unroll
+            for (int q0 = 0; q0 < NIT; q0 += NB) {
+            u32x4 tv[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int it = tid + (q0 + q) * NTHR;
+                tv[q] = *(const u32x4*)(T + (it / CH) * TLD + (it % CH) * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int it = tid + (q0 + q) * NTHR;
+                const int r = it / CH, c = it % CH;
+                const int left = rel_cols - (col0 + c * 8);           // columns of this chunk inside the relation
+                if (row0 + r >= rel_rows || left <= 0) continue;
+                u32x4 v = tv[q];
+                if (left < 8) {                                       // padding columns of R stay zero
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e >= left) v[e >> 1] &= ~(0xFFFFu << (16 * (e & 1)));
+                }
+#ifndef SKF_PROBE_NOSTORE
+                *(u32x4*)(g.R + (int64_t)(row0 + r) * g.ldr + col0 + c * 8) = v;
+#else
+                if (v[0] == 0x12345678u) *(u32x4*)(g.R + (int64_t)(row0 + r) * g.ldr + col0 + c * 8) = v;
+#endif
+            }
+            }
+        } else {
+        // item = 8 consecutive columns of one relation row; BM / 8 lanes cover the contiguous bytes of a tile row.
+        // All mask bytes of the thread first (independent loads, one wait), then the stores.
+        uint32_t mb[NIT];
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) {
+            const int it = tid + q * NTHR;
+            const int r = it / CH, c = it % CH;
+            const int m = row0 + r;
+            const bool in = m < rel_rows && (int64_t)(col0 >> 3) + c < g.ldmb;
+            mb[q] = in ? g.mbits[(int64_t)m * g.ldmb + (col0 >> 3) + c] : 0u;   // bit b: column col0 + 8c + b is unknown
+        }
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) {
+            if (mb[q] == 0u) continue;
+            const int it = tid + q * NTHR;
+            const int r = it / CH, c = it % CH;
+            u32x4 v = *(const u32x4*)(T + r * TLD + c * 8);
+            u32x4* dst = (u32x4*)(g.R + (int64_t)(row0 + r) * g.ldr + col0 + c * 8);
+            if (mb[q] != 0xFFu) {
+                const u32x4 old = *dst;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (!(mb[q] & (1u << e))) {
+                        const uint32_t sh = 16 * (e & 1), msk = 0xFFFFu << sh;
+                        v[e >> 1] = (v[e >> 1] & ~msk) | (old[e >> 1] & msk);
+                    }
+            }
+            *dst = v;
+        }
+        }
+    } else {
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        for (int it = tid; it < BN * CH; it += NTHR) {       // zero outside the stored matrix: never compared
+            const int r = it / CH, c = it % CH;
+            const int m = row0 + r;
+            const int64_t col = (int64_t)col0 + c * 8;
+            u32x4 v = zero;
+            if (g.Rbits != nullptr) {
+                if (m < rel_rows && (col >> 3) < g.ldrbits) v = bits_to_bf16x8(g.Rbits[(int64_t)m * g.ldrbits + (col >> 3)]);
+            } else if (m < rel_rows && col + 8 <= g.ldr) {
+                v = *(const u32x4*)(g.R + (int64_t)m * g.ldr + col);
+            }
+            *(u32x4*)(T + r * TLD + c * 8) = v;
+        }
+        __syncthreads();
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nl = wm0 + i * 16 + 4 * (lane >> 4), ml = wn0 + j * 16 + (lane & 15);
+                const uint32_t* src = (const uint32_t*)(T + ml * TLD + nl);
+                const uint32_t lo = src[0], hi = src[1];
+                const float rv[4] = {bf16_to_f32((uint16_t)(lo & 0xFFFFu)), bf16_to_f32((uint16_t)(lo >> 16)),
+                                     bf16_to_f32((uint16_t)(hi & 0xFFFFu)), bf16_to_f32((uint16_t)(hi >> 16))};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + ml < rel_rows && col0 + nl + r < rel_cols) {
+                        const float d = rv[r] - acc[i][j][r];
+                        sacc += d * d;
+                    }
+            }
+        const double ws = wave_sum((double)sacc);
+        __syncthreads();                     // every wave is done with T: its first bytes carry the wave sums now
+        double* wsum = (double*)smem;
+        if (lane == 0) wsum[wave] = ws;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < NTHR / 64; ++w) tot += wsum[w];
+            g.sq[tile] = tot;
+        }
+    }
+}
+
 template <int BN, int TAG, bool AT, int EPI = EPI_T_STORE, bool ABITS = false>
 __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     static_assert(EPI == EPI_T_STORE || (BN == 256 && !AT), "the elementwise epilogues use the 256 x 256 P-form tile");
@@ -985,20 +1177,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
     const int tile = blockIdx.y * gridDim.x + blockIdx.x;     // EPI_T_*: index of the tile in koff / sq
 
-    // EPI_T_COMPLETE: the first known entries of the tile (3 per thread: 1536 of on average 1300) travel while the K loop runs
-    constexpr int KPF = 3;
+    // EPI_T_COMPLETE: the first known entries of the tile (3 per thread) travel while the K loop runs
     uint32_t kq0 = 0u, kq1 = 0u, kpre[KPF] = {0u, 0u, 0u};
-    if constexpr (EPI == EPI_T_COMPLETE) {
-        if (g.klist != nullptr) {
-            kq0 = g.koff[tile];
-            kq1 = g.koff[tile + 1];
-#pragma unroll
-            for (int q = 0; q < KPF; ++q) {
-                const uint32_t k = kq0 + tid + q * 512;
-                if (k < kq1) kpre[q] = __builtin_nontemporal_load(g.klist + k);
-            }
-        }
-    }
+    if constexpr (EPI == EPI_T_COMPLETE) bf16_tile_prefetch_known<512>(g, tile, kq0, kq1, kpre);
 
     f32x4 acc[4][NJ];
 #pragma unroll
@@ -1301,149 +1482,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                     if (m < g.M && n < g.N) out[(int64_t)m * ldo + n] = acc[i][j][r];
                 }
     } else {
-        // The passes that touch a relation ELEMENTWISE against its reconstruction T = H G_j^T (K = c_j: a handful
-        // of K tiles -- the pass is bound by the relation's bytes).  The product is taken TRANSPOSED: the kernel's
-        // A operand is bf16(G_j) (tile rows = relation COLUMNS n), its Bt operand bf16(H) (tile columns = relation
-        // ROWS m), so that the four accumulator elements of a lane are four CONSECUTIVE columns of one relation row:
-        //   EPI_T_COMPLETE  DFMC completion (_dfmc.py:319-325): R[m][n] = bf16(T[m][n]) where the mask bit is set;
-        //                   the tile is staged as bf16 in LDS (one 8-byte store per 16 x 16 block and lane) and written
-        //                   as whole 16-byte chunks along the rows of R, the old chunk being read only when it holds
-        //                   a known entry to keep
-        //   EPI_T_SQERR     partial of sum (R - T)^2: the R tile is staged in LDS with coalesced 16-byte loads and
-        //                   every lane compares its accumulator elements with it (f32 product, stored bf16 entries)
-        // (the last barrier of the K loop has released the operand rings: the whole LDS is free)
-        constexpr int TLD = BM + 8;              // halfwords per staged relation row: 528 B (16-byte aligned rows)
-        constexpr int CH = BM / 8;               // 16-byte chunks per staged row
-        uint16_t* T = (uint16_t*)smem;           // T[m_loc][n_loc], m_loc < BN (relation rows), n_loc < BM (relation columns)
-        const int rel_rows = g.N, rel_cols = g.M, row0 = bn0, col0 = bm0;
-        if constexpr (EPI == EPI_T_COMPLETE) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int nl = wm0 + i * 16 + 4 * (lane >> 4), ml = wn0 + j * 16 + (lane & 15);
-                    const uint32_t lo = (uint32_t)f32_to_bf16_rne(acc[i][j][0]) | ((uint32_t)f32_to_bf16_rne(acc[i][j][1]) << 16);
-                    const uint32_t hi = (uint32_t)f32_to_bf16_rne(acc[i][j][2]) | ((uint32_t)f32_to_bf16_rne(acc[i][j][3]) << 16);
-                    uint32_t* dst = (uint32_t*)(T + ml * TLD + nl);
-                    dst[0] = lo; dst[1] = hi;
-                }
-            __syncthreads();
-            constexpr int NIT = BN * CH / 512;
-            if (g.klist != nullptr) {
-                // Known entries of this tile from their compact list straight into the staged tile, then EVERY chunk
-                // is written out: full-line streaming stores, no read of the old relation, no mask traffic
-                // (at 2 % known entries the blend below reads 3 of 4 lines of R back).
-#pragma unroll
-                for (int q = 0; q < KPF; ++q)
-                    if (kq0 + tid + q * 512 < kq1) T[((kpre[q] >> 8) & 0xFFu) * TLD + (kpre[q] & 0xFFu)] = (uint16_t)(kpre[q] >> 16);
-                for (uint32_t k = kq0 + tid + KPF * 512; k < kq1; k += 512) {
-                    const uint32_t e = g.klist[k];
-                    T[((e >> 8) & 0xFFu) * TLD + (e & 0xFFu)] = (uint16_t)(e >> 16);
-                }
-                __syncthreads();
-                constexpr int NB = 8;            // chunks out of LDS per batch (one wait), then their stores
-                static_assert(NIT % NB == 0, "write-out batches");
-#pragma unroll
-                for (int q0 = 0; q0 < NIT; q0 += NB) {
-                u32x4 tv[NB];
-#pragma unroll
-                for (int q = 0; q < NB; ++q) {
-                    const int it = tid + (q0 + q) * 512;
-                    tv[q] = *(const u32x4*)(T + (it / CH) * TLD + (it % CH) * 8);
-                }
-#pragma unroll
-                for (int q = 0; q < NB; ++q) {
-                    const int it = tid + (q0 + q) * 512;
-                    const int r = it / CH, c = it % CH;
-                    const int left = rel_cols - (col0 + c * 8);           // columns of this chunk inside the relation
-                    if (row0 + r >= rel_rows || left <= 0) continue;
-                    u32x4 v = tv[q];
-                    if (left < 8) {                                       // padding columns of R stay zero
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (e >= left) v[e >> 1] &= ~(0xFFFFu << (16 * (e & 1)));
-                    }
-#ifndef SKF_PROBE_NOSTORE
-                    *(u32x4*)(g.R + (int64_t)(row0 + r) * g.ldr + col0 + c * 8) = v;
-#else
-                    if (v[0] == 0x12345678u) *(u32x4*)(g.R + (int64_t)(row0 + r) * g.ldr + col0 + c * 8) = v;
-#endif
-                }
-                }
-            } else {
-            // item = 8 consecutive columns of one relation row; 32 lanes cover the 512 contiguous bytes of a tile row.
-            // All mask bytes of the thread first (independent loads, one wait), then the stores.
-            uint32_t mb[NIT];
-#pragma unroll
-            for (int q = 0; q < NIT; ++q) {
-                const int it = tid + q * 512;
-                const int r = it / CH, c = it % CH;
-                const int m = row0 + r;
-                const bool in = m < rel_rows && (int64_t)(col0 >> 3) + c < g.ldmb;
-                mb[q] = in ? g.mbits[(int64_t)m * g.ldmb + (col0 >> 3) + c] : 0u;   // bit b: column col0 + 8c + b is unknown
-            }
-#pragma unroll
-            for (int q = 0; q < NIT; ++q) {
-                if (mb[q] == 0u) continue;
-                const int it = tid + q * 512;
-                const int r = it / CH, c = it % CH;
-                u32x4 v = *(const u32x4*)(T + r * TLD + c * 8);
-                u32x4* dst = (u32x4*)(g.R + (int64_t)(row0 + r) * g.ldr + col0 + c * 8);
-                if (mb[q] != 0xFFu) {
-                    const u32x4 old = *dst;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (!(mb[q] & (1u << e))) {
-                            const uint32_t sh = 16 * (e & 1), msk = 0xFFFFu << sh;
-                            v[e >> 1] = (v[e >> 1] & ~msk) | (old[e >> 1] & msk);
-                        }
-                }
-                *dst = v;
-            }
-            }
-        } else {
-            const u32x4 zero = {0u, 0u, 0u, 0u};
-            for (int it = tid; it < BN * CH; it += 512) {       // zero outside the stored matrix: never compared
-                const int r = it / CH, c = it % CH;
-                const int m = row0 + r;
-                const int64_t col = (int64_t)col0 + c * 8;
-                u32x4 v = zero;
-                if (g.Rbits != nullptr) {
-                    if (m < rel_rows && (col >> 3) < g.ldrbits) v = bits_to_bf16x8(g.Rbits[(int64_t)m * g.ldrbits + (col >> 3)]);
-                } else if (m < rel_rows && col + 8 <= g.ldr) {
-                    v = *(const u32x4*)(g.R + (int64_t)m * g.ldr + col);
-                }
-                *(u32x4*)(T + r * TLD + c * 8) = v;
-            }
-            __syncthreads();
-            float sacc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int nl = wm0 + i * 16 + 4 * (lane >> 4), ml = wn0 + j * 16 + (lane & 15);
-                    const uint32_t* src = (const uint32_t*)(T + ml * TLD + nl);
-                    const uint32_t lo = src[0], hi = src[1];
-                    const float rv[4] = {bf16_to_f32((uint16_t)(lo & 0xFFFFu)), bf16_to_f32((uint16_t)(lo >> 16)),
-                                         bf16_to_f32((uint16_t)(hi & 0xFFFFu)), bf16_to_f32((uint16_t)(hi >> 16))};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (row0 + ml < rel_rows && col0 + nl + r < rel_cols) {
-                            const float d = rv[r] - acc[i][j][r];
-                            sacc += d * d;
-                        }
-                }
-            const double ws = wave_sum((double)sacc);
-            __syncthreads();                     // every wave is done with T: its first bytes carry the wave sums now
-            double* wsum = (double*)smem;
-            if (lane == 0) wsum[wave] = ws;
-            __syncthreads();
-            if (tid == 0) {
-                double tot = 0.0;
-                for (int w = 0; w < 8; ++w) tot += wsum[w];
-                g.sq[tile] = tot;
-            }
-        }
+        bf16_tile_epilogue<EPI, BM, BN, 512, NJ>(g, acc, smem, bm0, bn0, tile, kq0, kq1, kpre);
     }
 }
 
@@ -1720,18 +1759,20 @@ struct KnownArgs {
     uint32_t* counts;
     const uint32_t* off;
     uint32_t* list;
+    int tile_cols;           // 256 or 128: columns per tile (rows per tile: 256)
 };
 __global__ __launch_bounds__(256) void known_entries_kernel(KnownArgs a) {
     __shared__ uint32_t cnt;
     const int tid = threadIdx.x;
-    const int row0 = blockIdx.x * 256, col0 = blockIdx.y * 256;
+    const int wpr = a.tile_cols >> 5;                         // 32-column words per tile row
+    const int row0 = blockIdx.x * 256, col0 = blockIdx.y * a.tile_cols;
     const int tile = blockIdx.y * gridDim.x + blockIdx.x;
     if (tid == 0) cnt = 0u;
     __syncthreads();
     const uint32_t base = a.list ? a.off[tile] : 0u;
     uint32_t mine = 0u;
-    for (int it = tid; it < 256 * 8; it += 256) {          // (row, 32-column word) items
-        const int r = it >> 3, w = it & 7;
+    for (int it = tid; it < 256 * wpr; it += 256) {        // (row, 32-column word) items
+        const int r = it / wpr, w = it % wpr;
         const int m = row0 + r, c0 = col0 + 32 * w;
         if (m >= a.rows || c0 >= a.cols || (int64_t)(c0 >> 3) + 4 > a.ldmb) continue;
         const uint32_t word = *(const uint32_t*)(a.mbits + (int64_t)m * a.ldmb + (c0 >> 3));
