@@ -1,0 +1,20 @@
+#!/bin/bash
+# Text summaries for profiles/ from the outputs of a GPU session (tools/gpu_round2.sh <name> smoke tests_all dist_smoke
+# fullbench prof_bf16 c5_bf16 c5prof_bf16):   tools/refresh_profiles.sh <name> [round-prefix]
+cd "$(dirname "$0")/.."
+G=gpurun_out/$1; R=${2:-r02}
+{ echo "# rocprofv3 --kernel-trace, bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-engines (config 3 full size, the bf16 leg of the default bench.py run: 7 iterations + set-up), final build of the round"
+  python tools/rocpd_summary.py $G/prof_bf16/prof_results.db 40; echo
+  echo "# one iteration as a timeline (tools/timeline.py): start offset, duration, stream (s1 = main, s2 = second stream), grid"
+  python tools/timeline.py $G/prof_bf16/prof_results.db 3; } > profiles/${R}_bf16_kernel_stats.txt
+{ echo "# rocprofv3 --kernel-trace, bench.py --workload c5 --dtype bf16 --steps 3 --warmup 1 (config 5 full size, 4 iterations + set-up incl. torch data generation), final build of the round"
+  python tools/rocpd_summary.py $G/c5prof_bf16/prof_results.db 45; echo
+  echo "# one iteration as a timeline (tools/timeline.py)"
+  python tools/timeline.py $G/c5prof_bf16/prof_results.db 6; } > profiles/${R}_c5_bf16_kernel_stats.txt
+grep '^{' $G/bench_full.log > profiles/${R}_bf16_bench.json
+grep '^{' $G/c5_bf16.log > profiles/${R}_c5_bf16_bench.json
+{ echo "# python -m pytest tests -m gpu -q --durations=10 on the MI355X box (final build of the round)"; tail -22 $G/pytest.log; } > profiles/${R}_pytest_gpu.log
+cp gpurun_out/test_deviations.txt profiles/${R}_test_deviations.txt
+{ echo "# bench.py --gpus 2 (self-launched through torch.distributed.run) on the one-GPU box, two ranks sharing GPU 0 over a gloo group (SKF_BENCH_BACKEND=gloo): every multi-GPU mode end to end; the throughput of two ranks on one GPU is not a scaling number"
+  grep -h "^dist\|^{" $G/summary.txt | grep -A1 "^dist" | grep -v "^--" | cut -c1-700; } > profiles/${R}_dist_smoke.txt
+ls -la profiles/${R}_*
