@@ -24,10 +24,11 @@ The JSON line also carries
                  engine reads every relation once per contraction, i.e. TWICE per iteration (a fused
                  P+Q pass has to spill one of the two outputs as partial sums, which costs more than
                  the second read): 215 flop/B as scheduled, below the ridge -> bound = "hbm".
-                 achieved = algorithmic bytes per launch / average launch time; `traffic` = the bytes
-                 one launch is SCHEDULED to move from HBM (relation once, G^T once per XCD, output),
-                 not a counter reading (PMC passes: profiles/); `mfma` and `hbm_scheduled` give the
-                 other two views of the same launches.
+                 achieved = algorithmic bytes per launch / average launch time; `traffic` = HBM bytes
+                 per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command
+                 (profiles/pmc_traffic.json; null for a workload / size without a committed pass),
+                 `traffic_scheduled` = the bytes a launch is scheduled to move (relation once, G^T once
+                 per XCD, output); `mfma` and `hbm_scheduled` give the other two views of the launches.
   engines      : short runs (3 steps) of the f32 and f64 engines on the same graph (the reference's
                  own arithmetic is f64), default single-GPU run only.
   cpu_baseline : the NumPy oracle (reference operation order, fp64, all host cores): ONE iteration at FULL size
@@ -161,7 +162,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achi
 RIDGE = {'bf16': 2500e12 / 8e12, 'f32': 157.3e12 / 8e12, 'f64': 78.6e12 / 8e12}     # flop per HBM byte
 
 
-def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, elapsed):
+def measured_traffic(dtype, c5, scale):
+    """HBM bytes per contraction launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE in passes of their own over this very command, FETCH_SIZE with the gfx950 x2 correction), or None: the
+    counters cannot be read from inside the timed run."""
+    if c5 or scale != 1.0:
+        return None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')) as f:
+            e = json.load(f).get('%s_round2' % dtype)
+        return {'bytes': float(e['fetch_bytes_per_launch']) + float(e['write_bytes_per_launch']), 'source': e['source']} if e else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, elapsed, pmc=None):
     """SURVEY.md 8(d) accounting of the relation-contraction launches (see the module docstring)."""
     esz = {'bf16': 2, 'f32': 4, 'f64': 8}[dtype]
     msz = 4 if dtype != 'f64' else 8                       # master type of P / Q
@@ -194,9 +209,14 @@ def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, ela
     sched_gbs = sched_iter * iters / sec / 1e9
     rec['mfma'] = {'achieved': mfma_tf, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': mfma_tf / peak_tf}
     rec['hbm_scheduled'] = {'achieved': sched_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': sched_gbs / HBM_PEAK_GBS}
-    rec['traffic'] = sched_iter / per_iter
-    rec['traffic_kind'] = 'scheduled bytes per launch (relation once per contraction + G^T once per XCD + output), not a counter; rocprofv3 --pmc passes: profiles/'
-    rec['traffic_ratio'] = sched_iter / alg_bytes_iter
+    rec['traffic_scheduled'] = sched_iter / per_iter        # relation once per contraction + G^T once per XCD + output
+    if pmc:
+        rec['traffic'] = pmc['bytes']
+        rec['traffic_kind'] = 'HBM bytes per launch from PMC counters: ' + pmc['source']
+    else:
+        rec['traffic'] = None
+        rec['traffic_kind'] = 'no counter pass committed for this workload / size (scheduled bytes per launch: traffic_scheduled)'
+    rec['traffic_ratio'] = (pmc['bytes'] if pmc else sched_iter / per_iter) / (alg_bytes_iter / per_iter)
     rec['alg_bytes_per_launch'] = alg_bytes_iter / per_iter
     if bound == 'hbm':
         rec.update({'bound': 'hbm', 'achieved': alg_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_gbs / HBM_PEAK_GBS})
@@ -476,7 +496,8 @@ def main():
         how = {'restarts': 'one random restart per GPU',
                'relations': 'one fit, whole relations partitioned over the GPUs',
                'rows': 'one fit, balanced row blocks of the relations over the GPUs'}[args.mode]
-        roof = roofline_record(args.dtype, n, ranks_, spec, k_ms, k_launches, k_flops, args.steps, elapsed)
+        roof = roofline_record(args.dtype, n, ranks_, spec, k_ms, k_launches, k_flops, args.steps, elapsed,
+                               measured_traffic(args.dtype, c5, args.scale))
         out = {
             'metric': ('DFMC update iters/sec (+ RMSE), MovieLens-style 6-relation graph with masks and constraints'
                        if c5 else

@@ -27,7 +27,15 @@ def test_algorithmic_work_of_config_3_and_5():
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert r['achieved'] == pytest.approx(22e9 / 12e-3 / 1e9)                      # one iteration = 6 launches, 12 ms
     assert r['frac'] == pytest.approx(r['achieved'] / 8000.0)
-    assert 2.0 < r['traffic_ratio'] < 2.2 and r['traffic'] * 6 == pytest.approx(r['traffic_ratio'] * 22e9)
+    # without a committed counter pass `traffic` is null and the scheduled bytes are reported beside it
+    assert r['traffic'] is None and 2.0 < r['traffic_ratio'] < 2.2
+    assert r['traffic_scheduled'] * 6 == pytest.approx(r['traffic_ratio'] * 22e9)
+    # with the rocprofv3 --pmc passes of profiles/pmc_traffic.json (config 3 at full size only): measured bytes per launch
+    pmc = bench.measured_traffic('bf16', False, 1.0)
+    assert pmc is not None and 7e9 < pmc['bytes'] < 9e9 and 'FETCH_SIZE' in pmc['source']
+    assert bench.measured_traffic('bf16', True, 1.0) is None and bench.measured_traffic('bf16', False, 0.1) is None
+    rp = bench.roofline_record('bf16', bench.FULL, bench.RANKS, spec3, 12.0, 6, 9.472e12, 1, 0.015, pmc)
+    assert rp['traffic'] == pmc['bytes'] and rp['traffic_ratio'] == pytest.approx(pmc['bytes'] * 6 / 22e9)
     assert r['intensity_algorithmic'] == pytest.approx(9.472e12 / 22e9) and r['intensity_scheduled'] < r['ridge']
     assert r['mfma']['achieved'] == pytest.approx(9.472e12 / 12e-3 / 1e12) and r['mfma']['peak'] == 2500.0
     assert r['whole_iteration']['mfma_frac'] == pytest.approx(9.472e12 / 0.015 / 1e12 / 2500.0)
