@@ -580,6 +580,11 @@ static void mixed_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
     run_gemm(GemmTypes{p->mt, p->mt, SKF_F64}, p->engine, g, 0, p->part.ptr, p->part_bytes, st);
 }
 
+// the same on the second stream: one K slice (the split-K scratch belongs to the main stream)
+static void mixed_gemm_unsplit(skf_plan* p, GemmArgs g, hipStream_t st) {
+    run_gemm(GemmTypes{p->mt, p->mt, SKF_F64}, p->engine, g, 1, nullptr, 0, st);
+}
+
 static hipEvent_t next_event(skf_plan* p) {
     if (p->ev_used == p->ev_pool.size()) {
         hipEvent_t e;
@@ -899,25 +904,28 @@ static void contraction_Q(skf_plan* p, RelState& r, hipStream_t st) {      // Q 
     relation_gemm(p, g, st, &r, true);
 }
 
+// DFMC, first iteration: the unknown entries of every masked relation start at zero (_dfmc.py:287-292)
+static void zero_unknown_entries(skf_plan* p, hipStream_t st) {
+    for (RelState& r : p->rels) {
+        if (!r.mask) continue;
+        const int64_t rows = r.nr, cols = p->types[r.col].n;
+        if (p->bf16)
+            hipLaunchKernelGGL((mask_zero_kernel<uint16_t>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
+                               (uint16_t*)r.Rb.ptr, r.ldrb, (const uint8_t*)r.Mb.ptr, r.ldmb, rows, cols);
+        else if (p->f64)
+            hipLaunchKernelGGL((mask_zero_kernel<double>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
+                               (double*)r.Rw.ptr, r.ldr, (const uint8_t*)r.Mb.ptr, r.ldmb, rows, cols);
+        else
+            hipLaunchKernelGGL((mask_zero_kernel<float>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
+                               (float*)r.Rw.ptr, r.ldr, (const uint8_t*)r.Mb.ptr, r.ldmb, rows, cols);
+        check_launch("mask_zero");
+    }
+}
+
 // Stage 1 of an iteration (SKF_STAGE_CONTRACT): everything that depends on G only.
 static void stage_contract(skf_plan* p, hipStream_t st) {
     const bool dfmc = (p->variant == SKF_DFMC);
-    if (dfmc && p->first_iter) {            // _dfmc.py:287-292
-        for (RelState& r : p->rels) {
-            if (!r.mask) continue;
-            const int64_t rows = r.nr, cols = p->types[r.col].n;
-            if (p->bf16)
-                hipLaunchKernelGGL((mask_zero_kernel<uint16_t>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
-                                   (uint16_t*)r.Rb.ptr, r.ldrb, (const uint8_t*)r.Mb.ptr, r.ldmb, rows, cols);
-            else if (p->f64)
-                hipLaunchKernelGGL((mask_zero_kernel<double>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
-                                   (double*)r.Rw.ptr, r.ldr, (const uint8_t*)r.Mb.ptr, r.ldmb, rows, cols);
-            else
-                hipLaunchKernelGGL((mask_zero_kernel<float>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
-                                   (float*)r.Rw.ptr, r.ldr, (const uint8_t*)r.Mb.ptr, r.ldmb, rows, cols);
-            check_launch("mask_zero");
-        }
-    }
+    if (dfmc && p->first_iter) zero_unknown_entries(p, st);
     p->first_iter = false;
 
     std::vector<int> all;
@@ -988,11 +996,17 @@ static void stage_contract(skf_plan* p, hipStream_t st) {
 // SKF_BF16: one elementwise pass over the stored relation against its reconstruction H G_j^T (r.H = G_i S must
 // be current): DFMC completion of the unknown entries, or the squared residual into p->sqpart (one f64 per tile)
 enum { MODE_COMPLETE = 0, MODE_SQERR = 1 };
-static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t st) {
+static void tile_epilogue_operands(skf_plan* p, RelState& r, hipStream_t st) {      // bf16 H and G_j of the tile kernels
     TypeState& tj = p->types[r.col];
     const int nr = (int)r.nr, nj = (int)tj.n, cj = tj.c;
     launch_to_bf16<float>((uint16_t*)r.Hb.ptr, r.ldhb, (const float*)r.H.ptr, (int64_t)cj, nr, cj, false, st);
     launch_to_bf16<float>((uint16_t*)r.Gb.ptr, r.ldhb, (const float*)tj.G.ptr, (int64_t)cj, nj, cj, false, st);
+}
+
+static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t st, bool operands = true) {
+    TypeState& tj = p->types[r.col];
+    const int nr = (int)r.nr, nj = (int)tj.n, cj = tj.c;
+    if (operands) tile_epilogue_operands(p, r, st);
     Bf16GemmArgs g;
     memset(&g, 0, sizeof g);
     // transposed product: tile rows = relation columns (A = bf16 G_j), tile columns = relation rows (Bt = bf16 H)
@@ -1289,26 +1303,46 @@ static void apply_update(skf_plan* p, hipStream_t st) {
 // only the order in which the relations add into E / D differs (relations are walked cheapest-last).
 // ------------------------------------------------------------------------------------------
 static bool can_pipeline(const skf_plan* p) {
-    if (!p->overlap || p->sliced || p->variant != SKF_DFMF || p->engine != SKF_ENGINE_MFMA || !p->pipeline) return false;
+    if (!p->overlap || p->sliced || p->engine != SKF_ENGINE_MFMA || !p->pipeline) return false;
+    if (p->variant != SKF_DFMF && p->variant != SKF_DFMC) return false;
     if (p->rels.empty() || p->rels.size() > 64) return false;
     for (const ThetaState& th : p->thetas)
         if (!th.sparse) return false;            // (dense constraint products share the split-K scratch of the main stream)
-    for (const TypeState& t : p->types)
-        if (t.c <= SMALLC || t.c > 512) return false;
+    // every rank <= 64: the one-workgroup chains of the staged schedule are the faster path (launch-bound graphs);
+    // above 512 (DFMC: 256) a c x c product on the second stream could ask for the main stream's split-K scratch
+    const int cmax = (p->variant == SKF_DFMC) ? 256 : 512;
+    bool all_small = true;
+    for (const TypeState& t : p->types) {
+        if (t.c > cmax) return false;
+        if (t.c > SMALLC) all_small = false;
+    }
+    if (all_small) return false;
+    if (p->variant == SKF_DFMF)
+        for (const TypeState& t : p->types)
+            if (t.c <= SMALLC) return false;     // (DFMF: the mixed case stays on the schedule it was measured on)
     for (const RelState& r : p->rels)
-        if (r.absent || r.masked) return false;
+        if (r.absent || (r.masked && p->variant != SKF_DFMC)) return false;
     return true;
 }
 
+// DFMC adds one dependency to the pipeline: a masked relation is contracted once BEFORE its completion (W = G_i^T R G_j
+// of the backbone, _dfmc.py:311-314) and twice after it (_dfmc.py:319-325, 341-345).  Main stream: Gram products; the
+// first contraction and W of every masked relation; P, W, Q of the unmasked relations; then completion, P, Q of the
+// masked ones -- by then their backbones and reconstruction operands, computed on the second stream underneath the
+// unmasked relations' contractions, are long done.
 static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
     const size_t nt = p->types.size(), nr = p->rels.size();
     hipStream_t ax = p->aux;
-    const int nan_upd = 1;                                   // DFMF: nan_to_num on the A/B/C/D terms (_dfmf.py:254-276)
+    const bool dfmc = (p->variant == SKF_DFMC);
+    const int nan_upd = dfmc ? 0 : 1;             // DFMF: nan_to_num on the A/B/C/D terms (_dfmf.py:254-276); DFMC: none (_dfmc.py:127-178)
+    if (dfmc && p->first_iter) zero_unknown_entries(p, st);
     p->first_iter = false;
-    if (p->ev_rel.size() < 2 * nr) {              // per relation: P and W done | Q done
+    // per relation: [0] first contraction and W done (main) | [1] backbone and reconstruction operands done (second
+    // stream, masked relations) | [2] P done (main) | [3] Q done (main)
+    if (p->ev_rel.size() < 4 * nr) {
         const size_t old = p->ev_rel.size();
-        p->ev_rel.resize(2 * nr);
-        for (size_t k = old; k < 2 * nr; ++k) SKF_HIP(hipEventCreateWithFlags(&p->ev_rel[k], hipEventDisableTiming));
+        p->ev_rel.resize(4 * nr);
+        for (size_t k = old; k < 4 * nr; ++k) SKF_HIP(hipEventCreateWithFlags(&p->ev_rel[k], hipEventDisableTiming));
     }
     // order of the relations: most expensive first, so that the exposed tail belongs to the cheapest one
     std::vector<size_t> order(nr);
@@ -1362,45 +1396,109 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         }
         side_update(p, nullptr, 0, 0, nullptr, 0, 0, t, t.G.ptr, t.E.ptr, t.D.ptr, (int)t.n, Bn, Bp, true, true, 0, ax);
     };
-    for (size_t q = 0; q < nr; ++q) {
+    std::vector<const void*> Sm(nr, nullptr);     // the backbone in the master type, per position in `order`
+    // second stream, behind event [0] of the relation: S = K_i W K_j, its B / D terms, the rounding of S
+    auto backbone_chain = [&](size_t q) {
         RelState& r = p->rels[order[q]];
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
-        const int ni = (int)r.nr, nj = (int)tj.n, ci = ti.c, cj = tj.c;
-        // ---- main stream: the products that stream the relation, and W = G_i^T P.  W goes out between P and Q: the
-        // backbone chain and the row side of the relation then run underneath its OWN Q (for the last relation the
-        // exposed tail is the column side only)
-        contraction_P(p, r, st);
-        GemmArgs g = gemm_args(ti.G.ptr, 1, ci, r.P.ptr, cj, 1, r.W.ptr, cj, ci, cj, ni, EPI_STORE, 0);
-        wide_gemm(p, g, st);
-        SKF_HIP(hipEventRecord(p->ev_rel[2 * q], st));
-        contraction_Q(p, r, st);
-        SKF_HIP(hipEventRecord(p->ev_rel[2 * q + 1], st));
-        // ---- second stream: everything else of this relation
-        SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[2 * q], 0));
-        g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);       // T1 = K_i W
+        const int ci = ti.c, cj = tj.c;
+        SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[4 * q], 0));
+        GemmArgs g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);       // T1 = K_i W
         small_gemm(p, g, ax);
-        g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);       // S = T1 K_j
+        g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);                // S = T1 K_j
         small_gemm(p, g, ax);
         relation_small_terms(p, r, nan_upd, EPI_SPLIT_ACC, ti.Bp_tot.ptr, ti.Bn_tot.ptr, tj.Bp_tot.ptr, tj.Bn_tot.ptr,
                              true, true, ax);
-        const void* Sm = r.S.ptr;
+        Sm[q] = r.S.ptr;
         if (!p->f64) {
             hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid((int64_t)ci * cj)), dim3(256), 0, ax,
                                (float*)r.S32.ptr, (int64_t)cj, (const double*)r.S.ptr, (int64_t)cj, (int64_t)ci, (int64_t)cj);
             check_launch("cast");
-            Sm = r.S32.ptr;
+            Sm[q] = r.S32.ptr;
         }
-        // row side: E_i (+)= (P S^T)+, D_i (+)= (P S^T)-;  column side: E_j (+)= (Q S)+, D_j (+)= (Q S)-
-        side_update(p, r.P.ptr, cj, cj, Sm, 1, cj, ti, ti.G.ptr, ti.E.ptr, ti.D.ptr, ni, nullptr, nullptr, false,
+    };
+    // second stream: the two side products of the relation behind `ev_p` (P) and event [3] (Q), then the type terms
+    // row side: E_i (+)= (P S^T)+, D_i (+)= (P S^T)-;  column side: E_j (+)= (Q S)+, D_j (+)= (Q S)-
+    auto side_products = [&](size_t q, size_t ev_p) {
+        RelState& r = p->rels[order[q]];
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        const int ni = (int)r.nr, nj = (int)tj.n, ci = ti.c, cj = tj.c;
+        SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[ev_p], 0));
+        side_update(p, r.P.ptr, cj, cj, Sm[q], 1, cj, ti, ti.G.ptr, ti.E.ptr, ti.D.ptr, ni, nullptr, nullptr, false,
                     touched[r.row] != 0, nan_upd, ax);
         touched[r.row] = 1;
-        SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[2 * q + 1], 0));
-        side_update(p, r.Q.ptr, ci, ci, Sm, cj, 1, tj, tj.G.ptr, tj.E.ptr, tj.D.ptr, nj, nullptr, nullptr, false,
+        SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[4 * q + 3], 0));
+        side_update(p, r.Q.ptr, ci, ci, Sm[q], cj, 1, tj, tj.G.ptr, tj.E.ptr, tj.D.ptr, nj, nullptr, nullptr, false,
                     touched[r.col] != 0, nan_upd, ax);
         touched[r.col] = 1;
         if (--rels_left[r.row] == 0) type_term(r.row);
         if (--rels_left[r.col] == 0) type_term(r.col);
+    };
+    auto w_product = [&](RelState& r, bool by_q) {        // W = G_i^T P, or (R^T G_i)^T G_j through the narrower factor
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        GemmArgs g = by_q ? gemm_args(r.Q.ptr, 1, ti.c, tj.G.ptr, tj.c, 1, r.W.ptr, tj.c, ti.c, tj.c, (int)tj.n, EPI_STORE, 0)
+                          : gemm_args(ti.G.ptr, 1, ti.c, r.P.ptr, tj.c, 1, r.W.ptr, tj.c, ti.c, tj.c, (int)r.nr, EPI_STORE, 0);
+        wide_gemm(p, g, st);
+    };
+
+    // ---- masked relations (DFMC), before their completion: the contraction W needs; second stream: backbone, H = G_i S
+    for (size_t q = 0; q < nr; ++q) {
+        RelState& r = p->rels[order[q]];
+        if (!(dfmc && r.masked)) continue;
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        const bool by_q = ti.c < tj.c;
+        if (by_q) contraction_Q(p, r, st);
+        else contraction_P(p, r, st);
+        w_product(r, by_q);
+        SKF_HIP(hipEventRecord(p->ev_rel[4 * q], st));
+        backbone_chain(q);
+        GemmArgs g = gemm_args(ti.G.ptr, ti.c, 1, r.S.ptr, tj.c, 1, r.H.ptr, tj.c, (int)r.nr, tj.c, ti.c, EPI_STORE, 0);
+        mixed_gemm_unsplit(p, g, ax);
+        if (p->bf16 && r.mask) tile_epilogue_operands(p, r, ax);
+        SKF_HIP(hipEventRecord(p->ev_rel[4 * q + 1], ax));
+    }
+    // ---- unmasked relations: P, W, Q on the main stream.  W goes out between P and Q: the backbone chain and the row
+    // side of the relation then run underneath its OWN Q (for the last relation the exposed tail is the column side only).
+    // (DFMC: putting the cheap half of them behind the completion block, to shorten the exposed tail, measured equal --
+    // their chains are latency-bound and hide better under the large launches; profiles/r02_pipeline_ab.txt.)
+    for (size_t q = 0; q < nr; ++q) {
+        RelState& r = p->rels[order[q]];
+        if (dfmc && r.masked) continue;
+        contraction_P(p, r, st);
+        w_product(r, false);
+        SKF_HIP(hipEventRecord(p->ev_rel[4 * q], st));
+        contraction_Q(p, r, st);
+        SKF_HIP(hipEventRecord(p->ev_rel[4 * q + 3], st));
+        backbone_chain(q);
+        side_products(q, 4 * q);
+    }
+    // ---- masked relations: completion (_dfmc.py:319-325), then the two contractions of the G update
+    for (size_t q = 0; q < nr; ++q) {
+        RelState& r = p->rels[order[q]];
+        if (!(dfmc && r.masked)) continue;
+        TypeState& tj = p->types[r.col];
+        SKF_HIP(hipStreamWaitEvent(st, p->ev_rel[4 * q + 1], 0));
+        if (r.mask) {
+            if (p->bf16) {
+                launch_tile_epilogue(p, r, MODE_COMPLETE, st, false);
+            } else {
+                GemmArgs g = gemm_args(r.H.ptr, tj.c, 1, tj.G.ptr, 1, tj.c, r.Rw.ptr, r.ldr, (int)r.nr, (int)tj.n, tj.c,
+                                       EPI_MASKED_STORE, 0);
+                g.mask = (const uint8_t*)r.Mb.ptr;
+                g.ldmask = r.ldmb;
+                g.mask_bits = 1;
+                plan_gemm(p, g, st);
+            }
+        }
+        contraction_P(p, r, st);
+        SKF_HIP(hipEventRecord(p->ev_rel[4 * q + 2], st));
+        contraction_Q(p, r, st);
+        SKF_HIP(hipEventRecord(p->ev_rel[4 * q + 3], st));
+        side_products(q, 4 * q + 2);
     }
     for (size_t i = 0; i < nt; ++i)
         if (rels_left[i] == 0 && !touched[i]) type_term(i);          // types without relations in this plan

@@ -484,6 +484,42 @@ def test_relation_pipelined_schedule_matches_the_staged_one_and_the_oracle(monke
         assert relerr(out['pipelined', 'f64'][1][k][0], So[k][0]) < 1e-10
 
 
+def test_dfmc_runs_the_relation_pipeline_with_the_completion_between_its_contractions(monkeypatch):
+    """DFMC with a rank above 64 runs the relation pipeline too: a masked relation is contracted once before its
+    completion (through the narrower factor) and twice after it; its backbone and reconstruction operands are computed
+    on the second stream while the unmasked relations are contracted.  Mixed ranks (one below 64), a masked relation, a
+    relation with a None mask, a sparse constraint: same iterates as the staged schedule (SKF_NO_PIPELINE=1) and as the
+    oracle, f64; bf16 within its engine tolerance."""
+    rs = np.random.RandomState(9)
+    types = ['u', 'm', 'g']
+    n = {'u': 110, 'm': 90, 'g': 40}
+    rank = {'u': 66, 'm': 70, 'g': 12}
+    Rum = rs.rand(110, 90)
+    Rmg = (rs.rand(90, 40) < 0.2).astype(np.float64)
+    Rug = rs.rand(110, 40)
+    Mum = rs.rand(110, 90) < 0.6                                   # True = unknown
+    R = {('u', 'm'): [Rum], ('m', 'g'): [Rmg], ('u', 'g'): [Rug]}
+    M = {('u', 'm'): [Mum], ('m', 'g'): [None], ('u', 'g'): [None]}
+    Tm = 0.05 * np.eye(90)
+    Tm[3, 7] = Tm[7, 3] = -0.01
+    Theta = {('m', 'm'): [Tm]}
+    G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.05 for t in types}
+    Go, So = orc.dfmc(R, M, Theta, types, rank, max_iter=3, G0=G0)
+    out = {}
+    for mode, dtypes in (('pipelined', ('f64', 'bf16')), ('staged', ('f64',))):
+        if mode == 'staged':
+            monkeypatch.setenv('SKF_NO_PIPELINE', '1')
+        for dtype in dtypes:
+            out[mode, dtype] = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=3, G0=G0, dtype=dtype)
+    for t in types:
+        assert relerr(out['pipelined', 'f64'][0][t, t], Go[t, t]) < 1e-10
+        assert relerr(out['pipelined', 'f64'][0][t, t], out['staged', 'f64'][0][t, t]) < 1e-11    # (summation order)
+        assert relerr(out['pipelined', 'bf16'][0][t, t], Go[t, t]) < 3e-2
+    for k in So:
+        assert relerr(out['pipelined', 'f64'][1][k][0], So[k][0]) < 1e-10
+    np.testing.assert_array_equal(R['u', 'm'][0], Rum)              # inputs untouched (reference test_dfmc.py:62,85)
+
+
 def test_binary_relations_as_bitmaps_give_the_dense_results_bit_for_bit():
     """SKF_BF16: a 0 / 1 relation travels as a bitmap (SKF_REL_BINARY, detected on the host) and is expanded to bf16
     0 / 1 in LDS -- the same operands reach the matrix cores, so factors, backbones and the residual equal those of
