@@ -1429,11 +1429,11 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         side_update(p, r.P.ptr, cj, cj, Sm[q], 1, cj, ti, ti.G.ptr, ti.E.ptr, ti.D.ptr, ni, nullptr, nullptr, false,
                     touched[r.row] != 0, nan_upd, ax);
         touched[r.row] = 1;
+        if (--rels_left[r.row] == 0) type_term(r.row);            // (before the wait for Q: under the relation's own Q)
         SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[4 * q + 3], 0));
         side_update(p, r.Q.ptr, ci, ci, Sm[q], cj, 1, tj, tj.G.ptr, tj.E.ptr, tj.D.ptr, nj, nullptr, nullptr, false,
                     touched[r.col] != 0, nan_upd, ax);
         touched[r.col] = 1;
-        if (--rels_left[r.row] == 0) type_term(r.row);
         if (--rels_left[r.col] == 0) type_term(r.col);
     };
     auto w_product = [&](RelState& r, bool by_q) {        // W = G_i^T P, or (R^T G_i)^T G_j through the narrower factor
