@@ -295,12 +295,18 @@ template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) {
     if (t < 0 || (t & ~(width - 1)) != (l & ~(width - 1))) t = l;
     return simt::wave_read(v, t);
 }
-inline unsigned long long __ballot(int pred) {
+inline unsigned long long __ballot(int pred) {      // one exchange: every lane posts its predicate, then reads all slots
+    simt::WaveSync& ws = simt::my_wave();
+    memcpy(ws.xchg[simt::lane_id()], &pred, sizeof pred);
+    simt::wave_sync();
     unsigned long long m = 0;
-    for (int s = 0; s < 64; ++s) {
-        int p = simt::wave_read(pred, s);
+    const int lanes = simt::wave_lanes(simt::g_cur->linear / simt::WAVE);
+    for (int s = 0; s < lanes; ++s) {
+        int p;
+        memcpy(&p, ws.xchg[s], sizeof p);
         if (p) m |= 1ull << s;
     }
+    simt::wave_sync();
     return m;
 }
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
