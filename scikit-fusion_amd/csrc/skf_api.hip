@@ -392,7 +392,7 @@ struct Switches {
     bool no_overlap = false;       // SKF_NO_OVERLAP=1      no second stream
     bool no_pipeline = false;      // SKF_NO_PIPELINE=1     staged schedule instead of the relation pipeline
     int side_tile = 0;             // SKF_SIDE_TILE=64|128  tile shape of the fused side update
-    int epi_tile = 128;            // SKF_EPI_TILE=256      completion / residual passes on the 256 x 256 tile (one workgroup per CU)
+    int epi_tile = 128;            // SKF_EPI_TILE=256      completion pass on the 256 x 256 tile (one workgroup per CU)
     static Switches read() {
         auto on = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
         Switches w;
@@ -1022,19 +1022,15 @@ static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t
         g.koff = (const uint32_t*)r.Koff.ptr;
         g.klist = (const uint32_t*)r.Klist.ptr;
     }
-    if (p->sw.epi_tile == 128) {
-        // 128 relation columns x 256 relation rows per workgroup, 256 threads, 68 KiB of LDS: two workgroups per CU
+    if (p->sw.epi_tile == 128 && mode == MODE_COMPLETE) {
+        // 128 relation columns x 256 relation rows per workgroup, 256 threads, 68 KiB of LDS: two workgroups per CU, one
+        // tile's write-out under the other's K loop (3.9 vs 4.7 ms at config 5).  The residual pass only reads the
+        // relation and is faster on the 256 x 256 tile (4.7 vs 4.9 ms): it stays there.
         dim3 grid(cdiv(nr, 256), cdiv(nj, 128));
         const int smem = 256 * (128 + 8) * 2;
-        if (mode == MODE_COMPLETE) {
-            static std::once_flag once;
-            allow_dynamic_lds(once, gemm_bf16_kernel<256, 0, EPI_T_COMPLETE>, smem);
-            hipLaunchKernelGGL((gemm_bf16_kernel<256, 0, EPI_T_COMPLETE>), grid, dim3(256), smem, st, g);
-        } else {
-            static std::once_flag once;
-            allow_dynamic_lds(once, gemm_bf16_kernel<256, 0, EPI_T_SQERR>, smem);
-            hipLaunchKernelGGL((gemm_bf16_kernel<256, 0, EPI_T_SQERR>), grid, dim3(256), smem, st, g);
-        }
+        static std::once_flag once;
+        allow_dynamic_lds(once, gemm_bf16_kernel<256, 0, EPI_T_COMPLETE>, smem);
+        hipLaunchKernelGGL((gemm_bf16_kernel<256, 0, EPI_T_COMPLETE>), grid, dim3(256), smem, st, g);
         check_launch("tile_epilogue_bf16");
         return;
     }
@@ -2290,7 +2286,7 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
             // one pass over the stored bf16 relation: bf16 H and G_j on the matrix cores, f32 residual
             launch_tile_epilogue(p, r, MODE_SQERR, st);
             hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(1), dim3(256), 0, st, (const double*)p->sqpart.ptr,
-                               cdiv(ni, 256) * cdiv(nj, p->sw.epi_tile), out);
+                               cdiv(ni, 256) * cdiv(nj, 256), out);
             check_launch("sum_partials");
             return;
         }
