@@ -142,6 +142,15 @@ def test_sparse_constraints_at_8000_objects(dtype):
         within(relerr(a, b), 2.5e-12 if dtype == 'f64' else 1.2e-6, 'sparse vs dense constraints at 8000 objects, %s' % dtype)
 
 
+def test_relation_pipeline_dfmf_and_dfmc_against_the_staged_schedule_and_the_oracle(monkeypatch):
+    """Both iteration schedules on the hardware (two HIP streams, events between them): the relation pipeline of DFMF
+    and of DFMC (completion between a masked relation's contractions) against SKF_NO_PIPELINE=1 and the oracle."""
+    import test_emul_engine as E
+    E.test_relation_pipelined_schedule_matches_the_staged_one_and_the_oracle(monkeypatch)
+    monkeypatch.delenv('SKF_NO_PIPELINE', raising=False)
+    E.test_dfmc_runs_the_relation_pipeline_with_the_completion_between_its_contractions(monkeypatch)
+
+
 def test_to_bf16(rt):
     K.test_to_bf16_and_transpose(rt)
 
