@@ -1375,7 +1375,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
+#ifdef SKF_PROBE_HALF_LDS
+                // probe (wrong products): every second B fragment re-uses its neighbour -> 8 instead of 12 fragment reads
+                // per phase, the LDS traffic of a 128 x 128 wave tile
+                if constexpr (j + 1 < NJ) {
+                    if constexpr ((j + 1) & 1) nb[j + 1] = nb[j];
+                    else nb[j + 1] = lds_read_b128<(j + 1) * 2048>(pb);
+                }
+#else
                 if constexpr (j + 1 < NJ) nb[j + 1] = lds_read_b128<(j + 1) * 2048>(pb);
+#endif
                 if constexpr (ABITS && ks == 0) {
                     if constexpr (j < 4 && j <= NJ - 2) expand_chunk(jc, kt);
                     if constexpr (NJ == 4 && j == 2) expand_chunk(std::integral_constant<int, 3>{}, kt);
