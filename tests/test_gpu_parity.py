@@ -151,6 +151,37 @@ def test_relation_pipeline_dfmf_and_dfmc_against_the_staged_schedule_and_the_ora
     E.test_dfmc_runs_the_relation_pipeline_with_the_completion_between_its_contractions(monkeypatch)
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+def test_two_runs_give_bit_identical_factors(dtype):
+    """No float atomics and a fixed order for every sum (split-K slices, E / D contributions of the relations on the second
+    stream, sum of B): two fits of the same plan inputs give bit-identical factors and backbones -- scaled config 5
+    (DFMC on the relation pipeline: completion, bitmaps, CSR constraints, known-entry lists built with atomics whose
+    order must not matter) and scaled config 3 (DFMF pipeline, split-K contractions)."""
+    import torch
+    import bench
+    for c5 in (True, False):
+        n = bench.sizes(0.12 if c5 else 0.1, bench.C5_FULL if c5 else None)
+        out = []
+        for rep in range(2):
+            if c5:
+                rels, thetas = bench.c5_graph(n, dtype)
+                plan = DevicePlan(bench.C5_TYPES, n, bench.C5_RANKS, rels, thetas, nat.SKF_DFMC, dtype=dtype)
+                types, ranks = bench.C5_TYPES, bench.C5_RANKS
+            else:
+                rels = [(i, j, bench.c3_relation(k, n, dtype), None) for k, (i, j, _) in enumerate(bench.PAIRS)]
+                plan = DevicePlan(bench.TYPES, n, bench.RANKS, rels, [], nat.SKF_DFMF, dtype=dtype)
+                types, ranks = bench.TYPES, bench.RANKS
+            for k, t in enumerate(types):
+                plan.set_factor(t, fill_uniform((n[t], ranks[t]), 100 + k, 'f32'))
+            plan.iterate(4)
+            out.append([plan.get_factor(t) for t in types] + [plan.get_backbone(k) for k in range(len(rels))])
+            plan.close()
+            del rels, plan
+            torch.cuda.empty_cache()
+        for a, b in zip(*out):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_to_bf16(rt):
     K.test_to_bf16_and_transpose(rt)
 
