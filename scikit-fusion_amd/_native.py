@@ -3,10 +3,9 @@ plumbing (PyTorch-ROCm tensors used purely as HBM containers).
 
 A *runtime* = (shared library, memory backend).  The product runtime is created lazily by
 :func:`get_runtime` and FAILS LOUDLY when the HIP library or a GPU is missing -- there is no
-CPU fallback in this package.  (The test-suite injects an emulated runtime with
-:func:`use_runtime`; that emulator lives under ``tests/emul`` and is not part of the package.)
+CPU fallback in this package.  (The test-suite swaps the module-level runtime for an emulated one from
+``tests/emul/runtime.py``; neither the emulator nor the hook that installs it is part of the package.)
 """
-import contextlib
 import ctypes as C
 import os
 
@@ -228,14 +227,3 @@ def get_runtime():
         mem = TorchDeviceMemory()                  # imports torch + initialises its HIP runtime
         _runtime = Runtime(load_library(), mem, 'hip')
     return _runtime
-
-
-@contextlib.contextmanager
-def use_runtime(rt):
-    """Temporarily install another runtime (test hook for the host SIMT emulator)."""
-    global _runtime
-    old, _runtime = _runtime, rt
-    try:
-        yield rt
-    finally:
-        _runtime = old

@@ -3,9 +3,10 @@
 Compiles the UNMODIFIED kernel / C-ABI sources of ``scikit-fusion_amd/csrc`` with host
 clang++ against ``tests/emul/include/hip/hip_runtime.h`` (a fiber-based SIMT emulator) into
 ``tests/emul/_build/libskf_emul.so`` and pairs it with plain host memory.  Tests install it
-with ``skfusion_amd._native.use_runtime(...)`` to check kernel index logic, tiling, the launch
+with ``use_runtime(...)`` (below) to check kernel index logic, tiling, the launch
 schedule and the C ABI without a GPU.  The product runtime never loads this library.
 """
+import contextlib
 import os
 import subprocess
 
@@ -81,3 +82,15 @@ def emulated_runtime():
     import skfusion_amd._native as nat
     lib = nat.load_library(build())
     return nat.Runtime(lib, HostMemory(), 'emul')
+
+
+@contextlib.contextmanager
+def use_runtime(rt):
+    """Install `rt` as the runtime of skfusion_amd._native for the duration of the block (test hook: the package itself
+    has none -- its own runtime is the HIP library on a GPU or an error)."""
+    import skfusion_amd._native as nat
+    old, nat._runtime = nat._runtime, rt
+    try:
+        yield rt
+    finally:
+        nat._runtime = old

@@ -4,13 +4,13 @@ import pytest
 
 import skfusion_amd._native as nat
 from skfusion_amd.fusion import Dfmf, Dfmc
-from emul.runtime import emulated_runtime
+from emul.runtime import emulated_runtime, use_runtime
 import api_cases as A
 
 
 @pytest.fixture(scope='module', autouse=True)
 def emul():
-    with nat.use_runtime(emulated_runtime()) as rt:
+    with use_runtime(emulated_runtime()) as rt:
         yield rt
 
 

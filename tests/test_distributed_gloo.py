@@ -84,12 +84,12 @@ def _worker(rank, world, port, out, what):
     import torch.distributed as dist
     import skfusion_amd._native as nat
     from skfusion_amd._distributed import my_runs, world as dist_world
-    from emul.runtime import emulated_runtime
+    from emul.runtime import emulated_runtime, use_runtime
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         assert dist_world() == (rank, world)
         assert my_runs(3) == ([0, 2] if rank == 0 else [1])
-        with nat.use_runtime(emulated_runtime()):
+        with use_runtime(emulated_runtime()):
             if what == 'runs':
                 np.savez(os.path.join(out, 'rank%d.npz' % rank), *_fit())
             elif what.startswith('stop:'):
@@ -104,9 +104,9 @@ def _worker(rank, world, port, out, what):
 def test_restarts_sharded_over_two_gloo_ranks(tmp_path):
     import torch.multiprocessing as mp
     import skfusion_amd._native as nat
-    from emul.runtime import emulated_runtime, build
+    from emul.runtime import emulated_runtime, use_runtime, build
     build()                                   # compile once, before the workers race for it
-    with nat.use_runtime(emulated_runtime()):
+    with use_runtime(emulated_runtime()):
         single = _fit()
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path), 'runs'), nprocs=2, join=True)
@@ -156,10 +156,10 @@ def test_stopping_and_callback_inside_a_sharded_fit(tmp_path, shard):
     stops at and return its factors."""
     import torch.multiprocessing as mp
     import skfusion_amd._native as nat
-    from emul.runtime import emulated_runtime, build
+    from emul.runtime import emulated_runtime, use_runtime, build
     from helpers import relerr
     build()
-    with nat.use_runtime(emulated_runtime()):
+    with use_runtime(emulated_runtime()):
         single = _probe_stopping(None)
     assert 2 < len(single[0]) < 40 and 2 < len(single[1]) <= 12        # stopping_system fired early
     port = _free_port()

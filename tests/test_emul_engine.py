@@ -6,7 +6,7 @@ import pytest
 
 import skfusion_amd._native as nat
 from skfusion_amd.fusion.decomposition import _dfmf, _dfmc
-from emul.runtime import emulated_runtime
+from emul.runtime import emulated_runtime, use_runtime
 from oracle import dfmf_oracle as orc
 from helpers import (golden, readme_graph, probe_graph, rank_deficient_graph, dicty_graph, g0_from,
                      Snapshots, compare_snapshots, relerr, TYPES)
@@ -14,7 +14,7 @@ from helpers import (golden, readme_graph, probe_graph, rank_deficient_graph, di
 
 @pytest.fixture(scope='module', autouse=True)
 def emul():
-    with nat.use_runtime(emulated_runtime()) as rt:
+    with use_runtime(emulated_runtime()) as rt:
         yield rt
 
 
