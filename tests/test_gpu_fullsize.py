@@ -162,3 +162,53 @@ def test_full_size_planted_structure_is_recovered(dtype):
         within(abs(host - rmse) / rmse, 0.012, 'full size %s planted: device RMSE vs host RMSE on sampled rows, relation %d'
                % (dtype, k))
     plan.close()
+
+
+def test_config5_full_size_completion_and_contractions_against_host_rows():
+    """BASELINE configs[4] at FULL size (100k users x 40k movies, 98 % of the ratings unknown, five 0 / 1 side relations,
+    two sparse constraints; DFMC on the relation pipeline, bf16 engine): the completion of the ratings relation
+    (_dfmc.py:319-325) and the two contractions that follow it (_dfmc.py:341-345), against HOST arithmetic on rows and
+    columns of the relation and its mask copied back before the fit.  The host repeats the engine's roundings (bf16 H
+    and G_j into the matrix cores, bf16 completed entries) and nothing else of it: a completion that lost known
+    entries, tiles, K tiles or used a stale backbone, or a contraction that dropped slices of the 8 GB relation, fails by
+    orders of magnitude."""
+    _need_big_gpu()
+    import torch
+    n = bench.sizes(1.0, bench.C5_FULL)
+    rels, thetas = bench.c5_graph(n, 'bf16')
+    i, j, Rdm, Mdm = rels[0]
+    assert (i, j) == ('user', 'movie')
+    Rt, Mt = Rdm.buf.owner, Mdm.buf.owner
+    rs = np.random.RandomState(3)
+    rows = np.sort(rs.choice(n['user'], 24, replace=False))
+    cols = np.sort(rs.choice(n['movie'], 24, replace=False))
+    tr, tc = torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()
+    R_rows, U_rows = Rt[tr].to(torch.float64).cpu().numpy(), Mt[tr].cpu().numpy().astype(bool)          # U = unknown
+    R_cols, U_cols = Rt[:, tc].to(torch.float64).cpu().numpy(), Mt[:, tc].cpu().numpy().astype(bool)
+    plan = DevicePlan(bench.C5_TYPES, n, bench.C5_RANKS, rels, thetas, nat.SKF_DFMC, dtype='bf16')
+    plan.release_relation_data()
+    del rels, thetas, Rdm, Mdm, Rt, Mt
+    torch.cuda.empty_cache()
+    for k, t in enumerate(bench.C5_TYPES):
+        plan.set_factor(t, fill_uniform((n[t], bench.C5_RANKS[t]), 100 + k, 'f32'))
+    plan.iterate(2)
+    Gu, Gm = plan.get_factor('user'), plan.get_factor('movie')          # the factors the third iteration works with
+    plan.iterate(1)
+    S = plan.get_backbone(0)                                            # backbone of the third iteration
+    P = plan.get_contraction(0, 0).astype(np.float64)
+    Q = plan.get_contraction(0, 1).astype(np.float64)
+    plan.close()
+
+    def bf16(x):
+        return nat.from_bf16_bits(nat.to_bf16_bits(np.asarray(x, dtype=np.float32))).astype(np.float64)
+    Hb = bf16(Gu.astype(np.float64) @ S)                                # H = G_user S, into the matrix cores as bf16
+    Gmb, Gub = bf16(Gm), bf16(Gu)
+    # completed rows: known entries as stored, unknown ones = bf16(H G_movie^T)
+    Rc_rows = np.where(U_rows, bf16(Hb[rows] @ Gmb.T), R_rows)
+    # measured (MI355X): P 3.7e-7, Q 5.7e-7 (the host accumulates in f64, the device in f32; a completed entry that
+    # rounds to the neighbouring bf16 value would show as ~1e-5)
+    within(relerr(P[rows], Rc_rows @ Gmb), 2e-6, 'config 5 full size: P rows of the completed ratings relation vs host')
+    Rc_cols = np.where(U_cols, bf16(Hb @ Gmb[cols].T), R_cols)
+    within(relerr(Q[cols], Rc_cols.T @ Gub), 2.5e-6, 'config 5 full size: Q rows of the completed ratings relation vs host')
+    # and the known entries weigh in: the same products with the unknown entries alone are far off
+    assert relerr(P[rows], np.where(U_rows, bf16(Hb[rows] @ Gmb.T), 0.0) @ Gmb) > 1e-2
