@@ -153,7 +153,7 @@ def run_gemm_bf16(rt, A, B, splits=0):
 
 @pytest.mark.parametrize('shape', [(1, 1, 1), (16, 16, 32), (128, 128, 64), (130, 100, 70), (257, 128, 200),
                                    (100, 256, 129), (200, 200, 500), (129, 300, 64),
-                                   (4100, 128, 70), (4200, 256, 200), (4097, 300, 64)])
+                                   (4100, 128, 70), (4200, 256, 200), (4097, 300, 64), (4100, 48, 200)])
 def test_gemm_bf16_contraction(rt, shape):
     """Both workgroup shapes: the 128-row register-staged kernel (M < 4096) and the 256-row LDS-DMA
     kernel with its 3-deep ring and scheduled DMA pieces (M >= 4096); row / column / K tails, split-K."""
@@ -186,7 +186,7 @@ def run_gemm_bf16_tn(rt, R, G, splits=0):
 
 
 @pytest.mark.parametrize('shape', [(1, 1, 1), (16, 16, 32), (64, 128, 64), (100, 130, 70), (200, 257, 128),
-                                   (129, 100, 256), (500, 200, 200), (64, 129, 300), (300, 520, 100)])
+                                   (129, 100, 256), (500, 200, 200), (64, 129, 300), (300, 520, 100), (200, 300, 40)])
 def test_gemm_bf16_transposed_a(rt, shape):
     """Q = R^T G_i from the row-major relation: LDS-DMA of [64 k][256 m] tiles, ds_read_b64_tr_b16 fragments
     (emulated with the lane map measured on the hardware); K x M x N with tails everywhere, split-K."""
@@ -227,7 +227,7 @@ def run_gemm_bits(rt, Rb, G, transposed, splits=0):
 
 
 @pytest.mark.parametrize('shape', [(1, 1, 1), (70, 100, 130), (128, 200, 257), (256, 129, 100), (200, 500, 200),
-                                   (300, 64, 129), (100, 300, 520)])
+                                   (300, 64, 129), (100, 300, 520), (33, 260, 200)])
 @pytest.mark.parametrize('transposed', [0, 1])
 def test_gemm_bits_binary_relation_as_a_bitmap(rt, shape, transposed):
     """A 0 / 1 relation stored as one bit per entry, expanded to bf16 in LDS between the MFMA groups: both

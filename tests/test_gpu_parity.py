@@ -80,20 +80,20 @@ def test_errors(rt):
 
 
 @pytest.mark.parametrize('shape', [(1, 1, 1), (16, 16, 32), (130, 100, 70), (257, 128, 200), (100, 256, 129),
-                                   (129, 300, 64), (3000, 256, 10000), (4097, 128, 6000)])
+                                   (129, 300, 64), (3000, 256, 10000), (4097, 128, 6000), (5000, 64, 3000), (4097, 20, 200)])
 def test_gemm_bf16_contraction(rt, shape):
     K.test_gemm_bf16_contraction(rt, shape)
 
 
 @pytest.mark.parametrize('shape', [(1, 1, 1), (16, 16, 32), (100, 130, 70), (200, 257, 128), (129, 100, 256),
-                                   (64, 129, 300), (300, 520, 100), (10000, 3000, 256), (6000, 4097, 128)])
+                                   (64, 129, 300), (300, 520, 100), (10000, 3000, 256), (6000, 4097, 128), (5000, 3000, 64), (200, 300, 40)])
 def test_gemm_bf16_transposed_a(rt, shape):
     """Q = R^T G_i read from the row-major relation (ds_read_b64_tr_b16 fragments) on the hardware."""
     K.test_gemm_bf16_transposed_a(rt, shape)
 
 
 @pytest.mark.parametrize('shape', [(1, 1, 1), (70, 100, 130), (128, 200, 257), (256, 129, 100), (300, 64, 129),
-                                   (100, 300, 520), (256, 3000, 10000), (128, 6000, 4097)])
+                                   (100, 300, 520), (256, 3000, 10000), (128, 6000, 4097), (64, 5000, 3000), (33, 260, 200)])
 @pytest.mark.parametrize('transposed', [0, 1])
 def test_gemm_bits_binary_relation_as_a_bitmap(rt, shape, transposed):
     K.test_gemm_bits_binary_relation_as_a_bitmap(rt, shape, transposed)
