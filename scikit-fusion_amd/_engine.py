@@ -44,7 +44,8 @@ def pack_mask(mask, mem):
 
 
 def device_matrix_from_tensor(t):
-    """Wrap a contiguous 2-D torch tensor that lives on the engine's device (no copy)."""
+    """Wrap a contiguous 2-D torch tensor that lives on the engine's device (no copy).  The engine reads it on ITS stream:
+    the work that produces the tensor must be complete (torch.cuda.synchronize()) before a plan is created from it."""
     assert t.dim() == 2 and t.is_contiguous()
     return DeviceMatrix(nat.Buffer(t.data_ptr(), t.numel() * t.element_size(), t), tuple(t.shape))
 

@@ -449,6 +449,10 @@ struct RelState {
     bool binary = false;           // SKF_BF16 + SKF_REL_BINARY: the relation is stored as a bitmap (Bb) instead of Rb
     Slot Bb;                       // bitmap [pad64(nr)][ldbb bytes], bit (c & 7) of byte c >> 3; padding zero
     int64_t ldbb = 0;
+    // a very sparse binary relation (at most 1 entry in 256 set): the positions of the ones as CSR and CSC beside the bitmap
+    bool sparse = false;
+    Slot SpRp, SpCi, SpCp, SpRi, SpCnt;     // row pointers / columns, column pointers / rows (ascending), count scratch
+    int64_t sp_cap = 0, sp_nnz = 0;
     Slot Mb;                       // DFMC: the mask as packed bits, [nr][ldmb bytes], bit (n & 7) of byte n >> 3
     int64_t ldmb = 0;
     bool mask_is_bits = false;     // the caller's mask is already packed (SKF_REL_MASK_BITS)
@@ -600,7 +604,13 @@ static void relation_gemm(skf_plan* p, GemmArgs g, hipStream_t st, const RelStat
     if (p->bf16) {
         const TypeState& ti = p->types[r->row];
         const TypeState& tj = p->types[r->col];
-        if (r->binary) {        // the relation as a bitmap: 1/16 of the bytes, expanded to bf16 0 / 1 on the way into LDS
+        if (r->sparse) {        // a handful of ones per row / column: gather the factor's f32 rows (binary_spmm_kernel)
+            const int wgrid = (int)(((int64_t)g.M + 3) / 4 < 4096 ? ((int64_t)g.M + 3) / 4 : 4096);
+            hipLaunchKernelGGL(binary_spmm_kernel, dim3(wgrid), dim3(256), 0, st,
+                               (const int64_t*)(is_q ? r->SpCp.ptr : r->SpRp.ptr), (const int*)(is_q ? r->SpRi.ptr : r->SpCi.ptr),
+                               (const float*)g.B, (int64_t)g.N, (float*)g.C, (int64_t)g.ldc, (int64_t)g.M, g.N);
+            check_launch("binary_spmm");
+        } else if (r->binary) {        // the relation as a bitmap: 1/16 of the bytes, expanded to bf16 0 / 1 on the way into LDS
             if (!is_q)
                 run_gemm_bf16((const uint16_t*)r->Bb.ptr, r->ldbb, (const uint16_t*)tj.GTb.ptr, tj.ldgt, (float*)g.C,
                               g.ldc, g.M, g.N, (int)r->ldrb, 0, p->part.ptr, p->part_bytes, true, st, false, true);
@@ -1832,6 +1842,14 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 if (r.binary) {
                     r.ldbb = r.ldrb / 8;
                     add_slot(p, r.Bb, (size_t)r.kq * r.ldbb);
+                    if (!r.masked) {                       // room for the CSR / CSC form of a very sparse relation
+                        r.sp_cap = (int64_t)nr * tj.n / 256 > 0 ? (int64_t)nr * tj.n / 256 : 1;
+                        add_slot(p, r.SpRp, (size_t)(nr + 1) * 8);
+                        add_slot(p, r.SpCp, (size_t)(tj.n + 1) * 8);
+                        add_slot(p, r.SpCi, (size_t)r.sp_cap * 4);
+                        add_slot(p, r.SpRi, (size_t)r.sp_cap * 4);
+                        add_slot(p, r.SpCnt, (size_t)(nr + 2 * tj.n + 8) * 4);
+                    }
                 } else {
                     add_slot(p, r.Rb, (size_t)r.kq * r.ldrb * 2);
                 }
@@ -1915,6 +1933,54 @@ int skf_plan_workspace_bytes(const skf_plan* plan, size_t* bytes) {
     });
 }
 
+// CSR + CSC of a very sparse binary relation from its bitmap (bind time): per-row counts on the device, prefix sums on the
+// host; kept only when the ones fit the slots sized at plan creation (1 entry in 256)
+static void build_sparse_pattern(skf_plan* p, RelState& r, hipStream_t st) {
+    r.sparse = false;
+    if (r.sp_cap <= 0 || !r.SpRp.ptr) return;
+    const int64_t rows = r.nr, cols = p->types[r.col].n;
+    if (rows <= 0 || cols <= 0) return;
+    const int wgrid = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+    int* rowcnt = (int*)r.SpCnt.ptr;
+    int* colcnt = rowcnt + rows;
+    int* fillpos = colcnt + cols;
+    hipLaunchKernelGGL(bits_row_count_kernel, dim3(wgrid), dim3(256), 0, st, (const uint8_t*)r.Bb.ptr, r.ldbb, rows, rowcnt);
+    check_launch("bits_row_count");
+    std::vector<int> cnt((size_t)(rows > cols ? rows : cols));
+    SKF_HIP(hipMemcpyAsync(cnt.data(), rowcnt, (size_t)rows * 4, hipMemcpyDeviceToHost, st));
+    SKF_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> ptr((size_t)(rows > cols ? rows : cols) + 1);
+    int64_t tot = 0;
+    for (int64_t k = 0; k < rows; ++k) { ptr[k] = tot; tot += cnt[k]; }
+    ptr[rows] = tot;
+    if (tot > r.sp_cap) return;
+    r.sp_nnz = tot;
+    SKF_HIP(hipMemcpyAsync(r.SpRp.ptr, ptr.data(), (size_t)(rows + 1) * 8, hipMemcpyHostToDevice, st));
+    SKF_HIP(hipMemsetAsync(colcnt, 0, (size_t)cols * 2 * 4, st));
+    SKF_HIP(hipStreamSynchronize(st));                       // (`ptr` is reused below)
+    if (tot > 0) {
+        hipLaunchKernelGGL(bits_csr_fill_kernel, dim3(wgrid), dim3(256), 0, st, (const uint8_t*)r.Bb.ptr, r.ldbb, rows,
+                           (const int64_t*)r.SpRp.ptr, (int*)r.SpCi.ptr);
+        hipLaunchKernelGGL(csr_col_count_kernel, dim3(elem_grid(tot)), dim3(256), 0, st, (const int*)r.SpCi.ptr, tot, colcnt);
+        check_launch("bits_csr_fill");
+    }
+    SKF_HIP(hipMemcpyAsync(cnt.data(), colcnt, (size_t)cols * 4, hipMemcpyDeviceToHost, st));
+    SKF_HIP(hipStreamSynchronize(st));
+    int64_t t2 = 0;
+    for (int64_t k = 0; k < cols; ++k) { ptr[k] = t2; t2 += cnt[k]; }
+    ptr[cols] = t2;
+    SKF_HIP(hipMemcpyAsync(r.SpCp.ptr, ptr.data(), (size_t)(cols + 1) * 8, hipMemcpyHostToDevice, st));
+    if (tot > 0) {
+        hipLaunchKernelGGL(csr_transpose_fill_kernel, dim3(wgrid), dim3(256), 0, st, (const int64_t*)r.SpRp.ptr,
+                           (const int*)r.SpCi.ptr, rows, (const int64_t*)r.SpCp.ptr, fillpos, (int*)r.SpRi.ptr);
+        hipLaunchKernelGGL(csc_sort_kernel, dim3(elem_grid(cols)), dim3(256), 0, st, (const int64_t*)r.SpCp.ptr,
+                           (int*)r.SpRi.ptr, cols);
+        check_launch("csc_build");
+    }
+    SKF_HIP(hipStreamSynchronize(st));
+    r.sparse = true;
+}
+
 int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
     return guarded([&] {
         if (!p || !ws) SKF_FAIL(SKF_E_INVALID, "null argument");
@@ -1995,6 +2061,7 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
                     }
                     r.R = r.Bb.ptr;
                     r.ldr = r.ldrb;
+                    build_sparse_pattern(p, r, st);
                     continue;
                 }
                 SKF_HIP(hipMemsetAsync(r.Rb.ptr, 0, r.Rb.bytes, st));

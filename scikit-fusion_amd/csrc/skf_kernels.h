@@ -1964,6 +1964,128 @@ __global__ __launch_bounds__(256) void theta_spmm_kernel(const int64_t* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// VERY sparse binary relations (SKF_BF16, SKF_REL_BINARY, at most 1 entry in 256 set -- config 5's movie x actor and
+// movie x director at 0.1 %): besides the bitmap the plan keeps the positions of the ones as CSR (rows -> columns) and
+// CSC (columns -> rows), both in ascending order, and the two contractions become row gathers of the f32 factor:
+//     P[m] = sum over the ones of row m of G_j[k]          Q[n] = sum over the ones of column n of G_i[m]
+// nnz * c * 4 bytes of L2 / MALL traffic instead of a pass of the matrix cores over the whole bitmap (40k x 40k x 256:
+// 0.72 ms on the bitmap kernel).  The sums run over the f32 masters (the bitmap path rounds G to bf16 first), in a
+// fixed order.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(v, (unsigned)off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// counts[r] = number of set bits of bitmap row r (words of 8 bytes; ldb % 8 == 0, padding bits are zero)
+__global__ __launch_bounds__(256) void bits_row_count_kernel(const uint8_t* __restrict__ B, int64_t ldb, int64_t rows,
+                                                             int* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t nw = ldb >> 3;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const unsigned long long* w = (const unsigned long long*)(B + r * ldb);
+        int cnt = 0;
+        for (int64_t k = lane; k < nw; k += 64) cnt += __popcll(w[k]);
+        cnt = wave_sum(cnt);
+        if (lane == 0) counts[r] = cnt;
+    }
+}
+
+// cols[rowptr[r] ...] = the columns of the ones of row r, ascending
+__global__ __launch_bounds__(256) void bits_csr_fill_kernel(const uint8_t* __restrict__ B, int64_t ldb, int64_t rows,
+                                                            const int64_t* __restrict__ rowptr, int* __restrict__ cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t nw = ldb >> 3;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const unsigned long long* w = (const unsigned long long*)(B + r * ldb);
+        int64_t base = rowptr[r];
+        for (int64_t k0 = 0; k0 < nw; k0 += 64) {
+            unsigned long long x = (k0 + lane < nw) ? w[k0 + lane] : 0ull;
+            const int pc = __popcll(x);
+            const int incl = wave_incl_scan(pc);
+            int64_t at = base + incl - pc;
+            while (x) {
+                const int b = __ffsll((long long)x) - 1;
+                x &= x - 1ull;
+                cols[at++] = (int)((k0 + lane) * 64 + b);
+            }
+            base += __shfl(incl, 63, 64);
+        }
+    }
+}
+
+// transpose of the CSR pattern: per-column counts, then a fill in arbitrary order, then every column's rows sorted
+__global__ __launch_bounds__(256) void csr_col_count_kernel(const int* __restrict__ cols, int64_t nnz, int* __restrict__ colcnt) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&colcnt[cols[q]], 1);
+}
+__global__ __launch_bounds__(256) void csr_transpose_fill_kernel(const int64_t* __restrict__ rowptr, const int* __restrict__ cols,
+                                                                 int64_t rows, const int64_t* __restrict__ colptr,
+                                                                 int* __restrict__ fillpos, int* __restrict__ rowidx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < rows; r += nwaves)
+        for (int64_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) {
+            const int c = cols[q];
+            rowidx[colptr[c] + atomicAdd(&fillpos[c], 1)] = (int)r;
+        }
+}
+__global__ __launch_bounds__(256) void csc_sort_kernel(const int64_t* __restrict__ colptr, int* __restrict__ rowidx, int64_t ncols) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * blockDim.x) {
+        int* a = rowidx + colptr[c];
+        const int n = (int)(colptr[c + 1] - colptr[c]);
+        for (int i = 1; i < n; ++i) {                    // insertion sort: a column holds a few dozen ones
+            const int v = a[i];
+            int j = i - 1;
+            for (; j >= 0 && a[j] > v; --j) a[j + 1] = a[j];
+            a[j + 1] = v;
+        }
+    }
+}
+
+// out[r][0 .. c) = sum over q in [ptr[r], ptr[r+1]) of G[idx[q]][0 .. c)      (one wave per output row)
+__global__ __launch_bounds__(256) void binary_spmm_kernel(const int64_t* __restrict__ ptr, const int* __restrict__ idx,
+                                                          const float* __restrict__ G, int64_t ldg, float* __restrict__ out,
+                                                          int64_t ldo, int64_t rows, int c) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const bool vec = (c & 3) == 0 && (ldg & 3) == 0 && (ldo & 3) == 0 && ((((uintptr_t)G) | ((uintptr_t)out)) & 15) == 0;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const int64_t a = ptr[r], b = ptr[r + 1];
+        if (vec) {
+            for (int j0 = 0; j0 < c; j0 += 256) {
+                const int j = j0 + 4 * lane;
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+                if (j < c) {
+                    int64_t q = a;
+                    for (; q + 1 < b; q += 2) {          // two gathers in flight, summed in the order of the list
+                        const f32x4 g0 = *(const f32x4*)(G + (int64_t)idx[q] * ldg + j);
+                        const f32x4 g1 = *(const f32x4*)(G + (int64_t)idx[q + 1] * ldg + j);
+                        s0 += g0;
+                        s0 += g1;
+                    }
+                    if (q < b) s0 += *(const f32x4*)(G + (int64_t)idx[q] * ldg + j);
+                    *(f32x4*)(out + r * ldo + j) = s0;
+                }
+            }
+        } else {
+            for (int j = lane; j < c; j += 64) {
+                float s = 0.f;
+                for (int64_t q = a; q < b; ++q) s += G[(int64_t)idx[q] * ldg + j];
+                out[r * ldo + j] = s;
+            }
+        }
+    }
+}
+
 // flags[0] |= any(Theta > 0), flags[1] |= any(Theta < 0): the all-zero half of a constraint's +- split
 // (_dfmf.py:203-208) is never multiplied (e.g. a non-positive similarity has Theta+ == 0)
 template <typename T>

@@ -313,6 +313,7 @@ template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return 
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}

@@ -605,3 +605,48 @@ def test_sparse_constraints_as_csr_give_the_dense_product(dtype, wide):
     low.nnz = int(np.count_nonzero(T1)) - 1
     with pytest.raises(nat.SkfNativeError):
         DevicePlan(types, n, rank, [('a', 'b', R, None)], [('a', low)], nat.SKF_DFMF, dtype=dtype)
+
+
+def test_very_sparse_binary_relation_is_contracted_by_row_gathers():
+    """SKF_BF16: a 0 / 1 relation with at most 1 entry in 256 set keeps the positions of its ones as CSR and CSC (built
+    from the bitmap at bind time, ascending) and P = R G_j, Q = R^T G_i become gathers of the f32 factor rows -- exact f32
+    sums, where the bitmap path rounds G to bf16 first: P and Q equal the host products to f32 rounding (the bitmap path
+    would be off by 1e-3), rows and columns without ones give zeros, and a fit agrees with the oracle."""
+    from skfusion_amd._engine import DevicePlan, DeviceMatrix
+    rs = np.random.RandomState(31)
+    types, n, rank = ['m', 'a'], {'m': 210, 'a': 300}, {'m': 8, 'a': 12}
+    A = (rs.rand(210, 300) < 0.002).astype(np.float64)
+    A[5, :] = 0.0
+    A[:, 17] = 0.0
+    A[100, 299] = 1.0
+    A[209, 0] = 1.0
+    assert 0 < A.sum() <= 210 * 300 // 256
+    G0 = {t: (rs.rand(n[t], rank[t]) + 0.05).astype(np.float32) for t in types}
+    rt = nat.get_runtime()
+    dm = DeviceMatrix(rt.mem.from_host(nat.to_bf16_bits(A.astype(np.float32))), A.shape, binary=True)
+    plan = DevicePlan(types, n, rank, [('m', 'a', dm, None)], [], nat.SKF_DFMF, dtype='bf16')
+    for t in types:
+        plan.set_factor(t, G0[t])
+    plan.iterate(1)
+    P, Q = plan.get_contraction(0, 0), plan.get_contraction(0, 1)
+    plan.close()
+    assert relerr(P, A @ G0['a'].astype(np.float64)) < 1e-6
+    assert relerr(Q, A.T @ G0['m'].astype(np.float64)) < 1e-6
+    assert not P[5].any() and not Q[17].any()
+    # a denser relation of the same shape stays on the bitmap kernel (bf16-rounded factor: 1e-3 off the exact product)
+    B = (rs.rand(210, 300) < 0.05).astype(np.float64)
+    dmb = DeviceMatrix(rt.mem.from_host(nat.to_bf16_bits(B.astype(np.float32))), B.shape, binary=True)
+    plan = DevicePlan(types, n, rank, [('m', 'a', dmb, None)], [], nat.SKF_DFMF, dtype='bf16')
+    for t in types:
+        plan.set_factor(t, G0[t])
+    plan.iterate(1)
+    Pb = plan.get_contraction(0, 0)
+    plan.close()
+    assert 1e-5 < relerr(Pb, B @ G0['a'].astype(np.float64)) < 1e-2
+    # through the host layer (0 / 1 detection), three iterations against the oracle
+    R = {('m', 'a'): [A]}
+    G0d = {(t, t): G0[t].astype(np.float64) for t in types}
+    G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=3, G0=G0d, dtype='bf16')
+    Go, So = orc.dfmf(R, {}, types, rank, max_iter=3, G0=G0d)
+    for t in types:
+        assert relerr(G[t, t], Go[t, t]) < 1e-4

@@ -182,6 +182,36 @@ def test_two_runs_give_bit_identical_factors(dtype):
             np.testing.assert_array_equal(a, b)
 
 
+def test_very_sparse_binary_relations_on_the_hardware():
+    """The CSR / CSC gather path of 0 / 1 relations with at most 1 entry in 256 set: the emulator-suite case, and a
+    30000 x 20000 relation at 0.1 % (config 5's movie x actor at 1/2 scale) whose P and Q must equal the exact products
+    with the f32 factors."""
+    import test_emul_engine as E
+    E.test_very_sparse_binary_relation_is_contracted_by_row_gathers()
+    import torch
+    from skfusion_amd._engine import device_matrix_from_tensor as wrap
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(5)
+    n, rank = {'m': 30000, 'a': 20000}, {'m': 256, 'a': 128}
+    At = (torch.rand((30000, 20000), generator=gen, device='cuda') < 0.001)
+    dm = wrap(At.to(torch.bfloat16).contiguous())
+    dm.binary = True
+    torch.cuda.synchronize()                       # the engine reads the tensor on its own stream
+    plan = DevicePlan(['m', 'a'], n, rank, [('m', 'a', dm, None)], [], nat.SKF_DFMF, dtype='bf16')
+    G0 = {t: fill_uniform((n[t], rank[t]), 7 + k, 'f32') for k, t in enumerate(['m', 'a'])}
+    for t in ('m', 'a'):
+        plan.set_factor(t, G0[t])
+    Gm, Ga = plan.get_factor('m').astype(np.float64), plan.get_factor('a').astype(np.float64)
+    plan.iterate(1)
+    P, Q = plan.get_contraction(0, 0), plan.get_contraction(0, 1)
+    plan.close()
+    A = At.cpu().numpy()
+    rows, cols = np.arange(0, 30000, 997), np.arange(0, 20000, 613)
+    # measured 7.1e-8 / 8.3e-8 (f32 sums of ~20 / ~30 f32 rows)
+    within(relerr(P[rows], A[rows].astype(np.float64) @ Ga), 3e-7, 'sparse binary relation 30000 x 20000: P rows vs exact f32-factor product')
+    within(relerr(Q[cols], A[:, cols].astype(np.float64).T @ Gm), 3e-7, 'sparse binary relation 30000 x 20000: Q rows vs exact f32-factor product')
+
+
 def test_to_bf16(rt):
     K.test_to_bf16_and_transpose(rt)
 
