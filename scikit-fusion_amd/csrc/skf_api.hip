@@ -1015,7 +1015,7 @@ static void tile_epilogue_operands(skf_plan* p, RelState& r, hipStream_t st) {  
 
 static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t st, bool operands = true) {
     TypeState& tj = p->types[r.col];
-    const int nr = (int)r.nr, nj = (int)tj.n, cj = tj.c;
+    const int nr = (int)r.nr, nj = (int)tj.n;
     if (operands) tile_epilogue_operands(p, r, st);
     Bf16GemmArgs g;
     memset(&g, 0, sizeof g);

@@ -2328,7 +2328,6 @@ __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_kernel(EighArgs e, 
     __shared__ double col[EIGH_MAXN];
     __shared__ double red[EIGH_THREADS / 64];
     __shared__ double s_max;
-    __shared__ int s_fail;
     const int b = blockIdx.x;
     const int n = e.n_orig[b], ld = e.n[b];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -2346,7 +2345,6 @@ __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_kernel(EighArgs e, 
     }
     for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
     if ((tid & 63) == 0) red[tid >> 6] = mx;
-    if (tid == 0) s_fail = 0;
     __syncthreads();
     if (tid == 0) {
         double s = 0.0;
