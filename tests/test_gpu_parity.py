@@ -441,6 +441,13 @@ def test_row_block_sharding_c3_scaled_c5_and_probe():
             assert relerr(G[t, t], z5['dfmc/G_%s_it29' % t]) < 1e-9
         for (i, j) in R:
             assert relerr(S[i, j][0], z5['dfmc/S_%s_%s_0_it29' % (i, j)]) < 1e-9
+    # the bf16 engine under row blocks (bitmaps, CSR / CSC of the sparse 0 / 1 relations and the completion lists are built
+    # per block): against the same engine on whole relations
+    G0 = g0_from(z5, 'dfmc/', types)
+    Gw, Sw = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=5, G0=G0, dtype='bf16')
+    for G, S in fit_row_blocks('dfmc', R, M, Theta, types, rank, G0, 5, 3, dtype='bf16'):
+        for t in types:
+            within(relerr(G[t, t], Gw[t, t]), 2e-3, 'c5 scaled bf16, 3 row blocks vs whole relations: G_%s after 5 iterations' % t)
 
 
 def test_rccl_stream_ordered_exchanges_single_rank(monkeypatch):
