@@ -2042,11 +2042,34 @@ __global__ __launch_bounds__(256) void csc_sort_kernel(const int64_t* __restrict
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * blockDim.x) {
         int* a = rowidx + colptr[c];
         const int n = (int)(colptr[c + 1] - colptr[c]);
-        for (int i = 1; i < n; ++i) {                    // insertion sort: a column holds a few dozen ones
-            const int v = a[i];
-            int j = i - 1;
-            for (; j >= 0 && a[j] > v; --j) a[j + 1] = a[j];
-            a[j + 1] = v;
+        if (n <= 48) {                                   // a column holds a few dozen ones: insertion sort
+            for (int i = 1; i < n; ++i) {
+                const int v = a[i];
+                int j = i - 1;
+                for (; j >= 0 && a[j] > v; --j) a[j + 1] = a[j];
+                a[j + 1] = v;
+            }
+            continue;
+        }
+        // a heavy column (one object related to a large share of the others): heap sort, O(n log n) in place
+        auto sift = [&](int root, int end) {
+            for (;;) {
+                int child = 2 * root + 1;
+                if (child >= end) break;
+                if (child + 1 < end && a[child] < a[child + 1]) ++child;
+                if (a[root] >= a[child]) break;
+                const int t = a[root];
+                a[root] = a[child];
+                a[child] = t;
+                root = child;
+            }
+        };
+        for (int i = n / 2 - 1; i >= 0; --i) sift(i, n);
+        for (int end = n - 1; end > 0; --end) {
+            const int t = a[0];
+            a[0] = a[end];
+            a[end] = t;
+            sift(0, end);
         }
     }
 }

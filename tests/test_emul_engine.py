@@ -620,6 +620,8 @@ def test_very_sparse_binary_relation_is_contracted_by_row_gathers():
     A[:, 17] = 0.0
     A[100, 299] = 1.0
     A[209, 0] = 1.0
+    A[:, 123] = 0.0
+    A[::3, 123] = 1.0                     # a heavy column (70 ones): the long-column branch of the CSC build
     assert 0 < A.sum() <= 210 * 300 // 256
     G0 = {t: (rs.rand(n[t], rank[t]) + 0.05).astype(np.float32) for t in types}
     rt = nat.get_runtime()
