@@ -652,3 +652,25 @@ def test_very_sparse_binary_relation_is_contracted_by_row_gathers():
     Go, So = orc.dfmf(R, {}, types, rank, max_iter=3, G0=G0d)
     for t in types:
         assert relerr(G[t, t], Go[t, t]) < 1e-4
+
+
+def test_fold_in_of_binary_new_relations_bf16():
+    """SKF_TRANSFORM with 0 / 1 new-object relations in the bf16 engine: one kept as a bitmap, one sparse enough for the
+    CSR / CSC gathers, in both orientations (target on the row and on the column side) -- against the oracle's
+    transform on the same frozen model."""
+    rs = np.random.RandomState(41)
+    types, rank = ['t', 'a', 'b'], {'t': 7, 'a': 9, 'b': 6}
+    na, nb, nt = 220, 260, 40
+    Gf = {('a', 'a'): rs.rand(na, 9) + 0.05, ('b', 'b'): rs.rand(nb, 6) + 0.05, ('t', 't'): rs.rand(30, 7)}
+    S = {('t', 'a'): [rs.rand(7, 9)], ('b', 't'): [rs.rand(6, 7)]}
+    Rta = (rs.rand(nt, na) < 0.3).astype(np.float64)                  # bitmap
+    Rbt = (rs.rand(nb, nt) < 0.003).astype(np.float64)                # 1 in 256 at most: gathers
+    Rbt[7, 3] = 1.0
+    assert 0 < Rbt.sum() <= nb * nt // 256
+    Rn = {('t', 'a'): [Rta], ('b', 't'): [Rbt]}
+    G0 = rs.rand(nt, 7) + 0.05
+    want = orc.transform(Rn, {}, 't', rank, Gf, S, max_iter=20, G0=G0)
+    got64 = _dfmf.transform(Rn, {}, 't', rank, Gf, S, max_iter=20, G0=G0)
+    assert relerr(got64, want) < 1e-10
+    got = _dfmf.transform(Rn, {}, 't', rank, Gf, S, max_iter=20, G0=G0, dtype='bf16')
+    assert relerr(got, want) < 1e-2

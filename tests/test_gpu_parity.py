@@ -102,6 +102,7 @@ def test_gemm_bits_binary_relation_as_a_bitmap(rt, shape, transposed):
 def test_binary_relations_as_bitmaps_in_the_engine():
     import test_emul_engine as E
     E.test_binary_relations_as_bitmaps_give_the_dense_results_bit_for_bit()
+    E.test_fold_in_of_binary_new_relations_bf16()
 
 
 @pytest.mark.parametrize('dtype,wide', [('f64', False), ('f64', True), ('bf16', False)])
