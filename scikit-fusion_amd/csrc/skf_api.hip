@@ -1292,6 +1292,13 @@ static void accumulate_fit(skf_plan* p, hipStream_t st) {
 // G_i <- G_i * sqrt(E_i / max(D_i, eps)) for every type   (_dfmf.py:294-296)
 static void apply_update(skf_plan* p, hipStream_t st) {
     for (TypeState& t : p->types) {
+        if (p->bf16 && t.n > 0) {                  // update and G^T refresh in one pass
+            hipLaunchKernelGGL(mult_update_transpose_kernel, dim3((unsigned)cdiv(t.c, 32), (unsigned)cdiv(t.n, 32)), dim3(256), 0,
+                               st, (float*)t.G.ptr, (const float*)t.E.ptr, (const float*)t.D.ptr, (int64_t)t.n, (int64_t)t.c,
+                               (uint16_t*)t.GTb.ptr, t.ldgt);
+            check_launch("mult_update_transpose");
+            continue;
+        }
         mult_update(p, t, st);
         refresh_gt(p, t, st);
     }

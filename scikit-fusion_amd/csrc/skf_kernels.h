@@ -1687,6 +1687,36 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(uint16_t* __rest
     }
 }
 
+// SKF_BF16: the multiplicative update (mult_update_kernel) and the refresh of the stored bf16 G^T in one pass over a
+// 32 x 32 tile: G is read and written once, the tile leaves transposed through LDS.  grid = (ceil(c/32), ceil(n/32)).
+__global__ __launch_bounds__(256) void mult_update_transpose_kernel(float* __restrict__ G, const float* __restrict__ E,
+                                                                    const float* __restrict__ D, int64_t rows, int64_t cols,
+                                                                    uint16_t* __restrict__ GT, int64_t ldgt) {
+    __shared__ uint16_t tile[32][33];
+    const float eps = 2.220446049250313e-16f;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t r = r0 + ty + 8 * k, c = c0 + tx;
+        uint16_t h = 0;
+        if (r < rows && c < cols) {
+            const float d = D[r * cols + c];
+            const float den = (d > eps || d != d) ? d : eps;     // np.maximum(D, eps) (NaN propagates)
+            const float g = G[r * cols + c] * sqrtf(E[r * cols + c] / den);
+            G[r * cols + c] = g;
+            h = f32_to_bf16_rne(g);
+        }
+        tile[ty + 8 * k][tx] = h;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < cols && r < rows) GT[c * ldgt + r] = tile[tx][ty + 8 * k];
+    }
+}
+
 // DFMC iteration 0: R[mask] = 0   (_dfmc.py:287-292); the mask is packed, one bit per entry
 template <typename T>
 __global__ __launch_bounds__(256) void mask_zero_kernel(T* __restrict__ R, int64_t ldr,
