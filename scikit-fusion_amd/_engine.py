@@ -43,6 +43,19 @@ def pack_mask(mask, mem):
     return PackedMask(mem.from_host(bits), m.shape, bits.shape[1])
 
 
+def is_binary_matrix(arr, chunk_rows=4096):
+    """True when every entry of the host matrix is 0 or 1 (SKF_REL_BINARY).  Row chunks with an early exit: no
+    full-size boolean temporaries, and a real-valued relation is rejected after the first chunk."""
+    a = np.asarray(arr)
+    if a.ndim != 2 or a.size == 0:
+        return False
+    for r0 in range(0, a.shape[0], chunk_rows):
+        blk = a[r0:r0 + chunk_rows]
+        if not bool(((blk == 0) | (blk == 1)).all()):
+            return False
+    return True
+
+
 def device_matrix_from_tensor(t):
     """Wrap a contiguous 2-D torch tensor that lives on the engine's device (no copy).  The engine reads it on ITS stream:
     the work that produces the tensor must be complete (torch.cuda.synchronize()) before a plan is created from it."""
@@ -201,9 +214,13 @@ class DevicePlan(object):
                 arr = np.ascontiguousarray(data, dtype=self.np_dtype)
                 if arr.ndim != 2:
                     raise ValueError('relation %d is not a matrix' % k)
-                # SKF_BF16: a 0 / 1 relation is kept as a bitmap on the device (1/16 of the bytes per iteration)
-                if self.dtype == nat.SKF_BF16 and mask is None and arr.size and bool(((arr == 0) | (arr == 1)).all()):
-                    rdesc[k].flags |= nat.SKF_REL_BINARY
+                # SKF_BF16: a 0 / 1 relation is kept as a bitmap on the device (1/16 of the bytes per iteration).  A row
+                # block carries the verdict on the WHOLE relation (`binary`), so that every rank of a row-sharded fit
+                # takes the same contraction path for it
+                if self.dtype == nat.SKF_BF16 and mask is None:
+                    binary = block['binary'] if (block is not None and 'binary' in block) else is_binary_matrix(arr)
+                    if binary:
+                        rdesc[k].flags |= nat.SKF_REL_BINARY
                 # SKF_BF16: relations are handed over as bf16 bit patterns
                 up = nat.to_bf16_bits(arr) if self.dtype == nat.SKF_BF16 else arr
                 buf, ld = mem.from_host(up), arr.shape[1]
@@ -420,7 +437,7 @@ def upload_graph(rel_list, theta_list, dtype, runtime=None):
         if not isinstance(data, DeviceMatrix):
             arr = np.ascontiguousarray(data, dtype=npd)
             up = nat.to_bf16_bits(arr) if code == nat.SKF_BF16 else arr
-            binary = code == nat.SKF_BF16 and mask is None and arr.size and bool(((arr == 0) | (arr == 1)).all())
+            binary = code == nat.SKF_BF16 and mask is None and is_binary_matrix(arr)
             data = DeviceMatrix(rt.mem.from_host(up), arr.shape, binary=binary)
         if mask is not None and not isinstance(mask, (DeviceMatrix, PackedMask)):
             mask = pack_mask(mask, rt.mem)

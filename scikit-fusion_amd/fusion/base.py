@@ -121,10 +121,16 @@ class FusionFit(FusionBase):
         at most ``block_rows`` rows per block, so that a relation whose dense reconstruction is too
         large for the host (BASELINE config 3: up to 40 GB) can be consumed piece by piece.  The backbone and the
         column factor are uploaded once and stay resident in HBM across the blocks.  ``device=True`` yields the
-        block as a device-resident matrix (valid until the next block; no copy back) for consumers that stay on
-        the GPU; otherwise a float64 ndarray, post-processed per block (exact for element-wise postprocessors).
+        block as a device-resident matrix in the engine's MASTER type (f64 for ``dtype='f64'``, f32 for ``'f32'`` and
+        ``'bf16'``) that aliases a scratch buffer: it is valid until the next block and is NOT post-processed -- a
+        relation with a postprocessor is refused with ``device=True``; otherwise a float64 ndarray, post-processed
+        per block (exact for element-wise postprocessors).
         Extension of the reference API (``complete`` itself is unchanged)."""
         from .._engine import DeviceReconstructor
+        if device and relation.postprocessor:
+            raise DataFusionError("complete_blocks(device=True) yields raw device blocks; relation %s -> %s has a "
+                                  "postprocessor (use device=False, or apply it to the blocks yourself)"
+                                  % (relation.row_type.name, relation.col_type.name))
         run = 0 if run is None else run
         G1 = self.factor(relation.row_type, run)
         rec = DeviceReconstructor(self.backbone(relation, run), self.factor(relation.col_type, run), dtype=dtype)
@@ -177,7 +183,11 @@ def save_fit(fuser, path):
         seen[pair] = pos + 1
         rel_meta.append({'row': pair[0], 'col': pair[1], 'name': str(getattr(rel, 'name', '') or ''), 'position': pos,
                          'shape': [int(d) for d in np.shape(rel.data)]})
-        for k, S in enumerate(fuser.backbones_[rel]):
+        # a same-type relation is a constraint (Theta): it has no backbone.  `.get`: no entry is inserted into the
+        # defaultdict, so `backbone(theta_relation)` keeps raising "Unknown relation." after a save
+        runs = fuser.backbones_.get(rel, [])
+        rel_meta[-1]['n_backbones'] = len(runs)
+        for k, S in enumerate(runs):
             arrays['S/%d/%d' % (b, k)] = np.asarray(S, dtype=np.float64)
     meta = {'format': _FORMAT, 'class': type(fuser).__name__, 'n_run': n_run,
             'params': {k: _plain(v) for k, v in (fuser._params or {}).items()},
@@ -233,7 +243,8 @@ def load_fit(path, fusion_graph=None):
         if list(np.shape(rel.data)) != list(r['shape']):
             raise DataFusionError("Relation %s -> %s: data shape %r, saved %r"
                                   % (r['row'], r['col'], np.shape(rel.data), r['shape']))
-        for k in range(n_run):
+        have = int(r.get('n_backbones', 0 if r['row'] == r['col'] else n_run))
+        for k in range(have):              # (constraints were saved without backbones)
             fuser.backbones_[rel].append(arrays['S/%d/%d' % (b, k)])
     return fuser
 

@@ -90,10 +90,13 @@ def row_block_plan(variant, rel_list, theta_list, obj_types, n_obj, obj_type2ran
     # block boundaries: multiples of the contraction tile for big graphs; bf16 needs multiples of 64
     align = 256 if min(n_obj.values()) >= 4096 else (64 if dtype == 'bf16' else 1)
     blocks, theta_owner = partition_rows(rel_list, theta_list, n_obj, obj_type2rank, align=align, size=size)
+    from ..._engine import is_binary_matrix
     local = []
     for (i, j, m, mask), blk in zip(rel_list, blocks):
         mine = [b for b in blk if b[0] == rank]
         info = {'masked': mask is not None, 'col_side': bool(mine) and mine[0][1] == 0}
+        if dtype == 'bf16' and mask is None:         # decided on the whole relation: the same path on every rank
+            info['binary'] = is_binary_matrix(m)
         if not mine:
             info.update(absent=True, row_begin=0, n_rows=0, col_side=False)
             local.append((i, j, None, None, info))
@@ -147,7 +150,11 @@ def run_fit_sharded(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, in
                     callback=None):
     """One fit whose relations are partitioned over the ranks of the process group (one GPU
     each): replicated factors, local contractions, ONE all-reduce of the E / D accumulators per
-    iteration (second row).  Every rank returns the full (G, S)."""
+    iteration (second row).  Every rank returns the full (G, S).
+    `callback`, `stopping`, `stopping_system` and `compute_err` must be given identically on EVERY rank (as with any
+    SPMD launch of the same script): the callback path gathers the backbones collectively, and a callback on one rank
+    only would leave the others out of that collective.  The current device of each rank must be set before the
+    fit (torch.cuda.set_device(LOCAL_RANK)) for the RCCL reductions."""
     from ..._distributed import partition_relations, gather_backbones, world
     obj_types = list(obj_types)
     n_obj = count_objects(obj_types, R)

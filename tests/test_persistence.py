@@ -90,3 +90,31 @@ def test_mismatches_are_reported(tmp_path):
     np.savez(str(tmp_path / 'other.npz'), meta=np.frombuffer(b'{"format": "x"}', dtype=np.uint8))
     with pytest.raises(DataFusionError):
         load_fit(str(tmp_path / 'other.npz'))
+
+
+def test_round_trip_with_a_constraint_relation(tmp_path):
+    """A same-type relation (Theta) has no backbone: save writes none, load expects none, and `backbone(theta)`
+    keeps raising the reference's "Unknown relation." after a save (round-2 ADVICE: KeyError 'S/<b>/0')."""
+    fuser, graph, (a, b, c), rels = _fitted(Dfmf, 2)
+    rs = np.random.RandomState(5)
+    theta = Relation(rs.rand(12, 12), a, a, name='ppi')
+    graph.add_relation(theta)
+    path = fuser.save(str(tmp_path / 'theta.npz'))
+    assert theta not in fuser.backbones_
+    with pytest.raises(DataFusionError):
+        fuser.backbone(theta)
+    for g in (graph, None):
+        back = load_fit(path, g)
+        g2 = back.fusion_graph
+        th2 = list(g2.get_relations(g2.get_object_type('genes'), g2.get_object_type('genes')))
+        assert len(th2) == 1 and th2[0] not in back.backbones_
+        with pytest.raises(DataFusionError):
+            back.backbone(th2[0])
+        for rel, rel2 in zip(rels, [r for r in g2.relations if r.row_type is not r.col_type]):
+            np.testing.assert_array_equal(back.backbone(rel2, run=1), fuser.backbone(rel, run=1))
+
+
+def test_device_blocks_refuse_a_postprocessor():
+    fuser, graph, ots, rels = _fitted(Dfmf, 1)
+    with pytest.raises(DataFusionError):
+        next(fuser.complete_blocks(rels[2], device=True))
