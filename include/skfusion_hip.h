@@ -76,6 +76,14 @@ typedef struct {
     int64_t row_begin;
     int64_t n_rows;
     int32_t flags;              /* SKF_REL_* */
+    int64_t known_bound;        /* masked relations (DFMC): 0 = unknown, or an upper bound on the number of KNOWN entries
+                                   (mask == 0).  When that is a small share of the relation, the plan keeps ONLY the known
+                                   entries (CSR + CSC with values) and never materialises the completed relation of
+                                   _dfmc.py:319-325: with E = (R - G_i S G_j^T) on the known entries, R_c = G_i S G_j^T + E,
+                                   so P, Q and the next backbone's G_i^T R_c G_j split into c x c algebra plus products
+                                   of the sparse E (cost ~ known * c + n * c^2 instead of n_i * n_j * c; same results up
+                                   to associativity).  A bound that turns out too small is an error at bind time.
+                                   Ignored for unmasked relations, row blocks and SKF_DFMF / SKF_TRANSFORM plans. */
 } skf_relation_desc;
 
 enum {
@@ -204,15 +212,19 @@ int skf_relation_sqerr(skf_plan* plan, int32_t rel, double* out, void* stream);
 
 /* The two contraction results the LAST iteration left in the workspace, for verification at sizes where the
  * host cannot recompute them: which = 0: P = R G_j (local rows x rank_col), 1: Q = R^T G_i (n_col x rank_row),
- * both from the factors BEFORE that iteration's update (like the backbone), master dtype, copied to `dst`. */
+ * both from the factors BEFORE that iteration's update (like the backbone), master dtype, copied to `dst`.
+ * A masked relation kept as known entries only (skf_relation_desc.known_bound) never forms P: it answers
+ * which = 2 with the row-side product P S^T (n_row x rank_row) it computes instead, and which = 1 as usual. */
 int skf_get_contraction(const skf_plan* plan, int32_t rel, int32_t which, void* dst, int64_t ld, void* stream);
 
-/* Optional hipEvent timing of the two contractions that stream a relation matrix
- * (P = R G_j, Q = R^T G_i -- the dominant kernel).  get_profile synchronises on the recorded
- * events, returns the summed duration [ms], the number of launches and their algorithmic flops
- * (2*M*N*K each) since the last call, and resets the counters. */
+/* Optional hipEvent timing of the launches that walk a relation (P = R G_j, Q = R^T G_i -- the dominant
+ * kernel -- and their sparse counterparts).  get_profile synchronises on the recorded events, returns the summed
+ * duration [ms], the number of launches, the flops they EXECUTE (2*M*N*K for a product on the matrix cores, dense or
+ * bitmap; 2 * ones * N for the row gathers of a very sparse 0/1 relation; 2 or 4 * known * c for a pass over the
+ * known entries of a masked relation) and the relation bytes they read from HBM as stored (bf16 / f32 / f64 entries,
+ * 1 bit per entry for a bitmap, index + value lists for the sparse forms) since the last call, and resets the counters. */
 int skf_plan_set_profiling(skf_plan* plan, int32_t enable);
-int skf_plan_get_profile(skf_plan* plan, double* total_ms, int64_t* launches, double* flops);
+int skf_plan_get_profile(skf_plan* plan, double* total_ms, int64_t* launches, double* flops, double* bytes);
 
 /* ---- stand-alone operators (building blocks, exported for tests / callers) -------------- */
 

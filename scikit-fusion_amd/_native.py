@@ -51,7 +51,8 @@ class TypeDesc(C.Structure):
 class RelationDesc(C.Structure):
     _fields_ = [('row_type', C.c_int32), ('col_type', C.c_int32), ('data', C.c_void_p),
                 ('ld', C.c_int64), ('mask', C.c_void_p), ('mask_ld', C.c_int64),
-                ('row_begin', C.c_int64), ('n_rows', C.c_int64), ('flags', C.c_int32)]
+                ('row_begin', C.c_int64), ('n_rows', C.c_int64), ('flags', C.c_int32),
+                ('known_bound', C.c_int64)]
 
 
 class ThetaDesc(C.Structure):
@@ -96,7 +97,8 @@ SIGNATURES = {
     'skf_relation_sqerr': (C.c_int, [_P, C.c_int32, _P, _P]),
     'skf_get_contraction': (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     'skf_plan_set_profiling': (C.c_int, [_P, C.c_int32]),
-    'skf_plan_get_profile': (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    'skf_plan_get_profile': (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double)]),
     'skf_gemm': (C.c_int, [C.c_int32, C.c_int32, C.POINTER(GemmDesc), _P, C.c_size_t, _P]),
     'skf_gemm_bf16': (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                C.c_int32, _P, C.c_size_t, _P]),
