@@ -95,7 +95,9 @@ def c5_graph(n, dtype, masked=0.98, lam=0.01):
             data = ((u * 10.0).floor_() + 1.0).div_(10.0).to(tdt)             # ratings 0.1 .. 1.0
             gen.manual_seed(seed + 100)
             mask = (torch.rand((n[i], n[j]), generator=gen, device='cuda', dtype=torch.float32) < masked).to(torch.uint8)
-            rels.append((i, j, wrap(data.contiguous()), wrap(mask.contiguous())))
+            mm = wrap(mask.contiguous())
+            mm.known = int(mask.numel() - int(mask.sum(dtype=torch.int64).item()))   # few known entries: kept as lists (known_bound)
+            rels.append((i, j, wrap(data.contiguous()), mm))
         else:
             dm = wrap((u < dens).to(tdt).contiguous())
             dm.binary = True                       # 0 / 1 relation: the bf16 engine keeps it as a bitmap (SKF_REL_BINARY)
@@ -464,7 +466,7 @@ def main():
         step(steps)
         sync()
         elapsed = time.perf_counter() - t0
-        k_ms, k_launches, k_flops = plan.get_profile()
+        k_ms, k_launches, k_flops, k_bytes = plan.get_profile()
         plan.set_profiling(False)
         if dist is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')

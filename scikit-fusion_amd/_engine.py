@@ -19,6 +19,7 @@ class DeviceMatrix(object):
         self.buf, self.shape, self.ld = buf, tuple(shape), ld if ld is not None else shape[1]
         self.binary = bool(binary)      # the caller's promise that every entry is 0 or 1 (SKF_REL_BINARY; checked at bind)
         self.nnz = 0                    # constraints: an upper bound on the non-zero entries (0 = unknown / dense)
+        self.known = 0                  # byte masks in HBM: the number of KNOWN entries (mask == 0); 0 = not counted
 
     def rows(self, begin, count, itemsize):
         """View of `count` rows from `begin` on (no copy; the parent buffer stays referenced)."""
@@ -30,8 +31,9 @@ class PackedMask(object):
     """A DFMC mask in HBM as packed bits: bit (c & 7) of byte [r * ld + (c >> 3)], 1 = unknown entry
     (SKF_REL_MASK_BITS, include/skfusion_hip.h)."""
 
-    def __init__(self, buf, shape, ld):
+    def __init__(self, buf, shape, ld, known=0):
         self.buf, self.shape, self.ld = buf, tuple(shape), ld
+        self.known = int(known)         # number of KNOWN entries (mask == 0); 0 = not counted
 
 
 def pack_mask(mask, mem):
@@ -40,7 +42,7 @@ def pack_mask(mask, mem):
     if m.ndim != 2:
         raise ValueError('mask is not a matrix')
     bits = np.ascontiguousarray(np.packbits(m, axis=1, bitorder='little'))
-    return PackedMask(mem.from_host(bits), m.shape, bits.shape[1])
+    return PackedMask(mem.from_host(bits), m.shape, bits.shape[1], known=m.size - int(np.count_nonzero(m)))
 
 
 def is_binary_matrix(arr, chunk_rows=4096):
@@ -166,11 +168,13 @@ class DevicePlan(object):
     """One (run, device) plan: relations + constraints uploaded, workspace bound."""
 
     def __init__(self, obj_types, n_obj, rank, relations, thetas, variant, dtype='f64',
-                 target=None, engine=None, runtime=None, part=None, stream=None):
+                 target=None, engine=None, runtime=None, part=None, stream=None, sparse_known=None):
         """relations: list of (row_type, col_type, ndarray, mask-or-None[, block]);
         thetas: list of (type, ndarray).  `block` (row-block sharding, `_distributed.partition_rows`)
         = dict(row_begin, n_rows, absent, col_side, masked): data / mask then hold only the local rows
-        (None when absent); `part` = (index, count) of this plan among the row-block plans."""
+        (None when absent); `part` = (index, count) of this plan among the row-block plans.
+        `sparse_known` (DFMC): None = the engine decides from the number of known entries of every masked relation
+        whether to keep only those (skf_relation_desc.known_bound); False = always the completed dense copy."""
         self.rt = runtime or nat.get_runtime()
         # `stream`: (raw handle, keep-alive) of a stream of its own for this plan (concurrent restarts);
         # default: the runtime's engine stream
@@ -235,11 +239,13 @@ class DevicePlan(object):
                 self._keep_rel.append(mask.buf)
                 rdesc[k].mask, rdesc[k].mask_ld = mask.buf.ptr, mask.ld
                 rdesc[k].flags |= nat.SKF_REL_MASK_BITS
+                rdesc[k].known_bound = mask.known
             elif isinstance(mask, DeviceMatrix):         # uint8 bytes already in HBM (device-generated data)
                 if tuple(mask.shape) != tuple(arr.shape):
                     raise ValueError('mask shape mismatch for relation (%s,%s)' % (i, j))
                 self._keep_rel.append(mask.buf)
                 rdesc[k].mask, rdesc[k].mask_ld = mask.buf.ptr, mask.ld
+                rdesc[k].known_bound = mask.known
             elif mask is not None:
                 pm = pack_mask(mask, mem)
                 if pm.shape != arr.shape:
@@ -247,6 +253,9 @@ class DevicePlan(object):
                 self._keep_rel.append(pm.buf)
                 rdesc[k].mask, rdesc[k].mask_ld = pm.buf.ptr, pm.ld
                 rdesc[k].flags |= nat.SKF_REL_MASK_BITS
+                rdesc[k].known_bound = pm.known
+            if sparse_known is False or block is not None:
+                rdesc[k].known_bound = 0
         hdesc = (nat.ThetaDesc * max(len(thetas), 1))()
         for k, (t, data) in enumerate(thetas):
             if isinstance(data, DeviceMatrix):           # master dtype, already in HBM
@@ -329,10 +338,13 @@ class DevicePlan(object):
         return self.rt.mem.to_host(buf, shape, self.np_dtype).astype(np.float64)
 
     def get_contraction(self, rel, which, rows=None):
-        """P = R G_j (which=0) or Q = R^T G_i (which=1) as the last iteration left it (verification accessor)."""
+        """P = R G_j (which=0) or Q = R^T G_i (which=1) as the last iteration left it (verification accessor); a masked
+        relation kept as lists of its known entries answers which=2 with the row-side product P S^T instead of P."""
         i, j = self.relations[rel][0], self.relations[rel][1]
         if which == 0:
             shape = (rows if rows is not None else self.n_obj[self.index[i]], self.rank[self.index[j]])
+        elif which == 2:
+            shape = (rows if rows is not None else self.n_obj[self.index[i]], self.rank[self.index[i]])
         else:
             shape = (self.n_obj[self.index[j]], self.rank[self.index[i]])
         buf = self.rt.mem.empty(shape[0] * shape[1] * np.dtype(self.np_dtype).itemsize)
@@ -406,10 +418,11 @@ class DevicePlan(object):
         self.rt.call('skf_plan_set_profiling', self.handle, 1 if enable else 0)
 
     def get_profile(self):
-        """(total ms, launches, algorithmic flops) of the relation contractions since last call."""
-        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
-        self.rt.call('skf_plan_get_profile', self.handle, C.byref(ms), C.byref(n), C.byref(fl))
-        return ms.value, n.value, fl.value
+        """(total ms, launches, executed flops, relation bytes read as stored) of the launches that walk a relation
+        since the last call."""
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        self.rt.call('skf_plan_get_profile', self.handle, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
+        return ms.value, n.value, fl.value, by.value
 
     def close(self):
         if self.handle:

@@ -13,6 +13,7 @@
 //   D_i += Theta+ G_i ; E_i += Theta- G_i                                   (:284-292)
 //   G_i <- G_i * sqrt(E_i / max(D_i, eps))                                  (:294-296)
 #include "skf_kernels.h"
+#include "skf_known.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -394,6 +395,7 @@ struct Switches {
     int side_tile = 0;             // SKF_SIDE_TILE=64|128  tile shape of the fused side update
     int aux_prio = 0;              // SKF_AUX_PRIO=default|high  priority of the second stream (0 = lowest, the default)
     int epi_tile = 128;            // SKF_EPI_TILE=256      completion pass on the 256 x 256 tile (one workgroup per CU)
+    bool known_generic = false;    // SKF_KNOWN_GENERIC=1   the any-width list kernel for the known-entry passes (tests, A/B)
     static Switches read() {
         auto on = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
         Switches w;
@@ -405,6 +407,7 @@ struct Switches {
         w.graph = on("SKF_GRAPH");
         w.no_overlap = on("SKF_NO_OVERLAP");
         w.no_pipeline = on("SKF_NO_PIPELINE");
+        w.known_generic = on("SKF_KNOWN_GENERIC");
         const char* st = getenv("SKF_SIDE_TILE");
         w.side_tile = st ? atoi(st) : 0;
         const char* ap = getenv("SKF_AUX_PRIO");
@@ -432,6 +435,8 @@ struct TypeState {
     Slot GTb;                      // SKF_BF16: bf16 transpose of G, [c][pad64(n)], zero padded
     int64_t ldgt = 0;
     bool set = false;
+    bool keep_prev = false;        // a known-entries relation touches this type: Gp = the factor before the last update
+    Slot Gp;
 };
 
 struct RelState {
@@ -468,6 +473,20 @@ struct RelState {
     bool absent = false;           // no local rows (W, Q, S are still kept for the exchange)
     bool masked = false;           // DFMC: the relation has a mask (here or, for an absent one, elsewhere)
     bool col_side = true;          // this plan adds the column-side terms E_j, D_j
+    // DFMC on the known entries only (skf_relation_desc.known_bound, skf_known.h): no completed copy of the relation
+    bool kn = false;
+    int64_t kn_cap = 0, kn_nnz = 0;        // bound given at plan creation / entries found at bind time
+    int kn_pc = 1, kn_pr = 1;              // column parts of the row lists, row parts of the column lists
+    int64_t kn_pw = 0, kn_ph = 0;          // columns per column part (multiple of 64), rows per row part
+    int64_t kn_ldf = 0;                    // leading dimension of the gathered vectors (bf16 copies: padded to 8)
+    Slot KrPtr, KrIdx, KrVal;              // rows -> known columns (ascending), R there
+    Slot KcPtr, KcIdx, KcVal, KcE;         // columns -> known rows (ascending), R there, residuals E of the last iteration
+    Slot KCnt;                             // count / fill-position scratch of the bind-time build
+    Slot FoB, FiB;                         // SKF_BF16: bf16 rows of G_i (n_i x ldf) and of T = G_j S^T (n_j x ldf)
+    Slot Tm;                               // T = G_j S^T in the master type (n_j x c_i)
+    Slot Apart, Qpart;                     // partial outputs of the parts, [parts][n][c_i] (only with more than one part)
+    Slot A;                                // E T, then the row-side product P S^T = G_i (S Gram_j S^T) + E T   (n_i x c_i)
+    Slot Sp, Xi, Xj, Bf, U2;               // S of the stored residuals; G_i'^T G_i, G_j^T G_j'; S Gram_j S^T; S^T Gram_i  (f64)
 };
 
 struct ThetaState {
@@ -528,8 +547,9 @@ struct skf_plan {
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
-    double prof_flops = 0.0;
+    double prof_flops = 0.0, prof_bytes = 0.0;
     int64_t prof_launches = 0;
+    bool kn_first = true;                  // no residuals stored yet: E = the known entries themselves, S_prev = 0
     ~skf_plan() {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_rel) (void)hipEventDestroy(e);
@@ -631,7 +651,15 @@ static void relation_gemm(skf_plan* p, GemmArgs g, hipStream_t st, const RelStat
     }
     if (p->profiling) {
         SKF_HIP(hipEventRecord(next_event(p), st));
-        p->prof_flops += 2.0 * (double)g.M * (double)g.N * (double)g.K;
+        // what the launch executes and the relation bytes it reads as stored (include/skfusion_hip.h, skf_plan_get_profile)
+        const double cells = (double)g.M * (double)g.K;
+        if (p->bf16 && r && r->sparse) {
+            p->prof_flops += 2.0 * (double)r->sp_nnz * (double)g.N;
+            p->prof_bytes += 4.0 * (double)r->sp_nnz;
+        } else {
+            p->prof_flops += 2.0 * cells * (double)g.N;
+            p->prof_bytes += (p->bf16 && r && r->binary) ? cells / 8.0 : cells * (p->bf16 ? 2.0 : (double)p->esz);
+        }
         p->prof_launches += 1;
     }
 }
@@ -917,10 +945,188 @@ static void contraction_Q(skf_plan* p, RelState& r, hipStream_t st) {      // Q 
     relation_gemm(p, g, st, &r, true);
 }
 
+// ------------------------------------------------------------------------------------------
+// DFMC on the known entries only (skf_known.h): launches of the list passes and the c x c / n x c x c algebra around them
+// ------------------------------------------------------------------------------------------
+template <typename TG, typename TM>
+static int launch_srp(const SrpArgs<TG, TM>& a, hipStream_t st, bool generic) {
+    const int per = 8 / a.parts;
+    const int64_t wgs = (a.n_out + 3) / 4;
+    const int grid = (int)((wgs + per - 1) / per * 8);
+    constexpr int VE = 16 / (int)sizeof(TG);
+    auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+    const bool vec = a.w % VE == 0 && a.ldi % VE == 0 && al(a.Fi) && (a.mode == SRP_APPLY || (a.ldo % VE == 0 && al(a.Fo)));
+    const int gl = (vec && !generic) ? a.w / VE : 0;
+    bool done = false;
+    if constexpr (std::is_same<TG, uint16_t>::value) {
+        done = true;
+        if (gl == 8) hipLaunchKernelGGL((srp_bf16_kernel<8>), dim3(grid), dim3(256), 0, st, a);
+        else if (gl == 16) hipLaunchKernelGGL((srp_bf16_kernel<16>), dim3(grid), dim3(256), 0, st, a);
+        else if (gl == 32) hipLaunchKernelGGL((srp_bf16_kernel<32>), dim3(grid), dim3(256), 0, st, a);
+        else done = false;
+    }
+    if (!done) {
+        if (gl == 8) hipLaunchKernelGGL((srp_vec_kernel<TG, TM, 8>), dim3(grid), dim3(256), 0, st, a);
+        else if (gl == 16) hipLaunchKernelGGL((srp_vec_kernel<TG, TM, 16>), dim3(grid), dim3(256), 0, st, a);
+        else if (gl == 32) hipLaunchKernelGGL((srp_vec_kernel<TG, TM, 32>), dim3(grid), dim3(256), 0, st, a);
+        else if (gl == 64) hipLaunchKernelGGL((srp_vec_kernel<TG, TM, 64>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((srp_any_kernel<TG, TM>), dim3(grid), dim3(256), 0, st, a);
+    }
+    check_launch("known-entry pass");
+    return grid * 4;                 // waves = error partials of an SRP_ERR pass
+}
+
+// One pass over the known entries of relation r: by_col == false walks the row lists (outer = rows, gathers the rows of
+// T = G_j S^T), by_col == true the column lists (outer = columns, gathers the rows of G_i).  Results land in r.A / r.Q
+// (SRP_ERR: partials in p->sqpart, the number of which is returned).
+static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream_t st) {
+    TypeState& ti = p->types[r.row];
+    TypeState& tj = p->types[r.col];
+    const int ci = ti.c;
+    const int64_t n_out = by_col ? tj.n : r.nr;
+    const int parts = by_col ? r.kn_pr : r.kn_pc;
+    void* final_out = by_col ? r.Q.ptr : r.A.ptr;
+    void* out = parts > 1 ? (by_col ? r.Qpart.ptr : r.Apart.ptr) : final_out;
+    const void* Gi = p->bf16 ? r.FoB.ptr : ti.G.ptr;          // vectors of the row objects
+    const void* Tj = p->bf16 ? r.FiB.ptr : r.Tm.ptr;          // vectors of the column objects
+    const int64_t ldv = p->bf16 ? r.kn_ldf : ci;
+    if (p->profiling) SKF_HIP(hipEventRecord(next_event(p), st));
+    int waves = 0;
+    auto fill = [&](auto& a) {
+        memset(&a, 0, sizeof a);
+        a.ptr = (const int64_t*)(by_col ? r.KcPtr.ptr : r.KrPtr.ptr);
+        a.idx = (const int*)(by_col ? r.KcIdx.ptr : r.KrIdx.ptr);
+        a.ldo = ldv; a.ldi = ldv; a.ld_out = ci; a.part_stride = n_out * ci; a.n_out = n_out;
+        a.w = ci; a.parts = parts; a.mode = mode;
+        a.sq = (double*)p->sqpart.ptr;
+    };
+    if (p->f64) {
+        SrpArgs<double, double> a;
+        fill(a);
+        a.rvals = (const double*)(by_col ? r.KcVal.ptr : r.KrVal.ptr);
+        a.evals = by_col ? (double*)r.KcE.ptr : nullptr;
+        a.Fo = (const double*)(by_col ? Tj : Gi); a.Fi = (const double*)(by_col ? Gi : Tj);
+        a.out = (double*)out;
+        waves = launch_srp(a, st, p->sw.known_generic);
+    } else if (p->bf16) {
+        SrpArgs<uint16_t, float> a;
+        fill(a);
+        a.rvals = (const float*)(by_col ? r.KcVal.ptr : r.KrVal.ptr);
+        a.evals = by_col ? (float*)r.KcE.ptr : nullptr;
+        a.Fo = (const uint16_t*)(by_col ? Tj : Gi); a.Fi = (const uint16_t*)(by_col ? Gi : Tj);
+        a.out = (float*)out;
+        waves = launch_srp(a, st, p->sw.known_generic);
+    } else {
+        SrpArgs<float, float> a;
+        fill(a);
+        a.rvals = (const float*)(by_col ? r.KcVal.ptr : r.KrVal.ptr);
+        a.evals = by_col ? (float*)r.KcE.ptr : nullptr;
+        a.Fo = (const float*)(by_col ? Tj : Gi); a.Fi = (const float*)(by_col ? Gi : Tj);
+        a.out = (float*)out;
+        waves = launch_srp(a, st, p->sw.known_generic);
+    }
+    if (parts > 1 && mode != SRP_ERR) {
+        const int64_t total = n_out * ci;
+        if (p->f64)
+            hipLaunchKernelGGL((sum_parts_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, (double*)final_out,
+                               (const double*)out, total, parts, total);
+        else
+            hipLaunchKernelGGL((sum_parts_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st, (float*)final_out,
+                               (const float*)out, total, parts, total);
+        check_launch("sum_parts");
+    }
+    if (p->profiling) {
+        SKF_HIP(hipEventRecord(next_event(p), st));
+        const size_t gsz = p->bf16 ? 2 : p->esz;
+        p->prof_flops += (mode == SRP_APPLY ? 2.0 : 4.0) * (double)r.kn_nnz * ci;
+        p->prof_bytes += (double)r.kn_nnz * (4.0 + 2.0 * p->esz);          // index + value (+ residual) lists
+        (void)gsz;
+        p->prof_launches += 1;
+    }
+    return waves;
+}
+
+// SKF_BF16: bf16 rows of the row factor for the gathers (the stored G^T is the wrong way round for them)
+static void known_refresh_rows(skf_plan* p, RelState& r, hipStream_t st) {
+    if (!p->bf16) return;
+    TypeState& ti = p->types[r.row];
+    launch_to_bf16<float>((uint16_t*)r.FoB.ptr, r.kn_ldf, (const float*)ti.G.ptr, (int64_t)ti.c, r.nr, ti.c, false, st);
+}
+
+// W = G_i^T R_c G_j for the backbone (_dfmc.py:311-314) with R_c = G_i,prev S_prev G_j,prev^T + E_prev:
+//     W = (G_i^T G_i,prev) S_prev (G_j,prev^T G_j) + (E_prev^T G_i)^T G_j
+// first iteration: R_c = the known entries, zeros elsewhere (_dfmc.py:287-292), i.e. E_prev = R on the lists, S_prev = 0
+static void known_w(skf_plan* p, RelState& r, hipStream_t st) {
+    TypeState& ti = p->types[r.row];
+    TypeState& tj = p->types[r.col];
+    const int ci = ti.c, cj = tj.c;
+    known_refresh_rows(p, r, st);
+    known_pass(p, r, true, SRP_APPLY, st);                                                          // Y = E_prev^T G_i  -> r.Q
+    GemmArgs g = gemm_args(r.Q.ptr, 1, ci, tj.G.ptr, cj, 1, r.W.ptr, cj, ci, cj, (int)tj.n, EPI_STORE, 0);
+    wide_gemm(p, g, st);                                                                            // W = Y^T G_j
+    if (p->kn_first) return;
+    g = gemm_args(ti.G.ptr, 1, ci, ti.Gp.ptr, ci, 1, r.Xi.ptr, ci, ci, ci, (int)r.nr, EPI_STORE, 0);    // Xi = G_i^T G_i,prev
+    wide_gemm(p, g, st);
+    g = gemm_args(tj.Gp.ptr, 1, cj, tj.G.ptr, cj, 1, r.Xj.ptr, cj, cj, cj, (int)tj.n, EPI_STORE, 0);    // Xj = G_j,prev^T G_j
+    wide_gemm(p, g, st);
+    g = gemm_args(r.Sp.ptr, cj, 1, r.Xj.ptr, cj, 1, r.U.ptr, cj, ci, cj, cj, EPI_STORE, 0);             // U = S_prev Xj
+    small_gemm(p, g, st);
+    g = gemm_args(r.Xi.ptr, ci, 1, r.U.ptr, cj, 1, r.W.ptr, cj, ci, cj, ci, EPI_ACC, 0);                // W += Xi U
+    small_gemm(p, g, st);
+}
+
+// behind the backbone S: the gathered vectors T = G_j S^T and the c x c operands of the dense parts
+//     U2 = S^T Gram_i (Q = G_j U2 + E^T G_i) ,  Bf = S Gram_j S^T (P S^T = G_i Bf + E T)
+static void known_operands(skf_plan* p, RelState& r, hipStream_t st, bool second_stream) {
+    TypeState& ti = p->types[r.row];
+    TypeState& tj = p->types[r.col];
+    const int ci = ti.c, cj = tj.c;
+    GemmArgs g = gemm_args(tj.G.ptr, cj, 1, r.S.ptr, 1, cj, r.Tm.ptr, ci, (int)tj.n, ci, cj, EPI_STORE, 0);
+    if (second_stream) mixed_gemm_unsplit(p, g, st);
+    else mixed_gemm(p, g, st);
+    if (p->bf16) launch_to_bf16<float>((uint16_t*)r.FiB.ptr, r.kn_ldf, (const float*)r.Tm.ptr, (int64_t)ci, tj.n, ci, false, st);
+    g = gemm_args(r.S.ptr, 1, cj, ti.Gram.ptr, ci, 1, r.U2.ptr, ci, cj, ci, ci, EPI_STORE, 0);
+    small_gemm(p, g, st);
+    g = gemm_args(r.S.ptr, cj, 1, tj.Gram.ptr, cj, 1, r.T1.ptr, cj, ci, cj, cj, EPI_STORE, 0);
+    small_gemm(p, g, st);
+    g = gemm_args(r.T1.ptr, cj, 1, r.S.ptr, 1, cj, r.Bf.ptr, ci, ci, ci, cj, EPI_STORE, 0);
+    small_gemm(p, g, st);
+}
+
+// the two residual passes of the factor update: r.A = E T (row lists), r.Q = E^T G_i + G_j U2 (column lists; the
+// residuals of this iteration replace the stored ones), and S_prev <- S
+static void known_row_pass(skf_plan* p, RelState& r, hipStream_t st) { known_pass(p, r, false, SRP_RESIDUAL, st); }
+static void known_col_pass(skf_plan* p, RelState& r, hipStream_t st) {
+    TypeState& ti = p->types[r.row];
+    TypeState& tj = p->types[r.col];
+    const int ci = ti.c, cj = tj.c;
+    known_pass(p, r, true, SRP_RESIDUAL, st);
+    GemmArgs g = gemm_args(tj.G.ptr, cj, 1, r.U2.ptr, ci, 1, r.Q.ptr, ci, (int)tj.n, ci, cj, EPI_ACC, 0);
+    mixed_gemm(p, g, st);
+    copy2d(r.Sp.ptr, cj, r.S.ptr, cj, ci, cj, 8, st);
+}
+
+// row side of the factor update from the row-side product itself: A = G_i Bf + E T, E_i (+)= A+, D_i (+)= A-
+static void known_row_side(skf_plan* p, RelState& r, bool accumulate, hipStream_t st, bool second_stream) {
+    TypeState& ti = p->types[r.row];
+    const int ci = ti.c;
+    GemmArgs g = gemm_args(ti.G.ptr, ci, 1, r.Bf.ptr, ci, 1, r.A.ptr, ci, (int)r.nr, ci, ci, EPI_ACC, 0);
+    if (second_stream) mixed_gemm_unsplit(p, g, st);
+    else mixed_gemm(p, g, st);
+    const int64_t total = r.nr * ci;
+    if (p->f64)
+        hipLaunchKernelGGL((split_accumulate_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, (double*)ti.E.ptr,
+                           (double*)ti.D.ptr, (const double*)r.A.ptr, total, accumulate ? 1 : 0);
+    else
+        hipLaunchKernelGGL((split_accumulate_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st, (float*)ti.E.ptr,
+                           (float*)ti.D.ptr, (const float*)r.A.ptr, total, accumulate ? 1 : 0);
+    check_launch("split_accumulate");
+}
+
 // DFMC, first iteration: the unknown entries of every masked relation start at zero (_dfmc.py:287-292)
 static void zero_unknown_entries(skf_plan* p, hipStream_t st) {
     for (RelState& r : p->rels) {
-        if (!r.mask) continue;
+        if (!r.mask || r.kn) continue;          // (a known-entries relation starts from E = R on its lists, S_prev = 0)
         const int64_t rows = r.nr, cols = p->types[r.col].n;
         if (p->bf16)
             hipLaunchKernelGGL((mask_zero_kernel<uint16_t>), dim3(elem_grid(rows * cols)), dim3(256), 0, st,
@@ -987,6 +1193,10 @@ static void stage_contract(skf_plan* p, hipStream_t st) {
         // W = G_i^T R G_j is needed (_dfmc.py:311-314), and the narrower factor does it -- with c_i < c_j as
         // W = (R^T G_i)^T G_j (config 5, user x movie: rank 128 instead of 256 through the 8 GB relation).
         const bool w_by_q = dfmc && r.masked && ti.c < tj.c;
+        if (r.kn) {                 // known entries only: W from the stored residuals and c x c cross-Gram products
+            known_w(p, r, st);
+            continue;
+        }
         if (r.absent) {
             SKF_HIP(hipMemsetAsync(r.W.ptr, 0, r.W.bytes, st));
         } else if (w_by_q) {
@@ -1111,6 +1321,12 @@ static void stage_backbone(skf_plan* p, hipStream_t st) {
             small_gemm(p, g, st);
         }
         if (!(dfmc && r.masked)) continue;
+        if (r.kn) {                 // completion, P and Q of _dfmc.py:319-325, 341-345 on the known entries
+            known_operands(p, r, st, false);
+            known_row_pass(p, r, st);
+            known_col_pass(p, r, st);
+            continue;
+        }
         if (!r.absent) {
             // H = G_i[blk] S ; Rw[mask] = (H G_j^T)[mask] ; P = Rw G_j        (_dfmc.py:319-325)
             g = gemm_args(rows_of(p, ti.G, ti, r.r0), ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, nr, cj, ci, EPI_STORE, 0);
@@ -1251,7 +1467,12 @@ static void stage_accumulate(skf_plan* p, hipStream_t st) {
             // row side: A = P S^T (Sop(k,j) = S[j][k]);  column side: C = Q S
             if (!row_side && !col_side) continue;
             const void* Sm = S_m[rk];
-            if (row_side) {
+            if (row_side && r.kn) {
+                const bool last = fuse_type_term && --sides_left[r.row] == 0;
+                known_row_side(p, r, touched[r.row] != 0, st, false);
+                touched[r.row] = 1;
+                if (last) type_term(r.row);
+            } else if (row_side) {
                 const bool last = fuse_type_term && --sides_left[r.row] == 0;
                 side_update(p, r.P.ptr, cj, cj, Sm, 1, cj, ti, Gi, Ei, Di, nr, Bn_m[r.row], Bp_m[r.row], last,
                             touched[r.row] != 0, nan_upd, st);
@@ -1265,7 +1486,9 @@ static void stage_accumulate(skf_plan* p, hipStream_t st) {
             }
             continue;
         }
-        if (row_side) {
+        if (row_side && r.kn) {
+            known_row_side(p, r, true, st, false);
+        } else if (row_side) {
             // E_i += (P S^T)+ ; D_i += (P S^T)-          (_dfmf.py:254-258, 278-279)
             g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, Ei, ci, nr, ci, cj, EPI_SPLIT_ACC, nan_upd);
             g.C2 = Di;
@@ -1294,6 +1517,9 @@ static void accumulate_fit(skf_plan* p, hipStream_t st) {
 
 // G_i <- G_i * sqrt(E_i / max(D_i, eps)) for every type   (_dfmf.py:294-296)
 static void apply_update(skf_plan* p, hipStream_t st) {
+    for (TypeState& t : p->types)          // known-entries relations: the factors their stored residuals belong to
+        if (t.keep_prev) SKF_HIP(hipMemcpyAsync(t.Gp.ptr, t.G.ptr, t.G.bytes, hipMemcpyDeviceToDevice, st));
+    p->kn_first = false;
     for (TypeState& t : p->types) {
         if (p->bf16 && t.n > 0) {                  // update and G^T refresh in one pass
             hipLaunchKernelGGL(mult_update_transpose_kernel, dim3((unsigned)cdiv(t.c, 32), (unsigned)cdiv(t.n, 32)), dim3(256), 0,
@@ -1442,8 +1668,11 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         TypeState& tj = p->types[r.col];
         const int ni = (int)r.nr, nj = (int)tj.n, ci = ti.c, cj = tj.c;
         SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[ev_p], 0));
-        side_update(p, r.P.ptr, cj, cj, Sm[q], 1, cj, ti, ti.G.ptr, ti.E.ptr, ti.D.ptr, ni, nullptr, nullptr, false,
-                    touched[r.row] != 0, nan_upd, ax);
+        if (r.kn)
+            known_row_side(p, r, touched[r.row] != 0, ax, true);
+        else
+            side_update(p, r.P.ptr, cj, cj, Sm[q], 1, cj, ti, ti.G.ptr, ti.E.ptr, ti.D.ptr, ni, nullptr, nullptr, false,
+                        touched[r.row] != 0, nan_upd, ax);
         touched[r.row] = 1;
         if (--rels_left[r.row] == 0) type_term(r.row);            // (before the wait for Q: under the relation's own Q)
         SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[4 * q + 3], 0));
@@ -1467,6 +1696,14 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
         const bool by_q = ti.c < tj.c;
+        if (r.kn) {           // known entries only: W from the stored residuals; second stream: backbone, gathered vectors, c x c operands
+            known_w(p, r, st);
+            SKF_HIP(hipEventRecord(p->ev_rel[4 * q], st));
+            backbone_chain(q);
+            known_operands(p, r, ax, true);
+            SKF_HIP(hipEventRecord(p->ev_rel[4 * q + 1], ax));
+            continue;
+        }
         if (by_q) contraction_Q(p, r, st);
         else contraction_P(p, r, st);
         w_product(r, by_q);
@@ -1498,6 +1735,14 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         if (!(dfmc && r.masked)) continue;
         TypeState& tj = p->types[r.col];
         SKF_HIP(hipStreamWaitEvent(st, p->ev_rel[4 * q + 1], 0));
+        if (r.kn) {           // the two residual passes over the lists stand for completion, P and Q
+            known_row_pass(p, r, st);
+            SKF_HIP(hipEventRecord(p->ev_rel[4 * q + 2], st));
+            known_col_pass(p, r, st);
+            SKF_HIP(hipEventRecord(p->ev_rel[4 * q + 3], st));
+            side_products(q, 4 * q + 2);
+            continue;
+        }
         if (r.mask) {
             if (p->bf16) {
                 launch_tile_epilogue(p, r, MODE_COMPLETE, st, false);
@@ -1622,6 +1867,73 @@ static void iterate_transform(skf_plan* p, hipStream_t st) {
     if (!p->thetas.empty()) refresh_gt(p, tt, st);      // SKF_BF16: the constraint products read the stored G^T
 }
 
+// The known entries of a masked relation as row lists and column lists (bind time): counts per (row, column part) on the
+// device, prefix sums on the host, fills on the device; the column lists are the transpose of the row lists, every
+// (column, row part) segment sorted by row.  R values come from the caller's relation, which is not referenced afterwards.
+template <typename TR, typename TM>
+static void build_known_lists_t(skf_plan* p, RelState& r, hipStream_t st) {
+    const int64_t rows = r.nr, cols = p->types[r.col].n;
+    const int pc = r.kn_pc, pr = r.kn_pr;
+    const int wgrid = (int)((rows + 3) / 4 < 2048 ? ((rows + 3) / 4 > 0 ? (rows + 3) / 4 : 1) : 2048);
+    int* cnt = (int*)r.KCnt.ptr;
+    hipLaunchKernelGGL(known_row_count_kernel, dim3(wgrid), dim3(256), 0, st, (const uint8_t*)r.Mb.ptr, r.ldmb, rows, cols, pc,
+                       r.kn_pw, cnt);
+    check_launch("known_row_count");
+    const size_t nseg_r = (size_t)rows * pc, nseg_c = (size_t)cols * pr;
+    std::vector<int> hc(std::max(nseg_r, nseg_c));
+    std::vector<int64_t> hp(std::max(nseg_r, nseg_c) + 1);
+    SKF_HIP(hipMemcpyAsync(hc.data(), cnt, nseg_r * 4, hipMemcpyDeviceToHost, st));
+    SKF_HIP(hipStreamSynchronize(st));
+    int64_t tot = 0;
+    for (size_t k = 0; k < nseg_r; ++k) { hp[k] = tot; tot += hc[k]; }
+    hp[nseg_r] = tot;
+    if (tot > r.kn_cap)
+        SKF_FAIL(SKF_E_INVALID, "a masked relation holds %lld known entries, more than the bound %lld given in skf_relation_desc.known_bound",
+                 (long long)tot, (long long)r.kn_cap);
+    r.kn_nnz = tot;
+    SKF_HIP(hipMemcpyAsync(r.KrPtr.ptr, hp.data(), (nseg_r + 1) * 8, hipMemcpyHostToDevice, st));
+    SKF_HIP(hipMemsetAsync(cnt, 0, 2 * nseg_c * 4, st));
+    SKF_HIP(hipStreamSynchronize(st));                      // (`hp` is reused below)
+    int* fillpos = cnt + nseg_c;
+    if (tot > 0) {
+        hipLaunchKernelGGL((known_row_fill_kernel<TR, TM>), dim3(wgrid), dim3(256), 0, st, (const uint8_t*)r.Mb.ptr, r.ldmb, rows, cols,
+                           pc, (const int64_t*)r.KrPtr.ptr, (const TR*)r.R_in, r.ld_in, (int*)r.KrIdx.ptr, (TM*)r.KrVal.ptr);
+        hipLaunchKernelGGL(known_col_count_kernel, dim3(wgrid), dim3(256), 0, st, (const int64_t*)r.KrPtr.ptr, (const int*)r.KrIdx.ptr,
+                           pc, rows, pr, r.kn_ph, cnt);
+        check_launch("known_row_fill");
+    }
+    SKF_HIP(hipMemcpyAsync(hc.data(), cnt, nseg_c * 4, hipMemcpyDeviceToHost, st));
+    SKF_HIP(hipStreamSynchronize(st));
+    int64_t t2 = 0;
+    for (size_t k = 0; k < nseg_c; ++k) { hp[k] = t2; t2 += hc[k]; }
+    hp[nseg_c] = t2;
+    SKF_HIP(hipMemcpyAsync(r.KcPtr.ptr, hp.data(), (nseg_c + 1) * 8, hipMemcpyHostToDevice, st));
+    if (tot > 0) {
+        hipLaunchKernelGGL(known_col_fill_kernel, dim3(wgrid), dim3(256), 0, st, (const int64_t*)r.KrPtr.ptr, (const int*)r.KrIdx.ptr,
+                           pc, rows, pr, r.kn_ph, (const int64_t*)r.KcPtr.ptr, fillpos, (int*)r.KcIdx.ptr);
+        hipLaunchKernelGGL(csc_sort_kernel, dim3(elem_grid((int64_t)nseg_c)), dim3(256), 0, st, (const int64_t*)r.KcPtr.ptr,
+                           (int*)r.KcIdx.ptr, (int64_t)nseg_c);
+        const int cgrid = (int)((cols + 3) / 4 < 2048 ? ((cols + 3) / 4 > 0 ? (cols + 3) / 4 : 1) : 2048);
+        hipLaunchKernelGGL((known_col_values_kernel<TR, TM>), dim3(cgrid), dim3(256), 0, st, (const int64_t*)r.KcPtr.ptr,
+                           (const int*)r.KcIdx.ptr, pr, cols, (const TR*)r.R_in, r.ld_in, (TM*)r.KcVal.ptr);
+        check_launch("known_col_fill");
+        // before the first iteration the completed relation is the known entries and zeros (_dfmc.py:287-292): E = R there
+        SKF_HIP(hipMemcpyAsync(r.KcE.ptr, r.KcVal.ptr, (size_t)tot * sizeof(TM), hipMemcpyDeviceToDevice, st));
+    }
+    SKF_HIP(hipMemsetAsync(r.Sp.ptr, 0, r.Sp.bytes, st));
+    if (r.FoB.bytes) {
+        SKF_HIP(hipMemsetAsync(r.FoB.ptr, 0, r.FoB.bytes, st));
+        SKF_HIP(hipMemsetAsync(r.FiB.ptr, 0, r.FiB.bytes, st));
+    }
+    SKF_HIP(hipStreamSynchronize(st));                      // the host vectors die here; bind is not on the hot path
+    r.R = nullptr;                                          // nothing reads the relation itself after this
+}
+static void build_known_lists(skf_plan* p, RelState& r, hipStream_t st) {
+    if (p->bf16) build_known_lists_t<uint16_t, float>(p, r, st);
+    else if (p->f64) build_known_lists_t<double, double>(p, r, st);
+    else build_known_lists_t<float, float>(p, r, st);
+}
+
 }  // namespace skf
 
 using namespace skf;
@@ -1721,6 +2033,36 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             s.col_side = (d.flags & SKF_REL_NO_COL_SIDE) == 0;
             s.masked = d.mask != nullptr || (d.flags & SKF_REL_MASKED) != 0;
             if (absent) { s.R_in = s.R = nullptr; s.mask = nullptr; }
+            if (d.known_bound < 0) SKF_FAIL(SKF_E_INVALID, "relation %d: negative bound on the known entries", r);
+            s.kn_cap = (s.mask && p->variant == SKF_DFMC) ? d.known_bound : 0;
+        }
+        // masked relations with few known entries are kept as lists of those entries (skf_known.h).  The three passes over the
+        // lists gather rank_row-wide vectors -- ~70 ps per entry at rank 128 against ~2.2 ps per CELL for the four passes of
+        // the dense path over the completed relation (config 5, bf16) -- hence: known share * rank_row <= 4 (1/32 at rank
+        // 128).  SKF_DFMC_SPARSE=0: never; =1: whenever a bound is given (up to a quarter of the relation).  Plans with row
+        // blocks keep the dense form.
+        {
+            const char* ev = getenv("SKF_DFMC_SPARSE");
+            const int mode = ev ? atoi(ev) : -1;
+            const char* evp = getenv("SKF_KNOWN_PARTS");
+            int parts = evp ? atoi(evp) : 1;          // (pinning slices of the gathered factors to XCDs measured neutral)
+            if (parts != 2 && parts != 4 && parts != 8) parts = 1;
+            for (RelState& s : p->rels) {
+                if (s.kn_cap <= 0) continue;
+                const double cells = (double)s.nr * (double)p->types[s.col].n;
+                const double share = cells > 0 ? (double)s.kn_cap / cells : 1.0;
+                const int ci = p->types[s.row].c;
+                if (p->sliced || mode == 0 || share > 0.25 || (mode != 1 && share * ci > 4.0) || ci > 64 * SRP_MAXREP ||
+                    s.kn_cap > 2000000000LL) {
+                    s.kn_cap = 0;
+                    continue;
+                }
+                s.kn = true;
+                s.kn_pc = s.kn_pr = parts;
+                s.kn_pw = ((p->types[s.col].n + parts - 1) / parts + 63) / 64 * 64;
+                s.kn_ph = ((s.nr + parts - 1) / parts + 63) / 64 * 64;
+                p->types[s.row].keep_prev = p->types[s.col].keep_prev = true;
+            }
         }
         p->thetas.resize(n_thetas);
         for (int t = 0; t < n_thetas; ++t) {
@@ -1771,6 +2113,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 add_slot(p, t.GTb, (size_t)t.c * t.ldgt * 2);
             }
             want_part(t.c, t.c, (int)t.n, true);
+            if (t.keep_prev) add_slot(p, t.Gp, (size_t)t.n * t.c * es);
             if (p->variant != SKF_TRANSFORM) {
                 add_slot(p, t.K, (size_t)t.c * t.c * 8);
                 if (!p->f64) {
@@ -1815,8 +2158,8 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             if (p->variant == SKF_TRANSFORM) { r.nr = ti.n; r.r0 = 0; }
             add_slot(p, r.S, cc);
             add_slot(p, r.U, cc);
-            if (nr > 0) add_slot(p, r.H, (size_t)nr * tj.c * es);
-            if (nr > 0 && (p->variant != SKF_TRANSFORM || r.row == p->target)) add_slot(p, r.P, (size_t)nr * tj.c * es);
+            if (nr > 0 && !r.kn) add_slot(p, r.H, (size_t)nr * tj.c * es);
+            if (nr > 0 && !r.kn && (p->variant != SKF_TRANSFORM || r.row == p->target)) add_slot(p, r.P, (size_t)nr * tj.c * es);
             if (p->variant == SKF_TRANSFORM && r.col == p->target) add_slot(p, r.Q, (size_t)tj.n * ti.c * es);
             if (p->variant != SKF_TRANSFORM) {
                 add_slot(p, r.T1, cc);
@@ -1827,6 +2170,43 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             want_part(ti.c, ti.c, tj.c, true);
             want_part(tj.c, tj.c, ti.c, true);
             if (nr <= 0) continue;
+            if (r.kn) {
+                // the known entries as row lists and column lists, the gathered vectors, the row-side product, c x c scratch
+                const size_t cap = (size_t)r.kn_cap;
+                r.ldmb = (tj.n + 127) / 128 * 16;
+                add_slot(p, r.Mb, (size_t)nr * r.ldmb);                         // (bind time only)
+                add_slot(p, r.KrPtr, ((size_t)nr * r.kn_pc + 1) * 8);
+                add_slot(p, r.KrIdx, cap * 4);
+                add_slot(p, r.KrVal, cap * es);
+                add_slot(p, r.KcPtr, ((size_t)tj.n * r.kn_pr + 1) * 8);
+                add_slot(p, r.KcIdx, cap * 4);
+                add_slot(p, r.KcVal, cap * es);
+                add_slot(p, r.KcE, cap * es);
+                const size_t cnt = std::max((size_t)nr * r.kn_pc, 2 * (size_t)tj.n * r.kn_pr);
+                add_slot(p, r.KCnt, cnt * 4);
+                r.kn_ldf = p->bf16 ? (ti.c + 7) / 8 * 8 : ti.c;
+                if (p->bf16) {
+                    add_slot(p, r.FoB, (size_t)nr * r.kn_ldf * 2);
+                    add_slot(p, r.FiB, (size_t)tj.n * r.kn_ldf * 2);
+                }
+                add_slot(p, r.Tm, (size_t)tj.n * ti.c * es);
+                add_slot(p, r.A, (size_t)nr * ti.c * es);
+                if (r.kn_pc > 1) add_slot(p, r.Apart, (size_t)r.kn_pc * nr * ti.c * es);
+                if (r.kn_pr > 1) add_slot(p, r.Qpart, (size_t)r.kn_pr * tj.n * ti.c * es);
+                add_slot(p, r.Sp, cc);
+                add_slot(p, r.U2, cc);
+                add_slot(p, r.Xi, (size_t)ti.c * ti.c * 8);
+                add_slot(p, r.Xj, (size_t)tj.c * tj.c * 8);
+                add_slot(p, r.Bf, (size_t)ti.c * ti.c * 8);
+                want_part(ti.c, tj.c, (int)tj.n, true);                         // W = Y^T G_j
+                want_part(ti.c, ti.c, (int)nr, true);                           // G_i'^T G_i
+                want_part(tj.c, tj.c, (int)tj.n, true);                         // G_j^T G_j'
+                want_part((int)tj.n, ti.c, tj.c, p->f64);                       // T = G_j S^T ; Q += G_j (S^T Gram_i)
+                want_part((int)nr, ti.c, ti.c, p->f64);                         // A += G_i (S Gram_j S^T)
+                const size_t waves = (size_t)r.kn_pr * ((size_t)tj.n + 32) + 64;   // error partials: one per wave of the column pass
+                if (waves > sq_elems) sq_elems = waves;
+                continue;
+            }
             if (r.mask && !p->bf16) add_slot(p, r.Rw, (size_t)nr * tj.n * es);
             if (r.mask) {
                 r.ldmb = (tj.n + 127) / 128 * 16;               // bytes per packed mask row: whole 128-column tiles
@@ -2014,6 +2394,10 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
                                    r.ldmb, r.mask, r.ldmask, rows, cols);
             }
             check_launch("pack_mask");
+            if (r.kn) {                            // the known entries as lists; no working copy of the relation
+                build_known_lists(p, r, st);
+                continue;
+            }
             if (p->bf16) {
                 // known entries of every tile of the completion pass (256 rows x epi_tile columns) as a compact list
                 // (count, prefix sum on the host, fill)
@@ -2053,7 +2437,7 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             // P = R G_j); it is not referenced after this call
             for (TypeState& t : p->types) SKF_HIP(hipMemsetAsync(t.GTb.ptr, 0, t.GTb.bytes, st));
             for (RelState& r : p->rels) {
-                if (r.absent) continue;
+                if (r.absent || r.kn) continue;
                 const int64_t rows = r.nr, cols = p->types[r.col].n;
                 if (r.binary) {
                     int* bad = (int*)p->sqpart.ptr;                  // (scratch word; bind is not on the hot path)
@@ -2186,6 +2570,7 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
         p->bound = true;
         p->prepared = false;
         p->first_iter = true;
+        p->kn_first = true;
     });
 }
 
@@ -2364,6 +2749,49 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
             SKF_HIP(hipMemsetAsync(out, 0, sizeof(double), st));
             return;
         }
+        if (r.kn) {
+            // The completed relation of _dfmc.py:385-386 is X_o + E (X_o = G_i,prev S_prev G_j,prev^T, E the stored residuals);
+            // with X_n = G_i S G_j^T of the current factors
+            //     |R_c - X_n|^2 = |X_o - X_n|^2 + sum over the known entries of (r - x_n)^2 - (x_o - x_n)^2 ,  x_o = r - e
+            // the first term from c x c Gram / cross-Gram products, the second from one pass over the column lists.
+            double* acc = (double*)p->sqpart.ptr;
+            auto trace_term = [&](const void* Ai, const void* S1, const void* Bj, const void* S2, double scale, bool first) {
+                GemmArgs h = gemm_args(Ai, ci, 1, S1, cj, 1, r.U.ptr, cj, ci, cj, ci, EPI_STORE, 0);          // U = A_i S1
+                small_gemm(p, h, st);
+                h = gemm_args(r.U.ptr, cj, 1, Bj, cj, 1, r.T1.ptr, cj, ci, cj, cj, EPI_STORE, 0);             // T1 = U B_j
+                small_gemm(p, h, st);
+                hipLaunchKernelGGL(dot_small_kernel, dim3(1), dim3(256), 0, st, (const double*)S2, (const double*)r.T1.ptr,
+                                   (int64_t)ci * cj, scale, acc, first ? 0 : 1);
+                check_launch("dot_small");
+            };
+            auto gram_of = [&](const void* A, const void* B, void* C, int c, int64_t n) {                      // C = A^T B (c x c)
+                GemmArgs h = gemm_args(A, 1, c, B, c, 1, C, c, c, c, (int)n, EPI_STORE, 0);
+                wide_gemm(p, h, st);
+            };
+            // (the partial slots [1, waves] belong to the pass below; slot 0 collects the trace terms)
+            gram_of(ti.G.ptr, ti.G.ptr, r.Xi.ptr, ci, r.nr);
+            gram_of(tj.G.ptr, tj.G.ptr, r.Xj.ptr, cj, tj.n);
+            trace_term(r.Xi.ptr, r.S.ptr, r.Xj.ptr, r.S.ptr, 1.0, true);
+            if (!p->kn_first) {
+                gram_of(ti.Gp.ptr, ti.G.ptr, r.Xi.ptr, ci, r.nr);            // G_i,prev^T G_i
+                gram_of(tj.G.ptr, tj.Gp.ptr, r.Xj.ptr, cj, tj.n);            // G_j^T G_j,prev
+                trace_term(r.Xi.ptr, r.S.ptr, r.Xj.ptr, r.Sp.ptr, -2.0, false);
+                gram_of(ti.Gp.ptr, ti.Gp.ptr, r.Xi.ptr, ci, r.nr);
+                gram_of(tj.Gp.ptr, tj.Gp.ptr, r.Xj.ptr, cj, tj.n);
+                trace_term(r.Xi.ptr, r.Sp.ptr, r.Xj.ptr, r.Sp.ptr, 1.0, false);
+            }
+            known_refresh_rows(p, r, st);
+            GemmArgs g2 = gemm_args(tj.G.ptr, cj, 1, r.S.ptr, 1, cj, r.Tm.ptr, ci, nj, ci, cj, EPI_STORE, 0);  // T = G_j S^T
+            mixed_gemm(p, g2, st);
+            if (p->bf16) launch_to_bf16<float>((uint16_t*)r.FiB.ptr, r.kn_ldf, (const float*)r.Tm.ptr, (int64_t)ci, tj.n, ci, false, st);
+            p->sqpart.ptr = (char*)p->sqpart.ptr + 8;                       // the pass writes its partials behind slot 0
+            const int waves = known_pass(p, r, true, SRP_ERR, st);
+            p->sqpart.ptr = (char*)p->sqpart.ptr - 8;
+            if ((size_t)waves + 1 > p->sq_elems) SKF_FAIL(SKF_E_STATE, "residual partials: %d waves > %zu slots", waves, p->sq_elems);
+            hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(1), dim3(256), 0, st, (const double*)p->sqpart.ptr, waves + 1, out);
+            check_launch("sum_partials");
+            return;
+        }
         GemmArgs g = gemm_args(rows_of(p, ti.G, ti, r.r0), ci, 1, r.S.ptr, cj, 1, r.H.ptr, cj, ni, cj, ci, EPI_STORE, 0);
         mixed_gemm(p, g, st);
         if (p->bf16) {
@@ -2395,13 +2823,14 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
 int skf_get_contraction(const skf_plan* p, int32_t rel, int32_t which, void* dst, int64_t ld, void* stream) {
     return guarded([&] {
         check_bound(p);
-        if (rel < 0 || rel >= (int)p->rels.size() || !dst || (which != 0 && which != 1))
+        if (rel < 0 || rel >= (int)p->rels.size() || !dst || which < 0 || which > 2)
             SKF_FAIL(SKF_E_INVALID, "bad relation index / selector / pointer");
         const RelState& r = p->rels[rel];
         const TypeState& ti = p->types[r.row];
         const TypeState& tj = p->types[r.col];
-        const Slot& src = which == 0 ? r.P : r.Q;
-        const int64_t rows = which == 0 ? r.nr : tj.n, cols = which == 0 ? tj.c : ti.c;
+        if (which == 2 && !r.kn) SKF_FAIL(SKF_E_STATE, "relation %d forms P, not P S^T (which = 2 is for known-entries relations)", rel);
+        const Slot& src = which == 0 ? r.P : which == 1 ? r.Q : r.A;
+        const int64_t rows = which == 1 ? tj.n : r.nr, cols = which == 0 ? tj.c : ti.c;
         if (!src.ptr || rows <= 0) SKF_FAIL(SKF_E_STATE, "relation %d keeps no %s here", rel, which == 0 ? "P" : "Q");
         if (ld < cols) SKF_FAIL(SKF_E_INVALID, "ld too small");
         copy2d(dst, ld, src.ptr, cols, rows, cols, p->esz, as_stream(stream));
@@ -2413,14 +2842,14 @@ int skf_plan_set_profiling(skf_plan* p, int32_t enable) {
         if (!p) SKF_FAIL(SKF_E_INVALID, "null plan");
         p->profiling = enable != 0;
         p->ev_used = 0;
-        p->prof_flops = 0.0;
+        p->prof_flops = p->prof_bytes = 0.0;
         p->prof_launches = 0;
     });
 }
 
-int skf_plan_get_profile(skf_plan* p, double* total_ms, int64_t* launches, double* flops) {
+int skf_plan_get_profile(skf_plan* p, double* total_ms, int64_t* launches, double* flops, double* bytes) {
     return guarded([&] {
-        if (!p || !total_ms || !launches || !flops) SKF_FAIL(SKF_E_INVALID, "null argument");
+        if (!p || !total_ms || !launches || !flops || !bytes) SKF_FAIL(SKF_E_INVALID, "null argument");
         double ms = 0.0;
         for (size_t k = 0; k + 1 < p->ev_used; k += 2) {
             SKF_HIP(hipEventSynchronize(p->ev_pool[k + 1]));
@@ -2431,8 +2860,9 @@ int skf_plan_get_profile(skf_plan* p, double* total_ms, int64_t* launches, doubl
         *total_ms = ms;
         *launches = p->prof_launches;
         *flops = p->prof_flops;
+        *bytes = p->prof_bytes;
         p->ev_used = 0;
-        p->prof_flops = 0.0;
+        p->prof_flops = p->prof_bytes = 0.0;
         p->prof_launches = 0;
     });
 }

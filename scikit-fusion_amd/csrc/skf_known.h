@@ -61,9 +61,9 @@ template <> struct GatherT<double> {
 // workgroup -> (part, outer object of wave 0): blocks b, b + 8, ... share an XCD; part = (b % 8) % parts
 __device__ __forceinline__ void srp_segment(int parts, int& part, int64_t& first) {
     const int xcd = blockIdx.x & 7;
+    const int lg = parts >= 8 ? 3 : parts >= 4 ? 2 : parts >= 2 ? 1 : 0;      // parts is 1, 2, 4 or 8
     part = xcd & (parts - 1);
-    const int per = 8 / parts;                                   // blocks of one part per round of 8
-    first = ((int64_t)(blockIdx.x >> 3) * per + xcd / parts) * 4;      // 4 waves = 4 outer objects per workgroup
+    first = ((int64_t)(blockIdx.x >> 3) * (8 >> lg) + (xcd >> lg)) * 4;       // 4 waves = 4 outer objects per workgroup
 }
 
 // 16-byte row chunks: GL lanes cover one gathered vector (w = GL * 16 / sizeof(TG)), 64 / GL entries per wave step.
@@ -174,12 +174,17 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_add(float x) {
     return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ int64_t wave_uniform(int64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)hi << 32) | lo);
-}
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// x + <a, b> over the eight bf16 of two 16-byte chunks: four v_dot2c_f32_bf16.  (The dwords are copied out of the vectors
+// first: host clang's __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index -- seen in the emulator
+// build; hipcc is not affected.)
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float x) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), x, false);
+}
+__device__ __forceinline__ float dot8_bf16(u32x4 a, u32x4 b, float x) {
+    const uint32_t a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+    return dot2_bf16(a3, b3, dot2_bf16(a2, b2, dot2_bf16(a1, b1, dot2_bf16(a0, b0, x))));
+}
 
 template <int GL>
 __global__ __launch_bounds__(256) void srp_bf16_kernel(SrpArgs<uint16_t, float> a) {
@@ -223,10 +228,7 @@ __global__ __launch_bounds__(256) void srp_bf16_kernel(SrpArgs<uint16_t, float> 
                     if (a.mode != SRP_RESIDUAL) e = __shfl(my_e, ent & 63, 64);
                     if (a.mode != SRP_APPLY) {
                         const float r = __shfl(my_r, ent & 63, 64);
-                        float x = 0.f;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            x = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, fo[t]), __builtin_bit_cast(bf16x2, v[u][t]), x, false);
+                        float x = dot8_bf16(fo, v[u], 0.f);
                         x = dpp_add<0xB1>(x);                            // quad_perm [1,0,3,2]
                         x = dpp_add<0x4E>(x);                            // quad_perm [2,3,0,1]
                         x = dpp_add<0x141>(x);                           // row_half_mirror

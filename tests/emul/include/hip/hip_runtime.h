@@ -316,6 +316,16 @@ inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+// DPP lane exchanges used by the kernels: quad_perm (ctrl < 0x100), row_mirror (0x140), row_half_mirror (0x141)
+inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
+    const int l = simt::lane_id();
+    int t;
+    if (ctrl < 0x100) t = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+    else if (ctrl == 0x140) t = (l & ~15) | (15 - (l & 15));
+    else if (ctrl == 0x141) t = (l & ~7) | (7 - (l & 7));
+    else abort();
+    return simt::wave_read(src, t);
+}
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
@@ -434,6 +444,13 @@ inline simt_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, simt_
     return d;
 }
 
+typedef __bf16 simt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short simt_u16x2 __attribute__((ext_vector_type(2)));
+inline float simt_bf16_to_f32(unsigned short h);
+inline float __builtin_amdgcn_fdot2_f32_bf16(simt_bf16x2 a, simt_bf16x2 b, float c, bool) {      // v_dot2c_f32_bf16
+    const simt_u16x2 ua = __builtin_bit_cast(simt_u16x2, a), ub = __builtin_bit_cast(simt_u16x2, b);
+    return c + simt_bf16_to_f32(ua[0]) * simt_bf16_to_f32(ub[0]) + simt_bf16_to_f32(ua[1]) * simt_bf16_to_f32(ub[1]);
+}
 typedef __bf16 simt_bf16x8 __attribute__((ext_vector_type(8)));
 inline simt_f32x4 simt_mfma_f32_16x16x32_bf16(simt_s16x8 a, simt_s16x8 b, simt_f32x4 c);
 inline simt_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(simt_bf16x8 a, simt_bf16x8 b, simt_f32x4 c, int, int, int) {

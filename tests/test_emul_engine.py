@@ -674,3 +674,47 @@ def test_fold_in_of_binary_new_relations_bf16():
     assert relerr(got64, want) < 1e-10
     got = _dfmf.transform(Rn, {}, 't', rank, Gf, S, max_iter=20, G0=G0, dtype='bf16')
     assert relerr(got, want) < 1e-2
+
+
+@pytest.mark.parametrize('dtype,parts,rank_a', [('f64', 1, 64), ('f64', 4, 64), ('f32', 1, 64), ('f32', 1, 20), ('bf16', 2, 64),
+                                               ('bf16', 1, 128)])
+def test_dfmc_on_the_known_entries_only_matches_the_dense_completion(dtype, parts, rank_a, monkeypatch):
+    """skf_relation_desc.known_bound: a masked relation kept as lists of its known entries (csrc/skf_known.h) -- the
+    completed relation of _dfmc.py:319-325 is never formed.  f64: equal to the dense path to rounding; rank 64 on the row
+    type takes the 16-byte-chunk list kernels (f64: 32 lanes per vector, f32: 16, bf16: 8 -- 16 at rank 128 -- with v_dot2 +
+    DPP), rank 20 the any-width kernel.  (bf16: the dense path rounds every completed entry to bf16, the lists do not.)"""
+    import known_cases as K
+    n, ranks = {'a': 150, 'b': 130, 'c': 40}, {'a': rank_a, 'b': 24, 'c': 5}
+    # (G, S, squared errors, P S^T, Q); measured f64 <= 3e-14 / 2e-13 / 1.2e-14 / 1.3e-13 / 1.3e-13, bf16 <= 1.4e-3 / 2e-2 / 1e-3 / 3e-2 / 2e-3
+    tol = {'f64': (2e-13, 1e-12, 1e-13, 1e-12, 1e-12), 'f32': (2e-6, 1e-5, 1e-6, 1e-5, 2e-6),
+           'bf16': (7e-3, 1e-1, 5e-3, 1.5e-1, 1e-2)}[dtype]
+    K.sparse_against_dense(n, ranks, 0.06, 3, dtype, tol, 'emulator %s parts %d rank %d' % (dtype, parts, rank_a), monkeypatch, parts)
+
+
+def test_known_entries_dfmc_c5_golden_and_bound_too_small(monkeypatch):
+    """The scaled config 5 (2 % of the ratings known) takes the list path by default and reproduces the reference golden;
+    a bound below the true count is refused at bind time."""
+    from helpers import movielens_style_graph
+    from skfusion_amd._engine import DevicePlan, flatten_relations, flatten_thetas, count_objects, pack_mask
+    z = golden('c5_movielens_scaled.npz')
+    R, M, Theta, types, rank = movielens_style_graph()
+    snaps = Snapshots(range(6))
+    _dfmc.dfmc(R, M, Theta, types, rank, max_iter=6, callback=snaps, G0=g0_from(z, 'dfmc/', types))
+    assert compare_snapshots(z, 'dfmc/', snaps.snap, 1e-10) < 1e-10
+    rel = flatten_relations(R, M)
+    n = count_objects(types, R)
+    plan = DevicePlan(types, n, rank, rel, flatten_thetas(Theta), nat.SKF_DFMC)
+    assert plan.get_contraction.__self__ is plan
+    for t in types:
+        plan.set_factor(t, z['dfmc/G0_%s' % t])
+    plan.iterate(1)
+    assert plan.get_contraction(0, 2).shape == (n['user'], rank['user'])       # the list path is the one that ran
+    with pytest.raises(nat.SkfNativeError):
+        plan.get_contraction(0, 0)                                             # ... and it never forms P
+    plan.close()
+    import emul.runtime as er
+    mem = nat._runtime.mem
+    pm = pack_mask(rel[0][3], mem)
+    pm.known = pm.known - 5
+    with pytest.raises(nat.SkfNativeError, match='known entries'):
+        DevicePlan(types, n, rank, [(rel[0][0], rel[0][1], rel[0][2], pm)] + rel[1:], flatten_thetas(Theta), nat.SKF_DFMC)

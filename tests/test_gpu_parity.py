@@ -654,3 +654,20 @@ def test_rank_deficient_fit_at_rank_256_keeps_its_speed(rt):
     for t in types:
         bound = {'a': 2.5e-13, 'b': 1e-12}[str(t)]                 # measured 4.7e-14 / 1.9e-13
         within(relerr(Gd[t], Go[t, t]), bound, 'rank-deficient fit at rank 256: G_%s vs the oracle (scipy pinv) after 8 iterations' % t)
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32', 'bf16'])
+@pytest.mark.parametrize('rank_a', [64, 128, 256])
+def test_dfmc_on_the_known_entries_only_matches_the_dense_completion(dtype, rank_a, monkeypatch):
+    """skf_relation_desc.known_bound on the hardware: a 3000 x 2600 masked relation with 2 % of its entries known kept as lists
+    (csrc/skf_known.h; the relation-pipelined DFMC schedule) against the dense path with its completed copy -- (G, S), the
+    squared errors of every iteration (skf_relation_sqerr: trace terms + one list pass), the row-side product and Q.  The
+    ranks walk the list kernels: bf16 8 / 16 / 32 lanes per vector (v_dot2c + DPP), f32 16 / 32 / 64, f64 32 / 64 / any-width."""
+    import known_cases as K
+    n, ranks = {'a': 3000, 'b': 2600, 'c': 500}, {'a': rank_a, 'b': 256 if rank_a < 256 else 128, 'c': 64}
+    # (G, S, squared errors, P S^T, Q), measured in round 3 (profiles/r03_test_deviations.txt):
+    #   f64  3.6e-13 / 1.2e-12 / 2.6e-14 / 5.1e-13 / 7.6e-13      f32  1.4e-6 / 7.1e-6 / 3.0e-8 / 2.0e-6 / 4.7e-7
+    #   bf16 2.3e-3 / 5.3e-3 / 1.1e-4 / 1.0e-2 / 2.3e-3  (the dense path rounds every completed entry to bf16, the lists do not)
+    tol = {'f64': (1.5e-12, 6e-12, 1.3e-13, 2.5e-12, 4e-12), 'f32': (7e-6, 3.5e-5, 1.5e-7, 1e-5, 2.5e-6),
+           'bf16': (1.2e-2, 2.5e-2, 5.5e-4, 5e-2, 1.2e-2)}[dtype]
+    K.sparse_against_dense(n, ranks, 0.02, 4, dtype, tol, 'GPU %s rank %d' % (dtype, rank_a), monkeypatch)
