@@ -528,6 +528,7 @@ struct skf_plan {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     skf::Slot part_aux;
     size_t part_aux_bytes = 0;
+
     skf::Switches sw;                      // read once in skf_plan_bind_workspace
     bool overlap = false;
     bool pipeline = true;                  // relation-pipelined schedule of the DFMF iteration (SKF_NO_PIPELINE=1 at bind: off)
@@ -960,10 +961,17 @@ static int launch_srp(const SrpArgs<TG, TM>& a, hipStream_t st, bool generic) {
     bool done = false;
     if constexpr (std::is_same<TG, uint16_t>::value) {
         done = true;
-        if (gl == 8) hipLaunchKernelGGL((srp_bf16_kernel<8>), dim3(grid), dim3(256), 0, st, a);
-        else if (gl == 16) hipLaunchKernelGGL((srp_bf16_kernel<16>), dim3(grid), dim3(256), 0, st, a);
-        else if (gl == 32) hipLaunchKernelGGL((srp_bf16_kernel<32>), dim3(grid), dim3(256), 0, st, a);
+#define SKF_SRP_BF16(GL_)                                                                                                   \
+    do {                                                                                                                    \
+        if (a.mode == SRP_RESIDUAL) hipLaunchKernelGGL((srp_bf16_kernel<GL_, SRP_RESIDUAL>), dim3(grid), dim3(256), 0, st, a); \
+        else if (a.mode == SRP_APPLY) hipLaunchKernelGGL((srp_bf16_kernel<GL_, SRP_APPLY>), dim3(grid), dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((srp_bf16_kernel<GL_, SRP_ERR>), dim3(grid), dim3(256), 0, st, a);                            \
+    } while (0)
+        if (gl == 8) SKF_SRP_BF16(8);
+        else if (gl == 16) SKF_SRP_BF16(16);
+        else if (gl == 32) SKF_SRP_BF16(32);
         else done = false;
+#undef SKF_SRP_BF16
     }
     if (!done) {
         if (gl == 8) hipLaunchKernelGGL((srp_vec_kernel<TG, TM, 8>), dim3(grid), dim3(256), 0, st, a);
@@ -1063,7 +1071,7 @@ static void known_w(skf_plan* p, RelState& r, hipStream_t st) {
     known_refresh_rows(p, r, st);
     known_pass(p, r, true, SRP_APPLY, st);                                                          // Y = E_prev^T G_i  -> r.Q
     GemmArgs g = gemm_args(r.Q.ptr, 1, ci, tj.G.ptr, cj, 1, r.W.ptr, cj, ci, cj, (int)tj.n, EPI_STORE, 0);
-    wide_gemm(p, g, st);                                                                            // W = Y^T G_j
+    wide_gemm(p, g, st);                                                                // W = Y^T G_j
     if (p->kn_first) return;
     g = gemm_args(ti.G.ptr, 1, ci, ti.Gp.ptr, ci, 1, r.Xi.ptr, ci, ci, ci, (int)r.nr, EPI_STORE, 0);    // Xi = G_i^T G_i,prev
     wide_gemm(p, g, st);
@@ -1107,12 +1115,16 @@ static void known_col_pass(skf_plan* p, RelState& r, hipStream_t st) {
 }
 
 // row side of the factor update from the row-side product itself: A = G_i Bf + E T, E_i (+)= A+, D_i (+)= A-
-static void known_row_side(skf_plan* p, RelState& r, bool accumulate, hipStream_t st, bool second_stream) {
+static void known_row_dense(skf_plan* p, RelState& r, hipStream_t st, bool second_stream) {
     TypeState& ti = p->types[r.row];
     const int ci = ti.c;
     GemmArgs g = gemm_args(ti.G.ptr, ci, 1, r.Bf.ptr, ci, 1, r.A.ptr, ci, (int)r.nr, ci, ci, EPI_ACC, 0);
     if (second_stream) mixed_gemm_unsplit(p, g, st);
     else mixed_gemm(p, g, st);
+}
+static void known_row_split(skf_plan* p, RelState& r, bool accumulate, hipStream_t st) {
+    TypeState& ti = p->types[r.row];
+    const int ci = ti.c;
     const int64_t total = r.nr * ci;
     if (p->f64)
         hipLaunchKernelGGL((split_accumulate_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, (double*)ti.E.ptr,
@@ -1121,6 +1133,10 @@ static void known_row_side(skf_plan* p, RelState& r, bool accumulate, hipStream_
         hipLaunchKernelGGL((split_accumulate_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st, (float*)ti.E.ptr,
                            (float*)ti.D.ptr, (const float*)r.A.ptr, total, accumulate ? 1 : 0);
     check_launch("split_accumulate");
+}
+static void known_row_side(skf_plan* p, RelState& r, bool accumulate, hipStream_t st, bool second_stream) {
+    known_row_dense(p, r, st, second_stream);
+    known_row_split(p, r, accumulate, st);
 }
 
 // DFMC, first iteration: the unknown entries of every masked relation start at zero (_dfmc.py:287-292)
@@ -1669,7 +1685,7 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         const int ni = (int)r.nr, nj = (int)tj.n, ci = ti.c, cj = tj.c;
         SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[ev_p], 0));
         if (r.kn)
-            known_row_side(p, r, touched[r.row] != 0, ax, true);
+            known_row_split(p, r, touched[r.row] != 0, ax);
         else
             side_update(p, r.P.ptr, cj, cj, Sm[q], 1, cj, ti, ti.G.ptr, ti.E.ptr, ti.D.ptr, ni, nullptr, nullptr, false,
                         touched[r.row] != 0, nan_upd, ax);
@@ -1697,6 +1713,9 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         TypeState& tj = p->types[r.col];
         const bool by_q = ti.c < tj.c;
         if (r.kn) {           // known entries only: W from the stored residuals; second stream: backbone, gathered vectors, c x c operands
+            // (Measured, profiles/r03_c5_known_entries.txt: on a third stream, beside the matrix-core contractions of the
+            // unmasked relations, the pass over the stored residuals just time-slices the chip with them -- 2.0 ms instead
+            // of 0.55 ms for user x tag, 92.2 vs 91.6 it/s.  Its 10 000 workgroups leave no CU to share.)
             known_w(p, r, st);
             SKF_HIP(hipEventRecord(p->ev_rel[4 * q], st));
             backbone_chain(q);
@@ -1737,6 +1756,8 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         SKF_HIP(hipStreamWaitEvent(st, p->ev_rel[4 * q + 1], 0));
         if (r.kn) {           // the two residual passes over the lists stand for completion, P and Q
             known_row_pass(p, r, st);
+            known_row_dense(p, r, st, false);       // (0.1 ms here; on the low-priority second stream it crawled for 2 ms
+                                                    // underneath the column pass and slowed that pass down by 0.4 ms)
             SKF_HIP(hipEventRecord(p->ev_rel[4 * q + 2], st));
             known_col_pass(p, r, st);
             SKF_HIP(hipEventRecord(p->ev_rel[4 * q + 3], st));

@@ -21,6 +21,7 @@
 // parts are summed in a fixed order: results are run-to-run deterministic, no float atomics.
 #pragma once
 #include "skf_kernels.h"
+#include <type_traits>
 
 namespace skf {
 
@@ -167,9 +168,11 @@ __global__ __launch_bounds__(256) void srp_vec_kernel(SrpArgs<TG, TM> a) {
 //     but touches 16 half-used lines per load and gathered 9 TB/s even without the dot products);
 //   * dot products as v_dot2c_f32_bf16 on the packed pairs (4 instead of 16 VALU operations per 8 elements), summed over
 //     the lane group by DPP adds (quad_perm / row_half_mirror / row_mirror: vector-ALU rate, no LDS crossbar);
-//   * indices / values are loaded 64 entries at a time (one coalesced load, lane l holds entry l of the batch) and handed
-//     to the lane groups by ds_bpermute (loading them per lane group instead -- one broadcast address per group, a loop
-//     trip ahead -- costs a vector-memory instruction each and was slower: 12.6 TB/s without dot products).
+//   * indices / values are loaded a batch at a time (one coalesced load) and handed to the lane groups by DPP row
+//     broadcasts (loading them per lane group instead -- one broadcast address per group, a loop trip ahead -- costs a
+//     vector-memory instruction each and was slower: 12.6 TB/s without dot products; ds_bpermute hand-outs sit on the
+//     LDS pipe), the residuals go back with one coalesced store per batch;
+//   * the mode is a template parameter and out-of-range slots are clamped, not branched around.
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float x) {
     return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
@@ -186,12 +189,28 @@ __device__ __forceinline__ float dot8_bf16(u32x4 a, u32x4 b, float x) {
     return dot2_bf16(a3, b3, dot2_bf16(a2, b2, dot2_bf16(a1, b1, dot2_bf16(a0, b0, x))));
 }
 
-template <int GL>
+// lane k of every row of 16 lanes, broadcast to the row (DPP row_newbcast: vector-ALU rate, no LDS crossbar)
+template <int K>
+__device__ __forceinline__ int row_bcast(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x150 + K, 0xF, 0xF, true); }
+template <int K>
+__device__ __forceinline__ float row_bcast(float x) { return __builtin_bit_cast(float, row_bcast<K>(__builtin_bit_cast(int, x))); }
+
+// GL lanes per gathered vector (w = 8 GL: GL = 8, 16, 32), MODE = SRP_*.  A batch is the entries one coalesced load of
+// the index / value lists hands to the wave -- every ROW of 16 lanes holds the 16 entries its own lane group(s) will
+// process, entry k of a row being broadcast to it by DPP (GL = 16: 64 entries, row g = group g takes 16 g + k;
+// GL = 8: the two groups of a row take its entries k and 8 + k; GL = 32: 32 entries, both rows of a group hold its 16).
+// Out-of-range slots of the last batch gather a valid row and contribute e = 0: no divergent branches in the loop.
+template <int GL, int MODE>
 __global__ __launch_bounds__(256) void srp_bf16_kernel(SrpArgs<uint16_t, float> a) {
-    constexpr int EPW = 64 / GL;            // entries per wave step
-    constexpr int NU = (GL <= 16) ? 4 : 2;  // wave steps (gathers per lane) in flight
+    constexpr int EPB = GL == 32 ? 32 : 64;     // entries per batch
+    constexpr int STEPS = GL == 8 ? 8 : 16;     // wave steps per batch
+    constexpr int NU = 4;                       // wave steps (gathers per lane) in flight
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = lane / GL, sub = lane % GL;
+    // the entry of the batch this lane loads, and the first entry of its group
+    const int slot = GL == 32 ? (lane >> 5) * 16 + (lane & 15) : lane;
+    const int gbase = GL == 32 ? (lane >> 5) * 16 : GL == 16 ? (lane >> 4) * 16 : (lane >> 3) * 8;
+    const bool upper = GL == 8 && (lane & 8) != 0;          // GL = 8: the group that takes the upper half of its row
     int part;
     int64_t first;
     srp_segment(a.parts, part, first);
@@ -200,62 +219,80 @@ __global__ __launch_bounds__(256) void srp_bf16_kernel(SrpArgs<uint16_t, float> 
     if (o < a.n_out) {                                  // (wave-uniform)
         const int64_t qa = a.ptr[o * a.parts + part], qb = a.ptr[o * a.parts + part + 1];
         u32x4 fo = {0u, 0u, 0u, 0u};
-        if (a.mode != SRP_APPLY) fo = *(const u32x4*)(a.Fo + o * a.ldo + sub * 8);
+        if (MODE != SRP_APPLY) fo = *(const u32x4*)(a.Fo + o * a.ldo + sub * 8);
         float acc[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] = 0.f;
-        for (int64_t q0 = qa; q0 < qb; q0 += 64) {
-            const int nb = (int)(qb - q0 < 64 ? qb - q0 : 64);           // entries of this batch: lane l holds entry l
-            const bool mine = lane < nb;
-            const int my_i = mine ? a.idx[q0 + lane] : 0;
-            const float my_r = (mine && a.mode != SRP_APPLY) ? a.rvals[q0 + lane] : 0.f;
-            float my_e = (mine && a.mode != SRP_RESIDUAL) ? a.evals[q0 + lane] : 0.f;
-            for (int s0 = 0; s0 < nb; s0 += EPW * NU) {
+        for (int64_t q0 = qa; q0 < qb; q0 += EPB) {
+            const int nb = (int)(qb - q0 < EPB ? qb - q0 : EPB);         // entries of this batch
+            const int64_t qm = q0 + (slot < nb ? slot : nb - 1);         // (clamped: always a valid entry)
+            const int my_i = a.idx[qm];
+            const float my_r = MODE != SRP_APPLY ? a.rvals[qm] : 0.f;
+            const float my_e = MODE != SRP_RESIDUAL ? a.evals[qm] : 0.f;
+            float e_out = 0.f;                                           // SRP_RESIDUAL: the residual of this lane's entry
+            auto chunk = [&](auto c0) {                                  // NU steps: k = c0 .. c0 + NU - 1
+                constexpr int K0 = decltype(c0)::value;
                 u32x4 v[NU];
+                float r[NU], e[NU];
+                auto fetch = [&](auto uu) {
+                    constexpr int U = decltype(uu)::value, K = K0 + U;
+                    int i = row_bcast<K>(my_i);
+                    r[U] = MODE != SRP_APPLY ? row_bcast<K>(my_r) : 0.f;
+                    e[U] = MODE != SRP_RESIDUAL ? row_bcast<K>(my_e) : 0.f;
+                    if (GL == 8) {                                       // the upper group of a row: entry 8 + k
+                        const int i2 = row_bcast<K + 8>(my_i);
+                        i = upper ? i2 : i;
+                        if (MODE != SRP_APPLY) { const float r2 = row_bcast<K + 8>(my_r); r[U] = upper ? r2 : r[U]; }
+                        if (MODE != SRP_RESIDUAL) { const float e2 = row_bcast<K + 8>(my_e); e[U] = upper ? e2 : e[U]; }
+                    }
+                    v[U] = *(const u32x4*)(a.Fi + (int64_t)i * a.ldi + sub * 8);
+                };
+                fetch(std::integral_constant<int, 0>());
+                fetch(std::integral_constant<int, 1>());
+                fetch(std::integral_constant<int, 2>());
+                fetch(std::integral_constant<int, 3>());
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    const int ent = s0 + u * EPW + grp;
-                    const int i = __shfl(my_i, ent & 63, 64);
-                    v[u] = u32x4{0u, 0u, 0u, 0u};
-                    if (ent < nb) v[u] = *(const u32x4*)(a.Fi + (int64_t)i * a.ldi + sub * 8);
-                }
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    if (s0 + u * EPW >= nb) break;                       // (wave-uniform)
-                    const int ent = s0 + u * EPW + grp;
-                    const bool ok = ent < nb;
-                    float e = 0.f;
-                    if (a.mode != SRP_RESIDUAL) e = __shfl(my_e, ent & 63, 64);
-                    if (a.mode != SRP_APPLY) {
-                        const float r = __shfl(my_r, ent & 63, 64);
+                    const bool ok = gbase + K0 + u < nb;
+                    float ev = e[u];
+                    if (MODE != SRP_APPLY) {
                         float x = dot8_bf16(fo, v[u], 0.f);
                         x = dpp_add<0xB1>(x);                            // quad_perm [1,0,3,2]
                         x = dpp_add<0x4E>(x);                            // quad_perm [2,3,0,1]
                         x = dpp_add<0x141>(x);                           // row_half_mirror
                         if (GL >= 16) x = dpp_add<0x140>(x);             // row_mirror
                         if (GL >= 32) x += __shfl_xor(x, 16, 64);
-                        if (a.mode == SRP_ERR) {
-                            if (sub == 0 && ok) sq += (double)((r - x) * (r - x)) - (double)((r - e - x) * (r - e - x));
+                        if (MODE == SRP_ERR) {
+                            if (sub == 0 && ok) sq += (double)((r[u] - x) * (r[u] - x)) - (double)((r[u] - ev - x) * (r[u] - ev - x));
                             continue;
                         }
-                        e = ok ? r - x : 0.f;
-                        if (a.evals && sub == 0 && ok) a.evals[q0 + ent] = e;
+                        ev = r[u] - x;
+                        if ((lane & (GL == 8 ? 7 : 15)) == K0 + u) e_out = ev;      // the lane that loaded this entry keeps it
                     }
-                    if (!ok) e = 0.f;
+                    if (!ok) ev = 0.f;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {                        // two bf16 per dword: low half, high half
                         union { uint32_t u; float f; } lo, hi;
                         lo.u = v[u][t] << 16;
                         hi.u = v[u][t] & 0xffff0000u;
-                        acc[2 * t] += e * lo.f;
-                        acc[2 * t + 1] += e * hi.f;
+                        acc[2 * t] += ev * lo.f;
+                        acc[2 * t + 1] += ev * hi.f;
                     }
                 }
+            };
+            const int steps = nb < STEPS ? nb : STEPS;                   // (a group runs out of entries when the batch does)
+            chunk(std::integral_constant<int, 0>());
+            if (steps > 4) chunk(std::integral_constant<int, 4>());
+            if (STEPS > 8) {
+                if (steps > 8) chunk(std::integral_constant<int, 8>());
+                if (steps > 12) chunk(std::integral_constant<int, 12>());
             }
+            // one coalesced store of the batch's residuals (GL = 32: the first row of every group)
+            if (MODE == SRP_RESIDUAL && a.evals && slot < nb && (GL != 32 || (lane & 16) == 0)) a.evals[q0 + slot] = e_out;
         }
-        if (a.mode != SRP_ERR) {
+        if (MODE != SRP_ERR) {
 #pragma unroll
-            for (int off = GL; off < 64; off <<= 1)                     // the EPW lane groups of the wave, fixed order
+            for (int off = GL; off < 64; off <<= 1)                     // the lane groups of the wave, fixed order
 #pragma unroll
                 for (int t = 0; t < 8; ++t) acc[t] += __shfl_xor(acc[t], off, 64);
             if (grp == 0) {
@@ -265,7 +302,7 @@ __global__ __launch_bounds__(256) void srp_bf16_kernel(SrpArgs<uint16_t, float> 
             }
         }
     }
-    if (a.mode == SRP_ERR) {
+    if (MODE == SRP_ERR) {
         sq = wave_sum(sq);
         if (lane == 0) a.sq[(int64_t)blockIdx.x * 4 + wv] = sq;
     }

@@ -316,13 +316,15 @@ inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
-// DPP lane exchanges used by the kernels: quad_perm (ctrl < 0x100), row_mirror (0x140), row_half_mirror (0x141)
+// DPP lane exchanges used by the kernels: quad_perm (ctrl < 0x100), row_mirror (0x140), row_half_mirror (0x141),
+// row_newbcast:k (0x150 + k)
 inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
     const int l = simt::lane_id();
     int t;
     if (ctrl < 0x100) t = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
     else if (ctrl == 0x140) t = (l & ~15) | (15 - (l & 15));
     else if (ctrl == 0x141) t = (l & ~7) | (7 - (l & 7));
+    else if (ctrl >= 0x150 && ctrl <= 0x15F) t = (l & ~15) | (ctrl - 0x150);
     else abort();
     return simt::wave_read(src, t);
 }

@@ -69,9 +69,11 @@ static void run(int64_t n_out, int64_t n_in, int per, int w) {
                     const int gl = w / VE;
                     if constexpr (sizeof(TG) == 2) {
                         if (getenv("SRP_TUNED")) {
-                            if (gl == 8) hipLaunchKernelGGL((srp_bf16_kernel<8>), dim3(grid), dim3(256), 0, 0, a);
-                            else if (gl == 16) hipLaunchKernelGGL((srp_bf16_kernel<16>), dim3(grid), dim3(256), 0, 0, a);
-                            else if (gl == 32) hipLaunchKernelGGL((srp_bf16_kernel<32>), dim3(grid), dim3(256), 0, 0, a);
+#define PROBE_SRP(GL_) do { if (mode == 0) hipLaunchKernelGGL((srp_bf16_kernel<GL_, SRP_RESIDUAL>), dim3(grid), dim3(256), 0, 0, a); \
+                           else hipLaunchKernelGGL((srp_bf16_kernel<GL_, SRP_APPLY>), dim3(grid), dim3(256), 0, 0, a); } while (0)
+                            if (gl == 8) PROBE_SRP(8);
+                            else if (gl == 16) PROBE_SRP(16);
+                            else if (gl == 32) PROBE_SRP(32);
                             return;
                         }
                     }
