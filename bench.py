@@ -17,23 +17,28 @@ With --gpus N > 1 and no WORLD_SIZE in the environment the script launches itsel
 torch.distributed.run (one rank per GPU); under a launcher it checks WORLD_SIZE == --gpus.
 
 The JSON line also carries
-  roofline     : the dominant kernel = the relation contractions P = R G_j, Q = R^T G_i, timed with
-                 hipEvents on the launch stream inside the timed region.  SURVEY.md 8(d) defines the
-                 algorithmic work of an iteration as ONE read of every relation and
-                 sum 2 n_i n_j (c_i + c_j) flops: 430 flop/B in bf16, above the 312 flop/B ridge.  The
-                 engine reads every relation once per contraction, i.e. TWICE per iteration (a fused
-                 P+Q pass has to spill one of the two outputs as partial sums, which costs more than
-                 the second read): 215 flop/B as scheduled, below the ridge -> bound = "hbm".
-                 achieved = algorithmic bytes per launch / average launch time; `traffic` = HBM bytes
-                 per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command
-                 (profiles/pmc_traffic.json; null for a workload / size without a committed pass),
-                 `traffic_scheduled` = the bytes a launch is scheduled to move (relation once, G^T once
-                 per XCD, output); `mfma` and `hbm_scheduled` give the other two views of the launches.
-  engines      : short runs (3 steps) of the f32 and f64 engines on the same graph (the reference's
-                 own arithmetic is f64), default single-GPU run only.
-  cpu_baseline : the NumPy oracle (reference operation order, fp64, all host cores): ONE iteration at FULL size
-                 when the host can hold the 88 GB of fp64 relations (child process, bounded to 240 s), otherwise a
-                 1/10-linear-scale sample scaled by the work ratio (`projection: true`).
+  roofline     : the dominant kernel = the relation contractions P = R G_j, Q = R^T G_i, timed with hipEvents on the
+                 launch stream inside the timed region.  SURVEY.md 8(d): the algorithmic work of an iteration is ONE read of
+                 every relation (22 GB in bf16) and sum 2 n_i n_j (c_i + c_j) flops = 9.472e12 -- 430 flop/B, above the
+                 312 flop/B ridge, so the MATRIX-CORE roof binds: t_min = max(flops / peak, bytes / 8 TB/s) = 3.79 ms per
+                 iteration, and frac = t_min / t_kernel (= achieved / peak of the binding roof).  Beside it: `hbm_algorithmic`
+                 (one-read bytes / launch time), `hbm_scheduled` (the engine reads every relation once per contraction,
+                 i.e. twice per iteration: a fused P+Q pass would have to spill one output as partial sums), `traffic` =
+                 HBM bytes per launch from committed rocprofv3 --pmc passes (profiles/pmc_traffic.json; null without one),
+                 `traffic_scheduled`, `whole_iteration`.
+  engines      : short runs (3 steps) of the f32 and f64 engines on the same graph (the reference computes in f64).
+  workloads    : the other single-GPU BASELINE configurations, default run only --
+                   c5_dfmc    configs[4]: Dfmc on the MovieLens-style graph (10 steps), its own roofline (flops the launches
+                              EXECUTE and relation bytes as STORED: bitmaps, gathers, known-entry lists) and cpu_baseline
+                              (oracle dfmc at 1/4 linear scale, projected by the cell ratio, labelled);
+                   c2_dicty   configs[1]: the dicty graph (tests/golden/dicty_inputs.npz), 100 iterations f32 and f64,
+                              and the NumPy oracle on the same host;
+                   c3_planted configs[2] on planted data (rank-structured + 1 % noise): RMSE after 30 iterations over the
+                              noise floor 0.01 / sqrt(12).
+  cpu_baseline : the NumPy oracle (reference operation order, fp64, all BLAS threads): TWO iterations at FULL size when the
+                 host can hold the 88 GB of fp64 relations (child process, bounded), the second one reported; inputs from
+                 the counter-based generator the device uses; otherwise a 1/10-linear-scale sample scaled by the work ratio
+                 (`projection: true`).
 
 Options beyond the driver's contract (defaults = the metric's configuration):
   --dtype bf16|f32|f64      engine (default bf16, the configuration the metric is quoted on)
@@ -178,12 +183,18 @@ def measured_traffic(dtype, c5, scale):
         return None
 
 
-def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, elapsed, pmc=None):
-    """SURVEY.md 8(d) accounting of the relation-contraction launches (see the module docstring)."""
+def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, elapsed, pmc=None, k_bytes=None,
+                    executed=False):
+    """Roofline of the launches that walk a relation (hipEvent time `k_ms` over `k_launches` launches).
+    executed == False (config 3): SURVEY.md 8(d) algorithmic work -- ONE read of every relation, sum 2 n_i n_j (c_i + c_j)
+    flops -- against the launch time.  executed == True (config 5): the flops the launches EXECUTE and the relation bytes they
+    read as STORED (bitmaps, index lists, known-entry lists), both counted by the library (skf_plan_get_profile).
+    frac = t_min / t_kernel with t_min = max(flops / matrix-core peak, bytes / 8 TB/s); `bound` names the binding term and
+    achieved / peak are quoted on it (so frac == achieved / peak)."""
     esz = {'bf16': 2, 'f32': 4, 'f64': 8}[dtype]
     msz = 4 if dtype != 'f64' else 8                       # master type of P / Q
     gsz = 2 if dtype == 'bf16' else msz                    # factor operand of the contraction
-    per_iter = sum(3 if m else 2 for _, _, m in spec)      # a masked relation recomputes P after completion
+    per_iter = sum(3 if m else 2 for _, _, m in spec)      # (dense model) a masked relation recomputes P after completion
     alg_bytes_iter = sum(float(n[i]) * n[j] for i, j, _ in spec) * esz            # ONE read of every relation
     sched_iter = 0.0                                                               # what the launches move from HBM
     for i, j, m in spec:
@@ -195,35 +206,48 @@ def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, ela
     peak_tf = PEAK_TFLOPS[dtype]
     rec = {'kernel': 'relation contractions P=R*G_j, Q=R^T*G_i (%s)'
                      % ('gemm_bf16_v2_kernel<BN,TAG=1,AT>' if dtype == 'bf16' else 'gemm_mfma_kernel<..,TAG=1>'),
-           'launches': int(k_launches), 'launches_per_iter': per_iter,
-           'avg_launch_ms': k_ms / k_launches if k_launches else None,
-           'alg_bytes_per_iter': alg_bytes_iter, 'alg_flops_per_iter': flops_iter,
-           'intensity_algorithmic': flops_iter / alg_bytes_iter,
-           'intensity_scheduled': flops_iter / sched_iter, 'ridge': RIDGE[dtype]}
-    bound = 'hbm' if flops_iter / sched_iter < RIDGE[dtype] else 'mfma'
+           'launches': int(k_launches), 'avg_launch_ms': k_ms / k_launches if k_launches else None}
+    if executed:
+        rec['kernel'] = 'launches that walk a relation: bitmap / dense contractions, 0/1 gathers, known-entry list passes'
+        rec['accounting'] = 'executed flops, relation bytes as stored (skf_plan_get_profile)'
+    else:
+        rec.update({'launches_per_iter': per_iter, 'alg_bytes_per_iter': alg_bytes_iter, 'alg_flops_per_iter': flops_iter,
+                    'intensity_algorithmic': flops_iter / alg_bytes_iter, 'intensity_scheduled': flops_iter / sched_iter,
+                    'ridge': RIDGE[dtype]})
     if not k_ms or not k_launches:
-        rec.update({'bound': bound, 'achieved': None, 'peak': None, 'unit': None, 'frac': None, 'traffic': None})
+        rec.update({'bound': None, 'achieved': None, 'peak': None, 'unit': None, 'frac': None, 'traffic': None})
         return rec
     sec = k_ms * 1e-3
-    iters = k_launches / float(per_iter)
-    mfma_tf = k_flops / sec / 1e12
-    alg_gbs = alg_bytes_iter * iters / sec / 1e9
-    sched_gbs = sched_iter * iters / sec / 1e9
+    if executed:
+        flops, nbytes = float(k_flops), float(k_bytes or 0.0)
+    else:
+        iters = k_launches / float(per_iter)
+        flops, nbytes = flops_iter * iters, alg_bytes_iter * iters
+    t_flops, t_bytes = flops / (peak_tf * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
+    mfma_tf, alg_gbs = flops / sec / 1e12, nbytes / sec / 1e9
     rec['mfma'] = {'achieved': mfma_tf, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': mfma_tf / peak_tf}
+    rec['hbm_algorithmic'] = {'achieved': alg_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_gbs / HBM_PEAK_GBS}
+    rec['t_min_ms'] = max(t_flops, t_bytes) * 1e3
+    rec['t_kernel_ms'] = k_ms
+    if t_flops >= t_bytes:
+        rec.update({'bound': 'mfma', 'achieved': mfma_tf, 'peak': peak_tf, 'unit': 'TFLOP/s'})
+    else:
+        rec.update({'bound': 'hbm', 'achieved': alg_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'})
+    rec['frac'] = max(t_flops, t_bytes) / sec
+    if executed:
+        rec['traffic'] = None
+        return rec
+    sched_gbs = sched_iter * iters / sec / 1e9
     rec['hbm_scheduled'] = {'achieved': sched_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': sched_gbs / HBM_PEAK_GBS}
     rec['traffic_scheduled'] = sched_iter / per_iter        # relation once per contraction + G^T once per XCD + output
     if pmc:
         rec['traffic'] = pmc['bytes']
-        rec['traffic_kind'] = 'HBM bytes per launch from PMC counters: ' + pmc['source']
+        rec['traffic_kind'] = 'PMC, committed pass: ' + pmc['source']
     else:
         rec['traffic'] = None
-        rec['traffic_kind'] = 'no counter pass committed for this workload / size (scheduled bytes per launch: traffic_scheduled)'
+        rec['traffic_kind'] = 'no counter pass committed for this workload / size (see traffic_scheduled)'
     rec['traffic_ratio'] = (pmc['bytes'] if pmc else sched_iter / per_iter) / (alg_bytes_iter / per_iter)
     rec['alg_bytes_per_launch'] = alg_bytes_iter / per_iter
-    if bound == 'hbm':
-        rec.update({'bound': 'hbm', 'achieved': alg_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg_gbs / HBM_PEAK_GBS})
-    else:
-        rec.update({'bound': 'mfma', 'achieved': mfma_tf, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': mfma_tf / peak_tf})
     rec['whole_iteration'] = {'mfma_frac': flops_iter * steps / elapsed / 1e12 / peak_tf,
                               'hbm_algorithmic_frac': alg_bytes_iter * steps / elapsed / 1e9 / HBM_PEAK_GBS,
                               'hbm_scheduled_frac': sched_iter * steps / elapsed / 1e9 / HBM_PEAK_GBS}
@@ -235,96 +259,316 @@ def host_info():
         ram = os.sysconf('SC_PHYS_PAGES') * os.sysconf('SC_PAGE_SIZE') / 2.0 ** 30
     except (ValueError, OSError, AttributeError):
         ram = None
-    return {'cpu_count': os.cpu_count(), 'ram_gib': ram}
+    return {'cpu_count': os.cpu_count(), 'cores_physical': physical_cores(), 'ram_gib': ram}
 
 
-def _parallel_uniform(shape, seed, threads=32):
-    """U[0,1) fp64 matrix filled by `threads` generator streams (values only matter statistically for a timing
-    run; the device data come from the counter-based generator)."""
+def physical_cores():
+    """Physical cores from /proc/cpuinfo ((physical id, core id) pairs); None when it cannot be read."""
+    try:
+        seen, phys, core = set(), None, None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('physical id'):
+                    phys = line.split(':')[1].strip()
+                elif line.startswith('core id'):
+                    core = line.split(':')[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return int(max([p.get('num_threads', 1) for p in threadpool_info()] or [1]))
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
+def _parallel_hash_uniform(seed, rows, cols, threads=64):
+    """fp64 matrix of the counter-based uniforms the device generates (oracle.hash_uniform), filled in row blocks by
+    `threads` host threads (NumPy releases the GIL inside the element-wise kernels)."""
     from concurrent.futures import ThreadPoolExecutor
-    out = np.empty(shape, dtype=np.float64)
-    rows = shape[0]
-    step = max((rows + threads - 1) // threads, 1)
+    from oracle import dfmf_oracle as orc
+    out = np.empty((rows, cols), dtype=np.float64)
+    chunk = max(1, (1 << 22) // max(cols, 1))                # ~4 M elements per call: small temporaries
 
-    def fill(k):
-        a, b = k * step, min((k + 1) * step, rows)
-        if a < b:
-            np.random.default_rng([seed, k]).random(out=out[a:b])
+    def fill(a):
+        b = min(a + chunk, rows)
+        out[a:b] = orc.hash_uniform(seed, a * cols, (b - a) * cols).reshape(b - a, cols)
     with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(fill, range((rows + step - 1) // step)))
+        list(ex.map(fill, range(0, rows, chunk)))
     return out
 
 
-def _oracle_timing(scale, seconds_budget, max_iters, parallel_data=False):
-    """(iterations, seconds, n) of the NumPy oracle (reference operation order, fp64) on the config-3 graph at `scale`."""
+def _oracle_timing(scale, iters, parallel_data=False):
+    """Seconds of each of `iters` oracle iterations (NumPy, reference operation order, fp64) on the config-3 graph."""
     from oracle import dfmf_oracle as orc
     n = sizes(scale)
-    if parallel_data:
-        R = {(i, j): [_parallel_uniform((n[i], n[j]), s)] for i, j, s in PAIRS}
-    else:
-        R = {(i, j): [orc.hash_uniform_matrix(s, n[i], n[j])] for i, j, s in PAIRS}
+    fill = _parallel_hash_uniform if parallel_data else orc.hash_uniform_matrix
+    R = {(i, j): [fill(s, n[i], n[j])] for i, j, s in PAIRS}
     G = {(t, t): orc.hash_uniform_matrix(100 + k, n[t], RANKS[t]) for k, t in enumerate(TYPES)}
-
-    def step(G):
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
         S, _ = orc._update_S(R, G)
-        return orc._update_G(R, G, S, {}, {}, True)
-    if not parallel_data:
-        G = step(G)                               # warm-up (BLAS threads, page faults)
-    t0 = time.perf_counter()
-    done = 0
-    while done < 1 or (done < max_iters and time.perf_counter() - t0 < seconds_budget):
-        G = step(G)
-        done += 1
-    return done, time.perf_counter() - t0, n
+        G = orc._update_G(R, G, S, {}, {}, True)
+        times.append(time.perf_counter() - t0)
+    return times, n
 
 
 def _full_size_child():
-    """`python bench.py --cpu-full-child`: ONE oracle iteration at full size after a 1/10-scale warm-up of the BLAS
-    threads; prints a JSON line.  Runs in a child process so that the parent can bound it in time and memory."""
-    _oracle_timing(0.1, 1.0, 1)
+    """`python bench.py --cpu-full-child`: TWO oracle iterations at full size (the second one is reported: BLAS threads
+    and pages warm) after a 1/10-scale warm-up; prints a JSON line.  Runs in a child process so that the parent can bound
+    it in time and memory."""
+    _oracle_timing(0.1, 1)
     t0 = time.perf_counter()
-    done, dt, n = _oracle_timing(1.0, 1.0, 1, parallel_data=True)
-    print(json.dumps({'iters': done, 'seconds': dt, 'total_seconds': time.perf_counter() - t0}))
+    times, n = _oracle_timing(1.0, 2, parallel_data=True)
+    print(json.dumps({'times': times, 'total_seconds': time.perf_counter() - t0}))
 
 
-def cpu_baseline(seconds_budget=25.0, full='auto'):
+def cpu_baseline(full='auto'):
     """Oracle (kind=port) on the host cores.  When the host can hold the fp64 graph (88 GB + temporaries: RAM >= 256 GiB
-    and >= 32 cores) ONE iteration is timed at FULL size in a child process bounded to 240 s; otherwise,
-    or when that fails, the 1/10-linear-scale sample is timed and scaled by the n_i*n_j work ratio."""
+    and >= 32 cores) two iterations are timed at FULL size in a child process bounded to 300 s and the
+    second is reported; otherwise, or when that fails, the 1/10-linear-scale sample is timed and scaled by the n_i*n_j work
+    ratio."""
     host = host_info()
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count()
-    base = {'unit': 'iters/s', 'cores': int(threads), 'kind': 'port', 'host_cpu_count': host['cpu_count'],
-            'host_ram_gib': host['ram_gib']}
+    base = {'unit': 'iters/s', 'cores': blas_threads(), 'cores_physical': host['cores_physical'], 'kind': 'port',
+            'host_cpu_count': host['cpu_count'], 'host_ram_gib': host['ram_gib']}
     want_full = full is True or (full == 'auto' and (host['ram_gib'] or 0) >= 256 and (host['cpu_count'] or 0) >= 32)
     note = ''
     if want_full:
         import subprocess
         try:
             out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-full-child'], capture_output=True,
-                                 text=True, timeout=240)
-            line = [l for l in out.stdout.splitlines() if l.startswith('{')]
-            r = json.loads(line[-1])
-            base.update({'value': r['iters'] / r['seconds'], 'projection': False,
-                         'sample': '%d oracle iteration(s) (NumPy fp64, reference op order, 3 big GEMMs per relation, scipy pinv) at '
-                                   'FULL size (50000x100000 / 50000x40000 / 100000x40000, ranks 128/256/256, 88 GB of fp64 '
-                                   'relations filled by 32 generator threads) in %.1f s (%.1f s with data generation)'
-                                   % (r['iters'], r['seconds'], r['total_seconds'])})
+                                 text=True, timeout=300)
+            r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+            base.update({'value': 1.0 / r['times'][-1], 'projection': False,
+                         'sample': 'oracle (NumPy fp64, reference op order, 3 big GEMMs per relation, scipy pinv) at FULL size, '
+                                   'device-identical inputs: iterations %s s, the last one reported (%.0f s with the 88 GB fill)'
+                                   % ('/'.join('%.1f' % t for t in r['times']), r['total_seconds'])})
             return base
         except Exception as exc:                   # time-out, memory, a host without the packages ...
             note = ' (full-size run failed: %s)' % (str(exc)[:120],)
-    done, dt, n = _oracle_timing(0.1, seconds_budget, 20)
-    sample_ips = done / dt
+    _oracle_timing(0.1, 1)
+    times, n = _oracle_timing(0.1, 3)
+    sample_ips = 1.0 / min(times)
     ratio = alg_flops(n) / alg_flops(FULL)       # the n_i*n_j work shrinks by 100
     base.update({'value': sample_ips * ratio, 'projection': True,
-                 'sample': '%d oracle iterations (NumPy fp64, reference op order) at 1/10 linear scale '
-                           '(%dx%d / %dx%d / %dx%d, ranks 128/256/256) = %.3f it/s measured, scaled by the '
-                           'n_i*n_j work ratio %.4f to the full graph%s'
-                           % (done, n['t1'], n['t2'], n['t1'], n['t3'], n['t2'], n['t3'], sample_ips, ratio, note)})
+                 'sample': 'oracle at 1/10 linear scale (%dx%d / %dx%d / %dx%d): %.3f it/s measured, scaled by the work '
+                           'ratio %.4f%s' % (n['t1'], n['t2'], n['t1'], n['t3'], n['t2'], n['t3'], sample_ips, ratio, note)})
     return base
+
+
+def _tests_path():
+    p = os.path.join(ROOT, 'tests')
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def cpu_baseline_c5(scale=0.25, target=1.0):
+    """Oracle dfmc (reference operation order incl. the boolean-mask completion, _dfmc.py:319-325) on the MovieLens-style
+    graph at `scale` of the linear sizes (constraints on Movie only, as in the device workload), projected to `target` by
+    the cell ratio (scale / target)^2 (labelled)."""
+    _tests_path()
+    from helpers import movielens_style_graph
+    from oracle import dfmf_oracle as orc
+    n = sizes(scale, C5_FULL)
+    R, M, Theta, types, ranks = movielens_style_graph(n, C5_RANKS)
+    Theta.pop(('user', 'user'), None)
+    G0 = {(t, t): orc.hash_uniform_matrix(100 + k, n[t], C5_RANKS[t]) for k, t in enumerate(types)}
+    t0 = time.perf_counter()
+    orc.dfmc(R, M, Theta, types, ranks, max_iter=1, G0=G0)
+    t1 = time.perf_counter()
+    orc.dfmc(R, M, Theta, types, ranks, max_iter=3, G0=G0)
+    t3 = time.perf_counter()
+    per_iter = max(((t3 - t1) - (t1 - t0)) / 2.0, 1e-9)
+    ratio = (scale / target) ** 2
+    return {'value': ratio / per_iter, 'unit': 'iters/s', 'cores': blas_threads(), 'cores_physical': physical_cores(),
+            'kind': 'port', 'projection': True,
+            'sample': 'oracle dfmc at %.3f linear scale (%d users x %d movies): %.3f s per iteration, projected by the cell '
+                      'ratio %.4f' % (scale, n['user'], n['movie'], per_iter, ratio)}
+
+
+def bench_dicty(iters=100):
+    """BASELINE configs[1]: the dicty graph (ann 1219 x 116, expr 1219 x 282, Theta = ppi; ranks 50/15/5), Dfmf from the
+    golden G0 -- f32 and f64 engines and the NumPy oracle on the same host."""
+    import torch
+    _tests_path()
+    from helpers import golden, dicty_graph, g0_from
+    from oracle import dfmf_oracle as orc
+    import skfusion_amd._native as nat
+    from skfusion_amd._engine import DevicePlan, flatten_relations, flatten_thetas
+    z = golden('c2_dicty.npz')
+    R, Theta, types, rank = dicty_graph()
+    G0 = g0_from(z, 'dfmf/', types)
+    n = {'gene': R['gene', 'go'][0].shape[0], 'go': R['gene', 'go'][0].shape[1], 'exc': R['gene', 'exc'][0].shape[1]}
+    out = {'graph': 'dicty: ann %dx%d, expr %dx%d, ppi constraint, ranks 50/15/5' % (n['gene'], n['go'], n['gene'], n['exc']),
+           'iters': iters}
+    for dtype in ('f32', 'f64'):
+        plan = DevicePlan(types, n, rank, flatten_relations(R), flatten_thetas(Theta), nat.SKF_DFMF, dtype=dtype)
+        for t in types:
+            plan.set_factor(t, G0[t, t])
+        plan.iterate(5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plan.iterate(iters)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        err = float(np.sqrt(plan.relation_sqerr(0)))
+        out[dtype] = {'value': iters / dt, 'unit': 'iters/s', 'ms_per_step': dt / iters * 1e3, 'err_ann': err}
+        plan.close()
+    orc.dfmf(R, Theta, types, rank, max_iter=2, G0=G0)
+    t0 = time.perf_counter()
+    orc.dfmf(R, Theta, types, rank, max_iter=20, G0=G0)
+    dt = time.perf_counter() - t0
+    out['cpu_baseline'] = {'value': 20 / dt, 'unit': 'iters/s', 'cores': blas_threads(), 'cores_physical': physical_cores(),
+                           'kind': 'port', 'sample': '20 oracle iterations (NumPy fp64) in %.2f s' % dt}
+    return out
+
+
+def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode='restarts', rank=0, world=1, dist=None,
+                 backend='nccl'):
+    """One engine on one workload.  Returns dict(elapsed, k_ms, k_launches, k_flops, k_bytes, rmse, n, spec, ranks, types)."""
+    import torch
+    import skfusion_amd._native as nat
+    from skfusion_amd._engine import DevicePlan, fill_uniform
+    c5 = (workload == 'c5')
+    types, ranks_ = (C5_TYPES, C5_RANKS) if c5 else (TYPES, RANKS)
+    n = sizes(scale, C5_FULL if c5 else FULL)
+    sharded = (mode in ('relations', 'rows') and world > 1)
+    variant = nat.SKF_DFMC if c5 else nat.SKF_DFMF
+    esz = {'bf16': 2, 'f32': 4, 'f64': 8}[dtype]
+    # the whole graph as (row, col, masked) + a maker of relation k's device matrices
+    if c5:
+        full_rels, full_thetas = c5_graph(n, dtype)
+        spec = [(i, j, dens is None) for i, j, _, dens in C5_PAIRS]
+
+        def make(k):
+            return full_rels[k][2], full_rels[k][3]
+    else:
+        full_rels, full_thetas = None, []
+        spec = [(i, j, False) for i, j, _ in PAIRS]
+        planted = {}
+
+        def make(k):                   # same values whatever the sharding (counter-based generator)
+            return c3_relation(k, n, dtype, data, planted), None
+    part_rel = [(i, j, None, None) for i, j, _ in spec]
+    part_th = [(t, None) for t, _ in full_thetas]
+    local_index = list(range(len(spec)))            # global index of every relation of this plan
+    thetas = list(full_thetas)
+    if sharded and mode == 'relations':       # this rank keeps only its share of the relations
+        from skfusion_amd._distributed import partition_relations
+        owner, th_owner = partition_relations(part_rel, part_th, n, ranks_)
+        local_index = [k for k, o in enumerate(owner) if o == rank]
+        thetas = [t for t, o in zip(full_thetas, th_owner) if o == rank]
+    if sharded and mode == 'rows':            # every relation listed, with this rank's row block of it
+        from skfusion_amd._distributed import partition_rows
+        blocks, th_owner = partition_rows(part_rel, part_th, n, ranks_, align=256 if min(n.values()) >= 4096 else 64)
+        thetas = [t for t, o in zip(full_thetas, th_owner) if o == rank]
+        rels = []
+        for k, ((i, j, masked), blk) in enumerate(zip(spec, blocks)):
+            mine = [b for b in blk if b[0] == rank]
+            if not mine:
+                rels.append((i, j, None, None, dict(absent=True, row_begin=0, n_rows=0, col_side=False, masked=masked)))
+                continue
+            _, a, cnt = mine[0]
+            rdata, mask = make(k)
+            rels.append((i, j, rdata.rows(a, cnt, esz), None if mask is None else mask.rows(a, cnt, 1),
+                         dict(absent=False, row_begin=a, n_rows=cnt, col_side=(a == 0), masked=masked)))
+            del rdata, mask
+    else:
+        rels = [(spec[k][0], spec[k][1]) + make(k) for k in local_index]
+    plan = DevicePlan(types, n, ranks_, rels, thetas, variant, dtype=dtype,
+                      part=(rank, world) if sharded and mode == 'rows' else None)
+    if dtype == 'bf16':          # the plan keeps its own padded bf16 copy (or bitmap / lists) of every relation
+        plan.release_relation_data()
+        rels = full_rels = None
+        torch.cuda.empty_cache()
+    for k, t in enumerate(types):      # one random restart per rank: G0 seed depends on the rank
+        seed = 100 + k + (0 if sharded else 10 * rank)       # sharded: replicated factors
+        plan.set_factor(t, fill_uniform((n[t], ranks_[t]), seed, MASTER[dtype]))
+    step = plan.iterate if not sharded else (plan.iterate_rows if mode == 'rows' else plan.iterate_sharded)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if warmup:
+        step(warmup)
+    sync()
+    plan.set_profiling(True)
+    t0 = time.perf_counter()
+    step(steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_launches, k_flops, k_bytes = plan.get_profile()
+    plan.set_profiling(False)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    rmse = {}
+    if sharded and mode == 'rows':            # every rank holds the squared error of its row blocks
+        sq = torch.tensor([plan.relation_sqerr(k) for k in range(len(spec))], dtype=torch.float64,
+                          device='cuda' if backend == 'nccl' else 'cpu')
+        dist.all_reduce(sq)
+        for k, (i, j, _) in enumerate(spec):
+            rmse['%s-%s' % (i, j)] = float(np.sqrt(float(sq[k]) / (n[i] * n[j])))
+    else:
+        for q, k in enumerate(local_index):
+            i, j, _ = spec[k]
+            rmse['%s-%s' % (i, j)] = float(np.sqrt(max(plan.relation_sqerr(q), 0.0) / (n[i] * n[j])))
+    plan.close()
+    del plan
+    torch.cuda.empty_cache()
+    return {'elapsed': elapsed, 'k_ms': k_ms, 'k_launches': k_launches, 'k_flops': k_flops, 'k_bytes': k_bytes,
+            'rmse': rmse, 'n': n, 'spec': spec, 'ranks': ranks_, 'types': types, 'sharded': sharded}
+
+
+def compact_roofline(r):
+    return {k: r.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 't_min_ms', 't_kernel_ms', 'launches',
+                                  'accounting') if k in r}
+
+
+def other_workloads(dtype='bf16'):
+    """The `workloads` sub-record of the default run (single GPU): BASELINE configs[4], configs[1] and the planted-data
+    RMSE of configs[2]; every leg reports its own failure instead of sinking the headline line."""
+    out = {}
+    try:
+        w = run_workload('c5', dtype, 10, 3)
+        roof = roofline_record(dtype, w['n'], w['ranks'], w['spec'], w['k_ms'], w['k_launches'], w['k_flops'], 10,
+                               w['elapsed'], None, w['k_bytes'], executed=True)
+        out['c5_dfmc'] = {'config': 'BASELINE configs[4]: Dfmc, MovieLens-style 6-relation graph (100k users x 40k movies, ratings '
+                                    '98% masked and kept as known-entry lists, five 0/1 relations, two constraints)',
+                          'value': 10 / w['elapsed'], 'unit': 'iters/s', 'steps': 10, 'warmup': 3,
+                          'ms_per_step': w['elapsed'] / 10 * 1e3, 'dtype': dtype, 'rmse_completed': w['rmse'],
+                          'roofline': compact_roofline(roof)}
+        try:
+            out['c5_dfmc']['cpu_baseline'] = cpu_baseline_c5()
+        except Exception as exc:
+            out['c5_dfmc']['cpu_baseline'] = {'error': str(exc)[:200]}
+    except Exception as exc:
+        out['c5_dfmc'] = {'error': str(exc)[:300]}
+    try:
+        out['c2_dicty'] = dict(bench_dicty(), config='BASELINE configs[1]')
+    except Exception as exc:
+        out['c2_dicty'] = {'error': str(exc)[:300]}
+    try:
+        w = run_workload('c3', dtype, 30, 0, data='planted')
+        floor = 0.01 / np.sqrt(12.0)
+        out['c3_planted'] = {'config': 'BASELINE configs[2] on planted data: R = G* S* G*^T / mean + 0.01 U', 'iters': 30,
+                             'dtype': dtype, 'rmse': w['rmse'], 'noise_floor': floor,
+                             'rmse_over_floor': {k: v / floor for k, v in w['rmse'].items()}}
+    except Exception as exc:
+        out['c3_planted'] = {'error': str(exc)[:300]}
+    return out
 
 
 def main():
@@ -349,8 +593,9 @@ def main():
                          'relations and all-reduces of W, Q and E/D (rows)')
     ap.add_argument('--cpu-full-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'full', 'sample'],
-                    help='cpu_baseline leg: one oracle iteration at FULL size when the host can hold it (auto), always, or the 1/10-scale sample')
+                    help='cpu_baseline leg: oracle iterations at FULL size when the host can hold them (auto), always, or the 1/10-scale sample')
     ap.add_argument('--no-engines', action='store_true', help='skip the short f32 / f64 runs of the default record')
+    ap.add_argument('--no-workloads', action='store_true', help='skip the config 5 / dicty / planted legs of the default record')
     args = ap.parse_args()
     if args.cpu_full_child:
         _full_size_child()
@@ -387,119 +632,21 @@ def main():
         __graft_entry__.build()
     if dist is not None:
         dist.barrier()
-    import skfusion_amd._native as nat
-    from skfusion_amd._engine import DevicePlan, fill_uniform
 
     c5 = (args.workload == 'c5')
-    types, ranks_ = (C5_TYPES, C5_RANKS) if c5 else (TYPES, RANKS)
-    n = sizes(args.scale, C5_FULL if c5 else FULL)
-    sharded = (args.mode in ('relations', 'rows') and world > 1)
-    spec = ([(i, j, dens is None) for i, j, _, dens in C5_PAIRS] if c5 else [(i, j, False) for i, j, _ in PAIRS])
-
-    def run_once(dtype, steps, warmup):
-        """One engine on the workload: returns (elapsed s, contraction ms, launches, flops, rmse dict)."""
-        variant = nat.SKF_DFMC if c5 else nat.SKF_DFMF
-        esz = {'bf16': 2, 'f32': 4, 'f64': 8}[dtype]
-        # the whole graph as (row, col, masked) + a maker of relation k's device matrices
-        if c5:
-            full_rels, full_thetas = c5_graph(n, dtype)
-            spec = [(i, j, dens is None) for i, j, _, dens in C5_PAIRS]
-
-            def make(k):
-                return full_rels[k][2], full_rels[k][3]
-        else:
-            full_thetas = []
-            spec = [(i, j, False) for i, j, _ in PAIRS]
-
-            planted = {}
-
-            def make(k):                   # same values whatever the sharding (counter-based generator)
-                return c3_relation(k, n, dtype, args.data, planted), None
-        part_rel = [(i, j, None, None) for i, j, _ in spec]
-        part_th = [(t, None) for t, _ in full_thetas]
-        local_index = list(range(len(spec)))            # global index of every relation of this plan
-        thetas = list(full_thetas)
-        if sharded and args.mode == 'relations':       # this rank keeps only its share of the relations
-            from skfusion_amd._distributed import partition_relations
-            owner, th_owner = partition_relations(part_rel, part_th, n, ranks_)
-            local_index = [k for k, o in enumerate(owner) if o == rank]
-            thetas = [t for t, o in zip(full_thetas, th_owner) if o == rank]
-        if sharded and args.mode == 'rows':            # every relation listed, with this rank's row block of it
-            from skfusion_amd._distributed import partition_rows
-            blocks, th_owner = partition_rows(part_rel, part_th, n, ranks_,
-                                              align=256 if min(n.values()) >= 4096 else 64)
-            thetas = [t for t, o in zip(full_thetas, th_owner) if o == rank]
-            rels = []
-            for k, ((i, j, masked), blk) in enumerate(zip(spec, blocks)):
-                mine = [b for b in blk if b[0] == rank]
-                if not mine:
-                    rels.append((i, j, None, None, dict(absent=True, row_begin=0, n_rows=0, col_side=False, masked=masked)))
-                    continue
-                _, a, cnt = mine[0]
-                data, mask = make(k)
-                rels.append((i, j, data.rows(a, cnt, esz), None if mask is None else mask.rows(a, cnt, 1),
-                             dict(absent=False, row_begin=a, n_rows=cnt, col_side=(a == 0), masked=masked)))
-                del data, mask
-        else:
-            rels = [(spec[k][0], spec[k][1]) + make(k) for k in local_index]
-        plan = DevicePlan(types, n, ranks_, rels, thetas, variant, dtype=dtype,
-                          part=(rank, world) if sharded and args.mode == 'rows' else None)
-        if dtype == 'bf16':          # the plan keeps its own padded bf16 copies of R and R^T
-            plan.release_relation_data()
-            rels = full_rels = None
-            torch.cuda.empty_cache()
-        for k, t in enumerate(types):      # one random restart per rank: G0 seed depends on the rank
-            seed = 100 + k + (0 if sharded else 10 * rank)       # sharded: replicated factors
-            plan.set_factor(t, fill_uniform((n[t], ranks_[t]), seed, MASTER[dtype]))
-        step = plan.iterate if not sharded else (plan.iterate_rows if args.mode == 'rows' else plan.iterate_sharded)
-
-        def sync():
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-                torch.cuda.synchronize()
-
-        step(warmup)
-        sync()
-        plan.set_profiling(True)
-        t0 = time.perf_counter()
-        step(steps)
-        sync()
-        elapsed = time.perf_counter() - t0
-        k_ms, k_launches, k_flops, k_bytes = plan.get_profile()
-        plan.set_profiling(False)
-        if dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-
-        rmse = {}
-        if sharded and args.mode == 'rows':            # every rank holds the squared error of its row blocks
-            sq = torch.tensor([plan.relation_sqerr(k) for k in range(len(spec))], dtype=torch.float64,
-                              device='cuda' if backend == 'nccl' else 'cpu')
-            dist.all_reduce(sq)
-            for k, (i, j, _) in enumerate(spec):
-                rmse['%s-%s' % (i, j)] = float(np.sqrt(float(sq[k]) / (n[i] * n[j])))
-        else:
-            for q, k in enumerate(local_index):
-                i, j, _ = spec[k]
-                rmse['%s-%s' % (i, j)] = float(np.sqrt(plan.relation_sqerr(q) / (n[i] * n[j])))
-        units = 1 if sharded else world        # fits advanced per step by the whole job
-
-        plan.close()
-        del plan
-        torch.cuda.empty_cache()
-        return elapsed, k_ms, k_launches, k_flops, rmse
-
-    elapsed, k_ms, k_launches, k_flops, rmse = run_once(args.dtype, args.steps, args.warmup)
+    w = run_workload(args.workload, args.dtype, args.steps, args.warmup, args.scale, args.data, args.mode, rank, world,
+                     dist, backend)
+    elapsed, rmse, n, spec, ranks_, types = w['elapsed'], w['rmse'], w['n'], w['spec'], w['ranks'], w['types']
+    sharded = w['sharded']
     units = 1 if sharded else world        # fits advanced per step by the whole job
 
+    out = None
     if rank == 0:
         how = {'restarts': 'one random restart per GPU',
                'relations': 'one fit, whole relations partitioned over the GPUs',
                'rows': 'one fit, balanced row blocks of the relations over the GPUs'}[args.mode]
-        roof = roofline_record(args.dtype, n, ranks_, spec, k_ms, k_launches, k_flops, args.steps, elapsed,
-                               measured_traffic(args.dtype, c5, args.scale))
+        roof = roofline_record(args.dtype, n, ranks_, spec, w['k_ms'], w['k_launches'], w['k_flops'], args.steps, elapsed,
+                               measured_traffic(args.dtype, c5, args.scale), w['k_bytes'], executed=c5)
         out = {
             'metric': ('DFMC update iters/sec (+ RMSE), MovieLens-style 6-relation graph with masks and constraints'
                        if c5 else
@@ -527,24 +674,30 @@ def main():
             'rmse': rmse,
             'roofline': roof,
             'mfma_frac': (roof.get('mfma') or {}).get('frac'),
-            'hbm_frac': roof.get('frac') if roof.get('bound') == 'hbm' else (roof.get('hbm_scheduled') or {}).get('frac'),
+            'hbm_frac': (roof.get('hbm_scheduled') or roof.get('hbm_algorithmic') or {}).get('frac'),
             'host': host_info(),
         }
-    if world == 1 and not c5 and not args.no_engines and args.scale == 1.0 and args.data == 'uniform':
+    default_run = world == 1 and not c5 and args.scale == 1.0 and args.data == 'uniform'
+    if default_run and not args.no_engines:
         # the reference computes in f64: short runs of the f32 and f64 engines on the same graph
         engines = {}
         for dt in ('f32', 'f64'):
             if dt == args.dtype:
                 continue
-            e_s, e_ms, e_l, e_fl, e_rmse = run_once(dt, 3, 1)
-            r = roofline_record(dt, n, ranks_, spec, e_ms, e_l, e_fl, 3, e_s)
-            engines[dt] = {'value': 3 / e_s, 'unit': 'iters/s', 'steps': 3, 'warmup': 1, 'ms_per_step': e_s / 3 * 1e3,
-                           'rmse': e_rmse, 'bound': r['bound'], 'achieved': r['achieved'], 'peak': r['peak'],
-                           'unit_roofline': r['unit'], 'frac': r['frac'], 'mfma_frac': (r.get('mfma') or {}).get('frac')}
+            e = run_workload('c3', dt, 3, 1)
+            r = roofline_record(dt, n, ranks_, spec, e['k_ms'], e['k_launches'], e['k_flops'], 3, e['elapsed'])
+            engines[dt] = {'value': 3 / e['elapsed'], 'unit': 'iters/s', 'steps': 3, 'warmup': 1,
+                           'ms_per_step': e['elapsed'] / 3 * 1e3, 'rmse': e['rmse'], 'bound': r['bound'],
+                           'achieved': r['achieved'], 'peak': r['peak'], 'unit_roofline': r['unit'], 'frac': r['frac']}
         out['engines'] = engines
+    if default_run and not args.no_workloads:
+        out['workloads'] = other_workloads(args.dtype)
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not c5:
-            out['cpu_baseline'] = cpu_baseline(full={'auto': 'auto', 'full': True, 'sample': False}[args.cpu_baseline])
+        if world == 1 and not args.no_cpu_baseline:
+            if c5:
+                out['cpu_baseline'] = cpu_baseline_c5(0.25 * args.scale, args.scale)
+            else:
+                out['cpu_baseline'] = cpu_baseline(full={'auto': 'auto', 'full': True, 'sample': False}[args.cpu_baseline])
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

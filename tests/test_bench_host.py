@@ -19,14 +19,16 @@ def test_algorithmic_work_of_config_3_and_5():
     n = bench.sizes(0.1)
     assert n == {'t1': 5000, 't2': 10000, 't3': 4000}
     assert bench.alg_flops(n) / bench.alg_flops(bench.FULL) == pytest.approx(0.01)
-    # algorithmic bytes = ONE read of every relation per iteration (22 GB in bf16); the engine
-    # schedules two (one per contraction) -> 215 flop/B, below the 312 flop/B ridge: the HBM roof binds
+    # algorithmic work = ONE read of every relation per iteration (22 GB in bf16) and 9.472e12 flops:
+    # 430 flop/B, above the 312 flop/B ridge -> the matrix-core roof binds, t_min = 3.79 ms, frac = t_min / t_kernel
     spec3 = [(i, j, False) for i, j, _ in bench.PAIRS]
     r = bench.roofline_record('bf16', bench.FULL, bench.RANKS, spec3, 12.0, 6, 9.472e12, 1, 0.015)
     assert r['alg_bytes_per_iter'] == pytest.approx(1.1e10 * 2)
-    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
-    assert r['achieved'] == pytest.approx(22e9 / 12e-3 / 1e9)                      # one iteration = 6 launches, 12 ms
-    assert r['frac'] == pytest.approx(r['achieved'] / 8000.0)
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 2500.0
+    assert r['t_min_ms'] == pytest.approx(9.472e12 / 2.5e15 * 1e3) and r['t_kernel_ms'] == 12.0
+    assert r['frac'] == pytest.approx(r['t_min_ms'] / 12.0) == pytest.approx(r['achieved'] / r['peak'])
+    assert r['achieved'] == pytest.approx(9.472e12 / 12e-3 / 1e12)                 # one iteration = 6 launches, 12 ms
+    assert r['hbm_algorithmic']['achieved'] == pytest.approx(22e9 / 12e-3 / 1e9)
     # without a committed counter pass `traffic` is null and the scheduled bytes are reported beside it
     assert r['traffic'] is None and 2.0 < r['traffic_ratio'] < 2.2
     assert r['traffic_scheduled'] * 6 == pytest.approx(r['traffic_ratio'] * 22e9)
@@ -40,7 +42,14 @@ def test_algorithmic_work_of_config_3_and_5():
     assert r['mfma']['achieved'] == pytest.approx(9.472e12 / 12e-3 / 1e12) and r['mfma']['peak'] == 2500.0
     assert r['whole_iteration']['mfma_frac'] == pytest.approx(9.472e12 / 0.015 / 1e12 / 2500.0)
     r64 = bench.roofline_record('f64', bench.FULL, bench.RANKS, spec3, 180.0, 6, 9.472e12, 1, 0.19)
-    assert r64['bound'] == 'mfma' and r64['unit'] == 'TFLOP/s'                    # 54 flop/B scheduled > 9.8 flop/B ridge
+    assert r64['bound'] == 'mfma' and r64['unit'] == 'TFLOP/s' and r64['frac'] == pytest.approx(9.472e12 / 78.6e12 / 0.18)
+    # config 5: what the launches EXECUTE (library counters), e.g. 100 launches, 3e13 flops, 4e10 relation bytes in 50 ms
+    spec5 = [(i, j, d is None) for i, j, _, d in bench.C5_PAIRS]
+    n5 = bench.sizes(1.0, bench.C5_FULL)
+    r5 = bench.roofline_record('bf16', n5, bench.C5_RANKS, spec5, 50.0, 100, 3e13, 10, 0.1, None, 4e10, executed=True)
+    assert r5['bound'] == 'mfma' and r5['t_min_ms'] == pytest.approx(12.0) and r5['frac'] == pytest.approx(0.24)
+    assert r5['hbm_algorithmic']['achieved'] == pytest.approx(800.0) and r5['traffic'] is None
+    assert bench.physical_cores() is None or bench.physical_cores() >= 1
     spec = [(i, j, d is None) for i, j, _, d in bench.C5_PAIRS]
     n5 = bench.sizes(1.0, bench.C5_FULL)
     base = sum(2.0 * n5[i] * n5[j] * (bench.C5_RANKS[i] + bench.C5_RANKS[j]) for i, j, _ in spec)
