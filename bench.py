@@ -492,6 +492,10 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
     for k, t in enumerate(types):      # one random restart per rank: G0 seed depends on the rank
         seed = 100 + k + (0 if sharded else 10 * rank)       # sharded: replicated factors
         plan.set_factor(t, fill_uniform((n[t], ranks_[t]), seed, MASTER[dtype]))
+    exchange = None
+    if sharded:                        # the library issues the exchanges itself: RCCL, or torch.distributed callbacks over gloo
+        plan.attach_comm()
+        exchange = plan.exchange_bytes(world)
     step = plan.iterate if not sharded else (plan.iterate_rows if mode == 'rows' else plan.iterate_sharded)
 
     def sync():
@@ -529,7 +533,8 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
     del plan
     torch.cuda.empty_cache()
     return {'elapsed': elapsed, 'k_ms': k_ms, 'k_launches': k_launches, 'k_flops': k_flops, 'k_bytes': k_bytes,
-            'rmse': rmse, 'n': n, 'spec': spec, 'ranks': ranks_, 'types': types, 'sharded': sharded}
+            'rmse': rmse, 'n': n, 'spec': spec, 'ranks': ranks_, 'types': types, 'sharded': sharded,
+            'exchange_bytes': exchange}
 
 
 def compact_roofline(r):
@@ -670,7 +675,8 @@ def main():
                                     'ranks 128/256/256, Dfmf, %s'
                                     % (n['t1'], n['t2'], n['t1'], n['t3'], n['t2'], n['t3'], how)),
                        'scale': args.scale, 'restarts': units, 'mode': args.mode,
-                       'alg_flops_per_iter': alg_flops(n, spec, ranks_)},
+                       'alg_flops_per_iter': alg_flops(n, spec, ranks_),
+                       'exchange_bytes_per_rank_and_iter': w['exchange_bytes']},
             'rmse': rmse,
             'roofline': roof,
             'mfma_frac': (roof.get('mfma') or {}).get('frac'),

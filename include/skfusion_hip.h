@@ -204,6 +204,33 @@ int skf_stage(skf_plan* plan, int32_t stage, void* stream);
 /* dtype: SKF_F64 for SKF_X_W, the master type otherwise; bytes may be 0 (nothing to reduce). */
 int skf_exchange_range(const skf_plan* plan, int32_t which, size_t* offset, size_t* bytes, int32_t* dtype);
 
+/* ---- collectives behind the boundary ------------------------------------------------------------------------------
+ * The reference spreads its restarts over joblib workers (dfmf.py:87-95) and its block products over `_par_bdot`
+ * (_dfmf.py:69-73); a fit spread over several GPUs needs the sums of the E / D accumulators (and, with row blocks, of W
+ * and Q) instead.  A communicator is either RCCL -- bound with dlopen at run time (the librccl of the process if one is
+ * loaded, else SKF_RCCL_PATH / the loader path / /opt/rocm/lib), one process per GPU, the current device at
+ * skf_comm_create -- or a callback the caller supplies (another transport; the CPU tests run it over gloo).
+ *     rank 0: skf_comm_unique_id(id)  -> hand the 128 bytes to every rank ->  skf_comm_create(id, rank, world, &comm)
+ *     skf_plan_set_comm(plan, comm);  skf_iterate_dist(plan, n_iters, stream)
+ * skf_iterate_dist = the same iteration as skf_accumulate + all-reduce + skf_apply_update (plans without row blocks) or the
+ * four skf_stage calls with their exchanges (plans with row blocks), issued on `stream` by the library itself: W, Q as
+ * all-reduce; E and D as REDUCE-SCATTER over `world` equal element ranges of the accumulator regions, the multiplicative
+ * update of the owned range of G, and an ALL-GATHER of G -- 3 (world-1)/world of the factor bytes per rank and iteration
+ * instead of the 4 (world-1)/world of all-reducing both accumulators (config 3 on 8 GPUs: 444 MB instead of 592 MB).  Every
+ * rank ends an iteration with identical factors.  skf_exchange_bytes: bytes one rank sends per iteration on a ring. */
+typedef struct skf_comm skf_comm;
+/* op 0: all-reduce(sum) of `count` elements in place; 1: reduce-scatter(sum) -- `buf` holds world * count elements, on
+ * return elements [rank * count, (rank + 1) * count) are reduced; 2: all-gather of that range to every rank, in place.
+ * dtype SKF_F64 / SKF_F32; `buf` is device memory, the call is ordered on `stream`; return 0 on success. */
+typedef int (*skf_collective_fn)(void* user, int32_t op, void* buf, size_t count, int32_t dtype, void* stream);
+int skf_comm_unique_id(void* id128);
+int skf_comm_create(const void* id128, int32_t rank, int32_t world, skf_comm** out);   /* id128 == NULL: world must be 1 */
+int skf_comm_create_callback(int32_t rank, int32_t world, skf_collective_fn fn, void* user, skf_comm** out);
+int skf_comm_destroy(skf_comm* comm);
+int skf_plan_set_comm(skf_plan* plan, skf_comm* comm);     /* not owned by the plan; NULL detaches */
+int skf_iterate_dist(skf_plan* plan, int32_t n_iters, void* stream);
+int skf_exchange_bytes(const skf_plan* plan, int32_t world, size_t* bytes);
+
 /* sum over the relation of (R - G_i S G_j^T)^2 with the current (G, S), written as one f64 to
  * the DEVICE address `out` (reconstruction error of _dfmf.py:306-316 without materialising the
  * n_i x n_j product).  For DFMC the working copy (completed entries) is used.  SKF_BF16: one pass

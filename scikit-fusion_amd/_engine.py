@@ -363,10 +363,84 @@ class DevicePlan(object):
     def synchronize(self):
         self.rt.mem.synchronize()
 
+    # -- collectives behind the C ABI -----------------------------------------------------
+    def attach_comm(self, force_callback=False):
+        """Give the plan a communicator over the ranks of the torch.distributed process group, so that
+        `skf_iterate_dist` issues the exchanges of a sharded iteration itself: RCCL bound by the library (backend nccl:
+        torch.distributed only carries the 128-byte unique id from rank 0 to the others), or -- gloo groups (CPU tests,
+        two ranks sharing one GPU in smoke runs), `force_callback` -- a callback that runs the collective through
+        torch.distributed on a view of the workspace.  Returns True when a communicator is attached."""
+        import os
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return False
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if world <= 1 and not os.environ.get('SKF_FORCE_COLLECTIVES'):
+            return False
+        self._comm = nat._P()
+        on_gpu = self.rt.name == 'hip'
+        if dist.get_backend() != 'gloo' and on_gpu and not force_callback:
+            ident = [None]
+            if rank == 0:
+                buf = (C.c_char * 128)()
+                self.rt.call('skf_comm_unique_id', buf)
+                ident[0] = bytes(buf)
+            dist.broadcast_object_list(ident, src=0)
+            raw = (C.c_char * 128).from_buffer_copy(ident[0])
+            self.rt.call('skf_comm_create', raw, rank, world, C.byref(self._comm))
+        else:
+            mem, ws = self.rt.mem, self.ws
+
+            def collective(user, op, buf, count, dtype, stream):
+                try:
+                    npd = nat.NP_DTYPE[dtype]
+                    es = np.dtype(npd).itemsize
+                    n = count * (1 if op == 0 else world)
+                    view = mem.as_tensor(ws, int(buf) - ws.ptr, n * es, npd)
+                    mem.synchronize()
+                    host = view.cpu() if view.is_cuda else view
+                    if op in (0, 1):              # (reduce-scatter: the all-reduce of the whole buffer covers the owned range)
+                        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                    else:
+                        import torch
+                        parts = [torch.empty(count, dtype=host.dtype) for _ in range(world)]
+                        dist.all_gather(parts, host[rank * count:(rank + 1) * count].clone())
+                        host = torch.cat(parts)
+                    if view.is_cuda or host is not view:
+                        view.copy_(host)
+                    mem.synchronize()
+                    return 0
+                except Exception:                 # never unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._comm_fn = nat.COLLECTIVE_FN(collective)          # keep the trampoline alive
+            self.rt.call('skf_comm_create_callback', rank, world, C.cast(self._comm_fn, C.c_void_p), None, C.byref(self._comm))
+        self.rt.call('skf_plan_set_comm', self.handle, self._comm)
+        return True
+
+    def exchange_bytes(self, world):
+        """Bytes one rank sends per iteration of the distributed iteration on a ring of `world` ranks."""
+        b = C.c_size_t()
+        self.rt.call('skf_exchange_bytes', self.handle, int(world), C.byref(b))
+        return b.value
+
+    def iterate_dist(self, n_iters=1):
+        """Iterations of a sharded fit (whole relations or row blocks) with the exchanges issued by the library
+        (include/skfusion_hip.h, skf_iterate_dist): all-reduce of W / Q, reduce-scatter of E and D, update of the owned
+        range of G, all-gather of G."""
+        self.rt.call('skf_iterate_dist', self.handle, int(n_iters), self.stream)
+
     def iterate_sharded(self, n_iters=1):
         """Iterations of a relation-sharded run: this plan holds only this rank's relations;
-        the E / D accumulators are summed over the ranks (one all-reduce per iteration: RCCL on
-        GPUs, gloo in the CPU tests) before the replicated G update."""
+        the E / D accumulators are summed over the ranks before the replicated G update -- by the library's own
+        collectives when a communicator is attached (attach_comm), else by one all-reduce per iteration through
+        torch.distributed."""
+        if getattr(self, '_comm', None):
+            return self.iterate_dist(n_iters)
         off, nbytes = C.c_size_t(), C.c_size_t()
         self.rt.call('skf_accumulator_range', self.handle, C.byref(off), C.byref(nbytes))
         acc = self.rt.mem.as_tensor(self.ws, off.value, nbytes.value, self.np_dtype)
@@ -392,7 +466,10 @@ class DevicePlan(object):
         """Iterations of a row-block-sharded run (every rank lists all relations, each with its row
         block): four stages with an all-reduce(sum) of W and Q, of the masked relations' Q (DFMC),
         and of E / D between them -- include/skfusion_hip.h `skf_stage`.  `reduce(tensor)` defaults
-        to torch.distributed.all_reduce (RCCL on GPUs, gloo in the CPU tests)."""
+        to torch.distributed.all_reduce (RCCL on GPUs, gloo in the CPU tests); with a communicator attached
+        (attach_comm) and no `reduce` the library issues the exchanges itself (skf_iterate_dist)."""
+        if reduce is None and getattr(self, '_comm', None):
+            return self.iterate_dist(n_iters)
         xw, xq, xqm, xed = self._exchange_views()
         mem, call, h = self.rt.mem, self.rt.call, self.handle
 
@@ -428,6 +505,9 @@ class DevicePlan(object):
         if self.handle:
             self.rt.lib.skf_plan_destroy(self.handle)
             self.handle = nat._P()
+        if getattr(self, '_comm', None):
+            self.rt.lib.skf_comm_destroy(self._comm)
+            self._comm = None
         self._keep, self._keep_rel = [], []
         self.ws = None
 

@@ -74,6 +74,9 @@ class GemmDesc(C.Structure):
                 ('splits', C.c_int32), ('a_dtype', C.c_int32), ('b_dtype', C.c_int32)]
 
 
+# skf_collective_fn: int (*)(void* user, int32_t op, void* buf, size_t count, int32_t dtype, void* stream)
+COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p)
+
 # every symbol include/skfusion_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -94,6 +97,13 @@ SIGNATURES = {
     'skf_stage': (C.c_int, [_P, C.c_int32, _P]),
     'skf_exchange_range': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                      C.POINTER(C.c_int32)]),
+    'skf_comm_unique_id': (C.c_int, [_P]),
+    'skf_comm_create': (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    'skf_comm_create_callback': (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.POINTER(_P)]),
+    'skf_comm_destroy': (C.c_int, [_P]),
+    'skf_plan_set_comm': (C.c_int, [_P, _P]),
+    'skf_iterate_dist': (C.c_int, [_P, C.c_int32, _P]),
+    'skf_exchange_bytes': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_size_t)]),
     'skf_relation_sqerr': (C.c_int, [_P, C.c_int32, _P, _P]),
     'skf_get_contraction': (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     'skf_plan_set_profiling': (C.c_int, [_P, C.c_int32]),

@@ -15,6 +15,7 @@
 #include "skf_kernels.h"
 #include "skf_known.h"
 
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -26,6 +27,8 @@
 #include <vector>
 
 #include "../../include/skfusion_hip.h"
+
+struct skf_comm;
 
 namespace skf {
 
@@ -275,12 +278,19 @@ static int pick_splits_bf16(int64_t units, int ktiles, int bm, int64_t out_elems
 // every transposed-A product, the 128-row register-staged kernel for small P-type products
 static int bf16_block_rows(int M, bool at) { return (at || M >= 4096) ? 256 : 128; }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and process, safe against the
-// concurrent host threads of run_fits_concurrent (one plan per thread)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and DEVICE (the attribute belongs to the kernel's
+// code object on one device: a process that drives several GPUs sets it on each), safe against the concurrent host
+// threads of run_fits_concurrent (one plan per thread)
+constexpr int SKF_MAX_DEVICES = 64;
+struct DeviceOnce {
+    std::once_flag flag[SKF_MAX_DEVICES];
+};
 template <class K>
-static void allow_dynamic_lds(std::once_flag& once, K kernel, int bytes) {
+static void allow_dynamic_lds(DeviceOnce& once, K kernel, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SKF_MAX_DEVICES) dev = 0;
     hipError_t err = hipSuccess;
-    std::call_once(once, [&] { err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+    std::call_once(once.flag[dev], [&] { err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
     if (err != hipSuccess) SKF_FAIL(SKF_E_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
 }
 
@@ -319,14 +329,14 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
 #define SKF_V2_LAUNCH(BN_, TAG_, AT_)                                                                             \
     do {                                                                                                          \
         const int smem_ = (3 * 256 + ((BN_ == 256) ? 2 : 3) * BN_) * 8 * 16;                                      \
-        static std::once_flag once_;                                                                              \
+        static DeviceOnce once_;                                                                              \
         allow_dynamic_lds(once_, gemm_bf16_v2_kernel<BN_, TAG_, AT_>, smem_);                                     \
         hipLaunchKernelGGL((gemm_bf16_v2_kernel<BN_, TAG_, AT_>), grid, dim3(512), smem_, st, g);                 \
     } while (0)
 #define SKF_V2_LAUNCH_BITS(BN_, AT_)                                                                              \
     do {                                                                                                          \
         const int smem_ = (3 * 256 + ((BN_ == 256) ? 2 : 3) * BN_) * 8 * 16;                                      \
-        static std::once_flag once_;                                                                              \
+        static DeviceOnce once_;                                                                              \
         allow_dynamic_lds(once_, gemm_bf16_v2_kernel<BN_, 1, AT_, EPI_T_STORE, true>, smem_);                     \
         hipLaunchKernelGGL((gemm_bf16_v2_kernel<BN_, 1, AT_, EPI_T_STORE, true>), grid, dim3(512), smem_, st, g); \
     } while (0)
@@ -534,6 +544,10 @@ struct skf_plan {
     bool pipeline = true;                  // relation-pipelined schedule of the DFMF iteration (SKF_NO_PIPELINE=1 at bind: off)
     std::vector<hipEvent_t> ev_rel;        // one event per relation: its contractions are done
     size_t acc_off = 0, acc_bytes = 0;     // contiguous range of all E / D accumulators
+    // E, D and G of all types as three regions of identical layout (flat_bytes each, a pad behind every one)
+    size_t flat_e_off = 0, flat_d_off = 0, flat_g_off = 0, flat_bytes = 0;
+    skf::Slot flat_pad[3];
+    skf_comm* comm = nullptr;              // collectives of the distributed iteration (skf_plan_set_comm; not owned)
     // row-block sharding: contiguous ranges of all W, of the Q of unmasked / of masked relations
     bool sliced = false;
     size_t xw_off = 0, xw_bytes = 0, xq_off = 0, xq_bytes = 0, xqm_off = 0, xqm_bytes = 0;
@@ -685,7 +699,7 @@ static void launch_chol(const Switches& sw, const EighArgs& e, int batch, int ma
         size_t wave_tiles = (size_t)(EIGH_THREADS / 64) * CHOLB_NB * (CHOLB_NB + 1);
         size_t panel = (size_t)CHOLB_NB * max_order;
         size_t smem = ((size_t)CHOLB_NB * (CHOLB_NB + 1) + (panel > wave_tiles ? panel : wave_tiles)) * sizeof(double);
-        static std::once_flag once;
+        static DeviceOnce once;
         allow_dynamic_lds(once, chol_inverse_blocked_kernel,
                           (int)(((size_t)CHOLB_NB * (CHOLB_NB + 1) + (size_t)CHOLB_NB * CHOLB_MAXN) * sizeof(double)));
         hipLaunchKernelGGL(chol_inverse_blocked_kernel, dim3((unsigned)batch), dim3(EIGH_THREADS), smem, st, e,
@@ -753,7 +767,7 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
     // a rank-deficient Gram matrix with a clear spectral gap: rank-revealing deflation (pchol_pinv_kernel); what it
     // declines goes to the eigen-solver with the exact singular-value cut-off
     {
-        static std::once_flag once;
+        static DeviceOnce once;
         allow_dynamic_lds(once, pchol_pinv_kernel, PCHOL_LDS_BYTES);
     }
     {   // dynamic LDS for the packed factor of L^T L, sized by the largest order of this plan (a no-op launch still has
@@ -1267,7 +1281,7 @@ static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t
         // relation and is faster on the 256 x 256 tile (4.7 vs 4.9 ms): it stays there.
         dim3 grid(cdiv(nr, 256), cdiv(nj, 128));
         const int smem = 256 * (128 + 8) * 2;
-        static std::once_flag once;
+        static DeviceOnce once;
         allow_dynamic_lds(once, gemm_bf16_kernel<256, 0, EPI_T_COMPLETE>, smem);
         hipLaunchKernelGGL((gemm_bf16_kernel<256, 0, EPI_T_COMPLETE>), grid, dim3(256), smem, st, g);
         check_launch("tile_epilogue_bf16");
@@ -1276,11 +1290,11 @@ static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t
     dim3 grid(cdiv(nr, 256), cdiv(nj, 256));
     const int smem = (3 * 256 + 2 * 256) * 8 * 16;
     if (mode == MODE_COMPLETE) {
-        static std::once_flag once;
+        static DeviceOnce once;
         allow_dynamic_lds(once, gemm_bf16_v2_kernel<256, 0, false, EPI_T_COMPLETE>, smem);
         hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0, false, EPI_T_COMPLETE>), grid, dim3(512), smem, st, g);
     } else {
-        static std::once_flag once;
+        static DeviceOnce once;
         allow_dynamic_lds(once, gemm_bf16_v2_kernel<256, 0, false, EPI_T_SQERR>, smem);
         hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0, false, EPI_T_SQERR>), grid, dim3(512), smem, st, g);
     }
@@ -1317,7 +1331,7 @@ static void stage_backbone(skf_plan* p, hipStream_t st) {
                 const size_t need = ((size_t)bb.ci[q] * bb.ci[q] + 2 * (size_t)bb.ci[q] * bb.cj[q] + (size_t)bb.cj[q] * bb.cj[q]) * 8;
                 if (need > smem) smem = need;
             }
-            static std::once_flag once_bb, once_bt;
+            static DeviceOnce once_bb, once_bt;
             allow_dynamic_lds(once_bb, backbone_small_kernel, 4 * SMALLC * SMALLC * 8);
             allow_dynamic_lds(once_bt, bterms_small_kernel, 4 * SMALLC * SMALLC * 8);
             hipLaunchKernelGGL(backbone_small_kernel, dim3(nb), dim3(256), smem, st, bb);
@@ -1550,6 +1564,150 @@ static void apply_update(skf_plan* p, hipStream_t st) {
 }
 
 
+
+// ------------------------------------------------------------------------------------------
+// Collectives behind the boundary (include/skfusion_hip.h, skf_comm_*): RCCL bound at run time with dlopen -- no
+// torch, no link-time dependency -- or caller-supplied callbacks (CPU tests over gloo, other transports).
+// ------------------------------------------------------------------------------------------
+struct NcclUniqueId { char internal[128]; };
+typedef int (*nccl_get_unique_id_t)(NcclUniqueId*);
+typedef int (*nccl_comm_init_rank_t)(void**, int, NcclUniqueId, int);
+typedef int (*nccl_comm_destroy_t)(void*);
+typedef int (*nccl_all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_reduce_scatter_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_all_gather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef const char* (*nccl_get_error_string_t)(int);
+struct Rccl {
+    void* handle = nullptr;
+    nccl_get_unique_id_t get_unique_id = nullptr;
+    nccl_comm_init_rank_t comm_init_rank = nullptr;
+    nccl_comm_destroy_t comm_destroy = nullptr;
+    nccl_all_reduce_t all_reduce = nullptr;
+    nccl_reduce_scatter_t reduce_scatter = nullptr;
+    nccl_all_gather_t all_gather = nullptr;
+    nccl_get_error_string_t error_string = nullptr;
+};
+static Rccl g_rccl;
+static std::once_flag g_rccl_once;
+
+// librccl of the process if one is loaded already (PyTorch-ROCm bundles its own), else SKF_RCCL_PATH / the loader path / ROCm
+static const Rccl& rccl() {
+    std::call_once(g_rccl_once, [] {
+        const char* names[] = {getenv("SKF_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        void* h = nullptr;
+        for (const char* nm : names)
+            if (nm && !h) h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char* nm : names)
+            if (nm && !h) h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        g_rccl.handle = h;
+        g_rccl.get_unique_id = (nccl_get_unique_id_t)dlsym(h, "ncclGetUniqueId");
+        g_rccl.comm_init_rank = (nccl_comm_init_rank_t)dlsym(h, "ncclCommInitRank");
+        g_rccl.comm_destroy = (nccl_comm_destroy_t)dlsym(h, "ncclCommDestroy");
+        g_rccl.all_reduce = (nccl_all_reduce_t)dlsym(h, "ncclAllReduce");
+        g_rccl.reduce_scatter = (nccl_reduce_scatter_t)dlsym(h, "ncclReduceScatter");
+        g_rccl.all_gather = (nccl_all_gather_t)dlsym(h, "ncclAllGather");
+        g_rccl.error_string = (nccl_get_error_string_t)dlsym(h, "ncclGetErrorString");
+    });
+    if (!g_rccl.handle || !g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce ||
+        !g_rccl.reduce_scatter || !g_rccl.all_gather)
+        SKF_FAIL(SKF_E_STATE, "librccl.so could not be loaded (set SKF_RCCL_PATH, or use skf_comm_create_callback)");
+    return g_rccl;
+}
+
+}  // namespace skf
+
+struct skf_comm {
+    int rank = 0, world = 1;
+    void* nccl = nullptr;                  // ncclComm_t, or
+    skf_collective_fn fn = nullptr;        // caller-supplied collectives
+    void* user = nullptr;
+};
+
+namespace skf {
+
+enum { COLL_ALL_REDUCE = 0, COLL_REDUCE_SCATTER = 1, COLL_ALL_GATHER = 2 };
+
+// op over `count` elements per rank (COLL_ALL_REDUCE: the whole buffer; the other two: chunk `rank` of world * count), in place
+static void collective(skf_comm* c, int op, void* buf, size_t count, int dtype, hipStream_t st) {
+    if (!c) SKF_FAIL(SKF_E_STATE, "no communicator attached to the plan (skf_plan_set_comm)");
+    if (count == 0) return;
+    if (c->fn) {
+        const int rc = c->fn(c->user, op, buf, count, dtype, (void*)st);
+        if (rc != 0) SKF_FAIL(SKF_E_HIP, "collective callback failed (op %d, status %d)", op, rc);
+        return;
+    }
+    if (c->world == 1 && !c->nccl) return;          // a single rank without a transport: nothing to exchange
+    const Rccl& r = rccl();
+    const int nt = dtype == SKF_F64 ? 8 /* ncclFloat64 */ : 7 /* ncclFloat32 */;
+    const size_t es = dtype == SKF_F64 ? 8 : 4;
+    char* mine = (char*)buf + (size_t)c->rank * count * es;
+    int rc = 0;
+    if (op == COLL_ALL_REDUCE) rc = r.all_reduce(buf, buf, count, nt, 0 /* ncclSum */, c->nccl, st);
+    else if (op == COLL_REDUCE_SCATTER) rc = r.reduce_scatter(buf, mine, count, nt, 0, c->nccl, st);
+    else rc = r.all_gather(mine, buf, count, nt, c->nccl, st);
+    if (rc != 0) SKF_FAIL(SKF_E_HIP, "RCCL collective %d failed: %s", op, r.error_string ? r.error_string(rc) : "?");
+}
+
+// elements per rank when `total` elements are cut into `world` equal ranges (multiples of 64; the region's pad takes the rest)
+static size_t flat_chunk(size_t total, int world) { return ((total + world - 1) / world + 63) / 64 * 64; }
+
+// One iteration with the exchanges inside: plans without row blocks run accumulate -> exchange -> update, plans with row
+// blocks the four stages.  E / D: reduce-scatter (every rank ends with the sums of ITS element range), update of that
+// range of G, all-gather of G -- (2 + 1) * (world - 1) / world of the factor bytes per rank instead of the
+// 2 * 2 * (world - 1) / world of an all-reduce of both accumulators.
+static void exchange_and_update(skf_plan* p, hipStream_t st) {
+    skf_comm* c = p->comm;
+    const size_t total = p->flat_bytes / p->esz;
+    const size_t chunk = flat_chunk(total, c->world);
+    if (chunk * c->world * p->esz > p->flat_bytes + 64 * 1024) SKF_FAIL(SKF_E_STATE, "exchange ranges exceed the region pad (world %d)", c->world);
+    char* base = (char*)p->ws_base;
+    void* E = base + p->flat_e_off;
+    void* D = base + p->flat_d_off;
+    void* G = base + p->flat_g_off;
+    collective(c, COLL_REDUCE_SCATTER, E, chunk, p->mt, st);
+    collective(c, COLL_REDUCE_SCATTER, D, chunk, p->mt, st);
+    for (TypeState& t : p->types)          // known-entries relations: the factors their stored residuals belong to
+        if (t.keep_prev) SKF_HIP(hipMemcpyAsync(t.Gp.ptr, t.G.ptr, t.G.bytes, hipMemcpyDeviceToDevice, st));
+    p->kn_first = false;
+    const size_t lo = (size_t)c->rank * chunk;
+    if (p->f64)
+        hipLaunchKernelGGL((mult_update_kernel<double>), dim3(elem_grid((int64_t)chunk)), dim3(256), 0, st, (double*)G + lo,
+                           (const double*)E + lo, (const double*)D + lo, (int64_t)chunk, 1, (int64_t)1, (int64_t)1);
+    else
+        hipLaunchKernelGGL((mult_update_kernel<float>), dim3(elem_grid((int64_t)chunk)), dim3(256), 0, st, (float*)G + lo,
+                           (const float*)E + lo, (const float*)D + lo, (int64_t)chunk, 1, (int64_t)1, (int64_t)1);
+    check_launch("mult_update(range)");
+    collective(c, COLL_ALL_GATHER, G, chunk, p->mt, st);
+    for (TypeState& t : p->types) refresh_gt(p, t, st);
+}
+
+static void iterate_dist(skf_plan* p, hipStream_t st) {
+    skf_comm* c = p->comm;
+    char* base = (char*)p->ws_base;
+    if (!p->sliced) {
+        accumulate_fit(p, st);
+    } else {
+        stage_contract(p, st);
+        collective(c, COLL_ALL_REDUCE, base + p->xw_off, p->xw_bytes / 8, SKF_F64, st);
+        collective(c, COLL_ALL_REDUCE, base + p->xq_off, p->xq_bytes / p->esz, p->mt, st);
+        stage_backbone(p, st);
+        collective(c, COLL_ALL_REDUCE, base + p->xqm_off, p->xqm_bytes / p->esz, p->mt, st);
+        stage_accumulate(p, st);
+    }
+    exchange_and_update(p, st);
+}
+
+// bytes one rank SENDS per iteration of skf_iterate_dist on a ring (reduce-scatter / all-gather: (world-1)/world of the
+// buffer, all-reduce: twice that)
+static size_t exchange_bytes(const skf_plan* p, int world) {
+    if (world <= 1) return 0;
+    const double f = (double)(world - 1) / world;
+    double b = 3.0 * f * (double)(flat_chunk(p->flat_bytes / p->esz, world) * world * p->esz);
+    if (p->sliced) b += 2.0 * f * (double)(p->xw_bytes + p->xq_bytes + p->xqm_bytes);
+    return (size_t)b;
+}
+
 // ------------------------------------------------------------------------------------------
 // The same DFMF iteration as stage_contract + stage_backbone + stage_accumulate, scheduled as a pipeline over
 // the relations (whole, unmasked relations; every rank between 65 and 512; MFMA engine): the main stream runs
@@ -1691,11 +1849,14 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
                         touched[r.row] != 0, nan_upd, ax);
         touched[r.row] = 1;
         if (--rels_left[r.row] == 0) type_term(r.row);            // (before the wait for Q: under the relation's own Q)
+        // the type-level term of the column type needs the B sums only (complete with this relation's backbone), not Q:
+        // it goes out under the relation's own Q as well, and only the column side product remains behind Q
+        const bool last_col = --rels_left[r.col] == 0;
+        if (last_col) type_term(r.col);
         SKF_HIP(hipStreamWaitEvent(ax, p->ev_rel[4 * q + 3], 0));
         side_update(p, r.Q.ptr, ci, ci, Sm[q], cj, 1, tj, tj.G.ptr, tj.E.ptr, tj.D.ptr, nj, nullptr, nullptr, false,
                     touched[r.col] != 0, nan_upd, ax);
         touched[r.col] = 1;
-        if (--rels_left[r.col] == 0) type_term(r.col);
     };
     auto w_product = [&](RelState& r, bool by_q) {        // W = G_i^T P, or (R^T G_i)^T G_j through the narrower factor
         TypeState& ti = p->types[r.row];
@@ -2113,21 +2274,30 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         int maxn = 2;
         // the E / D accumulators of all types form ONE contiguous range of the workspace, so that
         // a relation-sharded run sums them over the ranks with a single all-reduce
+        // Three regions with the SAME internal layout -- all E, all D, all G (every type at the same offset in each) -- so
+        // that the distributed iteration can cut them into `world` equal element ranges: reduce-scatter of E and of D,
+        // update of the owned range of G, all-gather of G (skf_iterate_dist).  A pad behind each region takes the rounding
+        // of the last range.
         p->acc_off = p->ws_bytes;
-        for (int i = 0; i < n_types; ++i) {
-            TypeState& t = p->types[i];
-            const bool active = (p->variant != SKF_TRANSFORM) || i == p->target;
-            if (active) {
-                add_slot(p, t.E, (size_t)t.n * t.c * es);
-                add_slot(p, t.D, (size_t)t.n * t.c * es);
+        for (int region = 0; region < 3; ++region) {
+            const size_t begin = p->ws_bytes;
+            for (int i = 0; i < n_types; ++i) {
+                TypeState& t = p->types[i];
+                const bool active = (p->variant != SKF_TRANSFORM) || i == p->target;
+                if (region < 2 && !active) continue;
+                add_slot(p, region == 0 ? t.E : region == 1 ? t.D : t.G, (size_t)t.n * t.c * es);
             }
+            const size_t bytes = p->ws_bytes - begin;
+            if (region == 0) { p->flat_e_off = begin; p->flat_bytes = bytes; }
+            if (region == 1) p->flat_d_off = begin;
+            if (region == 2) p->flat_g_off = begin;
+            add_slot(p, p->flat_pad[region], 64 * 1024);
+            if (region == 1) p->acc_bytes = p->ws_bytes - p->acc_off;
         }
-        p->acc_bytes = p->ws_bytes - p->acc_off;
         for (int i = 0; i < n_types; ++i) {
             TypeState& t = p->types[i];
             const bool active = (p->variant != SKF_TRANSFORM) || i == p->target;
             (void)active;
-            add_slot(p, t.G, (size_t)t.n * t.c * es);
             add_slot(p, t.Gram, (size_t)t.c * t.c * 8);
             if (p->bf16) {
                 t.ldgt = pad64(t.n);
@@ -2757,6 +2927,81 @@ int skf_accumulator_range(const skf_plan* p, size_t* offset, size_t* bytes) {
     });
 }
 
+int skf_comm_unique_id(void* id128) {
+    return guarded([&] {
+        if (!id128) SKF_FAIL(SKF_E_INVALID, "null argument");
+        NcclUniqueId id;
+        const int rc = rccl().get_unique_id(&id);
+        if (rc != 0) SKF_FAIL(SKF_E_HIP, "ncclGetUniqueId failed (%d)", rc);
+        memcpy(id128, &id, sizeof id);
+    });
+}
+
+int skf_comm_create(const void* id128, int32_t rank, int32_t world, skf_comm** out) {
+    return guarded([&] {
+        if (!out || world < 1 || rank < 0 || rank >= world) SKF_FAIL(SKF_E_INVALID, "bad rank / world / pointer");
+        skf_comm* c = new skf_comm();
+        c->rank = rank; c->world = world;
+        if (id128) {
+            NcclUniqueId id;
+            memcpy(&id, id128, sizeof id);
+            const int rc = rccl().comm_init_rank(&c->nccl, world, id, rank);
+            if (rc != 0) {
+                delete c;
+                SKF_FAIL(SKF_E_HIP, "ncclCommInitRank failed: %s", g_rccl.error_string ? g_rccl.error_string(rc) : "?");
+            }
+        } else if (world != 1) {
+            delete c;
+            SKF_FAIL(SKF_E_INVALID, "a communicator of %d ranks needs the unique id of skf_comm_unique_id", world);
+        }
+        *out = c;
+    });
+}
+
+int skf_comm_create_callback(int32_t rank, int32_t world, skf_collective_fn fn, void* user, skf_comm** out) {
+    return guarded([&] {
+        if (!out || !fn || world < 1 || rank < 0 || rank >= world) SKF_FAIL(SKF_E_INVALID, "bad rank / world / pointer");
+        skf_comm* c = new skf_comm();
+        c->rank = rank; c->world = world; c->fn = fn; c->user = user;
+        *out = c;
+    });
+}
+
+int skf_comm_destroy(skf_comm* c) {
+    return guarded([&] {
+        if (!c) return;
+        if (c->nccl && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(c->nccl);
+        delete c;
+    });
+}
+
+int skf_plan_set_comm(skf_plan* p, skf_comm* comm) {
+    return guarded([&] {
+        if (!p) SKF_FAIL(SKF_E_INVALID, "null plan");
+        if (p->variant == SKF_TRANSFORM && comm) SKF_FAIL(SKF_E_INVALID, "skf_plan_set_comm: SKF_DFMF / SKF_DFMC plans only");
+        p->comm = comm;
+    });
+}
+
+int skf_iterate_dist(skf_plan* p, int32_t n_iters, void* stream) {
+    return guarded([&] {
+        check_bound(p);
+        if (p->variant == SKF_TRANSFORM) SKF_FAIL(SKF_E_INVALID, "skf_iterate_dist: SKF_DFMF / SKF_DFMC plans only");
+        if (!p->comm) SKF_FAIL(SKF_E_STATE, "no communicator attached to the plan (skf_plan_set_comm)");
+        if (n_iters < 0) SKF_FAIL(SKF_E_INVALID, "n_iters < 0");
+        for (size_t i = 0; i < p->types.size(); ++i)
+            if (!p->types[i].set) SKF_FAIL(SKF_E_STATE, "factor of object type %zu not set", i);
+        for (int it = 0; it < n_iters; ++it) iterate_dist(p, as_stream(stream));
+    });
+}
+
+int skf_exchange_bytes(const skf_plan* p, int32_t world, size_t* bytes) {
+    return guarded([&] {
+        if (!p || !bytes || world < 1) SKF_FAIL(SKF_E_INVALID, "bad argument");
+        *bytes = exchange_bytes(p, world);
+    });
+}
+
 int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
     return guarded([&] {
         check_bound(p);
@@ -2998,7 +3243,7 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
                                eV, np, n, eOk);
         check_launch("chol_unpack");
         {
-            static std::once_flag once;
+            static DeviceOnce once;
             allow_dynamic_lds(once, pchol_pinv_kernel, PCHOL_LDS_BYTES);
         }
         const int lr = np < PCHOL_LDS_R ? np : PCHOL_LDS_R;

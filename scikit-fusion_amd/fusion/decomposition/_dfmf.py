@@ -127,6 +127,7 @@ def run_fit_rows(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_
     plan = row_block_plan(variant, rel_list, flatten_thetas(Theta), obj_types, n_obj, obj_type2rank, dtype,
                           engine, rank, size)
     try:
+        plan.attach_comm()                 # the library issues the exchanges itself (skf_iterate_dist)
         for t in obj_types:
             plan.set_factor(t, G0[t, t])
         if not (callback or stopping or stopping_system or compute_err):
@@ -170,6 +171,7 @@ def run_fit_sharded(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, in
                       [t for t, o in zip(theta_list, theta_owner) if o == rank], variant,
                       dtype=dtype, engine=engine)
     try:
+        plan.attach_comm()                 # the library issues the exchanges itself (skf_iterate_dist)
         for t in obj_types:
             plan.set_factor(t, G0[t, t])
 

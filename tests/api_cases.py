@@ -264,3 +264,48 @@ def n_jobs_concurrent_restarts_equal_sequential(cls):
     for r in rels[:3]:
         for a, b in zip(seq.backbone(r), par.backbone(r)):
             np.testing.assert_array_equal(a, b)
+
+
+def persistence_round_trip_on_the_engine(tmpdir, dtype='f32'):
+    """SURVEY.md 8 f4 on the device path: fit on the engine -> save -> load (onto the graph, and onto a skeleton graph) ->
+    the loaded model drives blockwise device completion and the fold-in to the SAME bits as the model that was never
+    saved (reference accessors base.py:35-56, 169-189; fold-in dfmf.py:109-115, 155-204; chaining as in
+    examples/dicty_chaining.py:56-63)."""
+    import os
+    import skfusion_amd._native as nat
+    from skfusion_amd.fusion import FusionFit
+    rs = np.random.RandomState(11)
+    t1, t2, t3 = ObjectType('genes', 12), ObjectType('terms', 9), ObjectType('conditions', 6)
+    rels = [Relation(rs.rand(140, 90), t1, t2, name='ann'), Relation(rs.rand(140, 60), t1, t3, name='expr'),
+            Relation(rs.rand(90, 60), t2, t3, name='ctx'), Relation(0.01 * np.eye(140), t1, t1, name='ppi')]
+    graph = FusionGraph(rels)
+    fuser = Dfmf(max_iter=8, init_type='random_vcol', random_state=5, n_run=2, dtype=dtype).fuse(graph)
+    path = fuser.save(os.path.join(str(tmpdir), 'fit.npz'))
+    mem = nat.get_runtime().mem
+    new_graph = lambda: FusionGraph([Relation(np.random.RandomState(3).rand(20, 90), t1, t2),
+                                     Relation(np.random.RandomState(4).rand(20, 60), t1, t3)])
+
+    def fold_in(model):
+        return DfmfTransform(max_iter=6, init_type='random_c', random_state=7, dtype=dtype).transform(t1, new_graph(), model)
+    want_tr = fold_in(fuser).factor(t1)
+    for onto in (graph, None):
+        back = FusionFit.load(path, onto)
+        g2 = back.fusion_graph
+        typ = {ot.name: ot for ot in g2.object_types}
+        rel2 = [r for r in g2.relations if r.row_type is not r.col_type]
+        for run in (0, 1):
+            for ot in (t1, t2, t3):
+                np.testing.assert_array_equal(back.factor(typ[ot.name], run=run), fuser.factor(ot, run=run))
+            for ra, rb in zip(rels[:3], rel2):
+                np.testing.assert_array_equal(back.backbone(rb, run=run), fuser.backbone(ra, run=run))
+                want = [mem.to_host(b.buf, b.shape, np.float64 if dtype == 'f64' else np.float32).copy()
+                        for _, b in fuser.complete_blocks(ra, block_rows=64, run=run, dtype=dtype, device=True)]
+                got = [mem.to_host(b.buf, b.shape, np.float64 if dtype == 'f64' else np.float32).copy()
+                       for _, b in back.complete_blocks(rb, block_rows=64, run=run, dtype=dtype, device=True)]
+                assert len(want) == len(got) == (ra.data.shape[0] + 63) // 64
+                for w, g in zip(want, got):
+                    np.testing.assert_array_equal(g, w)
+        assert [[t.name for t in p] for p in back.chain(typ['genes'], typ['conditions'])] == \
+               [['genes', 'conditions'], ['genes', 'terms', 'conditions']]
+        if onto is not None:                     # the fold-in reads the frozen factors / backbones of the loaded model
+            np.testing.assert_array_equal(fold_in(back).factor(t1), want_tr)

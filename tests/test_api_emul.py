@@ -50,3 +50,8 @@ def test_n_jobs_concurrent_restarts(cls):
 
 def test_fill_strategies_on_the_device():
     A.device_fill_strategies()
+
+
+def test_saved_model_drives_the_engine(tmp_path):
+    """f4: fit -> save -> load -> blockwise device completion and fold-in from the loaded model (same case as on the GPU)."""
+    A.persistence_round_trip_on_the_engine(tmp_path, 'f64')

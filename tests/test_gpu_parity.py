@@ -479,6 +479,28 @@ def test_rccl_stream_ordered_exchanges_single_rank(monkeypatch):
             Gc, Sc = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=10, G0=g0_from(z, 'dfmc/', types), shard=shard)
             for t in types:
                 assert relerr(Gc[t, t], z['dfmc/G_%s_it9' % t]) < 1e-9
+        # the exchanges of those fits were issued by the library on its own RCCL communicator (skf_comm_unique_id /
+        # skf_comm_create / skf_iterate_dist): reduce-scatter of E and D, update of the owned range, all-gather of G.  On a
+        # scaled config 3 in bf16 the same path must equal the staged single-device iteration bit for bit.
+        import bench
+        monkeypatch.setenv('SKF_NO_PIPELINE', '1')
+        n = bench.sizes(0.05)
+        out = []
+        for use_library in (True, False):
+            rels = [(i, j, bench.c3_relation(k, n, 'bf16'), None) for k, (i, j, _) in enumerate(bench.PAIRS)]
+            plan = DevicePlan(bench.TYPES, n, bench.RANKS, rels, [], nat.SKF_DFMF, dtype='bf16')
+            for k, t in enumerate(bench.TYPES):
+                plan.set_factor(t, fill_uniform((n[t], bench.RANKS[t]), 100 + k, 'f32'))
+            if use_library:
+                assert plan.attach_comm()
+                assert plan.exchange_bytes(8) > 3 * 7 / 8 * sum(n[t] * bench.RANKS[t] * 4 for t in bench.TYPES)
+                plan.iterate_dist(3)
+            else:
+                plan.iterate(3)
+            out.append([plan.get_factor(t) for t in bench.TYPES])
+            plan.close()
+        for a, b in zip(*out):
+            np.testing.assert_array_equal(a, b)
     finally:
         dist.destroy_process_group()
 
