@@ -310,8 +310,23 @@ def test_bf16_completion_kernel_against_f32_engine(known):
     R written in 16-byte chunks with the known entries blended back; the mask as packed bits) against the
     f32 engine's per-element masked store on the bf16-rounded relation, on shapes that are not multiples of
     the 128 x 128 tile / of 8.  The mask arrives once as host booleans (packed on the host,
-    SKF_REL_MASK_BITS) and once as device bytes (packed by the library at bind time)."""
+    SKF_REL_MASK_BITS) and once as device bytes (packed by the library at bind time).
+    (SKF_DFMC_SPARSE=0: this is the test of the DENSE path with its completed copy; by default a relation with so few
+    known entries is kept as lists of them -- test_dfmc_on_the_known_entries_only_*.)"""
+    import os
     from skfusion_amd._engine import DevicePlan, DeviceMatrix, flatten_relations
+    saved = os.environ.get('SKF_DFMC_SPARSE')
+    os.environ['SKF_DFMC_SPARSE'] = '0'
+    try:
+        _bf16_completion_case(known, DevicePlan, DeviceMatrix)
+    finally:
+        if saved is None:
+            os.environ.pop('SKF_DFMC_SPARSE')
+        else:
+            os.environ['SKF_DFMC_SPARSE'] = saved
+
+
+def _bf16_completion_case(known, DevicePlan, DeviceMatrix):
     rs = np.random.RandomState(9)
     types, n, rank = ['a', 'b'], {'a': 203, 'b': 157}, {'a': 7, 'b': 5}
     R = {('a', 'b'): [rs.rand(203, 157)]}

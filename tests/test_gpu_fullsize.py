@@ -164,8 +164,11 @@ def test_full_size_planted_structure_is_recovered(dtype):
     plan.close()
 
 
-def test_config5_full_size_completion_and_contractions_against_host_rows():
-    """BASELINE configs[4] at FULL size (100k users x 40k movies, 98 % of the ratings unknown, five 0 / 1 side relations,
+@pytest.mark.parametrize('form', ['dense', 'lists'])
+def test_config5_full_size_completion_and_contractions_against_host_rows(form):
+    """(form = dense: the completed copy of the ratings relation, sparse_known=False; lists: the default for 2 % known
+    entries -- only the known entries are kept, csrc/skf_known.h -- checked on the row-side product P S^T and on Q.)
+    BASELINE configs[4] at FULL size (100k users x 40k movies, 98 % of the ratings unknown, five 0 / 1 side relations,
     two sparse constraints; DFMC on the relation pipeline, bf16 engine): the completion of the ratings relation
     (_dfmc.py:319-325) and the two contractions that follow it (_dfmc.py:341-345), against HOST arithmetic on rows and
     columns of the relation and its mask copied back before the fit.  The host repeats the engine's roundings (bf16 H
@@ -185,7 +188,8 @@ def test_config5_full_size_completion_and_contractions_against_host_rows():
     tr, tc = torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()
     R_rows, U_rows = Rt[tr].to(torch.float64).cpu().numpy(), Mt[tr].cpu().numpy().astype(bool)          # U = unknown
     R_cols, U_cols = Rt[:, tc].to(torch.float64).cpu().numpy(), Mt[:, tc].cpu().numpy().astype(bool)
-    plan = DevicePlan(bench.C5_TYPES, n, bench.C5_RANKS, rels, thetas, nat.SKF_DFMC, dtype='bf16')
+    plan = DevicePlan(bench.C5_TYPES, n, bench.C5_RANKS, rels, thetas, nat.SKF_DFMC, dtype='bf16',
+                      sparse_known=False if form == 'dense' else None)
     plan.release_relation_data()
     del rels, thetas, Rdm, Mdm, Rt, Mt
     torch.cuda.empty_cache()
@@ -195,12 +199,28 @@ def test_config5_full_size_completion_and_contractions_against_host_rows():
     Gu, Gm = plan.get_factor('user'), plan.get_factor('movie')          # the factors the third iteration works with
     plan.iterate(1)
     S = plan.get_backbone(0)                                            # backbone of the third iteration
-    P = plan.get_contraction(0, 0).astype(np.float64)
+    P = plan.get_contraction(0, 0 if form == 'dense' else 2).astype(np.float64)      # lists: the row-side product P S^T
     Q = plan.get_contraction(0, 1).astype(np.float64)
     plan.close()
 
     def bf16(x):
         return nat.from_bf16_bits(nat.to_bf16_bits(np.asarray(x, dtype=np.float32))).astype(np.float64)
+    if form == 'lists':
+        # R_c = X + E with X = G_user S G_movie^T and E = R - X on the known entries (skf_known.h):
+        #   P S^T = G_user (S Gram_movie S^T) + E T ,  Q = G_movie (S^T Gram_user) + E^T G_user ,  T = G_movie S^T
+        # the lists see bf16 rows of G_user and T (as the matrix cores would), the c x c parts the f32 masters in f64
+        Gu64, Gm64 = Gu.astype(np.float64), Gm.astype(np.float64)
+        Tb, Gub = bf16(Gm64 @ S.T), bf16(Gu)
+        E_rows = np.where(U_rows, 0.0, R_rows - Gub[rows] @ Tb.T)
+        A_host = Gu64[rows] @ (S @ (Gm64.T @ Gm64) @ S.T) + E_rows @ Tb
+        # measured (MI355X, round 3): 2.1e-7 / 4.6e-7
+        within(relerr(P[rows], A_host), 1.2e-6, 'config 5 full size, known-entry lists: rows of P S^T vs host')
+        E_cols = np.where(U_cols, 0.0, R_cols - Gub @ Tb[cols].T)
+        Q_host = Gm64[cols] @ (S.T @ (Gu64.T @ Gu64)) + E_cols.T @ Gub
+        within(relerr(Q[cols], Q_host), 2.5e-6, 'config 5 full size, known-entry lists: rows of Q vs host')
+        # and the known entries weigh in: the c x c parts alone are far off
+        assert relerr(Q[cols], Gm64[cols] @ (S.T @ (Gu64.T @ Gu64))) > 1e-3
+        return
     Hb = bf16(Gu.astype(np.float64) @ S)                                # H = G_user S, into the matrix cores as bf16
     Gmb, Gub = bf16(Gm), bf16(Gu)
     # completed rows: known entries as stored, unknown ones = bf16(H G_movie^T)

@@ -415,7 +415,7 @@ def test_accumulate_apply_split_equals_iterate():
         assert relerr(Gc[t, t], z['dfmc/G_%s_it9' % t]) < 1e-9
 
 
-def test_row_block_sharding_c3_scaled_c5_and_probe():
+def test_row_block_sharding_c3_scaled_c5_and_probe(monkeypatch):
     """SURVEY.md 8e row blocks on the device: 2 / 3 / 4 simulated ranks (lockstep plans on this one
     GPU, exchange ranges summed where RCCL would all-reduce) against the reference goldens -- the
     scaled config 3 (f64 errors + S, f32, bf16), config 5 (MovieLens-style Dfmc) and the probe graph."""
@@ -444,8 +444,12 @@ def test_row_block_sharding_c3_scaled_c5_and_probe():
             assert relerr(S[i, j][0], z5['dfmc/S_%s_%s_0_it29' % (i, j)]) < 1e-9
     # the bf16 engine under row blocks (bitmaps, CSR / CSC of the sparse 0 / 1 relations and the completion lists are built
     # per block): against the same engine on whole relations
+    # (both on the dense path with its completed bf16 copy -- plans with row blocks always take it; by default the whole
+    # ratings relation would be kept as lists of its known entries, which do not round completed entries to bf16)
     G0 = g0_from(z5, 'dfmc/', types)
+    monkeypatch.setenv('SKF_DFMC_SPARSE', '0')
     Gw, Sw = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=5, G0=G0, dtype='bf16')
+    monkeypatch.delenv('SKF_DFMC_SPARSE')
     for G, S in fit_row_blocks('dfmc', R, M, Theta, types, rank, G0, 5, 3, dtype='bf16'):
         for t in types:
             within(relerr(G[t, t], Gw[t, t]), 2e-3, 'c5 scaled bf16, 3 row blocks vs whole relations: G_%s after 5 iterations' % t)
@@ -493,7 +497,7 @@ def test_rccl_stream_ordered_exchanges_single_rank(monkeypatch):
                 plan.set_factor(t, fill_uniform((n[t], bench.RANKS[t]), 100 + k, 'f32'))
             if use_library:
                 assert plan.attach_comm()
-                assert plan.exchange_bytes(8) > 3 * 7 / 8 * sum(n[t] * bench.RANKS[t] * 4 for t in bench.TYPES)
+                assert plan.exchange_bytes(8) >= 3 * 7 / 8 * sum(n[t] * bench.RANKS[t] * 4 for t in bench.TYPES)
                 plan.iterate_dist(3)
             else:
                 plan.iterate(3)
