@@ -14,6 +14,7 @@
 //   G_i <- G_i * sqrt(E_i / max(D_i, eps))                                  (:294-296)
 #include "skf_kernels.h"
 #include "skf_known.h"
+#include "skf_small.h"
 
 #include <dlfcn.h>
 #include <stdio.h>
@@ -406,6 +407,7 @@ struct Switches {
     int aux_prio = 0;              // SKF_AUX_PRIO=default|high  priority of the second stream (0 = lowest, the default)
     int epi_tile = 128;            // SKF_EPI_TILE=256      completion pass on the 256 x 256 tile (one workgroup per CU)
     bool known_generic = false;    // SKF_KNOWN_GENERIC=1   the any-width list kernel for the known-entry passes (tests, A/B)
+    bool no_small_fused = false;   // SKF_NO_SMALL_FUSED=1  small graphs on the general staged schedule (~33 launches per iteration)
     static Switches read() {
         auto on = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
         Switches w;
@@ -418,6 +420,7 @@ struct Switches {
         w.no_overlap = on("SKF_NO_OVERLAP");
         w.no_pipeline = on("SKF_NO_PIPELINE");
         w.known_generic = on("SKF_KNOWN_GENERIC");
+        w.no_small_fused = on("SKF_NO_SMALL_FUSED");
         const char* st = getenv("SKF_SIDE_TILE");
         w.side_tile = st ? atoi(st) : 0;
         const char* ap = getenv("SKF_AUX_PRIO");
@@ -497,6 +500,9 @@ struct RelState {
     Slot Apart, Qpart;                     // partial outputs of the parts, [parts][n][c_i] (only with more than one part)
     Slot A;                                // E T, then the row-side product P S^T = G_i (S Gram_j S^T) + E T   (n_i x c_i)
     Slot Sp, Xi, Xj, Bf, U2;               // S of the stored residuals; G_i'^T G_i, G_j^T G_j'; S Gram_j S^T; S^T Gram_i  (f64)
+    Slot SmBp, SmBn, SmDp, SmDn;           // small graphs: +- parts of S Gram_j S^T and S^T Gram_i S of THIS relation
+    Slot SmQ;                              // ... and Q as shares over row ranges of the relation, [sm_qparts][n_j][c_i]
+    int sm_qparts = 0;
 };
 
 struct ThetaState {
@@ -565,6 +571,10 @@ struct skf_plan {
     double prof_flops = 0.0, prof_bytes = 0.0;
     int64_t prof_launches = 0;
     bool kn_first = true;                  // no residuals stored yet: E = the known entries themselves, S_prev = 0
+    // small graphs (skf_small.h): the whole DFMF iteration as eight launches over job tables kept in the workspace
+    bool small_fused = false;
+    skf::Slot sm_tables, sm_jobs1, sm_jobs3, sm_wpart, sm_gpart;
+    std::vector<skf::SmJob> sm_j1, sm_j3;
     ~skf_plan() {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_rel) (void)hipEventDestroy(e);
@@ -712,6 +722,8 @@ static void launch_chol(const Switches& sw, const EighArgs& e, int batch, int ma
 
 // K_i = pinv(Gram_i) for every type (one workgroup each); `which` = 0..n_types-1, the order
 // of the per-matrix order arrays uploaded once by skf_plan_bind_workspace.
+static void pinv_fallbacks(skf_plan* p, const std::vector<int>& which, const PinvBatch& pb, const EighArgs& e, bool batched, int max_c,
+                           hipStream_t st);
 static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st) {
     if (which.empty()) return;
     const int64_t stride = p->eig_stride;
@@ -764,6 +776,14 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
             check_launch("chol_unpack");
         }
     }
+    pinv_fallbacks(p, which, pb, e, batched, max_c, st);
+}
+
+// the matrices the Cholesky fast path declined (verdicts in eigOk, packed copies in eigA); no-ops for the others
+static void pinv_fallbacks(skf_plan* p, const std::vector<int>& which, const PinvBatch& pb, const EighArgs& e, bool batched, int max_c,
+                           hipStream_t st) {
+    const int64_t stride = p->eig_stride;
+    const int nb = (int)which.size();
     // a rank-deficient Gram matrix with a clear spectral gap: rank-revealing deflation (pchol_pinv_kernel); what it
     // declines goes to the eigen-solver with the exact singular-value cut-off
     {
@@ -1951,7 +1971,55 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
     apply_update(p, st);
 }
 
+// The DFMF iteration of a small graph in eight launches (skf_small.h)
+template <typename T>
+static void iterate_small_fused_t(skf_plan* p, hipStream_t st) {
+    const SmTables* tb = (const SmTables*)p->sm_tables.ptr;
+    hipLaunchKernelGGL((small_contract_kernel<T>), dim3((unsigned)p->sm_j1.size()), dim3(256), 0, st, tb, (const SmJob*)p->sm_jobs1.ptr);
+    check_launch("small_contract");
+    hipLaunchKernelGGL(small_pinv_kernel, dim3((unsigned)(p->types.size() + p->rels.size())), dim3(SM_PINV_THREADS), 0, st, tb);
+    check_launch("small_pinv");
+    {   // what the fast path declined: deflation / eigen-solver (no-ops otherwise)
+        std::vector<int> all;
+        PinvBatch pb;
+        int max_c = 1;
+        for (size_t i = 0; i < p->types.size(); ++i) {
+            const TypeState& t = p->types[i];
+            all.push_back((int)i);
+            pb.gram[i] = (const double*)t.Gram.ptr; pb.K[i] = (double*)t.K.ptr; pb.c[i] = t.c; pb.n_pad[i] = t.n_pad;
+            if (t.c > max_c) max_c = t.c;
+        }
+        EighArgs e;
+        e.A = (double*)p->eigA.ptr; e.V = (double*)p->eigV.ptr; e.Vs = (double*)p->eigVs.ptr;
+        e.w = (double*)p->eigW.ptr; e.stride = p->eig_stride; e.wstride = p->eig_maxn;
+        e.n = (const int*)p->eigN.ptr; e.n_orig = (const int*)p->eigNorig.ptr;
+        e.chol_ok = (int*)p->eigOk.ptr;
+        e.max_sweeps = 30;
+        pinv_fallbacks(p, all, pb, e, true, max_c, st);
+    }
+    static DeviceOnce once;
+    constexpr int bb_lds = (2 * 64 + 2 * SM_BK) * SM_LD * 8;
+    allow_dynamic_lds(once, small_backbone_kernel, bb_lds);
+    hipLaunchKernelGGL(small_backbone_kernel, dim3((unsigned)p->rels.size()), dim3(256), bb_lds, st, tb);
+    check_launch("small_backbone");
+    hipLaunchKernelGGL((small_update_kernel<T>), dim3((unsigned)p->sm_j3.size()), dim3(256), 0, st, tb, (const SmJob*)p->sm_jobs3.ptr);
+    check_launch("small_update");
+    theta_terms(p, st);                       // sparse constraints: D += Theta+ G, E += Theta- G
+    // G <- G * sqrt(E / max(D, eps)) over the whole G region (E, D and G regions share their layout)
+    const int64_t total = (int64_t)(p->flat_bytes / p->esz);
+    char* base = (char*)p->ws_base;
+    hipLaunchKernelGGL((mult_update_kernel<T>), dim3(elem_grid(total)), dim3(256), 0, st, (T*)(base + p->flat_g_off),
+                       (const T*)(base + p->flat_e_off), (const T*)(base + p->flat_d_off), total, 1, (int64_t)1, (int64_t)1);
+    check_launch("mult_update");
+    p->first_iter = false;
+}
+
 static void iterate_fit(skf_plan* p, hipStream_t st) {
+    if (p->small_fused) {
+        if (p->f64) iterate_small_fused_t<double>(p, st);
+        else iterate_small_fused_t<float>(p, st);
+        return;
+    }
     if (can_pipeline(p)) {
         iterate_fit_pipelined(p, st);
         return;
@@ -2445,6 +2513,50 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             size_t blocks = (size_t)cdiv(nr, 32) * cdiv(tj.n, 32);           // smallest tile any engine uses
             if (blocks > sq_elems) sq_elems = blocks;
         }
+        // small graphs: every rank <= 64, sparse constraints only, a few thousand objects per type -> the fused schedule
+        {
+            bool ok = p->variant == SKF_DFMF && p->engine == SKF_ENGINE_MFMA && !p->bf16 && !p->sliced && n_types <= SM_MAXT &&
+                      n_relations >= 1 && n_relations <= SM_MAXR && n_thetas <= SM_MAXTH;
+            for (const TypeState& t : p->types) ok = ok && t.c <= SMALLC && t.n <= 65536;
+            for (const ThetaState& th : p->thetas) ok = ok && th.sparse;
+            for (const RelState& r : p->rels) ok = ok && !r.absent && !r.masked;
+            p->small_fused = ok;
+            if (ok) {
+                size_t wdoubles = 0, gdoubles = 0;
+                for (size_t k = 0; k < p->rels.size(); ++k) {
+                    RelState& r = p->rels[k];
+                    const TypeState& ti = p->types[r.row];
+                    const TypeState& tj = p->types[r.col];
+                    int part = 0;
+                    for (int64_t r0 = 0; r0 < ti.n; r0 += 64) p->sm_j1.push_back(SmJob{SMJ_P, (int)k, (int)r0, (int)std::min<int64_t>(64, ti.n - r0), part++, 0, 0, 0});
+                    // Q = R^T G_i: a long inner dimension (the rows of the relation) over a small output -> shares of 256 rows
+                    int qpart = 0;
+                    for (int64_t k0 = 0; k0 < ti.n; k0 += 256, ++qpart)
+                        for (int64_t c0 = 0; c0 < tj.n; c0 += 64)
+                            p->sm_j1.push_back(SmJob{SMJ_Q, (int)k, (int)c0, (int)std::min<int64_t>(64, tj.n - c0), qpart, (int)k0,
+                                                     (int)std::min<int64_t>(256, ti.n - k0), 0});
+                    r.sm_qparts = qpart;
+                    wdoubles += (size_t)part * ti.c * tj.c;
+                    add_slot(p, r.SmQ, (size_t)qpart * tj.n * ti.c * es);
+                    add_slot(p, r.SmBp, (size_t)ti.c * ti.c * 8);
+                    add_slot(p, r.SmBn, (size_t)ti.c * ti.c * 8);
+                    add_slot(p, r.SmDp, (size_t)tj.c * tj.c * 8);
+                    add_slot(p, r.SmDn, (size_t)tj.c * tj.c * 8);
+                }
+                for (size_t i = 0; i < p->types.size(); ++i) {
+                    const TypeState& t = p->types[i];
+                    int part = 0;
+                    for (int64_t r0 = 0; r0 < t.n; r0 += 256) p->sm_j1.push_back(SmJob{SMJ_GRAM, (int)i, (int)r0, (int)std::min<int64_t>(256, t.n - r0), part++, 0, 0, 0});
+                    gdoubles += (size_t)part * t.c * t.c;
+                    for (int64_t r0 = 0; r0 < t.n; r0 += 64) p->sm_j3.push_back(SmJob{0, (int)i, (int)r0, (int)std::min<int64_t>(64, t.n - r0), 0, 0, 0, 0});
+                }
+                add_slot(p, p->sm_tables, sizeof(SmTables));
+                add_slot(p, p->sm_jobs1, p->sm_j1.size() * sizeof(SmJob));
+                add_slot(p, p->sm_jobs3, p->sm_j3.size() * sizeof(SmJob));
+                add_slot(p, p->sm_wpart, wdoubles * 8);
+                add_slot(p, p->sm_gpart, gdoubles * 8);
+            }
+        }
         size_t theta_tmp_bytes = 0;
         for (ThetaState& th : p->thetas) {
             TypeState& t = p->types[th.type];
@@ -2736,6 +2848,43 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             SKF_HIP(hipMemcpyAsync(p->eigN.ptr, n_pad.data(), n_pad.size() * sizeof(int), hipMemcpyHostToDevice, st));
             SKF_HIP(hipMemcpyAsync(p->eigNorig.ptr, n_orig.data(), n_orig.size() * sizeof(int), hipMemcpyHostToDevice, st));
             SKF_HIP(hipStreamSynchronize(st));     // the host vectors die here; bind is not on the hot path
+        }
+        if (p->small_fused && (p->sw.no_small_fused || p->sw.no_small_chain)) p->small_fused = false;
+        if (p->small_fused) {
+            // job tables and the pointer table of the fused small-graph schedule (skf_small.h)
+            SmTables tb;
+            memset(&tb, 0, sizeof tb);
+            tb.n_types = (int)p->types.size(); tb.n_rels = (int)p->rels.size(); tb.n_thetas = (int)p->thetas.size();
+            tb.nan_upd = 1;                                   // DFMF: nan_to_num on the A / B / C / D terms (_dfmf.py:254-276)
+            tb.wpart = (double*)p->sm_wpart.ptr; tb.gpart = (double*)p->sm_gpart.ptr;
+            tb.eigA = (double*)p->eigA.ptr; tb.eigV = (double*)p->eigV.ptr; tb.eigOk = (int*)p->eigOk.ptr;
+            tb.eig_stride = p->eig_stride;
+            tb.chol_thr = chol_rel_threshold(p->sw);
+            int64_t goff = 0, woff = 0;
+            for (size_t i = 0; i < p->types.size(); ++i) {
+                TypeState& t = p->types[i];
+                SmType& d = tb.t[i];
+                d.G = t.G.ptr; d.E = t.E.ptr; d.D = t.D.ptr; d.Gram = (double*)t.Gram.ptr; d.K = (double*)t.K.ptr;
+                d.n = t.n; d.c = t.c; d.gpart_off = goff; d.n_gjobs = (int)((t.n + 255) / 256);
+                goff += (int64_t)d.n_gjobs * t.c * t.c;
+            }
+            for (size_t k = 0; k < p->rels.size(); ++k) {
+                RelState& r = p->rels[k];
+                SmRel& d = tb.r[k];
+                d.R = r.R; d.ldr = r.ldr; d.P = r.P.ptr; d.Q = r.SmQ.ptr; d.n_qparts = r.sm_qparts; d.W = (double*)r.W.ptr; d.S = (double*)r.S.ptr;
+                d.Bp = (double*)r.SmBp.ptr; d.Bn = (double*)r.SmBn.ptr; d.Dp = (double*)r.SmDp.ptr; d.Dn = (double*)r.SmDn.ptr;
+                d.row = r.row; d.col = r.col; d.wpart_off = woff; d.n_pjobs = (int)((p->types[r.row].n + 63) / 64);
+                woff += (int64_t)d.n_pjobs * p->types[r.row].c * p->types[r.col].c;
+            }
+            for (size_t k = 0; k < p->thetas.size(); ++k) {
+                ThetaState& th = p->thetas[k];
+                tb.th[k].rp = (const int64_t*)th.Rp.ptr; tb.th[k].ci = (const int*)th.Ci.ptr; tb.th[k].vv = th.Vv.ptr;
+                tb.th[k].type = th.type;
+            }
+            SKF_HIP(hipMemcpyAsync(p->sm_tables.ptr, &tb, sizeof tb, hipMemcpyHostToDevice, st));
+            SKF_HIP(hipMemcpyAsync(p->sm_jobs1.ptr, p->sm_j1.data(), p->sm_j1.size() * sizeof(SmJob), hipMemcpyHostToDevice, st));
+            SKF_HIP(hipMemcpyAsync(p->sm_jobs3.ptr, p->sm_j3.data(), p->sm_j3.size() * sizeof(SmJob), hipMemcpyHostToDevice, st));
+            SKF_HIP(hipStreamSynchronize(st));     // (`tb` dies here; bind is not on the hot path)
         }
         p->pipeline = !p->sw.no_pipeline;
         if (p->variant != SKF_TRANSFORM && !p->aux) {
@@ -3097,6 +3246,16 @@ int skf_get_contraction(const skf_plan* p, int32_t rel, int32_t which, void* dst
         if (which == 2 && !r.kn) SKF_FAIL(SKF_E_STATE, "relation %d forms P, not P S^T (which = 2 is for known-entries relations)", rel);
         const Slot& src = which == 0 ? r.P : which == 1 ? r.Q : r.A;
         const int64_t rows = which == 1 ? tj.n : r.nr, cols = which == 0 ? tj.c : ti.c;
+        if (p->small_fused && which == 1 && r.Q.ptr) {       // the fused small-graph schedule keeps Q as shares: sum them first
+            const int64_t total = rows * cols;
+            if (p->f64)
+                hipLaunchKernelGGL((sum_parts_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, as_stream(stream), (double*)r.Q.ptr,
+                                   (const double*)r.SmQ.ptr, total, r.sm_qparts, total);
+            else
+                hipLaunchKernelGGL((sum_parts_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, as_stream(stream), (float*)r.Q.ptr,
+                                   (const float*)r.SmQ.ptr, total, r.sm_qparts, total);
+            check_launch("sum_parts");
+        }
         if (!src.ptr || rows <= 0) SKF_FAIL(SKF_E_STATE, "relation %d keeps no %s here", rel, which == 0 ? "P" : "Q");
         if (ld < cols) SKF_FAIL(SKF_E_INVALID, "ld too small");
         copy2d(dst, ld, src.ptr, cols, rows, cols, p->esz, as_stream(stream));

@@ -1980,11 +1980,28 @@ __global__ __launch_bounds__(256) void theta_spmm_kernel(const int64_t* __restri
         for (int j0 = 0; j0 < c; j0 += 64) {
             const int j = j0 + lane;
             T e = (T)0, d = (T)0;
-            for (int64_t q = a; q < b; ++q) {
-                const T v = vals[q];
-                const T g = j < c ? G[(int64_t)cols[q] * c + j] : (T)0;
-                if (v > (T)0) d += v * g;
-                else e -= v * g;
+            // the row's entries 64 at a time: one coalesced load of columns / values (lane z holds entry z), then the
+            // gathers of the batch are independent of each other and of those loads (a chain of two dependent loads per
+            // entry before: the longest row -- a hub of dicty's ppi -- set the kernel time)
+            for (int64_t q0 = a; q0 < b; q0 += 64) {
+                const int nb = (int)(b - q0 < 64 ? b - q0 : 64);
+                const int my_c = lane < nb ? cols[q0 + lane] : 0;
+                const T my_v = lane < nb ? vals[q0 + lane] : (T)0;
+                for (int z0 = 0; z0 < nb; z0 += 8) {                     // eight gathers in flight, consumed in list order
+                    T g[8], v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int z = z0 + u < nb ? z0 + u : nb - 1;
+                        v[u] = z0 + u < nb ? __shfl(my_v, z, 64) : (T)0;
+                        const int cz = __shfl(my_c, z, 64);
+                        g[u] = j < c ? G[(int64_t)cz * c + j] : (T)0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (v[u] > (T)0) d += v[u] * g[u];
+                        else e -= v[u] * g[u];
+                    }
+                }
             }
             if (j < c) {
                 E[r * c + j] += e;

@@ -1,0 +1,421 @@
+// skf_small.h -- the DFMF iteration of a SMALL graph (every rank <= 64, a few thousand objects per type: the reference's
+// own examples, BASELINE configs[0] / [1]) in eight launches instead of ~33.
+//
+// On such graphs an iteration is a chain of dependent launches of a few microseconds each -- launch latency, not
+// arithmetic (dicty: 0.29 ms for 80 MFLOP, a third of it the one-wave Cholesky inverse).  Here the chain is
+//   1 small_contract_kernel   every P = R G_j row block, every Q = R^T G_i row block, every G^T G row block (jobs); the
+//                             P jobs also leave their share of W = G_i^T P                       (_dfmf.py:228-231, 254, 266)
+//   2 small_pinv_kernel       ONE workgroup: sums of the Gram / W shares, Cholesky inverse of every Gram matrix -- one
+//                             WAVE per matrix, its row in REGISTERS (v_readlane broadcasts, no LDS round trips) --,
+//                             K = X^T X, verdicts + packed copies for the fall-backs                       (:232)
+//   3-5 pchol_pinv / jacobi_eigh / eigh_unpack_pinv (the existing kernels: no-ops unless a verdict says otherwise)
+//   6 small_backbone_kernel   one workgroup per relation: S = K_i W K_j and the +- parts of S Gram_j S^T, S^T Gram_i S
+//                                                                                                 (:236-239, 260-276)
+//   7 small_update_kernel     per (type, 64 rows): the relation terms of E and D -- row sides, column sides, type term --
+//                             accumulated in registers and written once; then theta_spmm_kernel per sparse constraint
+//                                                                                                 (:254-292)
+//   8 mult_update_kernel      over the G region                                                  (:294-296)
+// Same arithmetic as the general schedule (f64 c x c algebra, master-type n-sized products, nan_to_num where the
+// reference has it); only the order of the sums differs.
+#pragma once
+#include "skf_kernels.h"
+
+namespace skf {
+
+constexpr int SM_MAXT = 16, SM_MAXR = 24, SM_MAXTH = 16;
+struct SmType {
+    void* G; void* E; void* D;
+    double* Gram; double* K;
+    int64_t n, gpart_off;        // offset (doubles) of this type's Gram shares in SmTables.gpart
+    int c, n_gjobs;
+};
+struct SmRel {
+    const void* R; int64_t ldr;
+    void* P; void* Q;
+    double* W; double* S; double* Bp; double* Bn; double* Dp; double* Dn;     // +- parts of S Gram_j S^T (row type) / S^T Gram_i S (column type)
+    int64_t wpart_off;           // offset (doubles) of this relation's W shares in SmTables.wpart
+    int row, col, n_pjobs, n_qparts;      // Q arrives as n_qparts shares (row ranges of the relation), summed where it is read
+};
+struct SmTheta {
+    const int64_t* rp; const int* ci; const void* vv;
+    int type, pad;
+};
+struct SmTables {
+    int n_types, n_rels, n_thetas, nan_upd;
+    double* wpart; double* gpart;
+    double* eigA; double* eigV; int* eigOk; int64_t eig_stride;
+    double chol_thr;
+    SmType t[SM_MAXT];
+    SmRel r[SM_MAXR];
+    SmTheta th[SM_MAXTH];
+};
+enum { SMJ_P = 0, SMJ_Q = 1, SMJ_GRAM = 2 };          // jobs of 64 rows each
+struct SmJob { int kind, idx, r0, nr, part, k0, nk, pad; };      // Q jobs: rows [k0, k0 + nk) of the relation, share `part`
+
+// ---- matrix-core tile of a workgroup ---------------------------------------------------------------------------------
+// 64 x 64 outputs per workgroup of 4 waves (2 x 2), K in tiles of 32 staged k-major in LDS (pitch 65); operands come
+// from callables at(row, k) / at(k, col) that return 0 outside their matrix.  T = float: one v_mfma_f32_32x32x2_f32 tile
+// per wave; T = double: 2 x 2 v_mfma_f64_16x16x4_f64 tiles per wave.
+constexpr int SM_BK = 32, SM_LD = 65;
+template <typename T>
+struct SmTile {
+    typedef Mfma<T> MF;
+    static constexpr int WR = 32 / MF::MT, WC = 32 / MF::NT;
+    static constexpr int PER = 64 * SM_BK / 256;                 // elements of a K tile a thread stages, per operand
+    typename MF::acc_t acc[WR][WC];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+#pragma unroll
+            for (int j = 0; j < WC; ++j)
+#pragma unroll
+                for (int r = 0; r < MF::NREG; ++r) acc[i][j][r] = (T)0;
+    }
+    // acc += A * B over K: a_at(m, k), b_at(k, n); a_kfast: consecutive threads walk k (A rows contiguous in k), else m.
+    // The operands of K tile t + 1 are fetched into registers before tile t goes through the matrix cores: the K loops of
+    // a small graph are a handful of tiles, each one a full memory round trip if fetched on demand.
+    template <class FA, class FB>
+    __device__ __forceinline__ void mma(int K, FA a_at, FB b_at, bool a_kfast, T* As, T* Bs) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+        T ra[PER], rb[PER];
+        auto fetch = [&](int k0) {
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int e = tid + 256 * q;
+                const int m = a_kfast ? e / SM_BK : e % 64, kk = a_kfast ? e % SM_BK : e / 64;
+                ra[q] = (k0 + kk < K) ? a_at(m, k0 + kk) : (T)0;
+                const int kb = e / 64, n = e % 64;
+                rb[q] = (k0 + kb < K) ? b_at(k0 + kb, n) : (T)0;
+            }
+        };
+        if (K > 0) fetch(0);
+        for (int k0 = 0; k0 < K; k0 += SM_BK) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int e = tid + 256 * q;
+                const int m = a_kfast ? e / SM_BK : e % 64, kk = a_kfast ? e % SM_BK : e / 64;
+                As[kk * SM_LD + m] = ra[q];
+                Bs[(e / 64) * SM_LD + e % 64] = rb[q];
+            }
+            __syncthreads();
+            if (k0 + SM_BK < K) fetch(k0 + SM_BK);
+#pragma unroll
+            for (int kk = 0; kk < SM_BK; kk += MF::KT) {
+                T av[WR], bv[WC];
+                const int kr = kk + MF::ab_k(lane);
+#pragma unroll
+                for (int i = 0; i < WR; ++i) av[i] = As[kr * SM_LD + wm0 + i * MF::MT + MF::a_row(lane)];
+#pragma unroll
+                for (int j = 0; j < WC; ++j) bv[j] = Bs[kr * SM_LD + wn0 + j * MF::NT + MF::a_row(lane)];
+#pragma unroll
+                for (int i = 0; i < WR; ++i)
+#pragma unroll
+                    for (int j = 0; j < WC; ++j) acc[i][j] = MF::mma(av[i], bv[j], acc[i][j]);
+            }
+        }
+    }
+    // f(row, col, value) for every accumulator element of this lane
+    template <class F>
+    __device__ __forceinline__ void for_each(F f) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+#pragma unroll
+            for (int j = 0; j < WC; ++j)
+#pragma unroll
+                for (int r = 0; r < MF::NREG; ++r)
+                    {
+                    const T val = acc[i][j][r];
+                    f(wm0 + i * MF::MT + MF::d_row(lane, r), wn0 + j * MF::NT + MF::d_col(lane), val);
+                }
+    }
+};
+
+// ---- 1 ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* __restrict__ tb, const SmJob* __restrict__ jobs) {
+    __shared__ double As[SM_BK * SM_LD];
+    __shared__ double Bs[SM_BK * SM_LD];
+    const SmJob jb = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (jb.kind == SMJ_GRAM) {           // share of G^T G from rows r0 .., f64 accumulation
+        const SmType& t = tb->t[jb.idx];
+        const T* G = (const T*)t.G;
+        const int c = t.c;
+        SmTile<double> w;
+        w.zero();
+        auto g_at = [&](int a, int k) -> double { return (a < c && k < jb.nr) ? (double)G[(int64_t)(jb.r0 + k) * c + a] : 0.0; };
+        w.mma(jb.nr, g_at, [&](int k, int b) { return g_at(b, k); }, false, As, Bs);
+        double* out = tb->gpart + t.gpart_off + (int64_t)jb.part * c * c;
+        w.for_each([&](int a, int b, double v) { if (a < c && b < c) out[a * c + b] = v; });
+        return;
+    }
+    const SmRel& r = tb->r[jb.idx];
+    const SmType& ti = tb->t[r.row];
+    const SmType& tj = tb->t[r.col];
+    const T* R = (const T*)r.R;
+    const int ci = ti.c, cj = tj.c;
+    SmTile<T> acc;
+    acc.zero();
+    if (jb.kind == SMJ_P) {              // P[r0 + m][:] = sum_k R[r0 + m][k] G_j[k][:]
+        const T* Gj = (const T*)tj.G;
+        const T* Gi = (const T*)ti.G;
+        const int nj = (int)tj.n;
+        acc.mma(nj, [&](int m, int k) { return m < jb.nr ? R[(int64_t)(jb.r0 + m) * r.ldr + k] : (T)0; },
+                [&](int k, int n) { return n < cj ? Gj[(int64_t)k * cj + n] : (T)0; }, true, (T*)As, (T*)Bs);
+        T* P = (T*)r.P;
+        acc.for_each([&](int m, int n, T v) { if (m < jb.nr && n < cj) P[(int64_t)(jb.r0 + m) * cj + n] = v; });
+        __syncthreads();                 // (the rows of P this workgroup just wrote are read back below)
+        // share of W = G_i^T P from these rows, f64 accumulation (as the general schedule's G^T P product)
+        SmTile<double> w;
+        w.zero();
+        w.mma(jb.nr, [&](int a, int k) -> double { return a < ci ? (double)Gi[(int64_t)(jb.r0 + k) * ci + a] : 0.0; },
+              [&](int k, int b) -> double { return b < cj ? (double)P[(int64_t)(jb.r0 + k) * cj + b] : 0.0; }, false, As, Bs);
+        double* out = tb->wpart + r.wpart_off + (int64_t)jb.part * ci * cj;
+        w.for_each([&](int a, int b, double v) { if (a < ci && b < cj) out[a * cj + b] = v; });
+    } else {                             // share `part` of Q[c0 + m][:] = sum over the rows k0 .. k0 + nk of R[k][c0 + m] G_i[k][:]
+        const T* Gi = (const T*)ti.G;
+        acc.mma(jb.nk, [&](int m, int k) { return m < jb.nr ? R[(int64_t)(jb.k0 + k) * r.ldr + jb.r0 + m] : (T)0; },
+                [&](int k, int n) { return n < ci ? Gi[(int64_t)(jb.k0 + k) * ci + n] : (T)0; }, false, (T*)As, (T*)Bs);
+        T* Q = (T*)r.Q + (int64_t)jb.part * tj.n * ci;       // r.Q: [n_qparts][n_j][c_i]
+        acc.for_each([&](int m, int n, T v) { if (m < jb.nr && n < ci) Q[(int64_t)(jb.r0 + m) * ci + n] = v; });
+    }
+}
+
+// ---- 2 ------------------------------------------------------------------------------------------------------------
+// p[0] + p[stride] + ... (count terms) in a fixed order, four independent chains so that the loads overlap
+__device__ __forceinline__ double sum_shares(const double* __restrict__ p, int64_t stride, int count) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int q = 0;
+    for (; q + 3 < count; q += 4) {
+        s0 += p[(int64_t)q * stride];
+        s1 += p[(int64_t)(q + 1) * stride];
+        s2 += p[(int64_t)(q + 2) * stride];
+        s3 += p[(int64_t)(q + 3) * stride];
+    }
+    for (; q < count; ++q) s0 += p[(int64_t)q * stride];
+    return (s0 + s1) + (s2 + s3);
+}
+
+// One workgroup per object type: Gram = nan_to_num(sum of its shares) (_dfmf.py:229), a packed copy for the fall-back
+// kernels, and K = Gram^-1 by the sweep operator in LDS -- n steps of a rank-one update of the whole matrix by all 256
+// threads (two barriers each), instead of a one-wave Cholesky whose every inner product is a chain of LDS round trips
+// (91 us at order 50).  The pivot of step k is the Schur complement the Cholesky factorisation would take the root of:
+// same verdict, same thresholds as chol_inverse_small_kernel; a failed pivot leaves the matrix to pchol_pinv /
+// jacobi_eigh.  One more workgroup per relation sums the shares of its W.
+constexpr int SM_PINV_THREADS = 1024;      // 64 x 64 / 1024 = 4 matrix elements per thread and sweep step
+__global__ __launch_bounds__(SM_PINV_THREADS) void small_pinv_kernel(const SmTables* __restrict__ tb) {
+    __shared__ double M[64 * SM_LD];
+    __shared__ double piv_col[64];
+    __shared__ double diag0[64];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x, t = blockIdx.x;
+    if (t >= tb->n_types) {              // workgroups behind the types: W of one relation = the sum of its shares
+        const SmRel& r = tb->r[t - tb->n_types];
+        const int cc = tb->t[r.row].c * tb->t[r.col].c;
+        const double* part = tb->wpart + r.wpart_off;
+        for (int e = tid; e < cc; e += SM_PINV_THREADS) r.W[e] = sum_shares(part + e, cc, r.n_pjobs);
+        return;
+    }
+    const SmType& ty = tb->t[t];
+    const int n = ty.c, n_pad = (n + 1) / 2 * 2;
+    double* A = tb->eigA + (int64_t)t * tb->eig_stride;
+    for (int e = tid; e < n_pad * n_pad; e += SM_PINV_THREADS) A[e] = 0.0;
+    __syncthreads();
+    {
+        const double* part = tb->gpart + ty.gpart_off;
+        for (int e = tid; e < n * n; e += SM_PINV_THREADS) {
+            const double s = nan_to_num(sum_shares(part + e, n * n, ty.n_gjobs));
+            ty.Gram[e] = s;
+            A[(e / n) * n_pad + e % n] = s;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += SM_PINV_THREADS) {
+        const int i = e / n, j = e % n;
+        M[i * SM_LD + j] = 0.5 * (ty.Gram[i * n + j] + ty.Gram[j * n + i]);
+    }
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    if (tid < n) diag0[tid] = M[tid * SM_LD + tid];
+    __syncthreads();
+    double mx = 0.0;
+    for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(diag0[i]));
+    const double floor_ = chol_diag_floor(n) * mx;
+    // the (at most PER) elements this thread updates in every step: row / column / LDS slot once, not per step; the spare
+    // slots point at an unused pad word, so that the update below is PER independent, branch-free read-modify-writes
+    constexpr int PER = 64 * 64 / SM_PINV_THREADS;
+    int ei[PER], ej[PER], es[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int e = tid + SM_PINV_THREADS * q;
+        const bool ok = e < n * n;
+        ei[q] = ok ? e / n : 0;
+        ej[q] = ok ? e % n : 0;
+        es[q] = ok ? ei[q] * SM_LD + ej[q] : 64 * SM_LD - 1;
+    }
+    for (int k = 0; k < n; ++k) {
+        const double piv = M[k * SM_LD + k], akk = diag0[k];
+        if (!(akk > floor_) || !(piv > tb->chol_thr * akk) || !(piv > 0.0)) {      // (uniform: every thread reads the same words)
+            if (tid == 0) s_ok = 0;
+            break;
+        }
+        if (tid < n) piv_col[tid] = M[tid * SM_LD + k];          // column k (= row k: the matrix stays symmetric)
+        __syncthreads();
+        const double d = 1.0 / piv;
+        double nv[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = ei[q], j = ej[q];
+            const double ci_ = piv_col[i], cj_ = piv_col[j], old = M[es[q]];
+            const double off = (i == k) ? cj_ * d : ci_ * d;              // row k / column k of the swept matrix
+            const double gen = old - ci_ * cj_ * d;
+            nv[q] = (i == k && j == k) ? -d : ((i == k || j == k) ? off : gen);
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) M[es[q]] = nv[q];
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_ok) {                                                    // all pivots swept: M = -Gram^-1
+        for (int e = tid; e < n * n; e += SM_PINV_THREADS) ty.K[e] = -M[(e / n) * SM_LD + e % n];
+    }
+    if (tid == 0) tb->eigOk[t] = s_ok;
+}
+
+// ---- 6 ------------------------------------------------------------------------------------------------------------
+// one workgroup per relation: six c x c x c products on the f64 matrix cores, operands and intermediates in LDS
+// (dynamic LDS: 3 x 64 x 65 doubles + the two staging tiles of SmTile)
+__global__ __launch_bounds__(256) void small_backbone_kernel(const SmTables* __restrict__ tb) {
+    HIP_DYNAMIC_SHARED(double, sm)
+    const SmRel& r = tb->r[blockIdx.x];
+    const SmType& ti = tb->t[r.row];
+    const SmType& tj = tb->t[r.col];
+    const int ci = ti.c, cj = tj.c, tid = threadIdx.x;
+    double* X = sm;                       // T1 = K_i W, then U
+    double* S = X + 64 * SM_LD;           // S
+    double* As = S + 64 * SM_LD;
+    double* Bs = As + SM_BK * SM_LD;
+    SmTile<double> t;
+    // T1 = K_i W
+    t.zero();
+    t.mma(ci, [&](int a, int k) { return a < ci ? ti.K[a * ci + k] : 0.0; }, [&](int k, int b) { return b < cj ? r.W[k * cj + b] : 0.0; },
+          true, As, Bs);
+    t.for_each([&](int a, int b, double v) { X[a * SM_LD + b] = v; });
+    __syncthreads();                      // (the next product fetches its first operands before its own first barrier)
+    // S = nan_to_num(T1 K_j)                                                                          (_dfmf.py:236-239)
+    t.zero();
+    t.mma(cj, [&](int a, int k) { return X[a * SM_LD + k]; }, [&](int k, int b) { return b < cj ? tj.K[k * cj + b] : 0.0; }, true, As, Bs);
+    t.for_each([&](int a, int b, double v) {
+        v = nan_to_num(v);
+        S[a * SM_LD + b] = (a < ci && b < cj) ? v : 0.0;
+        if (a < ci && b < cj) r.S[a * cj + b] = v;
+    });
+    __syncthreads();
+    // U = S Gram_j ; B = U S^T, split                                                                 (_dfmf.py:260-264)
+    t.zero();
+    t.mma(cj, [&](int a, int k) { return S[a * SM_LD + k]; }, [&](int k, int b) { return b < cj ? tj.Gram[k * cj + b] : 0.0; }, true, As, Bs);
+    t.for_each([&](int a, int b, double v) { X[a * SM_LD + b] = v; });
+    __syncthreads();
+    t.zero();
+    t.mma(cj, [&](int a, int k) { return X[a * SM_LD + k]; }, [&](int k, int c2) { return S[c2 * SM_LD + k]; }, true, As, Bs);
+    __syncthreads();                      // (every wave is done reading X)
+    t.for_each([&](int a, int c2, double v) {
+        if (a < ci && c2 < ci) {
+            if (tb->nan_upd) v = nan_to_num(v);
+            r.Bp[a * ci + c2] = v > 0.0 ? v : 0.0;
+            r.Bn[a * ci + c2] = v > 0.0 ? 0.0 : -v;
+        }
+    });
+    // U = Gram_i S ; D = S^T U, split                                                                 (_dfmf.py:272-276)
+    t.zero();
+    t.mma(ci, [&](int a, int k) { return a < ci ? ti.Gram[a * ci + k] : 0.0; }, [&](int k, int b) { return S[k * SM_LD + b]; }, true, As, Bs);
+    t.for_each([&](int a, int b, double v) { X[a * SM_LD + b] = v; });
+    __syncthreads();
+    t.zero();
+    t.mma(ci, [&](int a, int k) { return S[k * SM_LD + a]; }, [&](int k, int c2) { return X[k * SM_LD + c2]; }, false, As, Bs);
+    t.for_each([&](int a, int c2, double v) {
+        if (a < cj && c2 < cj) {
+            if (tb->nan_upd) v = nan_to_num(v);
+            r.Dp[a * cj + c2] = v > 0.0 ? v : 0.0;
+            r.Dn[a * cj + c2] = v > 0.0 ? 0.0 : -v;
+        }
+    });
+}
+
+// ---- 7 ------------------------------------------------------------------------------------------------------------
+// job = (type jb.idx, rows r0 .. r0 + nr <= 64): every term of E and D of those rows on the matrix cores, the +- split of a
+// relation side in registers (nan_to_num first, as the reference has it), the type term accumulated straight into E / D
+template <typename T>
+__global__ __launch_bounds__(256) void small_update_kernel(const SmTables* __restrict__ tb, const SmJob* __restrict__ jobs) {
+    __shared__ T As[SM_BK * SM_LD];
+    __shared__ T Bs[SM_BK * SM_LD];
+    const SmJob jb = jobs[blockIdx.x];
+    const SmType& ty = tb->t[jb.idx];
+    const int c = ty.c, tid = threadIdx.x;
+    SmTile<T> e, d, v;
+    e.zero();
+    d.zero();
+    auto split_add = [&]() {
+#pragma unroll
+        for (int i = 0; i < SmTile<T>::WR; ++i)
+#pragma unroll
+            for (int j = 0; j < SmTile<T>::WC; ++j)
+#pragma unroll
+                for (int q = 0; q < Mfma<T>::NREG; ++q) {
+                    T x = v.acc[i][j][q];
+                    if (tb->nan_upd) x = nan_to_num(x);
+                    e.acc[i][j][q] += x > (T)0 ? x : (T)0;
+                    d.acc[i][j][q] += x > (T)0 ? (T)0 : -x;
+                }
+    };
+    for (int k = 0; k < tb->n_rels; ++k) {
+        const SmRel& r = tb->r[k];
+        const int ci = tb->t[r.row].c, cj = tb->t[r.col].c;
+        if (r.row == jb.idx) {                     // (P S^T)+-                                      (_dfmf.py:254-258)
+            const T* P = (const T*)r.P;
+            v.zero();
+            v.mma(cj, [&](int m, int b) { return m < jb.nr ? P[(int64_t)(jb.r0 + m) * cj + b] : (T)0; },
+                  [&](int b, int a) { return a < ci ? (T)r.S[a * cj + b] : (T)0; }, true, As, Bs);
+            split_add();
+        }
+        if (r.col == jb.idx) {                     // (Q S)+-                                        (_dfmf.py:266-270)
+            const T* Q = (const T*)r.Q;
+            const int64_t qs = tb->t[r.col].n * ci;       // Q arrives as n_qparts shares
+            v.zero();
+            v.mma(ci, [&](int m, int a) {
+                      T x = (T)0;
+                      if (m < jb.nr)
+                          for (int z = 0; z < r.n_qparts; ++z) x += Q[z * qs + (int64_t)(jb.r0 + m) * ci + a];
+                      return x;
+                  },
+                  [&](int a, int b) { return b < cj ? (T)r.S[a * cj + b] : (T)0; }, true, As, Bs);
+            split_add();
+        }
+    }
+    // type term: E += G sum B-, D += G sum B+ (sums over the relations of the type, rounded to T once; _dfmf.py:278-282)
+    const T* G = (const T*)ty.G;
+    auto g_at = [&](int m, int k) { return m < jb.nr ? G[(int64_t)(jb.r0 + m) * c + k] : (T)0; };
+    auto bsum = [&](int k, int a, bool neg) -> T {
+        if (a >= c) return (T)0;
+        double s = 0.0;
+        for (int q = 0; q < tb->n_rels; ++q) {
+            const SmRel& r = tb->r[q];
+            if (r.row == jb.idx) s += (neg ? r.Bn : r.Bp)[k * c + a];
+            if (r.col == jb.idx) s += (neg ? r.Dn : r.Dp)[k * c + a];
+        }
+        return (T)s;
+    };
+    e.mma(c, g_at, [&](int k, int a) { return bsum(k, a, true); }, true, As, Bs);
+    d.mma(c, g_at, [&](int k, int a) { return bsum(k, a, false); }, true, As, Bs);
+    T* E = (T*)ty.E;
+    T* D = (T*)ty.D;
+    e.for_each([&](int m, int a, T x) { if (m < jb.nr && a < c) E[(int64_t)(jb.r0 + m) * c + a] = x; });
+    d.for_each([&](int m, int a, T x) { if (m < jb.nr && a < c) D[(int64_t)(jb.r0 + m) * c + a] = x; });
+    // (the sparse constraints follow as theta_spmm_kernel launches: one wave per row over the whole type)
+}
+
+}  // namespace skf

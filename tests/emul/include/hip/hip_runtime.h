@@ -317,6 +317,7 @@ inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __builtin_amdgcn_readlane(int v, int lane) { return simt::wave_read(v, lane); }     // v_readlane_b32
 // DPP lane exchanges used by the kernels: quad_perm (ctrl < 0x100), row_mirror (0x140), row_half_mirror (0x141),
 // row_newbcast:k (0x150 + k)
 inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {

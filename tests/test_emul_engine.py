@@ -18,11 +18,14 @@ def emul():
         yield rt
 
 
-@pytest.mark.parametrize('small_chain', ['on', 'off'])
+@pytest.mark.parametrize('small_chain', ['fused', 'on', 'off'])
 @pytest.mark.parametrize('engine', [nat.SKF_ENGINE_MFMA, nat.SKF_ENGINE_VALU])
 def test_c1_readme_f64_matches_reference_golden(engine, small_chain, monkeypatch):
     """(small_chain off: the c x c algebra through the generic GEMM launches and the blocked Cholesky
-    inverse, as for ranks above 64; on: the one-workgroup kernels for small ranks.)"""
+    inverse, as for ranks above 64; on: the one-workgroup kernels for small ranks on the staged
+    schedule; fused: the job-table schedule for small graphs, skf_small.h.)"""
+    if small_chain == 'on':
+        monkeypatch.setenv('SKF_NO_SMALL_FUSED', '1')
     if small_chain == 'off':
         monkeypatch.setenv('SKF_NO_SMALL_CHAIN', '1')
         monkeypatch.setenv('SKF_CHOL_NO_SMALL', '1')
@@ -71,7 +74,10 @@ def test_seeded_initialisers_match_reference_stream():
                    random_state=np.random.RandomState(0))
 
 
-def test_probe_graph_dfmf_theta_multirelation_negative_values():
+@pytest.mark.parametrize('schedule', ['fused', 'staged'])
+def test_probe_graph_dfmf_theta_multirelation_negative_values(schedule, monkeypatch):
+    if schedule == 'staged':
+        monkeypatch.setenv('SKF_NO_SMALL_FUSED', '1')
     z = golden('probe_multirel.npz')
     R, Theta, M, types, rank = probe_graph(z)
     snaps = Snapshots((0, 1, 9, 29))

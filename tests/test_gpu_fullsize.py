@@ -213,11 +213,11 @@ def test_config5_full_size_completion_and_contractions_against_host_rows(form):
         Tb, Gub = bf16(Gm64 @ S.T), bf16(Gu)
         E_rows = np.where(U_rows, 0.0, R_rows - Gub[rows] @ Tb.T)
         A_host = Gu64[rows] @ (S @ (Gm64.T @ Gm64) @ S.T) + E_rows @ Tb
-        # measured (MI355X, round 3): 2.1e-7 / 4.6e-7
-        within(relerr(P[rows], A_host), 1.2e-6, 'config 5 full size, known-entry lists: rows of P S^T vs host')
+        # measured (MI355X, round 3): 3.5e-7 / 1.9e-7
+        within(relerr(P[rows], A_host), 1.7e-6, 'config 5 full size, known-entry lists: rows of P S^T vs host')
         E_cols = np.where(U_cols, 0.0, R_cols - Gub @ Tb[cols].T)
         Q_host = Gm64[cols] @ (S.T @ (Gu64.T @ Gu64)) + E_cols.T @ Gub
-        within(relerr(Q[cols], Q_host), 2.5e-6, 'config 5 full size, known-entry lists: rows of Q vs host')
+        within(relerr(Q[cols], Q_host), 1e-6, 'config 5 full size, known-entry lists: rows of Q vs host')
         # and the known entries weigh in: the c x c parts alone are far off
         assert relerr(Q[cols], Gm64[cols] @ (S.T @ (Gu64.T @ Gu64))) > 1e-3
         return

@@ -346,8 +346,13 @@ def test_transform_fold_in(init):
     within(relerr(Gib, z['%s/G_it99' % init]), 1e-2, 'fold-in bf16 %s: G after 100 iterations vs golden' % init)   # measured 2.1e-3 (f32: 2.0e-6)
 
 
-def test_c2_dicty_dfmf_100_iterations_f64_and_f32():
-    """BASELINE config 2: dicty (2 relations + the ppi constraint), ranks 50/15/5."""
+@pytest.mark.parametrize('schedule', ['fused', 'staged'])
+def test_c2_dicty_dfmf_100_iterations_f64_and_f32(schedule, monkeypatch):
+    """BASELINE config 2: dicty (2 relations + the ppi constraint), ranks 50/15/5.  fused: the
+    job-table schedule for small graphs (skf_small.h, 9 launches per iteration); staged: the
+    general schedule (SKF_NO_SMALL_FUSED=1)."""
+    if schedule == 'staged':
+        monkeypatch.setenv('SKF_NO_SMALL_FUSED', '1')
     z = golden('c2_dicty.npz')
     R, Theta, types, rank = dicty_graph()
     G0 = g0_from(z, 'dfmf/', types)
