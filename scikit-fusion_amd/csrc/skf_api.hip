@@ -573,7 +573,7 @@ struct skf_plan {
     bool kn_first = true;                  // no residuals stored yet: E = the known entries themselves, S_prev = 0
     // small graphs (skf_small.h): the whole DFMF iteration as eight launches over job tables kept in the workspace
     bool small_fused = false;
-    skf::Slot sm_tables, sm_jobs1, sm_jobs3, sm_wpart, sm_gpart;
+    skf::Slot sm_tables, sm_jobs1, sm_jobs3, sm_wpart, sm_gpart, sm_tickets;
     std::vector<skf::SmJob> sm_j1, sm_j3;
     ~skf_plan() {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -1971,46 +1971,34 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
     apply_update(p, st);
 }
 
-// The DFMF iteration of a small graph in eight launches (skf_small.h)
+// The DFMF iteration of a small graph in four launches (skf_small.h)
 template <typename T>
 static void iterate_small_fused_t(skf_plan* p, hipStream_t st) {
     const SmTables* tb = (const SmTables*)p->sm_tables.ptr;
-    hipLaunchKernelGGL((small_contract_kernel<T>), dim3((unsigned)p->sm_j1.size()), dim3(256), 0, st, tb, (const SmJob*)p->sm_jobs1.ptr);
+    static DeviceOnce once_c, once_u;
+    allow_dynamic_lds(once_c, small_contract_kernel<T>, SM_TILE_BYTES);
+    allow_dynamic_lds(once_u, small_update_kernel<T>, SM_TILE_BYTES);
+    hipLaunchKernelGGL((small_contract_kernel<T>), dim3((unsigned)p->sm_j1.size()), dim3(256), SM_TILE_BYTES, st, tb, (const SmJob*)p->sm_jobs1.ptr);
     check_launch("small_contract");
-    hipLaunchKernelGGL(small_pinv_kernel, dim3((unsigned)(p->types.size() + p->rels.size())), dim3(SM_PINV_THREADS), 0, st, tb);
-    check_launch("small_pinv");
-    {   // what the fast path declined: deflation / eigen-solver (no-ops otherwise)
-        std::vector<int> all;
-        PinvBatch pb;
-        int max_c = 1;
-        for (size_t i = 0; i < p->types.size(); ++i) {
-            const TypeState& t = p->types[i];
-            all.push_back((int)i);
-            pb.gram[i] = (const double*)t.Gram.ptr; pb.K[i] = (double*)t.K.ptr; pb.c[i] = t.c; pb.n_pad[i] = t.n_pad;
-            if (t.c > max_c) max_c = t.c;
-        }
+    {   // what the sweep declined: deflation / eigen-solver / K = Vs V^T in one launch (a no-op otherwise)
         EighArgs e;
         e.A = (double*)p->eigA.ptr; e.V = (double*)p->eigV.ptr; e.Vs = (double*)p->eigVs.ptr;
         e.w = (double*)p->eigW.ptr; e.stride = p->eig_stride; e.wstride = p->eig_maxn;
         e.n = (const int*)p->eigN.ptr; e.n_orig = (const int*)p->eigNorig.ptr;
         e.chol_ok = (int*)p->eigOk.ptr;
         e.max_sweeps = 30;
-        pinv_fallbacks(p, all, pb, e, true, max_c, st);
+        const int lr = p->eig_maxn < PCHOL_LDS_R ? p->eig_maxn : PCHOL_LDS_R;
+        hipLaunchKernelGGL(small_fallback_kernel, dim3((unsigned)p->types.size()), dim3(EIGH_THREADS), (size_t)lr * (lr + 1) / 2 * 8, st, e,
+                           deflation_lo(p->sw), 1e-7, lr, tb);
+        check_launch("small_fallback");
     }
     static DeviceOnce once;
     constexpr int bb_lds = (2 * 64 + 2 * SM_BK) * SM_LD * 8;
     allow_dynamic_lds(once, small_backbone_kernel, bb_lds);
     hipLaunchKernelGGL(small_backbone_kernel, dim3((unsigned)p->rels.size()), dim3(256), bb_lds, st, tb);
     check_launch("small_backbone");
-    hipLaunchKernelGGL((small_update_kernel<T>), dim3((unsigned)p->sm_j3.size()), dim3(256), 0, st, tb, (const SmJob*)p->sm_jobs3.ptr);
+    hipLaunchKernelGGL((small_update_kernel<T>), dim3((unsigned)p->sm_j3.size()), dim3(256), SM_TILE_BYTES, st, tb, (const SmJob*)p->sm_jobs3.ptr);
     check_launch("small_update");
-    theta_terms(p, st);                       // sparse constraints: D += Theta+ G, E += Theta- G
-    // G <- G * sqrt(E / max(D, eps)) over the whole G region (E, D and G regions share their layout)
-    const int64_t total = (int64_t)(p->flat_bytes / p->esz);
-    char* base = (char*)p->ws_base;
-    hipLaunchKernelGGL((mult_update_kernel<T>), dim3(elem_grid(total)), dim3(256), 0, st, (T*)(base + p->flat_g_off),
-                       (const T*)(base + p->flat_e_off), (const T*)(base + p->flat_d_off), total, 1, (int64_t)1, (int64_t)1);
-    check_launch("mult_update");
     p->first_iter = false;
 }
 
@@ -2529,14 +2517,14 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                     const TypeState& tj = p->types[r.col];
                     int part = 0;
                     for (int64_t r0 = 0; r0 < ti.n; r0 += 64) p->sm_j1.push_back(SmJob{SMJ_P, (int)k, (int)r0, (int)std::min<int64_t>(64, ti.n - r0), part++, 0, 0, 0});
-                    // Q = R^T G_i: a long inner dimension (the rows of the relation) over a small output -> shares of 256 rows
+                    // Q = R^T G_i: a long inner dimension (the rows of the relation) over a small output -> shares of SM_QROWS rows
                     int qpart = 0;
-                    for (int64_t k0 = 0; k0 < ti.n; k0 += 256, ++qpart)
+                    for (int64_t k0 = 0; k0 < ti.n; k0 += SM_QROWS, ++qpart)
                         for (int64_t c0 = 0; c0 < tj.n; c0 += 64)
                             p->sm_j1.push_back(SmJob{SMJ_Q, (int)k, (int)c0, (int)std::min<int64_t>(64, tj.n - c0), qpart, (int)k0,
-                                                     (int)std::min<int64_t>(256, ti.n - k0), 0});
+                                                     (int)std::min<int64_t>(SM_QROWS, ti.n - k0), 0});
                     r.sm_qparts = qpart;
-                    wdoubles += (size_t)part * ti.c * tj.c;
+                    wdoubles += align_up((size_t)part * ti.c * tj.c, 16);      // (shares of different relations / types never share a cache line)
                     add_slot(p, r.SmQ, (size_t)qpart * tj.n * ti.c * es);
                     add_slot(p, r.SmBp, (size_t)ti.c * ti.c * 8);
                     add_slot(p, r.SmBn, (size_t)ti.c * ti.c * 8);
@@ -2546,15 +2534,23 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 for (size_t i = 0; i < p->types.size(); ++i) {
                     const TypeState& t = p->types[i];
                     int part = 0;
-                    for (int64_t r0 = 0; r0 < t.n; r0 += 256) p->sm_j1.push_back(SmJob{SMJ_GRAM, (int)i, (int)r0, (int)std::min<int64_t>(256, t.n - r0), part++, 0, 0, 0});
-                    gdoubles += (size_t)part * t.c * t.c;
+                    for (int64_t r0 = 0; r0 < t.n; r0 += SM_GROWS) p->sm_j1.push_back(SmJob{SMJ_GRAM, (int)i, (int)r0, (int)std::min<int64_t>(SM_GROWS, t.n - r0), part++, 0, 0, 0});
+                    gdoubles += align_up((size_t)part * t.c * t.c, 16);
                     for (int64_t r0 = 0; r0 < t.n; r0 += 64) p->sm_j3.push_back(SmJob{0, (int)i, (int)r0, (int)std::min<int64_t>(64, t.n - r0), 0, 0, 0, 0});
+                    bool constrained = false;
+                    for (const ThetaState& th : p->thetas) constrained = constrained || th.type == (int)i;
+                    if (constrained)      // one wave per row, four rows per workgroup
+                        for (int64_t r0 = 0; r0 < t.n; r0 += 4) p->sm_j1.push_back(SmJob{SMJ_THETA, (int)i, (int)r0, (int)std::min<int64_t>(4, t.n - r0), 0, 0, 0, 0});
                 }
+                // Gram shares first (the inverse hangs off the last of them), then P (W hangs off the last of those), Q, constraints
+                auto prio = [](const SmJob& j) { return j.kind == SMJ_GRAM ? 0 : (j.kind == SMJ_P ? 1 : (j.kind == SMJ_Q ? 2 : 3)); };
+                std::stable_sort(p->sm_j1.begin(), p->sm_j1.end(), [&](const SmJob& a, const SmJob& b) { return prio(a) < prio(b); });
                 add_slot(p, p->sm_tables, sizeof(SmTables));
                 add_slot(p, p->sm_jobs1, p->sm_j1.size() * sizeof(SmJob));
                 add_slot(p, p->sm_jobs3, p->sm_j3.size() * sizeof(SmJob));
                 add_slot(p, p->sm_wpart, wdoubles * 8);
                 add_slot(p, p->sm_gpart, gdoubles * 8);
+                add_slot(p, p->sm_tickets, (p->types.size() + p->rels.size()) * sizeof(int));
             }
         }
         size_t theta_tmp_bytes = 0;
@@ -2857,6 +2853,8 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             tb.n_types = (int)p->types.size(); tb.n_rels = (int)p->rels.size(); tb.n_thetas = (int)p->thetas.size();
             tb.nan_upd = 1;                                   // DFMF: nan_to_num on the A / B / C / D terms (_dfmf.py:254-276)
             tb.wpart = (double*)p->sm_wpart.ptr; tb.gpart = (double*)p->sm_gpart.ptr;
+            tb.tickets = (int*)p->sm_tickets.ptr;
+            SKF_HIP(hipMemsetAsync(p->sm_tickets.ptr, 0, p->sm_tickets.bytes, st));
             tb.eigA = (double*)p->eigA.ptr; tb.eigV = (double*)p->eigV.ptr; tb.eigOk = (int*)p->eigOk.ptr;
             tb.eig_stride = p->eig_stride;
             tb.chol_thr = chol_rel_threshold(p->sw);
@@ -2865,8 +2863,9 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
                 TypeState& t = p->types[i];
                 SmType& d = tb.t[i];
                 d.G = t.G.ptr; d.E = t.E.ptr; d.D = t.D.ptr; d.Gram = (double*)t.Gram.ptr; d.K = (double*)t.K.ptr;
-                d.n = t.n; d.c = t.c; d.gpart_off = goff; d.n_gjobs = (int)((t.n + 255) / 256);
-                goff += (int64_t)d.n_gjobs * t.c * t.c;
+                d.n = t.n; d.c = t.c; d.gpart_off = goff; d.n_gjobs = (int)((t.n + SM_GROWS - 1) / SM_GROWS);
+                goff += (int64_t)align_up((size_t)d.n_gjobs * t.c * t.c, 16);
+                for (const ThetaState& th : p->thetas) d.has_theta = d.has_theta || th.type == (int)i;
             }
             for (size_t k = 0; k < p->rels.size(); ++k) {
                 RelState& r = p->rels[k];
@@ -2874,7 +2873,7 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
                 d.R = r.R; d.ldr = r.ldr; d.P = r.P.ptr; d.Q = r.SmQ.ptr; d.n_qparts = r.sm_qparts; d.W = (double*)r.W.ptr; d.S = (double*)r.S.ptr;
                 d.Bp = (double*)r.SmBp.ptr; d.Bn = (double*)r.SmBn.ptr; d.Dp = (double*)r.SmDp.ptr; d.Dn = (double*)r.SmDn.ptr;
                 d.row = r.row; d.col = r.col; d.wpart_off = woff; d.n_pjobs = (int)((p->types[r.row].n + 63) / 64);
-                woff += (int64_t)d.n_pjobs * p->types[r.row].c * p->types[r.col].c;
+                woff += (int64_t)align_up((size_t)d.n_pjobs * p->types[r.row].c * p->types[r.col].c, 16);
             }
             for (size_t k = 0; k < p->thetas.size(); ++k) {
                 ThetaState& th = p->thetas[k];

@@ -1968,6 +1968,36 @@ __global__ __launch_bounds__(256) void theta_csr_fill_kernel(const T* __restrict
     }
 }
 
+// entries [a, b) of one CSR row against column j of G: d += v G[k][j] (v > 0), e -= v G[k][j] (v < 0), in list order.
+// The entries go 64 at a time: one coalesced load of columns / values (lane z holds entry z), then eight gathers in
+// flight, independent of each other and of those loads (a chain of two dependent loads per entry before: the longest
+// row -- a hub of dicty's ppi -- set the kernel time).  Whole wave; lanes with j >= c carry zeros.
+template <typename T>
+__device__ __forceinline__ void theta_row_walk(const int* __restrict__ cols, const T* __restrict__ vals, int64_t a, int64_t b,
+                                               const T* __restrict__ G, int c, int j, T& e, T& d) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t q0 = a; q0 < b; q0 += 64) {
+        const int nb = (int)(b - q0 < 64 ? b - q0 : 64);
+        const int my_c = lane < nb ? cols[q0 + lane] : 0;
+        const T my_v = lane < nb ? vals[q0 + lane] : (T)0;
+        for (int z0 = 0; z0 < nb; z0 += 8) {
+            T g[8], v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int z = z0 + u < nb ? z0 + u : nb - 1;
+                v[u] = z0 + u < nb ? __shfl(my_v, z, 64) : (T)0;
+                const int cz = __shfl(my_c, z, 64);
+                g[u] = j < c ? G[(int64_t)cz * c + j] : (T)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (v[u] > (T)0) d += v[u] * g[u];
+                else e -= v[u] * g[u];
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void theta_spmm_kernel(const int64_t* __restrict__ rowptr, const int* __restrict__ cols,
                                                          const T* __restrict__ vals, const T* __restrict__ G,
@@ -1980,29 +2010,7 @@ __global__ __launch_bounds__(256) void theta_spmm_kernel(const int64_t* __restri
         for (int j0 = 0; j0 < c; j0 += 64) {
             const int j = j0 + lane;
             T e = (T)0, d = (T)0;
-            // the row's entries 64 at a time: one coalesced load of columns / values (lane z holds entry z), then the
-            // gathers of the batch are independent of each other and of those loads (a chain of two dependent loads per
-            // entry before: the longest row -- a hub of dicty's ppi -- set the kernel time)
-            for (int64_t q0 = a; q0 < b; q0 += 64) {
-                const int nb = (int)(b - q0 < 64 ? b - q0 : 64);
-                const int my_c = lane < nb ? cols[q0 + lane] : 0;
-                const T my_v = lane < nb ? vals[q0 + lane] : (T)0;
-                for (int z0 = 0; z0 < nb; z0 += 8) {                     // eight gathers in flight, consumed in list order
-                    T g[8], v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int z = z0 + u < nb ? z0 + u : nb - 1;
-                        v[u] = z0 + u < nb ? __shfl(my_v, z, 64) : (T)0;
-                        const int cz = __shfl(my_c, z, 64);
-                        g[u] = j < c ? G[(int64_t)cz * c + j] : (T)0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (v[u] > (T)0) d += v[u] * g[u];
-                        else e -= v[u] * g[u];
-                    }
-                }
-            }
+            theta_row_walk<T>(cols, vals, a, b, G, c, j, e, d);
             if (j < c) {
                 E[r * c + j] += e;
                 D[r * c + j] += d;
@@ -2234,13 +2242,12 @@ __device__ __forceinline__ void jacobi_pair(int round, int k, int n, int& p, int
     q = a < b ? b : a;
 }
 
-__global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) {
+__device__ __forceinline__ void jacobi_eigh_body(const EighArgs& e, const int b) {
     __shared__ double cs[EIGH_MAXN / 2], sn[EIGH_MAXN / 2];
     __shared__ int pp[EIGH_MAXN / 2], qq[EIGH_MAXN / 2];
     __shared__ double red[EIGH_THREADS / 64];
     __shared__ double s_off, s_diag;
     __shared__ int s_rot;                     // some pair rotated in the current sweep
-    const int b = blockIdx.x;
     if (e.chol_ok[b]) return;                 // uniform: fast path already inverted this matrix
     const int n = e.n[b];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -2373,6 +2380,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) {
         Vs[idx] = V[idx] * inv;
     }
 }
+__global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) { jacobi_eigh_body(e, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------
 // Fast path of the pseudo-inverse: a symmetric positive definite Gram matrix whose pivots stay
@@ -2746,14 +2754,13 @@ __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_blocked_kernel(Eigh
 // ------------------------------------------------------------------------------------------
 constexpr int PCHOL_LDS_R = 176;           // packed r (r + 1) / 2 doubles of the small factor fit the dynamic LDS up to this rank
 constexpr int PCHOL_LDS_BYTES = PCHOL_LDS_R * (PCHOL_LDS_R + 1) / 2 * 8;
-__global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, double lo, double hi, int lds_rank) {
+__device__ __forceinline__ void pchol_pinv_body(const EighArgs& e, const int b, double lo, double hi, int lds_rank) {
     __shared__ double d[EIGH_MAXN];            // remaining diagonal; < 0: the index has been a pivot
     __shared__ double rowk[EIGH_MAXN];         // row of L of the current pivot (its first k entries)
     __shared__ double red_v[EIGH_THREADS / 64];
     __shared__ int red_i[EIGH_THREADS / 64];
     __shared__ double s_val;
     __shared__ int s_idx, s_fail;
-    const int b = blockIdx.x;
     if (e.chol_ok[b] || !(lo < 1.0)) return;   // uniform: the fast path inverted this matrix / deflation switched off
     const int n = e.n[b];
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
@@ -2891,6 +2898,9 @@ __global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, do
     __syncthreads();
     for (int idx = tid; idx < n * n; idx += nt) Lt[idx] = W[idx];
     if (tid == 0) e.chol_ok[b] = 2;
+}
+__global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, double lo, double hi, int lds_rank) {
+    pchol_pinv_body(e, blockIdx.x, lo, hi, lds_rank);
 }
 
 // K(r,c) = sum_{k >= max(r,c)} X(k,r) X(k,c)   (inverse from the inverted Cholesky factor)

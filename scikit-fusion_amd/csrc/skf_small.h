@@ -1,20 +1,18 @@
 // skf_small.h -- the DFMF iteration of a SMALL graph (every rank <= 64, a few thousand objects per type: the reference's
-// own examples, BASELINE configs[0] / [1]) in eight launches instead of ~33.
+// own examples, BASELINE configs[0] / [1]) in four launches instead of ~33.
 //
 // On such graphs an iteration is a chain of dependent launches of a few microseconds each -- launch latency, not
-// arithmetic (dicty: 0.29 ms for 80 MFLOP, a third of it the one-wave Cholesky inverse).  Here the chain is
-//   1 small_contract_kernel   every P = R G_j row block, every Q = R^T G_i row block, every G^T G row block (jobs); the
-//                             P jobs also leave their share of W = G_i^T P                       (_dfmf.py:228-231, 254, 266)
-//   2 small_pinv_kernel       ONE workgroup: sums of the Gram / W shares, Cholesky inverse of every Gram matrix -- one
-//                             WAVE per matrix, its row in REGISTERS (v_readlane broadcasts, no LDS round trips) --,
-//                             K = X^T X, verdicts + packed copies for the fall-backs                       (:232)
-//   3-5 pchol_pinv / jacobi_eigh / eigh_unpack_pinv (the existing kernels: no-ops unless a verdict says otherwise)
-//   6 small_backbone_kernel   one workgroup per relation: S = K_i W K_j and the +- parts of S Gram_j S^T, S^T Gram_i S
+// arithmetic (dicty: 0.30 ms for 80 MFLOP on the general schedule).  Here the chain is
+//   1 small_contract_kernel   jobs: every P = R G_j row block (leaving its share of W = G_i^T P), every Q = R^T G_i share,
+//                             every G^T G share, the constraint terms Theta-+ G of four rows.  The workgroup that finishes
+//                             the LAST Gram share of a type sums the shares and inverts the matrix (sweep operator, the
+//                             matrix in registers) while P / Q jobs are still in flight; the one that finishes the last P
+//                             job of a relation sums W.                              (_dfmf.py:228-232, 254, 266, 284-292)
+//   2 small_fallback_kernel   a no-op unless a sweep declined its matrix: deflation / Jacobi eigen-solver / K = Vs V^T
+//   3 small_backbone_kernel   one workgroup per relation: S = K_i W K_j and the +- parts of S Gram_j S^T, S^T Gram_i S
 //                                                                                                 (:236-239, 260-276)
-//   7 small_update_kernel     per (type, 64 rows): the relation terms of E and D -- row sides, column sides, type term --
-//                             accumulated in registers and written once; then theta_spmm_kernel per sparse constraint
-//                                                                                                 (:254-292)
-//   8 mult_update_kernel      over the G region                                                  (:294-296)
+//   4 small_update_kernel     per (type, 64 rows): the relation terms of E and D -- row sides, column sides, type term --
+//                             in registers, the constraint terms added, G <- G sqrt(E / D) written in place  (:254-296)
 // Same arithmetic as the general schedule (f64 c x c algebra, master-type n-sized products, nan_to_num where the
 // reference has it); only the order of the sums differs.
 #pragma once
@@ -28,6 +26,7 @@ struct SmType {
     double* Gram; double* K;
     int64_t n, gpart_off;        // offset (doubles) of this type's Gram shares in SmTables.gpart
     int c, n_gjobs;
+    int has_theta, pad;          // sparse constraints on this type: their terms arrive in E / D (THETA jobs of launch 1)
 };
 struct SmRel {
     const void* R; int64_t ldr;
@@ -43,20 +42,24 @@ struct SmTheta {
 struct SmTables {
     int n_types, n_rels, n_thetas, nan_upd;
     double* wpart; double* gpart;
+    int* tickets;                // [n_types + n_rels] finished Gram jobs per type / P jobs per relation (zero between launches)
     double* eigA; double* eigV; int* eigOk; int64_t eig_stride;
     double chol_thr;
     SmType t[SM_MAXT];
     SmRel r[SM_MAXR];
     SmTheta th[SM_MAXTH];
 };
-enum { SMJ_P = 0, SMJ_Q = 1, SMJ_GRAM = 2 };          // jobs of 64 rows each
+enum { SMJ_P = 0, SMJ_Q = 1, SMJ_GRAM = 2, SMJ_THETA = 3 };
+constexpr int SM_QROWS = 256, SM_GROWS = 64;       // rows of the relation per Q share / of the factor per Gram share
 struct SmJob { int kind, idx, r0, nr, part, k0, nk, pad; };      // Q jobs: rows [k0, k0 + nk) of the relation, share `part`
 
 // ---- matrix-core tile of a workgroup ---------------------------------------------------------------------------------
 // 64 x 64 outputs per workgroup of 4 waves (2 x 2), K in tiles of 32 staged k-major in LDS (pitch 65); operands come
 // from callables at(row, k) / at(k, col) that return 0 outside their matrix.  T = float: one v_mfma_f32_32x32x2_f32 tile
 // per wave; T = double: 2 x 2 v_mfma_f64_16x16x4_f64 tiles per wave.
-constexpr int SM_BK = 32, SM_LD = 65;
+constexpr int SM_BK = 32, SM_LD = 65;      // (K tiles of 64 measured slower: 16 staged elements per thread and operand, their
+                                            // index arithmetic, outweigh the saved round trips -- dicty 6940 -> 5850 it/s)
+constexpr int SM_TILE_BYTES = 2 * SM_BK * SM_LD * 8;      // the two staging tiles of SmTile<double>: dynamic LDS of launches 1 and 4
 template <typename T>
 struct SmTile {
     typedef Mfma<T> MF;
@@ -134,11 +137,143 @@ struct SmTile {
     }
 };
 
+// ---- 1b -----------------------------------------------------------------------------------------------------------
+// p[0] + p[stride] + ... (count terms) in a fixed order, four independent chains so that the loads overlap
+__device__ __forceinline__ double sum_shares(const double* __restrict__ p, int64_t stride, int count) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int q = 0;
+    for (; q + 3 < count; q += 4) {
+        s0 += p[(int64_t)q * stride];
+        s1 += p[(int64_t)(q + 1) * stride];
+        s2 += p[(int64_t)(q + 2) * stride];
+        s3 += p[(int64_t)(q + 3) * stride];
+    }
+    for (; q < count; ++q) s0 += p[(int64_t)q * stride];
+    return (s0 + s1) + (s2 + s3);
+}
+
+// One workgroup per object type -- the one that finishes the type's LAST Gram job in launch 1, so that the inverse runs
+// underneath the P and Q jobs still in flight: Gram = nan_to_num(sum of its shares) (_dfmf.py:229) and K = Gram^-1 by
+// the sweep operator -- n steps of a rank-one update of the whole matrix.  The matrix lives in
+// REGISTERS: thread (ti, tj) of the 16 x 16 grid owns the 4 x 4 block at (4 ti, 4 tj); per step the only LDS traffic is
+// the pivot column (published by its 16 owners into a double buffer, read back as two 32-byte vectors per thread) and
+// there is ONE barrier.  (A one-wave Cholesky whose every inner product is a chain of LDS round trips: 91 us at order
+// 50; the sweep with the matrix in LDS, 12 LDS reads per thread and step: 52 us; this form: see profiles/.)
+// The pivot of step k is the Schur complement the Cholesky factorisation would take the root of: same verdict, same
+// thresholds as chol_inverse_small_kernel; a failed pivot leaves the matrix to small_fallback_kernel.
+constexpr int SM_PINV_THREADS = 256;
+// (M: 64 x SM_LD doubles of LDS, free to clobber -- the staging tiles of the calling workgroup)
+__device__ __forceinline__ void small_pinv_body(const SmTables* __restrict__ tb, const int t, double* M) {
+    __shared__ __attribute__((aligned(32))) double col[2][4][64];
+    __shared__ double diag0[64], need[64];
+    const int tid = threadIdx.x;
+    const SmType& ty = tb->t[t];
+    const int n = ty.c;
+    for (int e = tid; e < 64 * SM_LD; e += SM_PINV_THREADS) M[e] = 0.0;
+    __syncthreads();
+    {
+        const double* part = tb->gpart + ty.gpart_off;
+        for (int e = tid; e < n * n; e += SM_PINV_THREADS) {
+            const double s = nan_to_num(sum_shares(part + e, n * n, ty.n_gjobs));
+            ty.Gram[e] = s;
+            M[(e / n) * SM_LD + e % n] = s;
+        }
+    }
+    __syncthreads();
+    const int ti = tid >> 4, tj = tid & 15, i0 = 4 * ti, j0 = 4 * tj;
+    double m[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) m[a][b] = 0.5 * (M[(i0 + a) * SM_LD + j0 + b] + M[(j0 + b) * SM_LD + i0 + a]);
+    if (tid < 64) diag0[tid] = 0.5 * (M[tid * SM_LD + tid] + M[tid * SM_LD + tid]);
+    // column k of the current matrix into col[buf][k & 3] (= row k: the matrix stays symmetric).  Its owners are the 16
+    // threads of block column k / 4; they publish all four of their columns, so that no register is indexed by k (a
+    // select over m[a][k & 3] sends the whole block to scratch memory: 105 us instead of 52).
+    auto publish = [&](int k, int buf) {
+        if (tj != (k >> 2)) return;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) col[buf][b][i0 + a] = m[a][b];
+    };
+    publish(0, 0);
+    __syncthreads();
+    double mx = 0.0;
+    for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(diag0[i]));
+    const double floor_ = chol_diag_floor(n) * mx, thr = tb->chol_thr;
+    // the three tests on pivot k -- a_kk > floor, pivot > thr a_kk, pivot > 0 -- as ONE bound the pivot has to exceed
+    // (+inf where the diagonal entry fails, NaN included), so that a step is one LDS round trip before its arithmetic
+    if (tid < 64) {
+        const double akk = diag0[tid];
+        need[tid] = (akk > floor_) ? fmax(thr * akk, 0.0) : __builtin_inf();
+    }
+    __syncthreads();
+    int ok = 1;
+    for (int k = 0; k < n; ++k) {
+        const double* c = col[k & 1][k & 3];
+        typedef double vec4 __attribute__((ext_vector_type(4)));
+        const vec4 cr = *(const vec4*)(c + i0), cc4 = *(const vec4*)(c + j0);
+        const double piv = c[k], bound = need[k];
+        if (!(piv > bound)) {                                      // (uniform: every thread reads the same words)
+            ok = 0;
+            break;
+        }
+        const double d = 1.0 / piv;
+        // swept matrix: m_ij - c_i c_j d in general; c_j d in row k, c_i d in column k, -d at (k, k) -- as ONE fused
+        // multiply-add per element with c_i -> -1 in row k, c_j d -> -d in column k and the old value dropped there
+        double ci[4], cjd[4];
+        bool rk[4], ck[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            rk[a] = (i0 + a == k);
+            ck[a] = (j0 + a == k);
+            ci[a] = rk[a] ? -1.0 : cr[a];
+            cjd[a] = ck[a] ? -d : cc4[a] * d;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double old = (rk[a] || ck[b]) ? 0.0 : m[a][b];
+                m[a][b] = fma(-ci[a], cjd[b], old);
+            }
+        if (k + 1 < n) publish(k + 1, (k + 1) & 1);
+        __syncthreads();
+    }
+    if (ok) {                                                      // all pivots swept: m = -Gram^-1
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (i0 + a < n && j0 + b < n) ty.K[(i0 + a) * n + j0 + b] = -m[a][b];
+    }
+    if (tid == 0) tb->eigOk[t] = ok;
+}
+
+// true in every thread of the LAST workgroup to get here out of `total` (the others' global writes are visible to it);
+// the counter is back at zero for the next iteration
+__device__ __forceinline__ bool last_arrival(int* counter, int total) {
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tk = atomicAdd(counter, 1);
+        s_last = (tk == total - 1) ? 1 : 0;
+        if (s_last) *counter = 0;
+    }
+    __syncthreads();
+    const bool last = s_last != 0;
+    if (last) __threadfence();
+    return last;
+}
+
 // ---- 1 ------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* __restrict__ tb, const SmJob* __restrict__ jobs) {
-    __shared__ double As[SM_BK * SM_LD];
-    __shared__ double Bs[SM_BK * SM_LD];
+    HIP_DYNAMIC_SHARED(double, sm_tiles)     // 2 x SM_BK x SM_LD = 64 x SM_LD doubles: the two staging tiles, or the matrix of the sweep
+    double* As = sm_tiles;
+    double* Bs = sm_tiles + SM_BK * SM_LD;
     const SmJob jb = jobs[blockIdx.x];
     const int tid = threadIdx.x;
     if (jb.kind == SMJ_GRAM) {           // share of G^T G from rows r0 .., f64 accumulation
@@ -151,6 +286,25 @@ __global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* __r
         w.mma(jb.nr, g_at, [&](int k, int b) { return g_at(b, k); }, false, As, Bs);
         double* out = tb->gpart + t.gpart_off + (int64_t)jb.part * c * c;
         w.for_each([&](int a, int b, double v) { if (a < c && b < c) out[a * c + b] = v; });
+        if (last_arrival(tb->tickets + jb.idx, t.n_gjobs)) small_pinv_body(tb, jb.idx, sm_tiles);
+        return;
+    }
+    if (jb.kind == SMJ_THETA) {          // rows r0 .. of a constrained type, one wave per row: E = Theta- G, D = Theta+ G
+        const SmType& t = tb->t[jb.idx]; //                                                                 (_dfmf.py:284-292)
+        const int lane = tid & 63, c = t.c;
+        for (int rr = tid >> 6; rr < jb.nr; rr += 4) {
+            const int64_t row = jb.r0 + rr;
+            T e = (T)0, d = (T)0;
+            for (int k = 0; k < tb->n_thetas; ++k) {
+                const SmTheta& th = tb->th[k];
+                if (th.type != jb.idx) continue;
+                theta_row_walk<T>(th.ci, (const T*)th.vv, th.rp[row], th.rp[row + 1], (const T*)t.G, c, lane, e, d);
+            }
+            if (lane < c) {
+                ((T*)t.E)[row * c + lane] = e;
+                ((T*)t.D)[row * c + lane] = d;
+            }
+        }
         return;
     }
     const SmRel& r = tb->r[jb.idx];
@@ -176,6 +330,10 @@ __global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* __r
               [&](int k, int b) -> double { return b < cj ? (double)P[(int64_t)(jb.r0 + k) * cj + b] : 0.0; }, false, As, Bs);
         double* out = tb->wpart + r.wpart_off + (int64_t)jb.part * ci * cj;
         w.for_each([&](int a, int b, double v) { if (a < ci && b < cj) out[a * cj + b] = v; });
+        if (last_arrival(tb->tickets + tb->n_types + jb.idx, r.n_pjobs)) {      // W = the sum of its shares, fixed order
+            const double* part = tb->wpart + r.wpart_off;
+            for (int e = tid; e < ci * cj; e += 256) r.W[e] = sum_shares(part + e, ci * cj, r.n_pjobs);
+        }
     } else {                             // share `part` of Q[c0 + m][:] = sum over the rows k0 .. k0 + nk of R[k][c0 + m] G_i[k][:]
         const T* Gi = (const T*)ti.G;
         acc.mma(jb.nk, [&](int m, int k) { return m < jb.nr ? R[(int64_t)(jb.k0 + k) * r.ldr + jb.r0 + m] : (T)0; },
@@ -185,105 +343,38 @@ __global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* __r
     }
 }
 
-// ---- 2 ------------------------------------------------------------------------------------------------------------
-// p[0] + p[stride] + ... (count terms) in a fixed order, four independent chains so that the loads overlap
-__device__ __forceinline__ double sum_shares(const double* __restrict__ p, int64_t stride, int count) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int q = 0;
-    for (; q + 3 < count; q += 4) {
-        s0 += p[(int64_t)q * stride];
-        s1 += p[(int64_t)(q + 1) * stride];
-        s2 += p[(int64_t)(q + 2) * stride];
-        s3 += p[(int64_t)(q + 3) * stride];
-    }
-    for (; q < count; ++q) s0 += p[(int64_t)q * stride];
-    return (s0 + s1) + (s2 + s3);
-}
-
-// One workgroup per object type: Gram = nan_to_num(sum of its shares) (_dfmf.py:229), a packed copy for the fall-back
-// kernels, and K = Gram^-1 by the sweep operator in LDS -- n steps of a rank-one update of the whole matrix by all 256
-// threads (two barriers each), instead of a one-wave Cholesky whose every inner product is a chain of LDS round trips
-// (91 us at order 50).  The pivot of step k is the Schur complement the Cholesky factorisation would take the root of:
-// same verdict, same thresholds as chol_inverse_small_kernel; a failed pivot leaves the matrix to pchol_pinv /
-// jacobi_eigh.  One more workgroup per relation sums the shares of its W.
-constexpr int SM_PINV_THREADS = 1024;      // 64 x 64 / 1024 = 4 matrix elements per thread and sweep step
-__global__ __launch_bounds__(SM_PINV_THREADS) void small_pinv_kernel(const SmTables* __restrict__ tb) {
-    __shared__ double M[64 * SM_LD];
-    __shared__ double piv_col[64];
-    __shared__ double diag0[64];
-    __shared__ int s_ok;
-    const int tid = threadIdx.x, t = blockIdx.x;
-    if (t >= tb->n_types) {              // workgroups behind the types: W of one relation = the sum of its shares
-        const SmRel& r = tb->r[t - tb->n_types];
-        const int cc = tb->t[r.row].c * tb->t[r.col].c;
-        const double* part = tb->wpart + r.wpart_off;
-        for (int e = tid; e < cc; e += SM_PINV_THREADS) r.W[e] = sum_shares(part + e, cc, r.n_pjobs);
-        return;
-    }
-    const SmType& ty = tb->t[t];
-    const int n = ty.c, n_pad = (n + 1) / 2 * 2;
-    double* A = tb->eigA + (int64_t)t * tb->eig_stride;
-    for (int e = tid; e < n_pad * n_pad; e += SM_PINV_THREADS) A[e] = 0.0;
-    __syncthreads();
-    {
-        const double* part = tb->gpart + ty.gpart_off;
-        for (int e = tid; e < n * n; e += SM_PINV_THREADS) {
-            const double s = nan_to_num(sum_shares(part + e, n * n, ty.n_gjobs));
-            ty.Gram[e] = s;
-            A[(e / n) * n_pad + e % n] = s;
+// ---- 3 ------------------------------------------------------------------------------------------------------------
+// What the sweep declined (a verdict other than 1), one workgroup per type and a no-op otherwise: rank-revealing
+// deflation, then the Jacobi eigen-solver for what that declines too, then K = Vs V^T -- the three fall-back launches of
+// the general schedule (pchol_pinv_kernel, jacobi_eigh_kernel, eigh_unpack_pinv_batched_kernel) as one.
+__global__ __launch_bounds__(EIGH_THREADS) void small_fallback_kernel(EighArgs e, double lo, double hi, int lds_rank,
+                                                                      const SmTables* __restrict__ tb) {
+    const int b = blockIdx.x;
+    if (e.chol_ok[b] == 1) return;
+    {   // the packed, zero-padded copy of the Gram matrix the fall-back kernels work on
+        const SmType& ty = tb->t[b];
+        const int n = ty.c, n_pad = e.n[b];
+        double* A = e.A + (int64_t)b * e.stride;
+        for (int idx = threadIdx.x; idx < n_pad * n_pad; idx += blockDim.x) {
+            const int r = idx / n_pad, c = idx % n_pad;
+            A[idx] = (r < n && c < n) ? ty.Gram[r * n + c] : 0.0;
         }
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += SM_PINV_THREADS) {
-        const int i = e / n, j = e % n;
-        M[i * SM_LD + j] = 0.5 * (ty.Gram[i * n + j] + ty.Gram[j * n + i]);
-    }
-    if (tid == 0) s_ok = 1;
-    __syncthreads();
-    if (tid < n) diag0[tid] = M[tid * SM_LD + tid];
-    __syncthreads();
-    double mx = 0.0;
-    for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(diag0[i]));
-    const double floor_ = chol_diag_floor(n) * mx;
-    // the (at most PER) elements this thread updates in every step: row / column / LDS slot once, not per step; the spare
-    // slots point at an unused pad word, so that the update below is PER independent, branch-free read-modify-writes
-    constexpr int PER = 64 * 64 / SM_PINV_THREADS;
-    int ei[PER], ej[PER], es[PER];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int e = tid + SM_PINV_THREADS * q;
-        const bool ok = e < n * n;
-        ei[q] = ok ? e / n : 0;
-        ej[q] = ok ? e % n : 0;
-        es[q] = ok ? ei[q] * SM_LD + ej[q] : 64 * SM_LD - 1;
-    }
-    for (int k = 0; k < n; ++k) {
-        const double piv = M[k * SM_LD + k], akk = diag0[k];
-        if (!(akk > floor_) || !(piv > tb->chol_thr * akk) || !(piv > 0.0)) {      // (uniform: every thread reads the same words)
-            if (tid == 0) s_ok = 0;
-            break;
-        }
-        if (tid < n) piv_col[tid] = M[tid * SM_LD + k];          // column k (= row k: the matrix stays symmetric)
-        __syncthreads();
-        const double d = 1.0 / piv;
-        double nv[PER];
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int i = ei[q], j = ej[q];
-            const double ci_ = piv_col[i], cj_ = piv_col[j], old = M[es[q]];
-            const double off = (i == k) ? cj_ * d : ci_ * d;              // row k / column k of the swept matrix
-            const double gen = old - ci_ * cj_ * d;
-            nv[q] = (i == k && j == k) ? -d : ((i == k || j == k) ? off : gen);
-        }
-#pragma unroll
-        for (int q = 0; q < PER; ++q) M[es[q]] = nv[q];
         __syncthreads();
     }
+    pchol_pinv_body(e, b, lo, hi, lds_rank);
     __syncthreads();
-    if (s_ok) {                                                    // all pivots swept: M = -Gram^-1
-        for (int e = tid; e < n * n; e += SM_PINV_THREADS) ty.K[e] = -M[(e / n) * SM_LD + e % n];
+    jacobi_eigh_body(e, b);
+    __syncthreads();
+    const SmType& ty = tb->t[b];
+    const int n = ty.c, n_pad = e.n[b];
+    const double* Vs = e.Vs + (int64_t)b * e.stride;
+    const double* V = e.V + (int64_t)b * e.stride;
+    for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+        const int r = idx / n, c = idx % n;
+        double s = 0.0;
+        for (int k = 0; k < n_pad; ++k) s += Vs[r * n_pad + k] * V[c * n_pad + k];
+        ty.K[(int64_t)r * n + c] = s;
     }
-    if (tid == 0) tb->eigOk[t] = s_ok;
 }
 
 // ---- 6 ------------------------------------------------------------------------------------------------------------
@@ -351,8 +442,9 @@ __global__ __launch_bounds__(256) void small_backbone_kernel(const SmTables* __r
 // relation side in registers (nan_to_num first, as the reference has it), the type term accumulated straight into E / D
 template <typename T>
 __global__ __launch_bounds__(256) void small_update_kernel(const SmTables* __restrict__ tb, const SmJob* __restrict__ jobs) {
-    __shared__ T As[SM_BK * SM_LD];
-    __shared__ T Bs[SM_BK * SM_LD];
+    HIP_DYNAMIC_SHARED(double, sm_tiles)
+    T* As = (T*)sm_tiles;
+    T* Bs = (T*)(sm_tiles + SM_BK * SM_LD);
     const SmJob jb = jobs[blockIdx.x];
     const SmType& ty = tb->t[jb.idx];
     const int c = ty.c, tid = threadIdx.x;
@@ -411,11 +503,32 @@ __global__ __launch_bounds__(256) void small_update_kernel(const SmTables* __res
     };
     e.mma(c, g_at, [&](int k, int a) { return bsum(k, a, true); }, true, As, Bs);
     d.mma(c, g_at, [&](int k, int a) { return bsum(k, a, false); }, true, As, Bs);
-    T* E = (T*)ty.E;
-    T* D = (T*)ty.D;
-    e.for_each([&](int m, int a, T x) { if (m < jb.nr && a < c) E[(int64_t)(jb.r0 + m) * c + a] = x; });
-    d.for_each([&](int m, int a, T x) { if (m < jb.nr && a < c) D[(int64_t)(jb.r0 + m) * c + a] = x; });
-    // (the sparse constraints follow as theta_spmm_kernel launches: one wave per row over the whole type)
+    // G <- G * sqrt(E / max(D, eps)) for the rows of this job (_dfmf.py:294-296; the arithmetic of mult_update_kernel): E and D
+    // never leave the registers; the constraint terms were left in the E / D arrays by the THETA jobs of the first launch.
+    // (Every read of these rows of G -- the type term above -- is behind the last barrier of the product.)
+    const T* E = (const T*)ty.E;
+    const T* D = (const T*)ty.D;
+    T* Gw = (T*)ty.G;
+    const T eps = (T)2.220446049250313e-16;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+#pragma unroll
+    for (int i = 0; i < SmTile<T>::WR; ++i)
+#pragma unroll
+        for (int j = 0; j < SmTile<T>::WC; ++j)
+#pragma unroll
+            for (int q = 0; q < Mfma<T>::NREG; ++q) {
+                const int m = wm0 + i * Mfma<T>::MT + Mfma<T>::d_row(lane, q), a = wn0 + j * Mfma<T>::NT + Mfma<T>::d_col(lane);
+                if (m >= jb.nr || a >= c) continue;
+                const int64_t off = (int64_t)(jb.r0 + m) * c + a;
+                T ev = e.acc[i][j][q], dv = d.acc[i][j][q];
+                if (ty.has_theta) {
+                    ev += E[off];
+                    dv += D[off];
+                }
+                const T den = (dv > eps || dv != dv) ? dv : eps;     // np.maximum(D, eps) (NaN propagates)
+                Gw[off] = Gw[off] * (T)sqrt(ev / den);
+            }
 }
 
 }  // namespace skf
