@@ -129,6 +129,17 @@ static int pick_splits(const TileCfg& t, int M, int N, int K) {
     return s < 1 ? 1 : s;
 }
 
+// the staging mode the kernel's stage_mode() would pick for an operand, evaluated on the host (every K slice starts at a
+// multiple of k_chunk)
+template <typename TS>
+static int host_stage_mode(const void* src, int64_t s_row, int64_t s_k, int row_end, int K, int k_chunk) {
+    constexpr int V = 16 / (int)sizeof(TS);
+    const bool aligned = (((uintptr_t)src) & 15) == 0;
+    if (s_k == 1 && aligned && s_row % V == 0 && K % V == 0 && k_chunk % V == 0) return STAGE_VEC_K;
+    if (s_row == 1 && aligned && s_k % V == 0 && row_end % V == 0) return STAGE_VEC_R;
+    return STAGE_SCALAR;
+}
+
 template <typename T, typename TA, typename TB>
 static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, bool relation, hipStream_t st) {
     dim3 grid(cdiv(g.N, t.bn), cdiv(g.M, t.bm), splits);
@@ -143,57 +154,46 @@ static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, 
             hipLaunchKernelGGL((gemm_mfma_kernel<double, double, double, 1, 1, 64, 0>), grid, block, 0, st, g);
         else
             SKF_FAIL(SKF_E_INVALID, "deep tile is f64 only");
-    } else if (big && relation) {
-        // f32 relation contractions P = R G_j (A along K, B along its rows) and Q = R^T G_i (both along
-        // their rows) with 16-byte aligned operands: kernels with compile-time staging modes
-        bool fixed = false;
-        if constexpr (std::is_same<T, float>::value && std::is_same<TA, float>::value && std::is_same<TB, float>::value) {
-            auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
-            const bool b_rows = g.sb_n == 1 && g.sb_k % 4 == 0 && g.N % 4 == 0 && al(g.B);
-            const bool k_ok = g.K % 4 == 0 && g.k_chunk % 4 == 0;
-            if (b_rows && al(g.A) && g.sa_k == 1 && g.sa_m % 4 == 0 && k_ok) {
-                hipLaunchKernelGGL((gemm_mfma_kernel<float, float, float, 2, 2, 32, 1, STAGE_VEC_K | (STAGE_VEC_R << 2)>),
-                                   grid, block, 0, st, g);
-                fixed = true;
-            } else if (b_rows && al(g.A) && g.sa_m == 1 && g.sa_k % 4 == 0 && g.M % 4 == 0) {
-                hipLaunchKernelGGL((gemm_mfma_kernel<float, float, float, 2, 2, 32, 1, STAGE_VEC_R | (STAGE_VEC_R << 2)>),
-                                   grid, block, 0, st, g);
-                fixed = true;
-            }
-        }
-        if constexpr (std::is_same<T, double>::value && std::is_same<TA, double>::value && std::is_same<TB, double>::value) {
-            // the same two layouts in the f64 engine (16-byte vectors = 2 doubles)
-            auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
-            const bool b_rows = g.sb_n == 1 && g.sb_k % 2 == 0 && g.N % 2 == 0 && al(g.B);
-            const bool k_ok = g.K % 2 == 0 && g.k_chunk % 2 == 0;
-            if (b_rows && al(g.A) && g.sa_k == 1 && g.sa_m % 2 == 0 && k_ok) {
-                hipLaunchKernelGGL((gemm_mfma_kernel<double, double, double, WRB, WCB, Tiles<double>::BK, 1,
-                                                     STAGE_VEC_K | (STAGE_VEC_R << 2)>), grid, block, 0, st, g);
-                fixed = true;
-            } else if (b_rows && al(g.A) && g.sa_m == 1 && g.sa_k % 2 == 0 && g.M % 2 == 0) {
-                hipLaunchKernelGGL((gemm_mfma_kernel<double, double, double, WRB, WCB, Tiles<double>::BK, 1,
-                                                     STAGE_VEC_R | (STAGE_VEC_R << 2)>), grid, block, 0, st, g);
-                fixed = true;
-            }
-        }
-        if (!fixed)
-            hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 1>), grid, block, 0, st, g);
     } else if (big) {
-        // Gram = G^T G and W = G_i^T P of the f32 / bf16 engines (f32 operands read along their rows,
-        // f64 arithmetic): compile-time staging modes when everything is 16-byte aligned
-        bool fixed = false;
-        if constexpr (std::is_same<T, double>::value && std::is_same<TA, float>::value && std::is_same<TB, float>::value) {
-            auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
-            if (al(g.A) && al(g.B) && g.sa_m == 1 && g.sb_n == 1 && g.sa_k % 4 == 0 && g.sb_k % 4 == 0 &&
-                g.M % 4 == 0 && g.N % 4 == 0) {
-                hipLaunchKernelGGL((gemm_mfma_kernel<double, float, float, WRB, WCB, Tiles<double>::BK, 0,
-                                                     STAGE_VEC_R | (STAGE_VEC_R << 2)>),
-                                   grid, block, 0, st, g);
-                fixed = true;
+        // The big tile stages its operands with COMPILE-TIME modes (with run-time modes the unrolled staging code of both
+        // forms ran the f32 kernels out of registers: 15 - 57 spilled per lane).  The host evaluates the conditions the
+        // kernel's stage_mode would and picks among the layouts the engines produce; anything else is staged element-wise.
+        //   K|R  A along K, B along its rows   P = R G_j, Theta G, H = G_i S, the n x c x c side products
+        //   R|R  both along their rows         Q = R^T G_i, Gram = G^T G, W = G_i^T P
+        //   K|K  both along K                  the reconstruction H G_j^T of the f32 / f64 completion
+        constexpr int KR = STAGE_VEC_K | (STAGE_VEC_R << 2), RR = STAGE_VEC_R | (STAGE_VEC_R << 2), KK = STAGE_VEC_K | (STAGE_VEC_K << 2);
+        constexpr int BKT = Tiles<T>::BK;
+        constexpr bool same = std::is_same<TA, T>::value && std::is_same<TB, T>::value;
+        const int fm = host_stage_mode<TA>(g.A, g.sa_m, g.sa_k, g.M, g.K, g.k_chunk) |
+                       (host_stage_mode<TB>(g.B, g.sb_n, g.sb_k, g.N, g.K, g.k_chunk) << 2);
+#define SKF_BIG(TAG_, FM_) hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, BKT, TAG_, FM_>), grid, block, 0, st, g)
+        // (no layout of the list: the small tile with its run-time modes -- the big tile has no registers left for those)
+        auto other = [&](auto tag) {
+            const TileCfg sm = Tiles<T>::small();
+            dim3 grid_s(cdiv(g.N, sm.bn), cdiv(g.M, sm.bm), splits);
+            hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, 1, 1, BKT, decltype(tag)::value>), grid_s, block, 0, st, g);
+        };
+        std::integral_constant<int, 0> tag0;
+        std::integral_constant<int, 1> tag1;
+        if constexpr (same) {
+            if (relation) {
+                if (fm == KR) SKF_BIG(1, KR);
+                else if (fm == RR) SKF_BIG(1, RR);
+                else other(tag1);
+            } else {
+                if (fm == KR) SKF_BIG(0, KR);
+                else if (fm == RR) SKF_BIG(0, RR);
+                else if (fm == KK) SKF_BIG(0, KK);
+                else other(tag0);
             }
+        } else if constexpr (std::is_same<T, double>::value) {      // (f64, f32, f32): Gram = G^T G and W = G_i^T P of the f32 / bf16 engines
+            if (fm == RR) SKF_BIG(0, RR);
+            else other(tag0);
+        } else {                                                     // (f32, f32, f64): n x c x c products with an f64 backbone
+            if (fm == KR) SKF_BIG(0, KR);
+            else other(tag0);
         }
-        if (!fixed)
-            hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, Tiles<T>::BK, 0>), grid, block, 0, st, g);
+#undef SKF_BIG
     } else {
         hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, 1, 1, Tiles<T>::BK, 0>), grid, block, 0, st, g);
     }
@@ -327,12 +327,17 @@ static void run_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Bt, in
     dim3 grid(cdiv(N, bn), cdiv(M, bm), splits);
     if (bm == 256) {
         // 256 x BN tile, LDS rings in dynamic shared memory (> 64 KiB needs the attribute)
+        // (SKF_V2_POLICY: what the K loop does -- the product's V2Full unless a bound-finding build of tools/probe names
+        // a policy of its own on the command line, the way SKF_A_AUX names the cache policy)
+#ifndef SKF_V2_POLICY
+#define SKF_V2_POLICY V2Full
+#endif
 #define SKF_V2_LAUNCH(BN_, TAG_, AT_)                                                                             \
     do {                                                                                                          \
         const int smem_ = (3 * 256 + ((BN_ == 256) ? 2 : 3) * BN_) * 8 * 16;                                      \
         static DeviceOnce once_;                                                                              \
-        allow_dynamic_lds(once_, gemm_bf16_v2_kernel<BN_, TAG_, AT_>, smem_);                                     \
-        hipLaunchKernelGGL((gemm_bf16_v2_kernel<BN_, TAG_, AT_>), grid, dim3(512), smem_, st, g);                 \
+        allow_dynamic_lds(once_, gemm_bf16_v2_kernel<BN_, TAG_, AT_, EPI_T_STORE, false, SKF_V2_POLICY>, smem_);  \
+        hipLaunchKernelGGL((gemm_bf16_v2_kernel<BN_, TAG_, AT_, EPI_T_STORE, false, SKF_V2_POLICY>), grid, dim3(512), smem_, st, g); \
     } while (0)
 #define SKF_V2_LAUNCH_BITS(BN_, AT_)                                                                              \
     do {                                                                                                          \
@@ -933,17 +938,16 @@ static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const v
         const bool k_major = (k1 == 0 || ss_k == 1);
         // measured at config 3 (rocprof, all six launches): the 64 x 64 fixed-mode kernels (78 VGPRs, 6
         // workgroups per CU) beat the 128 x 128 ones (182 VGPRs, 2 per CU): 0.98 vs 1.30 ms per iteration
-        if (big && force != 128 && (vec || force == 64)) big = false;
+        // (the 128 x 128 tile only with compile-time staging modes: its run-time form spilled registers)
+        if (big && !(force == 128 && vec)) big = false;
         constexpr int FM_K = SKF_SIDE_FM(STAGE_VEC_K, STAGE_VEC_K, STAGE_VEC_K, STAGE_VEC_R);
         constexpr int FM_R = SKF_SIDE_FM(STAGE_VEC_K, STAGE_VEC_R, STAGE_VEC_K, STAGE_VEC_R);
         if (big) {
             dim3 grid(cdiv(t.c, 128), cdiv(n, 128));
-            if (vec && k_major)
+            if (k_major)
                 hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16, FM_K>), grid, block, 0, st, a);
-            else if (vec)
-                hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16, FM_R>), grid, block, 0, st, a);
             else
-                hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16>), grid, block, 0, st, a);
+                hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16, FM_R>), grid, block, 0, st, a);
         } else {
             dim3 grid(cdiv(t.c, 64), cdiv(n, 64));
             if (vec && k_major && n > 64 && t.c >= 64)

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <utility>
+#include "skf_asm.h"      // LDS / global instructions in inline-assembly form, with counted waits (gfx950)
 
 namespace skf {
 
@@ -864,102 +865,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
 #ifndef SKF_B_AUX
 #define SKF_B_AUX 0
 #endif
-// bound-finding probe builds (tools/probe_*.sh; never defined in the product build):
-//   SKF_PROBE_NOMFMA  the K loop only moves tiles (LDS-DMA, waits, barriers)      -> ingest-only time
-//   SKF_PROBE_NODMA_A / SKF_PROBE_NODMA_B  the loop re-uses the tiles of the prologue -> time without
-//                     the relation stream / without the G^T stream
-#if defined(SKF_PROBE_NODMA_A)
-#define SKF_PROBE_A(x) (void)0
-#else
-#define SKF_PROBE_A(x) x
-#endif
-#if defined(SKF_PROBE_NODMA_B)
-#define SKF_PROBE_B(x) (void)0
-#else
-#define SKF_PROBE_B(x) x
-#endif
+// What the K loop of gemm_bf16_v2_kernel does.  The product: everything.  (The bound-finding builds of round 2 --
+// ingest-only, compute-only, one stream removed; profiles/r02_contraction_bounds.txt -- instantiate the kernel with a
+// policy of their own from tools/probe/v2_policies.h; nothing of them is compiled here.)
+struct V2Full {
+    static constexpr bool stream_a = true;     // LDS-DMA of the relation tiles inside the loop
+    static constexpr bool stream_b = true;     // LDS-DMA of the G^T tiles inside the loop
+    static constexpr bool mfma = true;         // the matrix-core instructions
+};
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-// ds_read_b64_tr_b16 with an immediate byte offset.  Issued as inline assembly: the compiler's waitcnt pass
-// treats the builtin form as a possible reader of every LDS-DMA in flight and puts s_waitcnt vmcnt(0) in
-// front of it (which serialises the ring); it knows nothing about this form, so the results are claimed
-// with lds_tr_wait() -- lgkmcnt(0) tied to the result registers -- before the first use.
-// (tests/emul defines SKF_HOST_EMULATOR: the host emulator models the instruction behind the builtin's name.)
-template <int OFF>
-__device__ __forceinline__ s16x4 lds_read_tr16_b64(const unsigned char* p) {
-#ifdef SKF_HOST_EMULATOR
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + OFF));
-#else
-    s16x4 r;
-    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
-    return r;
-#endif
-}
-__device__ __forceinline__ void lds_tr_wait(s16x4& a, s16x4& b, s16x4& c, s16x4& d, s16x4& e, s16x4& f, s16x4& g, s16x4& h) {
-#ifndef SKF_HOST_EMULATOR
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
-#endif
-}
-
-
-// ds_read_b128 in the same inline-assembly form (the fragment pipeline of gemm_bf16_v2_kernel counts its own
-// outstanding LDS reads: lds_wait<N>() = s_waitcnt lgkmcnt(N) tied to the registers it releases)
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_read_b128(const unsigned char* p) {
-#ifdef SKF_HOST_EMULATOR
-    return *(const u32x4*)(p + OFF);
-#else
-    u32x4 r;
-    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
-    return r;
-#endif
-}
-template <int CNT, typename T>
-__device__ __forceinline__ void lds_wait(T& x) {
-#ifndef SKF_HOST_EMULATOR
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(CNT));
-#endif
-}
-template <int CNT, typename T, typename U>
-__device__ __forceinline__ void lds_wait(T& x, U& y) {
-#ifndef SKF_HOST_EMULATOR
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(CNT));
-#endif
-}
-// the register holds a value that an earlier lds_wait has released: ties its consumers behind that wait
-template <typename T>
-__device__ __forceinline__ void lds_claim(T& x) {
-#ifndef SKF_HOST_EMULATOR
-    asm volatile("" : "+v"(x));
-#endif
-}
-// the bitmap loads and expansion stores of the ABITS flavour, in the same form (vm_wait<N>() = s_waitcnt vmcnt(N))
-__device__ __forceinline__ uint32_t global_load_u32(const void* p) {
-#ifdef SKF_HOST_EMULATOR
-    return *(const uint32_t*)p;
-#else
-    uint32_t r;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
-    return r;
-#endif
-}
-template <int CNT>
-__device__ __forceinline__ void vm_wait(uint32_t& x) {
-#ifndef SKF_HOST_EMULATOR
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(CNT));
-#endif
-}
-__device__ __forceinline__ void lds_write_b128(u32x4* p, u32x4 v) {
-#ifdef SKF_HOST_EMULATOR
-    *p = v;
-#else
-    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)p;
-    asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(v) : "memory");
-#endif
-}
 template <int... I, typename F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -1073,11 +989,7 @@ __device__ __forceinline__ void bf16_tile_epilogue(const Bf16GemmArgs& g, f32x4 
                     for (int e = 0; e < 8; ++e)
                         if (e >= left) v[e >> 1] &= ~(0xFFFFu << (16 * (e & 1)));
                 }
-#ifndef SKF_PROBE_NOSTORE
                 *(u32x4*)(g.R + (int64_t)(row0 + r) * g.ldr + col0 + c * 8) = v;
-#else
-                if (v[0] == 0x12345678u) *(u32x4*)(g.R + (int64_t)(row0 + r) * g.ldr + col0 + c * 8) = v;
-#endif
             }
             }
         } else {
@@ -1156,7 +1068,7 @@ __device__ __forceinline__ void bf16_tile_epilogue(const Bf16GemmArgs& g, f32x4 
     }
 }
 
-template <int BN, int TAG, bool AT, int EPI = EPI_T_STORE, bool ABITS = false>
+template <int BN, int TAG, bool AT, int EPI = EPI_T_STORE, bool ABITS = false, class POL = V2Full>
 __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
     static_assert(EPI == EPI_T_STORE || (BN == 256 && !AT), "the elementwise epilogues use the 256 x 256 P-form tile");
     constexpr int BM = 256, BK = 64;
@@ -1313,9 +1225,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
             if (kt + 2 >= nkt) return;
             const int k2 = kz0 + (kt + 2) * BK;
             if constexpr (ks == 0) {
-                if constexpr (!ABITS) SKF_PROBE_A(dma_A1(k2, (kt + 2) % AST, sidx));
-            } else if constexpr (sidx < PWB) {
-                SKF_PROBE_B(dma_B1(k2, (kt + 2) % BST, sidx));
+                if constexpr (!ABITS && POL::stream_a) dma_A1(k2, (kt + 2) % AST, sidx);
+            } else if constexpr (sidx < PWB && POL::stream_b) {
+                dma_B1(k2, (kt + 2) % BST, sidx);
             }
         };
         // ABITS, phase 0: chunk q of the bits of tile kt+2 (in wcur since the previous tile) goes into ring slot
@@ -1364,10 +1276,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                             for (int q = 0; q < NJ; ++q) lds_claim(fb[q]);
                         }
                     }
-#ifndef SKF_PROBE_NOMFMA
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                                        __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
-#endif
+                    if constexpr (POL::mfma)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                            __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
                     if constexpr (j == 0) __builtin_amdgcn_sched_barrier(0);    // (keeps MFMA i between waits i and i+1)
                     if constexpr (j == NJ - 1) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -1375,16 +1286,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
-#ifdef SKF_PROBE_HALF_LDS
-                // probe (wrong products): every second B fragment re-uses its neighbour -> 8 instead of 12 fragment reads
-                // per phase, the LDS traffic of a 128 x 128 wave tile
-                if constexpr (j + 1 < NJ) {
-                    if constexpr ((j + 1) & 1) nb[j + 1] = nb[j];
-                    else nb[j + 1] = lds_read_b128<(j + 1) * 2048>(pb);
-                }
-#else
                 if constexpr (j + 1 < NJ) nb[j + 1] = lds_read_b128<(j + 1) * 2048>(pb);
-#endif
                 if constexpr (ABITS && ks == 0) {
                     if constexpr (j < 4 && j <= NJ - 2) expand_chunk(jc, kt);
                     if constexpr (NJ == 4 && j == 2) expand_chunk(std::integral_constant<int, 3>{}, kt);

@@ -22,7 +22,6 @@
 // that a forward order hides).
 // =====================================================================================
 #pragma once
-#define SKF_HOST_EMULATOR 1
 #include <ucontext.h>
 #include <cmath>
 #include <cstdint>

@@ -22,6 +22,7 @@ CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 def _sources():
     deps = [os.path.join(SRC_DIR, f) for f in sorted(os.listdir(SRC_DIR))]
     deps.append(os.path.join(HERE, 'include', 'hip', 'hip_runtime.h'))
+    deps.append(os.path.join(HERE, 'include', 'skf_asm.h'))
     deps.append(os.path.join(ROOT, 'include', 'skfusion_hip.h'))
     return deps
 
@@ -35,6 +36,7 @@ def build(force=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O2', '-fPIC', '-shared', '-Wno-psabi',
            '-Wno-unused-variable', '-I', os.path.join(HERE, 'include'),
+           '-include', os.path.join(HERE, 'include', 'skf_asm.h'),      # host stand-ins ahead of csrc/skf_asm.h
            os.path.join(SRC_DIR, 'skf_api.hip'), '-o', OUT]
     subprocess.check_call(cmd)
     return OUT

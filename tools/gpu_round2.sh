@@ -39,7 +39,7 @@ case "$step" in
     echo "c5 $dt exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/c5_$dt.log" | cut -c1-900 | tee -a "$OUT/summary.txt" ;;
   prof_*)
     dt=${step#prof_}
-    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_$dt" -o prof -- python "$OLDPWD/bench.py" --dtype $dt --steps 5 --warmup 2 --no-cpu-baseline --no-engines ) > "$OUT/prof_$dt.log" 2>&1
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_$dt" -o prof -- python "$OLDPWD/bench.py" --dtype $dt --steps 5 --warmup 2 --no-cpu-baseline --no-engines --no-workloads ) > "$OUT/prof_$dt.log" 2>&1
     echo "rocprof $dt exit $?" | tee -a "$OUT/summary.txt"
     f=$(find "$OUT/prof_$dt" -name '*kernel_stats.csv' | head -1)
     [ -n "$f" ] && head -30 "$f" | tee -a "$OUT/summary.txt"
