@@ -129,6 +129,15 @@ static int pick_splits(const TileCfg& t, int M, int N, int K) {
     return s < 1 ? 1 : s;
 }
 
+// operand / result types of one contraction (SKF_F64 or SKF_F32 each).  Supported:
+//   (f64,f64,f64)  f64 engine, and the c x c algebra of every engine
+//   (f32,f32,f32)  relation contractions and Theta products of the f32 engine
+//   (f64,f32,f32)  Gram = G^T G and W = G^T P of the f32 engine: f32 operands, f64 arithmetic
+//   (f32,f32,f64)  n x c x c products of the f32 engine with an f64 backbone / B, D matrix
+struct GemmTypes {
+    int c, a, b;
+};
+
 // the staging mode the kernel's stage_mode() would pick for an operand, evaluated on the host (every K slice starts at a
 // multiple of k_chunk)
 template <typename TS>
@@ -138,6 +147,37 @@ static int host_stage_mode(const void* src, int64_t s_row, int64_t s_k, int row_
     if (s_k == 1 && aligned && s_row % V == 0 && K % V == 0 && k_chunk % V == 0) return STAGE_VEC_K;
     if (s_row == 1 && aligned && s_k % V == 0 && row_end % V == 0) return STAGE_VEC_R;
     return STAGE_SCALAR;
+}
+
+// The big tile stages its operands with COMPILE-TIME modes (with run-time modes the unrolled staging code of both forms
+// ran the f32 kernels out of registers: 15 - 57 spilled per lane).  The layouts the engines produce have instantiations:
+//   K|R  A along K, B along its rows   P = R G_j, Theta G, H = G_i S, the n x c x c side products
+//   R|R  both along their rows         Q = R^T G_i, Gram = G^T G, W = G_i^T P
+//   K|K  both along K                  the reconstruction H G_j^T of the f32 / f64 completion and residual
+// (every K slice starts at a multiple of the K tile, so the slicing never changes the verdict).  Returns the mode pair, or
+// -1: no instantiation -- such a product runs on the small tile, whose run-time modes cost no registers that matter.
+constexpr int FM_KR = STAGE_VEC_K | (STAGE_VEC_R << 2), FM_RR = STAGE_VEC_R | (STAGE_VEC_R << 2), FM_KK = STAGE_VEC_K | (STAGE_VEC_K << 2);
+static int big_tile_modes(GemmTypes ty, const GemmArgs& g, bool relation) {
+    const int bk = (ty.c == SKF_F64) ? Tiles<double>::BK : Tiles<float>::BK;
+    const int ma = ty.a == SKF_F64 ? host_stage_mode<double>(g.A, g.sa_m, g.sa_k, g.M, g.K, bk)
+                                   : host_stage_mode<float>(g.A, g.sa_m, g.sa_k, g.M, g.K, bk);
+    const int mb = ty.b == SKF_F64 ? host_stage_mode<double>(g.B, g.sb_n, g.sb_k, g.N, g.K, bk)
+                                   : host_stage_mode<float>(g.B, g.sb_n, g.sb_k, g.N, g.K, bk);
+    const int fm = ma | (mb << 2);
+    const bool same = ty.a == ty.c && ty.b == ty.c;
+    if (same) return (fm == FM_KR || fm == FM_RR || (fm == FM_KK && !relation)) ? fm : -1;
+    if (ty.c == SKF_F64) return fm == FM_RR ? fm : -1;           // (f64, f32, f32)
+    return fm == FM_KR ? fm : -1;                                // (f32, f32, f64)
+}
+// the tile a product runs on (run_gemm, and callers that size per-workgroup outputs: skf_relation_sqerr)
+static TileCfg gemm_tile(GemmTypes ty, int engine, const GemmArgs& g, bool deep_ok, bool relation) {
+    const bool is_f64 = (ty.c == SKF_F64);
+    const TileCfg t = pick_tile(is_f64, engine, g.M, g.N, g.K, deep_ok);
+    if (engine != SKF_ENGINE_MFMA) return t;
+    const TileCfg big = is_f64 ? Tiles<double>::big() : Tiles<float>::big();
+    if (t.bm == big.bm && t.bn == big.bn && t.bk == big.bk && big_tile_modes(ty, g, relation) < 0)
+        return is_f64 ? Tiles<double>::small() : Tiles<float>::small();
+    return t;
 }
 
 template <typename T, typename TA, typename TB>
@@ -155,43 +195,25 @@ static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, 
         else
             SKF_FAIL(SKF_E_INVALID, "deep tile is f64 only");
     } else if (big) {
-        // The big tile stages its operands with COMPILE-TIME modes (with run-time modes the unrolled staging code of both
-        // forms ran the f32 kernels out of registers: 15 - 57 spilled per lane).  The host evaluates the conditions the
-        // kernel's stage_mode would and picks among the layouts the engines produce; anything else is staged element-wise.
-        //   K|R  A along K, B along its rows   P = R G_j, Theta G, H = G_i S, the n x c x c side products
-        //   R|R  both along their rows         Q = R^T G_i, Gram = G^T G, W = G_i^T P
-        //   K|K  both along K                  the reconstruction H G_j^T of the f32 / f64 completion
-        constexpr int KR = STAGE_VEC_K | (STAGE_VEC_R << 2), RR = STAGE_VEC_R | (STAGE_VEC_R << 2), KK = STAGE_VEC_K | (STAGE_VEC_K << 2);
         constexpr int BKT = Tiles<T>::BK;
         constexpr bool same = std::is_same<TA, T>::value && std::is_same<TB, T>::value;
-        const int fm = host_stage_mode<TA>(g.A, g.sa_m, g.sa_k, g.M, g.K, g.k_chunk) |
-                       (host_stage_mode<TB>(g.B, g.sb_n, g.sb_k, g.N, g.K, g.k_chunk) << 2);
+        const int fm = big_tile_modes(GemmTypes{std::is_same<T, double>::value ? SKF_F64 : SKF_F32, std::is_same<TA, double>::value ? SKF_F64 : SKF_F32,
+                                                std::is_same<TB, double>::value ? SKF_F64 : SKF_F32}, g, relation);
+        if (fm < 0) SKF_FAIL(SKF_E_INVALID, "big tile without a staging layout (gemm_tile picks the small tile for these)");
 #define SKF_BIG(TAG_, FM_) hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, WRB, WCB, BKT, TAG_, FM_>), grid, block, 0, st, g)
-        // (no layout of the list: the small tile with its run-time modes -- the big tile has no registers left for those)
-        auto other = [&](auto tag) {
-            const TileCfg sm = Tiles<T>::small();
-            dim3 grid_s(cdiv(g.N, sm.bn), cdiv(g.M, sm.bm), splits);
-            hipLaunchKernelGGL((gemm_mfma_kernel<T, TA, TB, 1, 1, BKT, decltype(tag)::value>), grid_s, block, 0, st, g);
-        };
-        std::integral_constant<int, 0> tag0;
-        std::integral_constant<int, 1> tag1;
         if constexpr (same) {
             if (relation) {
-                if (fm == KR) SKF_BIG(1, KR);
-                else if (fm == RR) SKF_BIG(1, RR);
-                else other(tag1);
+                if (fm == FM_KR) SKF_BIG(1, FM_KR);
+                else SKF_BIG(1, FM_RR);
             } else {
-                if (fm == KR) SKF_BIG(0, KR);
-                else if (fm == RR) SKF_BIG(0, RR);
-                else if (fm == KK) SKF_BIG(0, KK);
-                else other(tag0);
+                if (fm == FM_KR) SKF_BIG(0, FM_KR);
+                else if (fm == FM_RR) SKF_BIG(0, FM_RR);
+                else SKF_BIG(0, FM_KK);
             }
         } else if constexpr (std::is_same<T, double>::value) {      // (f64, f32, f32): Gram = G^T G and W = G_i^T P of the f32 / bf16 engines
-            if (fm == RR) SKF_BIG(0, RR);
-            else other(tag0);
+            SKF_BIG(0, FM_RR);
         } else {                                                     // (f32, f32, f64): n x c x c products with an f64 backbone
-            if (fm == KR) SKF_BIG(0, KR);
-            else other(tag0);
+            SKF_BIG(0, FM_KR);
         }
 #undef SKF_BIG
     } else {
@@ -209,22 +231,13 @@ static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, 
     }
 }
 
-// operand / result types of one contraction (SKF_F64 or SKF_F32 each).  Supported:
-//   (f64,f64,f64)  f64 engine, and the c x c algebra of every engine
-//   (f32,f32,f32)  relation contractions and Theta products of the f32 engine
-//   (f64,f32,f32)  Gram = G^T G and W = G^T P of the f32 engine: f32 operands, f64 arithmetic
-//   (f32,f32,f64)  n x c x c products of the f32 engine with an f64 backbone / B, D matrix
-struct GemmTypes {
-    int c, a, b;
-};
-
 // `part`/`part_bytes`: scratch for split-K partials; splits is clamped to fit.
 static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void* part, size_t part_bytes,
                      hipStream_t st, bool relation = false) {
     if (g.M <= 0 || g.N <= 0) return;
     const bool is_f64 = (ty.c == SKF_F64);
     const bool all_f64 = (ty.c == SKF_F64 && ty.a == SKF_F64 && ty.b == SKF_F64);
-    const TileCfg t = pick_tile(is_f64, engine, g.M, g.N, g.K, all_f64 && want_splits <= 1);
+    const TileCfg t = gemm_tile(ty, engine, g, all_f64 && want_splits <= 1, relation);
     int splits = want_splits > 0 ? want_splits : pick_splits(t, g.M, g.N, g.K);
     if (g.epi == EPI_SQDIFF) splits = 1;
     const size_t per = (size_t)g.M * g.N;
@@ -3224,7 +3237,7 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
         g.C2 = p->sqpart.ptr;
         // one partial per workgroup of the tile run_gemm picks for THIS product (an all-f64 product of a small
         // relation with 64 <= c_j <= 1024 runs on the deep 32 x 32 tile)
-        const TileCfg t = pick_tile(p->f64, p->engine, ni, nj, cj, p->f64);
+        const TileCfg t = gemm_tile(GemmTypes{p->mt, p->mt, p->mt}, p->engine, g, p->f64, false);
         const int blocks = cdiv(ni, t.bm) * cdiv(nj, t.bn);
         if ((size_t)blocks > p->sq_elems) SKF_FAIL(SKF_E_STATE, "residual partials: %d tiles > %zu slots", blocks, p->sq_elems);
         plan_gemm(p, g, st);

@@ -164,6 +164,30 @@ def test_c2_dicty_first_iteration_f64():
         assert relerr(G[t, t], Go[t, t]) < 1e-9
 
 
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_device_squared_error_on_unaligned_shapes(dtype):
+    """skf_relation_sqerr sizes one partial per workgroup of the tile the product runs on: the dicty relations (1219 x 116
+    and 1219 x 282 at ranks 50 / 15 / 5: nothing divisible by the vector widths) take the small tile with run-time
+    staging modes -- the device value must still be the host's."""
+    from skfusion_amd._engine import DevicePlan, flatten_relations, flatten_thetas
+    z = golden('c2_dicty.npz')
+    R, Theta, types, rank = dicty_graph()
+    G0 = g0_from(z, 'dfmf/', types)
+    n = {'gene': R['gene', 'go'][0].shape[0], 'go': R['gene', 'go'][0].shape[1], 'exc': R['gene', 'exc'][0].shape[1]}
+    rel = flatten_relations(R)
+    plan = DevicePlan(types, n, rank, rel, flatten_thetas(Theta), nat.SKF_DFMF, dtype=dtype)
+    for t in types:
+        plan.set_factor(t, G0[t, t])
+    plan.iterate(2)
+    G = {t: plan.get_factor(t).astype(np.float64) for t in types}
+    for k in range(len(rel)):
+        i, j = rel[k][0], rel[k][1]
+        host = np.linalg.norm(R[i, j][0] - G[i] @ plan.get_backbone(k).astype(np.float64) @ G[j].T)
+        dev = float(np.sqrt(plan.relation_sqerr(k)))
+        assert abs(dev - host) / host < (1e-10 if dtype == 'f64' else 2e-5)
+    plan.close()
+
+
 def test_bf16_engine_against_oracle_on_bf16_rounded_relations():
     """SKF_BF16: bf16 R / R^T / G^T feed the relation contractions, everything else as the f32
     engine.  Oracle run on the bf16-rounded relations (exactly representable in f64) so that

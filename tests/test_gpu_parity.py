@@ -370,6 +370,32 @@ def test_c2_dicty_dfmf_100_iterations_f64_and_f32(schedule, monkeypatch):
         assert relerr(G32[t, t], G[t, t]) < 1e-3
 
 
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_device_squared_error_on_unaligned_shapes(dtype):
+    """skf_relation_sqerr sizes one partial per workgroup of the tile the product runs on; dicty's shapes (1219 x 116,
+    1219 x 282, ranks 50 / 15 / 5) take the small tile with run-time staging modes.  Device value vs host arithmetic."""
+    from skfusion_amd._engine import DevicePlan, flatten_relations, flatten_thetas
+    z = golden('c2_dicty.npz')
+    R, Theta, types, rank = dicty_graph()
+    G0 = g0_from(z, 'dfmf/', types)
+    n = {'gene': R['gene', 'go'][0].shape[0], 'go': R['gene', 'go'][0].shape[1], 'exc': R['gene', 'exc'][0].shape[1]}
+    rel = flatten_relations(R)
+    plan = DevicePlan(types, n, rank, rel, flatten_thetas(Theta), nat.SKF_DFMF, dtype=dtype)
+    for t in types:
+        plan.set_factor(t, G0[t, t])
+    plan.iterate(100)
+    G = {t: plan.get_factor(t).astype(np.float64) for t in types}
+    for k in range(len(rel)):
+        i, j = rel[k][0], rel[k][1]
+        host = np.linalg.norm(R[i, j][0] - G[i] @ plan.get_backbone(k).astype(np.float64) @ G[j].T)
+        dev = float(np.sqrt(plan.relation_sqerr(k)))
+        within(abs(dev - host) / host, 1e-10 if dtype == 'f64' else 2e-5, 'dicty %s: device squared error vs host arithmetic' % dtype)
+    # the error of the 100th iterate of the reference (golden): the fit itself, through the device's own error pass
+    if dtype == 'f64':
+        assert abs(np.sqrt(plan.relation_sqerr(0)) - float(np.ravel(z['dfmf/err_gene_go'])[0])) < 0.05
+    plan.close()
+
+
 def test_c2_dicty_dfmc_row_block_mask():
     z = golden('c2_dicty.npz')
     R, Theta, types, rank = dicty_graph()
