@@ -173,11 +173,14 @@ def measured_traffic(dtype, c5, scale):
     """HBM bytes per contraction launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE in passes of their own over this very command, FETCH_SIZE with the gfx950 x2 correction), or None: the
     counters cannot be read from inside the timed run."""
-    if c5 or scale != 1.0:
+    if scale != 1.0:
         return None
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')) as f:
-            e = json.load(f).get('%s_round2' % dtype)
+            table = json.load(f)
+        prefix = '%s_c5_round' % dtype if c5 else '%s_round' % dtype
+        rounds = [k for k in table if k.startswith(prefix) and k[len(prefix):].isdigit()]
+        e = table[max(rounds, key=lambda k: int(k[len(prefix):]))] if rounds else None       # the latest committed pass
         return {'bytes': float(e['fetch_bytes_per_launch']) + float(e['write_bytes_per_launch']), 'source': e['source']} if e else None
     except (OSError, ValueError, KeyError):
         return None
@@ -235,7 +238,10 @@ def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, ela
         rec.update({'bound': 'hbm', 'achieved': alg_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'})
     rec['frac'] = max(t_flops, t_bytes) / sec
     if executed:
-        rec['traffic'] = None
+        rec['traffic'] = pmc['bytes'] if pmc else None
+        if pmc:
+            rec['traffic_kind'] = 'PMC, committed pass: ' + pmc['source']
+            rec['executed_bytes_per_launch'] = nbytes / k_launches
         return rec
     sched_gbs = sched_iter * iters / sec / 1e9
     rec['hbm_scheduled'] = {'achieved': sched_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': sched_gbs / HBM_PEAK_GBS}
@@ -539,7 +545,7 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
 
 def compact_roofline(r):
     return {k: r.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 't_min_ms', 't_kernel_ms', 'launches',
-                                  'accounting') if k in r}
+                                  'accounting', 'traffic', 'executed_bytes_per_launch', 'traffic_kind') if k in r}
 
 
 def other_workloads(dtype='bf16'):
@@ -549,7 +555,7 @@ def other_workloads(dtype='bf16'):
     try:
         w = run_workload('c5', dtype, 10, 3)
         roof = roofline_record(dtype, w['n'], w['ranks'], w['spec'], w['k_ms'], w['k_launches'], w['k_flops'], 10,
-                               w['elapsed'], None, w['k_bytes'], executed=True)
+                               w['elapsed'], measured_traffic(dtype, True, 1.0), w['k_bytes'], executed=True)
         out['c5_dfmc'] = {'config': 'BASELINE configs[4]: Dfmc, MovieLens-style 6-relation graph (100k users x 40k movies, ratings '
                                     '98% masked and kept as known-entry lists, five 0/1 relations, two constraints)',
                           'value': 10 / w['elapsed'], 'unit': 'iters/s', 'steps': 10, 'warmup': 3,

@@ -280,7 +280,11 @@ static int pick_splits_bf16(int64_t units, int ktiles, int bm, int64_t out_elems
         if (s > 1 && ktiles / s < 4) break;
         const double rounds = (double)(int64_t)((double)units * s / slots + 0.999999);
         const double t = (rounds < 1.0 ? 1.0 : rounds) * ((ktiles + s - 1) / s + 3) * 1.5 + (s > 1 ? s * per_slice_us : 0.0);
-        if (t < best_t * 0.97) {                                 // more slices only for a clear gain (HBM-bound launches have none)
+        // more slices only for a clear gain (HBM-bound launches have none).  Round 3, profiles/r03_split_margin.txt: with the
+        // margin at 1.0 the model cuts P13 (196 of 256 CUs busy, one slice) into five slices -- inside the iteration that
+        // launch then takes 1.23 ms instead of 1.19 and the fit loses 0.7 %: the 60 idle CUs are not idle, the side
+        // products of the second stream run there.
+        if (t < best_t * 0.97) {
             best_t = t;
             best = s;
         }

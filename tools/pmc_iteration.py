@@ -8,7 +8,8 @@ import sqlite3
 import sys
 
 SETUP = ('fill_uniform', 'to_bf16_kernel<unsigned short>', 'at::native', 'rocclr', 'pack_', 'known_entries', 'sign_flags',
-         'split_to_bf16', 'mask_zero')
+         'split_to_bf16', 'mask_zero', 'csc_sort', 'known_row_', 'known_col_', 'theta_csr_fill', 'theta_row_count', 'bits_row_count',
+         'bits_csr_fill', 'csr_transpose_fill', 'csr_col_count')
 
 
 def short(name):
@@ -36,8 +37,9 @@ def main(root, iters):
             tw += wr
         if rd + wr > 0.005:
             print('%-64s %7d %14.3f %14.3f%s' % (k, n, rd, wr, '   (not summed)' if skip else ''))
-    print('iteration kernels: %.2f GB read + %.2f GB written per iteration; algorithmic (SURVEY 8d, one read of every bf16 '
-          'relation) 22.0 GB -> ratio %.2f' % (tr, tw, (tr + tw) / 22.0))
+    alg = float(os.environ.get('PMC_ALG_GB', '22.0'))
+    print('iteration kernels: %.2f GB read + %.2f GB written per iteration; algorithmic (SURVEY 8d, one read of every '
+          'relation as stored) %.1f GB -> ratio %.2f' % (tr, tw, alg, (tr + tw) / alg))
 
 
 if __name__ == '__main__':
