@@ -1992,7 +1992,7 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
     apply_update(p, st);
 }
 
-// The DFMF iteration of a small graph in four launches (skf_small.h)
+// The DFMF iteration of a small graph in three launches (skf_small.h)
 template <typename T>
 static void iterate_small_fused_t(skf_plan* p, hipStream_t st) {
     const SmTables* tb = (const SmTables*)p->sm_tables.ptr;
@@ -2001,22 +2001,10 @@ static void iterate_small_fused_t(skf_plan* p, hipStream_t st) {
     allow_dynamic_lds(once_u, small_update_kernel<T>, SM_TILE_BYTES);
     hipLaunchKernelGGL((small_contract_kernel<T>), dim3((unsigned)p->sm_j1.size()), dim3(256), SM_TILE_BYTES, st, tb, (const SmJob*)p->sm_jobs1.ptr);
     check_launch("small_contract");
-    {   // what the sweep declined: deflation / eigen-solver / K = Vs V^T in one launch (a no-op otherwise)
-        EighArgs e;
-        e.A = (double*)p->eigA.ptr; e.V = (double*)p->eigV.ptr; e.Vs = (double*)p->eigVs.ptr;
-        e.w = (double*)p->eigW.ptr; e.stride = p->eig_stride; e.wstride = p->eig_maxn;
-        e.n = (const int*)p->eigN.ptr; e.n_orig = (const int*)p->eigNorig.ptr;
-        e.chol_ok = (int*)p->eigOk.ptr;
-        e.max_sweeps = 30;
-        const int lr = p->eig_maxn < PCHOL_LDS_R ? p->eig_maxn : PCHOL_LDS_R;
-        hipLaunchKernelGGL(small_fallback_kernel, dim3((unsigned)p->types.size()), dim3(EIGH_THREADS), (size_t)lr * (lr + 1) / 2 * 8, st, e,
-                           deflation_lo(p->sw), 1e-7, lr, tb);
-        check_launch("small_fallback");
-    }
     static DeviceOnce once;
     constexpr int bb_lds = (2 * 64 + 2 * SM_BK) * SM_LD * 8;
     allow_dynamic_lds(once, small_backbone_kernel, bb_lds);
-    hipLaunchKernelGGL(small_backbone_kernel, dim3((unsigned)p->rels.size()), dim3(256), bb_lds, st, tb);
+    hipLaunchKernelGGL(small_backbone_kernel, dim3((unsigned)(2 * p->rels.size())), dim3(256), bb_lds, st, tb);
     check_launch("small_backbone");
     hipLaunchKernelGGL((small_update_kernel<T>), dim3((unsigned)p->sm_j3.size()), dim3(256), SM_TILE_BYTES, st, tb, (const SmJob*)p->sm_jobs3.ptr);
     check_launch("small_update");
@@ -2879,6 +2867,13 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             tb.eigA = (double*)p->eigA.ptr; tb.eigV = (double*)p->eigV.ptr; tb.eigOk = (int*)p->eigOk.ptr;
             tb.eig_stride = p->eig_stride;
             tb.chol_thr = chol_rel_threshold(p->sw);
+            tb.eig.A = (double*)p->eigA.ptr; tb.eig.V = (double*)p->eigV.ptr; tb.eig.Vs = (double*)p->eigVs.ptr;
+            tb.eig.w = (double*)p->eigW.ptr; tb.eig.stride = p->eig_stride; tb.eig.wstride = p->eig_maxn;
+            tb.eig.n = (const int*)p->eigN.ptr; tb.eig.n_orig = (const int*)p->eigNorig.ptr;
+            tb.eig.chol_ok = (int*)p->eigOk.ptr;
+            tb.eig.max_sweeps = 30;
+            tb.defl_lo = deflation_lo(p->sw); tb.defl_hi = 1e-7;
+            tb.lds_rank = p->eig_maxn < 64 ? p->eig_maxn : 64;          // packed r (r + 1) / 2 doubles inside the staging tiles
             int64_t goff = 0, woff = 0;
             for (size_t i = 0; i < p->types.size(); ++i) {
                 TypeState& t = p->types[i];

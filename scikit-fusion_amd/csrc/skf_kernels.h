@@ -2692,7 +2692,7 @@ __device__ __forceinline__ void pchol_pinv_body(const EighArgs& e, const int b, 
         if (tid == 0) {
             double v = red_v[0];
             int ix = red_i[0];
-            for (int w = 1; w < EIGH_THREADS / 64; ++w)
+            for (int w = 1; w < nt / 64; ++w)
                 if (red_v[w] > v || (red_v[w] == v && red_i[w] >= 0 && (ix < 0 || red_i[w] < ix))) { v = red_v[w]; ix = red_i[w]; }
             s_val = v;
             s_idx = ix;
@@ -2735,7 +2735,7 @@ __device__ __forceinline__ void pchol_pinv_body(const EighArgs& e, const int b, 
     const bool in_lds = r <= lds_rank;          // the launch reserved lds_rank (lds_rank + 1) / 2 doubles of dynamic LDS
     double* Cp = in_lds ? Cs : W;
     const int nel = r * (r + 1) / 2;
-    for (int el = wave; el < nel; el += EIGH_THREADS / 64) {
+    for (int el = wave; el < nel; el += nt / 64) {
         int a = (int)((sqrt(8.0 * el + 1.0) - 1.0) * 0.5);
         while ((a + 1) * (a + 2) / 2 <= el) ++a;
         while (a * (a + 1) / 2 > el) --a;

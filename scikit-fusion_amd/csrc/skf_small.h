@@ -1,5 +1,5 @@
 // skf_small.h -- the DFMF iteration of a SMALL graph (every rank <= 64, a few thousand objects per type: the reference's
-// own examples, BASELINE configs[0] / [1]) in four launches instead of ~33.
+// own examples, BASELINE configs[0] / [1]) in three launches instead of ~33.
 //
 // On such graphs an iteration is a chain of dependent launches of a few microseconds each -- launch latency, not
 // arithmetic (dicty: 0.30 ms for 80 MFLOP on the general schedule).  Here the chain is
@@ -8,10 +8,10 @@
 //                             the LAST Gram share of a type sums the shares and inverts the matrix (sweep operator, the
 //                             matrix in registers) while P / Q jobs are still in flight; the one that finishes the last P
 //                             job of a relation sums W.                              (_dfmf.py:228-232, 254, 266, 284-292)
-//   2 small_fallback_kernel   a no-op unless a sweep declined its matrix: deflation / Jacobi eigen-solver / K = Vs V^T
-//   3 small_backbone_kernel   one workgroup per relation: S = K_i W K_j and the +- parts of S Gram_j S^T, S^T Gram_i S
+//                             A declined sweep (rank-deficient Gram matrix) falls back to deflation / eigen-solver there.
+//   2 small_backbone_kernel   two workgroups per relation: S = K_i W K_j and the +- parts of S Gram_j S^T | S^T Gram_i S
 //                                                                                                 (:236-239, 260-276)
-//   4 small_update_kernel     per (type, 64 rows): the relation terms of E and D -- row sides, column sides, type term --
+//   3 small_update_kernel     per (type, 64 rows): the relation terms of E and D -- row sides, column sides, type term --
 //                             in registers, the constraint terms added, G <- G sqrt(E / D) written in place  (:254-296)
 // Same arithmetic as the general schedule (f64 c x c algebra, master-type n-sized products, nan_to_num where the
 // reference has it); only the order of the sums differs.
@@ -45,6 +45,9 @@ struct SmTables {
     int* tickets;                // [n_types + n_rels] finished Gram jobs per type / P jobs per relation (zero between launches)
     double* eigA; double* eigV; int* eigOk; int64_t eig_stride;
     double chol_thr;
+    EighArgs eig;                // the fall-back of a declined sweep: deflation / eigen-solver scratch of the plan
+    double defl_lo, defl_hi;
+    int lds_rank, pad;
     SmType t[SM_MAXT];
     SmRel r[SM_MAXR];
     SmTheta th[SM_MAXTH];
@@ -137,6 +140,36 @@ struct SmTile {
     }
 };
 
+// What the sweep declined: rank-revealing deflation, then the Jacobi eigen-solver for what that declines too, then
+// K = Vs V^T -- the three fall-back launches of the general schedule (pchol_pinv_kernel, jacobi_eigh_kernel,
+// eigh_unpack_pinv_batched_kernel) run by the workgroup that holds the matrix, inside launch 1.  Rare (a rank-deficient
+// Gram matrix) and slow (milliseconds): the rest of the launch does not wait for it, the next launch does.
+__device__ __forceinline__ void small_fallback_body(const SmTables* __restrict__ tb, const int b) {
+    const EighArgs& e = tb->eig;
+    const SmType& ty = tb->t[b];
+    const int n = ty.c, n_pad = e.n[b];
+    {   // the packed, zero-padded copy of the Gram matrix the fall-back kernels work on
+        double* A = e.A + (int64_t)b * e.stride;
+        for (int idx = threadIdx.x; idx < n_pad * n_pad; idx += blockDim.x) {
+            const int r = idx / n_pad, c = idx % n_pad;
+            A[idx] = (r < n && c < n) ? ty.Gram[r * n + c] : 0.0;
+        }
+        __syncthreads();
+    }
+    pchol_pinv_body(e, b, tb->defl_lo, tb->defl_hi, tb->lds_rank);
+    __syncthreads();
+    jacobi_eigh_body(e, b);
+    __syncthreads();
+    const double* Vs = e.Vs + (int64_t)b * e.stride;
+    const double* V = e.V + (int64_t)b * e.stride;
+    for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+        const int r = idx / n, c = idx % n;
+        double s2 = 0.0;
+        for (int k = 0; k < n_pad; ++k) s2 += Vs[r * n_pad + k] * V[c * n_pad + k];
+        ty.K[(int64_t)r * n + c] = s2;
+    }
+}
+
 // ---- 1b -----------------------------------------------------------------------------------------------------------
 // p[0] + p[stride] + ... (count terms) in a fixed order, four independent chains so that the loads overlap
 __device__ __forceinline__ double sum_shares(const double* __restrict__ p, int64_t stride, int count) {
@@ -160,7 +193,7 @@ __device__ __forceinline__ double sum_shares(const double* __restrict__ p, int64
 // there is ONE barrier.  (A one-wave Cholesky whose every inner product is a chain of LDS round trips: 91 us at order
 // 50; the sweep with the matrix in LDS, 12 LDS reads per thread and step: 52 us; this form: see profiles/.)
 // The pivot of step k is the Schur complement the Cholesky factorisation would take the root of: same verdict, same
-// thresholds as chol_inverse_small_kernel; a failed pivot leaves the matrix to small_fallback_kernel.
+// thresholds as chol_inverse_small_kernel; a failed pivot leaves the matrix to small_fallback_body.
 constexpr int SM_PINV_THREADS = 256;
 // (M: 64 x SM_LD doubles of LDS, free to clobber -- the staging tiles of the calling workgroup)
 __device__ __forceinline__ void small_pinv_body(const SmTables* __restrict__ tb, const int t, double* M) {
@@ -249,6 +282,10 @@ __device__ __forceinline__ void small_pinv_body(const SmTables* __restrict__ tb,
                 if (i0 + a < n && j0 + b < n) ty.K[(i0 + a) * n + j0 + b] = -m[a][b];
     }
     if (tid == 0) tb->eigOk[t] = ok;
+    if (!ok) {                                                     // (uniform)
+        __syncthreads();                                           // the verdict is in memory before the bodies read it
+        small_fallback_body(tb, t);
+    }
 }
 
 // true in every thread of the LAST workgroup to get here out of `total` (the others' global writes are visible to it);
@@ -343,46 +380,16 @@ __global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* __r
     }
 }
 
-// ---- 3 ------------------------------------------------------------------------------------------------------------
-// What the sweep declined (a verdict other than 1), one workgroup per type and a no-op otherwise: rank-revealing
-// deflation, then the Jacobi eigen-solver for what that declines too, then K = Vs V^T -- the three fall-back launches of
-// the general schedule (pchol_pinv_kernel, jacobi_eigh_kernel, eigh_unpack_pinv_batched_kernel) as one.
-__global__ __launch_bounds__(EIGH_THREADS) void small_fallback_kernel(EighArgs e, double lo, double hi, int lds_rank,
-                                                                      const SmTables* __restrict__ tb) {
-    const int b = blockIdx.x;
-    if (e.chol_ok[b] == 1) return;
-    {   // the packed, zero-padded copy of the Gram matrix the fall-back kernels work on
-        const SmType& ty = tb->t[b];
-        const int n = ty.c, n_pad = e.n[b];
-        double* A = e.A + (int64_t)b * e.stride;
-        for (int idx = threadIdx.x; idx < n_pad * n_pad; idx += blockDim.x) {
-            const int r = idx / n_pad, c = idx % n_pad;
-            A[idx] = (r < n && c < n) ? ty.Gram[r * n + c] : 0.0;
-        }
-        __syncthreads();
-    }
-    pchol_pinv_body(e, b, lo, hi, lds_rank);
-    __syncthreads();
-    jacobi_eigh_body(e, b);
-    __syncthreads();
-    const SmType& ty = tb->t[b];
-    const int n = ty.c, n_pad = e.n[b];
-    const double* Vs = e.Vs + (int64_t)b * e.stride;
-    const double* V = e.V + (int64_t)b * e.stride;
-    for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
-        const int r = idx / n, c = idx % n;
-        double s = 0.0;
-        for (int k = 0; k < n_pad; ++k) s += Vs[r * n_pad + k] * V[c * n_pad + k];
-        ty.K[(int64_t)r * n + c] = s;
-    }
-}
-
 // ---- 6 ------------------------------------------------------------------------------------------------------------
-// one workgroup per relation: six c x c x c products on the f64 matrix cores, operands and intermediates in LDS
-// (dynamic LDS: 3 x 64 x 65 doubles + the two staging tiles of SmTile)
+// TWO workgroups per relation, each a chain of four c x c x c products on the f64 matrix cores with operands and
+// intermediates in LDS: both form S = K_i W K_j (the same instructions on the same data: bit-identical), the even one goes
+// on to the +- parts of S Gram_j S^T (row type) and writes S, the odd one to those of S^T Gram_i S (column type) -- the two
+// branches are independent, so the dependent chain is four products deep instead of six.
+// (dynamic LDS: 2 x 64 x 65 doubles + the two staging tiles of SmTile)
 __global__ __launch_bounds__(256) void small_backbone_kernel(const SmTables* __restrict__ tb) {
     HIP_DYNAMIC_SHARED(double, sm)
-    const SmRel& r = tb->r[blockIdx.x];
+    const SmRel& r = tb->r[blockIdx.x >> 1];
+    const bool col_side = (blockIdx.x & 1) != 0;
     const SmType& ti = tb->t[r.row];
     const SmType& tj = tb->t[r.col];
     const int ci = ti.c, cj = tj.c, tid = threadIdx.x;
@@ -403,24 +410,26 @@ __global__ __launch_bounds__(256) void small_backbone_kernel(const SmTables* __r
     t.for_each([&](int a, int b, double v) {
         v = nan_to_num(v);
         S[a * SM_LD + b] = (a < ci && b < cj) ? v : 0.0;
-        if (a < ci && b < cj) r.S[a * cj + b] = v;
+        if (!col_side && a < ci && b < cj) r.S[a * cj + b] = v;
     });
     __syncthreads();
-    // U = S Gram_j ; B = U S^T, split                                                                 (_dfmf.py:260-264)
-    t.zero();
-    t.mma(cj, [&](int a, int k) { return S[a * SM_LD + k]; }, [&](int k, int b) { return b < cj ? tj.Gram[k * cj + b] : 0.0; }, true, As, Bs);
-    t.for_each([&](int a, int b, double v) { X[a * SM_LD + b] = v; });
-    __syncthreads();
-    t.zero();
-    t.mma(cj, [&](int a, int k) { return X[a * SM_LD + k]; }, [&](int k, int c2) { return S[c2 * SM_LD + k]; }, true, As, Bs);
-    __syncthreads();                      // (every wave is done reading X)
-    t.for_each([&](int a, int c2, double v) {
-        if (a < ci && c2 < ci) {
-            if (tb->nan_upd) v = nan_to_num(v);
-            r.Bp[a * ci + c2] = v > 0.0 ? v : 0.0;
-            r.Bn[a * ci + c2] = v > 0.0 ? 0.0 : -v;
-        }
-    });
+    if (!col_side) {
+        // U = S Gram_j ; B = U S^T, split                                                             (_dfmf.py:260-264)
+        t.zero();
+        t.mma(cj, [&](int a, int k) { return S[a * SM_LD + k]; }, [&](int k, int b) { return b < cj ? tj.Gram[k * cj + b] : 0.0; }, true, As, Bs);
+        t.for_each([&](int a, int b, double v) { X[a * SM_LD + b] = v; });
+        __syncthreads();
+        t.zero();
+        t.mma(cj, [&](int a, int k) { return X[a * SM_LD + k]; }, [&](int k, int c2) { return S[c2 * SM_LD + k]; }, true, As, Bs);
+        t.for_each([&](int a, int c2, double v) {
+            if (a < ci && c2 < ci) {
+                if (tb->nan_upd) v = nan_to_num(v);
+                r.Bp[a * ci + c2] = v > 0.0 ? v : 0.0;
+                r.Bn[a * ci + c2] = v > 0.0 ? 0.0 : -v;
+            }
+        });
+        return;
+    }
     // U = Gram_i S ; D = S^T U, split                                                                 (_dfmf.py:272-276)
     t.zero();
     t.mma(ci, [&](int a, int k) { return a < ci ? ti.Gram[a * ci + k] : 0.0; }, [&](int k, int b) { return S[k * SM_LD + b]; }, true, As, Bs);

@@ -165,6 +165,16 @@ def test_c2_dicty_first_iteration_f64():
 
 
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_small_graph_schedule_on_an_awkward_graph(dtype, monkeypatch):
+    """tests/small_cases.py: every job kind of skf_small.h on sizes that fit no tile; four-launch schedule vs the oracle
+    and vs the general schedule."""
+    import small_cases
+    worst_o, worst_s = small_cases.check(dtype, monkeypatch)
+    assert worst_o < (1e-10 if dtype == 'f64' else 2e-4)
+    assert worst_s < (1e-11 if dtype == 'f64' else 2e-4)
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
 def test_device_squared_error_on_unaligned_shapes(dtype):
     """skf_relation_sqerr sizes one partial per workgroup of the tile the product runs on: the dicty relations (1219 x 116
     and 1219 x 282 at ranks 50 / 15 / 5: nothing divisible by the vector widths) take the small tile with run-time

@@ -371,6 +371,17 @@ def test_c2_dicty_dfmf_100_iterations_f64_and_f32(schedule, monkeypatch):
 
 
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_small_graph_schedule_on_an_awkward_graph(dtype, monkeypatch):
+    """tests/small_cases.py: every job kind of skf_small.h on sizes that fit no tile (5 / 70 / 130 / 257 objects, ranks
+    1 / 7 / 33 / 64, a multi-relation, several sparse constraints per type, empty rows); 10 iterations of the small-graph
+    schedule vs the oracle and vs the general schedule."""
+    import small_cases
+    worst_o, worst_s = small_cases.check(dtype, monkeypatch, iters=10)
+    within(worst_o, 1e-9 if dtype == 'f64' else 2e-3, 'awkward small graph %s: small-graph schedule vs oracle, 10 iterations' % dtype)
+    within(worst_s, 1e-10 if dtype == 'f64' else 2e-3, 'awkward small graph %s: small-graph vs general schedule' % dtype)
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
 def test_device_squared_error_on_unaligned_shapes(dtype):
     """skf_relation_sqerr sizes one partial per workgroup of the tile the product runs on; dicty's shapes (1219 x 116,
     1219 x 282, ranks 50 / 15 / 5) take the small tile with run-time staging modes.  Device value vs host arithmetic."""
