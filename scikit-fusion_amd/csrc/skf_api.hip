@@ -2514,7 +2514,9 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         {
             bool ok = p->variant == SKF_DFMF && p->engine == SKF_ENGINE_MFMA && !p->bf16 && !p->sliced && n_types <= SM_MAXT &&
                       n_relations >= 1 && n_relations <= SM_MAXR && n_thetas <= SM_MAXTH;
-            for (const TypeState& t : p->types) ok = ok && t.c <= SMALLC && t.n <= 65536;
+            // (object counts: the Q shares of the schedule grow with n_i / 256 * n_j * c_i, and from a few thousand objects
+            // on the relation contractions are worth the big tiles of the general schedule)
+            for (const TypeState& t : p->types) ok = ok && t.c <= SMALLC && t.n <= 8192;
             for (const ThetaState& th : p->thetas) ok = ok && th.sparse;
             for (const RelState& r : p->rels) ok = ok && !r.absent && !r.masked;
             p->small_fused = ok;
