@@ -1942,11 +1942,21 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
     for (size_t q = 0; q < nr; ++q) {
         RelState& r = p->rels[order[q]];
         if (dfmc && r.masked) continue;
+        // W through the shorter of the two object dimensions: G_i^T P sums over the rows of the relation, Q^T G_j over its
+        // columns (config 3, 100k x 40k: 0.32 -> 0.13 ms).  The Q form has to wait for Q, so the relation's chain then runs
+        // under the NEXT relation's contractions instead of its own Q -- not for the last relation, whose tail it would grow.
+        const bool w_by_q = (q + 1 < nr) && 5 * p->types[r.col].n <= 3 * r.nr;
         contraction_P(p, r, st);
-        w_product(r, false);
-        SKF_HIP(hipEventRecord(p->ev_rel[4 * q], st));
+        if (!w_by_q) {
+            w_product(r, false);
+            SKF_HIP(hipEventRecord(p->ev_rel[4 * q], st));
+        }
         contraction_Q(p, r, st);
         SKF_HIP(hipEventRecord(p->ev_rel[4 * q + 3], st));
+        if (w_by_q) {
+            w_product(r, true);
+            SKF_HIP(hipEventRecord(p->ev_rel[4 * q], st));
+        }
         backbone_chain(q);
         side_products(q, 4 * q);
     }
