@@ -163,6 +163,15 @@ int skf_get_backbone(const skf_plan* plan, int32_t rel, void* S, int64_t ld, voi
  * and get_factor the factors AFTER it -- the same generation mismatch the reference returns
  * (_dfmf.py:239 vs :295, return :327). */
 int skf_iterate(skf_plan* plan, int32_t n_iters, void* stream);
+/* The same for `n_plans` (1 .. 64) plans of ONE graph at once -- independent random restarts (the reference's n_run loop
+ * over joblib workers, dfmf.py:87-95) of a graph too small to fill the chip: every launch of the iteration serves all of
+ * them (the restart is a grid dimension), so ten restarts of the dicty graph cost little more than one.  The plans must
+ * have been created from the same object types, ranks, relation shapes and engine and must run the schedule for small
+ * graphs (SKF_DFMF, every rank <= 64, sparse constraints, at most 8192 objects per type); each keeps its own workspace,
+ * factors and results, exactly as after skf_iterate.  SKF_E_STATE when the plans do not batch: iterate them one by one. */
+int skf_iterate_batch(skf_plan* const* plans, int32_t n_plans, int32_t n_iters, void* stream);
+/* *yes = 1 when the (bound) plan runs the schedule for small graphs, i.e. can be one of the plans of skf_iterate_batch. */
+int skf_plan_batchable(const skf_plan* plan, int32_t* yes);
 /* enable != 0: iterations 2..n of skf_iterate replay ONE captured hipGraph (a single host call per
  * iteration instead of one per kernel).  Off by default -- a single fit is bound by kernel time --
  * and switched on for restarts that run CONCURRENTLY on several streams of one GPU, where the

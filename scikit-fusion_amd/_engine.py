@@ -360,6 +360,29 @@ class DevicePlan(object):
     def iterate(self, n_iters=1):
         self.rt.call('skf_iterate', self.handle, int(n_iters), self.stream)
 
+    def batchable(self):
+        """True when this plan can be one of the plans of iterate_batch (the schedule for small graphs)."""
+        yes = C.c_int32(0)
+        self.rt.call('skf_plan_batchable', self.handle, C.byref(yes))
+        return bool(yes.value)
+
+    @staticmethod
+    def iterate_batch(plans, n_iters=1):
+        """`n_iters` iterations of several plans of ONE graph at once (skf_iterate_batch: independent restarts of a small
+        graph, every launch serving all of them) on the stream of the first plan.  Returns False, with nothing launched,
+        when the plans do not batch (not the small-graph schedule, different graphs / engines): iterate them one by
+        one."""
+        plans = list(plans)
+        first = plans[0]
+        arr = (nat._P * len(plans))(*[p.handle for p in plans])
+        try:
+            first.rt.call('skf_iterate_batch', arr, len(plans), int(n_iters), first.stream)
+        except nat.SkfNativeError as exc:
+            if exc.code == nat.SKF_E_STATE:
+                return False
+            raise
+        return True
+
     def synchronize(self):
         self.rt.mem.synchronize()
 
@@ -539,6 +562,7 @@ def upload_graph(rel_list, theta_list, dtype, runtime=None):
         if not isinstance(data, DeviceMatrix):
             arr = np.ascontiguousarray(data, dtype=npd)
             data = DeviceMatrix(rt.mem.from_host(arr), arr.shape)
+            data.nnz = int(np.count_nonzero(arr))          # (as DevicePlan counts a host array: the same path either way)
         thetas.append((t, data))
     return rels, thetas
 

@@ -17,6 +17,7 @@ SKF_ENGINE_MFMA, SKF_ENGINE_VALU = 0, 1
 SKF_REL_ABSENT, SKF_REL_NO_COL_SIDE, SKF_REL_MASKED, SKF_REL_MASK_BITS, SKF_REL_BINARY = 1, 2, 4, 8, 16
 SKF_STAGE_CONTRACT, SKF_STAGE_BACKBONE, SKF_STAGE_ACCUMULATE, SKF_STAGE_UPDATE = 0, 1, 2, 3
 SKF_X_W, SKF_X_Q, SKF_X_QM, SKF_X_ED = 0, 1, 2, 3
+SKF_OK, SKF_E_INVALID, SKF_E_STATE, SKF_E_WORKSPACE, SKF_E_HIP = 0, -1, -2, -3, -4
 
 DTYPES = {'f64': SKF_F64, 'f32': SKF_F32, 'bf16': SKF_BF16, 'float64': SKF_F64, 'float32': SKF_F32}
 NP_DTYPE = {SKF_F64: np.float64, SKF_F32: np.float32, SKF_BF16: np.float32}   # dtype of the masters
@@ -90,6 +91,8 @@ SIGNATURES = {
     'skf_set_backbone': (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
     'skf_get_backbone': (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
     'skf_iterate': (C.c_int, [_P, C.c_int32, _P]),
+    'skf_iterate_batch': (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, _P]),
+    'skf_plan_batchable': (C.c_int, [_P, C.POINTER(C.c_int32)]),
     'skf_plan_set_graph': (C.c_int, [_P, C.c_int32]),
     'skf_accumulate': (C.c_int, [_P, _P]),
     'skf_apply_update': (C.c_int, [_P, _P]),

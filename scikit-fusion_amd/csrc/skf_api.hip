@@ -300,6 +300,7 @@ static int bf16_block_rows(int M, bool at) { return (at || M >= 4096) ? 256 : 12
 // code object on one device: a process that drives several GPUs sets it on each), safe against the concurrent host
 // threads of run_fits_concurrent (one plan per thread)
 constexpr int SKF_MAX_DEVICES = 64;
+constexpr int SKF_MAX_BATCH = 64;        // plans of one skf_iterate_batch call
 struct DeviceOnce {
     std::once_flag flag[SKF_MAX_DEVICES];
 };
@@ -595,7 +596,8 @@ struct skf_plan {
     bool kn_first = true;                  // no residuals stored yet: E = the known entries themselves, S_prev = 0
     // small graphs (skf_small.h): the whole DFMF iteration as eight launches over job tables kept in the workspace
     bool small_fused = false;
-    skf::Slot sm_tables, sm_jobs1, sm_jobs3, sm_wpart, sm_gpart, sm_tickets;
+    skf::Slot sm_tables, sm_jobs1, sm_jobs3, sm_wpart, sm_gpart, sm_tickets, sm_batch;
+    std::vector<const void*> sm_batch_host;        // device addresses of the tables of the plans of the last batch (this plan first)
     std::vector<skf::SmJob> sm_j1, sm_j3;
     ~skf_plan() {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -2002,21 +2004,22 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
     apply_update(p, st);
 }
 
-// The DFMF iteration of a small graph in three launches (skf_small.h)
+// The DFMF iteration of a small graph in three launches (skf_small.h); n_batch > 1: of that many plans of the same graph at
+// once -- independent restarts side by side, blockIdx.y = the plan (skf_iterate_batch; p->sm_batch holds their tables)
 template <typename T>
-static void iterate_small_fused_t(skf_plan* p, hipStream_t st) {
-    const SmTables* tb = (const SmTables*)p->sm_tables.ptr;
+static void iterate_small_fused_t(skf_plan* p, hipStream_t st, unsigned n_batch = 1) {
+    const SmTables* const* tbs = (const SmTables* const*)p->sm_batch.ptr;
     static DeviceOnce once_c, once_u;
     allow_dynamic_lds(once_c, small_contract_kernel<T>, SM_TILE_BYTES);
     allow_dynamic_lds(once_u, small_update_kernel<T>, SM_TILE_BYTES);
-    hipLaunchKernelGGL((small_contract_kernel<T>), dim3((unsigned)p->sm_j1.size()), dim3(256), SM_TILE_BYTES, st, tb, (const SmJob*)p->sm_jobs1.ptr);
+    hipLaunchKernelGGL((small_contract_kernel<T>), dim3((unsigned)p->sm_j1.size(), n_batch), dim3(256), SM_TILE_BYTES, st, tbs, (const SmJob*)p->sm_jobs1.ptr);
     check_launch("small_contract");
     static DeviceOnce once;
     constexpr int bb_lds = (2 * 64 + 2 * SM_BK) * SM_LD * 8;
     allow_dynamic_lds(once, small_backbone_kernel, bb_lds);
-    hipLaunchKernelGGL(small_backbone_kernel, dim3((unsigned)(2 * p->rels.size())), dim3(256), bb_lds, st, tb);
+    hipLaunchKernelGGL(small_backbone_kernel, dim3((unsigned)(2 * p->rels.size()), n_batch), dim3(256), bb_lds, st, tbs);
     check_launch("small_backbone");
-    hipLaunchKernelGGL((small_update_kernel<T>), dim3((unsigned)p->sm_j3.size()), dim3(256), SM_TILE_BYTES, st, tb, (const SmJob*)p->sm_jobs3.ptr);
+    hipLaunchKernelGGL((small_update_kernel<T>), dim3((unsigned)p->sm_j3.size(), n_batch), dim3(256), SM_TILE_BYTES, st, tbs, (const SmJob*)p->sm_jobs3.ptr);
     check_launch("small_update");
     p->first_iter = false;
 }
@@ -2572,6 +2575,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 add_slot(p, p->sm_wpart, wdoubles * 8);
                 add_slot(p, p->sm_gpart, gdoubles * 8);
                 add_slot(p, p->sm_tickets, (p->types.size() + p->rels.size()) * sizeof(int));
+                add_slot(p, p->sm_batch, SKF_MAX_BATCH * sizeof(void*));          // table of tables: [0] = this plan's
             }
         }
         size_t theta_tmp_bytes = 0;
@@ -2909,6 +2913,8 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
                 tb.th[k].type = th.type;
             }
             SKF_HIP(hipMemcpyAsync(p->sm_tables.ptr, &tb, sizeof tb, hipMemcpyHostToDevice, st));
+            p->sm_batch_host.assign(1, p->sm_tables.ptr);
+            SKF_HIP(hipMemcpyAsync(p->sm_batch.ptr, p->sm_batch_host.data(), sizeof(void*), hipMemcpyHostToDevice, st));
             SKF_HIP(hipMemcpyAsync(p->sm_jobs1.ptr, p->sm_j1.data(), p->sm_j1.size() * sizeof(SmJob), hipMemcpyHostToDevice, st));
             SKF_HIP(hipMemcpyAsync(p->sm_jobs3.ptr, p->sm_j3.data(), p->sm_j3.size() * sizeof(SmJob), hipMemcpyHostToDevice, st));
             SKF_HIP(hipStreamSynchronize(st));     // (`tb` dies here; bind is not on the hot path)
@@ -3036,6 +3042,48 @@ int skf_iterate(skf_plan* p, int32_t n_iters, void* stream) {
             }
             for (; it < n_iters; ++it) iterate_fit(p, st);
         }
+    });
+}
+
+int skf_iterate_batch(skf_plan* const* plans, int32_t n_plans, int32_t n_iters, void* stream) {
+    return guarded([&] {
+        if (!plans || n_plans < 1 || n_plans > SKF_MAX_BATCH) SKF_FAIL(SKF_E_INVALID, "1 .. %d plans", SKF_MAX_BATCH);
+        if (n_iters < 0) SKF_FAIL(SKF_E_INVALID, "n_iters < 0");
+        skf_plan* p0 = plans[0];
+        for (int k = 0; k < n_plans; ++k) {
+            skf_plan* p = plans[k];
+            check_bound(p);
+            for (size_t i = 0; i < p->types.size(); ++i)
+                if (!p->types[i].set) SKF_FAIL(SKF_E_STATE, "plan %d: factor of object type %zu not set", k, i);
+            // one launch serves every plan: same graph (identical job tables), same engine, the small-graph schedule
+            if (!p->small_fused || p->f64 != p0->f64 || p->sm_j1.size() != p0->sm_j1.size() || p->sm_j3.size() != p0->sm_j3.size() ||
+                p->rels.size() != p0->rels.size() ||
+                memcmp(p->sm_j1.data(), p0->sm_j1.data(), p0->sm_j1.size() * sizeof(SmJob)) != 0 ||
+                memcmp(p->sm_j3.data(), p0->sm_j3.data(), p0->sm_j3.size() * sizeof(SmJob)) != 0)
+                SKF_FAIL(SKF_E_STATE, "plan %d does not batch with plan 0 (small-graph schedule, same graph and engine required)", k);
+            for (int q = 0; q < k; ++q)
+                if (plans[q] == p) SKF_FAIL(SKF_E_INVALID, "plan %d listed twice", k);
+        }
+        hipStream_t st = as_stream(stream);
+        std::vector<const void*> tabs((size_t)n_plans);
+        for (int k = 0; k < n_plans; ++k) tabs[(size_t)k] = plans[k]->sm_tables.ptr;
+        if (tabs != p0->sm_batch_host) {                  // (the table of tables lives in plan 0's workspace; [0] stays plan 0's own)
+            p0->sm_batch_host = tabs;
+            SKF_HIP(hipMemcpyAsync(p0->sm_batch.ptr, p0->sm_batch_host.data(), tabs.size() * sizeof(void*), hipMemcpyHostToDevice, st));
+        }
+        for (int it = 0; it < n_iters; ++it) {
+            if (p0->f64) iterate_small_fused_t<double>(p0, st, (unsigned)n_plans);
+            else iterate_small_fused_t<float>(p0, st, (unsigned)n_plans);
+        }
+        for (int k = 0; k < n_plans; ++k) plans[k]->first_iter = false;
+    });
+}
+
+int skf_plan_batchable(const skf_plan* p, int32_t* yes) {
+    return guarded([&] {
+        check_bound(p);
+        if (!yes) SKF_FAIL(SKF_E_INVALID, "null pointer");
+        *yes = p->small_fused ? 1 : 0;
     });
 }
 

@@ -198,11 +198,13 @@ def run_fit_sharded(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, in
 
 
 def run_fits_concurrent(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, dtype, G0_list, engine,
-                        n_streams):
-    """The restarts of ONE graph on one GPU, `n_streams` of them at a time, each on a HIP stream of its own
-    -- the reference's `n_jobs` over `n_run` (joblib workers, dfmf.py:87-95) for graphs too small to
-    fill the chip: a single fit is then a chain of dependent few-microsecond launches, and several
-    chains interleave on the device.  The graph is uploaded once and shared; one host thread per
+                        n_streams, batch_only=False):
+    """The restarts of ONE graph on one GPU, `n_streams` of them at a time -- the reference's `n_jobs` over `n_run`
+    (joblib workers, dfmf.py:87-95) for graphs too small to fill the chip.  Where the plans run the schedule for small
+    graphs the restarts of a batch share every launch (skf_iterate_batch: the restart is a grid dimension); otherwise each
+    runs on a HIP stream of its own: a single fit is then a chain of dependent few-microsecond launches, and several
+    chains interleave on the device.  batch_only: None (nothing run) unless the plans take the small-graph schedule -- the
+    caller asked for no concurrency (n_jobs = 1) and gets the shared launches only where they are free.  The graph is uploaded once and shared; one host thread per
     stream issues the launches.  Returns
     [(G, S)] in run order; results are identical to sequential runs (each plan is deterministic)."""
     from ..._engine import upload_graph
@@ -219,9 +221,14 @@ def run_fits_concurrent(variant, R, M, Theta, obj_types, obj_type2rank, max_iter
                 plan = DevicePlan(obj_types, n_obj, obj_type2rank, rel_list, theta_list, variant, dtype=dtype,
                                   engine=engine, stream=rt.mem.new_stream() if own_streams else None)
                 plans.append(plan)
+                if batch_only and not plan.batchable():        # (decided on the first plan, before a second workspace exists)
+                    return None
                 for t in obj_types:
                     plan.set_factor(t, G0[t, t])
-            if own_streams and len(plans) > 1:
+            rt.mem.synchronize()                               # the uploads went out on the plans' own streams
+            if len(plans) > 1 and DevicePlan.iterate_batch(plans, max_iter):
+                pass      # a small graph: every launch served all the restarts of the batch (skf_iterate_batch), one stream
+            elif own_streams and len(plans) > 1:
                 # one host thread per stream feeds the launches (ctypes releases the GIL inside skf_iterate;
                 # a plan is only ever touched by its own thread); the streams run side by side
                 import threading

@@ -92,6 +92,15 @@ def concurrent_streams(fuser):
     return min(fuser.n_run, 16 if nj < 0 else int(nj), 16)
 
 
+def shared_launches(fuser):
+    """Several restarts, the plain loop, one GPU: candidates for skf_iterate_batch (every launch serves all restarts of a
+    small graph; results identical to one restart after the other, so `n_jobs` need not ask for it)."""
+    from ..._distributed import world
+    if fuser.n_run < 2 or fuser.callback or fuser.stopping or fuser.stopping_system or fuser.compute_err:
+        return False
+    return fuser.shard == 'runs' and world()[1] <= 1 and fuser.dtype in ('f64', 'f32')
+
+
 def store_runs(fuser, runs):
     """(G, S) per run -> factors_[object_type][run], backbones_[relation][run]
     (dfmf.py:97-105)."""
@@ -139,6 +148,13 @@ class Dfmf(FusionFit):
         if self.shard in ('relations', 'rows'):                   # all GPUs cooperate on every restart
             store_runs(self, [_dfmf.dfmf(G0=G0[k], shard=self.shard, **kw) for k in range(self.n_run)])
             return self
+        if shared_launches(self):                       # restarts of a SMALL graph share their launches, whatever n_jobs says
+            from ... import _native as nat
+            runs = _dfmf.run_fits_concurrent(nat.SKF_DFMF, R, None, Theta, object_types, rank, self.max_iter, self.dtype,
+                                             G0, None, min(self.n_run, 32), batch_only=True)
+            if runs is not None:
+                store_runs(self, runs)
+                return self
         n_streams = concurrent_streams(self)
         if n_streams:                                   # n_jobs restarts side by side on this GPU
             from ... import _native as nat

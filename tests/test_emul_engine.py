@@ -165,6 +165,47 @@ def test_c2_dicty_first_iteration_f64():
 
 
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_batched_restarts_are_the_individual_runs(dtype):
+    """skf_iterate_batch: three restarts of the README graph share every launch (the restart is a grid dimension); each
+    plan ends with exactly the factors and backbones of its own skf_iterate run.  A plan that does not take the
+    small-graph schedule is refused (SKF_E_STATE -> False)."""
+    from skfusion_amd._engine import DevicePlan, flatten_relations
+    R, types, rank = readme_graph()
+    n = {'t1': 50, 't2': 100, 't3': 40}
+    rel = flatten_relations(R)
+    rs = np.random.RandomState(3)
+    starts = [{t: rs.rand(n[t], rank[t]) for t in types} for _ in range(3)]
+
+    def make(G0, dt=dtype):
+        plan = DevicePlan(types, n, rank, rel, [], nat.SKF_DFMF, dtype=dt)
+        for t in types:
+            plan.set_factor(t, G0[t])
+        return plan
+    alone = []
+    for G0 in starts:
+        plan = make(G0)
+        assert plan.batchable()
+        plan.iterate(4)
+        alone.append(([plan.get_factor(t) for t in types], [plan.get_backbone(k) for k in range(len(rel))]))
+        plan.close()
+    plans = [make(G0) for G0 in starts]
+    assert DevicePlan.iterate_batch(plans, 3)
+    plans[1].iterate(1)                                    # a batched plan goes on alone ...
+    assert DevicePlan.iterate_batch([plans[2], plans[0]], 1)      # ... and in another batch, in another order
+    for plan, (G, S) in zip(plans, alone):
+        for t, g in zip(types, G):
+            np.testing.assert_array_equal(plan.get_factor(t), g)
+        for k, sk in enumerate(S):
+            np.testing.assert_array_equal(plan.get_backbone(k), sk)
+    other = make(starts[0], 'bf16')                        # the bf16 engine has no small-graph schedule
+    assert not other.batchable() and not DevicePlan.iterate_batch([plans[0], other], 1)
+    with pytest.raises(nat.SkfNativeError):
+        DevicePlan.iterate_batch([plans[0], plans[0]], 1)
+    for plan in plans + [other]:
+        plan.close()
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
 def test_small_graph_schedule_on_an_awkward_graph(dtype, monkeypatch):
     """tests/small_cases.py: every job kind of skf_small.h on sizes that fit no tile; four-launch schedule vs the oracle
     and vs the general schedule."""

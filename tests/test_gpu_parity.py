@@ -371,6 +371,39 @@ def test_c2_dicty_dfmf_100_iterations_f64_and_f32(schedule, monkeypatch):
 
 
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_batched_restarts_are_the_individual_runs(dtype):
+    """skf_iterate_batch on the hardware: eight restarts of the dicty graph (sparse ppi constraint) share every launch;
+    each plan ends with exactly the factors and backbones of its own skf_iterate run (bit for bit: the restart is a grid
+    dimension, nothing else changes)."""
+    from skfusion_amd._engine import flatten_relations, flatten_thetas, upload_graph
+    R, Theta, types, rank = dicty_graph()
+    n = {'gene': R['gene', 'go'][0].shape[0], 'go': R['gene', 'go'][0].shape[1], 'exc': R['gene', 'exc'][0].shape[1]}
+    rel, thetas = upload_graph(flatten_relations(R), flatten_thetas(Theta), dtype)
+    rs = np.random.RandomState(11)
+    starts = [{t: rs.rand(n[t], rank[t]) + 0.01 for t in types} for _ in range(8)]
+
+    def make(G0):
+        plan = DevicePlan(types, n, rank, rel, thetas, nat.SKF_DFMF, dtype=dtype)
+        for t in types:
+            plan.set_factor(t, G0[t])
+        return plan
+    alone = []
+    for G0 in starts:
+        plan = make(G0)
+        plan.iterate(20)
+        alone.append(([plan.get_factor(t) for t in types], [plan.get_backbone(k) for k in range(len(rel))]))
+        plan.close()
+    plans = [make(G0) for G0 in starts]
+    assert all(p.batchable() for p in plans) and DevicePlan.iterate_batch(plans, 20)
+    for plan, (G, S) in zip(plans, alone):
+        for t, g in zip(types, G):
+            np.testing.assert_array_equal(plan.get_factor(t), g)
+        for k, sk in enumerate(S):
+            np.testing.assert_array_equal(plan.get_backbone(k), sk)
+        plan.close()
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
 def test_small_graph_schedule_on_an_awkward_graph(dtype, monkeypatch):
     """tests/small_cases.py: every job kind of skf_small.h on sizes that fit no tile (5 / 70 / 130 / 257 objects, ranks
     1 / 7 / 33 / 64, a multi-relation, several sparse constraints per type, empty rows); 10 iterations of the small-graph
