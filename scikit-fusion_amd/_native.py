@@ -188,10 +188,11 @@ class TorchDeviceMemory(object):
         t = self.torch.empty(max(int(nbytes), 256), dtype=self.torch.uint8, device=self.device)
         return Buffer(t.data_ptr(), int(nbytes), t)
 
-    def from_host(self, array):
+    def from_host(self, array, sync=True):
         a = np.ascontiguousarray(array)
         t = self.torch.from_numpy(a.view(np.uint8).reshape(-1)).to(self.device)
-        self.torch.cuda.synchronize(self.device)     # visible to the engine stream
+        if sync:                                     # (sync=False: the caller synchronises once for several uploads)
+            self.torch.cuda.synchronize(self.device)     # visible to the engine stream
         return Buffer(t.data_ptr(), a.nbytes, t)
 
     def to_host(self, buf, shape, dtype):

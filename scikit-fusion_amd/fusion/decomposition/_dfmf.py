@@ -24,12 +24,19 @@ def _as_rs(random_state):
     return np.random.RandomState(random_state)
 
 
-def _collect(plan, obj_types, rel_list):
-    G = {(t, t): plan.get_factor(t) for t in obj_types}
+def _unpack(values, obj_types, rel_list):
+    G = {(t, t): values[k] for k, t in enumerate(obj_types)}
     S = {}
-    for k, (i, j, _, _) in enumerate(rel_list):
-        S.setdefault((i, j), []).append(plan.get_backbone(k))
+    for k, rel in enumerate(rel_list):
+        S.setdefault((rel[0], rel[1]), []).append(values[len(obj_types) + k])
     return G, S
+
+
+def _collect(plan, obj_types, rel_list):
+    """(G, S) of the plan: all copies issued, ONE synchronisation, then the read-back."""
+    fetched = plan.fetch_results(obj_types, len(rel_list))
+    plan.synchronize()
+    return _unpack(plan.read_results(fetched), obj_types, rel_list)
 
 
 def _rel_index(rel_list, target):
@@ -223,8 +230,7 @@ def run_fits_concurrent(variant, R, M, Theta, obj_types, obj_type2rank, max_iter
                 plans.append(plan)
                 if batch_only and not plan.batchable():        # (decided on the first plan, before a second workspace exists)
                     return None
-                for t in obj_types:
-                    plan.set_factor(t, G0[t, t])
+                plan.set_factors({t: G0[t, t] for t in obj_types}, sync=False)
             rt.mem.synchronize()                               # the uploads went out on the plans' own streams
             if len(plans) > 1 and DevicePlan.iterate_batch(plans, max_iter):
                 pass      # a small graph: every launch served all the restarts of the batch (skf_iterate_batch), one stream
@@ -250,12 +256,10 @@ def run_fits_concurrent(variant, R, M, Theta, obj_types, obj_type2rank, max_iter
                 for plan in plans:
                     plan.iterate(max_iter)
             rt.mem.synchronize()
-            for plan in plans:
-                G = {(t, t): plan.get_factor(t) for t in obj_types}
-                S = {}
-                for k, rel in enumerate(rel_list):
-                    S.setdefault((rel[0], rel[1]), []).append(plan.get_backbone(k))
-                out.append((G, S))
+            fetched = [plan.fetch_results(obj_types, len(rel_list)) for plan in plans]
+            rt.mem.synchronize()                               # one synchronisation for the read-back of every plan
+            for plan, f in zip(plans, fetched):
+                out.append(_unpack(plan.read_results(f), obj_types, rel_list))
         finally:
             for plan in plans:
                 plan.close()
@@ -276,8 +280,7 @@ def run_fit(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
     plan = DevicePlan(obj_types, n_obj, obj_type2rank, rel_list, flatten_thetas(Theta), variant,
                       dtype=dtype, engine=engine)
     try:
-        for t in obj_types:
-            plan.set_factor(t, G0[t, t])
+        plan.set_factors({t: G0[t, t] for t in obj_types})
         if not (callback or stopping or stopping_system or compute_err):
             plan.iterate(max_iter)              # whole loop device-resident, no host sync
         else:

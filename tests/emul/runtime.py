@@ -62,7 +62,7 @@ class HostMemory(object):
         view[:] = 0xA5                      # poison: catch reads of unwritten workspace
         return HostBuffer(view)
 
-    def from_host(self, array):
+    def from_host(self, array, sync=True):
         a = np.ascontiguousarray(array)
         buf = self.empty(a.nbytes)
         buf.owner[:a.nbytes] = a.view(np.uint8).reshape(-1)
