@@ -430,6 +430,7 @@ struct Switches {
     int aux_prio = 0;              // SKF_AUX_PRIO=default|high  priority of the second stream (0 = lowest, the default)
     int epi_tile = 128;            // SKF_EPI_TILE=256      completion pass on the 256 x 256 tile (one workgroup per CU)
     bool known_generic = false;    // SKF_KNOWN_GENERIC=1   the any-width list kernel for the known-entry passes (tests, A/B)
+    bool known_no_v6 = false;      // SKF_KNOWN_V6=0        the round-3a list kernel (srp_bf16_kernel) at ranks 128 / 256 too (A/B)
     bool no_small_fused = false;   // SKF_NO_SMALL_FUSED=1  small graphs on the general staged schedule (~33 launches per iteration)
     static Switches read() {
         auto on = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
@@ -443,6 +444,7 @@ struct Switches {
         w.no_overlap = on("SKF_NO_OVERLAP");
         w.no_pipeline = on("SKF_NO_PIPELINE");
         w.known_generic = on("SKF_KNOWN_GENERIC");
+        { const char* v6 = getenv("SKF_KNOWN_V6"); w.known_no_v6 = v6 && atoi(v6) == 0; }
         w.no_small_fused = on("SKF_NO_SMALL_FUSED");
         const char* st = getenv("SKF_SIDE_TILE");
         w.side_tile = st ? atoi(st) : 0;
@@ -1017,6 +1019,15 @@ static int launch_srp(const SrpArgs<TG, TM>& a, hipStream_t st, bool generic) {
     const int gl = (vec && !generic) ? a.w / VE : 0;
     bool done = false;
     if constexpr (std::is_same<TG, uint16_t>::value) {
+        // srp_bf16_v6_kernel: a row of 16 lanes per gathered vector, w = 128 (both modes) or 256 (SRP_APPLY: measured, the
+        // residual pass at w = 256 is faster with two rows per vector), 32-bit byte offsets, an all-zero row behind Fi
+        if (a.zero_off != 0 && a.mode != SRP_ERR && (gl == 16 || (gl == 32 && a.mode == SRP_APPLY))) {
+            if (gl == 16 && a.mode == SRP_RESIDUAL) hipLaunchKernelGGL((srp_bf16_v6_kernel<1, SRP_RESIDUAL>), dim3(grid), dim3(256), 0, st, a);
+            else if (gl == 16) hipLaunchKernelGGL((srp_bf16_v6_kernel<1, SRP_APPLY>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((srp_bf16_v6_kernel<2, SRP_APPLY>), dim3(grid), dim3(256), 0, st, a);
+            check_launch("known-entry pass (v6)");
+            return grid * 4;
+        }
         done = true;
 #define SKF_SRP_BF16(GL_)                                                                                                   \
     do {                                                                                                                    \
@@ -1080,6 +1091,11 @@ static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream
         a.evals = by_col ? (float*)r.KcE.ptr : nullptr;
         a.Fo = (const uint16_t*)(by_col ? Tj : Gi); a.Fi = (const uint16_t*)(by_col ? Gi : Tj);
         a.out = (float*)out;
+        // the all-zero row behind the gathered matrix (FoB / FiB hold one row more than the factor): slots past the end of
+        // a list point there.  Byte offsets into the matrix are 32 bits wide in the v6 kernel.
+        const int64_t n_in = by_col ? r.nr : tj.n;
+        const int64_t zoff = n_in * ldv * 2;
+        a.zero_off = (zoff + ldv * 2 < (int64_t)0xffffffffLL && !p->sw.known_generic && !p->sw.known_no_v6) ? (uint32_t)zoff : 0u;
         waves = launch_srp(a, st, p->sw.known_generic);
     } else {
         SrpArgs<float, float> a;
@@ -2304,9 +2320,24 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         {
             const char* ev = getenv("SKF_DFMC_SPARSE");
             const int mode = ev ? atoi(ev) : -1;
+            // Parts of the lists (skf_known.h): with srp_bf16_v6_kernel the passes are no longer bound by instruction issue and
+            // pinning slices of the gathered matrix to XCDs pays (profiles/r03_srp_v6.txt: 25.6 MB of user factors, 8 parts:
+            // 1.75 -> 1.10 ms; 10 MB, 4 parts: 1.41 -> 1.25 ms) -- the smallest power of two that brings a slice under the
+            // 4 MiB L2 of an XCD, as long as a segment still holds a batch of entries.  Other engines / widths: 1 (their
+            // kernels are issue-bound; measured neutral in round 3).  SKF_KNOWN_PARTS=1|2|4|8 overrides.
             const char* evp = getenv("SKF_KNOWN_PARTS");
-            int parts = evp ? atoi(evp) : 1;          // (pinning slices of the gathered factors to XCDs measured neutral)
-            if (parts != 2 && parts != 4 && parts != 8) parts = 1;
+            int parts_env = evp ? atoi(evp) : 0;
+            if (parts_env != 1 && parts_env != 2 && parts_env != 4 && parts_env != 8) parts_env = 0;
+            const char* ev6 = getenv("SKF_KNOWN_V6");
+            const bool no_v6 = ev6 && atoi(ev6) == 0;
+            auto pick_parts = [&](int64_t n_in, int64_t n_out, int ci, int64_t cap) {
+                if (parts_env) return parts_env;
+                if (!p->bf16 || (ci != 128 && ci != 256) || no_v6) return 1;
+                int q = 1;
+                while (q < 8 && (double)n_in * ci * 2.0 / q > 3.5 * 1048576.0) q *= 2;
+                while (q > 1 && (double)cap / ((double)n_out * q) < 64.0) q /= 2;
+                return q;
+            };
             for (RelState& s : p->rels) {
                 if (s.kn_cap <= 0) continue;
                 const double cells = (double)s.nr * (double)p->types[s.col].n;
@@ -2318,9 +2349,10 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                     continue;
                 }
                 s.kn = true;
-                s.kn_pc = s.kn_pr = parts;
-                s.kn_pw = ((p->types[s.col].n + parts - 1) / parts + 63) / 64 * 64;
-                s.kn_ph = ((s.nr + parts - 1) / parts + 63) / 64 * 64;
+                s.kn_pc = pick_parts(p->types[s.col].n, s.nr, ci, s.kn_cap);        // row lists gather the column objects' vectors
+                s.kn_pr = pick_parts(s.nr, p->types[s.col].n, ci, s.kn_cap);        // column lists gather the row objects' vectors
+                s.kn_pw = ((p->types[s.col].n + s.kn_pc - 1) / s.kn_pc + 63) / 64 * 64;
+                s.kn_ph = ((s.nr + s.kn_pr - 1) / s.kn_pr + 63) / 64 * 64;
                 p->types[s.row].keep_prev = p->types[s.col].keep_prev = true;
             }
         }
@@ -2455,8 +2487,8 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 add_slot(p, r.KCnt, cnt * 4);
                 r.kn_ldf = p->bf16 ? (ti.c + 7) / 8 * 8 : ti.c;
                 if (p->bf16) {
-                    add_slot(p, r.FoB, (size_t)nr * r.kn_ldf * 2);
-                    add_slot(p, r.FiB, (size_t)tj.n * r.kn_ldf * 2);
+                    add_slot(p, r.FoB, ((size_t)nr + 1) * r.kn_ldf * 2);          // (+ 1: the all-zero row of the v6 list kernel)
+                    add_slot(p, r.FiB, ((size_t)tj.n + 1) * r.kn_ldf * 2);
                 }
                 add_slot(p, r.Tm, (size_t)tj.n * ti.c * es);
                 add_slot(p, r.A, (size_t)nr * ti.c * es);

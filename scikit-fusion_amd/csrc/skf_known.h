@@ -43,6 +43,7 @@ struct SrpArgs {
     double* sq;                 // SRP_ERR: [gridDim.x * 4] partials
     int64_t ldo, ldi, ld_out, part_stride, n_out;
     int w, parts, mode;
+    uint32_t zero_off;          // srp_bf16_v6_kernel: byte offset of an all-zero row behind Fi (0 = none: srp_bf16_kernel runs)
 };
 
 template <typename TG> struct GatherT;
@@ -305,6 +306,122 @@ __global__ __launch_bounds__(256) void srp_bf16_kernel(SrpArgs<uint16_t, float> 
     if (MODE == SRP_ERR) {
         sq = wave_sum(sq);
         if (lane == 0) a.sq[(int64_t)blockIdx.x * 4 + wv] = sq;
+    }
+}
+
+// srp_bf16_v6_kernel: the tuned pass with the vector-ALU work per entry almost halved (round 3, second half).  The ISA
+// of srp_bf16_kernel shows why its dot-product flavours ran at 11-13 TB/s of gathered rows against 17.5 TB/s for the
+// bare gathers: 49 vector-ALU instructions per wave step (4 entries), the pass is issue-bound -- 64-bit address
+// arithmetic (two quarter-rate v_mul_lo_u32 and a v_mad_u64_u32 per row), multiplies and adds of the accumulation left
+// unfused behind the shuffles of the SLP pass, a compare and two selects per step for the slots past the end of a list.
+// Here, per step (CPL = 1): one v_add_u32_dpp (the lane that loaded entry k of the row holds its BYTE offset, 32 bits:
+// the gathered matrix is below 4 GiB, checked at launch), the 16-byte load off a scalar base, four v_dot2c, the
+// butterfly (the SLP pass pairs the adds of two entries into v_pk_add_f32 behind v_mov_b32_dpp: 1.5 instructions per
+// add), r of lane k minus x, one select to keep the residual, eight conversions and four v_pk_fma_f32 (explicit
+// two-element vectors).  Slots past the end of a list point at an all-zero row kept behind the gathered matrix
+// (SrpArgs::zero_off) with r = 0 (e = 0 in SRP_APPLY): they contribute exactly nothing without a mask in the loop.
+// A row of 16 lanes always covers one gathered vector: w = 128 with one 16-byte chunk per lane (CPL = 1), w = 256 with
+// two (CPL = 2: chunks l and 16 + l, two coalesced 256-byte halves) -- the butterfly stays inside the row.
+// The list bounds are moved to scalar registers: the loop and its early exits branch on scalar conditions.
+// (A first version issued the DPP forms as inline assembly: the hazard recogniser does not look into assembly -- DPP
+// after an EXEC write, any other vector-ALU read of a v_dot2c result -- and the s_nop padding that looked sufficient was
+// not under low occupancy: wrong, run-to-run different sums in the eight-loads-in-flight variants.  Builtins only.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int64_t wave_uniform(int64_t x) {               // a value every lane holds, to scalar registers
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)x >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+template <int CPL, int MODE>
+__global__ __launch_bounds__(256) void srp_bf16_v6_kernel(SrpArgs<uint16_t, float> a) {
+    static_assert(CPL == 1 || CPL == 2, "w = 128 or 256");
+    static_assert(MODE == SRP_RESIDUAL || MODE == SRP_APPLY, "the error pass stays on srp_bf16_kernel");
+    constexpr int NU = 4;                       // wave steps (gathered rows per lane group) in flight
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int grp = lane >> 4, sub = lane & 15;
+    int part;
+    int64_t first;
+    srp_segment(a.parts, part, first);
+    const int64_t o = first + wv;
+    if (o >= a.n_out) return;                                              // (wave-uniform)
+    const int64_t qa = wave_uniform(a.ptr[o * a.parts + part]), qb = wave_uniform(a.ptr[o * a.parts + part + 1]);
+    u32x4 fo[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        fo[c] = u32x4{0u, 0u, 0u, 0u};
+        if (MODE == SRP_RESIDUAL) fo[c] = *(const u32x4*)(a.Fo + o * a.ldo + c * 128 + sub * 8);
+    }
+    f32x2 acc[4 * CPL];
+#pragma unroll
+    for (int t = 0; t < 4 * CPL; ++t) acc[t] = f32x2{0.f, 0.f};
+    const unsigned char* fi = (const unsigned char*)a.Fi;
+    const uint32_t ldb = (uint32_t)a.ldi * 2u, sub16 = (uint32_t)sub * 16u;
+    for (int64_t q0 = qa; q0 < qb; q0 += 64) {
+        const int nb = (int)(qb - q0 < 64 ? qb - q0 : 64);                 // entries of this batch: lane l loads entry l
+        const bool mine = lane < nb;
+        const int64_t qm = q0 + (mine ? lane : nb - 1);                    // (clamped: always a valid address)
+        const uint32_t ld_i = (uint32_t)a.idx[qm];
+        const float ld_v = MODE == SRP_RESIDUAL ? a.rvals[qm] : a.evals[qm];
+        const int my_off = (int)(mine ? ld_i * ldb : a.zero_off);
+        const float my_v = mine ? ld_v : 0.f;                              // r of the entry (SRP_APPLY: its stored residual)
+        float e_out = 0.f;                                                 // SRP_RESIDUAL: the residual of this lane's entry
+        auto chunk = [&](auto c0) {                                        // NU steps: k = c0 .. c0 + NU - 1
+            constexpr int K0 = decltype(c0)::value;
+            u32x4 v[NU][CPL];
+            static_for<NU>([&](auto uu) {
+                constexpr int U = decltype(uu)::value;
+                const unsigned char* src = fi + ((uint32_t)row_bcast<K0 + U>(my_off) + sub16);
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) v[U][c] = *(const u32x4*)(src + c * 256);
+            });
+            static_for<NU>([&](auto uu) {
+                constexpr int U = decltype(uu)::value, K = K0 + U;
+                float ev;
+                if (MODE == SRP_RESIDUAL) {
+                    float x = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) x = dot8_bf16(fo[c], v[U][c], x);
+                    x = dpp_add<0xB1>(x);                                  // quad_perm [1,0,3,2]
+                    x = dpp_add<0x4E>(x);                                  // quad_perm [2,3,0,1]
+                    x = dpp_add<0x141>(x);                                 // row_half_mirror
+                    x = dpp_add<0x140>(x);                                 // row_mirror
+                    ev = row_bcast<K>(my_v) - x;
+                    e_out = sub == K ? ev : e_out;                         // the lane that loaded this entry keeps it
+                } else {
+                    ev = row_bcast<K>(my_v);
+                }
+                const f32x2 e2 = {ev, ev};
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const uint32_t w[4] = {v[U][c].x, v[U][c].y, v[U][c].z, v[U][c].w};   // two bf16 per dword: low, high
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x2 g = {__builtin_bit_cast(float, w[t] << 16), __builtin_bit_cast(float, w[t] & 0xffff0000u)};
+                        acc[4 * c + t] = __builtin_elementwise_fma(g, e2, acc[4 * c + t]);
+                    }
+                }
+            });
+        };
+        chunk(std::integral_constant<int, 0>());                          // (a group runs out of entries when the batch does)
+        if (nb > 4) chunk(std::integral_constant<int, 4>());
+        if (nb > 8) chunk(std::integral_constant<int, 8>());
+        if (nb > 12) chunk(std::integral_constant<int, 12>());
+        if (MODE == SRP_RESIDUAL && a.evals && mine) a.evals[q0 + lane] = e_out;      // one coalesced store per batch
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        float out[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { out[2 * t] = acc[4 * c + t].x; out[2 * t + 1] = acc[4 * c + t].y; }
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1)                            // the lane groups of the wave, fixed order
+#pragma unroll
+            for (int t = 0; t < 8; ++t) out[t] += __shfl_xor(out[t], off, 64);
+        if (grp == 0) {
+            float* dst = a.out + (int64_t)part * a.part_stride + o * a.ld_out + c * 128 + sub * 8;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) dst[t] = out[t];
+        }
     }
 }
 

@@ -317,6 +317,7 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return simt::wave_read(v, lane); }     // v_readlane_b32
+inline int __builtin_amdgcn_readfirstlane(int v) { return simt::wave_read(v, 0); }              // v_readfirstlane_b32 (all lanes active)
 // DPP lane exchanges used by the kernels: quad_perm (ctrl < 0x100), row_mirror (0x140), row_half_mirror (0x141),
 // row_newbcast:k (0x150 + k)
 inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {

@@ -31,14 +31,24 @@ def build(force=False):
     if not os.path.exists(CLANG):
         raise RuntimeError('host clang++ not found at %s' % CLANG)
     newest = max(os.path.getmtime(p) for p in _sources())
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
+
+    def fresh():
+        return os.path.exists(OUT) and os.path.getmtime(OUT) >= newest
+    if not force and fresh():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O2', '-fPIC', '-shared', '-Wno-psabi',
-           '-Wno-unused-variable', '-I', os.path.join(HERE, 'include'),
-           '-include', os.path.join(HERE, 'include', 'skf_asm.h'),      # host stand-ins ahead of csrc/skf_asm.h
-           os.path.join(SRC_DIR, 'skf_api.hip'), '-o', OUT]
-    subprocess.check_call(cmd)
+    # several test processes (pytest-xdist workers) may get here at once: one builds, the others wait and find it done
+    import fcntl
+    with open(OUT + '.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not fresh():
+            tmp = '%s.%d.tmp' % (OUT, os.getpid())
+            cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O2', '-fPIC', '-shared', '-Wno-psabi',
+                   '-Wno-unused-variable', '-I', os.path.join(HERE, 'include'),
+                   '-include', os.path.join(HERE, 'include', 'skf_asm.h'),      # host stand-ins ahead of csrc/skf_asm.h
+                   os.path.join(SRC_DIR, 'skf_api.hip'), '-o', tmp]
+            subprocess.check_call(cmd)
+            os.replace(tmp, OUT)
     return OUT
 
 

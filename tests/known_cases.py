@@ -57,12 +57,12 @@ def run(types, n, ranks, rels, thetas, G0, dtype, iters, sparse, with_errors=Fal
         plan.close()
 
 
-def sparse_against_dense(n, ranks, known_share, iters, dtype, tol, what, monkeypatch, parts=1):
+def sparse_against_dense(n, ranks, known_share, iters, dtype, tol, what, monkeypatch, parts=1, seed=0):
     """Same graph, same start: lists of known entries vs completed dense copy.  tol = (G, S, squared errors, P S^T, Q)."""
     tol_g, tol_s, tol_e, tol_a, tol_q = tol
     monkeypatch.setenv('SKF_DFMC_SPARSE', '1')              # whenever a bound is given (up to a quarter known)
     monkeypatch.setenv('SKF_KNOWN_PARTS', str(parts))
-    types, rels, thetas, G0 = masked_graph(n, ranks, known_share)
+    types, rels, thetas, G0 = masked_graph(n, ranks, known_share, seed)
     Gs, Ss, Es, xs = run(types, n, ranks, rels, thetas, G0, dtype, iters, True, with_errors=True)
     Gd, Sd, Ed, xd = run(types, n, ranks, rels, thetas, G0, dtype, iters, False, with_errors=True)
     for t in types:

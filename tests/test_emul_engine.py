@@ -773,12 +773,13 @@ def test_fold_in_of_binary_new_relations_bf16():
 
 
 @pytest.mark.parametrize('dtype,parts,rank_a', [('f64', 1, 64), ('f64', 4, 64), ('f32', 1, 64), ('f32', 1, 20), ('bf16', 2, 64),
-                                               ('bf16', 1, 128)])
+                                               ('bf16', 2, 128), ('bf16', 1, 256)])
 def test_dfmc_on_the_known_entries_only_matches_the_dense_completion(dtype, parts, rank_a, monkeypatch):
     """skf_relation_desc.known_bound: a masked relation kept as lists of its known entries (csrc/skf_known.h) -- the
     completed relation of _dfmc.py:319-325 is never formed.  f64: equal to the dense path to rounding; rank 64 on the row
-    type takes the 16-byte-chunk list kernels (f64: 32 lanes per vector, f32: 16, bf16: 8 -- 16 at rank 128 -- with v_dot2 +
-    DPP), rank 20 the any-width kernel.  (bf16: the dense path rounds every completed entry to bf16, the lists do not.)"""
+    type takes the 16-byte-chunk list kernels (f64: 32 lanes per vector, f32: 16, bf16: 8 with v_dot2 + DPP), rank 20 the
+    any-width kernel; bf16 at rank 128 / 256: srp_bf16_v6_kernel (one / two chunks per lane, zero row for the list tails;
+    at 256 the residual passes stay on the two-rows-per-vector kernel).  (bf16: the dense path rounds every completed entry to bf16, the lists do not.)"""
     import known_cases as K
     n, ranks = {'a': 150, 'b': 130, 'c': 40}, {'a': rank_a, 'b': 24, 'c': 5}
     # (G, S, squared errors, P S^T, Q); measured f64 <= 3e-14 / 2e-13 / 1.2e-14 / 1.3e-13 / 1.3e-13, bf16 <= 1.4e-3 / 2e-2 / 1e-3 / 3e-2 / 2e-3

@@ -772,3 +772,15 @@ def test_dfmc_on_the_known_entries_only_matches_the_dense_completion(dtype, rank
     tol = {'f64': (1.5e-12, 6e-12, 1.3e-13, 2.5e-12, 4e-12), 'f32': (7e-6, 3.5e-5, 1.5e-7, 1e-5, 2.5e-6),
            'bf16': (1.2e-2, 2.5e-2, 5.5e-4, 5e-2, 1.2e-2)}[dtype]
     K.sparse_against_dense(n, ranks, 0.02, 4, dtype, tol, 'GPU %s rank %d' % (dtype, rank_a), monkeypatch)
+
+
+@pytest.mark.parametrize('rank_a,parts,share', [(128, 2, 0.1), (128, 8, 0.1), (256, 4, 0.05), (128, 4, 0.2)])
+def test_known_entry_lists_in_parts_on_the_v6_kernel(rank_a, parts, share, monkeypatch):
+    """srp_bf16_v6_kernel (bf16, ranks 128 / 256 on the row type) with the lists cut into parts pinned to XCDs -- segments
+    of a few full batches plus a tail (2 parts at 10 % known: 130 entries), tail-only segments (8 parts: 32), long ones
+    (20 % known), the zero row behind the gathered matrix for every slot past a segment's end -- against the dense path."""
+    import known_cases as K
+    n, ranks = {'a': 3000, 'b': 2600, 'c': 500}, {'a': rank_a, 'b': 256 if rank_a < 256 else 128, 'c': 64}
+    tol = (1.2e-2, 2.5e-2, 5.5e-4, 5e-2, 1.2e-2)
+    K.sparse_against_dense(n, ranks, share, 4, 'bf16', tol, 'GPU bf16 rank %d parts %d known %.2f' % (rank_a, parts, share),
+                           monkeypatch, parts, seed=parts)

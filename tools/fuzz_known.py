@@ -1,6 +1,6 @@
 """Randomised DFMC graphs with masked relations through the device engine -- lists of the known entries (SKF_DFMC_SPARSE=1) and
 the completed dense copy (=0) -- against the NumPy oracle:   python tools/fuzz_known.py [n_graphs] [seed]
-Sizes 40..500 objects, ranks 2..96, 1-25 % of a masked relation known, rows / columns without a known entry, unmasked
+Sizes 40..500 objects, ranks 2..96 (row type of the masked relations also 128 / 256), lists in 1 / 2 / 4 / 8 parts, 1-25 % of a masked relation known, rows / columns without a known entry, unmasked
 relations beside the masked ones, sparse constraints.  f64: 1e-8 vs the oracle; bf16 / f32: the two device forms against
 each other on the reconstruction error.  Exits non-zero on a violation."""
 import os
@@ -20,6 +20,9 @@ def random_graph(rs):
     types = ['a', 'b', 'c']
     n = {t: int(rs.choice([40, 64, 65, 130, 257, 400, 500])) for t in types}
     rank = {t: int(rs.choice([2, 5, 16, 31, 32, 48, 64, 96])) for t in types}
+    wide = [r for r in (128, 256) if 2 * r <= n['a']]            # the row type of the masked relations at the widths of
+    if wide and rs.rand() < 0.6:                                 # srp_bf16_v6_kernel (one / two 16-byte chunks per lane);
+        rank['a'] = int(rs.choice(wide))                         # (rank ~ objects: bf16 noise of EITHER form dominates)
     share = float(rs.choice([0.01, 0.03, 0.1, 0.25]))
     Ga, Gb = rs.rand(n['a'], 4), rs.rand(n['b'], 4)
     R_ab = (Ga @ rs.rand(4, 4) @ Gb.T) / 4.0 + 0.05 * rs.rand(n['a'], n['b'])
@@ -38,7 +41,8 @@ def random_graph(rs):
         np.fill_diagonal(T, 0.02)
         Theta['b', 'b'] = [T]
     G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.1 for t in types}
-    return types, n, rank, share, R, M, Theta, G0
+    parts = int(rs.choice([0, 0, 2, 4, 8]))                      # 0: the engine's own choice
+    return types, n, rank, share, R, M, Theta, G0, parts
 
 
 def run(types, n, rank, R, M, Theta, G0, dtype, iters, sparse):
@@ -62,7 +66,11 @@ def main(n_graphs, seed, iters=4):
     rs = np.random.RandomState(seed)
     bad = 0
     for g in range(n_graphs):
-        types, n, rank, share, R, M, Theta, G0 = random_graph(rs)
+        types, n, rank, share, R, M, Theta, G0, parts = random_graph(rs)
+        if parts:
+            os.environ['SKF_KNOWN_PARTS'] = str(parts)
+        else:
+            os.environ.pop('SKF_KNOWN_PARTS', None)
         Go, So = orc.dfmc(R, M, Theta, types, rank, max_iter=iters, G0=G0)
         so = [m for key in R for m in So[key]]
         out = []
@@ -77,9 +85,10 @@ def main(n_graphs, seed, iters=4):
             w = max(abs(a - b) / b for a, b in zip(e1, e0))
             out.append('%s lists~dense err %.1e' % (dtype, w))
             bad += not (w < tol)
-        print('graph %2d: n=%s rank=%s known=%.2f rel=%d theta=%d  %s' % (g, list(n.values()), list(rank.values()), share, len(R), len(Theta),
-                                                                         '  '.join(out)), flush=True)
+        print('graph %2d: n=%s rank=%s known=%.2f rel=%d theta=%d parts=%d  %s' % (g, list(n.values()), list(rank.values()), share, len(R),
+                                                                                  len(Theta), parts, '  '.join(out)), flush=True)
     os.environ.pop('SKF_DFMC_SPARSE', None)
+    os.environ.pop('SKF_KNOWN_PARTS', None)
     print('FAILED: %d' % bad if bad else 'all within tolerance')
     return 1 if bad else 0
 

@@ -27,9 +27,10 @@ static void run(int64_t n_out, int64_t n_in, int per, int w) {
             int64_t c = (int64_t)(k * stride + (rng() % 1000000) * 1e-6 * stride);
             idx[(size_t)(o * per + k)] = (int)(c < n_in ? c : n_in - 1);
         }
-    std::vector<TG> fo((size_t)n_out * w), fi((size_t)n_in * w);
+    std::vector<TG> fo((size_t)n_out * w), fi((size_t)(n_in + 1) * w);          // (one all-zero row behind the gathered matrix)
     for (auto& v : fo) v = sizeof(TG) == 2 ? (TG)f32_to_bf16_rne((rng() % 1000) * 1e-3f) : (TG)((rng() % 1000) * 1e-3f);
     for (auto& v : fi) v = sizeof(TG) == 2 ? (TG)f32_to_bf16_rne((rng() % 1000) * 1e-3f) : (TG)((rng() % 1000) * 1e-3f);
+    for (int t = 0; t < w; ++t) fi[(size_t)n_in * w + t] = (TG)0;
     std::vector<float> rv((size_t)nnz, 0.5f);
     int* d_idx; float *d_rv, *d_ev, *d_out; TG *d_fo, *d_fi; int64_t* d_ptr;
     CK(hipMalloc(&d_idx, nnz * 4)); CK(hipMalloc(&d_rv, nnz * 4)); CK(hipMalloc(&d_ev, nnz * 4));
@@ -61,6 +62,7 @@ static void run(int64_t n_out, int64_t n_in, int per, int w) {
                 a.ptr = d_ptr; a.idx = d_idx; a.rvals = d_rv; a.evals = (mode == 1 || store) ? d_ev : nullptr;
                 a.Fo = d_fo; a.Fi = d_fi; a.out = d_out; a.ldo = w; a.ldi = w; a.ld_out = w;
                 a.part_stride = n_out * w; a.n_out = n_out; a.w = w; a.parts = parts; a.mode = mode;
+                a.zero_off = (uint32_t)(n_in * w * sizeof(TG));
                 const int per_round = 8 / parts;
                 const int64_t blocks_per_part = (n_out + 3) / 4;
                 const int grid = (int)((blocks_per_part + per_round - 1) / per_round * 8);
@@ -68,6 +70,12 @@ static void run(int64_t n_out, int64_t n_in, int per, int w) {
                     constexpr int VE = 16 / (int)sizeof(TG);
                     const int gl = w / VE;
                     if constexpr (sizeof(TG) == 2) {
+                        if (getenv("SRP_V6") && (gl == 16 || gl == 32)) {          // srp_bf16_v6_kernel (w = 128 / 256)
+#define PROBE_V6(CPL_) do { if (mode == 0) hipLaunchKernelGGL((srp_bf16_v6_kernel<CPL_, SRP_RESIDUAL>), dim3(grid), dim3(256), 0, 0, a); \
+                           else hipLaunchKernelGGL((srp_bf16_v6_kernel<CPL_, SRP_APPLY>), dim3(grid), dim3(256), 0, 0, a); } while (0)
+                            if (gl == 16) PROBE_V6(1); else PROBE_V6(2);
+                            return;
+                        }
                         if (getenv("SRP_TUNED")) {
 #define PROBE_SRP(GL_) do { if (mode == 0) hipLaunchKernelGGL((srp_bf16_kernel<GL_, SRP_RESIDUAL>), dim3(grid), dim3(256), 0, 0, a); \
                            else hipLaunchKernelGGL((srp_bf16_kernel<GL_, SRP_APPLY>), dim3(grid), dim3(256), 0, 0, a); } while (0)
@@ -92,6 +100,15 @@ static void run(int64_t n_out, int64_t n_in, int per, int w) {
                 float ms = 0.f;
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 ms /= 5;
+                {   // checksum of the pass (parts summed) and of the stored residuals: the flavours must agree
+                    std::vector<float> ho((size_t)parts * n_out * w), he((size_t)nnz);
+                    CK(hipMemcpy(ho.data(), d_out, ho.size() * 4, hipMemcpyDeviceToHost));
+                    CK(hipMemcpy(he.data(), d_ev, he.size() * 4, hipMemcpyDeviceToHost));
+                    double so = 0, se = 0;
+                    for (float v : ho) so += (double)v * (double)v;
+                    for (float v : he) se += (double)v * (double)v;
+                    printf("  checksum out %.9e residuals %.9e\n", so, se);
+                }
                 printf("n_out %lld n_in %lld per %d w %d %s parts %d mode %s%s: %.3f ms  gathered %.2f GB -> %.2f TB/s\n",
                        (long long)n_out, (long long)n_in, per, w, sizeof(TG) == 2 ? "bf16" : "f32", parts,
                        mode == 0 ? "residual" : "apply", store ? "+store" : "", ms, nnz * (double)w * sizeof(TG) / 1e9,
