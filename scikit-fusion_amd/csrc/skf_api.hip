@@ -475,6 +475,11 @@ struct TypeState {
     bool set = false;
     bool keep_prev = false;        // a known-entries relation touches this type: Gp = the factor before the last update
     Slot Gp;
+    // SKF_BF16: the bf16 ROWS of G, [n + 1][ldrow] with an all-zero last row -- the gathered matrix of the list passes over
+    // the known entries of a masked relation and over the ones of a sparse 0/1 relation (skf_known.h); kept in step with GTb
+    bool need_rows = false;
+    Slot Grow;
+    int64_t ldrow = 0;
 };
 
 struct RelState {
@@ -499,6 +504,12 @@ struct RelState {
     bool sparse = false;
     Slot SpRp, SpCi, SpCp, SpRi, SpCnt;     // row pointers / columns, column pointers / rows (ascending), count scratch
     int64_t sp_cap = 0, sp_nnz = 0;
+    // ... contracted by srp_bf16_v6_kernel<.., SRP_ONES> over bf16 factor rows when both ranks are 64 / 128 / 256 (up to 1
+    // entry in 80 set); otherwise by binary_spmm_kernel over the f32 rows (up to 1 in 256).  Lists in parts pinned to XCDs:
+    bool sp_gather = false;
+    int sp_pc = 1, sp_pr = 1;               // column parts of the row lists (P), row parts of the column lists (Q)
+    int64_t sp_pw = 0, sp_ph = 0;
+    Slot SpRpP, SpCpP;                      // segment pointers of the parted lists
     Slot Mb;                       // DFMC: the mask as packed bits, [nr][ldmb bytes], bit (n & 7) of byte n >> 3
     int64_t ldmb = 0;
     bool mask_is_bits = false;     // the caller's mask is already packed (SKF_REL_MASK_BITS)
@@ -520,7 +531,7 @@ struct RelState {
     Slot KrPtr, KrIdx, KrVal;              // rows -> known columns (ascending), R there
     Slot KcPtr, KcIdx, KcVal, KcE;         // columns -> known rows (ascending), R there, residuals E of the last iteration
     Slot KCnt;                             // count / fill-position scratch of the bind-time build
-    Slot FoB, FiB;                         // SKF_BF16: bf16 rows of G_i (n_i x ldf) and of T = G_j S^T (n_j x ldf)
+    Slot FiB;                              // SKF_BF16: bf16 rows of T = G_j S^T (n_j x ldf; the rows of G_i: TypeState::Grow)
     Slot Tm;                               // T = G_j S^T in the master type (n_j x c_i)
     Slot Apart, Qpart;                     // partial outputs of the parts, [parts][n][c_i] (only with more than one part)
     Slot A;                                // E T, then the row-side product P S^T = G_i (S Gram_j S^T) + E T   (n_i x c_i)
@@ -569,6 +580,7 @@ struct skf_plan {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     skf::Slot part_aux;
     size_t part_aux_bytes = 0;
+    skf::Slot sp_part;                     // partial outputs of the parted list passes over sparse 0/1 relations
 
     skf::Switches sw;                      // read once in skf_plan_bind_workspace
     bool overlap = false;
@@ -678,7 +690,41 @@ static void relation_gemm(skf_plan* p, GemmArgs g, hipStream_t st, const RelStat
     if (p->bf16) {
         const TypeState& ti = p->types[r->row];
         const TypeState& tj = p->types[r->col];
-        if (r->sparse) {        // a handful of ones per row / column: gather the factor's f32 rows (binary_spmm_kernel)
+        if (r->sparse && r->sp_gather) {       // the ones as lists over the bf16 rows of the factor, every entry counting 1
+            const TypeState& tin = is_q ? ti : tj;           // the gathered factor: Q = R^T G_i sums rows of G_i, P = R G_j rows of G_j
+            const int parts = is_q ? r->sp_pr : r->sp_pc;
+            const int64_t in0 = is_q ? r->r0 : 0, n_in = tin.n - in0;
+            SrpArgs<uint16_t, float> a;
+            memset(&a, 0, sizeof a);
+            a.ptr = (const int64_t*)(parts > 1 ? (is_q ? r->SpCpP.ptr : r->SpRpP.ptr) : (is_q ? r->SpCp.ptr : r->SpRp.ptr));
+            a.idx = (const int*)(is_q ? r->SpRi.ptr : r->SpCi.ptr);
+            a.Fi = (const uint16_t*)tin.Grow.ptr + in0 * tin.ldrow;
+            a.ldi = tin.ldrow; a.ldo = tin.ldrow;
+            a.n_out = g.M; a.w = g.N; a.parts = parts; a.mode = SRP_ONES;
+            a.ld_out = parts > 1 ? g.N : g.ldc;
+            a.part_stride = (int64_t)g.M * g.N;
+            a.out = parts > 1 ? (float*)p->sp_part.ptr : (float*)g.C;
+            a.zero_off = (uint32_t)(n_in * tin.ldrow * 2);
+            if (((int64_t)(n_in + 1) * tin.ldrow * 2) >= (int64_t)0xffffffffLL || tin.ldrow != g.N)
+                SKF_FAIL(SKF_E_STATE, "sparse 0/1 relation: the gathered factor does not fit the list kernel");
+            const int per = 8 / parts;
+            const int64_t wgs = ((int64_t)g.M + 3) / 4;
+            const int grid = (int)((wgs + per - 1) / per * 8);
+            if (g.N == 64) hipLaunchKernelGGL((srp_bf16_v6_kernel<1, SRP_ONES, 2>), dim3(grid), dim3(256), 0, st, a);
+            else if (g.N == 128) hipLaunchKernelGGL((srp_bf16_v6_kernel<1, SRP_ONES, 4>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((srp_bf16_v6_kernel<2, SRP_ONES, 4>), dim3(grid), dim3(256), 0, st, a);
+            check_launch("sparse 0/1 relation (lists)");
+            if (parts > 1) {
+                if (g.ldc == g.N) {
+                    const int64_t total = (int64_t)g.M * g.N;
+                    hipLaunchKernelGGL((sum_parts_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st, (float*)g.C,
+                                       (const float*)p->sp_part.ptr, total, parts, total);
+                    check_launch("sum_parts");
+                } else {
+                    SKF_FAIL(SKF_E_STATE, "sparse 0/1 relation: strided output with parted lists");
+                }
+            }
+        } else if (r->sparse) {        // a handful of ones per row / column: gather the factor's f32 rows (binary_spmm_kernel)
             const int wgrid = (int)(((int64_t)g.M + 3) / 4 < 4096 ? ((int64_t)g.M + 3) / 4 : 4096);
             hipLaunchKernelGGL(binary_spmm_kernel, dim3(wgrid), dim3(256), 0, st,
                                (const int64_t*)(is_q ? r->SpCp.ptr : r->SpRp.ptr), (const int*)(is_q ? r->SpRi.ptr : r->SpCi.ptr),
@@ -719,6 +765,8 @@ static void relation_gemm(skf_plan* p, GemmArgs g, hipStream_t st, const RelStat
 static void refresh_gt(skf_plan* p, TypeState& t, hipStream_t st) {
     if (!p->bf16) return;
     launch_to_bf16<float>((uint16_t*)t.GTb.ptr, t.ldgt, (const float*)t.G.ptr, (int64_t)t.c, t.n, (int64_t)t.c, true, st);
+    if (t.Grow.ptr)        // the bf16 rows for the list passes (their all-zero last row is never written)
+        launch_to_bf16<float>((uint16_t*)t.Grow.ptr, t.ldrow, (const float*)t.G.ptr, (int64_t)t.c, t.n, (int64_t)t.c, false, st);
 }
 
 // Relative pivot threshold of the Cholesky fast path: below it the Gram matrix goes to the deflation / the
@@ -1063,7 +1111,7 @@ static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream
     const int parts = by_col ? r.kn_pr : r.kn_pc;
     void* final_out = by_col ? r.Q.ptr : r.A.ptr;
     void* out = parts > 1 ? (by_col ? r.Qpart.ptr : r.Apart.ptr) : final_out;
-    const void* Gi = p->bf16 ? r.FoB.ptr : ti.G.ptr;          // vectors of the row objects
+    const void* Gi = p->bf16 ? ti.Grow.ptr : ti.G.ptr;        // vectors of the row objects (bf16: kept in step with G^T)
     const void* Tj = p->bf16 ? r.FiB.ptr : r.Tm.ptr;          // vectors of the column objects
     const int64_t ldv = p->bf16 ? r.kn_ldf : ci;
     if (p->profiling) SKF_HIP(hipEventRecord(next_event(p), st));
@@ -1091,7 +1139,7 @@ static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream
         a.evals = by_col ? (float*)r.KcE.ptr : nullptr;
         a.Fo = (const uint16_t*)(by_col ? Tj : Gi); a.Fi = (const uint16_t*)(by_col ? Gi : Tj);
         a.out = (float*)out;
-        // the all-zero row behind the gathered matrix (FoB / FiB hold one row more than the factor): slots past the end of
+        // the all-zero row behind the gathered matrix (TypeState::Grow / FiB hold one row more than the factor): slots past the end of
         // a list point there.  Byte offsets into the matrix are 32 bits wide in the v6 kernel.
         const int64_t n_in = by_col ? r.nr : tj.n;
         const int64_t zoff = n_in * ldv * 2;
@@ -1127,12 +1175,6 @@ static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream
     return waves;
 }
 
-// SKF_BF16: bf16 rows of the row factor for the gathers (the stored G^T is the wrong way round for them)
-static void known_refresh_rows(skf_plan* p, RelState& r, hipStream_t st) {
-    if (!p->bf16) return;
-    TypeState& ti = p->types[r.row];
-    launch_to_bf16<float>((uint16_t*)r.FoB.ptr, r.kn_ldf, (const float*)ti.G.ptr, (int64_t)ti.c, r.nr, ti.c, false, st);
-}
 
 // W = G_i^T R_c G_j for the backbone (_dfmc.py:311-314) with R_c = G_i,prev S_prev G_j,prev^T + E_prev:
 //     W = (G_i^T G_i,prev) S_prev (G_j,prev^T G_j) + (E_prev^T G_i)^T G_j
@@ -1141,7 +1183,6 @@ static void known_w(skf_plan* p, RelState& r, hipStream_t st) {
     TypeState& ti = p->types[r.row];
     TypeState& tj = p->types[r.col];
     const int ci = ti.c, cj = tj.c;
-    known_refresh_rows(p, r, st);
     known_pass(p, r, true, SRP_APPLY, st);                                                          // Y = E_prev^T G_i  -> r.Q
     GemmArgs g = gemm_args(r.Q.ptr, 1, ci, tj.G.ptr, cj, 1, r.W.ptr, cj, ci, cj, (int)tj.n, EPI_STORE, 0);
     wide_gemm(p, g, st);                                                                // W = Y^T G_j
@@ -1613,7 +1654,7 @@ static void apply_update(skf_plan* p, hipStream_t st) {
         if (p->bf16 && t.n > 0) {                  // update and G^T refresh in one pass
             hipLaunchKernelGGL(mult_update_transpose_kernel, dim3((unsigned)cdiv(t.c, 32), (unsigned)cdiv(t.n, 32)), dim3(256), 0,
                                st, (float*)t.G.ptr, (const float*)t.E.ptr, (const float*)t.D.ptr, (int64_t)t.n, (int64_t)t.c,
-                               (uint16_t*)t.GTb.ptr, t.ldgt);
+                               (uint16_t*)t.GTb.ptr, t.ldgt, (uint16_t*)t.Grow.ptr, t.ldrow);
             check_launch("mult_update_transpose");
             continue;
         }
@@ -2197,10 +2238,7 @@ static void build_known_lists_t(skf_plan* p, RelState& r, hipStream_t st) {
         SKF_HIP(hipMemcpyAsync(r.KcE.ptr, r.KcVal.ptr, (size_t)tot * sizeof(TM), hipMemcpyDeviceToDevice, st));
     }
     SKF_HIP(hipMemsetAsync(r.Sp.ptr, 0, r.Sp.bytes, st));
-    if (r.FoB.bytes) {
-        SKF_HIP(hipMemsetAsync(r.FoB.ptr, 0, r.FoB.bytes, st));
-        SKF_HIP(hipMemsetAsync(r.FiB.ptr, 0, r.FiB.bytes, st));
-    }
+    if (r.FiB.bytes) SKF_HIP(hipMemsetAsync(r.FiB.ptr, 0, r.FiB.bytes, st));
     SKF_HIP(hipStreamSynchronize(st));                      // the host vectors die here; bind is not on the hot path
     r.R = nullptr;                                          // nothing reads the relation itself after this
 }
@@ -2354,6 +2392,24 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 s.kn_pw = ((p->types[s.col].n + s.kn_pc - 1) / s.kn_pc + 63) / 64 * 64;
                 s.kn_ph = ((s.nr + s.kn_pr - 1) / s.kn_pr + 63) / 64 * 64;
                 p->types[s.row].keep_prev = p->types[s.col].keep_prev = true;
+                if (p->bf16) p->types[s.row].need_rows = true;              // the column lists gather the row type's bf16 rows
+            }
+            // sparse 0/1 relations as lists over bf16 factor rows (srp_bf16_v6_kernel<.., SRP_ONES>): both ranks 64 / 128 / 256
+            auto gather_rank = [](int c) { return c == 64 || c == 128 || c == 256; };
+            for (RelState& s : p->rels) {
+                s.sp_gather = p->bf16 && s.binary && !s.masked && !s.absent && !no_v6 && gather_rank(p->types[s.row].c) &&
+                              gather_rank(p->types[s.col].c);
+                if (!s.sp_gather) continue;
+                p->types[s.row].need_rows = p->types[s.col].need_rows = true;
+                // parts by the size of the gathered matrix alone (the number of ones is known at bind time, which may lower them)
+                auto by_bytes = [&](int64_t n_in, int c) {
+                    if (parts_env) return parts_env;
+                    int q = 1;
+                    while (q < 8 && (double)n_in * c * 2.0 / q > 3.5 * 1048576.0) q *= 2;
+                    return q;
+                };
+                s.sp_pc = by_bytes(p->types[s.col].n, p->types[s.col].c);    // P: rows of G_j by the column index
+                s.sp_pr = by_bytes(p->types[s.row].n, p->types[s.row].c);    // Q: rows of G_i by the row index
             }
         }
         p->thetas.resize(n_thetas);
@@ -2376,6 +2432,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         // ---- workspace layout: n-sized buffers in the master type, every c x c matrix in f64
         const size_t es = p->esz;
         size_t part_bytes = 0;
+        size_t sp_part_bytes = 0;
         auto want_part = [&](int M, int N, int K, bool out_f64) {
             TileCfg t = pick_tile(out_f64, p->engine, M, N);
             size_t need = (size_t)pick_splits(t, M, N, K) * (size_t)M * (size_t)N * (out_f64 ? 8 : 4);
@@ -2415,6 +2472,10 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             }
             want_part(t.c, t.c, (int)t.n, true);
             if (t.keep_prev) add_slot(p, t.Gp, (size_t)t.n * t.c * es);
+            if (p->bf16 && t.need_rows) {
+                t.ldrow = (t.c + 7) / 8 * 8;
+                add_slot(p, t.Grow, ((size_t)t.n + 1) * t.ldrow * 2);           // (+ 1: the all-zero row of the v6 list kernel)
+            }
             if (p->variant != SKF_TRANSFORM) {
                 add_slot(p, t.K, (size_t)t.c * t.c * 8);
                 if (!p->f64) {
@@ -2486,10 +2547,8 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 const size_t cnt = std::max((size_t)nr * r.kn_pc, 2 * (size_t)tj.n * r.kn_pr);
                 add_slot(p, r.KCnt, cnt * 4);
                 r.kn_ldf = p->bf16 ? (ti.c + 7) / 8 * 8 : ti.c;
-                if (p->bf16) {
-                    add_slot(p, r.FoB, ((size_t)nr + 1) * r.kn_ldf * 2);          // (+ 1: the all-zero row of the v6 list kernel)
-                    add_slot(p, r.FiB, ((size_t)tj.n + 1) * r.kn_ldf * 2);
-                }
+                if (p->bf16) add_slot(p, r.FiB, ((size_t)tj.n + 1) * r.kn_ldf * 2);  // (+ 1: the all-zero row of the v6 list kernel;
+                                                                                    //  the row type's vectors: ti.Grow)
                 add_slot(p, r.Tm, (size_t)tj.n * ti.c * es);
                 add_slot(p, r.A, (size_t)nr * ti.c * es);
                 if (r.kn_pc > 1) add_slot(p, r.Apart, (size_t)r.kn_pc * nr * ti.c * es);
@@ -2533,8 +2592,16 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 if (r.binary) {
                     r.ldbb = r.ldrb / 8;
                     add_slot(p, r.Bb, (size_t)r.kq * r.ldbb);
-                    if (!r.masked) {                       // room for the CSR / CSC form of a very sparse relation
-                        r.sp_cap = (int64_t)nr * tj.n / 256 > 0 ? (int64_t)nr * tj.n / 256 : 1;
+                    if (!r.masked) {                       // room for the CSR / CSC form of a sparse relation
+                        const int64_t per = r.sp_gather ? 80 : 256;            // (one entry in 80 / in 256 set, see build_sparse_pattern)
+                        r.sp_cap = (int64_t)nr * tj.n / per > 0 ? (int64_t)nr * tj.n / per : 1;
+                        if (r.sp_gather) {
+                            if (r.sp_pc > 1) add_slot(p, r.SpRpP, ((size_t)nr * r.sp_pc + 1) * 8);
+                            if (r.sp_pr > 1) add_slot(p, r.SpCpP, ((size_t)tj.n * r.sp_pr + 1) * 8);
+                            const size_t pb = std::max(r.sp_pc > 1 ? (size_t)r.sp_pc * nr * tj.c * 4 : (size_t)0,
+                                                       r.sp_pr > 1 ? (size_t)r.sp_pr * tj.n * ti.c * 4 : (size_t)0);
+                            if (pb > sp_part_bytes) sp_part_bytes = pb;
+                        }
                         add_slot(p, r.SpRp, (size_t)(nr + 1) * 8);
                         add_slot(p, r.SpCp, (size_t)(tj.n + 1) * 8);
                         add_slot(p, r.SpCi, (size_t)r.sp_cap * 4);
@@ -2634,6 +2701,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         if (theta_tmp_bytes) add_slot(p, p->theta_tmp, theta_tmp_bytes);
         p->part_bytes = part_bytes;
         add_slot(p, p->part, part_bytes);
+        if (sp_part_bytes) add_slot(p, p->sp_part, sp_part_bytes);
         size_t aux_bytes = 0;
         for (TypeState& t : p->types) {
             TileCfg tc = pick_tile(true, p->engine, t.c, t.c);
@@ -2699,7 +2767,10 @@ static void build_sparse_pattern(skf_plan* p, RelState& r, hipStream_t st) {
     int64_t tot = 0;
     for (int64_t k = 0; k < rows; ++k) { ptr[k] = tot; tot += cnt[k]; }
     ptr[rows] = tot;
-    if (tot > r.sp_cap) return;
+    // the form by the count: lists over bf16 factor rows (srp_bf16_v6_kernel<.., SRP_ONES>) up to 1 entry in 80 -- measured
+    // at config 5 (profiles/r03_srp_v6.txt): ~14-22 ps per one and contraction against ~0.28 ps per CELL of the bitmap
+    // kernels, break-even near 1 in 64 --; without that form (other ranks) lists over the f32 rows up to 1 in 256
+    if (tot > r.sp_cap || (!r.sp_gather && tot > rows * cols / 256)) return;
     r.sp_nnz = tot;
     SKF_HIP(hipMemcpyAsync(r.SpRp.ptr, ptr.data(), (size_t)(rows + 1) * 8, hipMemcpyHostToDevice, st));
     SKF_HIP(hipMemsetAsync(colcnt, 0, (size_t)cols * 2 * 4, st));
@@ -2722,6 +2793,23 @@ static void build_sparse_pattern(skf_plan* p, RelState& r, hipStream_t st) {
         hipLaunchKernelGGL(csc_sort_kernel, dim3(elem_grid(cols)), dim3(256), 0, st, (const int64_t*)r.SpCp.ptr,
                            (int*)r.SpRi.ptr, cols);
         check_launch("csc_build");
+    }
+    if (r.sp_gather) {          // lists in parts pinned to XCDs, as long as a segment still holds a batch of entries
+        auto fit = [&](int q, int64_t n_out) {
+            while (q > 1 && (double)tot / ((double)n_out * q) < 64.0) q /= 2;
+            return q;
+        };
+        r.sp_pc = fit(r.SpRpP.ptr ? r.sp_pc : 1, rows);
+        r.sp_pr = fit(r.SpCpP.ptr ? r.sp_pr : 1, cols);
+        r.sp_pw = ((cols + r.sp_pc - 1) / r.sp_pc + 63) / 64 * 64;
+        r.sp_ph = ((rows + r.sp_pr - 1) / r.sp_pr + 63) / 64 * 64;
+        if (r.sp_pc > 1)
+            hipLaunchKernelGGL(parted_ptr_kernel, dim3(elem_grid(rows * r.sp_pc + 1)), dim3(256), 0, st, (const int64_t*)r.SpRp.ptr,
+                               (const int*)r.SpCi.ptr, rows, r.sp_pc, r.sp_pw, (int64_t*)r.SpRpP.ptr);
+        if (r.sp_pr > 1)
+            hipLaunchKernelGGL(parted_ptr_kernel, dim3(elem_grid(cols * r.sp_pr + 1)), dim3(256), 0, st, (const int64_t*)r.SpCp.ptr,
+                               (const int*)r.SpRi.ptr, cols, r.sp_pr, r.sp_ph, (int64_t*)r.SpCpP.ptr);
+        check_launch("parted_ptr");
     }
     SKF_HIP(hipStreamSynchronize(st));
     r.sparse = true;
@@ -2791,7 +2879,10 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             // the caller's bf16 relation is copied ONCE into a zero-padded row-major layout (rows to a multiple of
             // 64: the inner dimension of Q = R^T G_i; columns to a multiple of 64: the inner dimension of
             // P = R G_j); it is not referenced after this call
-            for (TypeState& t : p->types) SKF_HIP(hipMemsetAsync(t.GTb.ptr, 0, t.GTb.bytes, st));
+            for (TypeState& t : p->types) {
+                SKF_HIP(hipMemsetAsync(t.GTb.ptr, 0, t.GTb.bytes, st));
+                if (t.Grow.bytes) SKF_HIP(hipMemsetAsync(t.Grow.ptr, 0, t.Grow.bytes, st));
+            }
             for (RelState& r : p->rels) {
                 if (r.absent || r.kn) continue;
                 const int64_t rows = r.nr, cols = p->types[r.col].n;
@@ -3302,7 +3393,6 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
                 gram_of(tj.Gp.ptr, tj.Gp.ptr, r.Xj.ptr, cj, tj.n);
                 trace_term(r.Xi.ptr, r.Sp.ptr, r.Xj.ptr, r.Sp.ptr, 1.0, false);
             }
-            known_refresh_rows(p, r, st);
             GemmArgs g2 = gemm_args(tj.G.ptr, cj, 1, r.S.ptr, 1, cj, r.Tm.ptr, ci, nj, ci, cj, EPI_STORE, 0);  // T = G_j S^T
             mixed_gemm(p, g2, st);
             if (p->bf16) launch_to_bf16<float>((uint16_t*)r.FiB.ptr, r.kn_ldf, (const float*)r.Tm.ptr, (int64_t)ci, tj.n, ci, false, st);

@@ -1591,9 +1591,11 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(uint16_t* __rest
 
 // SKF_BF16: the multiplicative update (mult_update_kernel) and the refresh of the stored bf16 G^T in one pass over a
 // 32 x 32 tile: G is read and written once, the tile leaves transposed through LDS.  grid = (ceil(c/32), ceil(n/32)).
+// `Grow` (optional): the bf16 ROWS of the new factor as well, [rows][ldrow] -- the gathered matrix of the list passes.
 __global__ __launch_bounds__(256) void mult_update_transpose_kernel(float* __restrict__ G, const float* __restrict__ E,
                                                                     const float* __restrict__ D, int64_t rows, int64_t cols,
-                                                                    uint16_t* __restrict__ GT, int64_t ldgt) {
+                                                                    uint16_t* __restrict__ GT, int64_t ldgt,
+                                                                    uint16_t* __restrict__ Grow, int64_t ldrow) {
     __shared__ uint16_t tile[32][33];
     const float eps = 2.220446049250313e-16f;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
@@ -1608,6 +1610,7 @@ __global__ __launch_bounds__(256) void mult_update_transpose_kernel(float* __res
             const float g = G[r * cols + c] * sqrtf(E[r * cols + c] / den);
             G[r * cols + c] = g;
             h = f32_to_bf16_rne(g);
+            if (Grow) Grow[r * ldrow + c] = h;
         }
         tile[ty + 8 * k][tx] = h;
     }

@@ -321,7 +321,8 @@ __global__ __launch_bounds__(256) void srp_bf16_kernel(SrpArgs<uint16_t, float> 
 // two-element vectors).  Slots past the end of a list point at an all-zero row kept behind the gathered matrix
 // (SrpArgs::zero_off) with r = 0 (e = 0 in SRP_APPLY): they contribute exactly nothing without a mask in the loop.
 // A row of 16 lanes always covers one gathered vector: w = 128 with one 16-byte chunk per lane (CPL = 1), w = 256 with
-// two (CPL = 2: chunks l and 16 + l, two coalesced 256-byte halves) -- the butterfly stays inside the row.
+// two (CPL = 2: chunks l and 16 + l, two coalesced 256-byte halves) -- the butterfly stays inside the row; w = 64 with one
+// 8-byte chunk per lane (DW = 2; the 0/1 relations kept as lists, SRP_ONES: every entry counts 1, no value list at all).
 // The list bounds are moved to scalar registers: the loop and its early exits branch on scalar conditions.
 // (A first version issued the DPP forms as inline assembly: the hazard recogniser does not look into assembly -- DPP
 // after an EXEC write, any other vector-ALU read of a v_dot2c result -- and the s_nop padding that looked sufficient was
@@ -332,11 +333,19 @@ __device__ __forceinline__ int64_t wave_uniform(int64_t x) {               // a 
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)x >> 32));
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
-template <int CPL, int MODE>
+enum { SRP_ONES = 3 };      // srp_bf16_v6_kernel only: every entry counts 1 (0/1 relations as lists: out[o] = sum of Fi[i])
+template <int DW> struct SrpChunk;                                         // DW dwords (2 DW bf16) of a gathered row per lane
+template <> struct SrpChunk<4> { typedef u32x4 type; };
+template <> struct SrpChunk<2> { typedef unsigned int type __attribute__((ext_vector_type(2))); };
+// CPL chunks of DW dwords per lane: w = 16 lanes x CPL x 2 DW elements (DW = 4: 128 / 256, DW = 2: 64 / 128)
+template <int CPL, int MODE, int DW = 4>
 __global__ __launch_bounds__(256) void srp_bf16_v6_kernel(SrpArgs<uint16_t, float> a) {
-    static_assert(CPL == 1 || CPL == 2, "w = 128 or 256");
-    static_assert(MODE == SRP_RESIDUAL || MODE == SRP_APPLY, "the error pass stays on srp_bf16_kernel");
+    static_assert(CPL == 1 || CPL == 2, "one or two chunks per lane");
+    static_assert(DW == 4 || DW == 2, "16- or 8-byte chunks");
+    static_assert(MODE == SRP_RESIDUAL || MODE == SRP_APPLY || MODE == SRP_ONES, "the error pass stays on srp_bf16_kernel");
+    typedef typename SrpChunk<DW>::type chunk_t;
     constexpr int NU = 4;                       // wave steps (gathered rows per lane group) in flight
+    constexpr int CE = 2 * DW;                  // elements of a chunk per lane; a chunk spans 16 CE elements of the row
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
     int part;
@@ -345,34 +354,43 @@ __global__ __launch_bounds__(256) void srp_bf16_v6_kernel(SrpArgs<uint16_t, floa
     const int64_t o = first + wv;
     if (o >= a.n_out) return;                                              // (wave-uniform)
     const int64_t qa = wave_uniform(a.ptr[o * a.parts + part]), qb = wave_uniform(a.ptr[o * a.parts + part + 1]);
-    u32x4 fo[CPL];
+    uint32_t fo[CPL][DW];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-        fo[c] = u32x4{0u, 0u, 0u, 0u};
-        if (MODE == SRP_RESIDUAL) fo[c] = *(const u32x4*)(a.Fo + o * a.ldo + c * 128 + sub * 8);
-    }
-    f32x2 acc[4 * CPL];
 #pragma unroll
-    for (int t = 0; t < 4 * CPL; ++t) acc[t] = f32x2{0.f, 0.f};
+        for (int t = 0; t < DW; ++t) fo[c][t] = 0u;
+        if (MODE == SRP_RESIDUAL) {
+            const chunk_t v = *(const chunk_t*)(a.Fo + o * a.ldo + c * 16 * CE + sub * CE);
+#pragma unroll
+            for (int t = 0; t < DW; ++t) fo[c][t] = v[t];
+        }
+    }
+    f32x2 acc[DW * CPL];
+#pragma unroll
+    for (int t = 0; t < DW * CPL; ++t) acc[t] = f32x2{0.f, 0.f};
     const unsigned char* fi = (const unsigned char*)a.Fi;
-    const uint32_t ldb = (uint32_t)a.ldi * 2u, sub16 = (uint32_t)sub * 16u;
+    const uint32_t ldb = (uint32_t)a.ldi * 2u, subb = (uint32_t)sub * (4u * DW);
     for (int64_t q0 = qa; q0 < qb; q0 += 64) {
         const int nb = (int)(qb - q0 < 64 ? qb - q0 : 64);                 // entries of this batch: lane l loads entry l
         const bool mine = lane < nb;
         const int64_t qm = q0 + (mine ? lane : nb - 1);                    // (clamped: always a valid address)
         const uint32_t ld_i = (uint32_t)a.idx[qm];
-        const float ld_v = MODE == SRP_RESIDUAL ? a.rvals[qm] : a.evals[qm];
+        const float ld_v = MODE == SRP_RESIDUAL ? a.rvals[qm] : MODE == SRP_APPLY ? a.evals[qm] : 1.f;
         const int my_off = (int)(mine ? ld_i * ldb : a.zero_off);
         const float my_v = mine ? ld_v : 0.f;                              // r of the entry (SRP_APPLY: its stored residual)
         float e_out = 0.f;                                                 // SRP_RESIDUAL: the residual of this lane's entry
         auto chunk = [&](auto c0) {                                        // NU steps: k = c0 .. c0 + NU - 1
             constexpr int K0 = decltype(c0)::value;
-            u32x4 v[NU][CPL];
+            uint32_t v[NU][CPL][DW];
             static_for<NU>([&](auto uu) {
                 constexpr int U = decltype(uu)::value;
-                const unsigned char* src = fi + ((uint32_t)row_bcast<K0 + U>(my_off) + sub16);
+                const unsigned char* src = fi + ((uint32_t)row_bcast<K0 + U>(my_off) + subb);
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) v[U][c] = *(const u32x4*)(src + c * 256);
+                for (int c = 0; c < CPL; ++c) {
+                    const chunk_t x = *(const chunk_t*)(src + c * 64 * DW);
+#pragma unroll
+                    for (int t = 0; t < DW; ++t) v[U][c][t] = x[t];
+                }
             });
             static_for<NU>([&](auto uu) {
                 constexpr int U = decltype(uu)::value, K = K0 + U;
@@ -380,7 +398,9 @@ __global__ __launch_bounds__(256) void srp_bf16_v6_kernel(SrpArgs<uint16_t, floa
                 if (MODE == SRP_RESIDUAL) {
                     float x = 0.f;
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) x = dot8_bf16(fo[c], v[U][c], x);
+                    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+                        for (int t = 0; t < DW; ++t) x = dot2_bf16(fo[c][t], v[U][c][t], x);
                     x = dpp_add<0xB1>(x);                                  // quad_perm [1,0,3,2]
                     x = dpp_add<0x4E>(x);                                  // quad_perm [2,3,0,1]
                     x = dpp_add<0x141>(x);                                 // row_half_mirror
@@ -392,14 +412,13 @@ __global__ __launch_bounds__(256) void srp_bf16_v6_kernel(SrpArgs<uint16_t, floa
                 }
                 const f32x2 e2 = {ev, ev};
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-                    const uint32_t w[4] = {v[U][c].x, v[U][c].y, v[U][c].z, v[U][c].w};   // two bf16 per dword: low, high
+                for (int c = 0; c < CPL; ++c)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const f32x2 g = {__builtin_bit_cast(float, w[t] << 16), __builtin_bit_cast(float, w[t] & 0xffff0000u)};
-                        acc[4 * c + t] = __builtin_elementwise_fma(g, e2, acc[4 * c + t]);
+                    for (int t = 0; t < DW; ++t) {                         // two bf16 per dword: low half, high half
+                        const uint32_t w = v[U][c][t];
+                        const f32x2 g = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+                        acc[DW * c + t] = __builtin_elementwise_fma(g, e2, acc[DW * c + t]);
                     }
-                }
             });
         };
         chunk(std::integral_constant<int, 0>());                          // (a group runs out of entries when the batch does)
@@ -410,18 +429,35 @@ __global__ __launch_bounds__(256) void srp_bf16_v6_kernel(SrpArgs<uint16_t, floa
     }
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-        float out[8];
+        float out[CE];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { out[2 * t] = acc[4 * c + t].x; out[2 * t + 1] = acc[4 * c + t].y; }
+        for (int t = 0; t < DW; ++t) { out[2 * t] = acc[DW * c + t].x; out[2 * t + 1] = acc[DW * c + t].y; }
 #pragma unroll
         for (int off = 16; off < 64; off <<= 1)                            // the lane groups of the wave, fixed order
 #pragma unroll
-            for (int t = 0; t < 8; ++t) out[t] += __shfl_xor(out[t], off, 64);
+            for (int t = 0; t < CE; ++t) out[t] += __shfl_xor(out[t], off, 64);
         if (grp == 0) {
-            float* dst = a.out + (int64_t)part * a.part_stride + o * a.ld_out + c * 128 + sub * 8;
+            float* dst = a.out + (int64_t)part * a.part_stride + o * a.ld_out + c * 16 * CE + sub * CE;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) dst[t] = out[t];
+            for (int t = 0; t < CE; ++t) dst[t] = out[t];
         }
+    }
+}
+
+// segment pointers of lists cut into parts of the inner index (ascending within a list): seg[o * parts + p] = the first
+// entry of list o whose inner index is >= p * pw (binary search; one thread per segment), seg[n_out * parts] = the end
+__global__ __launch_bounds__(256) void parted_ptr_kernel(const int64_t* __restrict__ ptr, const int* __restrict__ idx, int64_t n_out,
+                                                         int parts, int64_t pw, int64_t* __restrict__ seg) {
+    const int64_t total = n_out * parts;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= total; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e == total) { seg[e] = ptr[n_out]; continue; }
+        const int64_t o = e / parts, lim = (e % parts) * pw;
+        int64_t lo = ptr[o], hi = ptr[o + 1];
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (idx[mid] < lim) lo = mid + 1; else hi = mid;
+        }
+        seg[e] = lo;
     }
 }
 
@@ -486,10 +522,25 @@ __global__ __launch_bounds__(256) void srp_any_kernel(SrpArgs<TG, TM> a) {
     }
 }
 
-// dst[e] = part 0 + part 1 + ... (fixed order), optionally + add[e]
+// dst[e] = part 0 + part 1 + ... (fixed order).  16-byte chunks where the layout allows it (the strides of the passes are
+// multiples of the rank: always, for the 16-byte-chunk list kernels): the parts of a chunk are independent loads in flight
+// (8 parts of config 5's 40k x 128 column side: 164 MB, 89 -> us with one element per thread and load)
 template <typename T>
 __global__ __launch_bounds__(256) void sum_parts_kernel(T* __restrict__ dst, const T* __restrict__ parts, int64_t stride,
                                                         int nparts, int64_t total) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    const bool vec = total % VE == 0 && stride % VE == 0 && (((uintptr_t)dst | (uintptr_t)parts) & 15) == 0;
+    if (vec) {
+        const int64_t nv = total / VE, sv = stride / VE;
+        const vec_t* src = (const vec_t*)parts;
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nv; e += (int64_t)gridDim.x * blockDim.x) {
+            vec_t s = src[e];
+            for (int p = 1; p < nparts; ++p) s += src[(int64_t)p * sv + e];
+            ((vec_t*)dst)[e] = s;
+        }
+        return;
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         T s = parts[e];
         for (int p = 1; p < nparts; ++p) s += parts[(int64_t)p * stride + e];

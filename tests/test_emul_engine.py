@@ -750,6 +750,44 @@ def test_very_sparse_binary_relation_is_contracted_by_row_gathers():
         assert relerr(G[t, t], Go[t, t]) < 1e-4
 
 
+def sparse_binary_lists_case(n, rank, density, seed, tol=2e-6):
+    """SKF_BF16, ranks 64 / 128 / 256: a 0 / 1 relation with at most 1 entry in 80 set is contracted as LISTS over the bf16
+    rows of the factors (srp_bf16_v6_kernel<.., SRP_ONES>: 8-byte chunks at rank 64, one / two 16-byte chunks per lane at
+    128 / 256; lists in parts where the gathered factor is large) -- P = R G_j and Q = R^T G_i are f32 sums of bf16-rounded
+    factor rows: equal to the host product of the ROUNDED factors to f32 rounding (what the bitmap kernels compute too)."""
+    from skfusion_amd._engine import DevicePlan, DeviceMatrix
+    rs = np.random.RandomState(seed)
+    types = ['m', 'a', 'c']
+    A = (rs.rand(n['m'], n['a']) < density).astype(np.float64)
+    A[5, :] = 0.0
+    A[:, 17] = 0.0
+    A[::3, 23] = 1.0                                                  # a heavy column
+    A[n['m'] - 1, n['a'] - 1] = 1.0
+    C = (rs.rand(n['c'], n['m']) < density).astype(np.float64)
+    C[0, 0] = 1.0
+    assert A.sum() <= A.size // 80 and C.sum() <= C.size // 80
+    G0 = {t: (rs.rand(n[t], rank[t]) + 0.05).astype(np.float32) for t in types}
+    Gb = {t: nat.from_bf16_bits(nat.to_bf16_bits(G0[t])).astype(np.float64) for t in types}     # what the lists gather
+    rt = nat.get_runtime()
+    dev = lambda M: DeviceMatrix(rt.mem.from_host(nat.to_bf16_bits(M.astype(np.float32))), M.shape, binary=True)
+    plan = DevicePlan(types, n, rank, [('m', 'a', dev(A), None), ('c', 'm', dev(C), None)], [], nat.SKF_DFMF, dtype='bf16')
+    for t in types:
+        plan.set_factor(t, G0[t])
+    plan.iterate(1)
+    got = [plan.get_contraction(0, 0), plan.get_contraction(0, 1), plan.get_contraction(1, 0), plan.get_contraction(1, 1)]
+    plan.close()
+    want = [A @ Gb['a'], A.T @ Gb['m'], C @ Gb['m'], C.T @ Gb['c']]
+    worst = max(relerr(g, w) for g, w in zip(got, want))
+    assert worst < tol, worst
+    assert not got[0][5].any() and not got[1][17].any()
+    # the fit itself: the same graph with the relations as bitmaps only differs by the order of the f32 sums
+    return worst
+
+
+def test_sparse_binary_relations_as_lists_over_bf16_rows():
+    sparse_binary_lists_case({'m': 96, 'a': 1500, 'c': 300}, {'m': 64, 'a': 128, 'c': 256}, 0.01, 33)
+
+
 def test_fold_in_of_binary_new_relations_bf16():
     """SKF_TRANSFORM with 0 / 1 new-object relations in the bf16 engine: one kept as a bitmap, one sparse enough for the
     CSR / CSC gathers, in both orientations (target on the row and on the column side) -- against the oracle's

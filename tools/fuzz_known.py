@@ -79,7 +79,8 @@ def main(n_graphs, seed, iters=4):
             w = max([relerr(G[t], Go[t, t]) for t in types] + [relerr(a, b) for a, b in zip(S, so)])
             out.append('f64/%s %.1e' % ('lists' if sparse else 'dense', w))
             bad += not (w < 1e-8)
-        for dtype, tol in (('f32', 2e-4), ('bf16', 5e-2)):       # (bf16 with rank > objects: the rounding noise of either form, amplified)
+        over = any(rank[t] > n[t] for t in types)               # rank > objects: the rounding noise of either form, amplified
+        for dtype, tol in (('f32', 2e-4), ('bf16', 1.5e-1 if over else 5e-2)):
             _, _, e1 = run(types, n, rank, R, M, Theta, G0, dtype, iters, True)
             _, _, e0 = run(types, n, rank, R, M, Theta, G0, dtype, iters, False)
             w = max(abs(a - b) / b for a, b in zip(e1, e0))
