@@ -431,6 +431,7 @@ struct Switches {
     int epi_tile = 128;            // SKF_EPI_TILE=256      completion pass on the 256 x 256 tile (one workgroup per CU)
     bool known_generic = false;    // SKF_KNOWN_GENERIC=1   the any-width list kernel for the known-entry passes (tests, A/B)
     bool known_no_v6 = false;      // SKF_KNOWN_V6=0        the round-3a list kernel (srp_bf16_kernel) at ranks 128 / 256 too (A/B)
+    bool no_gram_aux = false;      // SKF_GRAM_AUX=0        DFMC on known entries: Gram / cross-Gram products on the main stream (A/B)
     bool no_small_fused = false;   // SKF_NO_SMALL_FUSED=1  small graphs on the general staged schedule (~33 launches per iteration)
     static Switches read() {
         auto on = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
@@ -445,6 +446,7 @@ struct Switches {
         w.no_pipeline = on("SKF_NO_PIPELINE");
         w.known_generic = on("SKF_KNOWN_GENERIC");
         { const char* v6 = getenv("SKF_KNOWN_V6"); w.known_no_v6 = v6 && atoi(v6) == 0; }
+        { const char* ga = getenv("SKF_GRAM_AUX"); w.no_gram_aux = ga && atoi(ga) == 0; }
         w.no_small_fused = on("SKF_NO_SMALL_FUSED");
         const char* st = getenv("SKF_SIDE_TILE");
         w.side_tile = st ? atoi(st) : 0;
@@ -1179,6 +1181,19 @@ static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream
 // W = G_i^T R_c G_j for the backbone (_dfmc.py:311-314) with R_c = G_i,prev S_prev G_j,prev^T + E_prev:
 //     W = (G_i^T G_i,prev) S_prev (G_j,prev^T G_j) + (E_prev^T G_i)^T G_j
 // first iteration: R_c = the known entries, zeros elsewhere (_dfmc.py:287-292), i.e. E_prev = R on the lists, S_prev = 0
+// the two cross-Gram matrices of W: Xi = G_i^T G_i,prev, Xj = G_j,prev^T G_j (f64 accumulation over the objects)
+static void known_cross(skf_plan* p, RelState& r, hipStream_t st, bool on_aux) {
+    if (p->kn_first) return;
+    TypeState& ti = p->types[r.row];
+    TypeState& tj = p->types[r.col];
+    const int ci = ti.c, cj = tj.c;
+    void* part = on_aux ? p->part_aux.ptr : p->part.ptr;
+    const size_t part_bytes = on_aux ? p->part_aux_bytes : p->part_bytes;
+    GemmArgs g = gemm_args(ti.G.ptr, 1, ci, ti.Gp.ptr, ci, 1, r.Xi.ptr, ci, ci, ci, (int)r.nr, EPI_STORE, 0);    // Xi = G_i^T G_i,prev
+    run_gemm(GemmTypes{SKF_F64, p->mt, p->mt}, p->engine, g, 0, part, part_bytes, st);
+    g = gemm_args(tj.Gp.ptr, 1, cj, tj.G.ptr, cj, 1, r.Xj.ptr, cj, cj, cj, (int)tj.n, EPI_STORE, 0);             // Xj = G_j,prev^T G_j
+    run_gemm(GemmTypes{SKF_F64, p->mt, p->mt}, p->engine, g, 0, part, part_bytes, st);
+}
 static void known_w(skf_plan* p, RelState& r, hipStream_t st) {
     TypeState& ti = p->types[r.row];
     TypeState& tj = p->types[r.col];
@@ -1187,10 +1202,7 @@ static void known_w(skf_plan* p, RelState& r, hipStream_t st) {
     GemmArgs g = gemm_args(r.Q.ptr, 1, ci, tj.G.ptr, cj, 1, r.W.ptr, cj, ci, cj, (int)tj.n, EPI_STORE, 0);
     wide_gemm(p, g, st);                                                                // W = Y^T G_j
     if (p->kn_first) return;
-    g = gemm_args(ti.G.ptr, 1, ci, ti.Gp.ptr, ci, 1, r.Xi.ptr, ci, ci, ci, (int)r.nr, EPI_STORE, 0);    // Xi = G_i^T G_i,prev
-    wide_gemm(p, g, st);
-    g = gemm_args(tj.Gp.ptr, 1, cj, tj.G.ptr, cj, 1, r.Xj.ptr, cj, cj, cj, (int)tj.n, EPI_STORE, 0);    // Xj = G_j,prev^T G_j
-    wide_gemm(p, g, st);
+    known_cross(p, r, st, false);
     g = gemm_args(r.Sp.ptr, cj, 1, r.Xj.ptr, cj, 1, r.U.ptr, cj, ci, cj, cj, EPI_STORE, 0);             // U = S_prev Xj
     small_gemm(p, g, st);
     g = gemm_args(r.Xi.ptr, ci, 1, r.U.ptr, cj, 1, r.W.ptr, cj, ci, cj, ci, EPI_ACC, 0);                // W += Xi U
@@ -1874,13 +1886,26 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
     // contractions slow down by as much as those kernels take -- they are whole-chip launches and any co-resident
     // workgroup takes a CU from them; what the pipeline can hide is what fits on the 60 CUs the unsplit 196-tile
     // launches leave idle and in the launch tails: +1.5 % it/s.)
+    // DFMC with a relation kept as lists of its known entries: the main stream opens with the pass over the stored
+    // residuals, which is bound by its gathers and leaves the matrix cores idle -- there the Gram products go to the second
+    // stream and run BESIDE the pass (config 5: 138.0 -> 140.9 it/s; with the cross-Gram matrices of W there as well, ahead
+    // of the pseudo-inverses: 139.1 -- they hold up the chain the row pass waits for; profiles/r03_c5_overlap_ab.txt).
     std::vector<int> all;
+    bool any_kn = false;
+    for (const RelState& r : p->rels) any_kn = any_kn || r.kn;
+    const bool gram_aux = dfmc && any_kn && !p->sw.no_gram_aux;
+    if (gram_aux) {
+        SKF_HIP(hipEventRecord(p->ev_fork, st));
+        SKF_HIP(hipStreamWaitEvent(ax, p->ev_fork, 0));
+    }
     for (size_t i = 0; i < nt; ++i) {
-        gram(p, p->types[i], 1, st);
+        gram(p, p->types[i], 1, gram_aux ? ax : st, gram_aux);
         all.push_back((int)i);
     }
-    SKF_HIP(hipEventRecord(p->ev_fork, st));
-    SKF_HIP(hipStreamWaitEvent(ax, p->ev_fork, 0));
+    if (!gram_aux) {
+        SKF_HIP(hipEventRecord(p->ev_fork, st));
+        SKF_HIP(hipStreamWaitEvent(ax, p->ev_fork, 0));
+    }
     plan_pinv(p, all, ax);
     SKF_HIP(hipMemsetAsync((char*)p->ws_base + p->btot_off, 0, p->btot_bytes, ax));
 
