@@ -2090,19 +2090,35 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
 // once -- independent restarts side by side, blockIdx.y = the plan (skf_iterate_batch; p->sm_batch holds their tables)
 template <typename T>
 static void iterate_small_fused_t(skf_plan* p, hipStream_t st, unsigned n_batch = 1) {
+    const SmTables* tb = (const SmTables*)p->sm_tables.ptr;
     const SmTables* const* tbs = (const SmTables* const*)p->sm_batch.ptr;
-    static DeviceOnce once_c, once_u;
-    allow_dynamic_lds(once_c, small_contract_kernel<T>, SM_TILE_BYTES);
-    allow_dynamic_lds(once_u, small_update_kernel<T>, SM_TILE_BYTES);
-    hipLaunchKernelGGL((small_contract_kernel<T>), dim3((unsigned)p->sm_j1.size(), n_batch), dim3(256), SM_TILE_BYTES, st, tbs, (const SmJob*)p->sm_jobs1.ptr);
-    check_launch("small_contract");
-    static DeviceOnce once;
     constexpr int bb_lds = (2 * 64 + 2 * SM_BK) * SM_LD * 8;
-    allow_dynamic_lds(once, small_backbone_kernel, bb_lds);
-    hipLaunchKernelGGL(small_backbone_kernel, dim3((unsigned)(2 * p->rels.size()), n_batch), dim3(256), bb_lds, st, tbs);
-    check_launch("small_backbone");
-    hipLaunchKernelGGL((small_update_kernel<T>), dim3((unsigned)p->sm_j3.size(), n_batch), dim3(256), SM_TILE_BYTES, st, tbs, (const SmJob*)p->sm_jobs3.ptr);
-    check_launch("small_update");
+    const SmJob* j1 = (const SmJob*)p->sm_jobs1.ptr;
+    const SmJob* j3 = (const SmJob*)p->sm_jobs3.ptr;
+    const unsigned n1 = (unsigned)p->sm_j1.size(), n2 = (unsigned)(2 * p->rels.size()), n3 = (unsigned)p->sm_j3.size();
+    if (n_batch > 1) {          // restarts side by side: blockIdx.y = the plan
+        static DeviceOnce once_c, once_b, once_u;
+        allow_dynamic_lds(once_c, small_contract_kernel<T, true>, SM_TILE_BYTES);
+        allow_dynamic_lds(once_b, small_backbone_kernel<true>, bb_lds);
+        allow_dynamic_lds(once_u, small_update_kernel<T, true>, SM_TILE_BYTES);
+        hipLaunchKernelGGL((small_contract_kernel<T, true>), dim3(n1, n_batch), dim3(256), SM_TILE_BYTES, st, tb, tbs, j1);
+        check_launch("small_contract");
+        hipLaunchKernelGGL((small_backbone_kernel<true>), dim3(n2, n_batch), dim3(256), bb_lds, st, tb, tbs);
+        check_launch("small_backbone");
+        hipLaunchKernelGGL((small_update_kernel<T, true>), dim3(n3, n_batch), dim3(256), SM_TILE_BYTES, st, tb, tbs, j3);
+        check_launch("small_update");
+    } else {                    // one plan: its tables are the kernel argument
+        static DeviceOnce once_c, once_b, once_u;
+        allow_dynamic_lds(once_c, small_contract_kernel<T, false>, SM_TILE_BYTES);
+        allow_dynamic_lds(once_b, small_backbone_kernel<false>, bb_lds);
+        allow_dynamic_lds(once_u, small_update_kernel<T, false>, SM_TILE_BYTES);
+        hipLaunchKernelGGL((small_contract_kernel<T, false>), dim3(n1), dim3(256), SM_TILE_BYTES, st, tb, tbs, j1);
+        check_launch("small_contract");
+        hipLaunchKernelGGL((small_backbone_kernel<false>), dim3(n2), dim3(256), bb_lds, st, tb, tbs);
+        check_launch("small_backbone");
+        hipLaunchKernelGGL((small_update_kernel<T, false>), dim3(n3), dim3(256), SM_TILE_BYTES, st, tb, tbs, j3);
+        check_launch("small_update");
+    }
     p->first_iter = false;
 }
 

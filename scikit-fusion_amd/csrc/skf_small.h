@@ -306,9 +306,13 @@ __device__ __forceinline__ bool last_arrival(int* counter, int total) {
 }
 
 // ---- 1 ------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* const* __restrict__ tbs, const SmJob* __restrict__ jobs) {
-    const SmTables* __restrict__ tb = tbs[blockIdx.y];      // blockIdx.y: the plan of a batch of restarts (skf_iterate_batch)
+// BATCH: blockIdx.y = the plan of a batch of restarts (skf_iterate_batch), its tables looked up in `tbs`.  A single plan
+// passes its tables as the kernel argument itself: behind the look-up the compiler no longer treats the table entries as
+// invariant kernel inputs, and the three launches of an iteration took 155 us instead of 132 (dicty, profiles/r03_dicty_batch_ab.txt).
+template <typename T, bool BATCH>
+__global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* __restrict__ tb0, const SmTables* const* __restrict__ tbs,
+                                                             const SmJob* __restrict__ jobs) {
+    const SmTables* __restrict__ tb = BATCH ? tbs[blockIdx.y] : tb0;
     HIP_DYNAMIC_SHARED(double, sm_tiles)     // 2 x SM_BK x SM_LD = 64 x SM_LD doubles: the two staging tiles, or the matrix of the sweep
     double* As = sm_tiles;
     double* Bs = sm_tiles + SM_BK * SM_LD;
@@ -387,8 +391,9 @@ __global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* con
 // on to the +- parts of S Gram_j S^T (row type) and writes S, the odd one to those of S^T Gram_i S (column type) -- the two
 // branches are independent, so the dependent chain is four products deep instead of six.
 // (dynamic LDS: 2 x 64 x 65 doubles + the two staging tiles of SmTile)
-__global__ __launch_bounds__(256) void small_backbone_kernel(const SmTables* const* __restrict__ tbs) {
-    const SmTables* __restrict__ tb = tbs[blockIdx.y];
+template <bool BATCH>
+__global__ __launch_bounds__(256) void small_backbone_kernel(const SmTables* __restrict__ tb0, const SmTables* const* __restrict__ tbs) {
+    const SmTables* __restrict__ tb = BATCH ? tbs[blockIdx.y] : tb0;
     HIP_DYNAMIC_SHARED(double, sm)
     const SmRel& r = tb->r[blockIdx.x >> 1];
     const bool col_side = (blockIdx.x & 1) != 0;
@@ -451,9 +456,10 @@ __global__ __launch_bounds__(256) void small_backbone_kernel(const SmTables* con
 // ---- 7 ------------------------------------------------------------------------------------------------------------
 // job = (type jb.idx, rows r0 .. r0 + nr <= 64): every term of E and D of those rows on the matrix cores, the +- split of a
 // relation side in registers (nan_to_num first, as the reference has it), the type term accumulated straight into E / D
-template <typename T>
-__global__ __launch_bounds__(256) void small_update_kernel(const SmTables* const* __restrict__ tbs, const SmJob* __restrict__ jobs) {
-    const SmTables* __restrict__ tb = tbs[blockIdx.y];
+template <typename T, bool BATCH>
+__global__ __launch_bounds__(256) void small_update_kernel(const SmTables* __restrict__ tb0, const SmTables* const* __restrict__ tbs,
+                                                           const SmJob* __restrict__ jobs) {
+    const SmTables* __restrict__ tb = BATCH ? tbs[blockIdx.y] : tb0;
     HIP_DYNAMIC_SHARED(double, sm_tiles)
     T* As = (T*)sm_tiles;
     T* Bs = (T*)(sm_tiles + SM_BK * SM_LD);
