@@ -37,7 +37,7 @@ def test_algorithmic_work_of_config_3_and_5():
     assert pmc is not None and 7e9 < pmc['bytes'] < 9e9 and 'FETCH_SIZE' in pmc['source']
     assert 'r03' in pmc['source']                                                    # the latest committed pass wins
     c5 = bench.measured_traffic('bf16', True, 1.0)                                   # config 5: its own pass (round 3)
-    assert c5 is not None and 2e9 < c5['bytes'] < 6e9 and 'c5' in c5['source']
+    assert c5 is not None and 3e8 < c5['bytes'] < 1e9 and 'c5' in c5['source']      # (3.7e9 before the lists were pinned to XCDs)
     assert bench.measured_traffic('bf16', False, 0.1) is None and bench.measured_traffic('f32', True, 1.0) is None
     rp = bench.roofline_record('bf16', bench.FULL, bench.RANKS, spec3, 12.0, 6, 9.472e12, 1, 0.015, pmc)
     assert rp['traffic'] == pmc['bytes'] and rp['traffic_ratio'] == pytest.approx(pmc['bytes'] * 6 / 22e9)
