@@ -1,6 +1,6 @@
 """Randomised DFMC graphs with masked relations through the device engine -- lists of the known entries (SKF_DFMC_SPARSE=1) and
 the completed dense copy (=0) -- against the NumPy oracle:   python tools/fuzz_known.py [n_graphs] [seed]
-Sizes 40..500 objects, ranks 2..96 (row type of the masked relations also 128 / 256), lists in 1 / 2 / 4 / 8 parts, 1-25 % of a masked relation known, rows / columns without a known entry, unmasked
+Sizes 40..500 objects, ranks 2..96 below 3/4 of the objects (row type of the masked relations also 128 / 256), lists in 1 / 2 / 4 / 8 parts, 1-25 % of a masked relation known, rows / columns without a known entry, unmasked
 relations beside the masked ones, sparse constraints.  f64: 1e-8 vs the oracle; bf16 / f32: the two device forms against
 each other on the reconstruction error.  Exits non-zero on a violation."""
 import os
@@ -20,6 +20,9 @@ def random_graph(rs):
     types = ['a', 'b', 'c']
     n = {t: int(rs.choice([40, 64, 65, 130, 257, 400, 500])) for t in types}
     rank = {t: int(rs.choice([2, 5, 16, 31, 32, 48, 64, 96])) for t in types}
+    # (rank >= objects makes G^T G singular: the pseudo-inverse's cut-off then decides on rounding noise and ANY two arithmetic
+    #  variants drift apart -- seeds with such types failed between the f32 forms as well; the well-posed case is fuzzed)
+    rank = {t: min(rank[t], max(2, (3 * n[t]) // 4)) for t in types}
     wide = [r for r in (128, 256) if 2 * r <= n['a']]            # the row type of the masked relations at the widths of
     if wide and rs.rand() < 0.6:                                 # srp_bf16_v6_kernel (one / two 16-byte chunks per lane);
         rank['a'] = int(rs.choice(wide))                         # (rank ~ objects: bf16 noise of EITHER form dominates)
