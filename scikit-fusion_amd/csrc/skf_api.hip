@@ -2836,8 +2836,9 @@ static void build_sparse_pattern(skf_plan* p, RelState& r, hipStream_t st) {
         check_launch("csc_build");
     }
     if (r.sp_gather) {          // lists in parts pinned to XCDs, as long as a segment still holds a batch of entries
+        const bool forced = getenv("SKF_KNOWN_PARTS") != nullptr;       // (bind time; tests: short lists in parts too)
         auto fit = [&](int q, int64_t n_out) {
-            while (q > 1 && (double)tot / ((double)n_out * q) < 64.0) q /= 2;
+            while (!forced && q > 1 && (double)tot / ((double)n_out * q) < 64.0) q /= 2;
             return q;
         };
         r.sp_pc = fit(r.SpRpP.ptr ? r.sp_pc : 1, rows);

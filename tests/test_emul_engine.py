@@ -784,8 +784,13 @@ def sparse_binary_lists_case(n, rank, density, seed, tol=2e-6):
     return worst
 
 
-def test_sparse_binary_relations_as_lists_over_bf16_rows():
-    sparse_binary_lists_case({'m': 96, 'a': 1500, 'c': 300}, {'m': 64, 'a': 128, 'c': 256}, 0.01, 33)
+@pytest.mark.parametrize('parts', [0, 4])
+def test_sparse_binary_relations_as_lists_over_bf16_rows(parts, monkeypatch):
+    """parts = 4: SKF_KNOWN_PARTS cuts the (short) lists into four parts of the inner index -- parted_ptr_kernel's binary
+    search, empty segments, partial outputs summed by sum_parts_kernel; 0: the engine's choice (one part at this size)."""
+    if parts:
+        monkeypatch.setenv('SKF_KNOWN_PARTS', str(parts))
+    sparse_binary_lists_case({'m': 96, 'a': 1500, 'c': 300}, {'m': 64, 'a': 128, 'c': 256}, 0.01, 33 + parts)
 
 
 def test_fold_in_of_binary_new_relations_bf16():
