@@ -195,6 +195,14 @@ def test_config5_full_size_completion_and_contractions_against_host_rows(form):
     tr, tc = torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()
     R_rows, U_rows = Rt[tr].to(torch.float64).cpu().numpy(), Mt[tr].cpu().numpy().astype(bool)          # U = unknown
     R_cols, U_cols = Rt[:, tc].to(torch.float64).cpu().numpy(), Mt[:, tc].cpu().numpy().astype(bool)
+    # user x tag (1 % ones): contracted as LISTS over the bf16 rows of the factors (srp_bf16_v6_kernel<.., SRP_ONES>, the column
+    # lists in 8 parts over 25.6 MB of user rows) -- rows and columns of it for the same kind of host check
+    assert (rels[5][0], rels[5][1]) == ('user', 'tag')
+    Tt = rels[5][2].buf.owner
+    tag_cols = np.sort(rs.choice(n['tag'], 24, replace=False))
+    UT_rows = Tt[tr].to(torch.float64).cpu().numpy()
+    UT_cols = Tt[:, torch.from_numpy(tag_cols).cuda()].to(torch.float64).cpu().numpy()
+    del Tt
     plan = DevicePlan(bench.C5_TYPES, n, bench.C5_RANKS, rels, thetas, nat.SKF_DFMC, dtype='bf16',
                       sparse_known=False if form == 'dense' else None)
     plan.release_relation_data()
@@ -204,7 +212,9 @@ def test_config5_full_size_completion_and_contractions_against_host_rows(form):
         plan.set_factor(t, fill_uniform((n[t], bench.C5_RANKS[t]), 100 + k, 'f32'))
     plan.iterate(2)
     Gu, Gm = plan.get_factor('user'), plan.get_factor('movie')          # the factors the third iteration works with
+    Gt = plan.get_factor('tag')
     plan.iterate(1)
+    P_ut, Q_ut = plan.get_contraction(5, 0).astype(np.float64), plan.get_contraction(5, 1).astype(np.float64)
     S = plan.get_backbone(0)                                            # backbone of the third iteration
     P = plan.get_contraction(0, 0 if form == 'dense' else 2).astype(np.float64)      # lists: the row-side product P S^T
     Q = plan.get_contraction(0, 1).astype(np.float64)
@@ -212,6 +222,9 @@ def test_config5_full_size_completion_and_contractions_against_host_rows(form):
 
     def bf16(x):
         return nat.from_bf16_bits(nat.to_bf16_bits(np.asarray(x, dtype=np.float32))).astype(np.float64)
+    # the 0 / 1 relation: f32 sums of bf16-rounded factor rows, in either form of the ratings relation (measured 1.1e-8 / 3.8e-8)
+    within(relerr(P_ut[rows], UT_rows @ bf16(Gt)), 1e-7, 'config 5 full size, user x tag as lists: rows of P vs host')
+    within(relerr(Q_ut[tag_cols], UT_cols.T @ bf16(Gu)), 2e-7, 'config 5 full size, user x tag as lists: rows of Q vs host')
     if form == 'lists':
         # R_c = X + E with X = G_user S G_movie^T and E = R - X on the known entries (skf_known.h):
         #   P S^T = G_user (S Gram_movie S^T) + E T ,  Q = G_movie (S^T Gram_user) + E^T G_user ,  T = G_movie S^T
