@@ -94,11 +94,13 @@ enum {
     SKF_REL_BINARY = 16       /* every entry is 0 or 1 (checked at bind time; "movie has genre", "user tagged").
                                  SKF_BF16 keeps such a relation as a BITMAP -- 1 bit instead of a bf16 per entry
                                  in HBM and on the way to the matrix cores, where it is expanded to bf16 0 / 1 in
-                                 LDS: the same products as the dense form, bit for bit.  When at most 1 entry in
-                                 256 is set, the positions of the ones are also kept as CSR + CSC and both
-                                 contractions become gathers of the f32 factor rows (exact f32 sums; the bitmap
-                                 path rounds the factor to bf16 first).  Ignored for masked relations and by the
-                                 f32 / f64 engines. */
+                                 LDS: the same products as the dense form, bit for bit.  A sparse one also keeps
+                                 the positions of its ones as CSR + CSC and both contractions run over those
+                                 lists: with both ranks 64 / 128 / 256 and at most 1 entry in 80 set, as f32 sums
+                                 of the bf16 rows of the factors (what the bitmap kernels compute, in another
+                                 order); with other ranks and at most 1 entry in 256 set, as gathers of the f32
+                                 factor rows (exact f32 sums).  Ignored for masked relations and by the f32 / f64
+                                 engines. */
 };
 
 typedef struct {
