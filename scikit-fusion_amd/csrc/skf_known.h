@@ -316,9 +316,9 @@ __global__ __launch_bounds__(256) void srp_bf16_kernel(SrpArgs<uint16_t, float> 
 // unfused behind the shuffles of the SLP pass, a compare and two selects per step for the slots past the end of a list.
 // Here, per step (CPL = 1): one v_add_u32_dpp (the lane that loaded entry k of the row holds its BYTE offset, 32 bits:
 // the gathered matrix is below 4 GiB, checked at launch), the 16-byte load off a scalar base, four v_dot2c, the
-// butterfly (the SLP pass pairs the adds of two entries into v_pk_add_f32 behind v_mov_b32_dpp: 1.5 instructions per
-// add), r of lane k minus x, one select to keep the residual, eight conversions and four v_pk_fma_f32 (explicit
-// two-element vectors).  Slots past the end of a list point at an all-zero row kept behind the gathered matrix
+// butterfly as four v_add_f32_dpp, one v_sub_f32_dpp (r of lane k minus x), one select to keep the residual, eight
+// conversions and four v_pk_fma_f32 (explicit two-element vectors; the compiler emits the DPP forms itself once the
+// accumulation is out of the SLP pass's way): 25.  Slots past the end of a list point at an all-zero row kept behind the gathered matrix
 // (SrpArgs::zero_off) with r = 0 (e = 0 in SRP_APPLY): they contribute exactly nothing without a mask in the loop.
 // A row of 16 lanes always covers one gathered vector: w = 128 with one 16-byte chunk per lane (CPL = 1), w = 256 with
 // two (CPL = 2: chunks l and 16 + l, two coalesced 256-byte halves) -- the butterfly stays inside the row; w = 64 with one
