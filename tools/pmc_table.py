@@ -1,4 +1,5 @@
-"""Per-kernel sums of the rocprofv3 --pmc passes of tools/pmc_contraction.sh (rocpd sqlite or csv output) -> a table."""
+"""Per-kernel sums of the rocprofv3 --pmc passes of tools/pmc_contraction.sh / pmc_srp.sh (rocpd sqlite or csv output) -> a table.
+    python tools/pmc_table.py <dir> [substring of the kernel names to list, default gemm_bf16]"""
 import glob
 import os
 import sqlite3
@@ -20,7 +21,7 @@ def from_db(path):
     return out
 
 
-def main(root):
+def main(root, only='gemm_bf16'):
     rows = {}
     for d in sorted(glob.glob(os.path.join(root, '*'))):
         if not os.path.isdir(d):
@@ -29,7 +30,7 @@ def main(root):
             for k, cs in from_db(db).items():
                 rows.setdefault(k, {}).update(cs)
     for k, cs in rows.items():
-        if 'gemm_bf16' not in k:
+        if only not in k:
             continue
         print(k[:120])
         for c in sorted(cs):
@@ -38,4 +39,4 @@ def main(root):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'gemm_bf16')

@@ -1,7 +1,7 @@
 // srp_probe.hip -- stand-alone throughput probe of the known-entry passes of skf_known.h (sparse-residual DFMC):
 // random lists of `per` entries per outer object, gathered rows of width w, 1 / 2 / 4 / 8 parts pinned to XCDs.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I scikit-fusion_amd/csrc tools/probe/srp_probe.hip -o tools/probe/srp_probe
-//   tools/probe/srp_probe <n_out> <n_in> <per> <w> <bf16|f32>
+//   tools/probe/srp_probe <n_out> <n_in> <per> <w> <bf16|f32>     (SRP_TUNED=1 | SRP_V6=1: the tuned kernels; SRP_PARTS=n)
 #include "skf_known.h"
 
 #include <stdio.h>
@@ -42,7 +42,9 @@ static void run(int64_t n_out, int64_t n_in, int per, int w) {
     CK(hipMemcpy(d_fi, fi.data(), fi.size() * sizeof(TG), hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int only_parts = getenv("SRP_PARTS") ? atoi(getenv("SRP_PARTS")) : 0;     // SRP_PARTS=n: that many parts only (PMC passes)
     for (int parts = 1; parts <= 8; parts *= 2) {
+        if (only_parts && parts != only_parts) continue;
         // segment pointers: the entries of an outer object are ascending, a part = a contiguous range of the inner index
         std::vector<int64_t> ptr((size_t)(n_out * parts + 1));
         const int64_t pw = ((n_in + parts - 1) / parts + 63) / 64 * 64;
