@@ -42,9 +42,14 @@ The JSON line also carries
 
 Options beyond the driver's contract (defaults = the metric's configuration):
   --dtype bf16|f32|f64      engine (default bf16, the configuration the metric is quoted on)
-  --mode restarts|relations|rows   N > 1: independent restarts (default, weak scaling) or ONE fit
+  --mode restarts|relations|rows|owned   N > 1: independent restarts (default, weak scaling) or ONE fit
                             sharded by whole relations / balanced row blocks (strong scaling,
-                            RCCL all-reduces between the stages)
+                            RCCL all-reduces between the stages) / ownership of the factor rows (strong
+                            scaling with the least exchange: reduce-scatter of each partial Q, all-gather
+                            of the updated rows -- DESIGN.md 7)
+  --emulate-rank k/W|all/W  ONE GPU: the compute of rank k (or of every rank in turn) of a fit sharded by
+                            ownership over W ranks, exchanges skipped (null communicator) -- the measured
+                            half of the multi-GPU critical path of DESIGN.md 7; adds `emulated_ranks`
   --workload c3|c5          c5 = BASELINE configs[4]: Dfmc, MovieLens-style 6-relation graph
   --data uniform|planted    planted: rank-structured relations + 1 % noise (RMSE discriminates)
   --scale x                 linear scale of the object counts (smoke runs)
@@ -311,8 +316,20 @@ def _parallel_hash_uniform(seed, rows, cols, threads=64):
     return out
 
 
-def _oracle_timing(scale, iters, parallel_data=False):
-    """Seconds of each of `iters` oracle iterations (NumPy, reference operation order, fp64) on the config-3 graph."""
+PARITY_ROWS = 64               # rows of every factor kept for the full-size parity record
+PARITY_ITERS = 2
+
+
+def parity_rows(n_t):
+    """The PARITY_ROWS row indices of a factor of n_t rows that the parity record compares (evenly spread, first and last)."""
+    return np.unique(np.linspace(0, n_t - 1, PARITY_ROWS).astype(np.int64))
+
+
+def _oracle_timing(scale, iters, parallel_data=False, keep=None):
+    """Seconds of each of `iters` oracle iterations (NumPy, reference operation order, fp64) on the config-3 graph.
+    keep (a path): after the last iteration the oracle's backbones, PARITY_ROWS rows of every factor and the three relation
+    errors ||R - G_i S G_j^T||_F (_dfmf.py:306-316: factors AFTER the last update, backbones from before it) go to an
+    .npz there -- what the engine's own first `iters` iterations are compared with (`parity_full_size`)."""
     from oracle import dfmf_oracle as orc
     n = sizes(scale)
     fill = _parallel_hash_uniform if parallel_data else orc.hash_uniform_matrix
@@ -324,20 +341,43 @@ def _oracle_timing(scale, iters, parallel_data=False):
         S, _ = orc._update_S(R, G)
         G = orc._update_G(R, G, S, {}, {}, True)
         times.append(time.perf_counter() - t0)
+    if keep:
+        t0 = time.perf_counter()
+        errs = orc.relation_errors_blocked(R, G, S)
+        out = {'iters': iters, 'err_seconds': time.perf_counter() - t0}
+        for i, j, _ in PAIRS:
+            out['S_%s_%s' % (i, j)] = S[i, j][0]
+            out['err_%s_%s' % (i, j)] = errs[i, j][0]
+        for t in TYPES:
+            out['G_%s' % t] = G[t, t][parity_rows(n[t])]
+        np.savez(keep, **out)
     return times, n
 
 
-def _full_size_child():
-    """`python bench.py --cpu-full-child`: TWO oracle iterations at full size (the second one is reported: BLAS threads
-    and pages warm) after a 1/10-scale warm-up; prints a JSON line.  Runs in a child process so that the parent can bound
-    it in time and memory."""
+def _full_size_child(keep=None):
+    """`python bench.py --cpu-full-child [--parity-out file]`: TWO oracle iterations at full size (the second one is
+    reported: BLAS threads and pages warm) after a 1/10-scale warm-up; prints a JSON line.  Runs in a child process so that
+    the parent can bound it in time and memory."""
     _oracle_timing(0.1, 1)
     t0 = time.perf_counter()
-    times, n = _oracle_timing(1.0, 2, parallel_data=True)
+    times, n = _oracle_timing(1.0, PARITY_ITERS, parallel_data=True, keep=keep)
     print(json.dumps({'times': times, 'total_seconds': time.perf_counter() - t0}))
 
 
-def cpu_baseline(full='auto'):
+def parity_record(oracle_npz, engine):
+    """`parity_full_size` of one engine: its first PARITY_ITERS iterations from the hash-generated G0 against the oracle's
+    (same inputs, FULL size) -- max relative deviation of the backbones (Frobenius), of PARITY_ROWS rows of every factor, and
+    of the three relation errors.  north_star: results must match the reference path on the same inputs."""
+    z = np.load(oracle_npz)
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, dtype=np.float64) - b) / max(np.linalg.norm(b), 1e-300))   # noqa: E731
+    return {'iters': int(z['iters']),
+            'S_relerr': max(rel(engine['S_%s_%s' % (i, j)], z['S_%s_%s' % (i, j)]) for i, j, _ in PAIRS),
+            'G_rows_relerr': max(rel(engine['G_%s' % t], z['G_%s' % t]) for t in TYPES),
+            'err_relerr': max(abs(float(engine['err_%s_%s' % (i, j)]) / float(z['err_%s_%s' % (i, j)]) - 1.0) for i, j, _ in PAIRS),
+            'oracle_err': {'%s-%s' % (i, j): float(z['err_%s_%s' % (i, j)]) for i, j, _ in PAIRS}}
+
+
+def cpu_baseline(full='auto', parity_out=None):
     """Oracle (kind=port) on the host cores.  When the host can hold the fp64 graph (88 GB + temporaries: RAM >= 256 GiB
     and >= 32 cores) two iterations are timed at FULL size in a child process bounded to 300 s and the
     second is reported; otherwise, or when that fails, the 1/10-linear-scale sample is timed and scaled by the n_i*n_j work
@@ -350,8 +390,10 @@ def cpu_baseline(full='auto'):
     if want_full:
         import subprocess
         try:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-full-child'], capture_output=True,
-                                 text=True, timeout=300)
+            cmd = [sys.executable, os.path.abspath(__file__), '--cpu-full-child']
+            if parity_out:
+                cmd += ['--parity-out', parity_out]
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
             r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
             base.update({'value': 1.0 / r['times'][-1], 'projection': False,
                          'sample': 'oracle (NumPy fp64, reference op order, 3 big GEMMs per relation, scipy pinv) at FULL size, '
@@ -438,15 +480,20 @@ def bench_dicty(iters=100):
 
 
 def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode='restarts', rank=0, world=1, dist=None,
-                 backend='nccl'):
-    """One engine on one workload.  Returns dict(elapsed, k_ms, k_launches, k_flops, k_bytes, rmse, n, spec, ranks, types)."""
+                 backend='nccl', emulate=None, parity=False):
+    """One engine on one workload.  Returns dict(elapsed, k_ms, k_launches, k_flops, k_bytes, rmse, n, spec, ranks, types).
+    emulate = (k, W): this process computes what rank k of W would in mode 'owned', exchanges skipped (timing only).
+    parity: the first PARITY_ITERS iterations are run apart and their backbones, PARITY_ROWS factor rows and relation errors
+    kept (`parity` of the result; config 3, one GPU) -- the engine's side of `parity_full_size`; the timed steps follow on."""
     import torch
     import skfusion_amd._native as nat
     from skfusion_amd._engine import DevicePlan, fill_uniform
     c5 = (workload == 'c5')
     types, ranks_ = (C5_TYPES, C5_RANKS) if c5 else (TYPES, RANKS)
     n = sizes(scale, C5_FULL if c5 else FULL)
-    sharded = (mode in ('relations', 'rows') and world > 1)
+    if emulate:
+        mode, (rank, world) = 'owned', emulate
+    sharded = (mode in ('relations', 'rows', 'owned') and world > 1)
     variant = nat.SKF_DFMC if c5 else nat.SKF_DFMF
     esz = {'bf16': 2, 'f32': 4, 'f64': 8}[dtype]
     # the whole graph as (row, col, masked) + a maker of relation k's device matrices
@@ -487,10 +534,25 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
             rels.append((i, j, rdata.rows(a, cnt, esz), None if mask is None else mask.rows(a, cnt, 1),
                          dict(absent=False, row_begin=a, n_rows=cnt, col_side=(a == 0), masked=masked)))
             del rdata, mask
+    elif sharded and mode == 'owned':         # the rows of every type this rank owns, with the matching rows of the relations
+        from skfusion_amd._engine import owned_rows
+        rels = []
+        for k, (i, j, masked) in enumerate(spec):
+            a, cnt, _ = owned_rows(dtype, n[i], rank, world)
+            if cnt == 0:
+                rels.append((i, j, None, None, dict(absent=True, row_begin=0, n_rows=0, masked=masked)))
+                continue
+            rdata, mask = make(k)
+            blk = dict(absent=False, row_begin=a, n_rows=cnt, masked=masked)
+            if dtype == 'bf16' and mask is None:
+                blk['binary'] = bool(rdata.binary)
+            rels.append((i, j, rdata.rows(a, cnt, esz), None if mask is None else mask.rows(a, cnt, 1), blk))
+            del rdata, mask
     else:
         rels = [(spec[k][0], spec[k][1]) + make(k) for k in local_index]
     plan = DevicePlan(types, n, ranks_, rels, thetas, variant, dtype=dtype,
-                      part=(rank, world) if sharded and mode == 'rows' else None)
+                      part=(rank, world) if sharded and mode in ('rows', 'owned') else None,
+                      owned=sharded and mode == 'owned')
     if dtype == 'bf16':          # the plan keeps its own padded bf16 copy (or bitmap / lists) of every relation
         plan.release_relation_data()
         rels = full_rels = None
@@ -499,10 +561,14 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
         seed = 100 + k + (0 if sharded else 10 * rank)       # sharded: replicated factors
         plan.set_factor(t, fill_uniform((n[t], ranks_[t]), seed, MASTER[dtype]))
     exchange = None
-    if sharded:                        # the library issues the exchanges itself: RCCL, or torch.distributed callbacks over gloo
+    if emulate:
+        plan.attach_null_comm(rank, world)
+        exchange = plan.exchange_bytes(world)
+    elif sharded:                      # the library issues the exchanges itself: RCCL, or torch.distributed callbacks over gloo
         plan.attach_comm()
         exchange = plan.exchange_bytes(world)
-    step = plan.iterate if not sharded else (plan.iterate_rows if mode == 'rows' else plan.iterate_sharded)
+    step = plan.iterate if not sharded else {'rows': plan.iterate_rows, 'relations': plan.iterate_sharded,
+                                             'owned': plan.iterate_dist}[mode]
 
     def sync():
         torch.cuda.synchronize()
@@ -510,6 +576,15 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
             dist.barrier()
             torch.cuda.synchronize()
 
+    kept = None
+    if parity and not sharded and not c5:
+        step(PARITY_ITERS)
+        kept = {}
+        for q, (i, j, _) in enumerate(spec):
+            kept['S_%s_%s' % (i, j)] = plan.get_backbone(q)
+            kept['err_%s_%s' % (i, j)] = float(np.sqrt(max(plan.relation_sqerr(q), 0.0)))
+        for t in types:
+            kept['G_%s' % t] = plan.get_factor(t)[parity_rows(n[t])]
     if warmup:
         step(warmup)
     sync()
@@ -525,7 +600,9 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     rmse = {}
-    if sharded and mode == 'rows':            # every rank holds the squared error of its row blocks
+    if emulate:
+        pass                                  # (no exchanges: the factors mean nothing)
+    elif sharded and mode in ('rows', 'owned'):   # every rank holds the squared error of its row blocks
         sq = torch.tensor([plan.relation_sqerr(k) for k in range(len(spec))], dtype=torch.float64,
                           device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(sq)
@@ -540,7 +617,36 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
     torch.cuda.empty_cache()
     return {'elapsed': elapsed, 'k_ms': k_ms, 'k_launches': k_launches, 'k_flops': k_flops, 'k_bytes': k_bytes,
             'rmse': rmse, 'n': n, 'spec': spec, 'ranks': ranks_, 'types': types, 'sharded': sharded,
-            'exchange_bytes': exchange}
+            'exchange_bytes': exchange, 'parity': kept}
+
+
+XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md: 7 xGMI links per GPU, ~153 GB/s each (fully connected 8-GPU node)
+
+
+def emulated_ranks(args):
+    """`--emulate-rank k/W`: per-rank compute time of the ownership-sharded fit measured on THIS GPU (exchanges skipped) and
+    the wire time of the rank's exchange bytes modelled on the xGMI links (reduce-scatter / all-gather of a buffer over a
+    fully connected node: every peer's share crosses its own link, so a rank's bytes move at up to 7 links x 153 GB/s;
+    `wire_ms_ring` prices the same bytes on ONE link, the bound of a ring).  No multi-GPU node was available to the
+    builder: the sum is a model, the compute term is a measurement."""
+    which, world = args.emulate_rank.split('/')
+    world = int(world)
+    ks = list(range(world)) if which == 'all' else [int(which)]
+    out = {'metric': 'per-rank compute of the ownership-sharded iteration (exchanges skipped)', 'world': world,
+           'dtype': args.dtype, 'workload': args.workload, 'scale': args.scale, 'steps': args.steps, 'ranks': []}
+    for k in ks:
+        w = run_workload(args.workload, args.dtype, args.steps, args.warmup, args.scale, args.data, emulate=(k, world))
+        ms = w['elapsed'] / args.steps * 1e3
+        xb = float(w['exchange_bytes'])
+        out['ranks'].append({'rank': k, 'compute_ms_per_step': ms, 'exchange_bytes_per_step': xb,
+                             'wire_ms_all_links': xb / (7 * XGMI_LINK_GBS * 1e9) * 1e3,
+                             'wire_ms_ring': xb / (XGMI_LINK_GBS * 1e9) * 1e3})
+    worst = max(r['compute_ms_per_step'] for r in out['ranks'])
+    out['max_compute_ms_per_step'] = worst
+    out['modelled_ms_per_step'] = {'no_overlap_all_links': worst + out['ranks'][0]['wire_ms_all_links'],
+                                   'no_overlap_ring': worst + out['ranks'][0]['wire_ms_ring'],
+                                   'full_overlap': max(worst, out['ranks'][0]['wire_ms_all_links'])}
+    return out
 
 
 def compact_roofline(r):
@@ -597,19 +703,25 @@ def main():
     ap.add_argument('--workload', default='c3', choices=['c3', 'c5'],
                     help='c3 (default): BASELINE configs[2], the metric\'s workload; c5: BASELINE configs[4], '
                          'Dfmc on the MovieLens-style 6-relation graph with masks and constraints')
-    ap.add_argument('--mode', default='restarts', choices=['restarts', 'relations', 'rows'],
+    ap.add_argument('--emulate-rank', default=None, metavar='k/W',
+                    help='one GPU: time the compute of rank k (or `all`: every rank in turn) of W of the ownership-sharded '
+                         'fit, exchanges skipped')
+    ap.add_argument('--mode', default='restarts', choices=['restarts', 'relations', 'rows', 'owned'],
                     help='N>1: one independent restart per GPU (weak scaling, no collective; default); or ONE fit '
                          '(strong scaling) with whole relations partitioned over the GPUs and an RCCL all-reduce of '
                          'the E/D accumulators per iteration (relations), or with balanced row blocks of the '
-                         'relations and all-reduces of W, Q and E/D (rows)')
+                         'relations and all-reduces of W, Q and E/D (rows), or with the rows of every object type and '
+                         'the matching rows of its relations -- reduce-scatter of the partial Q, all-gather of the updated '
+                         'rows (owned)')
     ap.add_argument('--cpu-full-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--parity-out', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'full', 'sample'],
                     help='cpu_baseline leg: oracle iterations at FULL size when the host can hold them (auto), always, or the 1/10-scale sample')
     ap.add_argument('--no-engines', action='store_true', help='skip the short f32 / f64 runs of the default record')
     ap.add_argument('--no-workloads', action='store_true', help='skip the config 5 / dicty / planted legs of the default record')
     args = ap.parse_args()
     if args.cpu_full_child:
-        _full_size_child()
+        _full_size_child(args.parity_out)
         return
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -645,8 +757,15 @@ def main():
         dist.barrier()
 
     c5 = (args.workload == 'c5')
+    if args.emulate_rank:
+        print(json.dumps(emulated_ranks(args)))
+        return
+    default_run = world == 1 and not c5 and args.scale == 1.0 and args.data == 'uniform'
+    want_parity = default_run and not args.no_cpu_baseline
+    parity_kept = {}
     w = run_workload(args.workload, args.dtype, args.steps, args.warmup, args.scale, args.data, args.mode, rank, world,
-                     dist, backend)
+                     dist, backend, parity=want_parity)
+    parity_kept[args.dtype] = w['parity']
     elapsed, rmse, n, spec, ranks_, types = w['elapsed'], w['rmse'], w['n'], w['spec'], w['ranks'], w['types']
     sharded = w['sharded']
     units = 1 if sharded else world        # fits advanced per step by the whole job
@@ -655,7 +774,8 @@ def main():
     if rank == 0:
         how = {'restarts': 'one random restart per GPU',
                'relations': 'one fit, whole relations partitioned over the GPUs',
-               'rows': 'one fit, balanced row blocks of the relations over the GPUs'}[args.mode]
+               'rows': 'one fit, balanced row blocks of the relations over the GPUs',
+               'owned': 'one fit, every GPU owns the same share of the rows of every object type'}[args.mode]
         roof = roofline_record(args.dtype, n, ranks_, spec, w['k_ms'], w['k_launches'], w['k_flops'], args.steps, elapsed,
                                measured_traffic(args.dtype, c5, args.scale), w['k_bytes'], executed=c5)
         out = {
@@ -689,14 +809,14 @@ def main():
             'hbm_frac': (roof.get('hbm_scheduled') or roof.get('hbm_algorithmic') or {}).get('frac'),
             'host': host_info(),
         }
-    default_run = world == 1 and not c5 and args.scale == 1.0 and args.data == 'uniform'
     if default_run and not args.no_engines:
         # the reference computes in f64: short runs of the f32 and f64 engines on the same graph
         engines = {}
         for dt in ('f32', 'f64'):
             if dt == args.dtype:
                 continue
-            e = run_workload('c3', dt, 3, 1)
+            e = run_workload('c3', dt, 3, 1, parity=want_parity)
+            parity_kept[dt] = e['parity']
             r = roofline_record(dt, n, ranks_, spec, e['k_ms'], e['k_launches'], e['k_flops'], 3, e['elapsed'])
             engines[dt] = {'value': 3 / e['elapsed'], 'unit': 'iters/s', 'steps': 3, 'warmup': 1,
                            'ms_per_step': e['elapsed'] / 3 * 1e3, 'rmse': e['rmse'], 'bound': r['bound'],
@@ -709,7 +829,21 @@ def main():
             if c5:
                 out['cpu_baseline'] = cpu_baseline_c5(0.25 * args.scale, args.scale)
             else:
-                out['cpu_baseline'] = cpu_baseline(full={'auto': 'auto', 'full': True, 'sample': False}[args.cpu_baseline])
+                import tempfile
+                pfile = os.path.join(tempfile.gettempdir(), 'skf_parity_%d.npz' % os.getpid()) if want_parity else None
+                out['cpu_baseline'] = cpu_baseline(full={'auto': 'auto', 'full': True, 'sample': False}[args.cpu_baseline],
+                                                   parity_out=pfile)
+                # full-size parity: the engine's first iterations against the oracle's on the same inputs (both legs ran
+                # above; the oracle's only when the host could hold the fp64 graph)
+                if pfile and os.path.exists(pfile) and not out['cpu_baseline'].get('projection', True):
+                    out['parity_full_size'] = {dt: parity_record(pfile, kept) for dt, kept in parity_kept.items() if kept}
+                    out['parity_full_size']['what'] = ('engine vs NumPy oracle (reference op order, fp64) after %d iterations '
+                                                       'from the same counter-based R and G0 at FULL size: max relative deviation of '
+                                                       'the backbones, of %d rows of every factor, of the relation errors'
+                                                       % (PARITY_ITERS, PARITY_ROWS))
+                    os.remove(pfile)
+                elif want_parity:
+                    out['parity_full_size'] = {'error': 'no full-size oracle run on this host (cpu_baseline.projection)'}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -124,7 +124,21 @@ typedef struct {
      * D_i += G_i * sum_r B_r^+ (_dfmf.py:260-264,272-276,278-282 summed over the relations, which is
      * linear in B) on its 1/part_count share of the rows of every type.  0, 0 = all rows. */
     int32_t part_index, part_count;
+    int32_t flags;       /* SKF_OPT_* (ABI version 4: the field is new; callers check skf_abi_version() when they load the library) */
 } skf_options;
+
+enum {
+    SKF_OPT_OWNED_ROWS = 1 /* Ownership-aligned row sharding of ONE fit over `part_count` processes (replaces the
+                              reference's per-block joblib tasks, _dfmf.py:69-73, _dfmc.py:341-345): process `part_index` OWNS the
+                              rows skf_owned_rows() names of EVERY object type -- their factor rows, their E / D accumulators,
+                              their update -- and holds exactly those rows of every relation whose row type it is (the
+                              descriptors carry that block, or SKF_REL_ABSENT where the process owns no row of the type), and
+                              every constraint in full.  Row-side terms, type-level terms and constraint rows then need NO
+                              exchange; per iteration a process sends only: the partial Q = R_blk^T G_i[blk] of every relation
+                              (reduce-scatter to the owners of the column type), the updated factor rows (all-gather; SKF_BF16:
+                              the bf16 operand copy only, unless a constraint on the type reads the f32 rows), and the c x c
+                              partial Gram / W matrices (all-reduce).  Such a plan iterates through skf_iterate_dist only. */
+};
 
 /* ---- plan life cycle ------------------------------------------------------------------- */
 
@@ -228,15 +242,26 @@ int skf_exchange_range(const skf_plan* plan, int32_t which, size_t* offset, size
  * all-reduce; E and D as REDUCE-SCATTER over `world` equal element ranges of the accumulator regions, the multiplicative
  * update of the owned range of G, and an ALL-GATHER of G -- 3 (world-1)/world of the factor bytes per rank and iteration
  * instead of the 4 (world-1)/world of all-reducing both accumulators (config 3 on 8 GPUs: 444 MB instead of 592 MB).  Every
- * rank ends an iteration with identical factors.  skf_exchange_bytes: bytes one rank sends per iteration on a ring. */
+ * rank ends an iteration with identical factors.  skf_exchange_bytes: bytes one rank sends per iteration on a ring.
+ * SKF_OPT_OWNED_ROWS plans (ownership-aligned row blocks): no exchange of E / D at all -- all-reduce of the c x c partial
+ * Gram and W matrices, one reduce-scatter per relation of its partial Q to the owners of the column type, update of the
+ * OWNED rows, one all-gather per type of the updated rows (SKF_BF16: of their bf16 operand copy; the f32 rows of the other
+ * owners are fetched once, at the end of the call).  The exchanges go out on a stream of their own as soon as their input
+ * is complete -- a relation's Q under the next relation's contractions, a type's gather as soon as its last relation is
+ * through -- and the communicator's (rank, world) must be the plan's (part_index, part_count).  Config 3 on 8 GPUs, bf16:
+ * 172 MB per rank and iteration instead of 605 MB. */
 typedef struct skf_comm skf_comm;
 /* op 0: all-reduce(sum) of `count` elements in place; 1: reduce-scatter(sum) -- `buf` holds world * count elements, on
  * return elements [rank * count, (rank + 1) * count) are reduced; 2: all-gather of that range to every rank, in place.
- * dtype SKF_F64 / SKF_F32; `buf` is device memory, the call is ordered on `stream`; return 0 on success. */
+ * dtype SKF_F64 / SKF_F32 (SKF_BF16: 2-byte elements, all-gather only); `buf` is device memory, the call is ordered on
+ * `stream`; return 0 on success. */
 typedef int (*skf_collective_fn)(void* user, int32_t op, void* buf, size_t count, int32_t dtype, void* stream);
 int skf_comm_unique_id(void* id128);
 int skf_comm_create(const void* id128, int32_t rank, int32_t world, skf_comm** out);   /* id128 == NULL: world must be 1 */
 int skf_comm_create_callback(int32_t rank, int32_t world, skf_collective_fn fn, void* user, skf_comm** out);
+/* A communicator whose collectives do nothing: `rank` of `world` on ONE device, for timing the compute of that rank of a
+ * sharded fit where the other ranks do not exist (bench.py --emulate-rank k/W).  Results are meaningless. */
+int skf_comm_create_null(int32_t rank, int32_t world, skf_comm** out);
 int skf_comm_destroy(skf_comm* comm);
 int skf_plan_set_comm(skf_plan* plan, skf_comm* comm);     /* not owned by the plan; NULL detaches */
 int skf_iterate_dist(skf_plan* plan, int32_t n_iters, void* stream);
@@ -341,8 +366,18 @@ int skf_fill_unknown(int32_t dtype, void* data, int64_t ld, int64_t rows, int64_
 int skf_cast(int32_t dst_dtype, void* dst, int64_t ldd, int32_t src_dtype, const void* src,
              int64_t lds, int64_t rows, int64_t cols, void* stream);
 
+/* Rows [*begin, *begin + *count) of a type of `n_obj` objects that process `part_index` of `part_count` owns under
+ * SKF_OPT_OWNED_ROWS; *chunk = rows per process of the padded layout the exchanges use (equal for all processes, a multiple
+ * of 256 for large types / of 64 for SKF_BF16; part_count * chunk >= n_obj, the last owners may hold fewer rows or none). */
+int skf_owned_rows(int32_t dtype, int64_t n_obj, int32_t part_index, int32_t part_count, int64_t* begin, int64_t* count,
+                   int64_t* chunk);
+
 const char* skf_last_error(void);
 const char* skf_version(void);
+/* Layout version of the structs and signatures above (SKF_ABI_VERSION).  A binding built against another version must not
+ * call the library: descriptors grew between versions (skf_relation_desc.known_bound: 3, skf_options.flags: 4). */
+#define SKF_ABI_VERSION 4
+int skf_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -190,6 +190,22 @@ def relation_errors(R, G, S):
     return errs
 
 
+def relation_errors_blocked(R, G, S, rows=4096):
+    """The same errors (_dfmf.py:306-316) summed over row blocks of the relation: the n_i x n_j reconstruction is never
+    held as a whole (config 3 at full size: 40 GB per relation).  Equal to relation_errors up to the order of the sum."""
+    errs = {}
+    for (i, j), mats in R.items():
+        errs[i, j] = []
+        for l, Rl in enumerate(mats):
+            H = np.dot(S[i, j][l], G[j, j].T)
+            sq = 0.0
+            for r0 in range(0, Rl.shape[0], rows):
+                d = Rl[r0:r0 + rows] - np.dot(G[i, i][r0:r0 + rows], H)
+                sq += float(np.vdot(d, d))
+            errs[i, j].append(np.sqrt(sq))
+    return errs
+
+
 # --------------------------------------------------------------------------------------
 # the three solver entry points
 # --------------------------------------------------------------------------------------

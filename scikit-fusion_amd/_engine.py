@@ -81,6 +81,17 @@ def fill_uniform(shape, seed, dtype='f32', scale=1.0, shift=0.0, runtime=None):
     return DeviceMatrix(buf, shape)
 
 
+def owned_rows(dtype, n_obj, part_index, part_count, runtime=None):
+    """(begin, count, chunk): the rows of a type of `n_obj` objects that part `part_index` of `part_count` owns under
+    SKF_OPT_OWNED_ROWS, and the rows per part of the padded layout (skf_owned_rows: the library is the one place that
+    decides the boundaries)."""
+    rt = runtime or nat.get_runtime()
+    code = nat.DTYPES[dtype] if isinstance(dtype, str) else dtype
+    b, c, ch = C.c_int64(), C.c_int64(), C.c_int64()
+    rt.call('skf_owned_rows', code, int(n_obj), int(part_index), int(part_count), C.byref(b), C.byref(c), C.byref(ch))
+    return b.value, c.value, ch.value
+
+
 def _sparse_bound(nnz, n):
     """skf_theta_desc.nnz for a constraint with `nnz` non-zeros: the count itself when the matrix is sparse enough for
     the CSR path (<= n*n/16), 0 (dense product, as the reference) otherwise or when unknown."""
@@ -164,15 +175,87 @@ def _exchange(mem, tensors, reduce=None):
     mem.synchronize()
 
 
+_RCCL = {}          # (rank, world) -> communicator handle, or False when RCCL could not be bound on every rank
+
+
+def _shared_rccl_comm(rt, dist):
+    """The process's RCCL communicator (created once, reused by every plan and restart), or None when it cannot be had on
+    EVERY rank -- all ranks then agree on the callback path instead of some blocking in a broadcast the others never
+    reach.  Collective: every rank of the group must call it."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    key = (rank, world)
+    if key in _RCCL:
+        return _RCCL[key] or None
+    ident = [None]
+    if rank == 0:
+        try:
+            buf = (C.c_char * 128)()
+            rt.call('skf_comm_unique_id', buf)
+            ident[0] = bytes(buf)
+        except nat.SkfNativeError as exc:          # librccl not resolvable / symbol missing: tell the others
+            import logging
+            logging.getLogger('skfusion_amd').warning('RCCL not bound (%s): collectives through torch.distributed', exc)
+    dist.broadcast_object_list(ident, src=0)
+    comm, ok = nat._P(), 0
+    if ident[0] is not None:
+        try:
+            raw = (C.c_char * 128).from_buffer_copy(ident[0])
+            rt.call('skf_comm_create', raw, rank, world, C.byref(comm))
+            ok = 1
+        except nat.SkfNativeError as exc:
+            import logging
+            logging.getLogger('skfusion_amd').warning('skf_comm_create failed on rank %d (%s)', rank, exc)
+    flag = torch.tensor([ok], dtype=torch.int32, device='cuda' if dist.get_backend() != 'gloo' else 'cpu')
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        if ok:
+            rt.lib.skf_comm_destroy(comm)
+        _RCCL[key] = False
+        return None
+    _RCCL[key] = comm
+    return comm
+
+
+def _torch_collective(mem, ws, dist, rank, world):
+    """skf_collective_fn over torch.distributed on views of the workspace `ws` (gloo groups: CPU tests, smoke runs)."""
+    def collective(user, op, buf, count, dtype, stream):
+        try:
+            import torch
+            npd = np.int16 if dtype == nat.SKF_BF16 else nat.NP_DTYPE[dtype]
+            es = np.dtype(npd).itemsize
+            n = count * (1 if op == 0 else world)
+            view = mem.as_tensor(ws, int(buf) - ws.ptr, n * es, npd)
+            mem.synchronize()
+            host = view.cpu() if view.is_cuda else view
+            if op in (0, 1):              # (reduce-scatter: the all-reduce of the whole buffer covers the owned range)
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            else:
+                parts = [torch.empty(count, dtype=host.dtype) for _ in range(world)]
+                dist.all_gather(parts, host[rank * count:(rank + 1) * count].clone())
+                host = torch.cat(parts)
+            if view.is_cuda or host is not view:
+                view.copy_(host)
+            mem.synchronize()
+            return 0
+        except Exception:                 # never unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1
+    return collective
+
+
 class DevicePlan(object):
     """One (run, device) plan: relations + constraints uploaded, workspace bound."""
 
     def __init__(self, obj_types, n_obj, rank, relations, thetas, variant, dtype='f64',
-                 target=None, engine=None, runtime=None, part=None, stream=None, sparse_known=None):
+                 target=None, engine=None, runtime=None, part=None, stream=None, sparse_known=None, owned=False):
         """relations: list of (row_type, col_type, ndarray, mask-or-None[, block]);
         thetas: list of (type, ndarray).  `block` (row-block sharding, `_distributed.partition_rows`)
         = dict(row_begin, n_rows, absent, col_side, masked): data / mask then hold only the local rows
         (None when absent); `part` = (index, count) of this plan among the row-block plans.
+        `owned`: the row blocks are the ranges of `owned_rows` (SKF_OPT_OWNED_ROWS: every rank owns the same share of the rows
+        of every type; such a plan iterates through iterate_dist only).
         `sparse_known` (DFMC): None = the engine decides from the number of known entries of every masked relation
         whether to keep only those (skf_relation_desc.known_bound); False = always the completed dense copy."""
         self.rt = runtime or nat.get_runtime()
@@ -275,7 +358,9 @@ class DevicePlan(object):
             hdesc[k].nnz = _sparse_bound(int(np.count_nonzero(arr)), n_obj[t])
         opt = nat.Options(self.dtype, variant, self.index[target] if target is not None else -1,
                           nat.SKF_ENGINE_MFMA if engine is None else engine,
-                          part[0] if part else 0, part[1] if part else 0)
+                          part[0] if part else 0, part[1] if part else 0,
+                          nat.SKF_OPT_OWNED_ROWS if owned else 0)
+        self.owned = bool(owned)
         self.rt.call('skf_plan_create', len(self.types), tdesc, len(relations), rdesc, len(thetas),
                      hdesc, C.byref(opt), C.byref(self.handle))
         nbytes = C.c_size_t()
@@ -430,8 +515,9 @@ class DevicePlan(object):
     def attach_comm(self, force_callback=False):
         """Give the plan a communicator over the ranks of the torch.distributed process group, so that
         `skf_iterate_dist` issues the exchanges of a sharded iteration itself: RCCL bound by the library (backend nccl:
-        torch.distributed only carries the 128-byte unique id from rank 0 to the others), or -- gloo groups (CPU tests,
-        two ranks sharing one GPU in smoke runs), `force_callback` -- a callback that runs the collective through
+        torch.distributed only carries the 128-byte unique id from rank 0 to the others; ONE communicator per process,
+        shared by all plans and restarts), or -- gloo groups (CPU tests, two ranks sharing one GPU in smoke runs),
+        `force_callback`, or an RCCL that cannot be bound on EVERY rank -- a callback that runs the collective through
         torch.distributed on a view of the workspace.  Returns True when a communicator is attached."""
         import os
         try:
@@ -443,47 +529,49 @@ class DevicePlan(object):
         rank, world = dist.get_rank(), dist.get_world_size()
         if world <= 1 and not os.environ.get('SKF_FORCE_COLLECTIVES'):
             return False
-        self._comm = nat._P()
         on_gpu = self.rt.name == 'hip'
+        comm = None
         if dist.get_backend() != 'gloo' and on_gpu and not force_callback:
-            ident = [None]
-            if rank == 0:
-                buf = (C.c_char * 128)()
-                self.rt.call('skf_comm_unique_id', buf)
-                ident[0] = bytes(buf)
-            dist.broadcast_object_list(ident, src=0)
-            raw = (C.c_char * 128).from_buffer_copy(ident[0])
-            self.rt.call('skf_comm_create', raw, rank, world, C.byref(self._comm))
+            comm = _shared_rccl_comm(self.rt, dist)
+        if comm is not None:
+            self._comm, self._comm_shared = comm, True
         else:
-            mem, ws = self.rt.mem, self.ws
-
-            def collective(user, op, buf, count, dtype, stream):
-                try:
-                    npd = nat.NP_DTYPE[dtype]
-                    es = np.dtype(npd).itemsize
-                    n = count * (1 if op == 0 else world)
-                    view = mem.as_tensor(ws, int(buf) - ws.ptr, n * es, npd)
-                    mem.synchronize()
-                    host = view.cpu() if view.is_cuda else view
-                    if op in (0, 1):              # (reduce-scatter: the all-reduce of the whole buffer covers the owned range)
-                        dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                    else:
-                        import torch
-                        parts = [torch.empty(count, dtype=host.dtype) for _ in range(world)]
-                        dist.all_gather(parts, host[rank * count:(rank + 1) * count].clone())
-                        host = torch.cat(parts)
-                    if view.is_cuda or host is not view:
-                        view.copy_(host)
-                    mem.synchronize()
-                    return 0
-                except Exception:                 # never unwind through the C frames
-                    import traceback
-                    traceback.print_exc()
-                    return 1
-            self._comm_fn = nat.COLLECTIVE_FN(collective)          # keep the trampoline alive
+            self._comm = nat._P()
+            self._comm_shared = False
+            self._comm_fn = nat.COLLECTIVE_FN(_torch_collective(self.rt.mem, self.ws, dist, rank, world))   # keep the trampoline alive
             self.rt.call('skf_comm_create_callback', rank, world, C.cast(self._comm_fn, C.c_void_p), None, C.byref(self._comm))
         self.rt.call('skf_plan_set_comm', self.handle, self._comm)
         return True
+
+    def attach_null_comm(self, rank, world):
+        """A communicator whose collectives do nothing: times the compute of rank `rank` of `world` of a sharded fit on one
+        GPU (bench.py --emulate-rank); results are meaningless."""
+        self._comm = nat._P()
+        self._comm_shared = False
+        self.rt.call('skf_comm_create_null', int(rank), int(world), C.byref(self._comm))
+        self.rt.call('skf_plan_set_comm', self.handle, self._comm)
+
+    def attach_callback_comm(self, rank, world, collective):
+        """A communicator whose collectives are `collective(op, view, count, rank, world)` on tensor views of the workspace
+        (in-process groups of plans: tests, tests/helpers.ThreadGroup)."""
+        mem, ws = self.rt.mem, self.ws
+
+        def trampoline(user, op, buf, count, dtype, stream):
+            try:
+                npd = np.int16 if dtype == nat.SKF_BF16 else nat.NP_DTYPE[dtype]
+                n = count * (1 if op == 0 else world)
+                view = mem.as_tensor(ws, int(buf) - ws.ptr, n * np.dtype(npd).itemsize, npd)
+                collective(op, view, count, rank, world)
+                return 0
+            except Exception:                 # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._comm = nat._P()
+        self._comm_shared = False
+        self._comm_fn = nat.COLLECTIVE_FN(trampoline)
+        self.rt.call('skf_comm_create_callback', int(rank), int(world), C.cast(self._comm_fn, C.c_void_p), None, C.byref(self._comm))
+        self.rt.call('skf_plan_set_comm', self.handle, self._comm)
 
     def exchange_bytes(self, world):
         """Bytes one rank sends per iteration of the distributed iteration on a ring of `world` ranks."""
@@ -569,7 +657,8 @@ class DevicePlan(object):
             self.rt.lib.skf_plan_destroy(self.handle)
             self.handle = nat._P()
         if getattr(self, '_comm', None):
-            self.rt.lib.skf_comm_destroy(self._comm)
+            if not getattr(self, '_comm_shared', False):
+                self.rt.lib.skf_comm_destroy(self._comm)
             self._comm = None
         self._keep, self._keep_rel = [], []
         self.ws = None

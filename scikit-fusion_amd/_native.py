@@ -62,7 +62,12 @@ class ThetaDesc(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [('dtype', C.c_int32), ('variant', C.c_int32), ('target_type', C.c_int32),
-                ('engine', C.c_int32), ('part_index', C.c_int32), ('part_count', C.c_int32)]
+                ('engine', C.c_int32), ('part_index', C.c_int32), ('part_count', C.c_int32),
+                ('flags', C.c_int32)]
+
+
+SKF_OPT_OWNED_ROWS = 1
+SKF_ABI_VERSION = 4          # include/skfusion_hip.h: the struct layouts above belong to this version
 
 
 class GemmDesc(C.Structure):
@@ -103,7 +108,11 @@ SIGNATURES = {
     'skf_comm_unique_id': (C.c_int, [_P]),
     'skf_comm_create': (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
     'skf_comm_create_callback': (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.POINTER(_P)]),
+    'skf_comm_create_null': (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_P)]),
     'skf_comm_destroy': (C.c_int, [_P]),
+    'skf_owned_rows': (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int64)]),
+    'skf_abi_version': (C.c_int, []),
     'skf_plan_set_comm': (C.c_int, [_P, _P]),
     'skf_iterate_dist': (C.c_int, [_P, C.c_int32, _P]),
     'skf_exchange_bytes': (C.c_int, [_P, C.c_int32, C.POINTER(C.c_size_t)]),
@@ -155,6 +164,9 @@ def load_library(path=LIB_PATH):
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    if lib.skf_abi_version() != SKF_ABI_VERSION:     # descriptors grew between versions: never call across them
+        raise ImportError('%s has ABI version %d, this binding was written for %d -- rebuild the library'
+                          % (path, lib.skf_abi_version(), SKF_ABI_VERSION))
     return lib
 
 
@@ -216,7 +228,8 @@ class TorchDeviceMemory(object):
 
     def as_tensor(self, buf, offset, nbytes, np_dtype):
         """Zero-copy torch view of a byte range of a device buffer (for RCCL collectives)."""
-        tdt = {np.dtype(np.float32): self.torch.float32, np.dtype(np.float64): self.torch.float64}[np.dtype(np_dtype)]
+        tdt = {np.dtype(np.float32): self.torch.float32, np.dtype(np.float64): self.torch.float64,
+               np.dtype(np.int16): self.torch.int16}[np.dtype(np_dtype)]
         return buf.owner[offset:offset + nbytes].view(tdt)
 
 

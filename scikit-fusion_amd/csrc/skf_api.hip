@@ -74,6 +74,13 @@ static int guarded(F&& f) {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// SKF_OPT_OWNED_ROWS: rows per rank of a type of n objects over `world` ranks (include/skfusion_hip.h, skf_owned_rows):
+// boundaries at multiples of the 256-row contraction tile for large types, of 64 for SKF_BF16 (the K padding of Q = R^T G_i)
+static inline int64_t owned_chunk(int dtype, int64_t n, int world) {
+    const int64_t per = (n + world - 1) / world;
+    const int64_t a = per >= 1024 ? 256 : (dtype == 2 /* SKF_BF16 */ ? 64 : 1);
+    return (per + a - 1) / a * a;
+}
 static inline int elem_grid(int64_t total) {
     int64_t b = (total + 255) / 256;
     if (b < 1) b = 1;
@@ -472,6 +479,10 @@ struct TypeState {
     Slot Bp_tot, Bn_tot;           // sum over the relations of the B / D matrices' + and - parts (c x c f64)
     Slot Ec, Dc;                   // SKF_TRANSFORM target only
     int64_t t0 = 0, tn = 0;        // rows whose type-level terms G (sum B) this plan adds (row-block sharding)
+    // SKF_OPT_OWNED_ROWS: [t0, t0 + tn) are the rows this plan OWNS; `chunk` rows per rank in the padded layout of the
+    // exchanges (G, E, D, the bf16 rows and every Q over this type hold part_count * chunk rows)
+    int64_t chunk = 0, n_alloc = 0;
+    bool gather_master = true;     // the all-gather of the updated rows carries the master copy (false: SKF_BF16 operand rows only)
     Slot GTb;                      // SKF_BF16: bf16 transpose of G, [c][pad64(n)], zero padded
     int64_t ldgt = 0;
     bool set = false;
@@ -593,6 +604,13 @@ struct skf_plan {
     size_t flat_e_off = 0, flat_d_off = 0, flat_g_off = 0, flat_bytes = 0;
     skf::Slot flat_pad[3];
     skf_comm* comm = nullptr;              // collectives of the distributed iteration (skf_plan_set_comm; not owned)
+    // SKF_OPT_OWNED_ROWS: ownership-aligned row blocks (iterate_owned)
+    bool owned = false;
+    int part_index = 0, part_count = 0;
+    size_t xg_off = 0, xg_bytes = 0;       // contiguous range of every type's Gram matrix (one all-reduce of the partial sums)
+    hipStream_t cs = nullptr;              // the stream the exchanges go out on
+    std::vector<hipEvent_t> ev_own;
+    bool masters_stale = false;            // SKF_BF16: rows of other owners hold old f32 values until finalize_owned
     // row-block sharding: contiguous ranges of all W, of the Q of unmasked / of masked relations
     bool sliced = false;
     size_t xw_off = 0, xw_bytes = 0, xq_off = 0, xq_bytes = 0, xqm_off = 0, xqm_bytes = 0;
@@ -618,6 +636,8 @@ struct skf_plan {
     ~skf_plan() {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_rel) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_own) (void)hipEventDestroy(e);
+        if (cs) (void)hipStreamDestroy(cs);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (aux) (void)hipStreamDestroy(aux);
@@ -910,45 +930,55 @@ static void mult_update(skf_plan* p, TypeState& t, hipStream_t st) {
     check_launch("mult_update");
 }
 
-static void theta_terms(skf_plan* p, hipStream_t st) {
+// D_i += Theta+ G_i ; E_i += Theta- G_i   (_dfmf.py:284-292) on the rows [r0, r0 + nr) of the constrained type (all of
+// them, or -- ownership-aligned row blocks -- the rows this plan owns: a row of the product needs the row of Theta and the
+// whole factor).  `only_type` >= 0: the constraints of that type only.
+static void theta_terms_rows(skf_plan* p, int only_type, bool own_rows, hipStream_t st) {
     for (ThetaState& th : p->thetas) {
+        if (only_type >= 0 && th.type != only_type) continue;
         TypeState& t = p->types[th.type];
-        // D += Theta+ G   (_dfmf.py:285-288);  E += Theta- G   (:289-292); an all-zero half is skipped
+        const int64_t r0 = own_rows ? t.t0 : 0, nr = own_rows ? t.tn : t.n;
+        if (nr <= 0) continue;
+        void* Er = (char*)t.E.ptr + (size_t)r0 * t.c * p->esz;
+        void* Dr = (char*)t.D.ptr + (size_t)r0 * t.c * p->esz;
+        // an all-zero half is skipped
         if (th.sparse) {    // both halves in one pass over the CSR form, master precision
             if (th.nnz == 0) continue;
-            const int grid = (int)((t.n + 3) / 4 < 2048 ? (t.n + 3) / 4 : 2048);
+            const int grid = (int)((nr + 3) / 4 < 2048 ? (nr + 3) / 4 : 2048);
             if (p->f64)
-                hipLaunchKernelGGL((theta_spmm_kernel<double>), dim3(grid), dim3(256), 0, st, (const int64_t*)th.Rp.ptr,
-                                   (const int*)th.Ci.ptr, (const double*)th.Vv.ptr, (const double*)t.G.ptr, (double*)t.E.ptr,
-                                   (double*)t.D.ptr, t.n, t.c);
+                hipLaunchKernelGGL((theta_spmm_kernel<double>), dim3(grid), dim3(256), 0, st, (const int64_t*)th.Rp.ptr + r0,
+                                   (const int*)th.Ci.ptr, (const double*)th.Vv.ptr, (const double*)t.G.ptr, (double*)Er,
+                                   (double*)Dr, nr, t.c);
             else
-                hipLaunchKernelGGL((theta_spmm_kernel<float>), dim3(grid), dim3(256), 0, st, (const int64_t*)th.Rp.ptr,
-                                   (const int*)th.Ci.ptr, (const float*)th.Vv.ptr, (const float*)t.G.ptr, (float*)t.E.ptr,
-                                   (float*)t.D.ptr, t.n, t.c);
+                hipLaunchKernelGGL((theta_spmm_kernel<float>), dim3(grid), dim3(256), 0, st, (const int64_t*)th.Rp.ptr + r0,
+                                   (const int*)th.Ci.ptr, (const float*)th.Vv.ptr, (const float*)t.G.ptr, (float*)Er,
+                                   (float*)Dr, nr, t.c);
             check_launch("theta_spmm");
             continue;
         }
         if (p->bf16) {      // bf16 copies of the halves against the stored G^T, f32 accumulate, then added
             for (int half = 0; half < 2; ++half) {
                 if (!(half == 0 ? th.has_pos : th.has_neg)) continue;
-                run_gemm_bf16((const uint16_t*)(half == 0 ? th.Pb.ptr : th.Nb.ptr), th.ldb, (const uint16_t*)t.GTb.ptr,
-                              t.ldgt, (float*)p->theta_tmp.ptr, t.c, (int)t.n, t.c, (int)th.ldb, 0, p->part.ptr,
+                run_gemm_bf16((const uint16_t*)(half == 0 ? th.Pb.ptr : th.Nb.ptr) + r0 * th.ldb, th.ldb, (const uint16_t*)t.GTb.ptr,
+                              t.ldgt, (float*)p->theta_tmp.ptr, t.c, (int)nr, t.c, (int)th.ldb, 0, p->part.ptr,
                               p->part_bytes, false, st);
-                hipLaunchKernelGGL(add_into_kernel, dim3(elem_grid(t.n * t.c)), dim3(256), 0, st,
-                                   (float*)(half == 0 ? t.D.ptr : t.E.ptr), (const float*)p->theta_tmp.ptr,
-                                   (int64_t)t.n * t.c);
+                hipLaunchKernelGGL(add_into_kernel, dim3(elem_grid(nr * t.c)), dim3(256), 0, st,
+                                   (float*)(half == 0 ? Dr : Er), (const float*)p->theta_tmp.ptr, (int64_t)nr * t.c);
                 check_launch("add_into");
             }
             continue;
         }
-        GemmArgs g = gemm_args(th.data, th.ld, 1, t.G.ptr, t.c, 1, t.D.ptr, t.c, (int)t.n, t.c, (int)t.n, EPI_ACC, 0);
+        GemmArgs g = gemm_args((const char*)th.data + (size_t)r0 * th.ld * p->esz, th.ld, 1, t.G.ptr, t.c, 1, Dr, t.c, (int)nr, t.c,
+                               (int)t.n, EPI_ACC, 0);
         g.aop = AOP_POS;
         if (th.has_pos) plan_gemm(p, g, st);
-        g.C = t.E.ptr;
+        g.C = Er;
         g.aop = AOP_NEG;
         if (th.has_neg) plan_gemm(p, g, st);
     }
 }
+
+static void theta_terms(skf_plan* p, hipStream_t st) { theta_terms_rows(p, -1, false, st); }
 
 // [Xp, Xn] (+)= split( L * Gram * Rr )  helper for B = S Gram_j S^T and D = S^T Gram_i S
 // tmp = first product, then split-store/acc of the second.
@@ -1734,6 +1764,7 @@ struct skf_comm {
     void* nccl = nullptr;                  // ncclComm_t, or
     skf_collective_fn fn = nullptr;        // caller-supplied collectives
     void* user = nullptr;
+    bool null_comm = false;                // collectives skipped (skf_comm_create_null)
 };
 
 namespace skf {
@@ -1749,14 +1780,17 @@ static void collective(skf_comm* c, int op, void* buf, size_t count, int dtype, 
         if (rc != 0) SKF_FAIL(SKF_E_HIP, "collective callback failed (op %d, status %d)", op, rc);
         return;
     }
+    if (c->null_comm) return;                       // timing runs of one rank of a sharded fit (skf_comm_create_null)
     if (c->world == 1 && !c->nccl) return;          // a single rank without a transport: nothing to exchange
     const Rccl& r = rccl();
     const int nt = dtype == SKF_F64 ? 8 /* ncclFloat64 */ : 7 /* ncclFloat32 */;
-    const size_t es = dtype == SKF_F64 ? 8 : 4;
+    const size_t es = dtype == SKF_F64 ? 8 : dtype == SKF_BF16 ? 2 : 4;
     char* mine = (char*)buf + (size_t)c->rank * count * es;
     int rc = 0;
+    if (dtype == SKF_BF16 && op != COLL_ALL_GATHER) SKF_FAIL(SKF_E_INVALID, "bf16 collectives: all-gather only");
     if (op == COLL_ALL_REDUCE) rc = r.all_reduce(buf, buf, count, nt, 0 /* ncclSum */, c->nccl, st);
     else if (op == COLL_REDUCE_SCATTER) rc = r.reduce_scatter(buf, mine, count, nt, 0, c->nccl, st);
+    else if (dtype == SKF_BF16) rc = r.all_gather(mine, buf, count * 2, 1 /* ncclUint8: the bytes of the bf16 rows */, c->nccl, st);
     else rc = r.all_gather(mine, buf, count, nt, c->nccl, st);
     if (rc != 0) SKF_FAIL(SKF_E_HIP, "RCCL collective %d failed: %s", op, r.error_string ? r.error_string(rc) : "?");
 }
@@ -1815,9 +1849,357 @@ static void iterate_dist(skf_plan* p, hipStream_t st) {
 static size_t exchange_bytes(const skf_plan* p, int world) {
     if (world <= 1) return 0;
     const double f = (double)(world - 1) / world;
+    if (p->owned) {
+        // reduce-scatter of every relation's partial Q, all-gather of every type's updated rows (master type, or the bf16
+        // operand rows), all-reduce of the c x c Gram and W partials
+        double b = 0.0;
+        for (const RelState& r : p->rels) b += f * (double)p->types[r.col].n_alloc * p->types[r.row].c * (double)p->esz;
+        for (const TypeState& t : p->types)
+            b += f * (double)t.n_alloc * (t.gather_master ? (double)t.c * (double)p->esz : (double)t.ldrow * 2.0);
+        b += 2.0 * f * (double)p->xg_bytes;                 // (the Gram range goes out as a whole, slot padding included)
+        for (const RelState& r : p->rels) b += 2.0 * f * 8.0 * (double)p->types[r.row].c * p->types[r.col].c;
+        return (size_t)(b + 0.5);
+    }
     double b = 3.0 * f * (double)(flat_chunk(p->flat_bytes / p->esz, world) * world * p->esz);
     if (p->sliced) b += 2.0 * f * (double)(p->xw_bytes + p->xq_bytes + p->xqm_bytes);
     return (size_t)b;
+}
+
+// ------------------------------------------------------------------------------------------
+// SKF_OPT_OWNED_ROWS: one iteration of a fit whose row blocks follow the OWNERSHIP of the factor rows (every rank holds the
+// rows [t0, t0 + tn) of every type: of its factor, of E / D, of every relation with that row type).  Replaces the
+// reference's per-block tasks (_dfmf.py:69-73, _dfmc.py:341-345).  What crosses ranks:
+//     Gram_t = sum over ranks of G_t[own]^T G_t[own]            all-reduce, c x c f64, all types at once
+//     W_r    = sum over ranks of G_i[own]^T (R_blk G_j)         all-reduce, c_i x c_j f64, per relation
+//     Q_r    = sum over ranks of R_blk^T G_i[own]               REDUCE-SCATTER to the owners of type j (raw: the +- split of
+//                                                               _dfmf.py:268-270 is not linear), per relation
+//     G_t                                                       ALL-GATHER of the updated owned rows, per type (SKF_BF16: of
+//                                                               their bf16 operand copy unless a constraint reads the f32 rows)
+// Row sides (P S^T)+-, type terms G_i sum B-+, constraint rows and the update act on owned rows: no exchange of E / D.
+// Three streams when the graph allows (ranks in 65 .. 512, sparse constraints only -- the conditions under which the c x c
+// chains need no split-K scratch): main = Gram, contractions, W; second = pseudo-inverses, backbones, side products,
+// updates; `cs` = the exchanges.  A relation's exchanges run under the next relation's contractions, a type is updated and
+// gathered as soon as its last relation's sides are in.  Otherwise everything is issued in the same order on one stream.
+// ------------------------------------------------------------------------------------------
+static bool owned_can_overlap(const skf_plan* p) {
+    if (!p->overlap || p->engine != SKF_ENGINE_MFMA) return false;
+    for (const ThetaState& th : p->thetas)
+        if (!th.sparse) return false;
+    const int cmax = (p->variant == SKF_DFMC) ? 256 : 512;
+    for (const TypeState& t : p->types)
+        if (t.c > cmax || t.c <= SMALLC) return false;
+    return true;
+}
+
+static void iterate_owned(skf_plan* p, hipStream_t st) {
+    skf_comm* c = p->comm;
+    const size_t nt = p->types.size(), nr = p->rels.size();
+    const bool dfmc = (p->variant == SKF_DFMC);
+    const int nan_upd = dfmc ? 0 : 1;
+    const bool fused = (p->engine == SKF_ENGINE_MFMA);
+    const bool multi = owned_can_overlap(p);
+    hipStream_t ax = multi ? p->aux : st;
+    hipStream_t cs = (multi && p->cs) ? p->cs : st;
+    char* base = (char*)p->ws_base;
+    if (dfmc && p->first_iter) zero_unknown_entries(p, st);
+    p->first_iter = false;
+    // events: [0] Gram partials, [1] Gram sums; per relation: W partial, W sum, Q partial, Q scattered, backbone (+ completion
+    // operands), P after the completion; per type: rows updated, rows gathered, operand copies refreshed
+    const size_t n_ev = 2 + 6 * nr + 3 * nt;
+    while (p->ev_own.size() < n_ev) {
+        hipEvent_t e;
+        SKF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->ev_own.push_back(e);
+    }
+    enum { R_W = 0, R_WX = 1, R_Q = 2, R_QX = 3, R_S = 4, R_P2 = 5, T_UPD = 0, T_G = 1, T_GT = 2 };
+    auto ev_r = [&](size_t k, int what) { return p->ev_own[2 + 6 * k + what]; };
+    auto ev_t = [&](size_t i, int what) { return p->ev_own[2 + 6 * nr + 3 * i + what]; };
+    auto rec = [&](hipEvent_t e, hipStream_t s) { SKF_HIP(hipEventRecord(e, s)); };
+    auto wait = [&](hipStream_t s, hipEvent_t e) { SKF_HIP(hipStreamWaitEvent(s, e, 0)); };
+    auto own = [&](const Slot& s, const TypeState& t) { return rows_of(p, s, t, t.t0); };
+
+    // ---- Gram partials over the owned rows (main), their sum (exchange stream), the pseudo-inverses (second stream)
+    std::vector<int> all;
+    for (size_t i = 0; i < nt; ++i) {
+        TypeState& t = p->types[i];
+        all.push_back((int)i);
+        if (t.tn <= 0) {
+            SKF_HIP(hipMemsetAsync(t.Gram.ptr, 0, t.Gram.bytes, st));
+            continue;
+        }
+        GemmArgs g = gemm_args(own(t.G, t), 1, t.c, own(t.G, t), t.c, 1, t.Gram.ptr, t.c, t.c, t.c, (int)t.tn, EPI_STORE, 1);
+        run_gemm(GemmTypes{SKF_F64, p->mt, p->mt}, p->engine, g, 0, p->part.ptr, p->part_bytes, st);
+    }
+    rec(p->ev_own[0], st);
+    wait(cs, p->ev_own[0]);
+    collective(c, COLL_ALL_REDUCE, base + p->xg_off, p->xg_bytes / 8, SKF_F64, cs);
+    rec(p->ev_own[1], cs);
+    wait(ax, p->ev_own[1]);
+    plan_pinv(p, all, ax);
+    SKF_HIP(hipMemsetAsync(base + p->btot_off, 0, p->btot_bytes, ax));
+
+    std::vector<char> touched(nt, 0);          // E / D of the type's owned rows already written this iteration
+    std::vector<int> sides_left(nt, 0);        // side products of the type still to come
+    for (const RelState& r : p->rels) {
+        sides_left[r.row] += 1;
+        sides_left[r.col] += 1;
+    }
+    std::vector<const void*> Sm(nr, nullptr);  // the backbone in the master type
+    std::vector<char> finished(nt, 0);
+    const bool chain = small_chain(p);
+
+    // the type is complete: type term, constraint rows, update of the owned rows (second stream), gather (exchange stream)
+    auto finish_type = [&](size_t i) {
+        TypeState& t = p->types[i];
+        finished[i] = 1;
+        if (t.tn > 0) {
+            void* G = own(t.G, t);
+            void* E = own(t.E, t);
+            void* D = own(t.D, t);
+            if (!touched[i]) {
+                SKF_HIP(hipMemsetAsync(E, 0, (size_t)t.tn * t.c * p->esz, ax));
+                SKF_HIP(hipMemsetAsync(D, 0, (size_t)t.tn * t.c * p->esz, ax));
+                touched[i] = 1;
+            }
+            if (fused) {
+                const void* Bn = t.Bn_tot.ptr;
+                const void* Bp = t.Bp_tot.ptr;
+                if (!p->f64) {
+                    const int cc = t.c * t.c;
+                    hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid(cc)), dim3(256), 0, ax, (float*)t.Bn32.ptr,
+                                       (int64_t)cc, (const double*)t.Bn_tot.ptr, (int64_t)cc, (int64_t)1, (int64_t)cc);
+                    hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid(cc)), dim3(256), 0, ax, (float*)t.Bp32.ptr,
+                                       (int64_t)cc, (const double*)t.Bp_tot.ptr, (int64_t)cc, (int64_t)1, (int64_t)cc);
+                    check_launch("cast");
+                    Bn = t.Bn32.ptr;
+                    Bp = t.Bp32.ptr;
+                }
+                side_update(p, nullptr, 0, 0, nullptr, 0, 0, t, G, E, D, (int)t.tn, Bn, Bp, true, true, 0, ax);
+            } else {
+                GemmArgs g = gemm_args(G, t.c, 1, t.Bn_tot.ptr, t.c, 1, E, t.c, (int)t.tn, t.c, t.c, EPI_ACC, 0);
+                mixed_gemm(p, g, ax);
+                g = gemm_args(G, t.c, 1, t.Bp_tot.ptr, t.c, 1, D, t.c, (int)t.tn, t.c, t.c, EPI_ACC, 0);
+                mixed_gemm(p, g, ax);
+            }
+            theta_terms_rows(p, (int)i, true, ax);
+            // G[own] <- G[own] * sqrt(E / max(D, eps))   (_dfmf.py:294-296); SKF_BF16: with the bf16 copies of those rows
+            if (p->bf16) {
+                hipLaunchKernelGGL(mult_update_transpose_kernel, dim3((unsigned)cdiv(t.c, 32), (unsigned)cdiv(t.tn, 32)), dim3(256), 0,
+                                   ax, (float*)G, (const float*)E, (const float*)D, (int64_t)t.tn, (int64_t)t.c,
+                                   (uint16_t*)t.GTb.ptr + t.t0, t.ldgt, (uint16_t*)t.Grow.ptr + t.t0 * t.ldrow, t.ldrow);
+                check_launch("mult_update_transpose(rows)");
+            } else if (p->f64) {
+                hipLaunchKernelGGL((mult_update_kernel<double>), dim3(elem_grid(t.tn * t.c)), dim3(256), 0, ax, (double*)G,
+                                   (const double*)E, (const double*)D, t.tn, t.c, (int64_t)t.c, (int64_t)t.c);
+                check_launch("mult_update(rows)");
+            } else {
+                hipLaunchKernelGGL((mult_update_kernel<float>), dim3(elem_grid(t.tn * t.c)), dim3(256), 0, ax, (float*)G,
+                                   (const float*)E, (const float*)D, t.tn, t.c, (int64_t)t.c, (int64_t)t.c);
+                check_launch("mult_update(rows)");
+            }
+        }
+        rec(ev_t(i, T_UPD), ax);
+        wait(cs, ev_t(i, T_UPD));
+        if (t.gather_master) collective(c, COLL_ALL_GATHER, t.G.ptr, (size_t)t.chunk * t.c, p->mt, cs);
+        else collective(c, COLL_ALL_GATHER, t.Grow.ptr, (size_t)t.chunk * t.ldrow, SKF_BF16, cs);
+        rec(ev_t(i, T_G), cs);
+        if (p->bf16) {      // the operand copies of ALL rows from what was gathered
+            wait(ax, ev_t(i, T_G));
+            if (t.gather_master) refresh_gt(p, t, ax);
+            else launch_to_bf16<uint16_t>((uint16_t*)t.GTb.ptr, t.ldgt, (const uint16_t*)t.Grow.ptr, t.ldrow, t.n, (int64_t)t.c, true, ax);
+            rec(ev_t(i, T_GT), ax);
+        }
+    };
+    auto side_done = [&](int type) {
+        if (--sides_left[type] == 0) finish_type((size_t)type);
+    };
+    // W partial of relation k from its P (main stream), then its sum (exchange stream)
+    auto w_partial = [&](size_t k) {
+        RelState& r = p->rels[k];
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        if (r.absent) {
+            SKF_HIP(hipMemsetAsync(r.W.ptr, 0, r.W.bytes, st));
+        } else {
+            GemmArgs g = gemm_args(own(ti.G, ti), 1, ti.c, r.P.ptr, tj.c, 1, r.W.ptr, tj.c, ti.c, tj.c, (int)r.nr, EPI_STORE, 0);
+            wide_gemm(p, g, st);
+        }
+        rec(ev_r(k, R_W), st);
+        wait(cs, ev_r(k, R_W));
+        collective(c, COLL_ALL_REDUCE, r.W.ptr, (size_t)ti.c * tj.c, SKF_F64, cs);
+        rec(ev_r(k, R_WX), cs);
+    };
+    // partial Q of relation k (main stream), then the rows of its sum this rank owns (exchange stream)
+    auto q_partial = [&](size_t k) {
+        RelState& r = p->rels[k];
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        if (r.absent) SKF_HIP(hipMemsetAsync(r.Q.ptr, 0, (size_t)tj.n * ti.c * p->esz, st));
+        else contraction_Q(p, r, st);
+        rec(ev_r(k, R_Q), st);
+        wait(cs, ev_r(k, R_Q));
+        collective(c, COLL_REDUCE_SCATTER, r.Q.ptr, (size_t)tj.chunk * ti.c, p->mt, cs);
+        rec(ev_r(k, R_QX), cs);
+    };
+    // second stream, behind the sum of W: S = K_i W K_j, its B / D terms, the rounding of S
+    auto backbone_chain = [&](size_t k) {
+        RelState& r = p->rels[k];
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        const int ci = ti.c, cj = tj.c;
+        wait(ax, ev_r(k, R_WX));
+        if (chain) {
+            BackboneBatch bb;
+            bb.Ki[0] = (const double*)ti.K.ptr; bb.Kj[0] = (const double*)tj.K.ptr;
+            bb.W[0] = (const double*)r.W.ptr; bb.S[0] = (double*)r.S.ptr;
+            bb.ci[0] = ci; bb.cj[0] = cj;
+            const size_t smem = ((size_t)ci * ci + 2 * (size_t)ci * cj + (size_t)cj * cj) * 8;
+            static DeviceOnce once_bb, once_bt;
+            allow_dynamic_lds(once_bb, backbone_small_kernel, 4 * SMALLC * SMALLC * 8);
+            allow_dynamic_lds(once_bt, bterms_small_kernel, 4 * SMALLC * SMALLC * 8);
+            hipLaunchKernelGGL(backbone_small_kernel, dim3(1), dim3(256), smem, ax, bb);
+            check_launch("backbone_small");
+            BTermsArgs ba;
+            ba.S = (const double*)r.S.ptr; ba.Gram_i = (const double*)ti.Gram.ptr; ba.Gram_j = (const double*)tj.Gram.ptr;
+            ba.Bp_i = (double*)ti.Bp_tot.ptr; ba.Bn_i = (double*)ti.Bn_tot.ptr;
+            ba.Bp_j = (double*)tj.Bp_tot.ptr; ba.Bn_j = (double*)tj.Bn_tot.ptr;
+            ba.ci = ci; ba.cj = cj; ba.nan_to_num = nan_upd;
+            hipLaunchKernelGGL(bterms_small_kernel, dim3(1), dim3(256), smem, ax, ba);
+            check_launch("bterms_small");
+        } else {
+            GemmArgs g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);       // T1 = K_i W
+            small_gemm(p, g, ax);
+            g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);                // S = T1 K_j
+            small_gemm(p, g, ax);
+            relation_small_terms(p, r, nan_upd, EPI_SPLIT_ACC, ti.Bp_tot.ptr, ti.Bn_tot.ptr, tj.Bp_tot.ptr, tj.Bn_tot.ptr,
+                                 true, true, ax);
+        }
+        Sm[k] = r.S.ptr;
+        if (!p->f64 && fused) {
+            hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid((int64_t)ci * cj)), dim3(256), 0, ax,
+                               (float*)r.S32.ptr, (int64_t)cj, (const double*)r.S.ptr, (int64_t)cj, (int64_t)ci, (int64_t)cj);
+            check_launch("cast");
+            Sm[k] = r.S32.ptr;
+        }
+    };
+    // second stream: row side on the local rows behind `ev_p`, column side on the owned rows of the column type behind the
+    // scattered Q;  E_i (+)= (P S^T)+, D_i (+)= (P S^T)-;  E_j (+)= (Q S)+, D_j (+)= (Q S)-
+    auto side_products = [&](size_t k, hipEvent_t ev_p) {
+        RelState& r = p->rels[k];
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        const int ci = ti.c, cj = tj.c;
+        wait(ax, ev_p);
+        if (!r.absent) {
+            if (fused) {
+                side_update(p, r.P.ptr, cj, cj, Sm[k], 1, cj, ti, own(ti.G, ti), own(ti.E, ti), own(ti.D, ti), (int)r.nr, nullptr,
+                            nullptr, false, touched[r.row] != 0, nan_upd, ax);
+            } else {
+                if (!touched[r.row]) {
+                    SKF_HIP(hipMemsetAsync(own(ti.E, ti), 0, (size_t)ti.tn * ci * p->esz, ax));
+                    SKF_HIP(hipMemsetAsync(own(ti.D, ti), 0, (size_t)ti.tn * ci * p->esz, ax));
+                }
+                GemmArgs g = gemm_args(r.P.ptr, cj, 1, r.S.ptr, 1, cj, own(ti.E, ti), ci, (int)r.nr, ci, cj, EPI_SPLIT_ACC, nan_upd);
+                g.C2 = own(ti.D, ti);
+                mixed_gemm(p, g, ax);
+            }
+            touched[r.row] = 1;
+        }
+        side_done(r.row);
+        wait(ax, ev_r(k, R_QX));
+        if (tj.tn > 0) {
+            const void* Qo = (const char*)r.Q.ptr + (size_t)tj.t0 * ci * p->esz;
+            if (fused) {
+                side_update(p, Qo, ci, ci, Sm[k], cj, 1, tj, own(tj.G, tj), own(tj.E, tj), own(tj.D, tj), (int)tj.tn, nullptr,
+                            nullptr, false, touched[r.col] != 0, nan_upd, ax);
+            } else {
+                if (!touched[r.col]) {
+                    SKF_HIP(hipMemsetAsync(own(tj.E, tj), 0, (size_t)tj.tn * cj * p->esz, ax));
+                    SKF_HIP(hipMemsetAsync(own(tj.D, tj), 0, (size_t)tj.tn * cj * p->esz, ax));
+                }
+                GemmArgs g = gemm_args(Qo, ci, 1, r.S.ptr, cj, 1, own(tj.E, tj), cj, (int)tj.tn, cj, ci, EPI_SPLIT_ACC, nan_upd);
+                g.C2 = own(tj.D, tj);
+                mixed_gemm(p, g, ax);
+            }
+            touched[r.col] = 1;
+        }
+        side_done(r.col);
+    };
+
+    // ---- masked relations (DFMC), before their completion: P, W (_dfmc.py:311-314); second stream: backbone, H = G_i[own] S
+    for (size_t k = 0; k < nr; ++k) {
+        RelState& r = p->rels[k];
+        if (!(dfmc && r.masked)) continue;
+        TypeState& ti = p->types[r.row];
+        TypeState& tj = p->types[r.col];
+        if (!r.absent) contraction_P(p, r, st);
+        w_partial(k);
+        backbone_chain(k);
+        if (!r.absent) {
+            GemmArgs g = gemm_args(own(ti.G, ti), ti.c, 1, r.S.ptr, tj.c, 1, r.H.ptr, tj.c, (int)r.nr, tj.c, ti.c, EPI_STORE, 0);
+            if (multi) mixed_gemm_unsplit(p, g, ax);
+            else mixed_gemm(p, g, ax);
+            if (p->bf16 && r.mask) {        // bf16 operands of the completion tiles: H, and G_j from what this rank holds of it
+                launch_to_bf16<float>((uint16_t*)r.Hb.ptr, r.ldhb, (const float*)r.H.ptr, (int64_t)tj.c, r.nr, tj.c, false, ax);
+                if (tj.gather_master)
+                    launch_to_bf16<float>((uint16_t*)r.Gb.ptr, r.ldhb, (const float*)tj.G.ptr, (int64_t)tj.c, tj.n, tj.c, false, ax);
+                else
+                    launch_to_bf16<uint16_t>((uint16_t*)r.Gb.ptr, r.ldhb, (const uint16_t*)tj.Grow.ptr, tj.ldrow, tj.n, tj.c, false, ax);
+            }
+        }
+        rec(ev_r(k, R_S), ax);
+    }
+    // ---- unmasked relations: P, W, Q on the main stream, their exchanges and everything behind them underneath
+    for (size_t k = 0; k < nr; ++k) {
+        RelState& r = p->rels[k];
+        if (dfmc && r.masked) continue;
+        if (!r.absent) contraction_P(p, r, st);
+        w_partial(k);
+        q_partial(k);
+        backbone_chain(k);
+        side_products(k, ev_r(k, R_WX));
+    }
+    // ---- masked relations: completion of the local rows (_dfmc.py:319-325), then the two contractions of the G update
+    for (size_t k = 0; k < nr; ++k) {
+        RelState& r = p->rels[k];
+        if (!(dfmc && r.masked)) continue;
+        TypeState& tj = p->types[r.col];
+        wait(st, ev_r(k, R_S));
+        if (!r.absent) {
+            if (r.mask) {
+                if (p->bf16) {
+                    launch_tile_epilogue(p, r, MODE_COMPLETE, st, false);
+                } else {
+                    GemmArgs g = gemm_args(r.H.ptr, tj.c, 1, tj.G.ptr, 1, tj.c, r.Rw.ptr, r.ldr, (int)r.nr, (int)tj.n, tj.c,
+                                           EPI_MASKED_STORE, 0);
+                    g.mask = (const uint8_t*)r.Mb.ptr;
+                    g.ldmask = r.ldmb;
+                    g.mask_bits = 1;
+                    plan_gemm(p, g, st);
+                }
+            }
+            contraction_P(p, r, st);
+        }
+        rec(ev_r(k, R_P2), st);
+        q_partial(k);
+        side_products(k, ev_r(k, R_P2));
+    }
+    for (size_t i = 0; i < nt; ++i)
+        if (!finished[i]) finish_type(i);          // a type without relations: constraints only
+    // ---- the next iteration starts behind every gather (and operand refresh)
+    for (size_t i = 0; i < nt; ++i) wait(st, ev_t(i, p->bf16 ? T_GT : T_G));
+    p->masters_stale = false;
+    for (const TypeState& t : p->types) p->masters_stale = p->masters_stale || !t.gather_master;
+}
+
+// SKF_BF16 plans with owned rows gather only the bf16 operand rows of a type without constraints; at the end of
+// skf_iterate_dist every rank fetches the f32 rows of the other owners once, so that skf_get_factor / skf_relation_sqerr see
+// the same factors everywhere.
+static void finalize_owned(skf_plan* p, hipStream_t st) {
+    if (!p->masters_stale) return;
+    for (TypeState& t : p->types)
+        if (!t.gather_master) collective(p->comm, COLL_ALL_GATHER, t.G.ptr, (size_t)t.chunk * t.c, p->mt, st);
+    p->masters_stale = false;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2337,7 +2719,19 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             p->types[i].n_pad = (types[i].rank + 1) / 2 * 2;
             p->types[i].t0 = 0;
             p->types[i].tn = types[i].n_obj;
-            if (opt->part_count > 1) {      // even shares of the rows, boundaries at multiples of 64
+            p->types[i].n_alloc = types[i].n_obj;
+            if (opt->flags & SKF_OPT_OWNED_ROWS) {      // the rows this process owns (skf_owned_rows)
+                if (opt->part_count < 1 || opt->part_index < 0 || opt->part_index >= opt->part_count)
+                    SKF_FAIL(SKF_E_INVALID, "SKF_OPT_OWNED_ROWS: part_index %d outside [0, %d)", opt->part_index, opt->part_count);
+                const int64_t ch = owned_chunk(opt->dtype, types[i].n_obj, opt->part_count);
+                int64_t lo = ch * opt->part_index, hi = lo + ch;
+                if (lo > types[i].n_obj) lo = types[i].n_obj;
+                if (hi > types[i].n_obj) hi = types[i].n_obj;
+                p->types[i].t0 = lo;
+                p->types[i].tn = hi - lo;
+                p->types[i].chunk = ch;
+                p->types[i].n_alloc = ch * opt->part_count;
+            } else if (opt->part_count > 1) {      // even shares of the rows, boundaries at multiples of 64
                 if (opt->part_index < 0 || opt->part_index >= opt->part_count)
                     SKF_FAIL(SKF_E_INVALID, "part_index %d outside [0, %d)", opt->part_index, opt->part_count);
                 const int64_t per = (types[i].n_obj + opt->part_count - 1) / opt->part_count;
@@ -2350,6 +2744,12 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             }
         }
         if (opt->part_count > 1) p->sliced = true;
+        if (opt->flags & SKF_OPT_OWNED_ROWS) {
+            if (p->variant == SKF_TRANSFORM) SKF_FAIL(SKF_E_INVALID, "SKF_OPT_OWNED_ROWS is for SKF_DFMF / SKF_DFMC plans");
+            p->owned = p->sliced = true;
+            p->part_index = opt->part_index;
+            p->part_count = opt->part_count;
+        }
         p->rels.resize(n_relations);
         for (int r = 0; r < n_relations; ++r) {
             const skf_relation_desc& d = relations[r];
@@ -2388,6 +2788,13 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             s.col_side = (d.flags & SKF_REL_NO_COL_SIDE) == 0;
             s.masked = d.mask != nullptr || (d.flags & SKF_REL_MASKED) != 0;
             if (absent) { s.R_in = s.R = nullptr; s.mask = nullptr; }
+            if (p->owned) {         // the block of a relation is the owned range of its row type, nothing else
+                const TypeState& ti = p->types[d.row_type];
+                if (ti.tn == 0 ? !absent : (absent || s.r0 != ti.t0 || s.nr != ti.tn))
+                    SKF_FAIL(SKF_E_INVALID, "relation %d: SKF_OPT_OWNED_ROWS wants the rows [%lld, +%lld) of its row type here (skf_owned_rows)",
+                             r, (long long)ti.t0, (long long)ti.tn);
+                s.col_side = true;  // every process adds the column-side terms of ITS rows of the column type
+            }
             if (d.known_bound < 0) SKF_FAIL(SKF_E_INVALID, "relation %d: negative bound on the known entries", r);
             s.kn_cap = (s.mask && p->variant == SKF_DFMC) ? d.known_bound : 0;
         }
@@ -2470,6 +2877,15 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 p->thetas[t].nnz_cap = thetas[t].nnz;
             }
         }
+        if (p->owned) {
+            // SKF_BF16: the other owners' rows of a factor are read as bf16 operands only -- unless a constraint on the type
+            // multiplies the f32 rows (theta_spmm_kernel / dense Theta).  Every type keeps its bf16 rows (the gathered form).
+            for (TypeState& t : p->types) {
+                t.gather_master = !p->bf16;
+                if (p->bf16) t.need_rows = true;
+            }
+            for (const ThetaState& th : p->thetas) p->types[th.type].gather_master = true;
+        }
         // ---- workspace layout: n-sized buffers in the master type, every c x c matrix in f64
         const size_t es = p->esz;
         size_t part_bytes = 0;
@@ -2493,7 +2909,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 TypeState& t = p->types[i];
                 const bool active = (p->variant != SKF_TRANSFORM) || i == p->target;
                 if (region < 2 && !active) continue;
-                add_slot(p, region == 0 ? t.E : region == 1 ? t.D : t.G, (size_t)t.n * t.c * es);
+                add_slot(p, region == 0 ? t.E : region == 1 ? t.D : t.G, (size_t)t.n_alloc * t.c * es);
             }
             const size_t bytes = p->ws_bytes - begin;
             if (region == 0) { p->flat_e_off = begin; p->flat_bytes = bytes; }
@@ -2502,11 +2918,14 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             add_slot(p, p->flat_pad[region], 64 * 1024);
             if (region == 1) p->acc_bytes = p->ws_bytes - p->acc_off;
         }
+        // the Gram matrices of all types form one range (SKF_OPT_OWNED_ROWS: one all-reduce of the partial sums)
+        p->xg_off = p->ws_bytes;
+        for (int i = 0; i < n_types; ++i) add_slot(p, p->types[i].Gram, (size_t)p->types[i].c * p->types[i].c * 8);
+        p->xg_bytes = p->ws_bytes - p->xg_off;
         for (int i = 0; i < n_types; ++i) {
             TypeState& t = p->types[i];
             const bool active = (p->variant != SKF_TRANSFORM) || i == p->target;
             (void)active;
-            add_slot(p, t.Gram, (size_t)t.c * t.c * 8);
             if (p->bf16) {
                 t.ldgt = pad64(t.n);
                 add_slot(p, t.GTb, (size_t)t.c * t.ldgt * 2);
@@ -2515,7 +2934,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             if (t.keep_prev) add_slot(p, t.Gp, (size_t)t.n * t.c * es);
             if (p->bf16 && t.need_rows) {
                 t.ldrow = (t.c + 7) / 8 * 8;
-                add_slot(p, t.Grow, ((size_t)t.n + 1) * t.ldrow * 2);           // (+ 1: the all-zero row of the v6 list kernel)
+                add_slot(p, t.Grow, ((size_t)t.n_alloc + 1) * t.ldrow * 2);     // (+ 1: the all-zero row of the v6 list kernel)
             }
             if (p->variant != SKF_TRANSFORM) {
                 add_slot(p, t.K, (size_t)t.c * t.c * 8);
@@ -2546,11 +2965,11 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             p->xw_bytes = p->ws_bytes - p->xw_off;
             p->xq_off = p->ws_bytes;
             for (RelState& r : p->rels)
-                if (!r.masked) add_slot(p, r.Q, (size_t)p->types[r.col].n * p->types[r.row].c * es);
+                if (!r.masked) add_slot(p, r.Q, (size_t)p->types[r.col].n_alloc * p->types[r.row].c * es);
             p->xq_bytes = p->ws_bytes - p->xq_off;
             p->xqm_off = p->ws_bytes;
             for (RelState& r : p->rels)
-                if (r.masked) add_slot(p, r.Q, (size_t)p->types[r.col].n * p->types[r.row].c * es);
+                if (r.masked) add_slot(p, r.Q, (size_t)p->types[r.col].n_alloc * p->types[r.row].c * es);
             p->xqm_bytes = p->ws_bytes - p->xqm_off;
         }
         for (RelState& r : p->rels) {
@@ -3084,6 +3503,21 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             SKF_HIP(hipMemcpyAsync(p->sm_jobs3.ptr, p->sm_j3.data(), p->sm_j3.size() * sizeof(SmJob), hipMemcpyHostToDevice, st));
             SKF_HIP(hipStreamSynchronize(st));     // (`tb` dies here; bind is not on the hot path)
         }
+        if (p->owned) {
+            // padded layouts of the exchanges: rows past the objects of a type stay zero for good (they are gathered and
+            // scattered with the rest), the Gram range is summed as a whole
+            for (TypeState& t : p->types) {
+                SKF_HIP(hipMemsetAsync(t.G.ptr, 0, t.G.bytes, st));
+                SKF_HIP(hipMemsetAsync(t.E.ptr, 0, t.E.bytes, st));
+                SKF_HIP(hipMemsetAsync(t.D.ptr, 0, t.D.bytes, st));
+            }
+            for (RelState& r : p->rels) SKF_HIP(hipMemsetAsync(r.Q.ptr, 0, r.Q.bytes, st));
+            SKF_HIP(hipMemsetAsync((char*)ws + p->xg_off, 0, p->xg_bytes, st));
+            SKF_HIP(hipMemsetAsync((char*)ws + p->xw_off, 0, p->xw_bytes, st));
+            const char* ec = getenv("SKF_COMM_STREAM");
+            if (!p->cs && !p->sw.no_overlap && !(ec && atoi(ec) == 0))
+                SKF_HIP(hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking));
+        }
         p->pipeline = !p->sw.no_pipeline;
         if (p->variant != SKF_TRANSFORM && !p->aux) {
             if (!p->sw.no_overlap) {
@@ -3263,6 +3697,7 @@ int skf_accumulate(skf_plan* p, void* stream) {
     return guarded([&] {
         check_bound(p);
         if (p->variant == SKF_TRANSFORM) SKF_FAIL(SKF_E_INVALID, "skf_accumulate: SKF_DFMF / SKF_DFMC plans only");
+        if (p->owned) SKF_FAIL(SKF_E_STATE, "a plan with owned rows (SKF_OPT_OWNED_ROWS) iterates through skf_iterate_dist");
         for (size_t i = 0; i < p->types.size(); ++i)
             if (!p->types[i].set) SKF_FAIL(SKF_E_STATE, "factor of object type %zu not set", i);
         accumulate_fit(p, as_stream(stream));
@@ -3281,6 +3716,7 @@ int skf_stage(skf_plan* p, int32_t stage, void* stream) {
     return guarded([&] {
         check_bound(p);
         if (p->variant == SKF_TRANSFORM) SKF_FAIL(SKF_E_INVALID, "skf_stage: SKF_DFMF / SKF_DFMC plans only");
+        if (p->owned) SKF_FAIL(SKF_E_STATE, "a plan with owned rows (SKF_OPT_OWNED_ROWS) iterates through skf_iterate_dist");
         for (size_t i = 0; i < p->types.size(); ++i)
             if (!p->types[i].set) SKF_FAIL(SKF_E_STATE, "factor of object type %zu not set", i);
         hipStream_t st = as_stream(stream);
@@ -3356,6 +3792,33 @@ int skf_comm_create_callback(int32_t rank, int32_t world, skf_collective_fn fn, 
     });
 }
 
+int skf_comm_create_null(int32_t rank, int32_t world, skf_comm** out) {
+    return guarded([&] {
+        if (!out || world < 1 || rank < 0 || rank >= world) SKF_FAIL(SKF_E_INVALID, "bad rank / world / pointer");
+        skf_comm* c = new skf_comm();
+        c->rank = rank; c->world = world; c->null_comm = true;
+        *out = c;
+    });
+}
+
+int skf_owned_rows(int32_t dtype, int64_t n_obj, int32_t part_index, int32_t part_count, int64_t* begin, int64_t* count,
+                   int64_t* chunk) {
+    return guarded([&] {
+        if (n_obj <= 0 || part_count < 1 || part_index < 0 || part_index >= part_count || !begin || !count || !chunk)
+            SKF_FAIL(SKF_E_INVALID, "bad argument");
+        if (dtype != SKF_F64 && dtype != SKF_F32 && dtype != SKF_BF16) SKF_FAIL(SKF_E_INVALID, "unknown dtype %d", dtype);
+        const int64_t ch = owned_chunk(dtype, n_obj, part_count);
+        int64_t lo = ch * part_index, hi = lo + ch;
+        if (lo > n_obj) lo = n_obj;
+        if (hi > n_obj) hi = n_obj;
+        *begin = lo;
+        *count = hi - lo;
+        *chunk = ch;
+    });
+}
+
+int skf_abi_version(void) { return SKF_ABI_VERSION; }
+
 int skf_comm_destroy(skf_comm* c) {
     return guarded([&] {
         if (!c) return;
@@ -3380,6 +3843,14 @@ int skf_iterate_dist(skf_plan* p, int32_t n_iters, void* stream) {
         if (n_iters < 0) SKF_FAIL(SKF_E_INVALID, "n_iters < 0");
         for (size_t i = 0; i < p->types.size(); ++i)
             if (!p->types[i].set) SKF_FAIL(SKF_E_STATE, "factor of object type %zu not set", i);
+        if (p->owned) {
+            if (p->comm->world != p->part_count || p->comm->rank != p->part_index)
+                SKF_FAIL(SKF_E_STATE, "the communicator is rank %d of %d, the plan part %d of %d", p->comm->rank, p->comm->world,
+                         p->part_index, p->part_count);
+            for (int it = 0; it < n_iters; ++it) iterate_owned(p, as_stream(stream));
+            finalize_owned(p, as_stream(stream));
+            return;
+        }
         for (int it = 0; it < n_iters; ++it) iterate_dist(p, as_stream(stream));
     });
 }

@@ -4,15 +4,15 @@
 iteration (_dfmc.py:287-292, :319-325).  The relation matrices passed in are never modified
 (the engine completes a device-side copy)."""
 from ... import _native as nat
-from ._dfmf import run_fit, run_fit_sharded, run_fit_rows
+from ._dfmf import run_fit, run_fit_sharded, run_fit_rows, run_fit_owned
 
 
 def dfmc(R, M, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol",
          stopping=None, stopping_system=None, verbose=0, compute_err=False, callback=None,
          random_state=None, n_jobs=1, dtype='f64', G0=None, engine=None, shard=None):
     """Data fusion by matrix completion -- drop-in for reference ``dfmc`` (_dfmc.py:181)."""
-    if shard in ('relations', 'rows'):
-        fit = run_fit_sharded if shard == 'relations' else run_fit_rows
+    if shard in ('relations', 'rows', 'owned'):
+        fit = {'relations': run_fit_sharded, 'rows': run_fit_rows, 'owned': run_fit_owned}[shard]
         return fit(nat.SKF_DFMC, R, M, Theta, obj_types, obj_type2rank, max_iter,
                    init_type, random_state, dtype, G0, engine, stopping, stopping_system, compute_err, callback)
     return run_fit(nat.SKF_DFMC, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,

@@ -116,6 +116,61 @@ def row_block_plan(variant, rel_list, theta_list, obj_types, n_obj, obj_type2ran
                       dtype=dtype, engine=engine, part=(rank, size))
 
 
+def owned_plan(variant, rel_list, theta_list, obj_types, n_obj, obj_type2rank, dtype, engine, rank, size):
+    """The plan of rank `rank` of `size` in a fit sharded by OWNERSHIP (SKF_OPT_OWNED_ROWS): the rank owns the same share
+    of the rows of every object type (`_engine.owned_rows`) and holds exactly those rows of every relation whose row type
+    it is -- work is 1 / size of every relation, the row-side terms never leave the rank -- and every constraint."""
+    from ..._engine import is_binary_matrix, owned_rows
+    local = []
+    for (i, j, m, mask) in rel_list:
+        begin, count, _ = owned_rows(dtype, n_obj[i], rank, size)
+        info = {'masked': mask is not None, 'col_side': True, 'row_begin': begin if count else 0, 'n_rows': count,
+                'absent': count == 0}
+        if dtype == 'bf16' and mask is None:         # decided on the whole relation: the same path on every rank
+            info['binary'] = is_binary_matrix(m)
+        if count == 0:
+            local.append((i, j, None, None, info))
+            continue
+        local.append((i, j, np.asarray(m)[begin:begin + count],
+                      None if mask is None else np.asarray(mask)[begin:begin + count], info))
+    return DevicePlan(obj_types, n_obj, obj_type2rank, local, list(theta_list), variant, dtype=dtype, engine=engine,
+                      part=(rank, size), owned=True)
+
+
+def run_fit_owned(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
+                  random_state, dtype, G0, engine, stopping=None, stopping_system=None, compute_err=False,
+                  callback=None):
+    """One fit sharded by ownership over the ranks of the process group (`shard='owned'`; SURVEY.md 8e, second row, in
+    the form with the least exchange): per iteration a rank sends the partial Q of every relation (reduce-scatter), its
+    updated factor rows (all-gather) and c x c partial sums -- no E / D exchange (DevicePlan.iterate_dist, the library
+    issues the collectives).  Every rank ends with the full (G, S)."""
+    from ..._distributed import world, sum_over_ranks
+    obj_types = list(obj_types)
+    n_obj = count_objects(obj_types, R)
+    if G0 is None:
+        R_first = {k: np.asarray(v[0], dtype=float) for k, v in R.items()}
+        G0 = initialize(obj_types, n_obj, obj_type2rank, R_first, init_type, _as_rs(random_state))
+    rel_list = flatten_relations(R, M)
+    rank, size = world()
+    plan = owned_plan(variant, rel_list, flatten_thetas(Theta), obj_types, n_obj, obj_type2rank, dtype, engine, rank, size)
+    try:
+        if not plan.attach_comm():
+            plan.attach_null_comm(0, 1)        # a single process: every row is owned here, nothing to exchange
+        for t in obj_types:
+            plan.set_factor(t, G0[t, t])
+        if not (callback or stopping or stopping_system or compute_err):
+            plan.iterate_dist(max_iter)
+        else:
+            def sqerrs(idx):                   # every rank holds the squared error of ITS rows
+                return sum_over_ranks([plan.relation_sqerr(k) for k in idx])
+            _host_loop(lambda: plan.iterate_dist(1), sqerrs, rel_list, max_iter, stopping, stopping_system,
+                       compute_err,
+                       (lambda it: callback(*(_collect(plan, obj_types, rel_list) + (it,)))) if callback else None)
+        return _collect(plan, obj_types, rel_list)
+    finally:
+        plan.close()
+
+
 def run_fit_rows(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init_type,
                  random_state, dtype, G0, engine, stopping=None, stopping_system=None, compute_err=False,
                  callback=None):
@@ -298,9 +353,9 @@ def dfmf(R, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol
     """Data fusion by matrix factorization -- drop-in for reference ``dfmf`` (_dfmf.py:127).
     ``shard='relations'`` (with an initialised torch.distributed group) partitions the relations
     of this ONE fit over the ranks."""
-    if shard in ('relations', 'rows'):
+    if shard in ('relations', 'rows', 'owned'):
         logging.basicConfig(format="%(asctime)s %(levelname)s: %(message)s", level=50 - verbose)
-        fit = run_fit_sharded if shard == 'relations' else run_fit_rows
+        fit = {'relations': run_fit_sharded, 'rows': run_fit_rows, 'owned': run_fit_owned}[shard]
         return fit(nat.SKF_DFMF, R, None, Theta, obj_types, obj_type2rank, max_iter,
                    init_type, random_state, dtype, G0, engine, stopping, stopping_system, compute_err, callback)
     return run_fit(nat.SKF_DFMF, R, None, Theta, obj_types, obj_type2rank, max_iter, init_type,

@@ -36,7 +36,7 @@ class Dfmc(FusionFit):
                   stopping_system=self.stopping_system, verbose=self.verbose,
                   compute_err=self.compute_err, callback=self.callback,
                   random_state=self.random_state, n_jobs=self.n_jobs, dtype=self.dtype)
-        if self.shard in ('relations', 'rows'):
+        if self.shard in ('relations', 'rows', 'owned'):
             store_runs(self, [_dfmc.dfmc(G0=G0[k], shard=self.shard, **kw) for k in range(self.n_run)])
             return self
         n_streams = concurrent_streams(self)

@@ -122,9 +122,11 @@ class Dfmf(FusionFit):
     stopping=None, stopping_system=None, verbose=0, compute_err=False, callback=None,
     random_state=None, n_jobs=1 (here: that many restarts run concurrently on streams of one GPU;
     results do not depend on it).  Additions: dtype='f64' | 'f32' | 'bf16' (device arithmetic),
-    shard='runs' | 'relations' | 'rows' (what a torch.distributed process group shares out: whole
-    restarts -- no collective; the relations of each restart -- one all-reduce per iteration; or
-    balanced row blocks of the relations -- all-reduces of W, Q and E / D per iteration).
+    shard='runs' | 'relations' | 'rows' | 'owned' (what a torch.distributed process group shares out: whole
+    restarts -- no collective; the relations of each restart -- one all-reduce per iteration;
+    balanced row blocks of the relations -- all-reduces of W, Q and E / D per iteration; or the rows of
+    every object type with the matching rows of its relations -- a reduce-scatter of each partial Q and an
+    all-gather of the updated factor rows, the form with the least exchange).
     """
 
     def __init__(self, max_iter=100, init_type='random_c', n_run=1, stopping=None,
@@ -145,7 +147,7 @@ class Dfmf(FusionFit):
                   stopping_system=self.stopping_system, verbose=self.verbose,
                   compute_err=self.compute_err, callback=self.callback,
                   random_state=self.random_state, n_jobs=self.n_jobs, dtype=self.dtype)
-        if self.shard in ('relations', 'rows'):                   # all GPUs cooperate on every restart
+        if self.shard in ('relations', 'rows', 'owned'):                   # all GPUs cooperate on every restart
             store_runs(self, [_dfmf.dfmf(G0=G0[k], shard=self.shard, **kw) for k in range(self.n_run)])
             return self
         if shared_launches(self):                       # restarts of a SMALL graph share their launches, whatever n_jobs says

@@ -180,6 +180,115 @@ def fit_row_blocks(variant, R, M, Theta, types, rank, G0, max_iter, size, dtype=
             p.close()
 
 
+class ThreadGroup(object):
+    """`world` plans of ONE process as the ranks of a group (test vehicle of skf_iterate_dist where there is one device or
+    none): every plan is driven by its own thread, the collective callback of each meets the others at a barrier and rank 0
+    does the arithmetic on the tensor views of all workspaces.  `serial` (the host emulator is not re-entrant): one thread
+    inside the library at a time -- the lock is handed over while a thread waits at the barrier."""
+
+    def __init__(self, world, sync=None, serial=True):
+        import threading
+        self.world, self.sync = world, sync or (lambda: None)
+        self.barrier = threading.Barrier(world)
+        self.lock = threading.Lock() if serial else None
+        self.views = [None] * world
+        self.calls = []                           # (op, elements per rank, element size) of every collective of rank 0
+
+    def _meet(self):
+        if self.lock:
+            self.lock.release()
+        try:
+            self.barrier.wait(timeout=600)
+        finally:
+            if self.lock:
+                self.lock.acquire()
+
+    def collective(self, op, view, count, rank, world):
+        self.sync()
+        self.views[rank] = view
+        if rank == 0:
+            self.calls.append((op, int(count), view.element_size()))
+        self._meet()
+        if rank == 0:
+            vs = self.views
+            if op in (0, 1):                      # (all-reduce of the whole buffer covers the reduce-scatter's range)
+                total = vs[0].clone()
+                for v in vs[1:]:
+                    total += v
+                for v in vs:
+                    v.copy_(total)
+            else:
+                for src in range(world):
+                    chunk = vs[src][src * count:(src + 1) * count].clone()
+                    for v in vs:
+                        v[src * count:(src + 1) * count] = chunk
+            self.sync()
+        self._meet()
+
+    def run(self, plans, fn):
+        """fn(plan) for every plan, each in its own thread; raises the first error."""
+        import threading
+        errors = []
+
+        def drive(plan):
+            if self.lock:
+                self.lock.acquire()
+            try:
+                fn(plan)
+            except BaseException as exc:          # noqa: B902  (surfaced after the join)
+                errors.append(exc)
+                self.barrier.abort()
+            finally:
+                if self.lock:
+                    self.lock.release()
+        threads = [threading.Thread(target=drive, args=(p,)) for p in plans]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+
+    def bytes_sent_per_rank(self):
+        """Ring accounting of what ONE rank sent in the collectives seen so far (skf_exchange_bytes' convention)."""
+        f = (self.world - 1) / float(self.world)
+        return sum((2.0 if op == 0 else 1.0) * f * (n if op == 0 else n * self.world) * es for op, n, es in self.calls)
+
+
+def fit_owned(variant, R, M, Theta, types, rank, G0, max_iter, size, dtype='f64', calls=1, group=None):
+    """Ownership-sharded fit (SKF_OPT_OWNED_ROWS) with `size` ranks of this process driven through skf_iterate_dist by a
+    ThreadGroup; `calls` calls of max_iter / calls iterations each.  Returns [(G, S) of every rank] (+ the group)."""
+    import skfusion_amd._native as nat
+    from skfusion_amd._engine import flatten_relations, flatten_thetas, count_objects
+    from skfusion_amd.fusion.decomposition._dfmf import owned_plan
+    code = {'dfmf': nat.SKF_DFMF, 'dfmc': nat.SKF_DFMC}[variant]
+    n = count_objects(types, R)
+    rel = flatten_relations(R, M if variant == 'dfmc' else None)
+    th = flatten_thetas(Theta)
+    rt = nat.get_runtime()
+    grp = group or ThreadGroup(size, sync=rt.mem.synchronize, serial=True)
+    plans = [owned_plan(code, rel, th, types, n, rank, dtype, None, q, size) for q in range(size)]
+    try:
+        for q, p in enumerate(plans):
+            p.attach_callback_comm(q, size, grp.collective)
+            for t in types:
+                p.set_factor(t, G0[t, t])
+        for _ in range(calls):
+            grp.run(plans, lambda p: p.iterate_dist(max_iter // calls))
+        out = []
+        for p in plans:
+            G = {(t, t): p.get_factor(t) for t in types}
+            S = {}
+            for k, (i, j, _, _) in enumerate(rel):
+                S.setdefault((i, j), []).append(p.get_backbone(k))
+            out.append((G, S))
+        out_bytes = [p.exchange_bytes(size) for p in plans]
+        return out, grp, out_bytes
+    finally:
+        for p in plans:
+            p.close()
+
+
 # ---- measured deviations -------------------------------------------------------------------------------
 # `within(value, bound, what)` asserts value < bound and records (what, value, bound); conftest writes the
 # records of a session to gpurun_out/test_deviations.txt, so the bounds in the GPU tests can be kept at a

@@ -124,3 +124,36 @@ def test_bench_gpus_n_launches_itself_and_checks_the_world_size(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert 'WORLD_SIZE=4' in str(e.value.code)
+
+
+def test_parity_full_size_record_plumbing(tmp_path):
+    """`parity_full_size` of the bench record (north_star: same inputs, results matching the reference
+    path): the oracle leg keeps its backbones, 64 rows of every factor and the relation errors after two iterations
+    (`_oracle_timing(keep=...)`, what `--cpu-full-child --parity-out` writes at full size), `parity_record` compares an
+    engine's side with them.  Here at 1/100 scale with the oracle's own two-GEMM form standing in for the engine: every key
+    present, deviations at rounding level; a perturbed engine side shows up in the matching key."""
+    from oracle import dfmf_oracle as orc
+    path = str(tmp_path / 'parity.npz')
+    times, n = bench._oracle_timing(0.01, bench.PARITY_ITERS, keep=path)
+    assert len(times) == bench.PARITY_ITERS and n == {'t1': 500, 't2': 1000, 't3': 400}
+    R = {(i, j): [orc.hash_uniform_matrix(s, n[i], n[j])] for i, j, s in bench.PAIRS}
+    G = {(t, t): orc.hash_uniform_matrix(100 + k, n[t], bench.RANKS[t]) for k, t in enumerate(bench.TYPES)}
+    for _ in range(bench.PARITY_ITERS):
+        G, S = orc.dfmf_two_gemm_step(R, G, {}, {})
+    errs = orc.relation_errors(R, G, S)
+    eng = {}
+    for i, j, _ in bench.PAIRS:
+        eng['S_%s_%s' % (i, j)] = S[i, j][0]
+        eng['err_%s_%s' % (i, j)] = errs[i, j][0]
+    for t in bench.TYPES:
+        rows = bench.parity_rows(n[t])
+        assert len(rows) == bench.PARITY_ROWS and rows[0] == 0 and rows[-1] == n[t] - 1
+        eng['G_%s' % t] = G[t, t][rows]
+    rec = bench.parity_record(path, eng)
+    assert set(rec) >= {'iters', 'S_relerr', 'G_rows_relerr', 'err_relerr', 'oracle_err'} and rec['iters'] == bench.PARITY_ITERS
+    assert rec['S_relerr'] < 1e-9 and rec['G_rows_relerr'] < 1e-10 and rec['err_relerr'] < 1e-12
+    eng['G_t2'] = eng['G_t2'] * (1.0 + 1e-3)
+    eng['err_t1_t3'] = eng['err_t1_t3'] * (1.0 - 2e-4)
+    bad = bench.parity_record(path, eng)
+    assert bad['G_rows_relerr'] == pytest.approx(1e-3, rel=1e-6) and bad['err_relerr'] == pytest.approx(2e-4, rel=1e-6)
+    assert bad['S_relerr'] == rec['S_relerr']

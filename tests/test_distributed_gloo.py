@@ -124,7 +124,7 @@ def _worker(rank, world, port, out, what):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         assert dist_world() == (rank, world)
-        assert my_runs(3) == ([0, 2] if rank == 0 else [1])
+        assert my_runs(3) == [k for k in range(3) if k % world == rank]
         with use_runtime(emulated_runtime()):
             if what == 'runs':
                 np.savez(os.path.join(out, 'rank%d.npz' % rank), *_fit())
@@ -154,21 +154,23 @@ def test_restarts_sharded_over_two_gloo_ranks(tmp_path):
             np.testing.assert_array_equal(z['arr_%d' % k], want)
 
 
-@pytest.mark.parametrize('shard', ['relations', 'rows'])
-def test_one_fit_sharded_over_two_gloo_ranks_matches_golden(tmp_path, shard):
-    """One fit over 2 ranks -- whole relations + constraints partitioned (E/D all-reduced every
-    iteration), or balanced row blocks of the relations (W, Q, E/D all-reduced between the stages):
-    both ranks must reproduce the reference goldens (iteration 10 of the probe graph, DFMF and
+@pytest.mark.parametrize('shard,world', [('relations', 2), ('rows', 2), ('owned', 2), ('owned', 3)])
+def test_one_fit_sharded_over_gloo_ranks_matches_golden(tmp_path, shard, world):
+    """One fit over 2 (3) ranks -- whole relations + constraints partitioned (E/D all-reduced every
+    iteration), balanced row blocks of the relations (W, Q, E/D all-reduced between the stages), or the rows of every type
+    with the matching rows of its relations (`owned`: reduce-scatter of the partial Q, all-gather of the updated rows,
+    issued by the library through the callback communicator):
+    every rank must reproduce the reference goldens (iteration 10 of the probe graph, DFMF and
     DFMC; iteration 2 of the MovieLens-style config 5) to 1e-9 -- the bar of the single-device engine."""
     import torch.multiprocessing as mp
     from emul.runtime import build
     from helpers import golden, TYPES, relerr
     build()
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), shard), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), shard), nprocs=world, join=True)
     z = golden('probe_multirel.npz')
     pairs = [('t1', 't2', 0), ('t1', 't2', 1), ('t1', 't3', 0), ('t2', 't3', 0)]
-    for rank in range(2):
+    for rank in range(world):
         a = np.load(os.path.join(str(tmp_path), 'shard%d.npz' % rank))
         arrs = [a['arr_%d' % k] for k in range(len(a.files))]
         for v, variant in ((0, 'dfmf'), (7, 'dfmc')):
@@ -178,7 +180,7 @@ def test_one_fit_sharded_over_two_gloo_ranks_matches_golden(tmp_path, shard):
                 assert relerr(arrs[v + 3 + k], z['%s/S_%s_%s_%d_it9' % (variant, i, j, l)]) < 1e-9
     # config 5 (MovieLens-style Dfmc, 6 relations + 3 constraints over 2 ranks): iteration 2 of the golden
     z5 = golden('c5_movielens_scaled.npz')
-    for rank in range(2):
+    for rank in range(world):
         a = np.load(os.path.join(str(tmp_path), 'c5_%d.npz' % rank))
         arrs = [a['arr_%d' % k] for k in range(len(a.files))]
         for k, t in enumerate(C5_TYPES):
@@ -187,7 +189,7 @@ def test_one_fit_sharded_over_two_gloo_ranks_matches_golden(tmp_path, shard):
             assert relerr(arrs[len(C5_TYPES) + k], z5['dfmc/S_%s_%s_0_it1' % (i, j)]) < 1e-9
 
 
-@pytest.mark.parametrize('shard', ['relations', 'rows'])
+@pytest.mark.parametrize('shard', ['relations', 'rows', 'owned'])
 def test_stopping_and_callback_inside_a_sharded_fit(tmp_path, shard):
     """`stopping`, `stopping_system`, `compute_err` and `callback` under shard='relations' / 'rows' (the reference
     supports them on every path, _dfmf.py:213-221, 301-322): both ranks stop at the iteration the single-device fit

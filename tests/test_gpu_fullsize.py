@@ -252,3 +252,20 @@ def test_config5_full_size_completion_and_contractions_against_host_rows(form):
     within(relerr(Q[cols], Rc_cols.T @ Gub), 2.5e-6, 'config 5 full size: Q rows of the completed ratings relation vs host')
     # and the known entries weigh in: the same products with the unknown entries alone are far off
     assert relerr(P[rows], np.where(U_rows, bf16(Hb[rows] @ Gmb.T), 0.0) @ Gmb) > 1e-2
+
+
+def test_bench_parity_record_at_a_tenth_of_the_size(tmp_path):
+    """The `parity_full_size` path of bench.py (engine's first two iterations vs the oracle's, same counter-based R and G0)
+    at 1/10 linear scale, where the oracle takes seconds: the bounds the bench record is held to at full size -- bf16
+    err_relerr <= 1e-4, f32 <= 1e-5 -- and f64 at rounding level.  At FULL size the same record is part of
+    the bench line itself (BENCH_rNN.json `parity_full_size`)."""
+    path = str(tmp_path / 'parity.npz')
+    bench._oracle_timing(0.1, bench.PARITY_ITERS, keep=path)
+    bounds = {'f64': (1e-9, 1e-10, 1e-11), 'f32': (2e-3, 1e-4, 1e-5), 'bf16': (1.0, 3e-2, 1e-4)}
+    for dtype in ('f64', 'f32', 'bf16'):
+        w = bench.run_workload('c3', dtype, 1, 0, scale=0.1, parity=True)
+        rec = bench.parity_record(path, w['parity'])
+        s_b, g_b, e_b = bounds[dtype]
+        within(rec['err_relerr'], e_b, 'bench parity at 1/10 scale, %s: relation errors after 2 iterations vs the oracle' % dtype)
+        within(rec['G_rows_relerr'], g_b, 'bench parity at 1/10 scale, %s: 64 rows of every factor vs the oracle' % dtype)
+        within(rec['S_relerr'], s_b, 'bench parity at 1/10 scale, %s: backbones vs the oracle' % dtype)

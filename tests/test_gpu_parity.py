@@ -541,6 +541,41 @@ def test_row_block_sharding_c3_scaled_c5_and_probe(monkeypatch):
             within(relerr(G[t, t], Gw[t, t]), 2e-3, 'c5 scaled bf16, 3 row blocks vs whole relations: G_%s after 5 iterations' % t)
 
 
+def test_owned_rows_sharding_on_the_device(rt, monkeypatch):
+    """SKF_OPT_OWNED_ROWS on the hardware: the ranks of a group as threads of this process on ONE GPU (helpers.ThreadGroup),
+    every plan driving skf_iterate_dist with its three streams (contractions / chains and side products / exchanges) -- the
+    probe and config-5 goldens over 2 and 3 ranks (1e-9), the wide-rank graph in all three engines, the ABI errors, the
+    byte accounting of config 3 on 8 ranks; then the scaled config 3 over 4 ranks in f64 / f32 / bf16 against the golden's
+    reconstruction errors, with the exchanges on the main stream as well (SKF_COMM_STREAM=0: same results)."""
+    import test_owned_sharding as O
+    from helpers import fit_owned
+    for variant in ('dfmf', 'dfmc'):
+        O.test_owned_rows_reproduce_the_reference_golden_on_2_and_3_ranks(variant)
+        O.test_owned_rows_wide_ranks_all_engines(variant)
+    O.test_owned_rows_c5_movielens_style_dfmc()
+    O.test_exchange_bytes_of_config_3_on_8_ranks(rt)
+    O.test_owned_rows_abi_errors(rt)
+    z = golden('c3_scaled.npz')
+    R, G0, types, rank = c3_scaled_graph(z)
+    Rb = {k: [nat.from_bf16_bits(nat.to_bf16_bits(v[0])).astype(np.float64)] for k, v in R.items()}
+    for size, dtype, tol, comm_stream in ((3, 'f64', 1e-9, '1'), (4, 'f32', 1e-5, '1'), (4, 'bf16', 1e-2, '1'), (2, 'bf16', 1e-2, '0')):
+        monkeypatch.setenv('SKF_COMM_STREAM', comm_stream)
+        out, grp, said = fit_owned('dfmf', R, None, {}, types, rank, G0, 5, size, dtype=dtype)
+        for G, S in out:
+            e = orc.relation_errors(Rb if dtype == 'bf16' else R, G, S)
+            got = np.array([e[k][0] for k in sorted(e)])
+            within(np.abs(got - z['errs'][4]).max() / z['errs'][4].min(), tol,
+                   'c3 scaled, %d owned-row ranks, %s: reconstruction errors after 5 iterations vs the golden' % (size, dtype))
+            if dtype == 'f64':
+                for (i, j) in R:
+                    assert relerr(S[i, j][0], z['S_%s_%s_it4' % (i, j)]) < 1e-7
+        for t in types:
+            for G, _ in out[1:]:
+                np.testing.assert_array_equal(G[t, t], out[0][0][t, t])
+        assert abs(grp.bytes_sent_per_rank() / 5.0 - said[0]) <= 1.0
+    monkeypatch.delenv('SKF_COMM_STREAM')
+
+
 def test_rccl_stream_ordered_exchanges_single_rank(monkeypatch):
     """The RCCL path of the sharded iterations (collectives issued on the engine's stream, no host
     synchronisation between the stages) with a one-rank nccl group on this box's GPU: the all-reduces
@@ -562,7 +597,7 @@ def test_rccl_stream_ordered_exchanges_single_rank(monkeypatch):
         monkeypatch.setenv('SKF_FORCE_COLLECTIVES', '1')
         z = golden('probe_multirel.npz')
         R, Theta, M, types, rank = probe_graph(z)
-        for shard in ('relations', 'rows'):
+        for shard in ('relations', 'rows', 'owned'):
             G, S = _dfmf.dfmf(R, Theta, types, rank, max_iter=10, G0=g0_from(z, 'dfmf/', types), shard=shard)
             for t in types:
                 assert relerr(G[t, t], z['dfmf/G_%s_it9' % t]) < 1e-9
@@ -591,6 +626,23 @@ def test_rccl_stream_ordered_exchanges_single_rank(monkeypatch):
             plan.close()
         for a, b in zip(*out):
             np.testing.assert_array_equal(a, b)
+        # ownership-sharded plan of the ONE rank (reduce-scatter of Q, all-gather of the bf16 rows as bytes, all-reduce of the
+        # c x c sums -- all in place through RCCL, exchanges on their own stream): the same iteration up to the order in which
+        # the type term joins E / D (a launch of its own here, fused into the last side product there)
+        from skfusion_amd._engine import owned_rows
+        rels = []
+        for k, (i, j, _) in enumerate(bench.PAIRS):
+            a, cnt, _ = owned_rows('bf16', n[i], 0, 1)
+            assert (a, cnt) == (0, n[i])
+            rels.append((i, j, bench.c3_relation(k, n, 'bf16'), None, dict(absent=False, row_begin=0, n_rows=cnt, masked=False)))
+        plan = DevicePlan(bench.TYPES, n, bench.RANKS, rels, [], nat.SKF_DFMF, dtype='bf16', part=(0, 1), owned=True)
+        for k, t in enumerate(bench.TYPES):
+            plan.set_factor(t, fill_uniform((n[t], bench.RANKS[t]), 100 + k, 'f32'))
+        assert plan.attach_comm()
+        plan.iterate_dist(3)
+        for t, b in zip(bench.TYPES, out[1]):
+            within(relerr(plan.get_factor(t), b), 1e-5, 'one-rank RCCL, owned rows, bf16 c3 at 1/20 scale: G_%s vs the staged iteration' % t)
+        plan.close()
     finally:
         dist.destroy_process_group()
 
