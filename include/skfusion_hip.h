@@ -259,8 +259,10 @@ typedef int (*skf_collective_fn)(void* user, int32_t op, void* buf, size_t count
 int skf_comm_unique_id(void* id128);
 int skf_comm_create(const void* id128, int32_t rank, int32_t world, skf_comm** out);   /* id128 == NULL: world must be 1 */
 int skf_comm_create_callback(int32_t rank, int32_t world, skf_collective_fn fn, void* user, skf_comm** out);
-/* A communicator whose collectives do nothing: `rank` of `world` on ONE device, for timing the compute of that rank of a
- * sharded fit where the other ranks do not exist (bench.py --emulate-rank k/W).  Results are meaningless. */
+/* A communicator that exchanges nothing: `rank` of `world` on ONE device, for timing the compute of that rank of a
+ * sharded fit where the other ranks do not exist (bench.py --emulate-rank k/W).  A sum over the ranks is stood in for by
+ * world x this rank's partial sum (so that the factors stay in the range of a real run and the timed launches take the paths
+ * they would); gathers leave the other ranks' rows as they were.  The factors it produces are not a fit. */
 int skf_comm_create_null(int32_t rank, int32_t world, skf_comm** out);
 int skf_comm_destroy(skf_comm* comm);
 int skf_plan_set_comm(skf_plan* plan, skf_comm* comm);     /* not owned by the plan; NULL detaches */

@@ -209,10 +209,20 @@ def relation_errors_blocked(R, G, S, rows=4096):
 # --------------------------------------------------------------------------------------
 # the three solver entry points
 # --------------------------------------------------------------------------------------
+def _system_error(R, G, S):
+    """_dfmf.py:306-316 / _dfmc.py:376-386: the UNSQUARED sum of the per-relation Frobenius errors."""
+    e = relation_errors(R, G, S)
+    return sum(sum(v) for v in e.values())
+
+
 def dfmf(R, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol",
-         callback=None, random_state=None, G0=None):
+         callback=None, random_state=None, G0=None, stopping=None, stopping_system=None, compute_err=False):
     """Restatement of ``dfmf()`` (_dfmf.py:127-327).  ``G0`` (dict keyed (t,t)) overrides
-    the initialiser so that parity tests do not depend on set-iteration order."""
+    the initialiser so that parity tests do not depend on set-iteration order.
+    stopping = ((row, col), eps) / stopping_system = eps: the early-stopping rules of _dfmf.py:213-221 -- checked from the
+    third iteration on, on the change of the target relation's error (:301-304; the reference's expression subtracts the
+    LISTS of a pair and only means something for the first relation of the pair: that one is taken) / of the summed
+    objective (:306-319; forces compute_err, :198-200)."""
     R = {k: [np.asarray(m, dtype=float) for m in v] for k, v in R.items()}
     n_obj = count_objects(obj_types, R)
     if G0 is None:
@@ -222,19 +232,33 @@ def dfmf(R, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol
         G = {k: np.array(v, dtype=float) for k, v in G0.items()}
     Tp, Tn = _theta_split(Theta)
     S = None
+    if stopping_system:
+        compute_err = True                            # _dfmf.py:198-200
+    err, err_system = (None, None), (None, None)
     for it in range(max_iter):
+        if it > 1 and stopping and err[1] - err[0] < stopping[1]:                            # _dfmf.py:213-216
+            break
+        if it > 1 and stopping_system and err_system[1] - err_system[0] < stopping_system:   # :217-221
+            break
         S, _ = _update_S(R, G)
         G = _update_G(R, G, S, Tp, Tn, nan_to_num=True)
+        if stopping:                                  # :301-304
+            i, j = stopping[0]
+            err = (np.linalg.norm(R[i, j][0] - np.dot(G[i, i], np.dot(S[i, j][0], G[j, j].T))), err[0])
+        if compute_err:                               # :306-319
+            err_system = (_system_error(R, G, S), err_system[0])
         if callback:
             callback(G, S, it)
     return G, S
 
 
 def dfmc(R, M, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol",
-         callback=None, random_state=None, G0=None):
+         callback=None, random_state=None, G0=None, stopping=None, stopping_system=None, compute_err=False):
     """Restatement of ``dfmc()`` (_dfmc.py:181-397): dfmf + completion of masked entries
     (zeroed at iteration 0, :287-292; overwritten with G_i S G_j^T after every S update,
-    :319-325).  The relation data is copied (:268), inputs are never mutated."""
+    :319-325).  The relation data is copied (:268), inputs are never mutated.
+    stopping = (((row, col), l), eps) (_dfmc.py:370-374) / stopping_system = eps (:376-389), both on the WORKING copy of
+    the relations (completed entries included), checked from the third iteration on (:271-279)."""
     R = {k: [np.array(m, dtype=float) for m in v] for k, v in R.items()}      # copies
     n_obj = count_objects(obj_types, R)
     if G0 is None:
@@ -244,7 +268,14 @@ def dfmc(R, M, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_v
         G = {k: np.array(v, dtype=float) for k, v in G0.items()}
     Tp, Tn = _theta_split(Theta)
     S = None
+    if stopping_system:
+        compute_err = True                            # _dfmc.py:256-258
+    err, err_system = (None, None), (None, None)
     for it in range(max_iter):
+        if it > 1 and stopping and err[1] - err[0] < stopping[1]:                            # _dfmc.py:271-274
+            break
+        if it > 1 and stopping_system and err_system[1] - err_system[0] < stopping_system:   # :275-279
+            break
         if it == 0:
             for r in M:
                 for l in range(len(R[r])):
@@ -259,6 +290,11 @@ def dfmc(R, M, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_v
                 app = np.dot(G[i, i], np.dot(S[i, j][l], G[j, j].T))
                 R[r][l][M[r][l]] = app[M[r][l]]
         G = _update_G(R, G, S, Tp, Tn, nan_to_num=False)
+        if stopping:                                  # _dfmc.py:370-374
+            (i, j), l = stopping[0]
+            err = (np.linalg.norm(R[i, j][l] - np.dot(G[i, i], np.dot(S[i, j][l], G[j, j].T))), err[0])
+        if compute_err:                               # :376-389
+            err_system = (_system_error(R, G, S), err_system[0])
         if callback:
             callback(G, S, it)
     return G, S

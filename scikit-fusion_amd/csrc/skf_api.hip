@@ -1780,7 +1780,21 @@ static void collective(skf_comm* c, int op, void* buf, size_t count, int dtype, 
         if (rc != 0) SKF_FAIL(SKF_E_HIP, "collective callback failed (op %d, status %d)", op, rc);
         return;
     }
-    if (c->null_comm) return;                       // timing runs of one rank of a sharded fit (skf_comm_create_null)
+    if (c->null_comm) {
+        // timing runs of ONE rank of a sharded fit (skf_comm_create_null): nothing is exchanged; a sum over the ranks is stood
+        // in for by `world` times this rank's partial, so that the Gram matrices, backbones and updates the timed launches see
+        // stay in the range of a real run (a Gram matrix of 1/8 of the rows sends the factors off scale, and the
+        // pseudo-inverses then take their slow fallbacks); gathered rows of other ranks keep their old values
+        if (op == COLL_ALL_GATHER || c->world == 1 || dtype == SKF_BF16) return;
+        const size_t es = dtype == SKF_F64 ? 8 : 4;
+        char* at = (char*)buf + (op == COLL_REDUCE_SCATTER ? (size_t)c->rank * count * es : 0);
+        if (dtype == SKF_F64)
+            hipLaunchKernelGGL((scale_kernel<double>), dim3(elem_grid((int64_t)count)), dim3(256), 0, st, (double*)at, (int64_t)count, (double)c->world);
+        else
+            hipLaunchKernelGGL((scale_kernel<float>), dim3(elem_grid((int64_t)count)), dim3(256), 0, st, (float*)at, (int64_t)count, (float)c->world);
+        check_launch("scale (null communicator)");
+        return;
+    }
     if (c->world == 1 && !c->nccl) return;          // a single rank without a transport: nothing to exchange
     const Rccl& r = rccl();
     const int nt = dtype == SKF_F64 ? 8 /* ncclFloat64 */ : 7 /* ncclFloat32 */;

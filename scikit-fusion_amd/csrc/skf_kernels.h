@@ -2099,6 +2099,12 @@ __global__ __launch_bounds__(256) void split_to_bf16_kernel(uint16_t* __restrict
 }
 
 // dst += src  (n x c, both row-major with leading dimension c)
+// x[e] *= f   (the null communicator of the rank-emulation runs: a partial sum times the number of ranks stands for the sum)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ x, int64_t n, T f) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) x[e] *= f;
+}
+
 __global__ __launch_bounds__(256) void add_into_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                        int64_t total) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;

@@ -313,3 +313,123 @@ def persistence_round_trip_on_the_engine(tmpdir, dtype='f32'):
                [['genes', 'conditions'], ['genes', 'terms', 'conditions']]
         if onto is not None:                     # the fold-in reads the frozen factors / backbones of the loaded model
             np.testing.assert_array_equal(fold_in(back).factor(t1), want_tr)
+
+
+def probe_fusion_graph(masked):
+    """The probe graph of tests/golden/probe_multirel.npz (two relations between one pair, a negative-valued relation,
+    constraints on two types; `masked`: the two masks as masked arrays) as a FusionGraph.  Returns (graph, types by name)."""
+    from helpers import golden, probe_graph
+    R, Theta, M, types, rank = probe_graph(golden('probe_multirel.npz'))
+    ot = {t: ObjectType(t, rank[t]) for t in types}
+    rels = []
+    for (i, j), mats in R.items():
+        for l, m in enumerate(mats):
+            data = np.ma.masked_array(m.copy(), mask=M[i, j][l].copy()) if (masked and M[i, j][l] is not None) else m.copy()
+            rels.append(Relation(data, ot[i], ot[j], fill_value=0.0))
+    for (i, _), mats in Theta.items():
+        for th in mats:
+            rels.append(Relation(th.copy(), ot[i], ot[i]))
+    return FusionGraph(rels), ot
+
+
+def early_stopping_matches_the_reference_rule(dtypes=('f64',), shards=('runs',)):
+    """`stopping`, `stopping_system` and `compute_err` through Dfmf / Dfmc / DfmfTransform on the probe graph (reference
+    _dfmf.py:213-221, 301-319; _dfmc.py:271-279, 370-389 with its ((row, col), l) target; fold-in _dfmf.py:367-376, 433-450):
+    the fit stops at the iteration at which the oracle, driven with the reference's rule on the same dictionaries and the
+    same G0, stops, and returns its factors -- f64 to 1e-9, f32 to its engine tolerance (1e-4), on one device and sharded
+    (`shards`: 'rows' / 'owned' need a torch.distributed group; a one-rank group exercises the library's exchanges)."""
+    from oracle import dfmf_oracle as orc
+    from helpers import relerr
+    from skfusion_amd.fusion.decomposition.dfmf import graph_matrices, initial_factors
+    checked = 0
+    for cls, variant in ((Dfmf, 'dfmf'), (Dfmc, 'dfmc')):
+        graph, ot = probe_fusion_graph(masked=(variant == 'dfmc'))
+        types = list(graph.object_types)
+        rank = {t: int(t.rank) for t in types}
+        if variant == 'dfmc':
+            R, Theta, M = graph_matrices(graph, with_masks=True)
+            assert sum(m is not None for v in M.values() for m in v) == 2
+            target = ((ot['t1'], ot['t2']), 0)
+        else:
+            R, Theta = graph_matrices(graph)
+            M = None
+            target = (ot['t1'], ot['t3'])
+        G0 = initial_factors(R, types, rank, 'random', np.random.RandomState(7), 1)[0]
+        # thresholds from the oracle's own error decrements, half-way between those of two consecutive iterations (the
+        # decision then has a margin no engine rounding can cross); the reference's errors: target relation and system
+        trace = {'t': [], 's': []}
+
+        def watch(G, S, it, R=R, M=M):
+            Rw = R
+            if variant == 'dfmc':                      # the working copy: masked entries hold the current completion
+                Rw = {k: [m.copy() for m in v] for k, v in R.items()}
+                for k, masks in M.items():
+                    for l, m in enumerate(masks):
+                        if m is not None:
+                            Rw[k][l][m] = (G[k[0], k[0]] @ S[k][l] @ G[k[1], k[1]].T)[m]
+            e = orc.relation_errors(Rw, G, S)
+            (i, j), l = target if variant == 'dfmc' else (target, 0)
+            trace['t'].append(e[i, j][l])
+            trace['s'].append(sum(sum(v) for v in e.values()))
+        if variant == 'dfmc':
+            orc.dfmc(R, M, Theta, types, rank, max_iter=16, G0=G0, callback=watch)
+        else:
+            orc.dfmf(R, Theta, types, rank, max_iter=16, G0=G0, callback=watch)
+        dt, ds = -np.diff(trace['t']), -np.diff(trace['s'])
+        eps_t, eps_s = 0.5 * (dt[9] + dt[10]), 0.5 * (ds[11] + ds[12])
+        assert dt[9] > eps_t * 1.005 and dt[10] < eps_t * 0.995 and ds[11] > eps_s * 1.005 and ds[12] < eps_s * 0.995
+        for kw, max_iter in ((dict(stopping_system=eps_s), 40), (dict(stopping=(target, eps_t)), 40),
+                             (dict(stopping=(target, eps_t), stopping_system=1e-9, compute_err=True), 40)):
+            want_seen = []
+            okw = dict(kw)
+            if variant == 'dfmc':
+                Go, So = orc.dfmc(R, M, Theta, types, rank, max_iter=max_iter, G0=G0,
+                                  callback=lambda g, s, it: want_seen.append(it), **okw)
+            else:
+                Go, So = orc.dfmf(R, Theta, types, rank, max_iter=max_iter, G0=G0,
+                                  callback=lambda g, s, it: want_seen.append(it), **okw)
+            assert 2 < len(want_seen) < max_iter, (variant, kw, len(want_seen))          # the rule fired, and not at once
+            for dtype in dtypes:
+                for shard in shards:
+                    seen = []
+                    fuser = cls(max_iter=max_iter, init_type='random', random_state=7, dtype=dtype, shard=shard,
+                                callback=lambda g, s, it: seen.append(it), **kw).fuse(graph)
+                    assert seen == want_seen, (variant, kw, dtype, shard, len(seen), len(want_seen))
+                    tol = 1e-9 if dtype == 'f64' else 1e-4
+                    for t in types:
+                        assert relerr(fuser.factor(t), Go[t, t]) < tol, (variant, kw, dtype, shard, t.name)
+                    checked += 1
+        # compute_err alone changes nothing
+        a = cls(max_iter=6, init_type='random', random_state=7, compute_err=True).fuse(graph)
+        b = cls(max_iter=6, init_type='random', random_state=7).fuse(graph)
+        for t in types:
+            np.testing.assert_array_equal(a.factor(t), b.factor(t))
+    # fold-in: new objects of t1 against the frozen model of a Dfmf fit; stopping_system on the error of the new relations
+    graph, ot = probe_fusion_graph(masked=False)
+    fuser = Dfmf(max_iter=15, init_type='random', random_state=7).fuse(graph)
+    rs = np.random.RandomState(3)
+    new = [Relation(rs.rand(9, 30), ot['t1'], ot['t2']), Relation(rs.rand(9, 20) - 0.3, ot['t1'], ot['t3'])]
+    from skfusion_amd.fusion.decomposition._init import initialize
+    G = {(t, t): fuser.factor(t) for t in graph.object_types}
+    S = {(r.row_type, r.col_type): [fuser.backbone(r)] for r in graph.relations if r.row_type != r.col_type}
+    Rn = {(r.row_type, r.col_type): [r.data] for r in new}
+    rank = {t: int(t.rank) for t in graph.object_types}
+    G0 = initialize([ot['t1']], {ot['t1']: 9}, rank, {}, 'random', np.random.RandomState(5))[ot['t1'], ot['t1']]
+    # the oracle's fold-in and the reference's rule on the summed error of the new relations (_dfmf.py:433-450); the
+    # threshold half-way between two consecutive decrements of that error
+    errs = []
+    for it in range(16):
+        Gh = orc.transform(Rn, {}, ot['t1'], rank, G, S, max_iter=it + 1, G0=G0)
+        errs.append(sum(np.linalg.norm(m[0] - Gh @ S[k][0] @ G[k[1], k[1]].T) for k, m in Rn.items()))
+    d = -np.diff(errs)
+    eps = 0.5 * (d[7] + d[8])
+    assert d[7] > eps * 1.005 and d[8] < eps * 0.995
+    stop_at = next(it for it in range(2, len(errs)) if errs[it - 2] - errs[it - 1] < eps)
+    want = orc.transform(Rn, {}, ot['t1'], rank, G, S, max_iter=stop_at, G0=G0)
+    for dtype in dtypes:
+        seen = []
+        tr = DfmfTransform(max_iter=60, init_type='random', random_state=5, stopping_system=eps, dtype=dtype,
+                           callback=lambda g, it: seen.append(it)).transform(ot['t1'], FusionGraph(new), fuser)
+        assert 2 < stop_at < 16 and len(seen) == stop_at, (dtype, stop_at, len(seen))
+        assert relerr(tr.factor(ot['t1']), want) < (1e-9 if dtype == 'f64' else 1e-4)
+    return checked

@@ -62,6 +62,28 @@ def c3_scaled_graph(z):
     return R, G0, list(TYPES), dict(zip(TYPES, c))
 
 
+def c3_planted_graph(shape=(2000, 4000, 1600), ranks=(128, 256, 256), noise=0.01, bf16=False):
+    """The PLANTED variant of BASELINE config 3: R_ij = G*_i S*_ij G*_j^T / mean + noise * U with G*, S*, U
+    from the counter-based generator (seeds 200 + type, 300 + relation, 400 + relation), G0 from seeds 100 + type -- the one
+    workload on which the RMSE discriminates (iid-uniform data sits at sqrt(1/12) whatever the fit); noise floor
+    noise / sqrt(12).  bf16: the relations rounded to bf16 (what the SKF_BF16 engine stores).  1/25 linear scale by default."""
+    from oracle.dfmf_oracle import hash_uniform_matrix
+    n = dict(zip(TYPES, shape))
+    c = dict(zip(TYPES, ranks))
+    Gs = {t: hash_uniform_matrix(200 + q, n[t], c[t]) for q, t in enumerate(TYPES)}
+    R = {}
+    for seed, (i, j) in enumerate([('t1', 't2'), ('t1', 't3'), ('t2', 't3')]):
+        Rm = Gs[i].dot(hash_uniform_matrix(300 + seed, c[i], c[j])).dot(Gs[j].T)
+        Rm /= Rm.mean()
+        Rm += noise * hash_uniform_matrix(400 + seed, n[i], n[j])
+        if bf16:
+            import skfusion_amd._native as nat
+            Rm = nat.from_bf16_bits(nat.to_bf16_bits(Rm)).astype(np.float64)
+        R[i, j] = [Rm]
+    G0 = {(t, t): hash_uniform_matrix(100 + q, n[t], c[t]) for q, t in enumerate(TYPES)}
+    return R, G0, list(TYPES), c
+
+
 C5_TYPES = ['user', 'movie', 'genre', 'actor', 'tag', 'director']
 C5_SIZES = {'user': 400, 'movie': 240, 'genre': 16, 'actor': 200, 'tag': 120, 'director': 80}
 C5_RANKS = {'user': 16, 'movie': 24, 'genre': 6, 'actor': 12, 'tag': 8, 'director': 8}

@@ -55,3 +55,26 @@ def test_fill_strategies_on_the_device():
 def test_saved_model_drives_the_engine(tmp_path):
     """f4: fit -> save -> load -> blockwise device completion and fold-in from the loaded model (same case as on the GPU)."""
     A.persistence_round_trip_on_the_engine(tmp_path, 'f64')
+
+
+def test_early_stopping_through_the_classes():
+    """stopping / stopping_system / compute_err through Dfmf, Dfmc and DfmfTransform against the oracle driven with the
+    reference's rule (same case as on the GPU, f64)."""
+    assert A.early_stopping_matches_the_reference_rule(('f64',), ('runs',)) == 6
+
+
+def test_early_stopping_inside_sharded_fits_of_a_one_rank_group(monkeypatch):
+    """The same decisions with shard='rows' / 'owned' over a one-rank gloo group: the library issues its exchanges through
+    the callback communicator, the squared errors are summed over the ranks of the group."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+    try:
+        monkeypatch.setenv('SKF_FORCE_COLLECTIVES', '1')
+        assert A.early_stopping_matches_the_reference_rule(('f64',), ('rows', 'owned')) == 12
+    finally:
+        dist.destroy_process_group()

@@ -43,6 +43,31 @@ def test_pipeline_and_fold_in():
     A.blockwise_completion()
 
 
+def test_early_stopping_through_the_classes_single_device_and_sharded(monkeypatch):
+    """`stopping`, `stopping_system`, `compute_err` through Dfmf / Dfmc / DfmfTransform on the probe graph
+    ON THE HARDWARE: the same stopping iteration and the same final factors as the oracle driven with the reference's rule
+    (_dfmf.py:213-221, 301-319; _dfmc.py:370-389), f64 and f32, on one device and with shard='rows' / 'owned' over a one-rank
+    RCCL group (the library's own exchanges, squared errors summed over the ranks)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    assert A.early_stopping_matches_the_reference_rule(('f64', 'f32'), ('runs',)) == 12
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    try:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                                device_id=torch.device('cuda', torch.cuda.current_device()))
+    except Exception as exc:                                  # pragma: no cover
+        pytest.skip('no one-rank RCCL group on this box: %r' % (exc,))
+    try:
+        monkeypatch.setenv('SKF_FORCE_COLLECTIVES', '1')
+        assert A.early_stopping_matches_the_reference_rule(('f64', 'f32'), ('rows', 'owned')) == 24
+    finally:
+        dist.destroy_process_group()
+
+
 def test_f32_engine_reaches_the_same_fixed_point():
     import numpy as np
     from skfusion_amd.fusion import Relation, ObjectType, FusionGraph

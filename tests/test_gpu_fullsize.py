@@ -129,10 +129,22 @@ def test_one_full_size_iteration_against_host_regenerated_rows(dtype):
         within(relerr(G3[t][rows], want), 6e-7, 'full size %s: updated rows of G_%s vs host update' % (dtype, t))
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+_PLANTED_RMSE = {}          # dtype -> RMSE per relation of the full-size planted fit (f32 runs first, bf16 checks against it)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_full_size_planted_structure_is_recovered(dtype):
+    """Planted data at FULL size (the counter-based planted graph of tests/helpers.py:c3_planted_graph, formed on the device):
+    the bounds come from the reference-derived golden of the same graph at 1/25 scale (tests/golden/c3_planted_scaled.npz) --
+    the reference reaches 1.141 / 1.297 / 1.134 x the noise floor on the fp64 relations and, fed the bf16-rounded relations,
+    exactly RMSE^2 = RMSE_f64^2 + q^2 with q = ||bf16(R) - R||_F / sqrt(cells).  f32 engine: within 10 % of the golden's
+    ratios (the excess over the floor depends on the size of the graph: measured 1.14 / 1.36 / 1.14 at full size).  bf16
+    engine: RMSE^2 against RMSE_f32^2 + q^2 with THIS run's f32 result and the q measured on the device -- 1.5 % (BASELINE.md:
+    abs(dRMSE) / RMSE <= 1e-2 against the fp64 path on the same, i.e. rounded, inputs)."""
     _need_big_gpu()
     import torch
+    from helpers import golden
+    z = golden('c3_planted_scaled.npz')
     floor = 0.01 / np.sqrt(12.0)
     iters = 100
     cache = {}
@@ -145,6 +157,7 @@ def test_full_size_planted_structure_is_recovered(dtype):
         assert t is not None and tuple(t.shape) == (N[i], N[j])
         sample.append((rows, t[torch.from_numpy(rows).cuda()].to(torch.float64).cpu().numpy()))
         rels.append((i, j, dm, None))
+    quant = [cache.get('quant_%d' % k) for k in range(3)]
     cache.clear()
     plan = DevicePlan(TYPES, N, RANK, rels, [], nat.SKF_DFMF, dtype=dtype)
     plan.release_relation_data()
@@ -154,13 +167,16 @@ def test_full_size_planted_structure_is_recovered(dtype):
         plan.set_factor(t, fill_uniform((N[t], RANK[t]), 100 + k, 'f32'))
     plan.iterate(iters)
     G = {t: plan.get_factor(t) for t in TYPES}
+    n25 = z['shape']
+    cells25 = np.array([n25[0] * n25[1], n25[0] * n25[2], n25[1] * n25[2]], dtype=np.float64)
+    gold = z['bf16/errs' if dtype == 'bf16' else 'f64/errs'][-1] / np.sqrt(cells25) / floor
+    mine = []
     for k, (i, j, _) in enumerate(bench.PAIRS):
         rmse = np.sqrt(plan.relation_sqerr(k) / (float(N[i]) * N[j]))
-        # measured f32 1.14 / 1.36 / 1.14, bf16 1.31 / 1.50 / 1.31 of the floor, unchanged between 60 and 100
-        # iterations (the bf16 rounding of R ~ 1 alone lifts the floor to 1.27; a fit that lost a K slice, a tile or a
-        # +- term stays above 10)
-        within(rmse / floor, 1.6, 'full size %s planted: RMSE / noise floor of relation %d after %d iterations'
-               % (dtype, k, iters))
+        mine.append(rmse)
+        # (a fit that lost a K slice, a tile or a +- term stays above 10 x the floor)
+        within(rmse / floor / gold[k], 1.10, 'full size %s planted: RMSE / floor over the reference\'s ratio at 1/25 scale (%.3f), '
+               'relation %d after %d iterations' % (dtype, gold[k], k, iters))
         rows, Rrows = sample[k]
         host = np.sqrt(np.mean((Rrows - G[i][rows] @ plan.get_backbone(k) @ G[j].T) ** 2))
         # the backbone belongs to the factors before the last update (reference _dfmf.py:239 vs :295), as in
@@ -168,6 +184,14 @@ def test_full_size_planted_structure_is_recovered(dtype):
         # 384 rows 0.003-0.31 %)
         within(abs(host - rmse) / rmse, 0.012, 'full size %s planted: device RMSE vs host RMSE on sampled rows, relation %d'
                % (dtype, k))
+    _PLANTED_RMSE[dtype] = mine
+    if dtype == 'bf16':
+        for k in range(3):
+            within(abs(quant[k] / floor - 0.627), 0.02, 'full size planted: quantisation term q / floor of relation %d vs 0.627' % k)
+        if 'f32' in _PLANTED_RMSE:
+            for k in range(3):
+                model = _PLANTED_RMSE['f32'][k] ** 2 + quant[k] ** 2
+                within(abs(mine[k] ** 2 / model - 1.0), 1.5e-2, 'full size planted: bf16 RMSE^2 vs f32 RMSE^2 + quantisation^2, relation %d' % k)
     plan.close()
 
 
@@ -261,7 +285,10 @@ def test_bench_parity_record_at_a_tenth_of_the_size(tmp_path):
     the bench line itself (BENCH_rNN.json `parity_full_size`)."""
     path = str(tmp_path / 'parity.npz')
     bench._oracle_timing(0.1, bench.PARITY_ITERS, keep=path)
-    bounds = {'f64': (1e-9, 1e-10, 1e-11), 'f32': (2e-3, 1e-4, 1e-5), 'bf16': (1.0, 3e-2, 1e-4)}
+    # (backbones, factor rows, relation errors); measured on the hardware: f64 1.2e-11 / 2.3e-13 / 0, f32 7.4e-5 / 3.1e-7 /
+    # 6.8e-10, bf16 4.6e-3 / 3.1e-4 / 1.05e-5 (the backbones S = K_i W K_j amplify a perturbation by the condition numbers of
+    # two Gram matrices of uniform random factors; the factors and the errors do not)
+    bounds = {'f64': (1e-10, 2e-12, 1e-13), 'f32': (4e-4, 2e-6, 5e-9), 'bf16': (2.5e-2, 1.5e-3, 5e-5)}
     for dtype in ('f64', 'f32', 'bf16'):
         w = bench.run_workload('c3', dtype, 1, 0, scale=0.1, parity=True)
         rec = bench.parity_record(path, w['parity'])

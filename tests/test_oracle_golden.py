@@ -177,6 +177,30 @@ def test_c3_scaled_and_two_gemm_form():
             assert relerr(S2[k][0], S1[k][0]) < 1e-8
 
 
+def test_c3_planted_scaled():
+    """The PLANTED variant of config 3 at 1/25 linear scale (tools/gen_golden.py:gen_planted): the oracle's
+    first ten iterations against the reference's per-relation errors, on the fp64 relations and on their bf16 roundings;
+    and what the golden says about the bf16 engine's tolerance: the reference ITSELF, fed the bf16-rounded relations, ends
+    11-14 % above its fp64 RMSE, and exactly by the quantisation term -- RMSE_bf16^2 = RMSE_f64^2 + ||bf16(R) - R||^2 / cells
+    to 3e-3 (the quantisation error is all but uncorrelated with the fit's residual: 1.0e-3 / 2.0e-3 / 2.7e-3)."""
+    from helpers import c3_planted_graph
+    z = golden('c3_planted_scaled.npz')
+    assert list(z['f64/iters']) == [9, 29, 59]
+    for tag, bf16 in (('f64', False), ('bf16', True)):
+        R, G0, types, rank = c3_planted_graph(bf16=bf16)
+        assert [R['t1', 't2'][0].shape[0], R['t1', 't2'][0].shape[1], R['t1', 't3'][0].shape[1]] == list(z['shape'])
+        G, S = orc.dfmf(R, {}, types, rank, max_iter=10, G0=G0)
+        e = orc.relation_errors(R, G, S)
+        assert relerr(np.array([e[k][0] for k in sorted(e)]), z['%s/errs' % tag][0]) < 1e-10
+    n = z['shape']
+    cells = np.array([n[0] * n[1], n[0] * n[2], n[1] * n[2]], dtype=np.float64)
+    rm64, rmb, q = z['f64/errs'][-1] / np.sqrt(cells), z['bf16/errs'][-1] / np.sqrt(cells), z['quantisation'] / np.sqrt(cells)
+    floor = 0.01 / np.sqrt(12.0)
+    assert (rm64 / floor < 1.31).all() and (rm64 / floor > 1.12).all()         # 1.141 / 1.297 / 1.134 x the noise floor
+    assert ((rmb / rm64 - 1.0) > 0.10).all() and ((rmb / rm64 - 1.0) < 0.15).all()
+    assert np.abs(rmb ** 2 / (rm64 ** 2 + q ** 2) - 1.0).max() < 4e-3
+
+
 def test_two_gemm_form_with_masks_and_theta():
     z = golden('probe_multirel.npz')
     R, Theta, M, types, rank = probe_graph(z)

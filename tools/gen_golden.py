@@ -293,6 +293,50 @@ def gen_c3_scaled():
     save('c3_scaled.npz', out)
 
 
+# ------------------------------------------------------------------ C3 planted, 1/25 scale
+def gen_planted():
+    """The reference on the planted variant of config 3 at 1/25 linear scale (tests/helpers.py:c3_planted_graph; inputs
+    regenerable from seeds), 60 iterations from the hash-generated G0: per-relation Frobenius errors at iterations 10, 30,
+    60, the backbones and 16 rows of every factor at iteration 60 -- once on the fp64 relations and once on their bf16
+    roundings (what the SKF_BF16 engine stores), plus the quantisation term ||bf16(R) - R||_F of every relation."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import c3_planted_graph
+    out = {}
+    keep = (9, 29, 59)
+    for tag, bf16 in (('f64', False), ('bf16', True)):
+        R, G0, types, rank = c3_planted_graph(bf16=bf16)
+        if not bf16:
+            Rexact = R
+            out['shape'] = np.array([R['t1', 't2'][0].shape[0], R['t1', 't2'][0].shape[1], R['t1', 't3'][0].shape[1]])
+            out['ranks'] = np.array([rank[t] for t in types])
+        else:
+            out['quantisation'] = np.array([np.linalg.norm(R[k][0] - Rexact[k][0]) for k in sorted(R)])
+        orig = ref_dfmf.initialize
+        ref_dfmf.initialize = lambda *a, **k: {r: v.copy() for r, v in G0.items()}
+        errs_it, last = {}, {}
+
+        def cb(G, S, it):
+            if it in keep:
+                e = fro_errs(R, G, S)
+                errs_it[it] = [e[k][0] for k in sorted(e)]
+            if it == keep[-1]:
+                last['G'] = {r: v[:16].copy() for r, v in G.items()}
+                last['S'] = {r: [s.copy() for s in v] for r, v in S.items()}
+        try:
+            ref_dfmf.dfmf(R, {}, types, rank, max_iter=keep[-1] + 1, init_type='random', callback=cb,
+                          random_state=np.random.RandomState(0))
+        finally:
+            ref_dfmf.initialize = orig
+        out['%s/iters' % tag] = np.array(keep)
+        out['%s/errs' % tag] = np.array([errs_it[i] for i in keep])
+        if not bf16:
+            for (t, _), v in last['G'].items():
+                out['f64/Grows_%s' % t] = v
+            for (i, j), lst in last['S'].items():
+                out['f64/S_%s_%s' % (i, j)] = lst[0]
+    save('c3_planted_scaled.npz', out)
+
+
 # ------------------------------------------------------------------ C5: MovieLens-style Dfmc
 def gen_c5():
     """BASELINE config 5 scaled down (tests/helpers.py:movielens_style_graph): inputs are regenerated
@@ -347,7 +391,7 @@ def gen_fill():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['c1', 'probe', 'rd', 'transform', 'dicty', 'c3s', 'c5', 'fill']
+    which = sys.argv[1:] or ['c1', 'probe', 'rd', 'transform', 'dicty', 'c3s', 'c3p', 'c5', 'fill']
     G = S = None
     if 'c1' in which or 'transform' in which:
         G, S = gen_c1()
@@ -361,6 +405,8 @@ if __name__ == '__main__':
         gen_dicty()
     if 'c3s' in which:
         gen_c3_scaled()
+    if 'c3p' in which:
+        gen_planted()
     if 'c5' in which:
         gen_c5()
     if 'fill' in which:
