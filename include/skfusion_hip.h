@@ -184,9 +184,13 @@ int skf_iterate(skf_plan* plan, int32_t n_iters, void* stream);
  * them (the restart is a grid dimension), so ten restarts of the dicty graph cost little more than one.  The plans must
  * have been created from the same object types, ranks, relation shapes and engine and must run the schedule for small
  * graphs (SKF_DFMF, every rank <= 64, sparse constraints, at most 8192 objects per type); each keeps its own workspace,
- * factors and results, exactly as after skf_iterate.  SKF_E_STATE when the plans do not batch: iterate them one by one. */
+ * factors and results, exactly as after skf_iterate.  SKF_E_STATE when the plans do not batch: iterate them one by one.
+ * SKF_TRANSFORM plans batch as well: the fold-ins of ONE set of new relations into the models of several restarts (the
+ * reference's n_run fold-ins over joblib workers, dfmf.py:191-199) -- same object types, ranks and relations, each plan with
+ * the frozen factors / backbones of its restart, no constraint on the target type; one launch per iteration serves all. */
 int skf_iterate_batch(skf_plan* const* plans, int32_t n_plans, int32_t n_iters, void* stream);
-/* *yes = 1 when the (bound) plan runs the schedule for small graphs, i.e. can be one of the plans of skf_iterate_batch. */
+/* *yes = 1 when the (bound) plan can be one of the plans of skf_iterate_batch: the schedule for small graphs, or a fold-in
+ * without constraints on the target type. */
 int skf_plan_batchable(const skf_plan* plan, int32_t* yes);
 /* enable != 0: iterations 2..n of skf_iterate replay ONE captured hipGraph (a single host call per
  * iteration instead of one per kernel).  Off by default -- a single fit is bound by kernel time --

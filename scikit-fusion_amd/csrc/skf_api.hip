@@ -478,6 +478,7 @@ struct TypeState {
     Slot Bp32, Bn32;               // f32 engines: roundings of Bp_tot / Bn_tot for the fused side update
     Slot Bp_tot, Bn_tot;           // sum over the relations of the B / D matrices' + and - parts (c x c f64)
     Slot Ec, Dc;                   // SKF_TRANSFORM target only
+    Slot Galt;                     // SKF_TRANSFORM target: the second factor buffer of the one-launch iteration (foldin_step_kernel)
     int64_t t0 = 0, tn = 0;        // rows whose type-level terms G (sum B) this plan adds (row-block sharding)
     // SKF_OPT_OWNED_ROWS: [t0, t0 + tn) are the rows this plan OWNS; `chunk` rows per rank in the padded layout of the
     // exchanges (G, E, D, the bf16 rows and every Q over this type hold part_count * chunk rows)
@@ -2607,7 +2608,57 @@ static void prepare_transform(skf_plan* p, hipStream_t st) {
     p->prepared = true;
 }
 
+// The fold-in iteration as ONE launch (foldin_step_kernel): no constraint on the target type (a constraint couples the
+// rows of an iteration through E / D, which this form never writes)
+static bool fold_fused(const skf_plan* p) {
+    return p->variant == SKF_TRANSFORM && p->engine == SKF_ENGINE_MFMA && p->thetas.empty();
+}
+
+// `iters` fold-in iterations of `n_plans` plans of one graph (same object count and rank of the target), every launch
+// serving all of them; each plan's factor ends in its G slot (the two buffers swap roles per launch)
+static void fold_steps(skf_plan* const* plans, int n_plans, int iters, hipStream_t st) {
+    skf_plan* p0 = plans[0];
+    const TypeState& t0 = p0->types[p0->target];
+    for (int b0 = 0; b0 < n_plans; b0 += FOLD_MAXB) {
+        const int nb = n_plans - b0 < FOLD_MAXB ? n_plans - b0 : FOLD_MAXB;
+        for (int it = 0; it < iters; ++it) {
+            FoldArgs a;
+            memset(&a, 0, sizeof a);
+            a.n = (int)t0.n; a.c = t0.c;
+            for (int k = 0; k < nb; ++k) {
+                TypeState& t = plans[b0 + k]->types[plans[b0 + k]->target];
+                a.G[k] = t.G.ptr; a.Gout[k] = t.Galt.ptr;
+                a.Bn[k] = t.Bn_tot.ptr; a.Bp[k] = t.Bp_tot.ptr;
+                a.Ec[k] = t.Ec.ptr; a.Dc[k] = t.Dc.ptr;
+            }
+            if (p0->f64) {
+                if (t0.n > 64 && t0.c > 64) {
+                    dim3 grid(cdiv(t0.c, 64), cdiv(t0.n, 64), nb);
+                    hipLaunchKernelGGL((foldin_step_kernel<double, 2, 2, 16>), grid, dim3(GEMM_THREADS), 0, st, a);
+                } else {
+                    dim3 grid(cdiv(t0.c, 32), cdiv(t0.n, 32), nb);
+                    hipLaunchKernelGGL((foldin_step_kernel<double, 1, 1, 16>), grid, dim3(GEMM_THREADS), 0, st, a);
+                }
+            } else {
+                dim3 grid(cdiv(t0.c, 64), cdiv(t0.n, 64), nb);
+                hipLaunchKernelGGL((foldin_step_kernel<float, 1, 1, 16>), grid, dim3(GEMM_THREADS), 0, st, a);
+            }
+            check_launch("foldin_step");
+            for (int k = 0; k < nb; ++k) {
+                TypeState& t = plans[b0 + k]->types[plans[b0 + k]->target];
+                std::swap(t.G.ptr, t.Galt.ptr);
+                std::swap(t.G.off, t.Galt.off);
+            }
+        }
+    }
+}
+
 static void iterate_transform(skf_plan* p, hipStream_t st) {
+    if (fold_fused(p)) {
+        skf_plan* one[1] = {p};
+        fold_steps(one, 1, 1, st);
+        return;
+    }
     TypeState& tt = p->types[p->target];
     const int n = (int)tt.n, c = tt.c;
     SKF_HIP(hipMemcpyAsync(tt.E.ptr, tt.Ec.ptr, tt.E.bytes, hipMemcpyDeviceToDevice, st));
@@ -2960,6 +3011,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             } else if (i == p->target) {
                 add_slot(p, t.Ec, (size_t)t.n * t.c * es);
                 add_slot(p, t.Dc, (size_t)t.n * t.c * es);
+                add_slot(p, t.Galt, (size_t)t.n * t.c * es);
                 add_slot(p, t.Bp_tot, (size_t)t.c * t.c * 8);
                 add_slot(p, t.Bn_tot, (size_t)t.c * t.c * 8);
             }
@@ -3663,16 +3715,57 @@ int skf_iterate_batch(skf_plan* const* plans, int32_t n_plans, int32_t n_iters, 
         if (!plans || n_plans < 1 || n_plans > SKF_MAX_BATCH) SKF_FAIL(SKF_E_INVALID, "1 .. %d plans", SKF_MAX_BATCH);
         if (n_iters < 0) SKF_FAIL(SKF_E_INVALID, "n_iters < 0");
         skf_plan* p0 = plans[0];
+        if (p0 && p0->variant == SKF_TRANSFORM) {
+            // fold-ins of one graph into the models of several restarts (reference dfmf.py:191-199): same new relations, the
+            // frozen factors / backbones of each restart in its own plan; one launch per iteration serves all of them
+            for (int k = 0; k < n_plans; ++k) {
+                skf_plan* p = plans[k];
+                check_bound(p);
+                if (!fold_fused(p) || p->dtype != p0->dtype || p->types.size() != p0->types.size() || p->rels.size() != p0->rels.size() ||
+                    p->target != p0->target)
+                    SKF_FAIL(SKF_E_STATE, "plan %d does not batch with plan 0 (fold-in without constraints on the target, same graph and engine required)", k);
+                for (size_t i = 0; i < p->types.size(); ++i) {
+                    if (p->types[i].n != p0->types[i].n || p->types[i].c != p0->types[i].c)
+                        SKF_FAIL(SKF_E_STATE, "plan %d: object type %zu differs from plan 0", k, i);
+                    if (!p->types[i].set) SKF_FAIL(SKF_E_STATE, "plan %d: factor of object type %zu not set", k, i);
+                }
+                for (size_t r = 0; r < p->rels.size(); ++r) {
+                    if (p->rels[r].row != p0->rels[r].row || p->rels[r].col != p0->rels[r].col)
+                        SKF_FAIL(SKF_E_STATE, "plan %d: relation %zu differs from plan 0", k, r);
+                    if (!p->rels[r].s_set) SKF_FAIL(SKF_E_STATE, "plan %d: backbone of relation %zu not set", k, r);
+                }
+                for (int q = 0; q < k; ++q)
+                    if (plans[q] == p) SKF_FAIL(SKF_E_INVALID, "plan %d listed twice", k);
+            }
+            hipStream_t st = as_stream(stream);
+            for (int k = 0; k < n_plans; ++k)
+                if (!plans[k]->prepared) prepare_transform(plans[k], st);
+            fold_steps(plans, n_plans, n_iters, st);
+            return;
+        }
         for (int k = 0; k < n_plans; ++k) {
             skf_plan* p = plans[k];
             check_bound(p);
             for (size_t i = 0; i < p->types.size(); ++i)
                 if (!p->types[i].set) SKF_FAIL(SKF_E_STATE, "plan %d: factor of object type %zu not set", k, i);
-            // one launch serves every plan: same graph (identical job tables), same engine, the small-graph schedule
-            if (!p->small_fused || p->f64 != p0->f64 || p->sm_j1.size() != p0->sm_j1.size() || p->sm_j3.size() != p0->sm_j3.size() ||
-                p->rels.size() != p0->rels.size() ||
-                memcmp(p->sm_j1.data(), p0->sm_j1.data(), p0->sm_j1.size() * sizeof(SmJob)) != 0 ||
-                memcmp(p->sm_j3.data(), p0->sm_j3.data(), p0->sm_j3.size() * sizeof(SmJob)) != 0)
+            // one launch serves every plan (plan 0's grid, LDS and job tables): the small-graph schedule, the same engine and
+            // the same graph -- object counts, ranks, relation and constraint structure compared field by field
+            bool same = p->small_fused && p->f64 == p0->f64 && p->variant == p0->variant && p->engine == p0->engine &&
+                        p->types.size() == p0->types.size() && p->rels.size() == p0->rels.size() &&
+                        p->thetas.size() == p0->thetas.size() && p->sm_j1.size() == p0->sm_j1.size() &&
+                        p->sm_j3.size() == p0->sm_j3.size();
+            for (size_t i = 0; same && i < p->types.size(); ++i)
+                same = p->types[i].n == p0->types[i].n && p->types[i].c == p0->types[i].c;
+            for (size_t r = 0; same && r < p->rels.size(); ++r)
+                same = p->rels[r].row == p0->rels[r].row && p->rels[r].col == p0->rels[r].col;
+            for (size_t t = 0; same && t < p->thetas.size(); ++t)
+                same = p->thetas[t].type == p0->thetas[t].type && p->thetas[t].sparse == p0->thetas[t].sparse;
+            auto same_job = [](const SmJob& a, const SmJob& b) {
+                return a.kind == b.kind && a.idx == b.idx && a.r0 == b.r0 && a.nr == b.nr && a.part == b.part && a.k0 == b.k0 && a.nk == b.nk;
+            };
+            for (size_t j = 0; same && j < p->sm_j1.size(); ++j) same = same_job(p->sm_j1[j], p0->sm_j1[j]);
+            for (size_t j = 0; same && j < p->sm_j3.size(); ++j) same = same_job(p->sm_j3[j], p0->sm_j3[j]);
+            if (!same)
                 SKF_FAIL(SKF_E_STATE, "plan %d does not batch with plan 0 (small-graph schedule, same graph and engine required)", k);
             for (int q = 0; q < k; ++q)
                 if (plans[q] == p) SKF_FAIL(SKF_E_INVALID, "plan %d listed twice", k);
@@ -3696,7 +3789,7 @@ int skf_plan_batchable(const skf_plan* p, int32_t* yes) {
     return guarded([&] {
         check_bound(p);
         if (!yes) SKF_FAIL(SKF_E_INVALID, "null pointer");
-        *yes = p->small_fused ? 1 : 0;
+        *yes = (p->small_fused || fold_fused(p)) ? 1 : 0;
     });
 }
 

@@ -573,6 +573,115 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
 }
 
 // ------------------------------------------------------------------------------------------
+// One fold-in iteration (reference _dfmf.py:385-428, the target type without constraints) in ONE launch, for up to
+// FOLD_MAXB plans of one graph at once (blockIdx.z = the plan: the restarts the reference hands to joblib workers,
+// dfmf.py:191-199).  Everything that does not depend on the folded-in factor was summed once (Ec, Dc, Bn = sum B-,
+// Bp = sum B+: prepare_transform), so an iteration is
+//     E = Ec + G * Bn ;  D = Dc + G * Bp ;  Gout = G * sqrt(E / max(D, eps))
+// -- two contractions that share their A tile, the update in the epilogue, E and D never written.  G and Gout are two
+// buffers (another column tile of the same rows still reads the old rows); the host swaps them after every launch.
+// G, Ec, Dc, Gout are T (the master type), Bn / Bp are f64 c x c matrices rounded to T while staged.
+// ------------------------------------------------------------------------------------------
+#define FOLD_MAXB 16
+struct FoldArgs {
+    const void* G[FOLD_MAXB];
+    void* Gout[FOLD_MAXB];
+    const void* Bn[FOLD_MAXB];
+    const void* Bp[FOLD_MAXB];
+    const void* Ec[FOLD_MAXB];
+    const void* Dc[FOLD_MAXB];
+    int n, c;
+};
+
+template <typename T, int WR, int WC, int BK>
+__global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void foldin_step_kernel(FoldArgs a) {
+    typedef Mfma<T> MF;
+    constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
+    constexpr int LDA = BM + 1, LDB = BN + 1;
+    __shared__ T As[BK][LDA];
+    __shared__ T Bs[BK][LDB];
+    __shared__ T Bs2[BK][LDB];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * (WR * MF::MT), wn0 = (wave & 1) * (WC * MF::NT);
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+    const T* __restrict__ G = (const T*)a.G[z];
+    const double* __restrict__ Bn = (const double*)a.Bn[z];
+    const double* __restrict__ Bp = (const double*)a.Bp[z];
+    const int64_t ld = a.c;
+
+    typename MF::acc_t accE[WR][WC], accD[WR][WC];
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int j = 0; j < WC; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) accE[i][j][r] = accD[i][j][r] = (T)0;
+
+    T ra[BM * BK / GEMM_THREADS];
+    double rb[BN * BK / GEMM_THREADS], rb2[BN * BK / GEMM_THREADS];
+    const int mg = stage_mode<T>(G, ld, 1, a.n, 0, a.c);
+    const int mbn = stage_mode<double>(Bn, 1, ld, a.c, 0, a.c);
+    const int mbp = stage_mode<double>(Bp, 1, ld, a.c, 0, a.c);
+    stage_load<T, BM, BK>(ra, G, ld, 1, bm0, 0, a.n, a.c, tid, mg);
+    stage_load<double, BN, BK>(rb, Bn, 1, ld, bn0, 0, a.c, a.c, tid, mbn);
+    stage_load<double, BN, BK>(rb2, Bp, 1, ld, bn0, 0, a.c, a.c, tid, mbp);
+    for (int k0 = 0; k0 < a.c; k0 += BK) {
+        __syncthreads();
+        stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.c, AOP_NONE, tid, mg);
+        stage_store<T, double, BN, BK, LDB>(Bs, rb, ld == 1, k0, a.c, AOP_NONE, tid, mbn);
+        stage_store<T, double, BN, BK, LDB>(Bs2, rb2, ld == 1, k0, a.c, AOP_NONE, tid, mbp);
+        __syncthreads();
+        if (k0 + BK < a.c) {
+            stage_load<T, BM, BK>(ra, G, ld, 1, bm0, k0 + BK, a.n, a.c, tid, mg);
+            stage_load<double, BN, BK>(rb, Bn, 1, ld, bn0, k0 + BK, a.c, a.c, tid, mbn);
+            stage_load<double, BN, BK>(rb2, Bp, 1, ld, bn0, k0 + BK, a.c, a.c, tid, mbp);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += MF::KT) {
+            T av[WR], bv[WC], bv2[WC];
+            const int kr = kk + MF::ab_k(lane);
+#pragma unroll
+            for (int i = 0; i < WR; ++i) av[i] = As[kr][wm0 + i * MF::MT + MF::a_row(lane)];
+#pragma unroll
+            for (int j = 0; j < WC; ++j) {
+                bv[j] = Bs[kr][wn0 + j * MF::NT + MF::a_row(lane)];
+                bv2[j] = Bs2[kr][wn0 + j * MF::NT + MF::a_row(lane)];
+            }
+#pragma unroll
+            for (int i = 0; i < WR; ++i)
+#pragma unroll
+                for (int j = 0; j < WC; ++j) {
+                    accE[i][j] = MF::mma(av[i], bv[j], accE[i][j]);
+                    accD[i][j] = MF::mma(av[i], bv2[j], accD[i][j]);
+                }
+        }
+    }
+    // ---- epilogue: the multiplicative update (_dfmf.py:427-428)
+    const T eps = (T)2.220446049250313e-16;
+    const T* __restrict__ Ec = (const T*)a.Ec[z];
+    const T* __restrict__ Dc = (const T*)a.Dc[z];
+    T* __restrict__ Gout = (T*)a.Gout[z];
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int j = 0; j < WC; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) {
+                const int m = bm0 + wm0 + i * MF::MT + MF::d_row(lane, r);
+                const int n = bn0 + wn0 + j * MF::NT + MF::d_col(lane);
+                if (m < a.n && n < a.c) {
+                    const int64_t idx = (int64_t)m * ld + n;
+                    const T e = Ec[idx] + accE[i][j][r];
+                    const T d = Dc[idx] + accD[i][j][r];
+                    const T den = (d > eps || d != d) ? d : eps;         // np.maximum(D, eps) (NaN propagates)
+                    Gout[idx] = G[idx] * (T)sqrt(e / den);
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------
 // vector-ALU GEMM with the same contract (64 x 64 block tile, 4 x 4 outputs per thread).
 // ------------------------------------------------------------------------------------------
 template <typename T, typename TA, typename TB>

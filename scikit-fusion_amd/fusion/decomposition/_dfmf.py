@@ -363,6 +363,64 @@ def dfmf(R, Theta, obj_types, obj_type2rank, max_iter=10, init_type="random_vcol
                    dtype, G0, engine)
 
 
+def _transform_graph(R_ij, target_obj_type, G):
+    """(types, n_obj, n_t) of a fold-in: the target + every partner type of the new relations (reference _dfmf.py:342-350)."""
+    t = target_obj_type
+    sizes = [R_ij[i, j][0].shape[0 if t == i else 1] for i, j in R_ij]
+    if len(set(sizes)) > 1:
+        from ..base import DataFusionError
+        raise DataFusionError("Target object type: %s size mismatch" % t)
+    types = [t]
+    for (i, j) in R_ij:
+        for o in (i, j):
+            if o not in types:
+                types.append(o)
+    n_obj = {t: sizes[0]}
+    for o in types[1:]:
+        n_obj[o] = G[o, o].shape[0]
+    return types, n_obj, sizes[0]
+
+
+def transform_runs(R_ij, Theta_i, target_obj_type, obj_type2rank, models, max_iter=10, init_type="random_c",
+                   random_state=None, dtype='f64', G0=None, engine=None):
+    """The fold-ins of ONE set of new relations into the models of several restarts -- `models` = [(G, S)] per restart, as
+    `transform` takes them -- in shared launches: the reference runs `transform` once per restart on joblib workers
+    (dfmf.py:191-199).  The new relations and constraints go to the device ONCE, every restart gets a plan with its frozen
+    factors / backbones, and one launch per iteration serves all of them (skf_iterate_batch; plans that do not batch --
+    a constraint on the target type -- are iterated one after the other, still on the shared uploads).  G0 of restart k is
+    drawn k-th from `random_state` (the order in which the per-restart calls would draw).  Returns [G_target] per restart."""
+    from ..._engine import upload_graph
+    t = target_obj_type
+    types, n_obj, n_t = _transform_graph(R_ij, t, models[0][0])
+    rs = _as_rs(random_state)
+    if G0 is None:
+        R_first = {k: np.asarray(v[0], dtype=float) for k, v in R_ij.items()}
+        G0 = [initialize([t], {t: n_t}, obj_type2rank, R_first, init_type, rs)[t, t] for _ in models]
+    rt = nat.get_runtime()
+    rel_list, theta_list = upload_graph(flatten_relations(R_ij), flatten_thetas(Theta_i), dtype, rt)
+    plans = []
+    try:
+        for (G, S), g0 in zip(models, G0):
+            plan = DevicePlan(types, n_obj, obj_type2rank, rel_list, theta_list, nat.SKF_TRANSFORM, dtype=dtype, target=t,
+                              engine=engine)
+            plans.append(plan)
+            plan.set_factors(dict([(t, g0)] + [(o, G[o, o]) for o in types[1:]]), sync=False)
+            seen = {}
+            for k, (i, j, _, _) in enumerate(rel_list):
+                l = seen.get((i, j), 0)
+                seen[i, j] = l + 1
+                plan.set_backbone(k, S[i, j][l])
+        rt.mem.synchronize()
+        if not (len(plans) > 1 and plans[0].batchable() and DevicePlan.iterate_batch(plans, max_iter)):
+            for plan in plans:
+                plan.iterate(max_iter)
+        rt.mem.synchronize()
+        return [plan.get_factor(t) for plan in plans]
+    finally:
+        for plan in plans:
+            plan.close()
+
+
 def transform(R_ij, Theta_i, target_obj_type, obj_type2rank, G, S, max_iter=10,
               init_type="random_c", stopping=None, stopping_system=None, verbose=0,
               compute_err=False, callback=None, random_state=None, dtype='f64', G0=None,

@@ -206,6 +206,19 @@ class DfmfTransform(FusionTransform):
                 dest.setdefault((relation.row_type, relation.col_type), []).append(data)
 
         self.factors_ = defaultdict(list)
+        if self.n_run > 1 and not (self.callback or self.stopping or self.stopping_system or self.compute_err):
+            # the fold-ins into the models of all restarts share the uploads of the new relations and every launch
+            # (reference: one joblib task per restart, dfmf.py:191-199)
+            models = []
+            for run in range(self.n_run):
+                G = {(ot, ot): fuser.factor(ot, run) for ot in fuser.fusion_graph.object_types}
+                S = {(rel.row_type, rel.col_type): [fuser.backbone(rel, run)]
+                     for rel in fuser.fusion_graph.relations if rel.row_type != rel.col_type}
+                models.append((G, S))
+            self.factors_[target] = _dfmf.transform_runs(R, Theta, target, rank, models, max_iter=self.max_iter,
+                                                         init_type=init_type, random_state=self.random_state,
+                                                         dtype=self.dtype)
+            return self
         for run in range(self.n_run):
             # frozen model of this run (dfmf.py:109-115); only the LAST relation of a type pair
             # survives in S there -- kept: one backbone per pair

@@ -433,3 +433,38 @@ def early_stopping_matches_the_reference_rule(dtypes=('f64',), shards=('runs',))
         assert 2 < stop_at < 16 and len(seen) == stop_at, (dtype, stop_at, len(seen))
         assert relerr(tr.factor(ot['t1']), want) < (1e-9 if dtype == 'f64' else 1e-4)
     return checked
+
+
+def fold_in_of_several_runs_shares_launches(dtype='f64', n_new=15, tol=1e-9):
+    """DfmfTransform(n_run=3): the fold-ins into the models of the three restarts (reference dfmf.py:191-199: one joblib
+    task each) run as plans of ONE set of uploaded relations with every launch shared (skf_iterate_batch) -- the same
+    factors, bit for bit, as one fold-in after the other (a callback forces that path), and the oracle's to `tol`."""
+    from oracle import dfmf_oracle as orc
+    from helpers import relerr
+    from skfusion_amd.fusion.decomposition._init import initialize
+    rs = np.random.RandomState(21)
+    t1, t2, t3 = ObjectType('type1', 7), ObjectType('type2', 5), ObjectType('type3', 6)
+    rels = [Relation(rs.rand(40, 30), t1, t2), Relation(rs.rand(40, 25) - 0.2, t1, t3), Relation(rs.rand(30, 25), t2, t3),
+            Relation(rs.rand(30, 40), t2, t1)]
+    fuser = Dfmf(max_iter=6, init_type='random', random_state=3, n_run=3).fuse(FusionGraph(rels))
+    new = lambda: FusionGraph([Relation(np.random.RandomState(5).rand(n_new, 30), t1, t2),          # noqa: E731
+                               Relation(np.random.RandomState(6).rand(n_new, 25), t1, t3),
+                               Relation(np.random.RandomState(7).rand(30, n_new), t2, t1)])
+    shared = DfmfTransform(max_iter=12, init_type='random', random_state=9, n_run=3, dtype=dtype).transform(t1, new(), fuser)
+    one_by_one = DfmfTransform(max_iter=12, init_type='random', random_state=9, n_run=3, dtype=dtype,
+                               callback=lambda g, it: None).transform(t1, new(), fuser)
+    got = list(shared.factor(t1))
+    assert len(got) == 3 and got[0].shape == (n_new, 7)
+    for a, b in zip(got, one_by_one.factor(t1)):
+        np.testing.assert_array_equal(a, b)
+    assert not np.allclose(got[0], got[1])
+    g = new()
+    Rn = {(r.row_type, r.col_type): [r.data] for r in g.relations}
+    rank = {t: int(t.rank) for t in (t1, t2, t3)}
+    draw = np.random.RandomState(9)
+    for run in range(3):
+        G = {(t, t): fuser.factor(t, run) for t in (t1, t2, t3)}
+        S = {(r.row_type, r.col_type): [fuser.backbone(r, run)] for r in rels}
+        G0 = initialize([t1], {t1: n_new}, rank, {}, 'random', draw)[t1, t1]
+        want = orc.transform(Rn, {}, t1, rank, G, S, max_iter=12, G0=G0)
+        assert relerr(got[run], want) < tol, (dtype, run)

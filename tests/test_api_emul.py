@@ -78,3 +78,7 @@ def test_early_stopping_inside_sharded_fits_of_a_one_rank_group(monkeypatch):
         assert A.early_stopping_matches_the_reference_rule(('f64',), ('rows', 'owned')) == 12
     finally:
         dist.destroy_process_group()
+
+
+def test_fold_in_of_several_runs_shares_launches():
+    A.fold_in_of_several_runs_shares_launches('f64')

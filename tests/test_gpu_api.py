@@ -68,6 +68,11 @@ def test_early_stopping_through_the_classes_single_device_and_sharded(monkeypatc
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-9), ('f32', 1e-5), ('bf16', 1e-2)])
+def test_fold_in_of_several_runs_shares_launches(dtype, tol):
+    A.fold_in_of_several_runs_shares_launches(dtype, tol=tol)
+
+
 def test_f32_engine_reaches_the_same_fixed_point():
     import numpy as np
     from skfusion_amd.fusion import Relation, ObjectType, FusionGraph

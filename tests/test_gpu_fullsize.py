@@ -296,3 +296,35 @@ def test_bench_parity_record_at_a_tenth_of_the_size(tmp_path):
         within(rec['err_relerr'], e_b, 'bench parity at 1/10 scale, %s: relation errors after 2 iterations vs the oracle' % dtype)
         within(rec['G_rows_relerr'], g_b, 'bench parity at 1/10 scale, %s: 64 rows of every factor vs the oracle' % dtype)
         within(rec['S_relerr'], s_b, 'bench parity at 1/10 scale, %s: backbones vs the oracle' % dtype)
+
+
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-9), ('f32', 1e-4), ('bf16', 2e-2)])
+def test_fold_in_of_8192_objects_into_three_models(dtype, tol):
+    """SURVEY.md 8 f2 at scale: 8192 new objects of t1 with their relations to the 100k objects of t2 and the 40k of t3 folded
+    into the frozen models of THREE restarts (reference dfmf.py:191-199, _dfmf.py:385-428) in shared launches
+    (`transform_runs`: relations uploaded once, skf_iterate_batch).  Without constraints a fold-in is separable by rows, so
+    the oracle runs on 64 sampled rows that the host regenerates from the counter-based generator and must give those rows
+    of the device result: f64 1e-9, f32 / bf16 at their engine tolerances."""
+    _need_big_gpu()
+    from skfusion_amd.fusion.decomposition import _dfmf
+    n = {'t1': 8192, 't2': N['t2'], 't3': N['t3']}
+    iters = 10
+    R = {('t1', 't2'): [fill_uniform((n['t1'], n['t2']), 0, dtype)], ('t1', 't3'): [fill_uniform((n['t1'], n['t3']), 1, dtype)]}
+    models, G0 = [], []
+    for run in range(3):
+        G = {(t, t): orc.hash_uniform_matrix(500 + 10 * run + k, n[t], RANK[t]) for k, t in enumerate(TYPES) if t != 't1'}
+        S = {('t1', 't2'): [1e-3 * orc.hash_uniform_matrix(600 + run, RANK['t1'], RANK['t2'])],
+             ('t1', 't3'): [1e-3 * orc.hash_uniform_matrix(610 + run, RANK['t1'], RANK['t3'])]}
+        models.append((G, S))
+        G0.append(orc.hash_uniform_matrix(700 + run, n['t1'], RANK['t1']))
+    got = _dfmf.transform_runs(R, {}, 't1', RANK, models, max_iter=iters, dtype=dtype, G0=G0)
+    rows = np.unique(np.linspace(0, n['t1'] - 1, 64).astype(np.int64))
+    Rrows = {}
+    for (i, j), seed in ((('t1', 't2'), 0), (('t1', 't3'), 1)):
+        idx = rows[:, None] * n[j] + np.arange(n[j])[None, :]
+        Rrows[i, j] = [_round(orc.hash_uniform_at(seed, idx), dtype)]
+    assert len(got) == 3
+    for run, ((G, S), g0) in enumerate(zip(models, G0)):
+        want = orc.transform(Rrows, {}, 't1', RANK, G, S, max_iter=iters, G0=g0[rows])
+        within(relerr(got[run][rows], want), tol, 'fold-in of 8192 objects, %s engine, model of restart %d: 64 sampled rows vs the oracle' % (dtype, run))
+    assert not np.allclose(got[0][rows], got[1][rows])
