@@ -148,6 +148,9 @@ def c3_relation(k, n, dtype, data='uniform', cache=None):
     cache = cache if cache is not None else {}
 
     def hashed(shape, sd):
+        # (the engine fills on ITS stream: torch's pending work first -- the caching allocator may hand out a block that a
+        # queued torch kernel still reads -- and the fill before torch touches the result)
+        torch.cuda.synchronize()
         dm = fill_uniform(shape, sd, 'f32')
         torch.cuda.synchronize()
         return dm.buf.owner[:shape[0] * shape[1] * 4].view(torch.float32).view(shape)
@@ -201,6 +204,56 @@ def measured_traffic(dtype, c5, scale):
         return {'bytes': float(e['fetch_bytes_per_launch']) + float(e['write_bytes_per_launch']), 'source': e['source']} if e else None
     except (OSError, ValueError, KeyError):
         return None
+
+
+def pmc_traffic_in_run(dtype, workload='c3', steps=2, timeout=420):
+    """HBM bytes per contraction launch measured IN THIS RUN: two children of this very script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes;
+    counters only, no API / memory-copy tracing), `steps` + 1 iterations each; FETCH_SIZE is in KiB and counts 64 B per 128-B
+    request of a wide streaming read on gfx950 (x2), WRITE_SIZE is taken as reported.  Returns {'bytes', 'source', ...} like
+    measured_traffic, or None (no rocprofv3 on PATH, SKF_BENCH_PMC=0, a child failed or timed out): the committed pass then
+    stands in, labelled as such."""
+    import glob
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if dtype != 'bf16' or os.environ.get('SKF_BENCH_PMC', '1') == '0' or not shutil.which('rocprofv3'):
+        return None
+    sums, calls = {}, {}
+    t0 = time.perf_counter()
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        out = tempfile.mkdtemp(prefix='skf_pmc_')
+        cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '-d', out, '-o', 'pmc', '--', sys.executable,
+               os.path.abspath(__file__), '--steps', str(steps), '--warmup', '1', '--workload', workload, '--dtype', dtype,
+               '--no-cpu-baseline', '--no-engines', '--no-workloads', '--no-pmc']
+        try:
+            subprocess.run(cmd, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()),
+                           capture_output=True, text=True, timeout=timeout, check=True)
+            tot = n = 0.0
+            for db in glob.glob(os.path.join(out, '**', '*.db'), recursive=True):
+                cur = sqlite3.connect(db).cursor()
+                for name, cnt, val in cur.execute("select kernel_name, count(*), sum(value) from counters_collection "
+                                                  "where counter_name = ? group by kernel_name", (counter,)):
+                    short = re.sub(r'\(.*$', '', name).replace('skf::', '').replace('void ', '')
+                    m = re.match(r'gemm_bf16_v2_kernel<\s*\d+\s*,\s*(\d+)\s*,', short)
+                    if m and m.group(1) == '1':                 # TAG = 1: the launches that walk a relation (P, Q)
+                        tot += float(val)
+                        n += cnt
+            if n <= 0:
+                return None
+            sums[counter], calls[counter] = tot * 1024.0 * (2.0 if counter == 'FETCH_SIZE' else 1.0), n
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    fetch, write = sums['FETCH_SIZE'] / calls['FETCH_SIZE'], sums['WRITE_SIZE'] / calls['WRITE_SIZE']
+    return {'bytes': fetch + write, 'fetch_bytes_per_launch': fetch, 'write_bytes_per_launch': write,
+            'launches_counted': int(calls['FETCH_SIZE']), 'seconds': time.perf_counter() - t0, 'in_run': True,
+            'source': 'this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes of bench.py, %d + 1 '
+                      'iterations each), FETCH_SIZE x2 gfx950 correction, mean over the %d relation-contraction launches'
+                      % (steps, int(calls['FETCH_SIZE']))}
 
 
 def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, elapsed, pmc=None, k_bytes=None,
@@ -265,7 +318,7 @@ def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, ela
     rec['traffic_scheduled'] = sched_iter / per_iter        # relation once per contraction + G^T once per XCD + output
     if pmc:
         rec['traffic'] = pmc['bytes']
-        rec['traffic_kind'] = 'PMC, committed pass: ' + pmc['source']
+        rec['traffic_kind'] = ('PMC, ' if pmc.get('in_run') else 'PMC, committed pass: ') + pmc['source']
     else:
         rec['traffic'] = None
         rec['traffic_kind'] = 'no counter pass committed for this workload / size (see traffic_scheduled)'
@@ -454,6 +507,69 @@ def cpu_baseline_c5(scale=0.25, target=1.0):
                       'ratio %.4f' % (scale, n['user'], n['movie'], per_iter, ratio)}
 
 
+def _c5_full_child(scale=1.0):
+    """`python bench.py --cpu-c5-child [--scale x]`: the oracle's dfmc (reference operation order, boolean-mask completion)
+    on the MovieLens-style graph at `scale` (1.0 = FULL size: 100k users x 40k movies), data of the same distributions as the
+    device workload drawn by 64 host threads; two iterations timed through the callback, the second one reported.  A child
+    process, so that the parent can bound it in time and memory (R, its copy and the 32 GB reconstruction: ~150 GB)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import dfmf_oracle as orc
+    n = sizes(scale, C5_FULL)
+
+    def uniform(seed, rows, cols):
+        out = np.empty((rows, cols))
+        chunk = max(1, (1 << 23) // max(cols, 1))
+
+        def fill(a):
+            b = min(a + chunk, rows)
+            out[a:b] = np.random.default_rng([seed, a]).random((b - a, cols))
+        with ThreadPoolExecutor(64) as ex:
+            list(ex.map(fill, range(0, rows, chunk)))
+        return out
+    t_fill = time.perf_counter()
+    R, M = {}, {}
+    for i, j, seed, dens in C5_PAIRS:
+        u = uniform(seed, n[i], n[j])
+        if dens is None:
+            np.multiply(u, 10.0, out=u)
+            np.floor(u, out=u)
+            u += 1.0
+            u /= 10.0
+            R[i, j] = [u]
+            M[i, j] = [uniform(seed + 100, n[i], n[j]) < 0.98]
+        else:
+            R[i, j] = [(u < dens).astype(np.float64)]
+            M[i, j] = [None]
+    nm = n['movie']
+    sim = uniform(60, nm, nm) < 1.0 / nm
+    sim = -0.001 * (sim | sim.T)
+    np.fill_diagonal(sim, 0.0)
+    Theta = {('movie', 'movie'): [0.01 * np.eye(nm), sim]}
+    G0 = {(t, t): orc.hash_uniform_matrix(100 + k, n[t], C5_RANKS[t]) for k, t in enumerate(C5_TYPES)}
+    t_fill = time.perf_counter() - t_fill
+    stamps = [time.perf_counter()]
+    orc.dfmc(R, M, Theta, C5_TYPES, C5_RANKS, max_iter=2, G0=G0, callback=lambda g, s_, it: stamps.append(time.perf_counter()))
+    print(json.dumps({'times': [b - a for a, b in zip(stamps, stamps[1:])], 'fill_seconds': t_fill,
+                      'users': n['user'], 'movies': n['movie']}))
+
+
+def cpu_baseline_c5_full(scale=1.0, timeout=900):
+    """The config-5 oracle at FULL size in a bounded child (`--workload c5 --cpu-baseline full`; not part of the default
+    run: it is minutes of CPU work): {'value', 'projection': False, ...} or None."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-c5-child', '--scale', str(scale)],
+                             capture_output=True, text=True, timeout=timeout)
+        r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    except Exception:
+        return None
+    return {'value': 1.0 / r['times'][-1], 'unit': 'iters/s', 'cores': blas_threads(), 'cores_physical': physical_cores(),
+            'kind': 'port', 'projection': False,
+            'sample': 'oracle dfmc (NumPy fp64, reference op order, boolean-mask completion) at FULL size (%d users x %d movies): '
+                      'iterations %s s, the last one reported (%.0f s of data fill)'
+                      % (r['users'], r['movies'], '/'.join('%.1f' % t for t in r['times']), r['fill_seconds'])}
+
+
 def bench_dicty(iters=100):
     """BASELINE configs[1]: the dicty graph (ann 1219 x 116, expr 1219 x 282, Theta = ppi; ranks 50/15/5), Dfmf from the
     golden G0 -- f32 and f64 engines and the NumPy oracle on the same host."""
@@ -492,7 +608,7 @@ def bench_dicty(iters=100):
 
 
 def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode='restarts', rank=0, world=1, dist=None,
-                 backend='nccl', emulate=None, parity=False):
+                 backend='nccl', emulate=None, parity=False, sustained=0):
     """One engine on one workload.  Returns dict(elapsed, k_ms, k_launches, k_flops, k_bytes, rmse, n, spec, ranks, types).
     emulate = (k, W): this process computes what rank k of W would in mode 'owned', exchanges skipped (timing only).
     parity: the first PARITY_ITERS iterations are run apart and their backbones, PARITY_ROWS factor rows and relation errors
@@ -603,10 +719,19 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
     plan.set_profiling(True)
     t0 = time.perf_counter()
     step(steps)
+    enqueued = time.perf_counter() - t0        # host time to issue the launches of `steps` iterations (nothing waited for)
     sync()
     elapsed = time.perf_counter() - t0
     k_ms, k_launches, k_flops, k_bytes = plan.get_profile()
     plan.set_profiling(False)
+    sus = None
+    if sustained and not emulate:              # a second, long timed region on the same plan: the rate the part sustains
+        sync()                                 # (the chip clocks down under real operands: 1.67 GHz vs 2.41 GHz on zeros)
+        s0 = time.perf_counter()
+        step(sustained)
+        sync()
+        s1 = time.perf_counter() - s0
+        sus = {'steps': int(sustained), 'seconds': s1, 'value': sustained / s1, 'unit': 'iters/s', 'ms_per_step': s1 / sustained * 1e3}
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -629,7 +754,7 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
     torch.cuda.empty_cache()
     return {'elapsed': elapsed, 'k_ms': k_ms, 'k_launches': k_launches, 'k_flops': k_flops, 'k_bytes': k_bytes,
             'rmse': rmse, 'n': n, 'spec': spec, 'ranks': ranks_, 'types': types, 'sharded': sharded,
-            'exchange_bytes': exchange, 'parity': kept,
+            'exchange_bytes': exchange, 'parity': kept, 'sustained': sus, 'enqueue_ms_per_step': enqueued / steps * 1e3,
             'quantisation': ({'%s-%s' % (i, j): planted.get('quant_%d' % k) for k, (i, j, _) in enumerate(spec)}
                              if (not c5 and data == 'planted' and dtype == 'bf16') else None)}
 
@@ -652,7 +777,8 @@ def emulated_ranks(args):
         w = run_workload(args.workload, args.dtype, args.steps, args.warmup, args.scale, args.data, emulate=(k, world))
         ms = w['elapsed'] / args.steps * 1e3
         xb = float(w['exchange_bytes'])
-        out['ranks'].append({'rank': k, 'compute_ms_per_step': ms, 'exchange_bytes_per_step': xb,
+        out['ranks'].append({'rank': k, 'compute_ms_per_step': ms, 'host_enqueue_ms_per_step': w['enqueue_ms_per_step'],
+                             'exchange_bytes_per_step': xb,
                              'wire_ms_all_links': xb / (7 * XGMI_LINK_GBS * 1e9) * 1e3,
                              'wire_ms_ring': xb / (XGMI_LINK_GBS * 1e9) * 1e3})
     worst = max(r['compute_ms_per_step'] for r in out['ranks'])
@@ -737,14 +863,22 @@ def main():
                          'the matching rows of its relations -- reduce-scatter of the partial Q, all-gather of the updated '
                          'rows (owned)')
     ap.add_argument('--cpu-full-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-c5-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--parity-out', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'full', 'sample'],
                     help='cpu_baseline leg: oracle iterations at FULL size when the host can hold them (auto), always, or the 1/10-scale sample')
     ap.add_argument('--no-engines', action='store_true', help='skip the short f32 / f64 runs of the default record')
     ap.add_argument('--no-workloads', action='store_true', help='skip the config 5 / dicty / planted legs of the default record')
+    ap.add_argument('--no-pmc', action='store_true', help='do not spawn the rocprofv3 counter passes that fill roofline.traffic '
+                                                          '(the committed pass of profiles/pmc_traffic.json stands in)')
+    ap.add_argument('--sustained-steps', type=int, default=1000,
+                    help='default run: a second timed region of this many steps (>= 10 s), reported as `sustained`; 0 = off')
     args = ap.parse_args()
     if args.cpu_full_child:
         _full_size_child(args.parity_out)
+        return
+    if args.cpu_c5_child:
+        _c5_full_child(args.scale)
         return
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -787,7 +921,7 @@ def main():
     want_parity = default_run and not args.no_cpu_baseline
     parity_kept = {}
     w = run_workload(args.workload, args.dtype, args.steps, args.warmup, args.scale, args.data, args.mode, rank, world,
-                     dist, backend, parity=want_parity)
+                     dist, backend, parity=want_parity, sustained=args.sustained_steps if default_run else 0)
     parity_kept[args.dtype] = w['parity']
     elapsed, rmse, n, spec, ranks_, types = w['elapsed'], w['rmse'], w['n'], w['spec'], w['ranks'], w['types']
     sharded = w['sharded']
@@ -799,8 +933,11 @@ def main():
                'relations': 'one fit, whole relations partitioned over the GPUs',
                'rows': 'one fit, balanced row blocks of the relations over the GPUs',
                'owned': 'one fit, every GPU owns the same share of the rows of every object type'}[args.mode]
+        pmc = None
+        if default_run and not args.no_pmc:
+            pmc = pmc_traffic_in_run(args.dtype)              # counters of THIS run when the box has rocprofv3
         roof = roofline_record(args.dtype, n, ranks_, spec, w['k_ms'], w['k_launches'], w['k_flops'], args.steps, elapsed,
-                               measured_traffic(args.dtype, c5, args.scale), w['k_bytes'], executed=c5)
+                               pmc or measured_traffic(args.dtype, c5, args.scale), w['k_bytes'], executed=c5)
         out = {
             'metric': ('DFMC update iters/sec (+ RMSE), MovieLens-style 6-relation graph with masks and constraints'
                        if c5 else
@@ -827,6 +964,7 @@ def main():
                        'alg_flops_per_iter': alg_flops(n, spec, ranks_),
                        'exchange_bytes_per_rank_and_iter': w['exchange_bytes']},
             'rmse': rmse,
+            'sustained': w['sustained'],
             'roofline': roof,
             'mfma_frac': (roof.get('mfma') or {}).get('frac'),
             'hbm_frac': (roof.get('hbm_scheduled') or roof.get('hbm_algorithmic') or {}).get('frac'),
@@ -850,7 +988,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             if c5:
-                out['cpu_baseline'] = cpu_baseline_c5(0.25 * args.scale, args.scale)
+                full = cpu_baseline_c5_full(args.scale) if args.cpu_baseline == 'full' else None
+                out['cpu_baseline'] = full or cpu_baseline_c5(0.25 * args.scale, args.scale)
             else:
                 import tempfile
                 pfile = os.path.join(tempfile.gettempdir(), 'skf_parity_%d.npz' % os.getpid()) if want_parity else None

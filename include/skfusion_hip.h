@@ -265,8 +265,9 @@ int skf_comm_create(const void* id128, int32_t rank, int32_t world, skf_comm** o
 int skf_comm_create_callback(int32_t rank, int32_t world, skf_collective_fn fn, void* user, skf_comm** out);
 /* A communicator that exchanges nothing: `rank` of `world` on ONE device, for timing the compute of that rank of a
  * sharded fit where the other ranks do not exist (bench.py --emulate-rank k/W).  A sum over the ranks is stood in for by
- * world x this rank's partial sum (so that the factors stay in the range of a real run and the timed launches take the paths
- * they would); gathers leave the other ranks' rows as they were.  The factors it produces are not a fit. */
+ * world x this rank's partial sum and the multiplicative update of the owned rows is not applied (so that the Gram matrices
+ * the timed launches see stay those of well-conditioned factors and the pseudo-inverses take the path they take in a real
+ * run); gathers leave the other ranks' rows as they were.  Every other launch of the iteration runs. */
 int skf_comm_create_null(int32_t rank, int32_t world, skf_comm** out);
 int skf_comm_destroy(skf_comm* comm);
 int skf_plan_set_comm(skf_plan* plan, skf_comm* comm);     /* not owned by the plan; NULL detaches */

@@ -1136,12 +1136,16 @@ static int launch_srp(const SrpArgs<TG, TM>& a, hipStream_t st, bool generic) {
 // One pass over the known entries of relation r: by_col == false walks the row lists (outer = rows, gathers the rows of
 // T = G_j S^T), by_col == true the column lists (outer = columns, gathers the rows of G_i).  Results land in r.A / r.Q
 // (SRP_ERR: partials in p->sqpart, the number of which is returned).
-static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream_t st) {
+static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream_t st, int sq_first = 0) {
     TypeState& ti = p->types[r.row];
     TypeState& tj = p->types[r.col];
     const int ci = ti.c;
     const int64_t n_out = by_col ? tj.n : r.nr;
     const int parts = by_col ? r.kn_pr : r.kn_pc;
+    if (mode == SRP_ERR) {          // one error partial per wave, written from slot `sq_first` of p->sqpart on: room for all of them?
+        const int64_t need = ((n_out + 3) / 4 + (8 / parts) - 1) / (8 / parts) * 8 * 4 + sq_first;
+        if ((size_t)need > p->sq_elems) SKF_FAIL(SKF_E_STATE, "residual partials: %lld > %zu slots", (long long)need, p->sq_elems);
+    }
     void* final_out = by_col ? r.Q.ptr : r.A.ptr;
     void* out = parts > 1 ? (by_col ? r.Qpart.ptr : r.Apart.ptr) : final_out;
     const void* Gi = p->bf16 ? ti.Grow.ptr : ti.G.ptr;        // vectors of the row objects (bf16: kept in step with G^T)
@@ -1155,7 +1159,7 @@ static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream
         a.idx = (const int*)(by_col ? r.KcIdx.ptr : r.KrIdx.ptr);
         a.ldo = ldv; a.ldi = ldv; a.ld_out = ci; a.part_stride = n_out * ci; a.n_out = n_out;
         a.w = ci; a.parts = parts; a.mode = mode;
-        a.sq = (double*)p->sqpart.ptr;
+        a.sq = (double*)p->sqpart.ptr + sq_first;
     };
     if (p->f64) {
         SrpArgs<double, double> a;
@@ -1933,19 +1937,31 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
     auto wait = [&](hipStream_t s, hipEvent_t e) { SKF_HIP(hipStreamWaitEvent(s, e, 0)); };
     auto own = [&](const Slot& s, const TypeState& t) { return rows_of(p, s, t, t.t0); };
 
-    // ---- Gram partials over the owned rows (main), their sum (exchange stream), the pseudo-inverses (second stream)
+    // ---- Gram partials over the owned rows (main stream, at the head: the chain Gram -> sum -> pseudo-inverses (~1.2 ms at
+    // rank 256, one workgroup per type) -> backbones -> side products IS the critical path of a rank, the contractions run
+    // beside it), their sum (exchange stream), the pseudo-inverses (second stream).
+    // (Measured, rank 3 of 8 at config 3: with the partials on the second stream underneath the first contraction their
+    // split-K reduce crawled for 0.26 ms, the pseudo-inverses started 0.33 ms later and the iteration took as long as
+    // before -- 2.55 ms; profiles/r04_owned_rank_timeline.txt.)
     std::vector<int> all;
+    hipStream_t sg = st;
+    const bool gram_aux = false;
+    if (gram_aux) {
+        rec(p->ev_fork, st);                       // (factors set / updated on the caller's stream before this call)
+        wait(ax, p->ev_fork);
+    }
     for (size_t i = 0; i < nt; ++i) {
         TypeState& t = p->types[i];
         all.push_back((int)i);
         if (t.tn <= 0) {
-            SKF_HIP(hipMemsetAsync(t.Gram.ptr, 0, t.Gram.bytes, st));
+            SKF_HIP(hipMemsetAsync(t.Gram.ptr, 0, t.Gram.bytes, sg));
             continue;
         }
         GemmArgs g = gemm_args(own(t.G, t), 1, t.c, own(t.G, t), t.c, 1, t.Gram.ptr, t.c, t.c, t.c, (int)t.tn, EPI_STORE, 1);
-        run_gemm(GemmTypes{SKF_F64, p->mt, p->mt}, p->engine, g, 0, p->part.ptr, p->part_bytes, st);
+        run_gemm(GemmTypes{SKF_F64, p->mt, p->mt}, p->engine, g, 0, gram_aux ? p->part_aux.ptr : p->part.ptr,
+                 gram_aux ? p->part_aux_bytes : p->part_bytes, sg);
     }
-    rec(p->ev_own[0], st);
+    rec(p->ev_own[0], sg);
     wait(cs, p->ev_own[0]);
     collective(c, COLL_ALL_REDUCE, base + p->xg_off, p->xg_bytes / 8, SKF_F64, cs);
     rec(p->ev_own[1], cs);
@@ -1998,7 +2014,12 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
             }
             theta_terms_rows(p, (int)i, true, ax);
             // G[own] <- G[own] * sqrt(E / max(D, eps))   (_dfmf.py:294-296); SKF_BF16: with the bf16 copies of those rows
-            if (p->bf16) {
+            if (c->null_comm) {
+                // rank-emulation runs (skf_comm_create_null): the factors stay as they were set -- with nothing exchanged the
+                // updated rows drift away from the rows of the ranks that do not exist, the Gram matrices go singular and the
+                // timed pseudo-inverses take their slow fallbacks (measured: 4-15 ms per iteration); the update launch
+                // itself (~10 us per type) is what the measurement then leaves out
+            } else if (p->bf16) {
                 hipLaunchKernelGGL(mult_update_transpose_kernel, dim3((unsigned)cdiv(t.c, 32), (unsigned)cdiv(t.tn, 32)), dim3(256), 0,
                                    ax, (float*)G, (const float*)E, (const float*)D, (int64_t)t.tn, (int64_t)t.c,
                                    (uint16_t*)t.GTb.ptr + t.t0, t.ldgt, (uint16_t*)t.Grow.ptr + t.t0 * t.ldrow, t.ldrow);
@@ -2141,14 +2162,31 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
         side_done(r.col);
     };
 
-    // ---- masked relations (DFMC), before their completion: P, W (_dfmc.py:311-314); second stream: backbone, H = G_i[own] S
+    // The launches go out stream by stream, not relation by relation: every contraction of the main stream is enqueued BEFORE
+    // the chains of the second stream, whose first packets wait for the pseudo-inverses (~1.2 ms at rank 256).  Streams
+    // share hardware queues, and a queue hands out its packets in order: issued relation by relation, the third relation's
+    // contractions sat behind the first relation's waiting chain for 0.5 ms (rocprof timeline of rank 3 of 8, config 3).
+    // ---- main stream (+ exchanges): masked relations (DFMC) before their completion: P, W (_dfmc.py:311-314) ...
+    for (size_t k = 0; k < nr; ++k) {
+        RelState& r = p->rels[k];
+        if (!(dfmc && r.masked)) continue;
+        if (!r.absent) contraction_P(p, r, st);
+        w_partial(k);
+    }
+    // ... and the unmasked relations: P, W, Q
+    for (size_t k = 0; k < nr; ++k) {
+        RelState& r = p->rels[k];
+        if (dfmc && r.masked) continue;
+        if (!r.absent) contraction_P(p, r, st);
+        w_partial(k);
+        q_partial(k);
+    }
+    // ---- second stream: backbone, H = G_i[own] S and the completion operands of the masked relations ...
     for (size_t k = 0; k < nr; ++k) {
         RelState& r = p->rels[k];
         if (!(dfmc && r.masked)) continue;
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
-        if (!r.absent) contraction_P(p, r, st);
-        w_partial(k);
         backbone_chain(k);
         if (!r.absent) {
             GemmArgs g = gemm_args(own(ti.G, ti), ti.c, 1, r.S.ptr, tj.c, 1, r.H.ptr, tj.c, (int)r.nr, tj.c, ti.c, EPI_STORE, 0);
@@ -2164,17 +2202,8 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
         }
         rec(ev_r(k, R_S), ax);
     }
-    // ---- unmasked relations: P, W, Q on the main stream, their exchanges and everything behind them underneath
-    for (size_t k = 0; k < nr; ++k) {
-        RelState& r = p->rels[k];
-        if (dfmc && r.masked) continue;
-        if (!r.absent) contraction_P(p, r, st);
-        w_partial(k);
-        q_partial(k);
-        backbone_chain(k);
-        side_products(k, ev_r(k, R_WX));
-    }
-    // ---- masked relations: completion of the local rows (_dfmc.py:319-325), then the two contractions of the G update
+    // ---- main stream: completion of the local rows of the masked relations (_dfmc.py:319-325), then the two contractions of
+    // the G update
     for (size_t k = 0; k < nr; ++k) {
         RelState& r = p->rels[k];
         if (!(dfmc && r.masked)) continue;
@@ -2197,6 +2226,17 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
         }
         rec(ev_r(k, R_P2), st);
         q_partial(k);
+    }
+    // ---- second stream: backbones and side products of the unmasked relations, then the side products of the masked ones
+    for (size_t k = 0; k < nr; ++k) {
+        RelState& r = p->rels[k];
+        if (dfmc && r.masked) continue;
+        backbone_chain(k);
+        side_products(k, ev_r(k, R_WX));
+    }
+    for (size_t k = 0; k < nr; ++k) {
+        RelState& r = p->rels[k];
+        if (!(dfmc && r.masked)) continue;
         side_products(k, ev_r(k, R_P2));
     }
     for (size_t i = 0; i < nt; ++i)
@@ -3591,6 +3631,9 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
                     // leave free instead of taking CUs from them (config 5 +0.9 %, config 3 +0.5 %; SKF_AUX_PRIO=default|high: A/B)
                     int lo = 0, hi = 0;
                     SKF_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                    // (plans with owned rows, where the second stream carries the critical path of a rank: lowest / default /
+                    // highest priority measured equal -- 2.58 / 2.56 / 2.55 ms for rank 3 of 8 at config 3 --, a running
+                    // contraction workgroup is not preempted; profiles/r04_owned_rank_emulation.txt)
                     if (p->sw.aux_prio == 0) SKF_HIP(hipStreamCreateWithPriority(&p->aux, hipStreamNonBlocking, lo));
                     else if (p->sw.aux_prio == 2) SKF_HIP(hipStreamCreateWithPriority(&p->aux, hipStreamNonBlocking, hi));
                     else SKF_HIP(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
@@ -4016,10 +4059,8 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
             GemmArgs g2 = gemm_args(tj.G.ptr, cj, 1, r.S.ptr, 1, cj, r.Tm.ptr, ci, nj, ci, cj, EPI_STORE, 0);  // T = G_j S^T
             mixed_gemm(p, g2, st);
             if (p->bf16) launch_to_bf16<float>((uint16_t*)r.FiB.ptr, r.kn_ldf, (const float*)r.Tm.ptr, (int64_t)ci, tj.n, ci, false, st);
-            p->sqpart.ptr = (char*)p->sqpart.ptr + 8;                       // the pass writes its partials behind slot 0
-            const int waves = known_pass(p, r, true, SRP_ERR, st);
-            p->sqpart.ptr = (char*)p->sqpart.ptr - 8;
-            if ((size_t)waves + 1 > p->sq_elems) SKF_FAIL(SKF_E_STATE, "residual partials: %d waves > %zu slots", waves, p->sq_elems);
+            const int waves = known_pass(p, r, true, SRP_ERR, st, 1);       // the pass writes its partials behind slot 0
+                                                                            // (capacity checked before it launches)
             hipLaunchKernelGGL((sum_partials_kernel<double>), dim3(1), dim3(256), 0, st, (const double*)p->sqpart.ptr, waves + 1, out);
             check_launch("sum_partials");
             return;

@@ -98,7 +98,22 @@ def shared_launches(fuser):
     from ..._distributed import world
     if fuser.n_run < 2 or fuser.callback or fuser.stopping or fuser.stopping_system or fuser.compute_err:
         return False
-    return fuser.shard == 'runs' and world()[1] <= 1 and fuser.dtype in ('f64', 'f32')
+    if not (fuser.shard == 'runs' and world()[1] <= 1 and fuser.dtype in ('f64', 'f32')):
+        return False
+    # the schedule for small graphs, decided here on the host (every rank <= 64, at most 8192 objects per type, constraints
+    # sparse enough for the CSR path) -- not by uploading the graph and binding a plan only to ask skf_plan_batchable
+    graph = fuser.fusion_graph
+    for ot in graph.object_types:
+        if int(ot.rank) > 64:
+            return False
+    for rel in graph.relations:
+        if max(rel.data.shape) > 8192:
+            return False
+        if rel.row_type is rel.col_type:
+            n = rel.data.shape[0]
+            if int(np.count_nonzero(np.ma.getdata(rel.data))) > n * n // 16:
+                return False
+    return True
 
 
 def store_runs(fuser, runs):
