@@ -2252,8 +2252,18 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
 // the same factors everywhere.
 static void finalize_owned(skf_plan* p, hipStream_t st) {
     if (!p->masters_stale) return;
+    // on the stream the iteration's exchanges went out on (one communicator, one order of collectives on every rank)
+    hipStream_t cs = (owned_can_overlap(p) && p->cs) ? p->cs : st;
+    if (cs != st) {
+        SKF_HIP(hipEventRecord(p->ev_own[0], st));
+        SKF_HIP(hipStreamWaitEvent(cs, p->ev_own[0], 0));
+    }
     for (TypeState& t : p->types)
-        if (!t.gather_master) collective(p->comm, COLL_ALL_GATHER, t.G.ptr, (size_t)t.chunk * t.c, p->mt, st);
+        if (!t.gather_master) collective(p->comm, COLL_ALL_GATHER, t.G.ptr, (size_t)t.chunk * t.c, p->mt, cs);
+    if (cs != st) {
+        SKF_HIP(hipEventRecord(p->ev_own[1], cs));
+        SKF_HIP(hipStreamWaitEvent(st, p->ev_own[1], 0));
+    }
     p->masters_stale = false;
 }
 

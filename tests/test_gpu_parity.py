@@ -600,6 +600,8 @@ def test_owned_rows_sharding_on_the_device(rt, monkeypatch):
         O.test_owned_rows_reproduce_the_reference_golden_on_2_and_3_ranks(variant)
         O.test_owned_rows_wide_ranks_all_engines(variant)
     O.test_owned_rows_c5_movielens_style_dfmc()
+    O.test_owned_rows_dense_constraint_in_the_bf16_engine()
+    O.test_owned_rows_rank_deficient_gram()
     O.test_exchange_bytes_of_config_3_on_8_ranks(rt)
     O.test_owned_rows_abi_errors(rt)
     z = golden('c3_scaled.npz')

@@ -65,10 +65,10 @@ def _wide_graph(seed=11):
     R = {('u', 'm'): [rs.rand(200, 150)], ('m', 'g'): [(rs.rand(150, 140) < 0.2).astype(np.float64)],
          ('u', 'g'): [rs.rand(200, 140) - 0.2]}
     M = {('u', 'm'): [rs.rand(200, 150) < 0.6], ('m', 'g'): [None], ('u', 'g'): [None]}
-    Tm = 0.05 * np.eye(150)
-    Tm[3, 7] = Tm[7, 3] = -0.01
-    Tm[140, 2] = Tm[2, 140] = 0.02
-    Theta = {('m', 'm'): [Tm]}
+    Tu = 0.05 * np.eye(200)                      # (the constraint sits on the ROW type of the masked relation: its column type
+    Tu[3, 7] = Tu[7, 3] = -0.01                  #  'm' then travels as bf16 rows, and the completion operand is built from them)
+    Tu[190, 2] = Tu[2, 190] = 0.02
+    Theta = {('u', 'u'): [Tu]}
     G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.05 for t in types}
     return R, M, Theta, types, rank, G0
 
@@ -79,7 +79,8 @@ def test_owned_rows_wide_ranks_all_engines(variant):
     the partial Gram / W / Q sums: f32 1e-5; bf16 1e-3 -- a factor entry that lands on the other side of a bf16 rounding
     boundary moves the operand by 2^-9; bf16 DFMC 5e-3: the single-device pipeline forms W of the masked relation through
     the narrower factor, (R^T G_i)^T G_j, the sharded one as G_i^T (R G_j) -- other bf16 products).  bf16: the constrained
-    type gathers its f32 rows, the others bf16 rows only."""
+    type ('u') gathers its f32 rows, the others bf16 rows only -- 'm', the column type of the masked relation, among them:
+    the bf16 operand of its completion tiles comes from the gathered rows."""
     R, M, Theta, types, rank, G0 = _wide_graph()
     its = 3
     if variant == 'dfmf':
@@ -104,11 +105,11 @@ def test_owned_rows_wide_ranks_all_engines(variant):
                 for G, _ in out[1:]:
                     np.testing.assert_array_equal(G[t, t], out[0][0][t, t])
             # per iteration what skf_exchange_bytes says; bf16: plus ONE gather of the f32 rows of the types that travel as
-            # bf16 rows ('u' and 'g': 'm' carries a constraint and gathers its f32 rows every iteration) at the end of the call
+            # bf16 rows ('m' and 'g': 'u' carries a constraint and gathers its f32 rows every iteration) at the end of the call
             final = 0.0
             if dtype == 'bf16':
                 final = (size - 1) / float(size) * sum(owned_rows(dtype, G0[t, t].shape[0], 0, size)[2] * size * rank[t] * 4
-                                                       for t in ('u', 'g'))
+                                                       for t in ('m', 'g'))
             assert abs(grp.bytes_sent_per_rank() - its * said[0] - final) <= float(its)
 
 
@@ -204,3 +205,42 @@ def test_owned_rows_abi_errors(emul):
     plan.iterate_dist(2)                              # timing vehicle: runs, exchanges skipped
     assert np.isfinite(plan.get_factor('a')).all()
     plan.close()
+
+
+def test_owned_rows_dense_constraint_in_the_bf16_engine():
+    """A DENSE constraint (more than n^2 / 16 non-zeros) under row ownership in the bf16 engine: a rank multiplies ITS rows of
+    the bf16 halves of Theta with the stored G^T (`theta_terms_rows`); 2 ranks (rows split at 128) against the single-device
+    fit of the same engine."""
+    rs = np.random.RandomState(17)
+    types, n, rank = ['a', 'b'], {'a': 256, 'b': 140}, {'a': 12, 'b': 9}
+    R = {('a', 'b'): [rs.rand(256, 140)]}
+    Ta = 0.02 * (rs.rand(256, 256) - 0.3)
+    Ta = 0.5 * (Ta + Ta.T)
+    Theta = {('a', 'a'): [Ta]}
+    G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.05 for t in types}
+    Gs, Ss = _dfmf.dfmf(R, Theta, types, rank, max_iter=3, G0=G0, dtype='bf16')
+    out, _, _ = fit_owned('dfmf', R, None, Theta, types, rank, G0, 3, 2, dtype='bf16')
+    for G, S in out:
+        for t in types:
+            assert relerr(G[t, t], Gs[t, t]) < 1e-3
+        assert relerr(S['a', 'b'][0], Ss['a', 'b'][0]) < 1e-2
+
+
+def test_owned_rows_rank_deficient_gram():
+    """Rank 50 > 30 objects (reference tests/test_n_run.py:14): the partial Gram matrices of the owners sum to a singular
+    matrix, every rank takes the rank-revealing pseudo-inverse path on the summed matrix and lands on the reference's
+    iterates (the golden of the single-device engine, 1e-7) and on the oracle's reconstruction errors."""
+    from helpers import rank_deficient_graph
+    z = golden('rank_deficient.npz')
+    R, types, rank = rank_deficient_graph(z)
+    G0 = g0_from(z, 'dfmf/', types)
+    Go, So = orc.dfmf(R, {}, types, rank, max_iter=2, G0=G0)
+    eo = orc.relation_errors(R, Go, So)
+    out, _, _ = fit_owned('dfmf', R, None, {}, types, rank, G0, 2, 2)
+    for G, S in out:
+        for t in types:
+            assert relerr(G[t, t], z['dfmf/G_%s_it1' % t]) < 1e-7
+            assert np.isfinite(G[t, t]).all()
+        e = orc.relation_errors(R, G, S)
+        for k in e:
+            assert abs(e[k][0] - eo[k][0]) <= 1e-6 * max(1.0, eo[k][0])

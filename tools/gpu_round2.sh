@@ -24,12 +24,25 @@ case "$step" in
   dist_smoke)
     # `bench.py --gpus 2` launches itself (torch.distributed.run, one rank per GPU); on this one-GPU box the two
     # ranks share GPU 0 over a gloo group: all three multi-GPU modes end to end
-    for mode in restarts relations rows; do
+    for mode in restarts relations rows owned; do
       ( SKF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --scale 0.2 --mode $mode --no-cpu-baseline --no-engines ) > "$OUT/dist_$mode.log" 2>&1
       echo "dist $mode exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/dist_$mode.log" | cut -c1-260 | tee -a "$OUT/summary.txt"
     done
-    ( SKF_BENCH_BACKEND=gloo timeout 600 python bench.py --workload c5 --gpus 2 --steps 2 --warmup 1 --scale 0.1 --mode rows --no-cpu-baseline ) > "$OUT/dist_c5_rows.log" 2>&1
-    echo "dist c5 rows exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/dist_c5_rows.log" | cut -c1-260 | tee -a "$OUT/summary.txt" ;;
+    for mode in rows owned; do
+      ( SKF_BENCH_BACKEND=gloo timeout 600 python bench.py --workload c5 --gpus 2 --steps 2 --warmup 1 --scale 0.1 --mode $mode --no-cpu-baseline ) > "$OUT/dist_c5_$mode.log" 2>&1
+      echo "dist c5 $mode exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/dist_c5_$mode.log" | cut -c1-260 | tee -a "$OUT/summary.txt"
+    done ;;
+  emulate)
+    # per-rank compute of the ownership-sharded fit (null communicator), config 3 at 2 / 4 / 8 ranks and config 5 at 8
+    for w in 2 4 8; do
+      ( timeout 300 python bench.py --emulate-rank all/$w --steps 20 --warmup 3 ) > "$OUT/emulate_all$w.log" 2>&1
+      echo "emulate all/$w exit $?" | tee -a "$OUT/summary.txt"
+    done
+    ( timeout 300 python bench.py --emulate-rank all/8 --steps 20 --warmup 3 --workload c5 ) > "$OUT/emulate_c5.log" 2>&1
+    echo "emulate c5 exit $?" | tee -a "$OUT/summary.txt" ;;
+  foldin)
+    ( timeout 600 python tools/bench_transform.py ) > "$OUT/foldin_scale.txt" 2>&1
+    echo "foldin exit $?" | tee -a "$OUT/summary.txt"; grep fold-in "$OUT/foldin_scale.txt" | cut -c1-200 | tee -a "$OUT/summary.txt" ;;
   fullbench)
     ( time timeout 1200 python bench.py ) > "$OUT/bench_full.log" 2>&1
     echo "bench exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/bench_full.log" | tee -a "$OUT/summary.txt" ;;
