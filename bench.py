@@ -504,7 +504,9 @@ def cpu_baseline_c5(scale=0.25, target=1.0):
     return {'value': ratio / per_iter, 'unit': 'iters/s', 'cores': blas_threads(), 'cores_physical': physical_cores(),
             'kind': 'port', 'projection': True,
             'sample': 'oracle dfmc at %.3f linear scale (%d users x %d movies): %.3f s per iteration, projected by the cell '
-                      'ratio %.4f' % (scale, n['user'], n['movie'], per_iter, ratio)}
+                      'ratio %.4f (measured once at FULL size, `--workload c5 --cpu-baseline full`: 26.4 s per iteration = 0.0379 '
+                      'it/s on 128 cores, profiles/r04_c5_cpu_full.txt -- the projection is 1.9x pessimistic)'
+                      % (scale, n['user'], n['movie'], per_iter, ratio)}
 
 
 def _c5_full_child(scale=1.0):

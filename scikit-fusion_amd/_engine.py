@@ -222,7 +222,10 @@ def _torch_collective(mem, ws, dist, rank, world):
     def collective(user, op, buf, count, dtype, stream):
         try:
             import torch
-            npd = np.int16 if dtype == nat.SKF_BF16 else nat.NP_DTYPE[dtype]
+            if dtype == nat.SKF_BF16:           # bf16 rows travel as bytes (all-gather only; gloo has no 16-bit integer type)
+                npd, count = np.uint8, count * 2
+            else:
+                npd = nat.NP_DTYPE[dtype]
             es = np.dtype(npd).itemsize
             n = count * (1 if op == 0 else world)
             view = mem.as_tensor(ws, int(buf) - ws.ptr, n * es, npd)
@@ -558,7 +561,10 @@ class DevicePlan(object):
 
         def trampoline(user, op, buf, count, dtype, stream):
             try:
-                npd = np.int16 if dtype == nat.SKF_BF16 else nat.NP_DTYPE[dtype]
+                if dtype == nat.SKF_BF16:       # bf16 rows travel as bytes (all-gather only)
+                    npd, count = np.uint8, count * 2
+                else:
+                    npd = nat.NP_DTYPE[dtype]
                 n = count * (1 if op == 0 else world)
                 view = mem.as_tensor(ws, int(buf) - ws.ptr, n * np.dtype(npd).itemsize, npd)
                 collective(op, view, count, rank, world)

@@ -229,7 +229,7 @@ class TorchDeviceMemory(object):
     def as_tensor(self, buf, offset, nbytes, np_dtype):
         """Zero-copy torch view of a byte range of a device buffer (for RCCL collectives)."""
         tdt = {np.dtype(np.float32): self.torch.float32, np.dtype(np.float64): self.torch.float64,
-               np.dtype(np.int16): self.torch.int16}[np.dtype(np_dtype)]
+               np.dtype(np.uint8): self.torch.uint8}[np.dtype(np_dtype)]
         return buf.owner[offset:offset + nbytes].view(tdt)
 
 

@@ -440,6 +440,7 @@ struct Switches {
     bool known_no_v6 = false;      // SKF_KNOWN_V6=0        the round-3a list kernel (srp_bf16_kernel) at ranks 128 / 256 too (A/B)
     bool no_gram_aux = false;      // SKF_GRAM_AUX=0        DFMC on known entries: Gram / cross-Gram products on the main stream (A/B)
     bool no_small_fused = false;   // SKF_NO_SMALL_FUSED=1  small graphs on the general staged schedule (~33 launches per iteration)
+    bool no_sweep = false;         // SKF_PINV_SWEEP=0      orders 65 .. 256: blocked Cholesky inverse + unpack instead of the blocked sweep (A/B)
     static Switches read() {
         auto on = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
         Switches w;
@@ -455,6 +456,7 @@ struct Switches {
         { const char* v6 = getenv("SKF_KNOWN_V6"); w.known_no_v6 = v6 && atoi(v6) == 0; }
         { const char* ga = getenv("SKF_GRAM_AUX"); w.no_gram_aux = ga && atoi(ga) == 0; }
         w.no_small_fused = on("SKF_NO_SMALL_FUSED");
+        { const char* sv = getenv("SKF_PINV_SWEEP"); w.no_sweep = sv && atoi(sv) == 0; }
         const char* st = getenv("SKF_SIDE_TILE");
         w.side_tile = st ? atoi(st) : 0;
         const char* ap = getenv("SKF_AUX_PRIO");
@@ -859,6 +861,19 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
     e.max_sweeps = 30;
     // fast path (Cholesky inverse) with an on-device verdict; the Jacobi eigen-solver only does
     // work for the matrices the fast path rejected -- no host round trip either way
+    // orders 65 .. 256 (round 4): the blocked sweep operator writes K itself -- one launch instead of the Cholesky inverse and
+    // its unpack (1.15 + 0.09 ms at order 256)
+    const bool sweep = batched && max_c > CHOLS_MAXN && max_c <= SWEEP_MAXN && !p->sw.no_sweep && !p->sw.chol_unblocked &&
+                       !p->sw.pinv_jacobi;
+    if (sweep) {
+        static DeviceOnce once;
+        allow_dynamic_lds(once, sweep_inverse_kernel, SWEEP_LDS_BYTES);
+        hipLaunchKernelGGL(sweep_inverse_kernel, dim3((unsigned)nb), dim3(SWEEP_THREADS), SWEEP_LDS_BYTES, st, e, pb,
+                           chol_rel_threshold(p->sw));
+        check_launch("sweep_inverse");
+        pinv_fallbacks(p, which, pb, e, batched, max_c, st);
+        return;
+    }
     launch_chol(p->sw, e, nb, p->eig_maxn, st);
     if (batched) {
         hipLaunchKernelGGL(chol_unpack_batched_kernel, dim3(elem_grid((int64_t)max_c * max_c), nb), dim3(256), 0, st, pb,
@@ -4261,14 +4276,27 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
         e.n = eN; e.n_orig = eNo; e.chol_ok = eOk; e.max_sweeps = 30;
         const int tot2 = n * n;
         const Switches sw = Switches::read();          // stand-alone operator: no plan to hold them
-        launch_chol(sw, e, 1, np, st);
-        if (dtype == SKF_F64)
-            hipLaunchKernelGGL((chol_unpack_kernel<double>), dim3(elem_grid(tot2)), dim3(256), 0, st, (double*)K, ldk,
-                               eV, np, n, eOk);
-        else
-            hipLaunchKernelGGL((chol_unpack_kernel<float>), dim3(elem_grid(tot2)), dim3(256), 0, st, (float*)K, ldk,
-                               eV, np, n, eOk);
-        check_launch("chol_unpack");
+        // fast path: the blocked sweep for orders 65 .. 256 (writes a contiguous f64 K itself), else Cholesky inverse + unpack
+        const bool sweep = dtype == SKF_F64 && ldk == n && n > CHOLS_MAXN && n <= SWEEP_MAXN && !sw.no_sweep && !sw.chol_unblocked &&
+                           !sw.pinv_jacobi;
+        if (sweep) {
+            PinvBatch pb;
+            memset(&pb, 0, sizeof pb);
+            pb.K[0] = (double*)K; pb.c[0] = n; pb.n_pad[0] = np;
+            static DeviceOnce once;
+            allow_dynamic_lds(once, sweep_inverse_kernel, SWEEP_LDS_BYTES);
+            hipLaunchKernelGGL(sweep_inverse_kernel, dim3(1), dim3(SWEEP_THREADS), SWEEP_LDS_BYTES, st, e, pb, chol_rel_threshold(sw));
+            check_launch("sweep_inverse");
+        } else {
+            launch_chol(sw, e, 1, np, st);
+            if (dtype == SKF_F64)
+                hipLaunchKernelGGL((chol_unpack_kernel<double>), dim3(elem_grid(tot2)), dim3(256), 0, st, (double*)K, ldk,
+                                   eV, np, n, eOk);
+            else
+                hipLaunchKernelGGL((chol_unpack_kernel<float>), dim3(elem_grid(tot2)), dim3(256), 0, st, (float*)K, ldk,
+                                   eV, np, n, eOk);
+            check_launch("chol_unpack");
+        }
         {
             static DeviceOnce once;
             allow_dynamic_lds(once, pchol_pinv_kernel, PCHOL_LDS_BYTES);

@@ -3117,6 +3117,172 @@ __global__ __launch_bounds__(256) void chol_unpack_batched_kernel(PinvBatch pb, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fast path of the pseudo-inverse for orders 65 .. SWEEP_MAXN (round 4): K = A^-1 of a symmetric positive definite matrix by
+// the BLOCKED SWEEP OPERATOR, one workgroup of 512 threads per matrix, straight into the K slot -- no factor, no triangular
+// inverse, no X^T X product behind it (chol_inverse_blocked_kernel + chol_unpack: 1.15 + 0.09 ms at order 256, and the
+// critical path of a rank of the ownership-sharded iteration and of config 5's pipeline; this kernel: see profiles/).
+// Sweeping pivot k of a symmetric M: m_ij -= c_i c_j / m_kk (c = column k), row / column k <- c / m_kk, m_kk <- -1 / m_kk;
+// after all n pivots M = -A^-1.  Blocked by NB = 32 pivots: with P = M_pp^-1 of the CURRENT pivot block
+//     M_rr -= M_rp P M_pr ,  M_rp <- M_rp P ,  M_pr <- P M_pr ,  M_pp <- -P
+// (sweeping a block is sweeping its pivots one after the other).  Per block: the panel C = M[:, block] and the pivot block
+// go to LDS; the 32 x 32 block is swept pivot by pivot with ONE barrier per pivot (two elements per thread in registers,
+// row k published through a double buffer) -- its pivots are the Schur complements a Cholesky factorisation would take the
+// roots of, so the verdict is that of the Cholesky kernels: pivot > rel_thr * a_kk, a_kk above the diagonal floor; a failed
+// pivot leaves the matrix (untouched in e.A) to the deflation / eigen-solver --; T = M_rp P (n x 32); then the rank-32 update
+// of the whole matrix, 8 x 8 outputs per thread and pass in registers, operands from LDS (rows ty + 16 a, columns tx + 32 b:
+// conflict-free LDS rows, coalesced read-modify-write of M).  The vector ALU runs f64 FMAs at the rate of the f64 matrix
+// cores on this part (78.6 TFLOP/s either way), so the update is plain FMAs: n^2 * 32 of them per block = 13.7 us on one CU at
+// order 256.  M lives in the plan's eigen scratch (e.V), 0.5 MB: L2 resident.
+// ------------------------------------------------------------------------------------------
+constexpr int SWEEP_MAXN = 256;
+constexpr int SWEEP_NB = 32;
+constexpr int SWEEP_LD = SWEEP_NB + 1;
+constexpr int SWEEP_THREADS = 512;
+constexpr int SWEEP_LDS_BYTES = ((2 * SWEEP_MAXN + SWEEP_NB) * SWEEP_LD + 2 * SWEEP_NB + SWEEP_MAXN) * 8;
+
+__global__ __launch_bounds__(SWEEP_THREADS) void sweep_inverse_kernel(EighArgs e, PinvBatch pb, double rel_thr) {
+    constexpr int NB = SWEEP_NB, LD = SWEEP_LD;
+    HIP_DYNAMIC_SHARED(double, ssm)
+    __shared__ double red[SWEEP_THREADS / 64];
+    __shared__ double s_max;
+    double* Cs = ssm;                              // [SWEEP_MAXN][LD]  panel C = M[:, kb .. kb + nb)
+    double* Ts = Cs + SWEEP_MAXN * LD;             // [SWEEP_MAXN][LD]  T = M_rp P
+    double* Pv = Ts + SWEEP_MAXN * LD;             // [NB][LD]          the swept pivot block: -P
+    double* rowk = Pv + NB * LD;                   // [2][NB]           row k of the pivot block, double-buffered
+    double* need = rowk + 2 * NB;                  // [SWEEP_MAXN]      the bound pivot k has to exceed
+    const int b = blockIdx.x;
+    const int n = e.n_orig[b], ld = e.n[b];
+    if (n > SWEEP_MAXN) return;                    // (the host sends such plans to chol_inverse_blocked_kernel)
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;      // 32 x 16
+    const int lane = tid & 63, wave = tid >> 6;
+    const double* A = e.A + (int64_t)b * e.stride;
+    double* M = e.V + (int64_t)b * e.stride;
+
+    double mx = 0.0;
+    for (int idx = tid; idx < n * n; idx += SWEEP_THREADS) {
+        const int r = idx / n, c = idx % n;
+        const double v = 0.5 * (A[r * ld + c] + A[c * ld + r]);
+        M[r * ld + c] = v;
+        if (r == c) mx = fmax(mx, fabs(v));
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int i = 0; i < SWEEP_THREADS / 64; ++i) s = fmax(s, red[i]);
+        s_max = s;
+    }
+    __syncthreads();
+    {   // the three tests on pivot k -- a_kk > floor, pivot > thr a_kk, pivot > 0 -- as ONE bound (+inf where a_kk fails)
+        const double floor_ = chol_diag_floor(n) * s_max;
+        for (int k = tid; k < n; k += SWEEP_THREADS) {
+            const double akk = A[k * ld + k];
+            need[k] = (akk > floor_) ? fmax(rel_thr * akk, 0.0) : __builtin_inf();
+        }
+    }
+    __syncthreads();
+
+    for (int kb = 0; kb < n; kb += NB) {
+        const int nb = (n - kb < NB) ? n - kb : NB;
+        // ---- panel and pivot block to LDS
+        for (int i = ty; i < n; i += 16) Cs[i * LD + tx] = (tx < nb) ? M[i * ld + kb + tx] : 0.0;
+        __syncthreads();
+        // ---- sweep of the pivot block: elements (r, c) = (ty, tx) and (ty + 16, tx) in registers
+        double v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = ty + 16 * h;
+            v[h] = (r < nb && tx < nb) ? Cs[(kb + r) * LD + tx] : 0.0;
+        }
+        if (ty == 0) rowk[tx] = v[0];                                    // row 0
+        __syncthreads();
+        bool ok = true;
+        for (int k = 0; k < nb; ++k) {
+            const double* rk = rowk + (k & 1) * NB;
+            const double piv = rk[k];
+            if (!(piv > need[kb + k])) {                                 // (uniform: every thread reads the same words)
+                ok = false;
+                break;
+            }
+            const double d = 1.0 / piv;
+            const double cc = rk[tx];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = ty + 16 * h;
+                const double cr = rk[r];
+                const double nv = (r == k) ? ((tx == k) ? -d : cc * d) : ((tx == k) ? cr * d : fma(-cr * d, cc, v[h]));
+                v[h] = (r < nb && tx < nb) ? nv : 0.0;
+                if (r == k + 1) rowk[((k + 1) & 1) * NB + tx] = v[h];     // row k + 1 of the swept block, for the next pivot
+            }
+            __syncthreads();
+        }
+        if (!ok) {                                                       // (uniform)
+            if (tid == 0) e.chol_ok[b] = 0;
+            return;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) Pv[(ty + 16 * h) * LD + tx] = v[h];
+        __syncthreads();
+        // ---- T = M_rp P = -(C Pv), every row (the pivot rows' entries are not used)
+        for (int i = ty; i < n; i += 16) {
+            double s = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < NB; ++k) s = fma(Cs[i * LD + k], Pv[k * LD + tx], s);
+            Ts[i * LD + tx] = -s;
+        }
+        __syncthreads();
+        // ---- M_rr -= T C^T outside the pivot rows / columns: rows ty + 16 a (two passes of 8), columns tx + 32 b
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (ty + 16 * 8 * pass >= n) break;
+            double acc[8][8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[a][q] = 0.0;
+            for (int k = 0; k < nb; ++k) {
+                double t[8], c[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) t[a] = Ts[(ty + 16 * (8 * pass + a)) * LD + k];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) c[q] = Cs[(tx + 32 * q) * LD + k];
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[a][q] = fma(t[a], c[q], acc[a][q]);
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const int i = ty + 16 * (8 * pass + a);
+                if (i >= n || (i >= kb && i < kb + nb)) continue;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = tx + 32 * q;
+                    if (j < n && !(j >= kb && j < kb + nb)) M[i * ld + j] -= acc[a][q];
+                }
+            }
+        }
+        // ---- pivot columns and rows <- T, pivot block <- -P
+        for (int i = ty; i < n; i += 16) {
+            if (tx >= nb) continue;
+            if (i >= kb && i < kb + nb) {
+                M[i * ld + kb + tx] = Pv[(i - kb) * LD + tx];
+            } else {
+                const double t = Ts[i * LD + tx];
+                M[i * ld + kb + tx] = t;
+                M[(kb + tx) * ld + i] = t;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- all pivots swept: M = -A^-1
+    double* K = pb.K[b];
+    for (int idx = tid; idx < n * n; idx += SWEEP_THREADS) K[idx] = -M[(idx / n) * ld + idx % n];
+    if (tid == 0) e.chol_ok[b] = 1;
+}
+
 __global__ __launch_bounds__(256) void eigh_unpack_pinv_batched_kernel(PinvBatch pb, const double* __restrict__ VsAll,
                                                                        const double* __restrict__ VAll, int64_t stride,
                                                                        const int* __restrict__ chol_ok) {

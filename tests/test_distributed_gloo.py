@@ -113,6 +113,17 @@ def _library_exchange_against_python_exchange(shard):
     return [a for a in out[0]] + [b for b in out[1]]
 
 
+def _bf16_owned():
+    """The bf16 engine under row ownership over a real process group: the bf16 operand rows of the types without a constraint
+    are gathered as BYTES through the callback communicator (gloo has no 16-bit integer type), the constrained type's f32
+    rows as floats."""
+    from test_owned_sharding import _wide_graph
+    from skfusion_amd.fusion.decomposition import _dfmc
+    R, M, Theta, types, rank, G0 = _wide_graph()
+    G, S = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=2, G0=G0, dtype='bf16', shard='owned')
+    return [G[t, t] for t in types] + [S[k][0] for k in sorted(S)]
+
+
 def _worker(rank, world, port, out, what):
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, HERE)
@@ -130,6 +141,8 @@ def _worker(rank, world, port, out, what):
                 np.savez(os.path.join(out, 'rank%d.npz' % rank), *_fit())
             elif what.startswith('stop:'):
                 np.savez(os.path.join(out, 'stop%d.npz' % rank), *_probe_stopping(what[5:]))
+            elif what == 'bf16:owned':
+                np.savez(os.path.join(out, 'bf16_%d.npz' % rank), *_bf16_owned())
             elif what.startswith('lib:'):
                 np.savez(os.path.join(out, 'lib%d.npz' % rank), *_library_exchange_against_python_exchange(what[4:]))
             else:
@@ -228,3 +241,23 @@ def test_exchanges_issued_by_the_library_match_the_python_exchanges(tmp_path, sh
         for k, t in enumerate(TYPES):
             assert relerr(a['arr_%d' % k], a['arr_%d' % (k + 3)]) < 1e-12
             assert relerr(a['arr_%d' % k], z['dfmc/G_%s_it5' % t]) < 1e-9 if 'dfmc/G_%s_it5' % t in z.files else True
+
+
+def test_bf16_engine_sharded_by_ownership_over_two_gloo_ranks(tmp_path):
+    """bf16 rows through the callback communicator of a gloo group (bytes): both ranks end with the same factors, those of
+    the single-process bf16 fit up to the order of the partial sums."""
+    import torch.multiprocessing as mp
+    from emul.runtime import emulated_runtime, use_runtime, build
+    from helpers import relerr
+    from test_owned_sharding import _wide_graph
+    from skfusion_amd.fusion.decomposition import _dfmc
+    build()
+    with use_runtime(emulated_runtime()):
+        R, M, Theta, types, rank, G0 = _wide_graph()
+        Gs, Ss = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=2, G0=G0, dtype='bf16')
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), 'bf16:owned'), nprocs=2, join=True)
+    a = [np.load(os.path.join(str(tmp_path), 'bf16_%d.npz' % r)) for r in range(2)]
+    for k, t in enumerate(types):
+        np.testing.assert_array_equal(a[0]['arr_%d' % k], a[1]['arr_%d' % k])
+        assert relerr(a[0]['arr_%d' % k], Gs[t, t]) < 5e-3

@@ -293,6 +293,43 @@ def test_pinv_full_rank_matches_scipy(rt, n, monkeypatch=None):
         assert relerr(A @ got @ A, A) < 1e-11
 
 
+@pytest.mark.parametrize('n', [65, 96, 130, 200, 256])
+def test_pinv_blocked_sweep_orders_65_to_256(rt, n):
+    """Orders 65 .. 256 take the blocked sweep operator (sweep_inverse_kernel: K written by the kernel itself): against
+    scipy and against the blocked Cholesky inverse it replaced (SKF_PINV_SWEEP=0), badly scaled columns included (the pivot
+    test is relative to each pivot's own diagonal entry, as in the Cholesky kernels); a singular matrix is declined and
+    lands on the deflation path with the same result as before."""
+    import os
+    import scipy.linalg as spla
+    rs = np.random.RandomState(n)
+    G = rs.rand(3 * n + 5, n)
+    A = G.T @ G
+    want = spla.pinv(A)
+    got = run_pinv(rt, nat.SKF_F64, A)
+    os.environ['SKF_PINV_SWEEP'] = '0'
+    try:
+        old = run_pinv(rt, nat.SKF_F64, A)
+    finally:
+        os.environ.pop('SKF_PINV_SWEEP', None)
+    assert relerr(got, want) < 1e-9 * max(1.0, np.linalg.cond(A) * 1e-3)
+    assert relerr(got, old) < 1e-9 * max(1.0, np.linalg.cond(A) * 1e-3)
+    assert relerr(A @ got @ A, A) < 1e-11
+    assert np.abs(got - got.T).max() <= 1e-12 * np.abs(got).max()
+    if n in (96, 200):
+        scale = 10.0 ** (-4.0 * rs.rand(n))
+        Gs = rs.rand(4 * n, n) * scale
+        As = Gs.T @ Gs
+        d = np.sqrt(np.diag(As))
+        gs = run_pinv(rt, nat.SKF_F64, As)
+        # (cond(As) ~ 4e9: scipy's own inverse is off by 1e-8 there; the equilibrated matrix has cond ~ 2e3 and its inverse,
+        # scaled back, is the reference -- the sweep is within 1e-13 of it, the Cholesky inverse within 3e-14)
+        W = np.outer(d, d)
+        assert relerr(gs * W, np.linalg.inv(As / W)) < 1e-12
+        Gd = rs.rand(n // 2, n)                        # rank n / 2: the sweep meets a failed pivot and hands over
+        Ad = Gd.T @ Gd
+        assert relerr(run_pinv(rt, nat.SKF_F64, Ad), spla.pinv(Ad)) < 1e-7
+
+
 def test_pinv_rank_deficient_truncates_like_scipy(rt):
     """reference tests/test_n_run.py:14: rank 50 factor of 30 objects -> Gram has rank 30."""
     import scipy.linalg as spla
