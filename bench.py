@@ -670,13 +670,25 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
         for k, (i, j, masked) in enumerate(spec):
             a, cnt, _ = owned_rows(dtype, n[i], rank, world)
             if cnt == 0:
-                rels.append((i, j, None, None, dict(absent=True, row_begin=0, n_rows=0, masked=masked)))
+                blk = dict(absent=True, row_begin=0, n_rows=0, masked=masked)
+                if masked:
+                    from skfusion_amd._engine import known_lists_pay
+                    blk['known_lists'] = known_lists_pay(make(k)[1].known, n[i], n[j], ranks_[i], dtype)
+                rels.append((i, j, None, None, blk))
                 continue
             rdata, mask = make(k)
             blk = dict(absent=False, row_begin=a, n_rows=cnt, masked=masked)
             if dtype == 'bf16' and mask is None:
                 blk['binary'] = bool(rdata.binary)
-            rels.append((i, j, rdata.rows(a, cnt, esz), None if mask is None else mask.rows(a, cnt, 1), blk))
+            mrows = None
+            if mask is not None:
+                # lists of the known entries under row ownership: decided on the WHOLE relation, for all ranks alike; the
+                # local rows' count bounds this rank's lists
+                from skfusion_amd._engine import known_lists_pay
+                blk['known_lists'] = known_lists_pay(mask.known, n[i], n[j], ranks_[i], dtype)
+                mrows = mask.rows(a, cnt, 1)
+                mrows.known = int((mask.buf.owner[a:a + cnt] == 0).sum().item())
+            rels.append((i, j, rdata.rows(a, cnt, esz), mrows, blk))
             del rdata, mask
     else:
         rels = [(spec[k][0], spec[k][1]) + make(k) for k in local_index]

@@ -91,6 +91,11 @@ enum {
     SKF_REL_NO_COL_SIDE = 2,  /* another process adds the column-side terms E_j, D_j of this relation */
     SKF_REL_MASKED = 4,       /* SKF_REL_ABSENT descriptors: the relation is masked where it lives */
     SKF_REL_MASK_BITS = 8,    /* `mask` is packed, one bit per entry (see skf_relation_desc.mask) */
+    SKF_REL_KNOWN_LISTS = 32, /* SKF_OPT_OWNED_ROWS plans: this masked relation is kept as lists of its known entries (see
+                                 known_bound) on EVERY process -- the caller decides it for all of them alike from the share of
+                                 known entries of the WHOLE relation (the partial sums the processes exchange follow one
+                                 convention per relation); also set on SKF_REL_ABSENT descriptors of such a relation.  known_bound
+                                 then bounds the known entries of the LOCAL rows.  Other plans: ignored (the library decides). */
     SKF_REL_BINARY = 16       /* every entry is 0 or 1 (checked at bind time; "movie has genre", "user tagged").
                                  SKF_BF16 keeps such a relation as a BITMAP -- 1 bit instead of a bf16 per entry
                                  in HBM and on the way to the matrix cores, where it is expanded to bf16 0 / 1 in

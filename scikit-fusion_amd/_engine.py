@@ -92,6 +92,20 @@ def owned_rows(dtype, n_obj, part_index, part_count, runtime=None):
     return b.value, c.value, ch.value
 
 
+def known_lists_pay(known, rows, cols, rank_row, dtype):
+    """Whether a masked relation of rows x cols entries, `known` of them known, is worth keeping as lists of its known entries
+    (the library's own rule for whole relations, skf_plan_create: share of known entries x rank of the row type <= 4;
+    SKF_DFMC_SPARSE=0 never, =1 up to a quarter known) -- for plans with owned rows, where the caller decides for all ranks
+    alike (SKF_REL_KNOWN_LISTS)."""
+    import os
+    mode = os.environ.get('SKF_DFMC_SPARSE')
+    cells = float(rows) * float(cols)
+    if mode == '0' or known <= 0 or cells <= 0 or rank_row > 1024:
+        return False
+    share = known / cells
+    return share <= 0.25 and (mode == '1' or share * rank_row <= 4.0)
+
+
 def _sparse_bound(nnz, n):
     """skf_theta_desc.nnz for a constraint with `nnz` non-zeros: the count itself when the matrix is sparse enough for
     the CSR path (<= n*n/16), 0 (dense product, as the reference) otherwise or when unknown."""
@@ -295,6 +309,8 @@ class DevicePlan(object):
                                   (0 if block.get('col_side', True) else nat.SKF_REL_NO_COL_SIDE) |
                                   (nat.SKF_REL_MASKED if block.get('masked') else 0))
                 if block.get('absent'):
+                    if block.get('known_lists'):
+                        rdesc[k].flags |= nat.SKF_REL_KNOWN_LISTS
                     continue
             if isinstance(data, DeviceMatrix):
                 arr, buf, ld = data, data.buf, data.ld
@@ -340,8 +356,10 @@ class DevicePlan(object):
                 rdesc[k].mask, rdesc[k].mask_ld = pm.buf.ptr, pm.ld
                 rdesc[k].flags |= nat.SKF_REL_MASK_BITS
                 rdesc[k].known_bound = pm.known
-            if sparse_known is False or block is not None:
+            if sparse_known is False or (block is not None and not block.get('known_lists')):
                 rdesc[k].known_bound = 0
+            if block is not None and block.get('known_lists'):       # (row ownership: decided for all ranks alike by the caller)
+                rdesc[k].flags |= nat.SKF_REL_KNOWN_LISTS
         hdesc = (nat.ThetaDesc * max(len(thetas), 1))()
         for k, (t, data) in enumerate(thetas):
             if isinstance(data, DeviceMatrix):           # master dtype, already in HBM

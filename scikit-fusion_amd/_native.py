@@ -15,6 +15,7 @@ SKF_F64, SKF_F32, SKF_BF16 = 0, 1, 2
 SKF_DFMF, SKF_DFMC, SKF_TRANSFORM = 0, 1, 2
 SKF_ENGINE_MFMA, SKF_ENGINE_VALU = 0, 1
 SKF_REL_ABSENT, SKF_REL_NO_COL_SIDE, SKF_REL_MASKED, SKF_REL_MASK_BITS, SKF_REL_BINARY = 1, 2, 4, 8, 16
+SKF_REL_KNOWN_LISTS = 32
 SKF_STAGE_CONTRACT, SKF_STAGE_BACKBONE, SKF_STAGE_ACCUMULATE, SKF_STAGE_UPDATE = 0, 1, 2, 3
 SKF_X_W, SKF_X_Q, SKF_X_QM, SKF_X_ED = 0, 1, 2, 3
 SKF_OK, SKF_E_INVALID, SKF_E_STATE, SKF_E_WORKSPACE, SKF_E_HIP = 0, -1, -2, -3, -4

@@ -1163,7 +1163,9 @@ static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream
     }
     void* final_out = by_col ? r.Q.ptr : r.A.ptr;
     void* out = parts > 1 ? (by_col ? r.Qpart.ptr : r.Apart.ptr) : final_out;
-    const void* Gi = p->bf16 ? ti.Grow.ptr : ti.G.ptr;        // vectors of the row objects (bf16: kept in step with G^T)
+    // vectors of the row objects of the block (bf16: kept in step with G^T); rows [r0, r0 + nr) of the type under row ownership
+    const void* Gi = p->bf16 ? (const void*)((const char*)ti.Grow.ptr + (size_t)r.r0 * ti.ldrow * 2)
+                             : (const void*)((const char*)ti.G.ptr + (size_t)r.r0 * ci * p->esz);
     const void* Tj = p->bf16 ? r.FiB.ptr : r.Tm.ptr;          // vectors of the column objects
     const int64_t ldv = p->bf16 ? r.kn_ldf : ci;
     if (p->profiling) SKF_HIP(hipEventRecord(next_event(p), st));
@@ -1193,7 +1195,7 @@ static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream
         a.out = (float*)out;
         // the all-zero row behind the gathered matrix (TypeState::Grow / FiB hold one row more than the factor): slots past the end of
         // a list point there.  Byte offsets into the matrix are 32 bits wide in the v6 kernel.
-        const int64_t n_in = by_col ? r.nr : tj.n;
+        const int64_t n_in = by_col ? ti.n - r.r0 : tj.n;          // (the zero row of Grow sits behind ALL rows of the type)
         const int64_t zoff = n_in * ldv * 2;
         a.zero_off = (zoff + ldv * 2 < (int64_t)0xffffffffLL && !p->sw.known_generic && !p->sw.known_no_v6) ? (uint32_t)zoff : 0u;
         waves = launch_srp(a, st, p->sw.known_generic);
@@ -1239,7 +1241,9 @@ static void known_cross(skf_plan* p, RelState& r, hipStream_t st, bool on_aux) {
     const int ci = ti.c, cj = tj.c;
     void* part = on_aux ? p->part_aux.ptr : p->part.ptr;
     const size_t part_bytes = on_aux ? p->part_aux_bytes : p->part_bytes;
-    GemmArgs g = gemm_args(ti.G.ptr, 1, ci, ti.Gp.ptr, ci, 1, r.Xi.ptr, ci, ci, ci, (int)r.nr, EPI_STORE, 0);    // Xi = G_i^T G_i,prev
+    // (over the rows of the block: under row ownership the block's own share of W, summed over the processes with the rest)
+    GemmArgs g = gemm_args(rows_of(p, ti.G, ti, r.r0), 1, ci, rows_of(p, ti.Gp, ti, r.r0), ci, 1, r.Xi.ptr, ci, ci, ci, (int)r.nr,
+                           EPI_STORE, 0);                                                                         // Xi = G_i^T G_i,prev
     run_gemm(GemmTypes{SKF_F64, p->mt, p->mt}, p->engine, g, 0, part, part_bytes, st);
     g = gemm_args(tj.Gp.ptr, 1, cj, tj.G.ptr, cj, 1, r.Xj.ptr, cj, cj, cj, (int)tj.n, EPI_STORE, 0);             // Xj = G_j,prev^T G_j
     run_gemm(GemmTypes{SKF_F64, p->mt, p->mt}, p->engine, g, 0, part, part_bytes, st);
@@ -1280,21 +1284,30 @@ static void known_operands(skf_plan* p, RelState& r, hipStream_t st, bool second
 // the two residual passes of the factor update: r.A = E T (row lists), r.Q = E^T G_i + G_j U2 (column lists; the
 // residuals of this iteration replace the stored ones), and S_prev <- S
 static void known_row_pass(skf_plan* p, RelState& r, hipStream_t st) { known_pass(p, r, false, SRP_RESIDUAL, st); }
-static void known_col_pass(skf_plan* p, RelState& r, hipStream_t st) {
+// the dense part of Q on the rows [j0, j0 + nj) of the column type: Q += G_j (S^T Gram_i)
+static void known_col_dense(skf_plan* p, RelState& r, int64_t j0, int64_t nj, hipStream_t st, bool second_stream) {
     TypeState& ti = p->types[r.row];
     TypeState& tj = p->types[r.col];
     const int ci = ti.c, cj = tj.c;
+    if (nj <= 0) return;
+    GemmArgs g = gemm_args(rows_of(p, tj.G, tj, j0), cj, 1, r.U2.ptr, ci, 1, (char*)r.Q.ptr + (size_t)j0 * ci * p->esz, ci, (int)nj, ci,
+                           cj, EPI_ACC, 0);
+    if (second_stream) mixed_gemm_unsplit(p, g, st);
+    else mixed_gemm(p, g, st);
+}
+static void known_col_pass(skf_plan* p, RelState& r, hipStream_t st) {
+    TypeState& ti = p->types[r.row];
+    TypeState& tj = p->types[r.col];
     known_pass(p, r, true, SRP_RESIDUAL, st);
-    GemmArgs g = gemm_args(tj.G.ptr, cj, 1, r.U2.ptr, ci, 1, r.Q.ptr, ci, (int)tj.n, ci, cj, EPI_ACC, 0);
-    mixed_gemm(p, g, st);
-    copy2d(r.Sp.ptr, cj, r.S.ptr, cj, ci, cj, 8, st);
+    known_col_dense(p, r, 0, tj.n, st, false);
+    copy2d(r.Sp.ptr, tj.c, r.S.ptr, tj.c, ti.c, tj.c, 8, st);
 }
 
 // row side of the factor update from the row-side product itself: A = G_i Bf + E T, E_i (+)= A+, D_i (+)= A-
 static void known_row_dense(skf_plan* p, RelState& r, hipStream_t st, bool second_stream) {
     TypeState& ti = p->types[r.row];
     const int ci = ti.c;
-    GemmArgs g = gemm_args(ti.G.ptr, ci, 1, r.Bf.ptr, ci, 1, r.A.ptr, ci, (int)r.nr, ci, ci, EPI_ACC, 0);
+    GemmArgs g = gemm_args(rows_of(p, ti.G, ti, r.r0), ci, 1, r.Bf.ptr, ci, 1, r.A.ptr, ci, (int)r.nr, ci, ci, EPI_ACC, 0);
     if (second_stream) mixed_gemm_unsplit(p, g, st);
     else mixed_gemm(p, g, st);
 }
@@ -1303,11 +1316,13 @@ static void known_row_split(skf_plan* p, RelState& r, bool accumulate, hipStream
     const int ci = ti.c;
     const int64_t total = r.nr * ci;
     if (p->f64)
-        hipLaunchKernelGGL((split_accumulate_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, (double*)ti.E.ptr,
-                           (double*)ti.D.ptr, (const double*)r.A.ptr, total, accumulate ? 1 : 0);
+        hipLaunchKernelGGL((split_accumulate_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st,
+                           (double*)rows_of(p, ti.E, ti, r.r0), (double*)rows_of(p, ti.D, ti, r.r0), (const double*)r.A.ptr, total,
+                           accumulate ? 1 : 0);
     else
-        hipLaunchKernelGGL((split_accumulate_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st, (float*)ti.E.ptr,
-                           (float*)ti.D.ptr, (const float*)r.A.ptr, total, accumulate ? 1 : 0);
+        hipLaunchKernelGGL((split_accumulate_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st,
+                           (float*)rows_of(p, ti.E, ti, r.r0), (float*)rows_of(p, ti.D, ti, r.r0), (const float*)r.A.ptr, total,
+                           accumulate ? 1 : 0);
     check_launch("split_accumulate");
 }
 static void known_row_side(skf_plan* p, RelState& r, bool accumulate, hipStream_t st, bool second_stream) {
@@ -1919,10 +1934,16 @@ static bool owned_can_overlap(const skf_plan* p) {
     if (!p->overlap || p->engine != SKF_ENGINE_MFMA) return false;
     for (const ThetaState& th : p->thetas)
         if (!th.sparse) return false;
+    // ranks above 512 (DFMC: 256): a c x c product on the second stream could ask for the main stream's split-K scratch;
+    // every rank <= 64: launch-bound graphs, one stream.  Mixed ranks (config 5: 16 ... 256) do overlap: the replicated
+    // pseudo-inverses (0.65 ms at order 256) then run beside the list passes instead of in front of them.
     const int cmax = (p->variant == SKF_DFMC) ? 256 : 512;
-    for (const TypeState& t : p->types)
-        if (t.c > cmax || t.c <= SMALLC) return false;
-    return true;
+    bool all_small = true;
+    for (const TypeState& t : p->types) {
+        if (t.c > cmax) return false;
+        if (t.c > SMALLC) all_small = false;
+    }
+    return !all_small;
 }
 
 static void iterate_owned(skf_plan* p, hipStream_t st) {
@@ -1998,6 +2019,8 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
     auto finish_type = [&](size_t i) {
         TypeState& t = p->types[i];
         finished[i] = 1;
+        // known-entries relations: the factor their stored residuals belong to (all rows: every one is current here)
+        if (t.keep_prev) SKF_HIP(hipMemcpyAsync(t.Gp.ptr, t.G.ptr, (size_t)t.n * t.c * p->esz, hipMemcpyDeviceToDevice, ax));
         if (t.tn > 0) {
             void* G = own(t.G, t);
             void* E = own(t.E, t);
@@ -2071,6 +2094,8 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
         TypeState& tj = p->types[r.col];
         if (r.absent) {
             SKF_HIP(hipMemsetAsync(r.W.ptr, 0, r.W.bytes, st));
+        } else if (r.kn) {                  // lists of known entries: the block's share of W from its stored residuals (skf_known.h)
+            known_w(p, r, st);
         } else {
             GemmArgs g = gemm_args(own(ti.G, ti), 1, ti.c, r.P.ptr, tj.c, 1, r.W.ptr, tj.c, ti.c, tj.c, (int)r.nr, EPI_STORE, 0);
             wide_gemm(p, g, st);
@@ -2086,7 +2111,8 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
         if (r.absent) SKF_HIP(hipMemsetAsync(r.Q.ptr, 0, (size_t)tj.n * ti.c * p->esz, st));
-        else contraction_Q(p, r, st);
+        else if (r.kn) known_pass(p, r, true, SRP_RESIDUAL, st);       // E^T G_i of the block's rows (the dense part of Q follows
+        else contraction_Q(p, r, st);                                  //  the scatter, on the owned rows of the column type)
         rec(ev_r(k, R_Q), st);
         wait(cs, ev_r(k, R_Q));
         collective(c, COLL_REDUCE_SCATTER, r.Q.ptr, (size_t)tj.chunk * ti.c, p->mt, cs);
@@ -2141,7 +2167,10 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
         TypeState& tj = p->types[r.col];
         const int ci = ti.c, cj = tj.c;
         wait(ax, ev_p);
-        if (!r.absent) {
+        if (!r.absent && r.kn) {            // the row-side product P S^T = G_i (S Gram_j S^T) + E T was formed by the row pass
+            known_row_split(p, r, touched[r.row] != 0, ax);
+            touched[r.row] = 1;
+        } else if (!r.absent) {
             if (fused) {
                 side_update(p, r.P.ptr, cj, cj, Sm[k], 1, cj, ti, own(ti.G, ti), own(ti.E, ti), own(ti.D, ti), (int)r.nr, nullptr,
                             nullptr, false, touched[r.row] != 0, nan_upd, ax);
@@ -2158,6 +2187,10 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
         }
         side_done(r.row);
         wait(ax, ev_r(k, R_QX));
+        if (r.kn) {                         // Q = G_j (S^T Gram_i) + E^T G_i: the dense part on the owned rows, then S_prev <- S
+            known_col_dense(p, r, tj.t0, tj.tn, ax, multi);
+            if (!r.absent) copy2d(r.Sp.ptr, cj, r.S.ptr, cj, ci, cj, 8, ax);
+        }
         if (tj.tn > 0) {
             const void* Qo = (const char*)r.Q.ptr + (size_t)tj.t0 * ci * p->esz;
             if (fused) {
@@ -2185,7 +2218,7 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
     for (size_t k = 0; k < nr; ++k) {
         RelState& r = p->rels[k];
         if (!(dfmc && r.masked)) continue;
-        if (!r.absent) contraction_P(p, r, st);
+        if (!r.absent && !r.kn) contraction_P(p, r, st);
         w_partial(k);
     }
     // ... and the unmasked relations: P, W, Q
@@ -2203,7 +2236,14 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
         TypeState& ti = p->types[r.row];
         TypeState& tj = p->types[r.col];
         backbone_chain(k);
-        if (!r.absent) {
+        if (r.kn) {                         // gathered vectors T = G_j S^T and the c x c operands of the dense parts
+            if (!r.absent) {
+                known_operands(p, r, ax, multi);
+            } else {                        // (no rows of the relation here: only U2 = S^T Gram_i for this process's rows of Q)
+                GemmArgs g = gemm_args(r.S.ptr, 1, tj.c, ti.Gram.ptr, ti.c, 1, r.U2.ptr, ti.c, tj.c, ti.c, ti.c, EPI_STORE, 0);
+                small_gemm(p, g, ax);
+            }
+        } else if (!r.absent) {
             GemmArgs g = gemm_args(own(ti.G, ti), ti.c, 1, r.S.ptr, tj.c, 1, r.H.ptr, tj.c, (int)r.nr, tj.c, ti.c, EPI_STORE, 0);
             if (multi) mixed_gemm_unsplit(p, g, ax);
             else mixed_gemm(p, g, ax);
@@ -2224,7 +2264,12 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
         if (!(dfmc && r.masked)) continue;
         TypeState& tj = p->types[r.col];
         wait(st, ev_r(k, R_S));
-        if (!r.absent) {
+        if (r.kn) {                         // the row pass stands for completion + P: A = E T + G_i (S Gram_j S^T)
+            if (!r.absent) {
+                known_row_pass(p, r, st);
+                known_row_dense(p, r, st, false);
+            }
+        } else if (!r.absent) {
             if (r.mask) {
                 if (p->bf16) {
                     launch_tile_epilogue(p, r, MODE_COMPLETE, st, false);
@@ -2260,6 +2305,7 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
     for (size_t i = 0; i < nt; ++i) wait(st, ev_t(i, p->bf16 ? T_GT : T_G));
     p->masters_stale = false;
     for (const TypeState& t : p->types) p->masters_stale = p->masters_stale || !t.gather_master;
+    p->kn_first = false;
 }
 
 // SKF_BF16 plans with owned rows gather only the bf16 operand rows of a type without constraints; at the end of
@@ -2954,17 +3000,31 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 while (q > 1 && (double)cap / ((double)n_out * q) < 64.0) q /= 2;
                 return q;
             };
-            for (RelState& s : p->rels) {
-                if (s.kn_cap <= 0) continue;
-                const double cells = (double)s.nr * (double)p->types[s.col].n;
-                const double share = cells > 0 ? (double)s.kn_cap / cells : 1.0;
+            for (size_t rk = 0; rk < p->rels.size(); ++rk) {
+                RelState& s = p->rels[rk];
                 const int ci = p->types[s.row].c;
-                if (p->sliced || mode == 0 || share > 0.25 || (mode != 1 && share * ci > 4.0) || ci > 64 * SRP_MAXREP ||
-                    s.kn_cap > 2000000000LL) {
-                    s.kn_cap = 0;
-                    continue;
+                if (p->owned) {
+                    // ownership-aligned row blocks: the caller decided for ALL processes alike (SKF_REL_KNOWN_LISTS); a process
+                    // without rows of the relation keeps the flag -- it adds the dense part of Q on ITS rows of the column type
+                    const bool lists = (relations[rk].flags & SKF_REL_KNOWN_LISTS) != 0 && s.masked && p->variant == SKF_DFMC;
+                    if (lists && (ci > 64 * SRP_MAXREP || s.kn_cap > 2000000000LL || (!s.absent && s.kn_cap <= 0)))
+                        SKF_FAIL(SKF_E_INVALID, "relation %zu: SKF_REL_KNOWN_LISTS needs a bound on the known entries of the local rows", rk);
+                    if (!lists) {
+                        s.kn_cap = 0;
+                        continue;
+                    }
+                } else {
+                    if (s.kn_cap <= 0) continue;
+                    const double cells = (double)s.nr * (double)p->types[s.col].n;
+                    const double share = cells > 0 ? (double)s.kn_cap / cells : 1.0;
+                    if (p->sliced || mode == 0 || share > 0.25 || (mode != 1 && share * ci > 4.0) || ci > 64 * SRP_MAXREP ||
+                        s.kn_cap > 2000000000LL) {
+                        s.kn_cap = 0;
+                        continue;
+                    }
                 }
                 s.kn = true;
+                if (s.absent) continue;             // (no lists here: only the flag)
                 s.kn_pc = pick_parts(p->types[s.col].n, s.nr, ci, s.kn_cap);        // row lists gather the column objects' vectors
                 s.kn_pr = pick_parts(s.nr, p->types[s.col].n, ci, s.kn_cap);        // column lists gather the row objects' vectors
                 s.kn_pw = ((p->types[s.col].n + s.kn_pc - 1) / s.kn_pc + 63) / 64 * 64;
@@ -3015,6 +3075,10 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 if (p->bf16) t.need_rows = true;
             }
             for (const ThetaState& th : p->thetas) p->types[th.type].gather_master = true;
+            // ... and the types of a masked relation (the same on every process, whatever it holds of the relation): the
+            // known-entry form multiplies the f32 rows of both factors (cross-Gram matrices, T = G_j S^T, the dense part of Q)
+            for (const RelState& r : p->rels)
+                if (r.masked) p->types[r.row].gather_master = p->types[r.col].gather_master = true;
         }
         // ---- workspace layout: n-sized buffers in the master type, every c x c matrix in f64
         const size_t es = p->esz;
@@ -3122,6 +3186,8 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             want_part(ti.c, tj.c, ti.c > tj.c ? ti.c : tj.c, true);
             want_part(ti.c, ti.c, tj.c, true);
             want_part(tj.c, tj.c, ti.c, true);
+            if (nr <= 0 && r.kn) add_slot(p, r.U2, cc);             // (owned rows, none of this relation's here: the dense part of Q
+                                                                    //  is still added on this process's rows of the column type)
             if (nr <= 0) continue;
             if (r.kn) {
                 // the known entries as row lists and column lists, the gathered vectors, the row-side product, c x c scratch
@@ -4070,14 +4136,16 @@ int skf_relation_sqerr(skf_plan* p, int32_t rel, double* out, void* stream) {
                 wide_gemm(p, h, st);
             };
             // (the partial slots [1, waves] belong to the pass below; slot 0 collects the trace terms)
-            gram_of(ti.G.ptr, ti.G.ptr, r.Xi.ptr, ci, r.nr);
+            const void* Gi_b = rows_of(p, ti.G, ti, r.r0);                   // the rows of the block (row ownership: the local ones)
+            const void* Gp_b = ti.Gp.ptr ? rows_of(p, ti.Gp, ti, r.r0) : nullptr;
+            gram_of(Gi_b, Gi_b, r.Xi.ptr, ci, r.nr);
             gram_of(tj.G.ptr, tj.G.ptr, r.Xj.ptr, cj, tj.n);
             trace_term(r.Xi.ptr, r.S.ptr, r.Xj.ptr, r.S.ptr, 1.0, true);
             if (!p->kn_first) {
-                gram_of(ti.Gp.ptr, ti.G.ptr, r.Xi.ptr, ci, r.nr);            // G_i,prev^T G_i
+                gram_of(Gp_b, Gi_b, r.Xi.ptr, ci, r.nr);                     // G_i,prev^T G_i
                 gram_of(tj.G.ptr, tj.Gp.ptr, r.Xj.ptr, cj, tj.n);            // G_j^T G_j,prev
                 trace_term(r.Xi.ptr, r.S.ptr, r.Xj.ptr, r.Sp.ptr, -2.0, false);
-                gram_of(ti.Gp.ptr, ti.Gp.ptr, r.Xi.ptr, ci, r.nr);
+                gram_of(Gp_b, Gp_b, r.Xi.ptr, ci, r.nr);
                 gram_of(tj.Gp.ptr, tj.Gp.ptr, r.Xj.ptr, cj, tj.n);
                 trace_term(r.Xi.ptr, r.Sp.ptr, r.Xj.ptr, r.Sp.ptr, 1.0, false);
             }

@@ -120,12 +120,16 @@ def owned_plan(variant, rel_list, theta_list, obj_types, n_obj, obj_type2rank, d
     """The plan of rank `rank` of `size` in a fit sharded by OWNERSHIP (SKF_OPT_OWNED_ROWS): the rank owns the same share
     of the rows of every object type (`_engine.owned_rows`) and holds exactly those rows of every relation whose row type
     it is -- work is 1 / size of every relation, the row-side terms never leave the rank -- and every constraint."""
-    from ..._engine import is_binary_matrix, owned_rows
+    from ..._engine import is_binary_matrix, owned_rows, known_lists_pay
     local = []
     for (i, j, m, mask) in rel_list:
         begin, count, _ = owned_rows(dtype, n_obj[i], rank, size)
         info = {'masked': mask is not None, 'col_side': True, 'row_begin': begin if count else 0, 'n_rows': count,
                 'absent': count == 0}
+        if mask is not None and variant == nat.SKF_DFMC:      # lists of the known entries: one decision for all ranks
+            mk = np.asarray(mask, dtype=bool)
+            info['known_lists'] = known_lists_pay(mk.size - int(np.count_nonzero(mk)), mk.shape[0], mk.shape[1],
+                                                  int(obj_type2rank[i]), dtype)
         if dtype == 'bf16' and mask is None:         # decided on the whole relation: the same path on every rank
             info['binary'] = is_binary_matrix(m)
         if count == 0:

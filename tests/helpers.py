@@ -277,7 +277,7 @@ class ThreadGroup(object):
         return sum((2.0 if op == 0 else 1.0) * f * (n if op == 0 else n * self.world) * es for op, n, es in self.calls)
 
 
-def fit_owned(variant, R, M, Theta, types, rank, G0, max_iter, size, dtype='f64', calls=1, group=None):
+def fit_owned(variant, R, M, Theta, types, rank, G0, max_iter, size, dtype='f64', calls=1, group=None, sqerr=None):
     """Ownership-sharded fit (SKF_OPT_OWNED_ROWS) with `size` ranks of this process driven through skf_iterate_dist by a
     ThreadGroup; `calls` calls of max_iter / calls iterations each.  Returns [(G, S) of every rank] (+ the group)."""
     import skfusion_amd._native as nat
@@ -305,6 +305,8 @@ def fit_owned(variant, R, M, Theta, types, rank, G0, max_iter, size, dtype='f64'
                 S.setdefault((i, j), []).append(p.get_backbone(k))
             out.append((G, S))
         out_bytes = [p.exchange_bytes(size) for p in plans]
+        if sqerr is not None:                       # squared errors of every relation: each rank holds those of ITS rows
+            sqerr.extend([[p.relation_sqerr(k) for k in range(len(rel))] for p in plans])
         return out, grp, out_bytes
     finally:
         for p in plans:

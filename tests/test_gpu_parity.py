@@ -602,6 +602,11 @@ def test_owned_rows_sharding_on_the_device(rt, monkeypatch):
     O.test_owned_rows_c5_movielens_style_dfmc()
     O.test_owned_rows_dense_constraint_in_the_bf16_engine()
     O.test_owned_rows_rank_deficient_gram()
+    for variant in ('dfmf', 'dfmc'):
+        O.test_owned_rows_mixed_ranks(variant)
+    for dtype, ranks, tol in (('f64', {'a': 16, 'b': 12, 'c': 8}, 1e-9), ('bf16', {'a': 128, 'b': 64, 'c': 16}, 2e-2)):
+        O.test_owned_rows_keep_the_lists_of_known_entries(dtype, ranks, tol, monkeypatch)
+    monkeypatch.delenv('SKF_DFMC_SPARSE', raising=False)
     O.test_exchange_bytes_of_config_3_on_8_ranks(rt)
     O.test_owned_rows_abi_errors(rt)
     z = golden('c3_scaled.npz')

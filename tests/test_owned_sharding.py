@@ -55,13 +55,13 @@ def test_owned_rows_c5_movielens_style_dfmc():
                 assert relerr(S[i, j][0], z['dfmc/S_%s_%s_0_it1' % (i, j)]) < 1e-9
 
 
-def _wide_graph(seed=11):
+def _wide_graph(seed=11, rank=None):
     """Ranks above 64 (the three-stream schedule with the exchanges on their own stream), row counts that split at multiples
     of 64 (bf16), a masked relation, a None mask, a sparse constraint, a type that sits on the column side only."""
     rs = np.random.RandomState(seed)
     types = ['u', 'm', 'g']
     n = {'u': 200, 'm': 150, 'g': 140}
-    rank = {'u': 66, 'm': 70, 'g': 68}
+    rank = rank or {'u': 66, 'm': 70, 'g': 68}
     R = {('u', 'm'): [rs.rand(200, 150)], ('m', 'g'): [(rs.rand(150, 140) < 0.2).astype(np.float64)],
          ('u', 'g'): [rs.rand(200, 140) - 0.2]}
     M = {('u', 'm'): [rs.rand(200, 150) < 0.6], ('m', 'g'): [None], ('u', 'g'): [None]}
@@ -79,8 +79,8 @@ def test_owned_rows_wide_ranks_all_engines(variant):
     the partial Gram / W / Q sums: f32 1e-5; bf16 1e-3 -- a factor entry that lands on the other side of a bf16 rounding
     boundary moves the operand by 2^-9; bf16 DFMC 5e-3: the single-device pipeline forms W of the masked relation through
     the narrower factor, (R^T G_i)^T G_j, the sharded one as G_i^T (R G_j) -- other bf16 products).  bf16: the constrained
-    type ('u') gathers its f32 rows, the others bf16 rows only -- 'm', the column type of the masked relation, among them:
-    the bf16 operand of its completion tiles comes from the gathered rows."""
+    type ('u') gathers its f32 rows, and so do both types of a masked relation (DFMC: 'u' and 'm'); the others travel as bf16
+    rows only."""
     R, M, Theta, types, rank, G0 = _wide_graph()
     its = 3
     if variant == 'dfmf':
@@ -105,12 +105,38 @@ def test_owned_rows_wide_ranks_all_engines(variant):
                 for G, _ in out[1:]:
                     np.testing.assert_array_equal(G[t, t], out[0][0][t, t])
             # per iteration what skf_exchange_bytes says; bf16: plus ONE gather of the f32 rows of the types that travel as
-            # bf16 rows ('m' and 'g': 'u' carries a constraint and gathers its f32 rows every iteration) at the end of the call
+            # bf16 rows at the end of the call ('u' carries a constraint and gathers its f32 rows every iteration; in the DFMC
+            # fit so does 'm', the other type of the masked relation)
             final = 0.0
             if dtype == 'bf16':
                 final = (size - 1) / float(size) * sum(owned_rows(dtype, G0[t, t].shape[0], 0, size)[2] * size * rank[t] * 4
-                                                       for t in ('m', 'g'))
+                                                       for t in (('g',) if variant == 'dfmc' else ('m', 'g')))
             assert abs(grp.bytes_sent_per_rank() - its * said[0] - final) <= float(its)
+
+
+@pytest.mark.parametrize('variant', ['dfmf', 'dfmc'])
+def test_owned_rows_mixed_ranks(variant):
+    """Ranks on both sides of 64 in one graph (config 5 has 16 ... 256): the three-stream schedule is kept, the small
+    types' c x c work runs beside the contractions.  f64 against the oracle, f32 / bf16 against the single-device fit."""
+    R, M, Theta, types, rank, G0 = _wide_graph(rank={'u': 72, 'm': 16, 'g': 64})
+    its = 3
+    if variant == 'dfmf':
+        Go, So = orc.dfmf(R, Theta, types, rank, max_iter=its, G0=G0)
+    else:
+        Go, So = orc.dfmc(R, M, Theta, types, rank, max_iter=its, G0=G0)
+    for dtype, tol in (('f64', 1e-9), ('f32', 1e-5), ('bf16', 5e-3)):
+        if dtype == 'f64':
+            Gs, Ss = Go, So
+        elif variant == 'dfmf':
+            Gs, Ss = _dfmf.dfmf(R, Theta, types, rank, max_iter=its, G0=G0, dtype=dtype)
+        else:
+            Gs, Ss = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=its, G0=G0, dtype=dtype)
+        out, _, _ = fit_owned(variant, R, M, Theta, types, rank, G0, its, 2, dtype=dtype)
+        for G, S in out:
+            for t in types:
+                assert relerr(G[t, t], Gs[t, t]) < tol, (dtype, t)
+            for k in Ss:
+                assert relerr(S[k][0], Ss[k][0]) < 10 * tol, (dtype, k)
 
 
 def _bare_plan(lib, sizes, ranks, rels, dtype, part, flags):
@@ -244,3 +270,42 @@ def test_owned_rows_rank_deficient_gram():
         e = orc.relation_errors(R, G, S)
         for k in e:
             assert abs(e[k][0] - eo[k][0]) <= 1e-6 * max(1.0, eo[k][0])
+
+
+@pytest.mark.parametrize('dtype,ranks,tol', [('f64', {'a': 16, 'b': 12, 'c': 8}, 1e-9), ('bf16', {'a': 128, 'b': 64, 'c': 16}, 2e-2)])
+def test_owned_rows_keep_the_lists_of_known_entries(dtype, ranks, tol, monkeypatch):
+    """DFMC on the known entries only (skf_known.h) UNDER row ownership: a rank keeps the lists of its own rows; the
+    stored-residual pass gives its share of W (all-reduce), the row pass its rows of P S^T, the column pass its partial
+    E^T G_i (reduce-scatter) and every rank -- also one without rows of the relation -- adds the dense part G_j (S^T Gram_i)
+    on ITS rows of the column type.  2 and 3 ranks against the oracle (f64 1e-9; bf16: engine tolerance, v6 list kernel at
+    rank 128), the summed squared errors of the ranks against the oracle's."""
+    import known_cases as KC
+    monkeypatch.setenv('SKF_DFMC_SPARSE', '1')
+    n = {'a': 200, 'b': 140, 'c': 130}
+    types, rels, thetas, G0 = KC.masked_graph(n, ranks, 0.05, seed=3)
+    R = {(i, j): [m] for i, j, m, _ in rels}
+    M = {(i, j): [mask] for i, j, _, mask in rels}
+    Theta = {(t, t): [th] for t, th in thetas}
+    G0d = {(t, t): G0[t] for t in types}
+    its = 4
+    Go, So = orc.dfmc(R, M, Theta, types, ranks, max_iter=its, G0=G0d)
+    # the oracle's errors on ITS working copy (masked entries = the completion of the last iteration)
+    Rw = {k: [m.copy() for m in v] for k, v in R.items()}
+    for k, masks in M.items():
+        if masks[0] is not None:
+            Rw[k][0][masks[0]] = (Go[k[0], k[0]] @ So[k][0] @ Go[k[1], k[1]].T)[masks[0]]
+    for size in (2, 3):
+        sq = []
+        out, grp, said = fit_owned('dfmc', R, M, Theta, types, ranks, G0d, its, size, dtype=dtype, sqerr=sq)
+        for G, S in out:
+            for t in types:
+                assert relerr(G[t, t], Go[t, t]) < tol, (dtype, size, t)
+        if dtype == 'f64':
+            tot = np.sum(np.array(sq), axis=0)
+            # (the engine's residual of a list relation refers to the completion of the iteration BEFORE the last update of S:
+            #  compare the unmasked relation exactly and the masked ones through their known entries' share)
+            eo = orc.relation_errors(R, Go, So)
+            k_unmasked = [k for k, (i, j, m, mask) in enumerate(rels) if mask is None][0]
+            i, j = rels[k_unmasked][0], rels[k_unmasked][1]
+            assert abs(np.sqrt(tot[k_unmasked]) - eo[i, j][0]) < 1e-8 * eo[i, j][0]
+            assert np.isfinite(tot).all() and (tot > 0).all()

@@ -1,6 +1,6 @@
 """One iteration of an --emulate-rank rocprofv3 kernel trace (rocpd sqlite) as a timeline: start offset, duration, stream.
 The iteration is cut at the operand refresh of the last type (transpose_to_bf16_kernel<unsigned short>) before a
-chol_inverse_blocked_kernel.   python tools/timeline_owned.py <prof_results.db>"""
+chol_inverse_blocked_kernel / sweep_inverse_kernel.   python tools/timeline_owned.py <prof_results.db>"""
 import re
 import sqlite3
 import sys
@@ -10,7 +10,7 @@ def main(path):
     cur = sqlite3.connect(path).cursor()
     rows = cur.execute("select name, grid_x, grid_y, grid_z, workgroup_x, (end-start)/1e3, start, stream_id, end "
                        "from kernels order by start").fetchall()
-    idx = [i for i, r in enumerate(rows) if 'chol_inverse_blocked' in r[0]]
+    idx = [i for i, r in enumerate(rows) if 'chol_inverse_blocked' in r[0] or 'sweep_inverse' in r[0]]
 
     def begin(i):
         while i > 0 and 'transpose_to_bf16_kernel<unsigned short>' not in rows[i - 1][0]:
