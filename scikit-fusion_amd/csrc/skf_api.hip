@@ -4330,15 +4330,11 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
         const int total = np * np;
         if (dtype == SKF_F64)
             hipLaunchKernelGGL((eigh_pack_kernel<double>), dim3(elem_grid(total)), dim3(256), 0, st, eA, np,
-                               (const double*)A, lda, n);
+                               (const double*)A, lda, n, eN, eNo);
         else
             hipLaunchKernelGGL((eigh_pack_kernel<float>), dim3(elem_grid(total)), dim3(256), 0, st, eA, np,
-                               (const float*)A, lda, n);
+                               (const float*)A, lda, n, eN, eNo);
         check_launch("eigh_pack");
-        int hn = np, ho = n;
-        SKF_HIP(hipMemcpyAsync(eN, &hn, sizeof(int), hipMemcpyHostToDevice, st));
-        SKF_HIP(hipMemcpyAsync(eNo, &ho, sizeof(int), hipMemcpyHostToDevice, st));
-        SKF_HIP(hipStreamSynchronize(st));
         EighArgs e;
         e.A = eA; e.V = eV; e.Vs = eVs; e.w = eW; e.stride = (int64_t)np * np; e.wstride = np;
         e.n = eN; e.n_orig = eNo; e.chol_ok = eOk; e.max_sweeps = 30;

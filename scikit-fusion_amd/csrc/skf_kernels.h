@@ -2941,7 +2941,15 @@ __global__ __launch_bounds__(256) void chol_unpack_kernel(T* __restrict__ K, int
 // the padding row/column is decoupled (zero off-diagonal, zero diagonal -> eigenvalue 0).
 template <typename T>
 __global__ __launch_bounds__(256) void eigh_pack_kernel(double* __restrict__ dst, int n_pad,
-                                                        const T* __restrict__ src, int64_t lds, int n) {
+                                                        const T* __restrict__ src, int64_t lds, int n,
+                                                        int* __restrict__ n_pad_out = nullptr,
+                                                        int* __restrict__ n_out = nullptr) {
+    // (the stand-alone operator has no bind step that could upload the two orders: written here, the call needs neither
+    //  host-to-device copies nor a stream synchronisation)
+    if (n_pad_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        n_pad_out[0] = n_pad;
+        n_out[0] = n;
+    }
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_pad * n_pad; idx += gridDim.x * blockDim.x) {
         const int r = idx / n_pad, c = idx % n_pad;
         dst[idx] = (r < n && c < n) ? (double)src[(int64_t)r * lds + c] : 0.0;

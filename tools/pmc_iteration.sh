@@ -7,7 +7,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 STEPS=${PMC_STEPS:-2}
 for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$OUT/$c" -o pmc -- python "$OLDPWD/bench.py" --steps $STEPS --warmup 1 --no-cpu-baseline --no-engines ${PMC_ARGS:-} ) > "$OUT/$c.log" 2>&1
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$OUT/$c" -o pmc -- python "$OLDPWD/bench.py" --steps $STEPS --warmup 1 --no-cpu-baseline --no-engines --no-workloads --no-pmc --sustained-steps 0 ${PMC_ARGS:-} ) > "$OUT/$c.log" 2>&1
   echo "pmc $c exit $?"
 done
 python tools/pmc_iteration.py "$OUT" $((STEPS + 1)) | tee "$OUT/traffic.txt"
