@@ -588,6 +588,17 @@ def test_row_block_sharding_c3_scaled_c5_and_probe(monkeypatch):
             within(relerr(G[t, t], Gw[t, t]), 2e-3, 'c5 scaled bf16, 3 row blocks vs whole relations: G_%s after 5 iterations' % t)
 
 
+def test_owned_rows_random_graphs(rt):
+    """tools/fuzz_owned.py: random graphs (1 .. 700 objects, ranks on both sides of 64, multi-relations, masks of every
+    density, sparse and dense constraints, 2 .. 4 ranks) through the ownership-sharded fit, every engine against the oracle
+    and against what ONE device deviates by on the same graph."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import fuzz_owned
+    assert fuzz_owned.fuzz(10, 5, 3) == 0
+
+
 def test_owned_rows_sharding_on_the_device(rt, monkeypatch):
     """SKF_OPT_OWNED_ROWS on the hardware: the ranks of a group as threads of this process on ONE GPU (helpers.ThreadGroup),
     every plan driving skf_iterate_dist with its three streams (contractions / chains and side products / exchanges) -- the
