@@ -441,6 +441,7 @@ struct Switches {
     bool no_gram_aux = false;      // SKF_GRAM_AUX=0        DFMC on known entries: Gram / cross-Gram products on the main stream (A/B)
     bool no_small_fused = false;   // SKF_NO_SMALL_FUSED=1  small graphs on the general staged schedule (~33 launches per iteration)
     bool no_sweep = false;         // SKF_PINV_SWEEP=0      orders 65 .. 256: blocked Cholesky inverse + unpack instead of the blocked sweep (A/B)
+    bool small_sweep1 = false;     // SKF_SMALL_SWEEP4=0    small graphs: one pivot per barrier in the register sweep (same bits; A/B, tests)
     static Switches read() {
         auto on = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
         Switches w;
@@ -457,6 +458,7 @@ struct Switches {
         { const char* ga = getenv("SKF_GRAM_AUX"); w.no_gram_aux = ga && atoi(ga) == 0; }
         w.no_small_fused = on("SKF_NO_SMALL_FUSED");
         { const char* sv = getenv("SKF_PINV_SWEEP"); w.no_sweep = sv && atoi(sv) == 0; }
+        { const char* s4 = getenv("SKF_SMALL_SWEEP4"); w.small_sweep1 = s4 && atoi(s4) == 0; }
         const char* st = getenv("SKF_SIDE_TILE");
         w.side_tile = st ? atoi(st) : 0;
         const char* ap = getenv("SKF_AUX_PRIO");
@@ -2608,23 +2610,23 @@ static void iterate_small_fused_t(skf_plan* p, hipStream_t st, unsigned n_batch 
         static DeviceOnce once_c, once_b, once_u;
         allow_dynamic_lds(once_c, small_contract_kernel<T, true>, SM_TILE_BYTES);
         allow_dynamic_lds(once_b, small_backbone_kernel<true>, bb_lds);
-        allow_dynamic_lds(once_u, small_update_kernel<T, true>, SM_TILE_BYTES);
+        allow_dynamic_lds(once_u, small_update_kernel<T, true>, SM_TILE3_BYTES);
         hipLaunchKernelGGL((small_contract_kernel<T, true>), dim3(n1, n_batch), dim3(256), SM_TILE_BYTES, st, tb, tbs, j1);
         check_launch("small_contract");
         hipLaunchKernelGGL((small_backbone_kernel<true>), dim3(n2, n_batch), dim3(256), bb_lds, st, tb, tbs);
         check_launch("small_backbone");
-        hipLaunchKernelGGL((small_update_kernel<T, true>), dim3(n3, n_batch), dim3(256), SM_TILE_BYTES, st, tb, tbs, j3);
+        hipLaunchKernelGGL((small_update_kernel<T, true>), dim3(n3, n_batch), dim3(256), SM_TILE3_BYTES, st, tb, tbs, j3);
         check_launch("small_update");
     } else {                    // one plan: its tables are the kernel argument
         static DeviceOnce once_c, once_b, once_u;
         allow_dynamic_lds(once_c, small_contract_kernel<T, false>, SM_TILE_BYTES);
         allow_dynamic_lds(once_b, small_backbone_kernel<false>, bb_lds);
-        allow_dynamic_lds(once_u, small_update_kernel<T, false>, SM_TILE_BYTES);
+        allow_dynamic_lds(once_u, small_update_kernel<T, false>, SM_TILE3_BYTES);
         hipLaunchKernelGGL((small_contract_kernel<T, false>), dim3(n1), dim3(256), SM_TILE_BYTES, st, tb, tbs, j1);
         check_launch("small_contract");
         hipLaunchKernelGGL((small_backbone_kernel<false>), dim3(n2), dim3(256), bb_lds, st, tb, tbs);
         check_launch("small_backbone");
-        hipLaunchKernelGGL((small_update_kernel<T, false>), dim3(n3), dim3(256), SM_TILE_BYTES, st, tb, tbs, j3);
+        hipLaunchKernelGGL((small_update_kernel<T, false>), dim3(n3), dim3(256), SM_TILE3_BYTES, st, tb, tbs, j3);
         check_launch("small_update");
     }
     p->first_iter = false;
@@ -3671,6 +3673,7 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             tb.eig.max_sweeps = 30;
             tb.defl_lo = deflation_lo(p->sw); tb.defl_hi = 1e-7;
             tb.lds_rank = p->eig_maxn < 64 ? p->eig_maxn : 64;          // packed r (r + 1) / 2 doubles inside the staging tiles
+            tb.sweep_single = p->sw.small_sweep1 ? 1 : 0;
             int64_t goff = 0, woff = 0;
             for (size_t i = 0; i < p->types.size(); ++i) {
                 TypeState& t = p->types[i];

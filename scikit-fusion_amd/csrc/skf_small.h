@@ -47,12 +47,13 @@ struct SmTables {
     double chol_thr;
     EighArgs eig;                // the fall-back of a declined sweep: deflation / eigen-solver scratch of the plan
     double defl_lo, defl_hi;
-    int lds_rank, pad;
+    int lds_rank, sweep_single;  // sweep_single: one pivot per barrier (SKF_SMALL_SWEEP4=0; tests: same bits either way)
     SmType t[SM_MAXT];
     SmRel r[SM_MAXR];
     SmTheta th[SM_MAXTH];
 };
 enum { SMJ_P = 0, SMJ_Q = 1, SMJ_GRAM = 2, SMJ_THETA = 3 };
+// (Gram shares of 128 / 256 rows, measured on dicty: the share's K loop grows by what the sum of the shares saves -- 9.1 / 9.3 / 9.0 k it/s)
 constexpr int SM_QROWS = 256, SM_GROWS = 64;       // rows of the relation per Q share / of the factor per Gram share
 struct SmJob { int kind, idx, r0, nr, part, k0, nk, pad; };      // Q jobs: rows [k0, k0 + nk) of the relation, share `part`
 
@@ -140,6 +141,65 @@ struct SmTile {
     }
 };
 
+// t1 += A * B1 and t2 += A * B2 over the same K tiles of A (the two type-term products G sum B- / G sum B+ of the update
+// launch): one staged A tile, one round trip per K tile for both -- every K tile whose operand another workgroup wrote in
+// the previous launch costs a trip through memory (~2 us on dicty).  Same order of the K tiles, separate accumulators: the
+// bits of two mma() calls.
+constexpr int SM_TILE3_BYTES = 3 * SM_BK * SM_LD * 8;
+template <typename T, class FA, class FB1, class FB2>
+__device__ __forceinline__ void sm_mma_dual(SmTile<T>& t1, SmTile<T>& t2, int K, FA a_at, FB1 b1_at, FB2 b2_at, bool a_kfast,
+                                            T* As, T* Bs1, T* Bs2) {
+    typedef Mfma<T> MF;
+    constexpr int PER = SmTile<T>::PER, WR = SmTile<T>::WR, WC = SmTile<T>::WC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    T ra[PER], rb1[PER], rb2[PER];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = tid + 256 * q;
+            const int m = a_kfast ? e / SM_BK : e % 64, kk = a_kfast ? e % SM_BK : e / 64;
+            ra[q] = (k0 + kk < K) ? a_at(m, k0 + kk) : (T)0;
+            const int kb = e / 64, n = e % 64;
+            rb1[q] = (k0 + kb < K) ? b1_at(k0 + kb, n) : (T)0;
+            rb2[q] = (k0 + kb < K) ? b2_at(k0 + kb, n) : (T)0;
+        }
+    };
+    if (K > 0) fetch(0);
+    for (int k0 = 0; k0 < K; k0 += SM_BK) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = tid + 256 * q;
+            const int m = a_kfast ? e / SM_BK : e % 64, kk = a_kfast ? e % SM_BK : e / 64;
+            As[kk * SM_LD + m] = ra[q];
+            Bs1[(e / 64) * SM_LD + e % 64] = rb1[q];
+            Bs2[(e / 64) * SM_LD + e % 64] = rb2[q];
+        }
+        __syncthreads();
+        if (k0 + SM_BK < K) fetch(k0 + SM_BK);
+#pragma unroll
+        for (int kk = 0; kk < SM_BK; kk += MF::KT) {
+            T av[WR], bv1[WC], bv2[WC];
+            const int kr = kk + MF::ab_k(lane);
+#pragma unroll
+            for (int i = 0; i < WR; ++i) av[i] = As[kr * SM_LD + wm0 + i * MF::MT + MF::a_row(lane)];
+#pragma unroll
+            for (int j = 0; j < WC; ++j) {
+                bv1[j] = Bs1[kr * SM_LD + wn0 + j * MF::NT + MF::a_row(lane)];
+                bv2[j] = Bs2[kr * SM_LD + wn0 + j * MF::NT + MF::a_row(lane)];
+            }
+#pragma unroll
+            for (int i = 0; i < WR; ++i)
+#pragma unroll
+                for (int j = 0; j < WC; ++j) {
+                    t1.acc[i][j] = MF::mma(av[i], bv1[j], t1.acc[i][j]);
+                    t2.acc[i][j] = MF::mma(av[i], bv2[j], t2.acc[i][j]);
+                }
+        }
+    }
+}
+
 // What the sweep declined: rank-revealing deflation, then the Jacobi eigen-solver for what that declines too, then
 // K = Vs V^T -- the three fall-back launches of the general schedule (pchol_pinv_kernel, jacobi_eigh_kernel,
 // eigh_unpack_pinv_batched_kernel) run by the workgroup that holds the matrix, inside launch 1.  Rare (a rank-deficient
@@ -171,18 +231,40 @@ __device__ __forceinline__ void small_fallback_body(const SmTables* __restrict__
 }
 
 // ---- 1b -----------------------------------------------------------------------------------------------------------
-// p[0] + p[stride] + ... (count terms) in a fixed order, four independent chains so that the loads overlap
-__device__ __forceinline__ double sum_shares(const double* __restrict__ p, int64_t stride, int count) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int q = 0;
-    for (; q + 3 < count; q += 4) {
-        s0 += p[(int64_t)q * stride];
-        s1 += p[(int64_t)(q + 1) * stride];
-        s2 += p[(int64_t)(q + 2) * stride];
-        s3 += p[(int64_t)(q + 3) * stride];
+// p[0] + p[stride] + ... (count terms) per element in a fixed order: four chains (share q on chain q mod 4, the tail on chain
+// 0), (s0 + s1) + (s2 + s3) -- for EL elements at once, element el at p + el * estride (valid while el < n_valid): the loads of
+// 8 shares of all EL elements are in flight together.  A thread of the summing workgroup owns up to 16 elements, and one
+// element at a time every group of four shares was a round trip to L2 of its own: 15 us for the 20 Gram shares of dicty's
+// genes (time stamps of a probe build), 5 us in this form.
+template <int EL>
+__device__ __forceinline__ void sum_shares_multi(const double* __restrict__ p, int64_t estride, int n_valid, int64_t stride, int count,
+                                                 double (&out)[EL]) {
+    double s[EL][4];
+#pragma unroll
+    for (int el = 0; el < EL; ++el)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[el][c] = 0.0;
+    const int full = count & ~3;                    // shares q < full go to chain q mod 4, the tail to chain 0
+    for (int q0 = 0; q0 < count; q0 += 8) {
+        double v[EL][8];
+#pragma unroll
+        for (int el = 0; el < EL; ++el)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[el][u] = (el < n_valid && q0 + u < count) ? p[(int64_t)el * estride + (int64_t)(q0 + u) * stride] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (q0 + u < full) {                    // (uniform)
+#pragma unroll
+                for (int el = 0; el < EL; ++el) s[el][u & 3] += v[el][u];
+            } else if (q0 + u < count) {
+#pragma unroll
+                for (int el = 0; el < EL; ++el) s[el][0] += v[el][u];
+            }
+        }
     }
-    for (; q < count; ++q) s0 += p[(int64_t)q * stride];
-    return (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int el = 0; el < EL; ++el) out[el] = (s[el][0] + s[el][1]) + (s[el][2] + s[el][3]);
 }
 
 // One workgroup per object type -- the one that finishes the type's LAST Gram job in launch 1, so that the inverse runs
@@ -202,17 +284,33 @@ __device__ __forceinline__ void small_pinv_body(const SmTables* __restrict__ tb,
     const int tid = threadIdx.x;
     const SmType& ty = tb->t[t];
     const int n = ty.c;
+#ifdef SKF_PROBE_STAMPS                    // probe builds only (tools/build_probe_libs.sh stamps:-DSKF_PROBE_STAMPS): where launch 1 spends its time
+    long long stamp[8];
+    stamp[0] = wall_clock64();
+#endif
     for (int e = tid; e < 64 * SM_LD; e += SM_PINV_THREADS) M[e] = 0.0;
     __syncthreads();
     {
         const double* part = tb->gpart + ty.gpart_off;
-        for (int e = tid; e < n * n; e += SM_PINV_THREADS) {
-            const double s = nan_to_num(sum_shares(part + e, n * n, ty.n_gjobs));
-            ty.Gram[e] = s;
-            M[(e / n) * SM_LD + e % n] = s;
+        for (int e0 = tid; e0 < n * n; e0 += 8 * SM_PINV_THREADS) {
+            double sums[8];
+            const int left = (n * n - e0 + SM_PINV_THREADS - 1) / SM_PINV_THREADS;
+            sum_shares_multi<8>(part + e0, SM_PINV_THREADS, left, n * n, ty.n_gjobs, sums);
+#pragma unroll
+            for (int el = 0; el < 8; ++el) {
+                const int e = e0 + el * SM_PINV_THREADS;
+                if (e < n * n) {
+                    const double s = nan_to_num(sums[el]);
+                    ty.Gram[e] = s;
+                    M[(e / n) * SM_LD + e % n] = s;
+                }
+            }
         }
     }
     __syncthreads();
+#ifdef SKF_PROBE_STAMPS
+    stamp[1] = wall_clock64();
+#endif
     const int ti = tid >> 4, tj = tid & 15, i0 = 4 * ti, j0 = 4 * tj;
     double m[4][4];
 #pragma unroll
@@ -242,7 +340,81 @@ __device__ __forceinline__ void small_pinv_body(const SmTables* __restrict__ tb,
         need[tid] = (akk > floor_) ? fmax(thr * akk, 0.0) : __builtin_inf();
     }
     __syncthreads();
+#ifdef SKF_PROBE_STAMPS
+    stamp[2] = wall_clock64();
+#endif
     int ok = 1;
+    // Four pivots per barrier (round 4).  A step of the loop below is one LDS round trip and one barrier for 16 fused
+    // multiply-adds per thread: latency, 0.7 us per pivot.  The owners of block column kb publish its four columns ONCE,
+    // as they stand before pivot 4 kb; every thread then replays the four sweeps on what it needs of them -- the panel
+    // rows of its own rows (U), of its own columns taken as rows (V: the role c[j0 + b] plays below) and of the pivot
+    // block itself (Wp, the same in every thread) -- with exactly the operations their owners would have applied between
+    // two barriers: x <- fma(-c_r, c_piv d, x), row k -> c_piv d.  Same inputs, same instructions: the same bits as the
+    // one-pivot loop (which stays behind SKF_SMALL_SWEEP4=0 and is compared with this one in the tests).
+    if (!tb->sweep_single) {
+        for (int k0 = 0; k0 < n && ok; k0 += 4) {
+            typedef double vec4 __attribute__((ext_vector_type(4)));
+            const int buf = (k0 >> 2) & 1;
+            double U[4][4], V[4][4], Wp[4][4];             // [row][q]: entry (row, k0 + q) of the current matrix
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const vec4 u = *(const vec4*)(&col[buf][q][i0]), v = *(const vec4*)(&col[buf][q][j0]), w = *(const vec4*)(&col[buf][q][k0]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { U[a][q] = u[a]; V[a][q] = v[a]; Wp[a][q] = w[a]; }
+            }
+            const int nq = n - k0 < 4 ? n - k0 : 4;
+            const bool row_hit = (i0 == k0), col_hit = (j0 == k0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nq && ok) {                                     // (uniform)
+                    const int k = k0 + q;
+                    const double piv = Wp[q][q], bound = need[k];
+                    if (!(piv > bound)) {
+                        ok = 0;
+                    } else {
+                        // x <- fma(-c_i, c_j d, x) everywhere, then the swept row and column written over it with what the
+                        // one-pivot step's selects produce there: row k  fma(1, c_j d, 0) = c_j d,  column k
+                        // fma(-c_i, -d, 0) = c_i d (one rounding either way),  (k, k)  -d.  In a block of four pivots row
+                        // k is row q of the threads with ti == kb, column k column q of those with tj == kb: a compile-time
+                        // register index under a branch instead of two selects per element.
+                        const double d = 1.0 / piv;
+                        double cjd[4];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) cjd[b] = V[b][q] * d;
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) m[a][b] = fma(-U[a][q], cjd[b], m[a][b]);
+                        if (row_hit) {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) m[q][b] = cjd[b];
+                        }
+                        if (col_hit) {
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) m[a][q] = U[a][q] * d;
+                            if (row_hit) m[q][q] = -d;
+                        }
+                        // the columns still to come in this block, as their owners would have updated them
+#pragma unroll
+                        for (int q2 = q + 1; q2 < 4; ++q2) {
+                            const double pd = Wp[q2][q] * d;            // c[k0 + q2] d: column k0 + q2 is not column k
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) {
+                                U[a][q2] = fma(-U[a][q], pd, U[a][q2]);
+                                V[a][q2] = fma(-V[a][q], pd, V[a][q2]);
+                                Wp[a][q2] = fma(-Wp[a][q], pd, Wp[a][q2]);
+                            }
+                            if (row_hit) U[q][q2] = pd;                 // row k of the panel: fma(1, c d, 0)
+                            if (col_hit) V[q][q2] = pd;
+                            Wp[q][q2] = pd;
+                        }
+                    }
+                }
+            }
+            if (ok && k0 + 4 < n) publish(k0 + 4, buf ^ 1);
+            __syncthreads();
+        }
+    } else
     for (int k = 0; k < n; ++k) {
         const double* c = col[k & 1][k & 3];
         typedef double vec4 __attribute__((ext_vector_type(4)));
@@ -274,6 +446,12 @@ __device__ __forceinline__ void small_pinv_body(const SmTables* __restrict__ tb,
         if (k + 1 < n) publish(k + 1, (k + 1) & 1);
         __syncthreads();
     }
+#ifdef SKF_PROBE_STAMPS
+    stamp[3] = wall_clock64();
+    if (tid == 0 && n >= 32)
+        printf("pinv type %d n %d: sum of shares %lld, set-up %lld, sweep %lld (x10 ns), entered at %lld\n", t, n, stamp[1] - stamp[0],
+               stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[0]);
+#endif
     if (ok) {                                                      // all pivots swept: m = -Gram^-1
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -319,6 +497,9 @@ __global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* __r
     const SmJob jb = jobs[blockIdx.x];
     const int tid = threadIdx.x;
     if (jb.kind == SMJ_GRAM) {           // share of G^T G from rows r0 .., f64 accumulation
+#ifdef SKF_PROBE_STAMPS
+        const long long g0 = wall_clock64();
+#endif
         const SmType& t = tb->t[jb.idx];
         const T* G = (const T*)t.G;
         const int c = t.c;
@@ -328,6 +509,14 @@ __global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* __r
         w.mma(jb.nr, g_at, [&](int k, int b) { return g_at(b, k); }, false, As, Bs);
         double* out = tb->gpart + t.gpart_off + (int64_t)jb.part * c * c;
         w.for_each([&](int a, int b, double v) { if (a < c && b < c) out[a * c + b] = v; });
+#ifdef SKF_PROBE_STAMPS
+        const long long g1 = wall_clock64();
+        const bool last_one = last_arrival(tb->tickets + jb.idx, t.n_gjobs);
+        if (last_one && tid == 0 && c >= 32) printf("gram job block %d: started %lld, product + store %lld, arrival %lld (x10 ns)\n", (int)blockIdx.x, g0, g1 - g0, wall_clock64() - g1);
+        if (last_one) small_pinv_body(tb, jb.idx, sm_tiles);
+        if (last_one && tid == 0 && c >= 32) printf("   done at %lld\n", wall_clock64());
+        return;
+#endif
         if (last_arrival(tb->tickets + jb.idx, t.n_gjobs)) small_pinv_body(tb, jb.idx, sm_tiles);
         return;
     }
@@ -374,7 +563,13 @@ __global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* __r
         w.for_each([&](int a, int b, double v) { if (a < ci && b < cj) out[a * cj + b] = v; });
         if (last_arrival(tb->tickets + tb->n_types + jb.idx, r.n_pjobs)) {      // W = the sum of its shares, fixed order
             const double* part = tb->wpart + r.wpart_off;
-            for (int e = tid; e < ci * cj; e += 256) r.W[e] = sum_shares(part + e, ci * cj, r.n_pjobs);
+            for (int e0 = tid; e0 < ci * cj; e0 += 8 * 256) {
+                double sums[8];
+                sum_shares_multi<8>(part + e0, 256, (ci * cj - e0 + 255) / 256, ci * cj, r.n_pjobs, sums);
+#pragma unroll
+                for (int el = 0; el < 8; ++el)
+                    if (e0 + el * 256 < ci * cj) r.W[e0 + el * 256] = sums[el];
+            }
         }
     } else {                             // share `part` of Q[c0 + m][:] = sum over the rows k0 .. k0 + nk of R[k][c0 + m] G_i[k][:]
         const T* Gi = (const T*)ti.G;
@@ -519,8 +714,8 @@ __global__ __launch_bounds__(256) void small_update_kernel(const SmTables* __res
         }
         return (T)s;
     };
-    e.mma(c, g_at, [&](int k, int a) { return bsum(k, a, true); }, true, As, Bs);
-    d.mma(c, g_at, [&](int k, int a) { return bsum(k, a, false); }, true, As, Bs);
+    sm_mma_dual<T>(e, d, c, g_at, [&](int k, int a) { return bsum(k, a, true); }, [&](int k, int a) { return bsum(k, a, false); }, true, As, Bs,
+                   (T*)(sm_tiles + 2 * SM_BK * SM_LD));
     // G <- G * sqrt(E / max(D, eps)) for the rows of this job (_dfmf.py:294-296; the arithmetic of mult_update_kernel): E and D
     // never leave the registers; the constraint terms were left in the E / D arrays by the THETA jobs of the first launch.
     // (Every read of these rows of G -- the type term above -- is behind the last barrier of the product.)

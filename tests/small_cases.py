@@ -66,4 +66,12 @@ def check(dtype, monkeypatch, iters=3):
     worst_o = max([relerr(Gf[t], Go[t, t]) for t in TYPES] + [relerr(a, b) for a, b in zip(Sf, so)])
     worst_s = max([relerr(Gf[t], Gs[t]) for t in TYPES] + [relerr(a, b) for a, b in zip(Sf, Ss)])
     assert worst_s > 0.0, 'bit-identical results: the plan did not take the four-launch schedule (the sums differ in order)'
+    # the register sweep with four pivots per barrier replays the one-pivot sweep operation by operation: the same bits
+    monkeypatch.setenv('SKF_SMALL_SWEEP4', '0')
+    G1, S1 = run(dtype, iters)
+    monkeypatch.delenv('SKF_SMALL_SWEEP4', raising=False)
+    for t in TYPES:
+        np.testing.assert_array_equal(Gf[t], G1[t])
+    for a, b in zip(Sf, S1):
+        np.testing.assert_array_equal(a, b)
     return worst_o, worst_s
