@@ -232,12 +232,10 @@ __device__ __forceinline__ void small_fallback_body(const SmTables* __restrict__
 
 // ---- 1b -----------------------------------------------------------------------------------------------------------
 // p[0] + p[stride] + ... (count terms) per element in a fixed order: four chains (share q on chain q mod 4, the tail on chain
-// 0), (s0 + s1) + (s2 + s3) -- for EL elements at once, element el at p + el * estride (valid while el < n_valid): the loads of
-// 8 shares of all EL elements are in flight together.  A thread of the summing workgroup owns up to 16 elements, and one
-// element at a time every group of four shares was a round trip to L2 of its own: 15 us for the 20 Gram shares of dicty's
-// genes (time stamps of a probe build), 5 us in this form.
+// 0), (s0 + s1) + (s2 + s3) -- for EL elements at once, element el at p + off[el] (off[el] < 0: none): the loads of 8 shares of
+// all EL elements are in flight together (a thread of the summing workgroup owns up to 16 elements).
 template <int EL>
-__device__ __forceinline__ void sum_shares_multi(const double* __restrict__ p, int64_t estride, int n_valid, int64_t stride, int count,
+__device__ __forceinline__ void sum_shares_multi(const double* __restrict__ p, const int (&off)[EL], int64_t stride, int count,
                                                  double (&out)[EL]) {
     double s[EL][4];
 #pragma unroll
@@ -251,7 +249,7 @@ __device__ __forceinline__ void sum_shares_multi(const double* __restrict__ p, i
         for (int el = 0; el < EL; ++el)
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                v[el][u] = (el < n_valid && q0 + u < count) ? p[(int64_t)el * estride + (int64_t)(q0 + u) * stride] : 0.0;
+                v[el][u] = (off[el] >= 0 && q0 + u < count) ? p[off[el] + (int64_t)(q0 + u) * stride] : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (q0 + u < full) {                    // (uniform)
@@ -292,19 +290,33 @@ __device__ __forceinline__ void small_pinv_body(const SmTables* __restrict__ tb,
     __syncthreads();
     {
         const double* part = tb->gpart + ty.gpart_off;
-        for (int e0 = tid; e0 < n * n; e0 += 8 * SM_PINV_THREADS) {
+        // Only the lower triangle is summed: a share is G^T G of its rows on the matrix cores -- element (a, b) and element
+        // (b, a) are the same products added in the same order, the same bits -- and the summing workgroup's time is the
+        // traffic of the shares (400 KB from other XCDs for dicty's genes: 14 us of the launch's 48), not their latency.
+        const int ntri = n * (n + 1) / 2;
+        for (int t0 = tid; t0 < ntri; t0 += 8 * SM_PINV_THREADS) {
             double sums[8];
-            const int left = (n * n - e0 + SM_PINV_THREADS - 1) / SM_PINV_THREADS;
-            sum_shares_multi<8>(part + e0, SM_PINV_THREADS, left, n * n, ty.n_gjobs, sums);
+            int off[8], ri[8], rj[8];
 #pragma unroll
             for (int el = 0; el < 8; ++el) {
-                const int e = e0 + el * SM_PINV_THREADS;
-                if (e < n * n) {
-                    const double s = nan_to_num(sums[el]);
-                    ty.Gram[e] = s;
-                    M[(e / n) * SM_LD + e % n] = s;
-                }
+                const int t = t0 + el * SM_PINV_THREADS;
+                int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+                while ((i + 1) * (i + 2) / 2 <= t) ++i;
+                while (i * (i + 1) / 2 > t) --i;
+                ri[el] = i;
+                rj[el] = t - i * (i + 1) / 2;
+                off[el] = t < ntri ? i * n + rj[el] : -1;
             }
+            sum_shares_multi<8>(part, off, n * n, ty.n_gjobs, sums);
+#pragma unroll
+            for (int el = 0; el < 8; ++el)
+                if (off[el] >= 0) {
+                    const double s = nan_to_num(sums[el]);
+                    ty.Gram[ri[el] * n + rj[el]] = s;
+                    ty.Gram[rj[el] * n + ri[el]] = s;
+                    M[ri[el] * SM_LD + rj[el]] = s;
+                    M[rj[el] * SM_LD + ri[el]] = s;
+                }
         }
     }
     __syncthreads();
@@ -565,10 +577,13 @@ __global__ __launch_bounds__(256) void small_contract_kernel(const SmTables* __r
             const double* part = tb->wpart + r.wpart_off;
             for (int e0 = tid; e0 < ci * cj; e0 += 8 * 256) {
                 double sums[8];
-                sum_shares_multi<8>(part + e0, 256, (ci * cj - e0 + 255) / 256, ci * cj, r.n_pjobs, sums);
+                int off[8];
+#pragma unroll
+                for (int el = 0; el < 8; ++el) off[el] = e0 + el * 256 < ci * cj ? e0 + el * 256 : -1;
+                sum_shares_multi<8>(part, off, ci * cj, r.n_pjobs, sums);
 #pragma unroll
                 for (int el = 0; el < 8; ++el)
-                    if (e0 + el * 256 < ci * cj) r.W[e0 + el * 256] = sums[el];
+                    if (off[el] >= 0) r.W[off[el]] = sums[el];
             }
         }
     } else {                             // share `part` of Q[c0 + m][:] = sum over the rows k0 .. k0 + nk of R[k][c0 + m] G_i[k][:]
