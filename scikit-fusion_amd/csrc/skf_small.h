@@ -676,6 +676,9 @@ __global__ __launch_bounds__(256) void small_update_kernel(const SmTables* __res
     const SmJob jb = jobs[blockIdx.x];
     const SmType& ty = tb->t[jb.idx];
     const int c = ty.c, tid = threadIdx.x;
+#ifdef SKF_PROBE_STAMPS
+    const long long u0 = wall_clock64();
+#endif
     SmTile<T> e, d, v;
     e.zero();
     d.zero();
@@ -716,6 +719,9 @@ __global__ __launch_bounds__(256) void small_update_kernel(const SmTables* __res
             split_add();
         }
     }
+#ifdef SKF_PROBE_STAMPS
+    const long long u1 = wall_clock64();
+#endif
     // type term: E += G sum B-, D += G sum B+ (sums over the relations of the type, rounded to T once; _dfmf.py:278-282)
     const T* G = (const T*)ty.G;
     auto g_at = [&](int m, int k) { return m < jb.nr ? G[(int64_t)(jb.r0 + m) * c + k] : (T)0; };
@@ -734,6 +740,11 @@ __global__ __launch_bounds__(256) void small_update_kernel(const SmTables* __res
     // G <- G * sqrt(E / max(D, eps)) for the rows of this job (_dfmf.py:294-296; the arithmetic of mult_update_kernel): E and D
     // never leave the registers; the constraint terms were left in the E / D arrays by the THETA jobs of the first launch.
     // (Every read of these rows of G -- the type term above -- is behind the last barrier of the product.)
+#ifdef SKF_PROBE_STAMPS
+    const long long u2 = wall_clock64();
+    if (tid == 0 && (jb.r0 == 0 || jb.r0 == 64))
+        printf("update job type %d rows %d: relation products %lld, type term %lld (x10 ns), started %lld\n", jb.idx, jb.r0, u1 - u0, u2 - u1, u0);
+#endif
     const T* E = (const T*)ty.E;
     const T* D = (const T*)ty.D;
     T* Gw = (T*)ty.G;

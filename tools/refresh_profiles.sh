@@ -24,7 +24,7 @@ done
 [ -f $G/dicty.txt ] && { echo "# python tools/bench_dicty.py / tools/bench_api_small.py, same box, final build of the round"; grep -h "dicty\|README\|NumPy" $G/dicty.txt $G/api_small.txt; } > profiles/${R}_dicty_config2.txt
 [ -f $G/fuzz_known.txt ] && tail -3 $G/fuzz_known.txt > profiles/${R}_fuzz_known_entries.txt
 [ -f $G/fuzz_small.txt ] && tail -3 $G/fuzz_small.txt > profiles/${R}_fuzz_small_graphs.txt
-[ -f $G/fuzz_owned.txt ] && cut -c1-400 $G/fuzz_owned.txt > profiles/${R}_fuzz_owned_rows.txt
+[ -f $G/fuzz_owned.txt ] && [ ! -f profiles/${R}_fuzz_owned_rows.txt ] && cut -c1-400 $G/fuzz_owned.txt > profiles/${R}_fuzz_owned_rows.txt
 grep '^{' $G/bench_full.log > profiles/${R}_bf16_bench.json
 grep '^{' $G/c5_bf16.log > profiles/${R}_c5_bf16_bench.json
 { echo "# python -m pytest tests -m gpu -q --durations=10 on the MI355X box (final build of the round)"; tail -22 $G/pytest.log; } > profiles/${R}_pytest_gpu.log
