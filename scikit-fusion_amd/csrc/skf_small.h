@@ -54,7 +54,10 @@ struct SmTables {
 };
 enum { SMJ_P = 0, SMJ_Q = 1, SMJ_GRAM = 2, SMJ_THETA = 3 };
 // (Gram shares of 128 / 256 rows, measured on dicty: the share's K loop grows by what the sum of the shares saves -- 9.1 / 9.3 / 9.0 k it/s)
-constexpr int SM_QROWS = 256, SM_GROWS = 64;       // rows of the relation per Q share / of the factor per Gram share
+#ifndef SKF_SM_QROWS
+#define SKF_SM_QROWS 256
+#endif
+constexpr int SM_QROWS = SKF_SM_QROWS, SM_GROWS = 64;       // rows of the relation per Q share / of the factor per Gram share
 struct SmJob { int kind, idx, r0, nr, part, k0, nk, pad; };      // Q jobs: rows [k0, k0 + nk) of the relation, share `part`
 
 // ---- matrix-core tile of a workgroup ---------------------------------------------------------------------------------
@@ -145,7 +148,7 @@ struct SmTile {
 // launch): one staged A tile, one round trip per K tile for both -- every K tile whose operand another workgroup wrote in
 // the previous launch costs a trip through memory (~2 us on dicty).  Same order of the K tiles, separate accumulators: the
 // bits of two mma() calls.
-constexpr int SM_TILE3_BYTES = 3 * SM_BK * SM_LD * 8;
+constexpr int SM_TILE3_BYTES = 3 * SM_BK * SM_LD * 8 + 2 * 64 * 64 * 8;      // + the two c x c sums of the type term (update launch)
 template <typename T, class FA, class FB1, class FB2>
 __device__ __forceinline__ void sm_mma_dual(SmTile<T>& t1, SmTile<T>& t2, int K, FA a_at, FB1 b1_at, FB2 b2_at, bool a_kfast,
                                             T* As, T* Bs1, T* Bs2) {
@@ -709,10 +712,20 @@ __global__ __launch_bounds__(256) void small_update_kernel(const SmTables* __res
             const T* Q = (const T*)r.Q;
             const int64_t qs = tb->t[r.col].n * ci;       // Q arrives as n_qparts shares
             v.zero();
-            v.mma(ci, [&](int m, int a) {
-                      T x = (T)0;
-                      if (m < jb.nr)
-                          for (int z = 0; z < r.n_qparts; ++z) x += Q[z * qs + (int64_t)(jb.r0 + m) * ci + a];
+            const int nqp = r.n_qparts;
+            v.mma(ci, [&](int m, int a) {        // the shares are loaded eight at a time, then added in their order: one round
+                      T x = (T)0;                //  trip per element instead of one per share (25 -> 10 us for a job of dicty's)
+                      if (m < jb.nr) {
+                          const T* q0 = Q + (int64_t)(jb.r0 + m) * ci + a;
+                          for (int z0 = 0; z0 < nqp; z0 += 8) {
+                              T sh[8];
+#pragma unroll
+                              for (int u = 0; u < 8; ++u) sh[u] = (z0 + u < nqp) ? q0[(z0 + u) * qs] : (T)0;
+#pragma unroll
+                              for (int u = 0; u < 8; ++u)
+                                  if (z0 + u < nqp) x += sh[u];
+                          }
+                      }
                       return x;
                   },
                   [&](int a, int b) { return b < cj ? (T)r.S[a * cj + b] : (T)0; }, true, As, Bs);
@@ -723,20 +736,26 @@ __global__ __launch_bounds__(256) void small_update_kernel(const SmTables* __res
     const long long u1 = wall_clock64();
 #endif
     // type term: E += G sum B-, D += G sum B+ (sums over the relations of the type, rounded to T once; _dfmf.py:278-282)
+    // The sums are staged in LDS once per workgroup (c x c each, behind the three staging tiles): inside the K loop every
+    // element was a walk over the relation table with two dependent loads per relation -- 22 us of the 30 a job of dicty's
+    // genes took (time stamps of a probe build).
     const T* G = (const T*)ty.G;
     auto g_at = [&](int m, int k) { return m < jb.nr ? G[(int64_t)(jb.r0 + m) * c + k] : (T)0; };
-    auto bsum = [&](int k, int a, bool neg) -> T {
-        if (a >= c) return (T)0;
-        double s = 0.0;
+    T* Bneg = (T*)(sm_tiles + 3 * SM_BK * SM_LD);
+    T* Bpos = Bneg + SMALLC * SMALLC;
+    for (int el = tid; el < c * c; el += 256) {
+        double sn = 0.0, sp = 0.0;
         for (int q = 0; q < tb->n_rels; ++q) {
             const SmRel& r = tb->r[q];
-            if (r.row == jb.idx) s += (neg ? r.Bn : r.Bp)[k * c + a];
-            if (r.col == jb.idx) s += (neg ? r.Dn : r.Dp)[k * c + a];
+            if (r.row == jb.idx) { sn += r.Bn[el]; sp += r.Bp[el]; }
+            if (r.col == jb.idx) { sn += r.Dn[el]; sp += r.Dp[el]; }
         }
-        return (T)s;
-    };
-    sm_mma_dual<T>(e, d, c, g_at, [&](int k, int a) { return bsum(k, a, true); }, [&](int k, int a) { return bsum(k, a, false); }, true, As, Bs,
-                   (T*)(sm_tiles + 2 * SM_BK * SM_LD));
+        Bneg[el] = (T)sn;
+        Bpos[el] = (T)sp;
+    }
+    __syncthreads();
+    sm_mma_dual<T>(e, d, c, g_at, [&](int k, int a) { return a < c ? Bneg[k * c + a] : (T)0; },
+                   [&](int k, int a) { return a < c ? Bpos[k * c + a] : (T)0; }, true, As, Bs, (T*)(sm_tiles + 2 * SM_BK * SM_LD));
     // G <- G * sqrt(E / max(D, eps)) for the rows of this job (_dfmf.py:294-296; the arithmetic of mult_update_kernel): E and D
     // never leave the registers; the constraint terms were left in the E / D arrays by the THETA jobs of the first launch.
     // (Every read of these rows of G -- the type term above -- is behind the last barrier of the product.)
