@@ -3137,15 +3137,18 @@ __global__ __launch_bounds__(256) void chol_unpack_batched_kernel(PinvBatch pb, 
 // go to LDS; the 32 x 32 block is swept pivot by pivot with ONE barrier per pivot (two elements per thread in registers,
 // row k published through a double buffer) -- its pivots are the Schur complements a Cholesky factorisation would take the
 // roots of, so the verdict is that of the Cholesky kernels: pivot > rel_thr * a_kk, a_kk above the diagonal floor; a failed
-// pivot leaves the matrix (untouched in e.A) to the deflation / eigen-solver --; T = M_rp P (n x 32); then the rank-32 update
-// of the whole matrix, 8 x 8 outputs per thread and pass in registers, operands from LDS (rows ty + 16 a, columns tx + 32 b:
-// conflict-free LDS rows, coalesced read-modify-write of M).  The vector ALU runs f64 FMAs at the rate of the f64 matrix
-// cores on this part (78.6 TFLOP/s either way), so the update is plain FMAs: n^2 * 32 of them per block = 13.7 us on one CU at
-// order 256.  M lives in the plan's eigen scratch (e.V), 0.5 MB: L2 resident.
+// pivot leaves the matrix (untouched in e.A) to the deflation / eigen-solver --; T = M_rp P (n x 32) and the rank-32 update
+// of the whole matrix run on the f64 matrix cores (16 x 16 x 4 tiles, operands from LDS at a pitch of 36 words: conflict-free
+// fragments; a wave owns 64 x 64 outputs of the update at a time, its accumulators start from M itself).  On this part the
+// vector ALU and the matrix cores run f64 FMAs at the same rate (78.6 TFLOP/s either way: 13.7 us per block on one CU at
+// order 256); what the matrix cores save is LDS traffic -- the plain-FMA T read two LDS words per FMA and took 14 of the
+// 66 us of a block (time stamps of a probe build, -DSKF_PROBE_STAMPS).  M lives in the plan's eigen scratch (e.V), 0.5 MB:
+// L2 resident.  Stand-alone at order 256: 0.53 ms (first version 0.63; Cholesky inverse + unpack 0.93) -- per block: panel
+// 2 us, pivot-block sweep 14, T 2.6, update 27, write-back 7.
 // ------------------------------------------------------------------------------------------
 constexpr int SWEEP_MAXN = 256;
 constexpr int SWEEP_NB = 32;
-constexpr int SWEEP_LD = SWEEP_NB + 1;
+constexpr int SWEEP_LD = SWEEP_NB + 4;      // (row r, k) -> 4 r + k mod 32: the fragments of the matrix-core tiles are conflict-free
 constexpr int SWEEP_THREADS = 512;
 constexpr int SWEEP_LDS_BYTES = ((2 * SWEEP_MAXN + SWEEP_NB) * SWEEP_LD + 2 * SWEEP_NB + SWEEP_MAXN) * 8;
 
@@ -3192,11 +3195,19 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_inverse_kernel(EighArgs e
     }
     __syncthreads();
 
+#ifdef SKF_PROBE_STAMPS
+    long long ph[6] = {0, 0, 0, 0, 0, 0}, t_in = wall_clock64();
+#define SKF_STAMP(i) { const long long now_ = wall_clock64(); ph[i] += now_ - t_in; t_in = now_; }
+#else
+#define SKF_STAMP(i)
+#endif
     for (int kb = 0; kb < n; kb += NB) {
         const int nb = (n - kb < NB) ? n - kb : NB;
+        SKF_STAMP(0)
         // ---- panel and pivot block to LDS
         for (int i = ty; i < n; i += 16) Cs[i * LD + tx] = (tx < nb) ? M[i * ld + kb + tx] : 0.0;
         __syncthreads();
+        SKF_STAMP(1)
         // ---- sweep of the pivot block: elements (r, c) = (ty, tx) and (ty + 16, tx) in registers
         double v[2];
 #pragma unroll
@@ -3233,58 +3244,110 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_inverse_kernel(EighArgs e
 #pragma unroll
         for (int h = 0; h < 2; ++h) Pv[(ty + 16 * h) * LD + tx] = v[h];
         __syncthreads();
-        // ---- T = M_rp P = -(C Pv), every row (the pivot rows' entries are not used)
-        for (int i = ty; i < n; i += 16) {
-            double s = 0.0;
-#pragma unroll 8
-            for (int k = 0; k < NB; ++k) s = fma(Cs[i * LD + k], Pv[k * LD + tx], s);
-            Ts[i * LD + tx] = -s;
-        }
-        __syncthreads();
-        // ---- M_rr -= T C^T outside the pivot rows / columns: rows ty + 16 a (two passes of 8), columns tx + 32 b
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-            if (ty + 16 * 8 * pass >= n) break;
-            double acc[8][8];
+        SKF_STAMP(2)
+        // ---- T = M_rp P = -(C Pv), every row (the pivot rows' entries are not used), on the f64 matrix cores: 16 x 16 tiles,
+        // row tiles wave, wave + 8, both column tiles on one A fragment.  (The plain-FMA form read two LDS words per FMA: 4 MB
+        // per block, 14 of the 66 us a block took at order 256 -- time stamps of a probe build.)
+        {
+            typedef Mfma<double> MF;
+            const int ntile = (n + 15) >> 4;
+            for (int it = wave; it < ntile; it += SWEEP_THREADS / 64) {
+                const int row = it * 16 + MF::a_row(lane);
+                MF::acc_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
+                for (int k0 = 0; k0 < NB; k0 += MF::KT) {
+                    const int kk = k0 + MF::ab_k(lane);
+                    const double a = row < n ? Cs[row * LD + kk] : 0.0;
+                    acc0 = MF::mma(a, Pv[kk * LD + MF::a_row(lane)], acc0);
+                    acc1 = MF::mma(a, Pv[kk * LD + 16 + MF::a_row(lane)], acc1);
+                }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc[a][q] = 0.0;
-            for (int k = 0; k < nb; ++k) {
-                double t[8], c[8];
-#pragma unroll
-                for (int a = 0; a < 8; ++a) t[a] = Ts[(ty + 16 * (8 * pass + a)) * LD + k];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) c[q] = Cs[(tx + 32 * q) * LD + k];
-#pragma unroll
-                for (int a = 0; a < 8; ++a)
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[a][q] = fma(t[a], c[q], acc[a][q]);
-            }
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const int i = ty + 16 * (8 * pass + a);
-                if (i >= n || (i >= kb && i < kb + nb)) continue;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int j = tx + 32 * q;
-                    if (j < n && !(j >= kb && j < kb + nb)) M[i * ld + j] -= acc[a][q];
+                for (int r = 0; r < MF::NREG; ++r) {
+                    const int i = it * 16 + MF::d_row(lane, r);
+                    if (i < n) {
+                        Ts[i * LD + MF::d_col(lane)] = -acc0[r];
+                        Ts[i * LD + 16 + MF::d_col(lane)] = -acc1[r];
+                    }
                 }
             }
         }
-        // ---- pivot columns and rows <- T, pivot block <- -P
+        __syncthreads();
+        SKF_STAMP(3)
+        // ---- M_rr -= T C^T outside the pivot rows / columns, on the f64 matrix cores: a wave owns 64 x 64 outputs at a time
+        // (4 x 4 tiles on four A and four B fragments per K step: 8 LDS reads for 16 instructions; 8 x 8 outputs per thread
+        // in plain FMAs read 16 words per 64 FMAs and ran on the LDS, 27 us per block at order 256)
+        {
+            typedef Mfma<double> MF;
+            const int nblk = (n + 63) >> 6;
+            for (int blk = wave; blk < nblk * nblk; blk += SWEEP_THREADS / 64) {
+                const int bi = (blk / nblk) * 64, bj = (blk % nblk) * 64;
+                // the accumulators start from M itself (the loads fly while the first products run) and take -T C^T
+                MF::acc_t acc[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int r = 0; r < MF::NREG; ++r) {
+                        const int i = bi + 16 * a + MF::d_row(lane, r);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int j = bj + 16 * q + MF::d_col(lane);
+                            acc[a][q][r] = (i < n && j < n) ? M[i * ld + j] : 0.0;
+                        }
+                    }
+#pragma unroll 2
+                for (int k0 = 0; k0 < NB; k0 += MF::KT) {
+                    const int kk = k0 + MF::ab_k(lane);
+                    double ta[4], cb[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int i = bi + 16 * a + MF::a_row(lane);
+                        ta[a] = i < n ? -Ts[i * LD + kk] : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = bj + 16 * q + MF::a_row(lane);
+                        cb[q] = j < n ? Cs[j * LD + kk] : 0.0;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[a][q] = MF::mma(ta[a], cb[q], acc[a][q]);
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int r = 0; r < MF::NREG; ++r) {
+                        const int i = bi + 16 * a + MF::d_row(lane, r);
+                        if (i >= n || (i >= kb && i < kb + nb)) continue;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int j = bj + 16 * q + MF::d_col(lane);
+                            if (j < n && !(j >= kb && j < kb + nb)) M[i * ld + j] = acc[a][q][r];
+                        }
+                    }
+            }
+        }
+        SKF_STAMP(4)
+        // ---- pivot columns <- T (lanes along the columns of the block), pivot block <- -P; pivot rows <- T^T with the lanes
+        // along the rows of T (the transposed copy as the mirror of the column loop: one 8-byte store per lane ld apart,
+        // 9 of the 66 us)
         for (int i = ty; i < n; i += 16) {
             if (tx >= nb) continue;
-            if (i >= kb && i < kb + nb) {
-                M[i * ld + kb + tx] = Pv[(i - kb) * LD + tx];
-            } else {
-                const double t = Ts[i * LD + tx];
-                M[i * ld + kb + tx] = t;
-                M[(kb + tx) * ld + i] = t;
-            }
+            if (i >= kb && i < kb + nb) M[i * ld + kb + tx] = Pv[(i - kb) * LD + tx];
+            else M[i * ld + kb + tx] = Ts[i * LD + tx];
+        }
+        for (int idx = tid; idx < nb * n; idx += SWEEP_THREADS) {
+            const int c = idx / n, i = idx % n;
+            if (!(i >= kb && i < kb + nb)) M[(kb + c) * ld + i] = Ts[i * LD + c];
         }
         __syncthreads();
     }
+    SKF_STAMP(5)
+#ifdef SKF_PROBE_STAMPS
+    if (tid == 0 && n >= 200)
+        printf("sweep_inverse n %d: panel load %lld, pivot block sweep %lld, T %lld, update %lld, write-back + barrier %lld (x10 ns, all blocks)\n", n,
+               ph[1], ph[2], ph[3], ph[4], ph[5] + ph[0]);
+#endif
     // ---- all pivots swept: M = -A^-1
     double* K = pb.K[b];
     for (int idx = tid; idx < n * n; idx += SWEEP_THREADS) K[idx] = -M[(idx / n) * ld + idx % n];
