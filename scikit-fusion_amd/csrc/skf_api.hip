@@ -1069,6 +1069,8 @@ static void side_update(skf_plan* p, const void* X, int64_t ldx, int k1, const v
                 hipLaunchKernelGGL((side_update_kernel<float, float, 2, 2, 16, FM_R>), grid, block, 0, st, a);
         } else {
             dim3 grid(cdiv(t.c, 64), cdiv(n, 64));
+            // (K tiles of 32 / 64 instead of 16, round 4: config 3 91.1 / 89.2 against 90.8 it/s, config 5 144.9 / 143.0
+            //  against 144.3 -- within the noise / worse)
             if (vec && k_major && n > 64 && t.c >= 64)
                 hipLaunchKernelGGL((side_update_kernel<float, float, 1, 1, 16, FM_K>), grid, block, 0, st, a);
             else if (vec && n > 64 && t.c >= 64)

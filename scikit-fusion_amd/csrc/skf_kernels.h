@@ -126,6 +126,24 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int m, int n, 
     }
 }
 
+// the accumulating epilogues with the old values handed in: a tile's old values are loaded together BEFORE its first store
+// (element by element, `C[i] += v` is a memory round trip per element -- the compiler cannot move the next load above a
+// store that may alias it; measured on the fused side update: 14-29 us of the 25-37 a workgroup took)
+template <typename T>
+__device__ __forceinline__ void epilogue_store_acc(const GemmArgs& g, int m, int n, T v, T old1, T old2) {
+    T* C = (T*)g.C;
+    T* C2 = (T*)g.C2;
+    if (g.nan_to_num) v = nan_to_num(v);
+    const int64_t i = (int64_t)m * g.ldc + n;
+    const int64_t i2 = (int64_t)m * g.ldc2 + n;
+    if (g.epi == EPI_ACC) {
+        C[i] = old1 + v;
+    } else {                                 // EPI_SPLIT_ACC
+        C[i] = old1 + (v > (T)0 ? v : (T)0);
+        C2[i2] = old2 + (v > (T)0 ? (T)0 : -v);
+    }
+}
+
 // sum over the 64 lanes of a wave (result valid in every lane)
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
@@ -368,6 +386,28 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
     // ---- epilogue
     const bool split = (gridDim.z > 1);
     T sq = (T)0;
+    if (!split && (g.epi == EPI_ACC || g.epi == EPI_SPLIT_ACC)) {          // (uniform)
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+#pragma unroll
+            for (int j = 0; j < WC; ++j) {
+                T o1[MF::NREG], o2[MF::NREG];
+                const int n = bn0 + wn0 + j * MF::NT + MF::d_col(lane);
+#pragma unroll
+                for (int r = 0; r < MF::NREG; ++r) {
+                    const int m = bm0 + wm0 + i * MF::MT + MF::d_row(lane, r);
+                    const bool in = m < g.M && n < g.N;
+                    o1[r] = in ? ((const T*)g.C)[(int64_t)m * g.ldc + n] : (T)0;
+                    o2[r] = (in && g.epi == EPI_SPLIT_ACC) ? ((const T*)g.C2)[(int64_t)m * g.ldc2 + n] : (T)0;
+                }
+#pragma unroll
+                for (int r = 0; r < MF::NREG; ++r) {
+                    const int m = bm0 + wm0 + i * MF::MT + MF::d_row(lane, r);
+                    if (m < g.M && n < g.N) epilogue_store_acc<T>(g, m, n, acc[i][j][r], o1[r], o2[r]);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WR; ++i)
 #pragma unroll
@@ -456,6 +496,9 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
 
     T ra[BM * BK / GEMM_THREADS];
     TB rb[BN * BK / GEMM_THREADS], rb2[BN * BK / GEMM_THREADS];
+#ifdef SKF_PROBE_STAMPS
+    const long long su0 = wall_clock64();
+#endif
 
     // ---- phase 1: accE = X * Sop
     {
@@ -493,6 +536,9 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
             }
         }
     }
+#ifdef SKF_PROBE_STAMPS
+    const long long su1 = wall_clock64();
+#endif
     // ---- split A into (A+, A-)
 #pragma unroll
     for (int i = 0; i < WR; ++i)
@@ -548,28 +594,49 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
             }
         }
     }
+#ifdef SKF_PROBE_STAMPS
+    const long long su2 = wall_clock64();
+#endif
     // ---- epilogue
     T* E = (T*)a.E;
     T* D = (T*)a.D;
+    // (accumulate: the old values of a tile are all loaded before the first store -- E and D may alias for all the compiler
+    //  knows, and `E[idx] += x; D[idx] += y` element by element was one memory round trip per element: 14-29 us of the 25-37 a
+    //  workgroup of config 5's movie side took, time stamps of a probe build)
 #pragma unroll
     for (int i = 0; i < WR; ++i)
 #pragma unroll
-        for (int j = 0; j < WC; ++j)
+        for (int j = 0; j < WC; ++j) {
+            T eo[MF::NREG], dq[MF::NREG];
+            const int n = bn0 + wn0 + j * MF::NT + MF::d_col(lane);
 #pragma unroll
             for (int r = 0; r < MF::NREG; ++r) {
                 const int m = bm0 + wm0 + i * MF::MT + MF::d_row(lane, r);
-                const int n = bn0 + wn0 + j * MF::NT + MF::d_col(lane);
+                const int64_t idx = (int64_t)m * a.lde + n;
+                const bool in = m < a.n && n < a.c;
+                eo[r] = (a.accumulate && in) ? E[idx] : (T)0;
+                dq[r] = (a.accumulate && in) ? D[idx] : (T)0;
+            }
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) {
+                const int m = bm0 + wm0 + i * MF::MT + MF::d_row(lane, r);
                 if (m < a.n && n < a.c) {
                     const int64_t idx = (int64_t)m * a.lde + n;
                     if (a.accumulate) {
-                        E[idx] += accE[i][j][r];
-                        D[idx] += accD[i][j][r];
+                        E[idx] = eo[r] + accE[i][j][r];
+                        D[idx] = dq[r] + accD[i][j][r];
                     } else {
                         E[idx] = accE[i][j][r];
                         D[idx] = accD[i][j][r];
                     }
                 }
             }
+        }
+#ifdef SKF_PROBE_STAMPS
+    if (tid == 0 && (blockIdx.y == 0 || blockIdx.y == gridDim.y / 2) && blockIdx.x == 0 && a.n >= 20000)
+        printf("side_update n %d c %d k1 %d phase2 %d acc %d block %d: phase 1 %lld, split + phase 2 %lld, epilogue %lld (x10 ns), start %lld\n", a.n, a.c, a.k1,
+               a.phase2, a.accumulate, (int)blockIdx.y, su1 - su0, su2 - su1, wall_clock64() - su2, su0);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
