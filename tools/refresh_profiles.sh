@@ -21,7 +21,7 @@ fi
 for k in 3 5; do
   [ -f gpurun_out/$1_pmc$k/traffic.txt ] && cp gpurun_out/$1_pmc$k/traffic.txt profiles/${R}_$([ $k = 5 ] && echo c5_)bf16_pmc_traffic.txt
 done
-[ -f $G/dicty.txt ] && { echo "# python tools/bench_dicty.py / tools/bench_api_small.py, same box, final build of the round"; grep -h "dicty\|README\|NumPy" $G/dicty.txt $G/api_small.txt; } > profiles/${R}_dicty_config2.txt
+[ -f $G/dicty.txt ] && [ ! -f profiles/${R}_dicty_config2.txt ] && { echo "# python tools/bench_dicty.py / tools/bench_api_small.py, same box, final build of the round"; grep -h "dicty\|README\|NumPy" $G/dicty.txt $G/api_small.txt; } > profiles/${R}_dicty_config2.txt
 [ -f $G/fuzz_known.txt ] && tail -3 $G/fuzz_known.txt > profiles/${R}_fuzz_known_entries.txt
 [ -f $G/fuzz_small.txt ] && tail -3 $G/fuzz_small.txt > profiles/${R}_fuzz_small_graphs.txt
 [ -f $G/fuzz_owned.txt ] && [ ! -f profiles/${R}_fuzz_owned_rows.txt ] && cut -c1-400 $G/fuzz_owned.txt > profiles/${R}_fuzz_owned_rows.txt
