@@ -215,6 +215,45 @@ def test_small_graph_schedule_on_an_awkward_graph(dtype, monkeypatch):
     assert worst_s < (1e-11 if dtype == 'f64' else 2e-4)
 
 
+@pytest.mark.parametrize('n_big', [2317, 1100])
+def test_small_graph_schedule_with_many_shares(n_big, monkeypatch):
+    """A type of a few thousand objects in the small-graph schedule: 37 / 18 Gram shares and 10 / 5 Q shares -- the share
+    sums take their shares eight at a time (a tail of 5 / 2 on chain 0, more than one batch of Q shares per element) and keep
+    the order of the additions: the oracle to 1e-10, the four-pivot and the one-pivot sweep bit for bit, the general schedule
+    within rounding."""
+    from skfusion_amd._engine import DevicePlan
+    rs = np.random.RandomState(n_big)
+    types = ['a', 'b', 'c']
+    n = {'a': n_big, 'b': 37, 'c': 90}
+    rank = {'a': 9, 'b': 5, 'c': 14}
+    R = {('a', 'b'): [rs.rand(n_big, 37)], ('a', 'c'): [rs.rand(n_big, 90) - 0.2], ('b', 'c'): [rs.rand(37, 90)]}
+    G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.05 for t in types}
+    rel = [(i, j, m, None) for (i, j), ms in R.items() for m in ms]
+
+    def run():
+        plan = DevicePlan(types, n, rank, rel, [], nat.SKF_DFMF, dtype='f64')
+        for t in types:
+            plan.set_factor(t, G0[t, t])
+        plan.iterate(3)
+        out = {t: plan.get_factor(t) for t in types}, [plan.get_backbone(k) for k in range(len(rel))]
+        plan.close()
+        return out
+    Go, So = orc.dfmf(R, {}, types, rank, max_iter=3, G0=G0)
+    G4, S4 = run()
+    monkeypatch.setenv('SKF_SMALL_SWEEP4', '0')
+    G1, S1 = run()
+    monkeypatch.delenv('SKF_SMALL_SWEEP4')
+    monkeypatch.setenv('SKF_NO_SMALL_FUSED', '1')
+    Gg, Sg = run()
+    monkeypatch.delenv('SKF_NO_SMALL_FUSED')
+    for t in types:
+        assert relerr(G4[t], Go[t, t]) < 1e-10
+        np.testing.assert_array_equal(G4[t], G1[t])
+        assert 0.0 < relerr(G4[t], Gg[t]) < 1e-11         # (not the same bits: the fused schedule ran)
+    for a, b in zip(S4, [m for key in R for m in So[key]]):
+        assert relerr(a, b) < 1e-10
+
+
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
 def test_device_squared_error_on_unaligned_shapes(dtype):
     """skf_relation_sqerr sizes one partial per workgroup of the tile the product runs on: the dicty relations (1219 x 116
