@@ -562,12 +562,21 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
         stage_load<T, BM, BK>(ra, G, a.ldg, 1, bm0, 0, a.n, a.c, tid, mg);
         stage_load<TB, BN, BK>(rb, Bn, 1, a.ldb, bn0, 0, a.c, a.c, tid, mbn);
         stage_load<TB, BN, BK>(rb2, Bp, 1, a.ldb, bn0, 0, a.c, a.c, tid, mbp);
+#ifdef SKF_PROBE_STAMPS
+        long long pw[4] = {0, 0, 0, 0}, pt = wall_clock64();
+#define SKF_PSTAMP(i) { const long long now_ = wall_clock64(); pw[i] += now_ - pt; pt = now_; }
+#else
+#define SKF_PSTAMP(i)
+#endif
         for (int k0 = 0; k0 < a.c; k0 += BK) {
             __syncthreads();
+            SKF_PSTAMP(0)
             stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.c, AOP_NONE, tid, mg);
             stage_store<T, TB, BN, BK, LDB>(Bs, rb, a.ldb == 1, k0, a.c, AOP_NONE, tid, mbn);
             stage_store<T, TB, BN, BK, LDB>(Bs2, rb2, a.ldb == 1, k0, a.c, AOP_NONE, tid, mbp);
+            SKF_PSTAMP(1)
             __syncthreads();
+            SKF_PSTAMP(2)
             if (k0 + BK < a.c) {
                 stage_load<T, BM, BK>(ra, G, a.ldg, 1, bm0, k0 + BK, a.n, a.c, tid, mg);
                 stage_load<TB, BN, BK>(rb, Bn, 1, a.ldb, bn0, k0 + BK, a.c, a.c, tid, mbn);
@@ -592,7 +601,13 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
                         accD[i][j] = MF::mma(av[i], bv2[j], accD[i][j]);
                     }
             }
+            SKF_PSTAMP(3)
         }
+#ifdef SKF_PROBE_STAMPS
+        if (tid == 0 && blockIdx.y == gridDim.y / 2 && blockIdx.x == 0 && a.n >= 20000)
+            printf("side_update phase 2 loop n %d c %d: first barrier %lld, registers -> LDS (waits for the loads) %lld, second barrier %lld, issue + matrix cores %lld (x10 ns)\n",
+                   a.n, a.c, pw[0], pw[1], pw[2], pw[3]);
+#endif
     }
 #ifdef SKF_PROBE_STAMPS
     const long long su2 = wall_clock64();
