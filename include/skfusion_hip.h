@@ -197,6 +197,14 @@ int skf_iterate_batch(skf_plan* const* plans, int32_t n_plans, int32_t n_iters, 
 /* *yes = 1 when the (bound) plan can be one of the plans of skf_iterate_batch: the schedule for small graphs, or a fold-in
  * without constraints on the target type. */
 int skf_plan_batchable(const skf_plan* plan, int32_t* yes);
+/* The limits behind that verdict for SKF_DFMF plans in f32 / f64 (the three-launch schedule of small graphs): every rank
+ * <= *max_rank, every type <= *max_objects objects, at most *max_types / *max_relations / *max_constraints of each, every
+ * constraint sparse (0 < nnz <= n * n / *constraint_nnz_divisor), no masked, absent or row-block relation -- so that a host
+ * layer can decide whether restarts will share launches WITHOUT uploading the graph (the reference hands restarts to joblib
+ * workers, dfmf.py:87-95; here the host picks between skf_iterate_batch and one plan after the other).  Null pointers are
+ * skipped. */
+int skf_small_graph_limits(int32_t* max_rank, int64_t* max_objects, int32_t* max_types, int32_t* max_relations,
+                           int32_t* max_constraints, int32_t* constraint_nnz_divisor);
 /* enable != 0: iterations 2..n of skf_iterate replay ONE captured hipGraph (a single host call per
  * iteration instead of one per kernel).  Off by default -- a single fit is bound by kernel time --
  * and switched on for restarts that run CONCURRENTLY on several streams of one GPU, where the

@@ -127,3 +127,15 @@ def sum_over_ranks(values):
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device='cuda' if on_gpu else 'cpu')
     d.all_reduce(t, op=d.ReduceOp.SUM)
     return [float(v) for v in t.cpu().tolist()]
+
+
+def same_on_all_ranks(value):
+    """Rank 0's `value` on every rank (a picklable host decision that fixes a layout or a partial-sum convention for the
+    whole group -- e.g. whether a masked relation is kept as lists of its known entries: each rank would otherwise read
+    its own environment); the value itself without a group."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return value
+    box = [value]
+    d.broadcast_object_list(box, src=0)
+    return box[0]

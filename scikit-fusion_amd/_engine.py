@@ -92,15 +92,31 @@ def owned_rows(dtype, n_obj, part_index, part_count, runtime=None):
     return b.value, c.value, ch.value
 
 
+_SMALL_LIMITS = {}
+
+
+def small_graph_limits(runtime=None):
+    """The library's limits for the three-launch schedule of small graphs / shared launches of restarts
+    (skf_small_graph_limits), read once per runtime."""
+    rt = runtime or nat.get_runtime()
+    if id(rt) not in _SMALL_LIMITS:
+        mr, mo, mt, ml, mc, dv = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        rt.call('skf_small_graph_limits', C.byref(mr), C.byref(mo), C.byref(mt), C.byref(ml), C.byref(mc), C.byref(dv))
+        _SMALL_LIMITS[id(rt)] = dict(max_rank=mr.value, max_objects=mo.value, max_types=mt.value, max_relations=ml.value,
+                                     max_constraints=mc.value, constraint_nnz_divisor=dv.value)
+    return _SMALL_LIMITS[id(rt)]
+
+
 def known_lists_pay(known, rows, cols, rank_row, dtype):
     """Whether a masked relation of rows x cols entries, `known` of them known, is worth keeping as lists of its known entries
     (the library's own rule for whole relations, skf_plan_create: share of known entries x rank of the row type <= 4;
     SKF_DFMC_SPARSE=0 never, =1 up to a quarter known) -- for plans with owned rows, where the caller decides for all ranks
-    alike (SKF_REL_KNOWN_LISTS)."""
+    alike (SKF_REL_KNOWN_LISTS: the flag fixes the partial-sum convention of Q and W, so the callers take rank 0's answer,
+    `_distributed.same_on_all_ranks` -- an environment that differs between ranks must not split them)."""
     import os
     mode = os.environ.get('SKF_DFMC_SPARSE')
     cells = float(rows) * float(cols)
-    if mode == '0' or known <= 0 or cells <= 0 or rank_row > 1024:
+    if mode == '0' or known <= 0 or cells <= 0 or rank_row > 1024 or known > 2000000000:      # (the library's own limits)
         return False
     share = known / cells
     return share <= 0.25 and (mode == '1' or share * rank_row <= 4.0)
@@ -108,9 +124,9 @@ def known_lists_pay(known, rows, cols, rank_row, dtype):
 
 def _sparse_bound(nnz, n):
     """skf_theta_desc.nnz for a constraint with `nnz` non-zeros: the count itself when the matrix is sparse enough for
-    the CSR path (<= n*n/16), 0 (dense product, as the reference) otherwise or when unknown."""
+    the CSR path (<= n*n / the library's divisor, 16), 0 (dense product, as the reference) otherwise or when unknown."""
     nnz = int(nnz or 0)
-    return max(nnz, 1) if 0 < nnz <= (int(n) * int(n)) // 16 else 0
+    return max(nnz, 1) if 0 < nnz <= (int(n) * int(n)) // small_graph_limits()['constraint_nnz_divisor'] else 0
 
 
 _FILL = {'mean': 0, 'row_mean': 1, 'col_mean': 2, 'const': 3}
@@ -189,18 +205,50 @@ def _exchange(mem, tensors, reduce=None):
     mem.synchronize()
 
 
-_RCCL = {}          # (rank, world) -> communicator handle, or False when RCCL could not be bound on every rank
+_RCCL = {}          # (rank, world, identity of the default process group) -> communicator handle (None: RCCL not bound on every rank)
+
+
+def _group_token(dist):
+    """What tells one default process group from the next one with the same (rank, world): the name torch gives every group
+    it creates, else the identity of the group object."""
+    try:
+        pg = dist.distributed_c10d._get_default_group()
+        return getattr(pg, 'group_name', None) or id(pg)
+    except Exception:
+        return None
+
+
+def release_rccl_comms(runtime=None):
+    """Destroy the RCCL communicators this process created (atexit; call it before destroy_process_group when the process
+    goes on to create another group -- a later group with the same rank / world never reuses a handle of an earlier one
+    either way: the cache is keyed on the group)."""
+    for key, comm in list(_RCCL.items()):
+        _RCCL.pop(key, None)
+        if comm:
+            try:
+                (runtime or nat.get_runtime()).lib.skf_comm_destroy(comm)
+            except Exception:
+                pass
 
 
 def _shared_rccl_comm(rt, dist):
-    """The process's RCCL communicator (created once, reused by every plan and restart), or None when it cannot be had on
-    EVERY rank -- all ranks then agree on the callback path instead of some blocking in a broadcast the others never
-    reach.  Collective: every rank of the group must call it."""
+    """The process's RCCL communicator for the CURRENT default process group (created once per group, reused by every plan
+    and restart), or None when it cannot be had on EVERY rank -- all ranks then agree on the callback path instead of some
+    blocking in a broadcast the others never reach.  A failure is remembered for that group only.  Collective: every rank
+    of the group must call it."""
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
-    key = (rank, world)
+    key = (rank, world, _group_token(dist))
     if key in _RCCL:
-        return _RCCL[key] or None
+        return _RCCL[key]
+    for stale in [k for k in _RCCL if k[:2] == key[:2]]:        # communicators of groups that no longer exist
+        comm = _RCCL.pop(stale)
+        if comm:
+            rt.lib.skf_comm_destroy(comm)
+    if not getattr(_shared_rccl_comm, '_atexit', False):
+        import atexit
+        atexit.register(release_rccl_comms)
+        _shared_rccl_comm._atexit = True
     ident = [None]
     if rank == 0:
         try:
@@ -225,14 +273,17 @@ def _shared_rccl_comm(rt, dist):
     if int(flag.item()) != 1:
         if ok:
             rt.lib.skf_comm_destroy(comm)
-        _RCCL[key] = False
+        _RCCL[key] = None
         return None
     _RCCL[key] = comm
     return comm
 
 
 def _torch_collective(mem, ws, dist, rank, world):
-    """skf_collective_fn over torch.distributed on views of the workspace `ws` (gloo groups: CPU tests, smoke runs)."""
+    """skf_collective_fn over torch.distributed on views of the workspace `ws`: the transport of gloo groups (CPU tests,
+    smoke runs: device views are staged through the host) and the fall-back of a group whose backend takes device tensors
+    (nccl = RCCL) when the library could not bind RCCL itself on every rank, or `force_callback` -- there the collective
+    runs on the device view directly (the nccl backend rejects host tensors)."""
     def collective(user, op, buf, count, dtype, stream):
         try:
             import torch
@@ -244,14 +295,19 @@ def _torch_collective(mem, ws, dist, rank, world):
             n = count * (1 if op == 0 else world)
             view = mem.as_tensor(ws, int(buf) - ws.ptr, n * es, npd)
             mem.synchronize()
-            host = view.cpu() if view.is_cuda else view
+            on_device = view.is_cuda and dist.get_backend() != 'gloo'
+            host = view if on_device else (view.cpu() if view.is_cuda else view)
             if op in (0, 1):              # (reduce-scatter: the all-reduce of the whole buffer covers the owned range)
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            elif on_device:
+                dist.all_gather_into_tensor(host, host[rank * count:(rank + 1) * count].clone())
             else:
                 parts = [torch.empty(count, dtype=host.dtype) for _ in range(world)]
                 dist.all_gather(parts, host[rank * count:(rank + 1) * count].clone())
                 host = torch.cat(parts)
-            if view.is_cuda or host is not view:
+            if on_device:
+                torch.cuda.synchronize()      # the backend's own stream: the engine's next launch must see the result
+            elif view.is_cuda or host is not view:
                 view.copy_(host)
             mem.synchronize()
             return 0
@@ -564,9 +620,18 @@ class DevicePlan(object):
         self.rt.call('skf_plan_set_comm', self.handle, self._comm)
         return True
 
+    def attach_single_comm(self):
+        """A genuine communicator of ONE rank without a transport (skf_comm_create(NULL, 0, 1)): every collective returns at
+        once and the iteration is the real one -- what a fit sharded by ownership runs on when the process has no group."""
+        self._comm = nat._P()
+        self._comm_shared = False
+        self.rt.call('skf_comm_create', None, 0, 1, C.byref(self._comm))
+        self.rt.call('skf_plan_set_comm', self.handle, self._comm)
+
     def attach_null_comm(self, rank, world):
         """A communicator whose collectives do nothing: times the compute of rank `rank` of `world` of a sharded fit on one
-        GPU (bench.py --emulate-rank); results are meaningless."""
+        GPU (bench.py --emulate-rank); results are meaningless: the factors are never updated.  NOT for fits -- a single
+        process takes attach_single_comm."""
         self._comm = nat._P()
         self._comm_shared = False
         self.rt.call('skf_comm_create_null', int(rank), int(world), C.byref(self._comm))
@@ -795,33 +860,30 @@ class DeviceReconstructor(object):
     """R_hat blocks = G_row[block] @ S @ G_col.T on the device (two strided MFMA GEMMs through ``skf_gemm``) with
     ``S`` and the column factor uploaded ONCE and kept resident across blocks -- the building block of
     ``FusionFit.complete_blocks`` for relations whose dense reconstruction does not fit on the host in one
-    piece (reference base.py:119-146 materialises the whole product)."""
+    piece (reference base.py:119-146 materialises the whole product) and of the chained latent profiles
+    (f4: ``S`` is then the product of the backbones along a ``chain()`` path).  ``G_col=None``: blocks are
+    ``G_row[block] @ S`` (the profile form of reference examples/pharma_chaining.py:43-53, one GEMM)."""
 
-    def __init__(self, S, G_col, dtype='f64', runtime=None):
+    def __init__(self, S, G_col=None, dtype='f64', runtime=None):
         self.rt = runtime or nat.get_runtime()
         code = nat.DTYPES[dtype]
         self.code = nat.SKF_F32 if code == nat.SKF_BF16 else code
         self.npd = nat.NP_DTYPE[self.code]
         self.es = np.dtype(self.npd).itemsize
         Sm = np.ascontiguousarray(S, dtype=self.npd)
-        B = np.ascontiguousarray(G_col, dtype=self.npd)
-        if Sm.ndim != 2 or B.ndim != 2 or B.shape[1] != Sm.shape[1]:
+        B = None if G_col is None else np.ascontiguousarray(G_col, dtype=self.npd)
+        if Sm.ndim != 2 or (B is not None and (B.ndim != 2 or B.shape[1] != Sm.shape[1])):
             raise ValueError('shape mismatch in reconstruction')
         self.ci, self.cj = Sm.shape
-        self.nj = B.shape[0]
+        self.nj = self.cj if B is None else B.shape[0]          # columns of a block
         self.s = self.rt.mem.from_host(Sm)
-        self.b = self.rt.mem.from_host(B)
-        self.uploads = 2                       # H2D copies of S / G_col so far (stays 2 whatever the block count)
+        self.b = None if B is None else self.rt.mem.from_host(B)
+        self.uploads = 1 if B is None else 2   # H2D copies of S / G_col so far (does not grow with the block count)
         self._h = self._out = None
         self._rows = 0
 
     def _gemm(self, Ap, sa_m, sa_k, Bp, sb_k, sb_n, Cp, ldc, M, N, K):
-        d = nat.GemmDesc()
-        d.A, d.B, d.C = Ap, Bp, Cp
-        d.sa_m, d.sa_k, d.sb_k, d.sb_n, d.ldc, d.ldc2 = sa_m, sa_k, sb_k, sb_n, ldc, ldc
-        d.M, d.N, d.K = M, N, K
-        d.splits, d.a_dtype, d.b_dtype = 1, -1, -1
-        self.rt.call('skf_gemm', self.code, nat.SKF_ENGINE_MFMA, C.byref(d), None, 0, self.rt.mem.stream)
+        _device_gemm(self.rt, self.code, Ap, sa_m, sa_k, Bp, sb_k, sb_n, Cp, ldc, M, N, K)
 
     def block(self, G_row_block, device=False):
         """Reconstruction of the rows of this block: a host ndarray (float64), or -- device=True -- a
@@ -833,15 +895,53 @@ class DeviceReconstructor(object):
         mem = self.rt.mem
         if m > self._rows:                     # scratch grows to the largest block seen, then is reused
             self._h = mem.empty(m * self.cj * self.es)
-            self._out = mem.empty(m * self.nj * self.es)
+            self._out = self._h if self.b is None else mem.empty(m * self.nj * self.es)
             self._rows = m
         a = mem.from_host(A)
         self._gemm(a.ptr, self.ci, 1, self.s.ptr, self.cj, 1, self._h.ptr, self.cj, m, self.cj, self.ci)      # H = G_blk S
-        self._gemm(self._h.ptr, self.cj, 1, self.b.ptr, 1, self.cj, self._out.ptr, self.nj, m, self.nj, self.cj)   # H G_col^T
+        if self.b is not None:
+            self._gemm(self._h.ptr, self.cj, 1, self.b.ptr, 1, self.cj, self._out.ptr, self.nj, m, self.nj, self.cj)   # H G_col^T
         mem.synchronize()
         if device:
             return DeviceMatrix(self._out, (m, self.nj))
         return mem.to_host(self._out, (m, self.nj), self.npd).astype(np.float64)
+
+
+def _device_gemm(rt, code, Ap, sa_m, sa_k, Bp, sb_k, sb_n, Cp, ldc, M, N, K):
+    """C[M x N] = A[M x K] B[K x N] through skf_gemm (strides in elements; matrix-core GEMM of the master type `code`)."""
+    d = nat.GemmDesc()
+    d.A, d.B, d.C = Ap, Bp, Cp
+    d.sa_m, d.sa_k, d.sb_k, d.sb_n, d.ldc, d.ldc2 = sa_m, sa_k, sb_k, sb_n, ldc, ldc
+    d.M, d.N, d.K = M, N, K
+    d.splits, d.a_dtype, d.b_dtype = 1, -1, -1
+    rt.call('skf_gemm', code, nat.SKF_ENGINE_MFMA, C.byref(d), None, 0, rt.mem.stream)
+
+
+def chain_backbone(backbones, runtime=None):
+    """Product of the backbones along one `chain()` path, S_01 S_12 ... (c_first x c_last), on the device in f64 whatever
+    the engine dtype (c x c work; the profile built from it inherits every digit lost here) -- left to right, the order of
+    `reduce(np.dot, cf)` in reference examples/dicty_chaining.py:43-45 / pharma_chaining.py:46-47.  Returns a float64
+    ndarray; an empty path has no backbone (the caller uses the factor itself)."""
+    rt = runtime or nat.get_runtime()
+    mats = [np.ascontiguousarray(S, dtype=np.float64) for S in backbones]
+    if not mats:
+        raise ValueError('an empty path has no backbone')
+    for a, b in zip(mats[:-1], mats[1:]):
+        if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[0]:
+            raise ValueError('backbones along the path do not chain: %r then %r' % (a.shape, b.shape))
+    if len(mats) == 1:
+        return mats[0].copy()
+    mem = rt.mem
+    ups = [mem.from_host(S, sync=False) for S in mats]          # every buffer lives until the last product is through:
+    mem.synchronize()                                           # the launches run on the engine's stream, not torch's
+    keep, acc, rows, inner = [], ups[0], mats[0].shape[0], mats[0].shape[1]
+    for S, nxt in zip(mats[1:], ups[1:]):
+        out = mem.empty(rows * S.shape[1] * 8)
+        keep.append(out)
+        _device_gemm(rt, nat.SKF_F64, acc.ptr, inner, 1, nxt.ptr, S.shape[1], 1, out.ptr, S.shape[1], rows, S.shape[1], inner)
+        acc, inner = out, S.shape[1]
+    mem.synchronize()
+    return mem.to_host(acc, (rows, inner), np.float64)
 
 
 def device_reconstruct(G_row_block, S, G_col, dtype='f64', runtime=None):

@@ -99,6 +99,8 @@ SIGNATURES = {
     'skf_iterate': (C.c_int, [_P, C.c_int32, _P]),
     'skf_iterate_batch': (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, _P]),
     'skf_plan_batchable': (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    'skf_small_graph_limits': (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'skf_plan_set_graph': (C.c_int, [_P, C.c_int32]),
     'skf_accumulate': (C.c_int, [_P, _P]),
     'skf_apply_update': (C.c_int, [_P, _P]),

@@ -3066,7 +3066,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             p->thetas[t].ld = thetas[t].ld;
             const int64_t nn = p->types[thetas[t].type].n;
             if (thetas[t].nnz < 0) SKF_FAIL(SKF_E_INVALID, "constraint %d: negative non-zero bound", t);
-            if (thetas[t].nnz > 0 && thetas[t].nnz <= nn * nn / 16) {
+            if (thetas[t].nnz > 0 && thetas[t].nnz <= nn * nn / SKF_THETA_SPARSE_DIV) {
                 p->thetas[t].sparse = true;
                 p->thetas[t].nnz_cap = thetas[t].nnz;
             }
@@ -3289,7 +3289,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                       n_relations >= 1 && n_relations <= SM_MAXR && n_thetas <= SM_MAXTH;
             // (object counts: the Q shares of the schedule grow with n_i / 256 * n_j * c_i, and from a few thousand objects
             // on the relation contractions are worth the big tiles of the general schedule)
-            for (const TypeState& t : p->types) ok = ok && t.c <= SMALLC && t.n <= 8192;
+            for (const TypeState& t : p->types) ok = ok && t.c <= SMALLC && t.n <= SM_MAX_OBJECTS;
             for (const ThetaState& th : p->thetas) ok = ok && th.sparse;
             for (const RelState& r : p->rels) ok = ok && !r.absent && !r.masked;
             p->small_fused = ok;
@@ -3929,6 +3929,18 @@ int skf_plan_batchable(const skf_plan* p, int32_t* yes) {
         check_bound(p);
         if (!yes) SKF_FAIL(SKF_E_INVALID, "null pointer");
         *yes = (p->small_fused || fold_fused(p)) ? 1 : 0;
+    });
+}
+
+int skf_small_graph_limits(int32_t* max_rank, int64_t* max_objects, int32_t* max_types, int32_t* max_relations,
+                           int32_t* max_constraints, int32_t* constraint_nnz_divisor) {
+    return guarded([&] {
+        if (max_rank) *max_rank = SMALLC;
+        if (max_objects) *max_objects = SM_MAX_OBJECTS;
+        if (max_types) *max_types = SM_MAXT;
+        if (max_relations) *max_relations = SM_MAXR;
+        if (max_constraints) *max_constraints = SM_MAXTH;
+        if (constraint_nnz_divisor) *constraint_nnz_divisor = SKF_THETA_SPARSE_DIV;
     });
 }
 

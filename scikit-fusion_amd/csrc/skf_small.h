@@ -21,6 +21,8 @@
 namespace skf {
 
 constexpr int SM_MAXT = 16, SM_MAXR = 24, SM_MAXTH = 16;
+constexpr int64_t SM_MAX_OBJECTS = 8192;     // objects per type up to which the three-launch schedule is chosen
+constexpr int64_t SKF_THETA_SPARSE_DIV = 16; // a constraint with at most n * n / 16 non-zeros is compacted to CSR
 struct SmType {
     void* G; void* E; void* D;
     double* Gram; double* K;

@@ -67,6 +67,75 @@ class FusionBase(object):
                         nxt.append(longer)
             frontier = nxt
 
+    # ---- chained latent profiles on the device --------------------------------------------------------
+    # The reference's base.py:69-96 only enumerates the paths; what its users compute from them is, per path c,
+    #     bb = reduce(np.dot, [backbone(first relation c[i] -> c[i+1])])          (examples/dicty_chaining.py:43-45)
+    #     profile = G_row . bb . G_col^T        (dicty_chaining.py:46-49)    or    G_row . bb   (pharma_chaining.py:48-50)
+    # hstack-ed over the object types and their paths (the path [row_type] contributes G_row itself).  At BASELINE config-3
+    # sizes one such block is 50k x 100k: it is produced blockwise on the device like `complete_blocks`.
+    def _chain_source(self, row_type, run):
+        """(the fit whose backbones / column factors the paths use, the factor of the starting type in run `run`)"""
+        raise NotImplementedError
+
+    def chain_paths(self, row_type, col_types=None, skip=()):
+        """[(col_type, path)] in the order the reference examples walk them: object types in `col_types` order (default:
+        the graph's), the paths of `chain()` for each, types in `skip` left out."""
+        fit, _ = self._chain_source(row_type, 0)
+        cols = list(fit.fusion_graph.object_types) if col_types is None else list(col_types)
+        out = []
+        for ct in cols:
+            if any(ct is s or ct == s for s in skip):
+                continue
+            for path in FusionBase.chain(fit, row_type, ct):      # the FITTED model's graph, also for a transformer
+                out.append((ct, path))
+        return out
+
+    def chain_backbone(self, path, run=None):
+        """Product of the backbones of the FIRST relation of every hop of `path` (as the examples take them), reduced on
+        the device in f64 (`_engine.chain_backbone`); None for the one-type path."""
+        from .._engine import chain_backbone
+        run = 0 if run is None else run
+        fit, _ = self._chain_source(path[0], run)
+        hops = []
+        for a, b in zip(path[:-1], path[1:]):
+            rels = list(fit.fusion_graph.get_relations(a, b))
+            if not rels:
+                raise DataFusionError("No relation %s -> %s on the path" % (a.name, b.name))
+            hops.append(fit.backbone(rels[0], run))
+        return chain_backbone(hops) if hops else None
+
+    def chain_profile_blocks(self, row_type, col_types=None, block_rows=4096, run=None, dtype='f64', project=True,
+                             skip=()):
+        """Yields ``(row_slice, X[row_slice])``: the chained latent profile of the objects of ``row_type`` (for a
+        transformer: of its target's NEW objects), at most ``block_rows`` rows at a time -- for every path of
+        ``chain_paths`` the block ``G_row[rows] . (prod of backbones) . G_col^T`` (``project=True``, reference
+        examples/dicty_chaining.py:40-53) or ``G_row[rows] . (prod of backbones)`` (``project=False``,
+        pharma_chaining.py:43-53), the one-type path contributing ``G_row[rows]`` itself, hstack-ed in path order.  The
+        backbone products (f64) and the column factors are uploaded once and stay resident across the blocks; the two
+        GEMMs of a block run in the master type of ``dtype`` ('f64' | 'f32' | 'bf16' -> f32).  float64 ndarrays."""
+        from .._engine import DeviceReconstructor
+        run = 0 if run is None else run
+        fit, G_row = self._chain_source(row_type, run)
+        G_row = np.asarray(G_row)
+        parts = []
+        for ct, path in self.chain_paths(row_type, col_types, skip):
+            bb = self.chain_backbone(path, run)
+            if bb is None:
+                parts.append(None)
+            else:
+                parts.append(DeviceReconstructor(bb, fit.factor(ct, run) if project else None, dtype=dtype))
+        if not parts:
+            raise DataFusionError("No path from %s to the requested object types" % row_type.name)
+        for r0 in range(0, G_row.shape[0], int(block_rows)):
+            sl = slice(r0, min(r0 + int(block_rows), G_row.shape[0]))
+            rows = G_row[sl]
+            yield sl, np.hstack([np.asarray(rows, dtype=np.float64) if rec is None else rec.block(rows) for rec in parts])
+
+    def chain_profile(self, row_type, col_types=None, run=None, dtype='f64', project=True, skip=(), block_rows=4096):
+        """The whole profile matrix (``np.vstack`` of ``chain_profile_blocks``) -- for sizes that fit the host."""
+        return np.vstack([blk for _, blk in self.chain_profile_blocks(row_type, col_types, block_rows, run, dtype,
+                                                                      project, skip)])
+
     def __repr__(self):
         inner = ', '.join('{}={}'.format(k, v) for k, v in (self._params or {}).items())
         return '{}({})'.format(type(self).__name__, inner)
@@ -76,6 +145,9 @@ class FusionBase(object):
 
 class FusionFit(FusionBase):
     """Accessors of a fitted fuser: backbones and reconstructed relations."""
+
+    def _chain_source(self, row_type, run):
+        return self, self.factor(row_type, run)
 
     def backbone(self, relation, run=None):
         """Backbone S of ``relation`` (rank_row x rank_col)."""
@@ -261,6 +333,13 @@ class FusionTransform(FusionBase):
             if self.target not in (relation.row_type, relation.col_type):
                 raise DataFusionError("Relation must include target object type: %s."
                                       % self.target.name)
+
+    def _chain_source(self, row_type, run):
+        # the paths, backbones and column factors are the fitted model's; the rows are the target's NEW objects
+        # (reference examples: profile(fuser, transformer) takes transformer.factor(gene) with fuser.chain / backbone)
+        if row_type is not None and row_type is not self.target:
+            raise DataFusionError("Starting type should be target type: %s" % self.target.name)
+        return self.fuser, self.factor(self.target, run)
 
     def chain(self, row_type=None, col_type=None):
         if row_type is not None and col_type is not None and row_type is not self.target:

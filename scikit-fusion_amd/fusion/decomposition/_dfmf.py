@@ -121,6 +121,7 @@ def owned_plan(variant, rel_list, theta_list, obj_types, n_obj, obj_type2rank, d
     of the rows of every object type (`_engine.owned_rows`) and holds exactly those rows of every relation whose row type
     it is -- work is 1 / size of every relation, the row-side terms never leave the rank -- and every constraint."""
     from ..._engine import is_binary_matrix, owned_rows, known_lists_pay
+    from ..._distributed import same_on_all_ranks
     local = []
     for (i, j, m, mask) in rel_list:
         begin, count, _ = owned_rows(dtype, n_obj[i], rank, size)
@@ -128,8 +129,8 @@ def owned_plan(variant, rel_list, theta_list, obj_types, n_obj, obj_type2rank, d
                 'absent': count == 0}
         if mask is not None and variant == nat.SKF_DFMC:      # lists of the known entries: one decision for all ranks
             mk = np.asarray(mask, dtype=bool)
-            info['known_lists'] = known_lists_pay(mk.size - int(np.count_nonzero(mk)), mk.shape[0], mk.shape[1],
-                                                  int(obj_type2rank[i]), dtype)
+            info['known_lists'] = same_on_all_ranks(known_lists_pay(
+                mk.size - int(np.count_nonzero(mk)), mk.shape[0], mk.shape[1], int(obj_type2rank[i]), dtype))
         if dtype == 'bf16' and mask is None:         # decided on the whole relation: the same path on every rank
             info['binary'] = is_binary_matrix(m)
         if count == 0:
@@ -159,7 +160,9 @@ def run_fit_owned(variant, R, M, Theta, obj_types, obj_type2rank, max_iter, init
     plan = owned_plan(variant, rel_list, flatten_thetas(Theta), obj_types, n_obj, obj_type2rank, dtype, engine, rank, size)
     try:
         if not plan.attach_comm():
-            plan.attach_null_comm(0, 1)        # a single process: every row is owned here, nothing to exchange
+            # a single process: every row is owned here and nothing is exchanged -- a genuine communicator of one rank (the
+            # null communicator of bench.py --emulate-rank never updates the factors: not for fits)
+            plan.attach_single_comm()
         for t in obj_types:
             plan.set_factor(t, G0[t, t])
         if not (callback or stopping or stopping_system or compute_err):

@@ -100,20 +100,27 @@ def shared_launches(fuser):
         return False
     if not (fuser.shard == 'runs' and world()[1] <= 1 and fuser.dtype in ('f64', 'f32')):
         return False
-    # the schedule for small graphs, decided here on the host (every rank <= 64, at most 8192 objects per type, constraints
-    # sparse enough for the CSR path) -- not by uploading the graph and binding a plan only to ask skf_plan_batchable
+    # the schedule for small graphs, decided here on the host from the library's own limits (skf_small_graph_limits) -- not
+    # by uploading the graph and binding a plan only to ask skf_plan_batchable, and not from a second copy of the constants
+    from ..._engine import small_graph_limits
+    lim = small_graph_limits()
     graph = fuser.fusion_graph
-    for ot in graph.object_types:
-        if int(ot.rank) > 64:
-            return False
+    types = list(graph.object_types)
+    if len(types) > lim['max_types'] or any(int(ot.rank) > lim['max_rank'] for ot in types):
+        return False
+    n_rel = n_theta = 0
     for rel in graph.relations:
-        if max(rel.data.shape) > 8192:
+        if max(rel.data.shape) > lim['max_objects']:
             return False
         if rel.row_type is rel.col_type:
+            n_theta += 1
             n = rel.data.shape[0]
-            if int(np.count_nonzero(np.ma.getdata(rel.data))) > n * n // 16:
+            nnz = int(np.count_nonzero(np.ma.getdata(rel.data)))
+            if nnz == 0 or nnz > n * n // lim['constraint_nnz_divisor']:
                 return False
-    return True
+        else:
+            n_rel += 1
+    return 1 <= n_rel <= lim['max_relations'] and n_theta <= lim['max_constraints']
 
 
 def store_runs(fuser, runs):

@@ -468,3 +468,118 @@ def fold_in_of_several_runs_shares_launches(dtype='f64', n_new=15, tol=1e-9):
         G0 = initialize([t1], {t1: n_new}, rank, {}, 'random', draw)[t1, t1]
         want = orc.transform(Rn, {}, t1, rank, G, S, max_iter=12, G0=G0)
         assert relerr(got[run], want) < tol, (dtype, run)
+
+
+def sharded_fits_of_a_single_process_are_the_plain_fit(dtype='f64', tol=1e-11, max_iter=4):
+    """`shard='owned' | 'rows' | 'relations'` on ONE process without a torch.distributed group and without
+    SKF_FORCE_COLLECTIVES (the owned mode had fallen to the null communicator of bench.py --emulate-rank,
+    which never updates the factors, and returned G0): every mode is then the plain fit -- same factors, same backbones
+    (f64: the same launches in another order, 1e-11; f32: its engine tolerance)."""
+    import os
+    from helpers import relerr
+    assert not os.environ.get('SKF_FORCE_COLLECTIVES')
+    checked = 0
+    for cls, masked in ((Dfmf, False), (Dfmc, True)):
+        graph, ot = probe_fusion_graph(masked)
+        kw = dict(init_type='random', random_state=np.random.RandomState(5), max_iter=max_iter, dtype=dtype)
+        plain = cls(**kw).fuse(graph)
+        g0_far = 0.0
+        for shard in ('owned', 'rows', 'relations'):
+            kw['random_state'] = np.random.RandomState(5)
+            fit = cls(shard=shard, **kw).fuse(graph)
+            for t in ot.values():
+                assert relerr(fit.factor(t), plain.factor(t)) < tol, (cls.__name__, shard, t.name)
+            for rel in graph.relations:
+                if rel.row_type is not rel.col_type:
+                    assert relerr(fit.backbone(rel), plain.backbone(rel)) < max(tol, 1e-9 if dtype == 'f64' else tol)
+            checked += 1
+        # ... and the plain fit did move away from its initial factors (the comparison above is not G0 against G0)
+        first = cls(**dict(kw, max_iter=1, random_state=np.random.RandomState(5))).fuse(graph)
+        for t in ot.values():
+            g0_far = max(g0_far, relerr(plain.factor(t), first.factor(t)))
+        assert g0_far > 1e-3
+    return checked
+
+
+def callback_transport_on_device_views(dtype='f64', tol=1e-11):
+    """the callback communicator under a backend that takes device tensors only (nccl) -- its
+    all-reduce / all-gather run on the device views of the workspace, not on host copies the backend rejects.  Needs an
+    initialised process group; `force_callback` keeps the library from binding RCCL itself."""
+    from helpers import golden, probe_graph, relerr, g0_from
+    import skfusion_amd._native as nat
+    from skfusion_amd.fusion.decomposition import _dfmf
+    z = golden('probe_multirel.npz')
+    R, Theta, M, types, rank = probe_graph(z)
+    G0 = g0_from(z, 'dfmf/', types)
+    Gp, Sp = _dfmf.dfmf(R, Theta, types, rank, max_iter=3, G0=G0, dtype=dtype)
+    n_obj = _dfmf.count_objects(types, R)
+    plan = _dfmf.owned_plan(nat.SKF_DFMF, _dfmf.flatten_relations(R, None), _dfmf.flatten_thetas(Theta), types, n_obj, rank,
+                            dtype, None, 0, 1)
+    try:
+        import os
+        os.environ['SKF_FORCE_COLLECTIVES'] = '1'
+        try:
+            assert plan.attach_comm(force_callback=True)
+        finally:
+            del os.environ['SKF_FORCE_COLLECTIVES']
+        for t in types:
+            plan.set_factor(t, G0[t, t])
+        plan.iterate_dist(3)
+        for t in types:
+            assert relerr(plan.get_factor(t), Gp[t, t]) < tol
+    finally:
+        plan.close()
+
+
+def chained_profiles_match_the_reference_examples(dtype='f64', tol=1e-9, block_rows=17):
+    """SURVEY 8 f4 / VERDICT round 4 #4: `chain_profile_blocks` of a fit and of a transformer against
+    tests/golden/chain_profiles.npz -- the REFERENCE's fit and fold-in of a four-type graph with one-, two- and three-hop
+    paths, the profiles computed by tools/gen_golden.py with the arithmetic of the reference's own examples
+    (examples/dicty_chaining.py:40-53: G_row . prod(S) . G_col^T, one type skipped; pharma_chaining.py:43-53: G_row . prod(S)).
+    The fitted (G, S) of the golden are attached to this package's classes; paths, backbone products (device, f64), blocks
+    (device, `dtype`) and the hstack order are this package's.  Blocks of 17 rows: several blocks, a ragged last one."""
+    from helpers import golden, relerr
+    z = golden('chain_profiles.npz')
+    names = 'ABCD'
+    ot = {k: ObjectType(k, int(z['G_' + k].shape[1])) for k in names}
+    pairs = [('A', 'B'), ('A', 'C'), ('B', 'C'), ('B', 'D'), ('C', 'D')]
+    nan = lambda a, b: np.broadcast_to(np.nan, (z['G_' + a].shape[0], z['G_' + b].shape[0]))     # noqa: E731
+    rels = {k: Relation(nan(*k), ot[k[0]], ot[k[1]]) for k in pairs}
+    graph = FusionGraph(list(rels.values()) + [Relation(nan('A', 'A'), ot['A'], ot['A'])])
+    fuser = Dfmf()
+    fuser.fusion_graph = graph
+    for k in names:
+        fuser.factors_[ot[k]].append(z['G_' + k])
+    for k in pairs:
+        fuser.backbones_[rels[k]].append(z['S_%s_%s' % k])
+    n_new = z['G_new_A'].shape[0]
+    transformer = DfmfTransform()
+    transformer.target, transformer.fuser = ot['A'], fuser
+    transformer.fusion_graph = FusionGraph([Relation(np.broadcast_to(np.nan, (n_new, z['G_' + b].shape[0])), ot['A'], ot[b])
+                                            for b in 'BC'])
+    transformer.factors_[ot['A']].append(z['G_new_A'])
+    order = [ot[k] for k in names]
+
+    said = ['>'.join(t.name for t in path) for _, path in fuser.chain_paths(ot['A'], order)]
+    assert said == [str(s) for s in z['paths/all']]
+    said = ['>'.join(t.name for t in path) for _, path in fuser.chain_paths(ot['A'], order, skip=[ot['B']])]
+    assert said == [str(s) for s in z['paths/skipB']]
+    # a three-hop backbone product against the host product of the golden's backbones
+    bb = fuser.chain_backbone([ot[k] for k in 'ABCD'])
+    assert relerr(bb, z['S_A_B'].dot(z['S_B_C']).dot(z['S_C_D'])) < 1e-13
+    worst = 0.0
+    for who, tag in ((fuser, 'fit'), (transformer, 'new')):
+        for project, skip, key in ((True, [ot['B']], '_project_skipB'), (False, (), '_plain')):
+            want = z['profile/' + tag + key]
+            seen = 0
+            for sl, blk in who.chain_profile_blocks(ot['A'], order, block_rows=block_rows, dtype=dtype, project=project,
+                                                    skip=skip):
+                assert blk.shape == (sl.stop - sl.start, want.shape[1]) and sl.start == seen
+                worst = max(worst, relerr(blk, want[sl]))
+                seen = sl.stop
+            assert seen == want.shape[0]
+            assert relerr(who.chain_profile(ot['A'], order, dtype=dtype, project=project, skip=skip), want) <= max(worst, tol)
+    assert worst < tol, worst
+    with np.testing.assert_raises(DataFusionError):       # a transformer's profiles start at its target
+        list(transformer.chain_profile_blocks(ot['B'], order))
+    return worst

@@ -82,3 +82,14 @@ def test_early_stopping_inside_sharded_fits_of_a_one_rank_group(monkeypatch):
 
 def test_fold_in_of_several_runs_shares_launches():
     A.fold_in_of_several_runs_shares_launches('f64')
+
+
+def test_chained_profiles_match_the_reference_examples():
+    """f4: chained latent profiles (fit and transformer, both example forms) against the golden of the reference run."""
+    assert A.chained_profiles_match_the_reference_examples('f64', 1e-12) < 1e-12
+
+
+def test_sharded_fits_of_a_single_process_are_the_plain_fit(monkeypatch):
+    """shard='owned' / 'rows' / 'relations' without a process group and without SKF_FORCE_COLLECTIVES: the plain fit, not G0."""
+    monkeypatch.delenv('SKF_FORCE_COLLECTIVES', raising=False)
+    assert A.sharded_fits_of_a_single_process_are_the_plain_fit('f64', 1e-11, max_iter=3) == 6

@@ -68,6 +68,40 @@ def test_early_stopping_through_the_classes_single_device_and_sharded(monkeypatc
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-12), ('f32', 2e-6), ('bf16', 2e-6)])
+def test_chained_profiles_match_the_reference_examples(dtype, tol):
+    """chained latent profiles on the device -- backbone products in f64, blocks through
+    the matrix-core GEMM of the engine's master type -- against the golden of the reference's fit / fold-in with the
+    arithmetic of its own examples (dicty_chaining.py:40-53, pharma_chaining.py:43-53)."""
+    from helpers import within
+    within(A.chained_profiles_match_the_reference_examples(dtype, tol), tol, 'chained profiles vs reference golden, ' + dtype)
+
+
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-11), ('f32', 1e-5)])
+def test_sharded_fits_of_a_single_process_are_the_plain_fit(dtype, tol, monkeypatch):
+    """shard='owned' on one process without a group returned the unfitted G0 (null communicator).  Every
+    sharded mode of a single process is the plain fit; also with the nccl fall-back transport (collectives of the callback
+    communicator on device views) over a one-rank RCCL group."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    monkeypatch.delenv('SKF_FORCE_COLLECTIVES', raising=False)
+    assert A.sharded_fits_of_a_single_process_are_the_plain_fit(dtype, tol) == 6
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    try:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                                device_id=torch.device('cuda', torch.cuda.current_device()))
+    except Exception as exc:                                  # pragma: no cover
+        pytest.skip('no one-rank RCCL group on this box: %r' % (exc,))
+    try:
+        A.callback_transport_on_device_views(dtype, tol)
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize('dtype,tol', [('f64', 1e-9), ('f32', 1e-5), ('bf16', 1e-2)])
 def test_fold_in_of_several_runs_shares_launches(dtype, tol):
     A.fold_in_of_several_runs_shares_launches(dtype, tol=tol)

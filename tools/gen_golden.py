@@ -390,8 +390,76 @@ def gen_fill():
     save('fill_strategies.npz', out)
 
 
+# ------------------------------------------------------------------ f4: chained latent profiles
+def chain_graph_data():
+    """Four types with multi-hop paths from A: A->B, A->C, B->C, B->D, C->D (+ a constraint on A), new A objects for the
+    fold-in.  (sizes, ranks, matrices) from one seed -- tests/helpers.chain_graph rebuilds the same arrays."""
+    rs = np.random.RandomState(21)
+    sizes = {'A': 60, 'B': 45, 'C': 30, 'D': 25}
+    ranks = {'A': 7, 'B': 5, 'C': 6, 'D': 4}
+    mats = {('A', 'B'): rs.rand(60, 45), ('A', 'C'): rs.rand(60, 30), ('B', 'C'): rs.rand(45, 30),
+            ('B', 'D'): rs.rand(45, 25), ('C', 'D'): rs.rand(30, 25)}
+    th = np.zeros((60, 60))
+    idx = rs.randint(0, 60, size=(40, 2))
+    th[idx[:, 0], idx[:, 1]] = -0.05
+    th = 0.5 * (th + th.T)
+    new = {('A', 'B'): rs.rand(12, 45), ('A', 'C'): rs.rand(12, 30)}
+    return sizes, ranks, mats, th, new
+
+
+def gen_chain():
+    """The REFERENCE classes fit the graph and fold new objects in; the profiles are computed with the arithmetic of the
+    reference's own examples (examples/dicty_chaining.py:40-53 `profile`: G_row . reduce(dot, backbones) . G_col^T, one type
+    skipped; examples/pharma_chaining.py:43-53: G_row . reduce(dot, backbones)) on the reference's (G, S), for the fit's own
+    objects and for the transformer's new ones.  Stored: every factor, every backbone, the transformer's factor, the
+    path list (type names) and the four profile matrices."""
+    from functools import reduce
+    sizes, ranks, mats, th, new = chain_graph_data()
+    f = skf.fusion
+    ot = {k: f.ObjectType(k, ranks[k]) for k in 'ABCD'}
+    rels = {k: f.Relation(m, ot[k[0]], ot[k[1]]) for k, m in mats.items()}
+    graph = f.FusionGraph(list(rels.values()) + [f.Relation(th, ot['A'], ot['A'])])
+    fuser = f.Dfmf(max_iter=30, init_type='random', random_state=np.random.RandomState(3)).fuse(graph)
+    tgraph = f.FusionGraph([f.Relation(new[k], ot[k[0]], ot[k[1]]) for k in new])
+    transformer = f.DfmfTransform(max_iter=30, init_type='random', random_state=np.random.RandomState(4))
+    transformer.transform(ot['A'], tgraph, fuser)
+    order = [ot[k] for k in 'ABCD']
+
+    def profile(fuser, transformer, project, skip=None):
+        X, paths = [], []
+        for obj_type in order:
+            for c in fuser.chain(ot['A'], obj_type):
+                if obj_type is skip:
+                    continue
+                cf = [fuser.backbone(fuser.fusion_graph[c[i]][c[i + 1]][0]) for i in range(len(c) - 1)]
+                bb = reduce(np.dot, cf) if cf != [] else []
+                row_factor = transformer.factor(ot['A'])
+                if project:
+                    obj_factor = fuser.factor(obj_type)
+                    X.append(np.dot(row_factor, np.dot(bb, obj_factor.T)) if len(cf) else row_factor)
+                else:
+                    X.append(np.dot(row_factor, bb) if len(cf) else row_factor)
+                paths.append('>'.join(t.name for t in c))
+        return np.hstack(X), paths
+
+    out = {}
+    for k in 'ABCD':
+        out['G_%s' % k] = fuser.factor(ot[k])
+    for k, r in rels.items():
+        out['S_%s_%s' % k] = fuser.backbone(r)
+    out['G_new_A'] = transformer.factor(ot['A'])
+    X, paths = profile(fuser, fuser, True, skip=ot['B'])
+    out['profile/fit_project_skipB'], out['paths/skipB'] = X, np.array(paths)
+    X, paths = profile(fuser, fuser, False)
+    out['profile/fit_plain'], out['paths/all'] = X, np.array(paths)
+    out['profile/new_project_skipB'] = profile(fuser, transformer, True, skip=ot['B'])[0]
+    out['profile/new_plain'] = profile(fuser, transformer, False)[0]
+    assert len(out['paths/all']) == 7 and 'A>B>C>D' in set(out['paths/all'])
+    save('chain_profiles.npz', out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['c1', 'probe', 'rd', 'transform', 'dicty', 'c3s', 'c3p', 'c5', 'fill']
+    which = sys.argv[1:] or ['c1', 'probe', 'rd', 'transform', 'dicty', 'c3s', 'c3p', 'c5', 'fill', 'chain']
     G = S = None
     if 'c1' in which or 'transform' in which:
         G, S = gen_c1()
@@ -411,3 +479,5 @@ if __name__ == '__main__':
         gen_c5()
     if 'fill' in which:
         gen_fill()
+    if 'chain' in which:
+        gen_chain()
