@@ -2013,9 +2013,16 @@ __global__ __launch_bounds__(256) void fill_apply_kernel(T* __restrict__ X, int6
         const bool unknown = (mask && mask[r * ldm + c]) || !(v - v == (T)0);      // masked, NaN or +-inf
         if (!unknown) continue;
         double f = value;
-        if (strategy == FILL_MEAN) f = overall;
-        else if (strategy == FILL_ROW_MEAN) f = stats[rows + r] > 0.0 ? stats[r] / stats[rows + r] : overall;
-        else if (strategy == FILL_COL_MEAN) f = stats[2 * rows + cols + c] > 0.0 ? stats[2 * rows + c] / stats[2 * rows + cols + c] : overall;
+        if (strategy == FILL_MEAN) {
+            f = overall;
+        } else if (strategy == FILL_ROW_MEAN || strategy == FILL_COL_MEAN) {
+            // the line's mean (0 / 0 = NaN without a known entry; inf - inf = NaN); a line without a usable mean takes the
+            // overall one -- with a mask every non-finite line mean (the reference masks them: masked_invalid,
+            // fusion_graph.py:479-480), without one only NaN (:483)
+            f = strategy == FILL_ROW_MEAN ? stats[r] / stats[rows + r] : stats[2 * rows + c] / stats[2 * rows + cols + c];
+            const bool unusable = mask ? !(f - f == 0.0) : (f != f);
+            if (unusable) f = overall;
+        }
         X[r * ld + c] = (T)f;
     }
 }

@@ -42,46 +42,73 @@ class ObjectType(object):
 
 
 # ---- fill strategies: what Relation.filled() does to NaN / inf / masked entries ------------
-# The operation sequences follow reference fusion_graph.py:464-501 one to one, because the
-# resulting masked-ness (which Dfmc turns into its completion mask, dfmc.py:77-82) depends on
-# NumPy's masked-array assignment rules; tests/golden/fill_strategies.npz pins the outcome.
-def _unknown(x):
-    bad = ~np.isfinite(x)
-    return np.logical_or(bad, x.mask) if np.ma.is_masked(x) else bad
+# Stated here as the OUTCOME the reference's masked-array statements (fusion_graph.py:464-501) have under NumPy, which
+# tests/golden/fill_strategies.npz pins bit for bit (incl. non-finite values under the mask, rows / columns unknown
+# throughout, both infinities in one line):
+#   unknown entry      = NaN, +-inf, or masked
+#   a mean             = numpy.nanmean: over the entries that are neither NaN nor masked -- an infinity COUNTS, so a line
+#                        holding one has an infinite (or NaN) mean, exactly as in the reference
+#   'mean', constant   -> the value is written into every unknown entry, also beneath the mask; the mask itself stays (Dfmc
+#                        turns it into its completion mask, dfmc.py:77-82)
+#   'row_mean'         -> every unknown entry takes the mean of its row, and the result carries no mask any more; a row
+#                        without a usable mean (masked input: non-finite; plain input: NaN) takes the matrix mean
+#   'col_mean'         -> the same along the columns
+# The same rules run on the device in skf_fill_unknown (`Relation.filled_device`).
+def _values_and_mask(x):
+    values = np.ma.getdata(x)
+    return values, (np.ma.getmaskarray(x) if np.ma.is_masked(x) else None)
+
+
+def _mean_of_known(values, hidden, axis=None):
+    """numpy.nanmean with the masked entries left out: sums of the zero-substituted matrix in NumPy's own reduction order
+    (the results carry the same bits as the reference's), divided by the number of entries that count."""
+    left_out = np.isnan(values) if hidden is None else np.logical_or(np.isnan(values), hidden)
+    total = np.where(left_out, 0.0, values).sum(axis=axis)
+    count = values.size - left_out.sum() if axis is None else values.shape[axis] - left_out.sum(axis=axis)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        return np.true_divide(total, count)
+
+
+def _unknown(values, hidden):
+    bad = ~np.isfinite(values)
+    return bad if hidden is None else np.logical_or(bad, hidden)
+
+
+def _write_beneath(x, where, value):
+    out = x.copy()
+    np.ma.getdata(out)[where] = value            # (a masked entry keeps its mask: only the stored value changes)
+    return out
 
 
 def fill_mean(x):
-    value = np.nanmean(x)
-    where = _unknown(x)
-    out = x.copy()
-    out[where] = value
-    return out
-
-
-def fill_row(x):
-    per_row = np.nanmean(x, 1)
-    overall = np.nanmean(x)
-    if np.ma.is_masked(x):
-        per_row = np.ma.filled(np.ma.masked_invalid(per_row), overall)
-        where = np.logical_or(~np.isfinite(x.data), x.mask)
-    else:
-        per_row[np.isnan(per_row)] = overall
-        where = ~np.isfinite(x)
-    out = x.copy()
-    out[where] = np.take(per_row, where.nonzero()[0])
-    return out
-
-
-def fill_col(x):
-    return fill_row(x.T).T
+    values, hidden = _values_and_mask(x)
+    return _write_beneath(x, _unknown(values, hidden), _mean_of_known(values, hidden))
 
 
 def fill_const(x, const):
-    out = x.copy()
-    out[~np.isfinite(x)] = const
-    if np.ma.is_masked(x):
-        out.data[x.mask] = const
-    return out
+    values, hidden = _values_and_mask(x)
+    return _write_beneath(x, _unknown(values, hidden), const)
+
+
+def _fill_lines(x, axis):
+    """Every unknown entry <- the mean of its line (axis=1: row, axis=0: column)."""
+    values, hidden = _values_and_mask(x)
+    line = np.atleast_1d(_mean_of_known(values, hidden, axis=axis))
+    unusable = np.isnan(line) if hidden is None else ~np.isfinite(line)
+    line = np.where(unusable, _mean_of_known(values, hidden), line)
+    where = _unknown(values, hidden)
+    filled = np.array(values, copy=True)
+    per_entry = np.broadcast_to(line[:, None] if axis == 1 else line[None, :], values.shape)
+    filled[where] = per_entry[where]
+    return filled if not np.ma.isMaskedArray(x) else np.ma.MaskedArray(filled, mask=np.zeros(values.shape, dtype=bool))
+
+
+def fill_row(x):
+    return _fill_lines(x, 1)
+
+
+def fill_col(x):
+    return _fill_lines(x, 0)
 
 
 _FILLERS = {'mean': fill_mean, 'row_mean': fill_row, 'col_mean': fill_col}
@@ -194,6 +221,9 @@ class FusionGraph(object):
     draw_networkx = draw_graphviz
 
     # ---- mutation ---------------------------------------------------------------------------
+    # Bookkeeping rule (what reference fusion_graph.py:174-251 maintains, stated once): `relations` is the truth; an object
+    # type is part of the graph exactly as long as some relation mentions it; `adjacency_matrix[row][col]` lists the
+    # relations of a pair in insertion order and holds no empty lists; the two name tables follow.
     def add_relation(self, relation):
         self.relations[relation] = True
         if relation.name:
@@ -201,47 +231,44 @@ class FusionGraph(object):
         for ot in (relation.row_type, relation.col_type):
             self.object_types[ot] = True
             self._name2object_type[ot.name] = ot
-        row = self.adjacency_matrix.setdefault(relation.row_type, {})
-        row[relation.col_type] = row.get(relation.col_type, []) + [relation]
+        pairs = self.adjacency_matrix.setdefault(relation.row_type, {})
+        pairs[relation.col_type] = pairs.get(relation.col_type, []) + [relation]
 
     def add_relations_from(self, relations):
         for relation in relations:
             self.add_relation(relation)
 
-    def _isolated(self, object_type):
-        return not any(True for _ in self.in_neighbors(object_type)) and \
-            not any(True for _ in self.out_neighbors(object_type))
+    def _mentioned(self, object_type):
+        return any(object_type in relation for relation in self.relations)
+
+    def _forget_type(self, object_type):
+        self.adjacency_matrix.pop(object_type, None)
+        for pairs in self.adjacency_matrix.values():
+            pairs.pop(object_type, None)
+        self._name2object_type.pop(object_type.name, None)
+        self.object_types.pop(object_type, None)
 
     def remove_relation(self, relation):
-        row = self.adjacency_matrix[relation.row_type]
-        row[relation.col_type].remove(relation)
-        self.relations.pop(relation)
+        pairs = self.adjacency_matrix[relation.row_type]
+        pairs[relation.col_type].remove(relation)
+        if not pairs[relation.col_type]:
+            del pairs[relation.col_type]
+        del self.relations[relation]
         if relation.name:
             self._name2relation.pop(relation.name, None)
-        if not row[relation.col_type]:
-            row.pop(relation.col_type, None)
-        if self._isolated(relation.row_type):
-            self.remove_object_type(relation.row_type)
-            if relation.row_type == relation.col_type:
-                return
-        if self._isolated(relation.col_type):
-            self.remove_object_type(relation.col_type)
+        for ot in (relation.row_type, relation.col_type):      # a type nobody mentions any more leaves with its last relation
+            if ot in self.object_types and not self._mentioned(ot):
+                self._forget_type(ot)
 
     def remove_relations_from(self, relations):
         for relation in relations:
             self.remove_relation(relation)
 
     def remove_object_type(self, object_type):
-        for relation in list(self.relations):
-            if object_type in relation and relation in self.relations:
+        for relation in [r for r in self.relations if object_type in r]:
+            if relation in self.relations:
                 self.remove_relation(relation)
-        if object_type not in self.object_types:
-            return          # dropped as a side effect of removing its last relation
-        self.adjacency_matrix.pop(object_type, None)
-        for row in self.adjacency_matrix.values():
-            row.pop(object_type, None)
-        self._name2object_type.pop(object_type.name, None)
-        self.object_types.pop(object_type)
+        self._forget_type(object_type)
 
     def remove_object_types_from(self, object_types):
         for object_type in object_types:

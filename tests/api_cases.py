@@ -195,9 +195,9 @@ def device_fill_strategies():
     from helpers import golden
     z = golden('fill_strategies.npz')
     mem = nat.get_runtime().mem
-    for tag in ('masked', 'plain', 'finite'):
-        if tag == 'plain':
-            arr = z['plain'].copy()
+    for tag in ('masked', 'plain', 'finite', 'corner', 'plaincorner'):
+        if tag.startswith('plain'):
+            arr = z[tag].copy()
         else:
             arr = np.ma.MaskedArray(z[tag + '_data'].copy(), mask=z[tag + '_mask'].copy())
         for fv in ('mean', 'row_mean', 'col_mean', 0.5):

@@ -101,12 +101,12 @@ def test_object_type_and_relation_identity():
         FusionGraph([r1]).draw_graphviz('x.pdf')
 
 
-@pytest.mark.parametrize('tag', ['masked', 'plain', 'finite'])
+@pytest.mark.parametrize('tag', ['masked', 'plain', 'finite', 'corner', 'plaincorner'])
 @pytest.mark.parametrize('fv', ['mean', 'row_mean', 'col_mean', 0.5])
 def test_fill_strategies_match_reference_outputs(tag, fv):
     z = golden('fill_strategies.npz')
-    if tag == 'plain':
-        arr = z['plain'].copy()
+    if tag.startswith('plain'):
+        arr = z[tag].copy()
     else:
         arr = np.ma.MaskedArray(z[tag + '_data'].copy(), mask=z[tag + '_mask'].copy())
     with warnings.catch_warnings():

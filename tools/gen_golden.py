@@ -374,11 +374,28 @@ def gen_fill():
     y[y < 0.2] = np.nan
     y[3, 2] = -np.inf
     z = np.ma.masked_greater(rs.rand(6, 5), 0.6)            # masked, all finite
+    # corners the three inputs above do not reach: NaN / inf UNDER the mask, a row that is unknown throughout (masked, NaN),
+    # a column unknown throughout, +inf and -inf in one row
+    w = rs.rand(7, 6)
+    wm = np.ma.masked_greater(w.copy(), 0.75)
+    wm.data[np.ma.getmaskarray(wm) & (w > 0.9)] = np.nan        # non-finite values beneath the mask
+    wm.data[0, 0] = np.inf
+    wm[0, 0] = np.ma.masked
+    wm[2, :] = np.ma.masked                                     # row 2: masked throughout
+    wm.data[4, :] = np.nan                                      # row 4: NaN throughout, where not masked
+    wm.data[:, 3] = np.nan                                      # column 3 likewise
+    wm.data[5, 1], wm.data[5, 2] = np.inf, -np.inf
+    wm.mask[5, 1] = wm.mask[5, 2] = False
+    v = rs.rand(6, 5)                                           # plain: a NaN row, a NaN column, both infinities
+    v[1, :] = np.nan
+    v[:, 4] = np.nan
+    v[3, 0], v[3, 1] = np.inf, -np.inf
     out = {'masked_data': xm.data, 'masked_mask': np.ma.getmaskarray(xm), 'plain': y,
-           'finite_data': z.data, 'finite_mask': np.ma.getmaskarray(z)}
+           'finite_data': z.data, 'finite_mask': np.ma.getmaskarray(z),
+           'corner_data': wm.data.copy(), 'corner_mask': np.ma.getmaskarray(wm).copy(), 'plaincorner': v}
     t1, t2 = ObjectType('a'), ObjectType('b')
     import warnings
-    for tag, arr in (('masked', xm), ('plain', y), ('finite', z)):
+    for tag, arr in (('masked', xm), ('plain', y), ('finite', z), ('corner', wm), ('plaincorner', v)):
         for fv in ('mean', 'row_mean', 'col_mean', 0.5):
             with warnings.catch_warnings():
                 warnings.simplefilter('ignore')
