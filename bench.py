@@ -382,7 +382,14 @@ def _parallel_hash_uniform(seed, rows, cols, threads=64):
 
 
 PARITY_ROWS = 64               # rows of every factor kept for the full-size parity record
-PARITY_ITERS = 2
+PARITY_CHECKPOINTS = (2, 5)    # iterations after which the engine is compared with the oracle (backbones, factor rows)
+PARITY_ITERS = PARITY_CHECKPOINTS[-1]          # ... and the relation errors after the last of them
+# S = K_i W K_j: a relative perturbation eps of W = G_i^T R G_j reaches S multiplied by up to cond(Gram_i) cond(Gram_j), so
+# the backbones are gated at  ||S - S_oracle|| / ||S_oracle||  <=  cond_i cond_j eps(engine)  with the condition numbers of
+# the Gram matrices S was formed from (computed from the engine's OWN factors) and eps = ten times the perturbation of W
+# each engine was measured to make at full size (f64: rounding; f32 / bf16: the contraction error of a row of P, 3e-6 / 1e-6,
+# averaged over the n_i = 5e4 .. 1e5 rows W sums)
+PARITY_S_EPS = {'f64': 5e-15, 'f32': 1.5e-7, 'bf16': 2e-7}
 
 
 def parity_rows(n_t):
@@ -392,35 +399,38 @@ def parity_rows(n_t):
 
 def _oracle_timing(scale, iters, parallel_data=False, keep=None):
     """Seconds of each of `iters` oracle iterations (NumPy, reference operation order, fp64) on the config-3 graph.
-    keep (a path): after the last iteration the oracle's backbones, PARITY_ROWS rows of every factor and the three relation
-    errors ||R - G_i S G_j^T||_F (_dfmf.py:306-316: factors AFTER the last update, backbones from before it) go to an
-    .npz there -- what the engine's own first `iters` iterations are compared with (`parity_full_size`)."""
+    keep (a path): after every iteration of PARITY_CHECKPOINTS the oracle's backbones and PARITY_ROWS rows of every factor, and
+    after the last iteration the three relation errors ||R - G_i S G_j^T||_F (_dfmf.py:306-316: factors AFTER the last
+    update, backbones from before it) go to an .npz there -- what the engine's own first `iters` iterations are compared with
+    (`parity_full_size`)."""
     from oracle import dfmf_oracle as orc
     n = sizes(scale)
     fill = _parallel_hash_uniform if parallel_data else orc.hash_uniform_matrix
     R = {(i, j): [fill(s, n[i], n[j])] for i, j, s in PAIRS}
     G = {(t, t): orc.hash_uniform_matrix(100 + k, n[t], RANKS[t]) for k, t in enumerate(TYPES)}
-    times = []
-    for _ in range(iters):
+    times, out = [], {'iters': iters, 'checkpoints': np.array([c for c in PARITY_CHECKPOINTS if c <= iters] or [iters])}
+    for it in range(1, iters + 1):
         t0 = time.perf_counter()
         S, _ = orc._update_S(R, G)
         G = orc._update_G(R, G, S, {}, {}, True)
         times.append(time.perf_counter() - t0)
+        if keep and it in out['checkpoints']:
+            for i, j, _ in PAIRS:
+                out['S_%s_%s@%d' % (i, j, it)] = S[i, j][0]
+            for t in TYPES:
+                out['G_%s@%d' % (t, it)] = G[t, t][parity_rows(n[t])]
     if keep:
         t0 = time.perf_counter()
         errs = orc.relation_errors_blocked(R, G, S)
-        out = {'iters': iters, 'err_seconds': time.perf_counter() - t0}
+        out['err_seconds'] = time.perf_counter() - t0
         for i, j, _ in PAIRS:
-            out['S_%s_%s' % (i, j)] = S[i, j][0]
             out['err_%s_%s' % (i, j)] = errs[i, j][0]
-        for t in TYPES:
-            out['G_%s' % t] = G[t, t][parity_rows(n[t])]
         np.savez(keep, **out)
     return times, n
 
 
 def _full_size_child(keep=None):
-    """`python bench.py --cpu-full-child [--parity-out file]`: TWO oracle iterations at full size (the second one is
+    """`python bench.py --cpu-full-child [--parity-out file]`: PARITY_ITERS oracle iterations at full size (the last one is
     reported: BLAS threads and pages warm) after a 1/10-scale warm-up; prints a JSON line.  Runs in a child process so that
     the parent can bound it in time and memory."""
     _oracle_timing(0.1, 1)
@@ -429,22 +439,47 @@ def _full_size_child(keep=None):
     print(json.dumps({'times': times, 'total_seconds': time.perf_counter() - t0}))
 
 
-def parity_record(oracle_npz, engine):
+def gram_condition(G):
+    """cond_2 of G^T G (f64, host) -- of the Gram matrix a backbone is formed from."""
+    g = np.asarray(G, dtype=np.float64)
+    lam = np.linalg.eigvalsh(g.T.dot(g))
+    return float(lam[-1] / max(lam[0], 1e-300))
+
+
+def parity_record(oracle_npz, engine, dtype=None):
     """`parity_full_size` of one engine: its first PARITY_ITERS iterations from the hash-generated G0 against the oracle's
-    (same inputs, FULL size) -- max relative deviation of the backbones (Frobenius), of PARITY_ROWS rows of every factor, and
-    of the three relation errors.  north_star: results must match the reference path on the same inputs."""
+    (same inputs, FULL size) -- per checkpoint the max relative deviation of the backbones (Frobenius) and of PARITY_ROWS rows
+    of every factor, after the last iteration that of the three relation errors; and the GATE on the backbones: every
+    relation's deviation over cond(Gram_i) cond(Gram_j) (the engine's own factors) against PARITY_S_EPS[dtype].
+    north_star: results must match the reference path on the same inputs."""
     z = np.load(oracle_npz)
     rel = lambda a, b: float(np.linalg.norm(np.asarray(a, dtype=np.float64) - b) / max(np.linalg.norm(b), 1e-300))   # noqa: E731
-    return {'iters': int(z['iters']),
-            'S_relerr': max(rel(engine['S_%s_%s' % (i, j)], z['S_%s_%s' % (i, j)]) for i, j, _ in PAIRS),
-            'G_rows_relerr': max(rel(engine['G_%s' % t], z['G_%s' % t]) for t in TYPES),
-            'err_relerr': max(abs(float(engine['err_%s_%s' % (i, j)]) / float(z['err_%s_%s' % (i, j)]) - 1.0) for i, j, _ in PAIRS),
-            'oracle_err': {'%s-%s' % (i, j): float(z['err_%s_%s' % (i, j)]) for i, j, _ in PAIRS}}
+    cps = [int(c) for c in z['checkpoints']]
+    rec = {'iters': int(z['iters']), 'checkpoints': {}}
+    worst_s = worst_g = worst_gate = 0.0
+    for c in cps:
+        s_dev = {(i, j): rel(engine['S_%s_%s@%d' % (i, j, c)], z['S_%s_%s@%d' % (i, j, c)]) for i, j, _ in PAIRS}
+        g_dev = max(rel(engine['G_%s@%d' % (t, c)], z['G_%s@%d' % (t, c)]) for t in TYPES)
+        cp = {'S_relerr': max(s_dev.values()), 'G_rows_relerr': g_dev}
+        if ('kappa_%s@%d' % (TYPES[0], c)) in engine:
+            kap = {t: float(engine['kappa_%s@%d' % (t, c)]) for t in TYPES}
+            cp['gram_condition'] = kap
+            cp['S_relerr_over_conditioning'] = max(v / (kap[i] * kap[j]) for (i, j), v in s_dev.items())
+            worst_gate = max(worst_gate, cp['S_relerr_over_conditioning'])
+        rec['checkpoints'][str(c)] = cp
+        worst_s, worst_g = max(worst_s, cp['S_relerr']), max(worst_g, g_dev)
+    rec.update({'S_relerr': worst_s, 'G_rows_relerr': worst_g,
+                'err_relerr': max(abs(float(engine['err_%s_%s' % (i, j)]) / float(z['err_%s_%s' % (i, j)]) - 1.0) for i, j, _ in PAIRS),
+                'oracle_err': {'%s-%s' % (i, j): float(z['err_%s_%s' % (i, j)]) for i, j, _ in PAIRS}})
+    if dtype in PARITY_S_EPS and worst_gate > 0.0:
+        rec['S_gate'] = {'S_relerr_over_conditioning': worst_gate, 'eps': PARITY_S_EPS[dtype],
+                         'ok': bool(worst_gate <= PARITY_S_EPS[dtype])}
+    return rec
 
 
 def cpu_baseline(full='auto', parity_out=None):
     """Oracle (kind=port) on the host cores.  When the host can hold the fp64 graph (88 GB + temporaries: RAM >= 256 GiB
-    and >= 32 cores) two iterations are timed at FULL size in a child process bounded to 300 s and the
+    and >= 32 cores) PARITY_ITERS iterations are timed at FULL size in a child process bounded to 420 s and the
     second is reported; otherwise, or when that fails, the 1/10-linear-scale sample is timed and scaled by the n_i*n_j work
     ratio."""
     host = host_info()
@@ -702,13 +737,14 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
     for k, t in enumerate(types):      # one random restart per rank: G0 seed depends on the rank
         seed = 100 + k + (0 if sharded else 10 * rank)       # sharded: replicated factors
         plan.set_factor(t, fill_uniform((n[t], ranks_[t]), seed, MASTER[dtype]))
-    exchange = None
+    exchange = comm = None
     if emulate:
         plan.attach_null_comm(rank, world)
         exchange = plan.exchange_bytes(world)
     elif sharded:                      # the library issues the exchanges itself: RCCL, or torch.distributed callbacks over gloo
         plan.attach_comm()
         exchange = plan.exchange_bytes(world)
+        comm = plan.comm_info()
     step = plan.iterate if not sharded else {'rows': plan.iterate_rows, 'relations': plan.iterate_sharded,
                                              'owned': plan.iterate_dist}[mode]
 
@@ -720,20 +756,30 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
 
     kept = None
     if parity and not sharded and not c5:
-        step(PARITY_ITERS)
-        kept = {}
+        kept, done = {}, 0
+        for cp in PARITY_CHECKPOINTS:
+            if cp - 1 > done:
+                step(cp - 1 - done)
+            for t in types:            # the factors the backbones of iteration `cp` are formed from: their conditioning
+                kept['kappa_%s@%d' % (t, cp)] = gram_condition(plan.get_factor(t))
+            step(1)
+            done = cp
+            for q, (i, j, _) in enumerate(spec):
+                kept['S_%s_%s@%d' % (i, j, cp)] = plan.get_backbone(q)
+            for t in types:
+                kept['G_%s@%d' % (t, cp)] = plan.get_factor(t)[parity_rows(n[t])]
         for q, (i, j, _) in enumerate(spec):
-            kept['S_%s_%s' % (i, j)] = plan.get_backbone(q)
             kept['err_%s_%s' % (i, j)] = float(np.sqrt(max(plan.relation_sqerr(q), 0.0)))
-        for t in types:
-            kept['G_%s' % t] = plan.get_factor(t)[parity_rows(n[t])]
     if warmup:
         step(warmup)
     sync()
     plan.set_profiling(True)
+    from skfusion_amd._engine import launch_count
+    l0 = launch_count()
     t0 = time.perf_counter()
     step(steps)
     enqueued = time.perf_counter() - t0        # host time to issue the launches of `steps` iterations (nothing waited for)
+    launches = (launch_count() - l0) / float(steps)
     sync()
     elapsed = time.perf_counter() - t0
     k_ms, k_launches, k_flops, k_bytes = plan.get_profile()
@@ -769,6 +815,7 @@ def run_workload(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode
     return {'elapsed': elapsed, 'k_ms': k_ms, 'k_launches': k_launches, 'k_flops': k_flops, 'k_bytes': k_bytes,
             'rmse': rmse, 'n': n, 'spec': spec, 'ranks': ranks_, 'types': types, 'sharded': sharded,
             'exchange_bytes': exchange, 'parity': kept, 'sustained': sus, 'enqueue_ms_per_step': enqueued / steps * 1e3,
+            'launches_per_step': launches, 'comm': comm,
             'quantisation': ({'%s-%s' % (i, j): planted.get('quant_%d' % k) for k, (i, j, _) in enumerate(spec)}
                              if (not c5 and data == 'planted' and dtype == 'bf16') else None)}
 
@@ -792,6 +839,7 @@ def emulated_ranks(args):
         ms = w['elapsed'] / args.steps * 1e3
         xb = float(w['exchange_bytes'])
         out['ranks'].append({'rank': k, 'compute_ms_per_step': ms, 'host_enqueue_ms_per_step': w['enqueue_ms_per_step'],
+                             'launches_per_step': w['launches_per_step'],
                              'exchange_bytes_per_step': xb,
                              'wire_ms_all_links': xb / (7 * XGMI_LINK_GBS * 1e9) * 1e3,
                              'wire_ms_ring': xb / (XGMI_LINK_GBS * 1e9) * 1e3})
@@ -800,6 +848,52 @@ def emulated_ranks(args):
     out['modelled_ms_per_step'] = {'no_overlap_all_links': worst + out['ranks'][0]['wire_ms_all_links'],
                                    'no_overlap_ring': worst + out['ranks'][0]['wire_ms_ring'],
                                    'full_overlap': max(worst, out['ranks'][0]['wire_ms_all_links'])}
+    return out
+
+
+def rank_of_8_record(dtype='bf16', rank=3, world=8, steps=10, warmup=3):
+    """`workloads.rank_of_8` of the default one-GPU line: what ONE rank of 8 of the ownership-sharded fit (north_star: "reported
+    at 1, 2, 4 and 8 MI355X"; reference per-block tasks _dfmf.py:69-73, _dfmc.py:341-345) computes per iteration, MEASURED on
+    this GPU with the exchanges skipped (null communicator: partial sums scaled, factors held at G0), for BASELINE configs[2]
+    and configs[4], with the bytes the rank would exchange and their modelled wire time.  The compute term is a measurement;
+    the 8-GPU iteration time is a model until a SCALE run's `strong` sub-record replaces it."""
+    out = {'what': 'compute of rank %d of %d of the ownership-sharded iteration on this GPU, exchanges skipped (bench.py '
+                   '--emulate-rank %d/%d); wire = exchange bytes over 7 xGMI links x %.0f GB/s (all links) or one link (ring)'
+                   % (rank, world, rank, world, XGMI_LINK_GBS), 'rank': rank, 'world': world, 'dtype': dtype}
+    for key, wl in (('c3', 'c3'), ('c5', 'c5')):
+        try:
+            w = run_workload(wl, dtype, steps, warmup, emulate=(rank, world))
+            ms = w['elapsed'] / steps * 1e3
+            xb = float(w['exchange_bytes'])
+            out[key] = {'compute_ms_per_step': ms, 'steps': steps, 'warmup': warmup,
+                        'launches_per_step': w['launches_per_step'], 'host_enqueue_ms_per_step': w['enqueue_ms_per_step'],
+                        'exchange_bytes_per_rank_and_iter': xb,
+                        'wire_ms_all_links': xb / (7 * XGMI_LINK_GBS * 1e9) * 1e3, 'wire_ms_ring': xb / (XGMI_LINK_GBS * 1e9) * 1e3,
+                        'contraction_ms_per_step': w['k_ms'] / steps}
+        except Exception as exc:
+            out[key] = {'error': str(exc)[:300]}
+    return out
+
+
+def strong_record(dtype, rank, world, dist, backend, steps=10, warmup=3, scale=1.0):
+    """`strong` sub-record of an N > 1 run: after the restarts measurement the SAME process group runs ONE fit sharded by
+    ownership (`--mode owned`: reduce-scatter of the partial Q, all-gather of the updated rows, c x c all-reduces -- the
+    exchange step of north_star / BASELINE configs[4]) on configs[2] and configs[4], so that one SCALE run yields both curves:
+    it/s of the one fit, bytes a rank sends per iteration, and what the transport says about itself (RCCL: ncclCommCount).
+    Every rank takes part; rank 0 keeps the record."""
+    out = {'mode': 'owned', 'scaling': 'strong', 'n_gpus': world, 'dtype': dtype, 'backend': backend}
+    for key, wl in (('c3', 'c3'), ('c5', 'c5')):
+        try:
+            w = run_workload(wl, dtype, steps, warmup, scale, 'uniform', 'owned', rank, world, dist, backend)
+            comm = w['comm'] or {}
+            out[key] = {'value': steps / w['elapsed'], 'unit': 'iters/s', 'steps': steps, 'warmup': warmup,
+                        'ms_per_step': w['elapsed'] / steps * 1e3,
+                        'exchange_bytes_per_rank_and_iter': w['exchange_bytes'],
+                        'launches_per_step': w['launches_per_step'],
+                        'transport': comm.get('transport'), 'transport_ranks': comm.get('transport_ranks'),
+                        'rmse': w['rmse']}
+        except Exception as exc:           # (a rank that fails here fails on every rank: same graph, same plan)
+            out[key] = {'error': str(exc)[:300]}
     return out
 
 
@@ -848,6 +942,7 @@ def other_workloads(dtype='bf16'):
                                                                         'bf16-rounded relations': [1.3005, 1.4392, 1.2963]}
     except Exception as exc:
         out['c3_planted'] = {'error': str(exc)[:300]}
+    out['rank_of_8'] = rank_of_8_record(dtype)
     return out
 
 
@@ -885,6 +980,8 @@ def main():
     ap.add_argument('--no-workloads', action='store_true', help='skip the config 5 / dicty / planted legs of the default record')
     ap.add_argument('--no-pmc', action='store_true', help='do not spawn the rocprofv3 counter passes that fill roofline.traffic '
                                                           '(the committed pass of profiles/pmc_traffic.json stands in)')
+    ap.add_argument('--no-strong', action='store_true', help='N > 1, mode restarts: skip the `strong` sub-record (one fit sharded '
+                                                             'by ownership over the same process group, configs 3 and 5)')
     ap.add_argument('--sustained-steps', type=int, default=1000,
                     help='default run: a second timed region of this many steps (>= 10 s), reported as `sustained`; 0 = off')
     args = ap.parse_args()
@@ -999,6 +1096,10 @@ def main():
         out['engines'] = engines
     if default_run and not args.no_workloads:
         out['workloads'] = other_workloads(args.dtype)
+    if world > 1 and args.mode == 'restarts' and not args.no_strong and not c5 and args.data == 'uniform':
+        strong = strong_record(args.dtype, rank, world, dist, backend, scale=args.scale)      # collective: every rank runs it
+        if rank == 0:
+            out['strong'] = strong
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             if c5:
@@ -1012,11 +1113,13 @@ def main():
                 # full-size parity: the engine's first iterations against the oracle's on the same inputs (both legs ran
                 # above; the oracle's only when the host could hold the fp64 graph)
                 if pfile and os.path.exists(pfile) and not out['cpu_baseline'].get('projection', True):
-                    out['parity_full_size'] = {dt: parity_record(pfile, kept) for dt, kept in parity_kept.items() if kept}
-                    out['parity_full_size']['what'] = ('engine vs NumPy oracle (reference op order, fp64) after %d iterations '
-                                                       'from the same counter-based R and G0 at FULL size: max relative deviation of '
-                                                       'the backbones, of %d rows of every factor, of the relation errors'
-                                                       % (PARITY_ITERS, PARITY_ROWS))
+                    out['parity_full_size'] = {dt: parity_record(pfile, kept, dt) for dt, kept in parity_kept.items() if kept}
+                    out['parity_full_size']['what'] = ('engine vs NumPy oracle (reference op order, fp64) from the same counter-based R and '
+                                                       'G0 at FULL size: max relative deviation of the backbones and of %d rows of every '
+                                                       'factor after iterations %s, of the relation errors after iteration %d; S_gate: '
+                                                       'backbone deviation / (cond(Gram_i) cond(Gram_j)) of the engine\'s own factors '
+                                                       'against eps(engine) -- S = K_i W K_j amplifies a perturbation of W by the two '
+                                                       'condition numbers' % (PARITY_ROWS, '/'.join(map(str, PARITY_CHECKPOINTS)), PARITY_ITERS))
                     os.remove(pfile)
                 elif want_parity:
                     out['parity_full_size'] = {'error': 'no full-size oracle run on this host (cpu_baseline.projection)'}

@@ -282,6 +282,12 @@ int skf_comm_create_callback(int32_t rank, int32_t world, skf_collective_fn fn, 
  * the timed launches see stay those of well-conditioned factors and the pseudo-inverses take the path they take in a real
  * run); gathers leave the other ranks' rows as they were.  Every other launch of the iteration runs. */
 int skf_comm_create_null(int32_t rank, int32_t world, skf_comm** out);
+/* What a communicator is: its rank / world as created, its transport, and how many ranks the transport itself reports
+ * (SKF_COMM_RCCL: ncclCommCount of the bound communicator, -1 when the library does not export it; callback: world;
+ * single: 1; null: 0) -- lets a caller (bench.py's strong-scaling record) state that RCCL really spans the ranks of the
+ * run.  Null pointers are skipped. */
+enum { SKF_COMM_SINGLE = 0, SKF_COMM_RCCL = 1, SKF_COMM_CALLBACK = 2, SKF_COMM_NULL = 3 };
+int skf_comm_info(const skf_comm* comm, int32_t* rank, int32_t* world, int32_t* transport, int32_t* transport_ranks);
 int skf_comm_destroy(skf_comm* comm);
 int skf_plan_set_comm(skf_plan* plan, skf_comm* comm);     /* not owned by the plan; NULL detaches */
 int skf_iterate_dist(skf_plan* plan, int32_t n_iters, void* stream);
@@ -391,6 +397,11 @@ int skf_cast(int32_t dst_dtype, void* dst, int64_t ldd, int32_t src_dtype, const
  * of 256 for large types / of 64 for SKF_BF16; part_count * chunk >= n_obj, the last owners may hold fewer rows or none). */
 int skf_owned_rows(int32_t dtype, int64_t n_obj, int32_t part_index, int32_t part_count, int64_t* begin, int64_t* count,
                    int64_t* chunk);
+
+/* Kernel launches the calling thread has issued through this library so far (every plan, every entry point; a hipGraph
+ * replay counts the launches it was captured from once, at capture).  Callers take differences: launches per iteration of a
+ * schedule are part of its latency budget (bench.py reports them for the rank-of-8 emulation). */
+int skf_launch_count(int64_t* launches);
 
 const char* skf_last_error(void);
 const char* skf_version(void);

@@ -4,6 +4,7 @@
 _dfmf.py:330), keeps every matrix resident in HBM for the whole ``max_iter`` loop and copies
 ``G`` / ``S`` back once at the end (or per iteration when a callback is installed).
 """
+import os
 import ctypes as C
 
 import numpy as np
@@ -231,6 +232,22 @@ def release_rccl_comms(runtime=None):
                 pass
 
 
+def comm_info(rt, comm):
+    """dict(rank, world, transport: 'single' | 'rccl' | 'callback' | 'null', transport_ranks) of a communicator handle
+    (skf_comm_info; transport_ranks of an RCCL communicator is what ncclCommCount reports)."""
+    r, w, k, n = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    rt.call('skf_comm_info', comm, C.byref(r), C.byref(w), C.byref(k), C.byref(n))
+    return {'rank': r.value, 'world': w.value, 'transport': nat.COMM_KIND[k.value], 'transport_ranks': n.value}
+
+
+def launch_count(runtime=None):
+    """Kernel launches this thread has issued through the library so far (skf_launch_count); callers take differences."""
+    rt = runtime or nat.get_runtime()
+    n = C.c_int64()
+    rt.call('skf_launch_count', C.byref(n))
+    return n.value
+
+
 def _shared_rccl_comm(rt, dist):
     """The process's RCCL communicator for the CURRENT default process group (created once per group, reused by every plan
     and restart), or None when it cannot be had on EVERY rank -- all ranks then agree on the callback path instead of some
@@ -249,28 +266,54 @@ def _shared_rccl_comm(rt, dist):
         import atexit
         atexit.register(release_rccl_comms)
         _shared_rccl_comm._atexit = True
-    ident = [None]
+    import logging
+    log = logging.getLogger('skfusion_amd')
+    where = 'cuda' if dist.get_backend() != 'gloo' else 'cpu'
+
+    def all_agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=where)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    # 1. every rank checks LOCALLY that it can resolve RCCL (ncclGetUniqueId needs no peer) and the ranks agree BEFORE anyone
+    #    enters ncclCommInitRank: that call is a rendezvous, and a rank that cannot load the library would leave the others
+    #    waiting in it until the transport's own timeout
+    mine, ident = None, [None]
+    try:
+        buf = (C.c_char * 128)()
+        rt.call('skf_comm_unique_id', buf)
+        mine = bytes(buf)
+    except nat.SkfNativeError as exc:
+        log.warning('RCCL not bound on rank %d (%s): collectives through torch.distributed', rank, exc)
+    if not all_agree(mine is not None):
+        _RCCL[key] = None
+        return None
     if rank == 0:
-        try:
-            buf = (C.c_char * 128)()
-            rt.call('skf_comm_unique_id', buf)
-            ident[0] = bytes(buf)
-        except nat.SkfNativeError as exc:          # librccl not resolvable / symbol missing: tell the others
-            import logging
-            logging.getLogger('skfusion_amd').warning('RCCL not bound (%s): collectives through torch.distributed', exc)
+        ident[0] = mine
     dist.broadcast_object_list(ident, src=0)
-    comm, ok = nat._P(), 0
-    if ident[0] is not None:
+    # 2. the rendezvous itself, bounded: a rank still inside ncclCommInitRank after SKF_COMM_TIMEOUT seconds (default 60)
+    #    gives up loudly instead of hanging until the NCCL watchdog fires
+    import threading
+    comm, box = nat._P(), {}
+
+    def create():
         try:
             raw = (C.c_char * 128).from_buffer_copy(ident[0])
             rt.call('skf_comm_create', raw, rank, world, C.byref(comm))
-            ok = 1
+            box['ok'] = True
         except nat.SkfNativeError as exc:
-            import logging
-            logging.getLogger('skfusion_amd').warning('skf_comm_create failed on rank %d (%s)', rank, exc)
-    flag = torch.tensor([ok], dtype=torch.int32, device='cuda' if dist.get_backend() != 'gloo' else 'cpu')
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) != 1:
+            box['error'] = exc
+    limit = float(os.environ.get('SKF_COMM_TIMEOUT', '60'))
+    th = threading.Thread(target=create, name='skf_comm_create', daemon=True)
+    th.start()
+    th.join(limit)
+    if th.is_alive():
+        raise RuntimeError('skf_comm_create: rank %d of %d still waits in ncclCommInitRank after %.0f s -- the ranks disagree '
+                           '(a peer failed or never called it); SKF_COMM_TIMEOUT sets the limit' % (rank, world, limit))
+    ok = bool(box.get('ok'))
+    if not ok:
+        log.warning('skf_comm_create failed on rank %d (%s)', rank, box.get('error'))
+    if not all_agree(ok):
         if ok:
             rt.lib.skf_comm_destroy(comm)
         _RCCL[key] = None
@@ -619,6 +662,10 @@ class DevicePlan(object):
             self.rt.call('skf_comm_create_callback', rank, world, C.cast(self._comm_fn, C.c_void_p), None, C.byref(self._comm))
         self.rt.call('skf_plan_set_comm', self.handle, self._comm)
         return True
+
+    def comm_info(self):
+        """What the attached communicator is (`_engine.comm_info`), None without one."""
+        return comm_info(self.rt, self._comm) if getattr(self, '_comm', None) else None
 
     def attach_single_comm(self):
         """A genuine communicator of ONE rank without a transport (skf_comm_create(NULL, 0, 1)): every collective returns at

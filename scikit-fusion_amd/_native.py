@@ -18,6 +18,8 @@ SKF_REL_ABSENT, SKF_REL_NO_COL_SIDE, SKF_REL_MASKED, SKF_REL_MASK_BITS, SKF_REL_
 SKF_REL_KNOWN_LISTS = 32
 SKF_STAGE_CONTRACT, SKF_STAGE_BACKBONE, SKF_STAGE_ACCUMULATE, SKF_STAGE_UPDATE = 0, 1, 2, 3
 SKF_X_W, SKF_X_Q, SKF_X_QM, SKF_X_ED = 0, 1, 2, 3
+SKF_COMM_SINGLE, SKF_COMM_RCCL, SKF_COMM_CALLBACK, SKF_COMM_NULL = 0, 1, 2, 3
+COMM_KIND = {0: 'single', 1: 'rccl', 2: 'callback', 3: 'null'}
 SKF_OK, SKF_E_INVALID, SKF_E_STATE, SKF_E_WORKSPACE, SKF_E_HIP = 0, -1, -2, -3, -4
 
 DTYPES = {'f64': SKF_F64, 'f32': SKF_F32, 'bf16': SKF_BF16, 'float64': SKF_F64, 'float32': SKF_F32}
@@ -112,6 +114,8 @@ SIGNATURES = {
     'skf_comm_create': (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
     'skf_comm_create_callback': (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.POINTER(_P)]),
     'skf_comm_create_null': (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_P)]),
+    'skf_comm_info': (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'skf_launch_count': (C.c_int, [C.POINTER(C.c_int64)]),
     'skf_comm_destroy': (C.c_int, [_P]),
     'skf_owned_rows': (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                  C.POINTER(C.c_int64)]),

@@ -53,7 +53,10 @@ struct Error {
         if (e_ != hipSuccess) SKF_FAIL(SKF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+static thread_local int64_t g_launches = 0;      // kernel launches this thread has issued through the library (skf_launch_count)
+
 static inline void check_launch(const char* what) {
+    ++g_launches;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) SKF_FAIL(SKF_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
 }
@@ -1758,7 +1761,10 @@ typedef int (*nccl_all_reduce_t)(const void*, void*, size_t, int, int, void*, hi
 typedef int (*nccl_reduce_scatter_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*nccl_all_gather_t)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef const char* (*nccl_get_error_string_t)(int);
+typedef int (*nccl_comm_count_t)(const void*, int*);
 struct Rccl {
+    nccl_comm_count_t comm_count = nullptr;          // optional (skf_comm_info)
+    nccl_comm_count_t comm_user_rank = nullptr;
     void* handle = nullptr;
     nccl_get_unique_id_t get_unique_id = nullptr;
     nccl_comm_init_rank_t comm_init_rank = nullptr;
@@ -1789,6 +1795,8 @@ static const Rccl& rccl() {
         g_rccl.reduce_scatter = (nccl_reduce_scatter_t)dlsym(h, "ncclReduceScatter");
         g_rccl.all_gather = (nccl_all_gather_t)dlsym(h, "ncclAllGather");
         g_rccl.error_string = (nccl_get_error_string_t)dlsym(h, "ncclGetErrorString");
+        g_rccl.comm_count = (nccl_comm_count_t)dlsym(h, "ncclCommCount");
+        g_rccl.comm_user_rank = (nccl_comm_count_t)dlsym(h, "ncclCommUserRank");
     });
     if (!g_rccl.handle || !g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce ||
         !g_rccl.reduce_scatter || !g_rccl.all_gather)
@@ -4076,6 +4084,33 @@ int skf_owned_rows(int32_t dtype, int64_t n_obj, int32_t part_index, int32_t par
 }
 
 int skf_abi_version(void) { return SKF_ABI_VERSION; }
+
+int skf_comm_info(const skf_comm* c, int32_t* rank, int32_t* world, int32_t* transport, int32_t* transport_ranks) {
+    return guarded([&] {
+        if (!c) SKF_FAIL(SKF_E_INVALID, "null communicator");
+        if (rank) *rank = c->rank;
+        if (world) *world = c->world;
+        const int kind = c->nccl ? SKF_COMM_RCCL : c->fn ? SKF_COMM_CALLBACK : c->null_comm ? SKF_COMM_NULL : SKF_COMM_SINGLE;
+        if (transport) *transport = kind;
+        if (transport_ranks) {
+            *transport_ranks = kind == SKF_COMM_SINGLE ? 1 : kind == SKF_COMM_NULL ? 0 : c->world;
+            if (c->nccl) {                     // what RCCL itself says about the communicator it built
+                int n = -1, r = -1;
+                if (g_rccl.comm_count && g_rccl.comm_count(c->nccl, &n) == 0) *transport_ranks = n;
+                else *transport_ranks = -1;
+                if (g_rccl.comm_user_rank && g_rccl.comm_user_rank(c->nccl, &r) == 0 && r != c->rank)
+                    SKF_FAIL(SKF_E_STATE, "RCCL numbers this rank %d, the communicator was created as rank %d", r, c->rank);
+            }
+        }
+    });
+}
+
+int skf_launch_count(int64_t* launches) {
+    return guarded([&] {
+        if (!launches) SKF_FAIL(SKF_E_INVALID, "null pointer");
+        *launches = g_launches;
+    });
+}
 
 int skf_comm_destroy(skf_comm* c) {
     return guarded([&] {

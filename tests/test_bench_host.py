@@ -127,33 +127,97 @@ def test_bench_gpus_n_launches_itself_and_checks_the_world_size(monkeypatch):
 
 
 def test_parity_full_size_record_plumbing(tmp_path):
-    """`parity_full_size` of the bench record (north_star: same inputs, results matching the reference
-    path): the oracle leg keeps its backbones, 64 rows of every factor and the relation errors after two iterations
-    (`_oracle_timing(keep=...)`, what `--cpu-full-child --parity-out` writes at full size), `parity_record` compares an
-    engine's side with them.  Here at 1/100 scale with the oracle's own two-GEMM form standing in for the engine: every key
-    present, deviations at rounding level; a perturbed engine side shows up in the matching key."""
+    """`parity_full_size` of the bench record (VERDICT rounds 3 / 4, north_star: same inputs, results matching the reference
+    path): the oracle leg keeps its backbones and 64 rows of every factor after iterations 2 AND 5 (PARITY_CHECKPOINTS) and
+    the relation errors after the last (`_oracle_timing(keep=...)`, what `--cpu-full-child --parity-out` writes at full
+    size); `parity_record` compares an engine's side with them and gates the backbones by the conditioning of the Gram
+    matrices they were formed from.  Here at 1/100 scale with the oracle's own two-GEMM form standing in for the engine: every
+    key present, deviations at rounding level, the gate open; a perturbed engine side shows up in the matching key, and a
+    backbone off by more than cond_i cond_j eps closes the gate."""
     from oracle import dfmf_oracle as orc
+    assert bench.PARITY_ITERS >= 5 and bench.PARITY_CHECKPOINTS[-1] == bench.PARITY_ITERS
     path = str(tmp_path / 'parity.npz')
     times, n = bench._oracle_timing(0.01, bench.PARITY_ITERS, keep=path)
     assert len(times) == bench.PARITY_ITERS and n == {'t1': 500, 't2': 1000, 't3': 400}
     R = {(i, j): [orc.hash_uniform_matrix(s, n[i], n[j])] for i, j, s in bench.PAIRS}
     G = {(t, t): orc.hash_uniform_matrix(100 + k, n[t], bench.RANKS[t]) for k, t in enumerate(bench.TYPES)}
-    for _ in range(bench.PARITY_ITERS):
-        G, S = orc.dfmf_two_gemm_step(R, G, {}, {})
-    errs = orc.relation_errors(R, G, S)
     eng = {}
+    for it in range(1, bench.PARITY_ITERS + 1):
+        if it in bench.PARITY_CHECKPOINTS:
+            for t in bench.TYPES:
+                eng['kappa_%s@%d' % (t, it)] = bench.gram_condition(G[t, t])
+        G, S = orc.dfmf_two_gemm_step(R, G, {}, {})
+        if it in bench.PARITY_CHECKPOINTS:
+            for i, j, _ in bench.PAIRS:
+                eng['S_%s_%s@%d' % (i, j, it)] = S[i, j][0]
+            for t in bench.TYPES:
+                rows = bench.parity_rows(n[t])
+                assert len(rows) == bench.PARITY_ROWS and rows[0] == 0 and rows[-1] == n[t] - 1
+                eng['G_%s@%d' % (t, it)] = G[t, t][rows]
+    errs = orc.relation_errors(R, G, S)
     for i, j, _ in bench.PAIRS:
-        eng['S_%s_%s' % (i, j)] = S[i, j][0]
         eng['err_%s_%s' % (i, j)] = errs[i, j][0]
-    for t in bench.TYPES:
-        rows = bench.parity_rows(n[t])
-        assert len(rows) == bench.PARITY_ROWS and rows[0] == 0 and rows[-1] == n[t] - 1
-        eng['G_%s' % t] = G[t, t][rows]
-    rec = bench.parity_record(path, eng)
-    assert set(rec) >= {'iters', 'S_relerr', 'G_rows_relerr', 'err_relerr', 'oracle_err'} and rec['iters'] == bench.PARITY_ITERS
-    assert rec['S_relerr'] < 1e-9 and rec['G_rows_relerr'] < 1e-10 and rec['err_relerr'] < 1e-12
-    eng['G_t2'] = eng['G_t2'] * (1.0 + 1e-3)
+    assert eng['kappa_t1@2'] > 100.0               # uniform random factors: cond(G^T G) ~ 1 + 3 c
+    rec = bench.parity_record(path, eng, 'f64')
+    assert set(rec) >= {'iters', 'checkpoints', 'S_relerr', 'G_rows_relerr', 'err_relerr', 'oracle_err', 'S_gate'}
+    assert rec['iters'] == bench.PARITY_ITERS and sorted(rec['checkpoints']) == sorted(str(c) for c in bench.PARITY_CHECKPOINTS)
+    assert rec['S_relerr'] < 1e-8 and rec['G_rows_relerr'] < 1e-10 and rec['err_relerr'] < 1e-12
+    assert rec['S_gate']['ok'] and rec['S_gate']['eps'] == bench.PARITY_S_EPS['f64']
+    last = str(bench.PARITY_ITERS)
+    assert rec['checkpoints'][last]['S_relerr_over_conditioning'] <= rec['checkpoints'][last]['S_relerr'] / 1e4
+    eng['G_t2@%s' % last] = eng['G_t2@%s' % last] * (1.0 + 1e-3)
     eng['err_t1_t3'] = eng['err_t1_t3'] * (1.0 - 2e-4)
-    bad = bench.parity_record(path, eng)
+    bad = bench.parity_record(path, eng, 'f64')
     assert bad['G_rows_relerr'] == pytest.approx(1e-3, rel=1e-6) and bad['err_relerr'] == pytest.approx(2e-4, rel=1e-6)
-    assert bad['S_relerr'] == rec['S_relerr']
+    assert bad['S_relerr'] == rec['S_relerr'] and bad['S_gate']['ok']
+    # a backbone that is off by more than its conditioning explains: the gate closes (f64 eps), and opens again at bf16's
+    eng['S_t1_t2@2'] = eng['S_t1_t2@2'] * (1.0 + 1e-4)
+    assert not bench.parity_record(path, eng, 'f64')['S_gate']['ok']
+    assert bench.parity_record(path, eng, 'bf16')['S_gate']['ok'] == (1e-4 / (eng['kappa_t1@2'] * eng['kappa_t2@2']) <= bench.PARITY_S_EPS['bf16'])
+
+
+def _fake_run(calls, fail=()):
+    def run(workload, dtype, steps, warmup, scale=1.0, data='uniform', mode='restarts', rank=0, world=1, dist=None,
+            backend='nccl', emulate=None, parity=False, sustained=0):
+        calls.append(dict(workload=workload, mode=mode, rank=rank, world=world, emulate=emulate, steps=steps))
+        if workload in fail:
+            raise RuntimeError('no such luck on %s' % workload)
+        return {'elapsed': 0.002 * steps, 'k_ms': 1.5 * steps, 'exchange_bytes': 178.7e6 if workload == 'c3' else 190e6,
+                'launches_per_step': 61.0, 'enqueue_ms_per_step': 0.4, 'rmse': {'t1-t2': 0.2887},
+                'comm': None if emulate else {'rank': rank, 'world': world, 'transport': 'rccl', 'transport_ranks': world}}
+    return run
+
+
+def test_rank_of_8_sub_record_of_the_default_line(monkeypatch):
+    """the default one-GPU line carries `workloads.rank_of_8` -- rank 3 of 8 of the ownership-sharded
+    fit on configs 3 and 5 with the exchanges skipped: ms, launches, exchange bytes, modelled wire time; a leg that fails
+    reports its error and leaves the other standing."""
+    calls = []
+    monkeypatch.setattr(bench, 'run_workload', _fake_run(calls))
+    rec = bench.rank_of_8_record('bf16')
+    assert [c['workload'] for c in calls] == ['c3', 'c5'] and all(c['emulate'] == (3, 8) for c in calls)
+    for key, nbytes in (('c3', 178.7e6), ('c5', 190e6)):
+        leg = rec[key]
+        assert leg['compute_ms_per_step'] == pytest.approx(2.0) and leg['launches_per_step'] == 61.0
+        assert leg['exchange_bytes_per_rank_and_iter'] == nbytes and leg['contraction_ms_per_step'] == pytest.approx(1.5)
+        assert leg['wire_ms_ring'] == pytest.approx(nbytes / 153e9 * 1e3) and leg['wire_ms_all_links'] == pytest.approx(leg['wire_ms_ring'] / 7)
+    assert rec['rank'] == 3 and rec['world'] == 8 and 'exchanges skipped' in rec['what']
+    calls[:] = []
+    monkeypatch.setattr(bench, 'run_workload', _fake_run(calls, fail=('c5',)))
+    rec = bench.rank_of_8_record('bf16')
+    assert 'compute_ms_per_step' in rec['c3'] and 'no such luck' in rec['c5']['error']
+
+
+def test_strong_sub_record_of_an_n_gpu_run(monkeypatch):
+    """an N > 1 run in the default mode (restarts) also runs ONE fit sharded by ownership over the same
+    process group on configs 3 and 5 and reports it as `strong`: it/s, bytes per rank and iteration, the transport and the
+    ranks it reports (RCCL: ncclCommCount)."""
+    calls = []
+    monkeypatch.setattr(bench, 'run_workload', _fake_run(calls))
+    rec = bench.strong_record('bf16', 0, 4, dist=object(), backend='nccl')
+    assert [(c['workload'], c['mode'], c['world']) for c in calls] == [('c3', 'owned', 4), ('c5', 'owned', 4)]
+    assert rec['scaling'] == 'strong' and rec['mode'] == 'owned' and rec['n_gpus'] == 4 and rec['backend'] == 'nccl'
+    for key in ('c3', 'c5'):
+        leg = rec[key]
+        assert leg['value'] == pytest.approx(500.0) and leg['unit'] == 'iters/s' and leg['ms_per_step'] == pytest.approx(2.0)
+        assert leg['transport'] == 'rccl' and leg['transport_ranks'] == 4 and leg['exchange_bytes_per_rank_and_iter'] > 1e8

@@ -288,17 +288,27 @@ def test_bench_parity_record_at_a_tenth_of_the_size(tmp_path):
     # (backbones, factor rows, relation errors); measured on the hardware: f64 1.2e-11 / 2.3e-13 / 0, f32 7.4e-5 / 3.1e-7 /
     # 6.8e-10, bf16 4.6e-3 / 3.1e-4 / 1.05e-5 (the backbones S = K_i W K_j amplify a perturbation by the condition numbers of
     # two Gram matrices of uniform random factors; the factors and the errors do not)
-    bounds = {'f64': (1e-10, 2e-12, 1e-13), 'f32': (4e-4, 2e-6, 5e-9), 'bf16': (2.5e-2, 1.5e-3, 5e-5)}
+    # (f64 relation errors: measured 2.2e-16 = one ulp of a sum of 2e7 squares; the bound is a rounding-level floor, 20 ulp --
+    # another summation order moves the last bits, ten times ONE ulp would not survive a change of the reduce tree)
+    bounds = {'f64': (1e-10, 2e-12, 5e-15), 'f32': (4e-4, 2e-6, 4e-9), 'bf16': (2.5e-2, 1.5e-3, 5e-5)}
     for dtype in ('f64', 'f32', 'bf16'):
         w = bench.run_workload('c3', dtype, 1, 0, scale=0.1, parity=True)
-        rec = bench.parity_record(path, w['parity'])
+        rec = bench.parity_record(path, w['parity'], dtype)
         s_b, g_b, e_b = bounds[dtype]
-        within(rec['err_relerr'], e_b, 'bench parity at 1/10 scale, %s: relation errors after 2 iterations vs the oracle' % dtype)
-        within(rec['G_rows_relerr'], g_b, 'bench parity at 1/10 scale, %s: 64 rows of every factor vs the oracle' % dtype)
-        within(rec['S_relerr'], s_b, 'bench parity at 1/10 scale, %s: backbones vs the oracle' % dtype)
+        its = bench.PARITY_ITERS
+        within(rec['err_relerr'], e_b, 'bench parity at 1/10 scale, %s: relation errors after %d iterations vs the oracle' % (dtype, its))
+        within(rec['G_rows_relerr'], g_b, 'bench parity at 1/10 scale, %s: 64 rows of every factor vs the oracle (iterations 2, 5)' % dtype)
+        within(rec['S_relerr'], s_b, 'bench parity at 1/10 scale, %s: backbones vs the oracle (iterations 2, 5)' % dtype)
+        # the gate of the full-size record (VERDICT round 4, weak #1 ii): backbone deviation over cond_i cond_j of the engine's
+        # own Gram matrices against eps(engine)
+        within(rec['S_gate']['S_relerr_over_conditioning'], rec['S_gate']['eps'],
+               'bench parity at 1/10 scale, %s: backbone deviation / (cond_i cond_j) vs eps(engine)' % dtype)
+        assert rec['S_gate']['ok']
 
 
-@pytest.mark.parametrize('dtype,tol', [('f64', 1e-9), ('f32', 1e-4), ('bf16', 2e-2)])
+# measured (MI355X, round 4): f64 2.8e-15, f32 1.0e-6, bf16 1.4e-6 (the oracle is fed the bf16-rounded relation rows; the fold-in
+# itself runs in the f32 masters)
+@pytest.mark.parametrize('dtype,tol', [('f64', 3e-14), ('f32', 1e-5), ('bf16', 1.5e-5)])
 def test_fold_in_of_8192_objects_into_three_models(dtype, tol):
     """SURVEY.md 8 f2 at scale: 8192 new objects of t1 with their relations to the 100k objects of t2 and the 40k of t3 folded
     into the frozen models of THREE restarts (reference dfmf.py:191-199, _dfmf.py:385-428) in shared launches

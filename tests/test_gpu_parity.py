@@ -1,7 +1,8 @@
 """Parity tests proper: the HIP engine on a real MI355X, called through the C ABI
 (libskfusion_hip.so), against the golden vectors of the reference and the CPU oracle.
-Run with `pytest -m gpu`.  Tolerances: the bounds marked `within(...)` are at most ~5x the deviation
-measured on the hardware (quoted next to them; every session writes measured vs bound to
+Run with `pytest -m gpu`.  Tolerances: the bounds marked `within(...)` are at most 10x the LARGEST deviation any check of
+that call site measured (round 5: re-derived from profiles/r04_test_deviations.txt; rounding-level f64 checks keep a floor of
+~20 ulp, said where they do), measured on the hardware (quoted next to them; every session writes measured vs bound to
 gpurun_out/test_deviations.txt -> profiles/).  f64 vs the goldens of the reference: after 100
 iterations on the README graph 2.5e-12 (`random`), 1.5e-10 (`random_vcol`), 1e-9 (`random_c`) -- measured
 5.5e-13 / 3.6e-11 / 2.2e-10: SURVEY.md 8d's 1e-10 holds for `random` and at iterations 1-10, the
@@ -189,7 +190,9 @@ def test_sparse_binary_relations_as_lists_on_the_hardware():
     parts over 15 MB), ranks 64 / 128 / 256 -- against host products of the bf16-rounded factors."""
     import test_emul_engine as E
     worst = E.sparse_binary_lists_case({'m': 3000, 'a': 40000, 'c': 30000}, {'m': 64, 'a': 128, 'c': 256}, 0.01, 35)
-    within(worst, 2e-6, 'sparse 0/1 relations as lists over bf16 factor rows: P, Q vs host products of the rounded factors')
+    # measured 0.0: the list kernel adds the same bf16-rounded rows in f32 in list order, as the host product does; the bound
+    # leaves one f32 ulp per sum
+    within(worst, 1.2e-7, 'sparse 0/1 relations as lists over bf16 factor rows: P, Q vs host products of the rounded factors')
 
 
 def test_very_sparse_binary_relations_on_the_hardware():
@@ -220,8 +223,8 @@ def test_very_sparse_binary_relations_on_the_hardware():
     A = At.cpu().numpy()
     rows, cols = np.arange(0, 30000, 997), np.arange(0, 20000, 613)
     # measured 7.1e-8 / 8.3e-8 with f32 rows in round 2 (f32 sums of ~20 / ~30 rows)
-    within(relerr(P[rows], A[rows].astype(np.float64) @ Ga), 3e-7, 'sparse binary relation 30000 x 20000: P rows vs the product with the bf16-rounded factor')
-    within(relerr(Q[cols], A[:, cols].astype(np.float64).T @ Gm), 3e-7, 'sparse binary relation 30000 x 20000: Q rows vs the product with the bf16-rounded factor')
+    within(relerr(P[rows], A[rows].astype(np.float64) @ Ga), 2e-8, 'sparse binary relation 30000 x 20000: P rows vs the product with the bf16-rounded factor')
+    within(relerr(Q[cols], A[:, cols].astype(np.float64).T @ Gm), 2e-8, 'sparse binary relation 30000 x 20000: Q rows vs the product with the bf16-rounded factor')
 
 
 def test_to_bf16(rt):
@@ -236,7 +239,7 @@ def test_c1_readme_100_iterations_f64(init):
     snaps = Snapshots((0, 1, 9, 99))
     G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=100, callback=snaps,
                       G0=g0_from(z, init + '/', types), dtype='f64')
-    bound = {'random': 2.5e-12, 'random_c': 1e-9, 'random_vcol': 1.5e-10}[init]          # measured 5.5e-13 / 2.2e-10 / 3.6e-11
+    bound = {'random': 2.5e-12, 'random_c': 8e-10, 'random_vcol': 1.5e-10}[init]          # measured 3.3e-13 / 7.8e-11 (2.2e-10 in round 2) / 3.6e-11
     within(compare_snapshots(z, init + '/', snaps.snap, bound), bound, 'c1 f64 %s: (G, S) at iterations 1/2/10/100 vs golden' % init)
     errs = orc.relation_errors(R, G, S)
     for (i, j), e in errs.items():
@@ -308,8 +311,9 @@ def test_c5_movielens_style_dfmc_f64_f32_bf16():
     _dfmc.dfmc(R, M, Theta, types, rank, max_iter=30, callback=snaps, G0=G0)
     within(compare_snapshots(z, 'dfmc/', snaps.snap, 1.5e-11), 1.5e-11, 'c5 scaled f64: (G, S) over 30 iterations vs golden')   # measured 3.3e-12
     known = ~M['user', 'movie'][0]
-    # measured (round 2, MI355X): f32 2.7e-7 known / 2.0e-7 unknown, bf16 1.0e-3 known / 4.6e-4 unknown
-    for dtype, tol in (('f32', (1.2e-6, 1e-6)), ('bf16', (5e-3, 2.2e-3))):
+    # measured (round 4, MI355X): f32 2.7e-7 known / 1.1e-7 unknown, bf16 4.6e-4 known / 6.2e-7 unknown (the unknown entries
+    # average the rounding of ~10^5 cells; round 2, before the known-entry lists: 1.0e-3 / 4.6e-4)
+    for dtype, tol in (('f32', (1.2e-6, 1e-6)), ('bf16', (4.5e-3, 6e-6))):
         G, S = _dfmc.dfmc(R, M, Theta, types, rank, max_iter=30, G0=G0, dtype=dtype)
         d = G['user', 'user'].dot(S['user', 'movie'][0]).dot(G['movie', 'movie'].T) - R['user', 'movie'][0]
         for sel, key, bound in ((known, 'dfmc/rmse_known', tol[0]), (~known, 'dfmc/rmse_unknown', tol[1])):
@@ -421,8 +425,9 @@ def test_small_graph_schedule_on_an_awkward_graph(dtype, monkeypatch):
     schedule vs the oracle and vs the general schedule."""
     import small_cases
     worst_o, worst_s = small_cases.check(dtype, monkeypatch, iters=10)
-    within(worst_o, 1e-9 if dtype == 'f64' else 2e-3, 'awkward small graph %s: small-graph schedule vs oracle, 10 iterations' % dtype)
-    within(worst_s, 1e-10 if dtype == 'f64' else 2e-3, 'awkward small graph %s: small-graph vs general schedule' % dtype)
+    # measured: f64 2.1e-13 / 2.4e-13, f32 1.1e-5 / 4.3e-6
+    within(worst_o, 2e-12 if dtype == 'f64' else 1.1e-4, 'awkward small graph %s: small-graph schedule vs oracle, 10 iterations' % dtype)
+    within(worst_s, 2.4e-12 if dtype == 'f64' else 4e-5, 'awkward small graph %s: small-graph vs general schedule' % dtype)
 
 
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
@@ -444,7 +449,8 @@ def test_device_squared_error_on_unaligned_shapes(dtype):
         i, j = rel[k][0], rel[k][1]
         host = np.linalg.norm(R[i, j][0] - G[i] @ plan.get_backbone(k).astype(np.float64) @ G[j].T)
         dev = float(np.sqrt(plan.relation_sqerr(k)))
-        within(abs(dev - host) / host, 1e-10 if dtype == 'f64' else 2e-5, 'dicty %s: device squared error vs host arithmetic' % dtype)
+        # measured: f64 2e-16 (one ulp; the bound is a rounding-level floor of 20 ulp), f32 1.6e-7
+        within(abs(dev - host) / host, 5e-15 if dtype == 'f64' else 1.6e-6, 'dicty %s: device squared error vs host arithmetic' % dtype)
     # the error of the 100th iterate of the reference (golden): the fit itself, through the device's own error pass
     if dtype == 'f64':
         assert abs(np.sqrt(plan.relation_sqerr(0)) - float(np.ravel(z['dfmf/err_gene_go'])[0])) < 0.05
@@ -505,7 +511,7 @@ def test_c3_planted_scaled_against_the_reference_golden():
     for k, (i, j, _) in enumerate(bench.PAIRS):
         dm = bench.c3_relation(k, n, 'f32', 'planted', cache)
         dev = dm.buf.owner.view(torch.float32).view(n[i], n[j]).cpu().numpy().astype(np.float64)
-        within(relerr(dev, R[i, j][0]), 5e-6, 'planted generator on the device (f32) vs the host graph of the golden, relation %d' % k)
+        within(relerr(dev, R[i, j][0]), 2e-6, 'planted generator on the device (f32) vs the host graph of the golden, relation %d' % k)
     # measured: f64 2.9e-14, f32 7.8e-7, bf16 3.7e-2 -- the bf16 engine also rounds the FACTOR operand of the two contractions
     # (P = R bf16(G_j), Q = R^T bf16(G_i)), which the reference on the rounded relations does not: at this size (1600 - 4000
     # objects per type) that adds 0.7 / 3.3 / 1.0 % to the three RMSEs (1.310 / 1.487 / 1.309 x the floor against 1.3005 /
@@ -529,9 +535,9 @@ def test_c3_planted_scaled_against_the_reference_golden():
                % (dtype, ' on the bf16-rounded relations' if dtype == 'bf16' else ''))
         if dtype == 'f64':
             for t in types:
-                within(relerr(errs['G'][t, t][:16], z['f64/Grows_%s' % t]), 1e-8, 'planted c3, f64: 16 rows of G_%s at iteration 60' % t)
+                within(relerr(errs['G'][t, t][:16], z['f64/Grows_%s' % t]), 2.5e-11, 'planted c3, f64: 16 rows of G_%s at iteration 60' % t)
             for (i, j) in R:
-                within(relerr(errs['S'][i, j][0], z['f64/S_%s_%s' % (i, j)]), 1e-6, 'planted c3, f64: backbone %s-%s at iteration 60' % (i, j))
+                within(relerr(errs['S'][i, j][0], z['f64/S_%s_%s' % (i, j)]), 2e-9, 'planted c3, f64: backbone %s-%s at iteration 60' % (i, j))
 
 
 def test_accumulate_apply_split_equals_iterate():
@@ -623,7 +629,8 @@ def test_owned_rows_sharding_on_the_device(rt, monkeypatch):
     z = golden('c3_scaled.npz')
     R, G0, types, rank = c3_scaled_graph(z)
     Rb = {k: [nat.from_bf16_bits(nat.to_bf16_bits(v[0])).astype(np.float64)] for k, v in R.items()}
-    for size, dtype, tol, comm_stream in ((3, 'f64', 1e-9, '1'), (4, 'f32', 1e-5, '1'), (4, 'bf16', 1e-2, '1'), (2, 'bf16', 1e-2, '0')):
+    # measured: f64 5.1e-15, f32 1.5e-9, bf16 1.4e-5 / 1.6e-5 (the sharded fit deviates by what the single device does)
+    for size, dtype, tol, comm_stream in ((3, 'f64', 5e-14, '1'), (4, 'f32', 1.5e-8, '1'), (4, 'bf16', 1.5e-4, '1'), (2, 'bf16', 1.5e-4, '0')):
         monkeypatch.setenv('SKF_COMM_STREAM', comm_stream)
         out, grp, said = fit_owned('dfmf', R, None, {}, types, rank, G0, 5, size, dtype=dtype)
         for G, S in out:
@@ -778,7 +785,7 @@ def test_bf16_engine_c1_and_c3_scaled():
     within(np.abs(got - z['errs'][4]).max() / z['errs'][4].min(), 7e-5, 'c3 scaled bf16: reconstruction error vs f64 golden')   # measured 1.4e-5
     Gf, Sf = _dfmf.dfmf(R, {}, types, rank, max_iter=5, G0=G0, dtype='f32')
     for t in types:
-        bound = {'t1': 8e-4, 't2': 4e-3, 't3': 2e-2}[str(t)]        # measured 1.7e-4 / 8.8e-4 / 4.4e-3
+        bound = {'t1': 8e-4, 't2': 4e-3, 't3': 1.4e-2}[str(t)]        # measured 1.4e-4 / 1.6e-3 / 1.5e-3 (round 2: 1.7e-4 / 8.8e-4 / 4.4e-3)
         within(relerr(G[t, t], Gf[t, t]), bound, 'c3 scaled bf16: G_%s vs the f32 engine after 5 iterations' % t)
 
 
