@@ -261,6 +261,9 @@ static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void
     g.k_chunk = cdiv(ktiles, splits) * t.bk;
     splits = cdiv(g.K > 0 ? g.K : 1, g.k_chunk);
     g.part = part;
+    // a symmetric product (the caller says so: Gram = G^T G) computes the tiles on and below the diagonal only; the reduce of
+    // the K slices mirrors the rest (GemmArgs::sym).  Unsplit launches write C themselves and compute every tile.
+    g.sym = (g.sym && splits > 1 && g.M == g.N && engine == SKF_ENGINE_MFMA && t.bn > t.bm) ? (t.bm | (t.bn << 16)) : 0;
     if (ty.c == SKF_F64 && ty.a == SKF_F64 && ty.b == SKF_F64)
         launch_gemm_t<double, double, double>(engine, t, g, splits, relation, st);
     else if (ty.c == SKF_F32 && ty.a == SKF_F32 && ty.b == SKF_F32)
@@ -445,6 +448,11 @@ struct Switches {
     bool no_small_fused = false;   // SKF_NO_SMALL_FUSED=1  small graphs on the general staged schedule (~33 launches per iteration)
     bool no_sweep = false;         // SKF_PINV_SWEEP=0      orders 65 .. 256: blocked Cholesky inverse + unpack instead of the blocked sweep (A/B)
     bool small_sweep1 = false;     // SKF_SMALL_SWEEP4=0    small graphs: one pivot per barrier in the register sweep (same bits; A/B, tests)
+    int gram_sym = 1;              // SKF_GRAM_SYM=0        split-K Gram products compute every tile (default: the tiles on / below the diagonal, mirrored by the reduce)
+    bool early_update = true;      // SKF_EARLY_UPDATE=0    pipeline: every type is updated at the end of the iteration (default: a type whose last relation is through
+                                   //                       and that nothing reads any more is updated on the second stream, underneath the remaining contractions)
+    std::string main_cu_drop;      // SKF_MAIN_CU_DROP=a-b,c,...  bits cleared in the CU mask of the stream that carries the contractions (an internal stream
+                                   //                       with that mask replaces the caller's for the iteration: CUs kept free for the second stream's small launches)
     static Switches read() {
         auto on = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
         Switches w;
@@ -462,6 +470,9 @@ struct Switches {
         w.no_small_fused = on("SKF_NO_SMALL_FUSED");
         { const char* sv = getenv("SKF_PINV_SWEEP"); w.no_sweep = sv && atoi(sv) == 0; }
         { const char* s4 = getenv("SKF_SMALL_SWEEP4"); w.small_sweep1 = s4 && atoi(s4) == 0; }
+        { const char* gs = getenv("SKF_GRAM_SYM"); w.gram_sym = (gs && atoi(gs) == 0) ? 0 : 1; }
+        { const char* eu = getenv("SKF_EARLY_UPDATE"); w.early_update = !(eu && atoi(eu) == 0); }
+        { const char* cd = getenv("SKF_MAIN_CU_DROP"); if (cd) w.main_cu_drop = cd; }
         const char* st = getenv("SKF_SIDE_TILE");
         w.side_tile = st ? atoi(st) : 0;
         const char* ap = getenv("SKF_AUX_PRIO");
@@ -599,6 +610,10 @@ struct skf_plan {
     // second stream: Gram + pseudo-inverse run concurrently with the relation contractions
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // SKF_MAIN_CU_DROP: an internal stream with a CU mask that carries the iteration instead of the caller's stream (the
+    // caller's stream waits for it at the end of every skf_iterate / skf_iterate_dist call)
+    hipStream_t mainq = nullptr;
+    hipEvent_t ev_mq_in = nullptr, ev_mq_out = nullptr;
     skf::Slot part_aux;
     size_t part_aux_bytes = 0;
     skf::Slot sp_part;                     // partial outputs of the parted list passes over sparse 0/1 relations
@@ -647,6 +662,9 @@ struct skf_plan {
         for (hipEvent_t e : ev_own) (void)hipEventDestroy(e);
         if (cs) (void)hipStreamDestroy(cs);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (mainq) (void)hipStreamDestroy(mainq);
+        if (ev_mq_in) (void)hipEventDestroy(ev_mq_in);
+        if (ev_mq_out) (void)hipEventDestroy(ev_mq_out);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (aux) (void)hipStreamDestroy(aux);
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -936,6 +954,7 @@ static void pinv_fallbacks(skf_plan* p, const std::vector<int>& which, const Pin
 static void gram(skf_plan* p, TypeState& t, int nan, hipStream_t st, bool on_aux = false) {
     // Gram = G^T G : A = G^T (m-contiguous), B = G; f64 accumulation
     GemmArgs g = gemm_args(t.G.ptr, 1, t.c, t.G.ptr, t.c, 1, t.Gram.ptr, t.c, t.c, t.c, (int)t.n, EPI_STORE, nan);
+    g.sym = p->sw.gram_sym;
     run_gemm(GemmTypes{SKF_F64, p->mt, p->mt}, p->engine, g, 0, on_aux ? p->part_aux.ptr : p->part.ptr,
              on_aux ? p->part_aux_bytes : p->part_bytes, st);
 }
@@ -1729,22 +1748,26 @@ static void accumulate_fit(skf_plan* p, hipStream_t st) {
     stage_accumulate(p, st);
 }
 
-// G_i <- G_i * sqrt(E_i / max(D_i, eps)) for every type   (_dfmf.py:294-296)
-static void apply_update(skf_plan* p, hipStream_t st) {
+// G_i <- G_i * sqrt(E_i / max(D_i, eps)) of one type   (_dfmf.py:294-296)
+static void update_type(skf_plan* p, TypeState& t, hipStream_t st) {
+    if (p->bf16 && t.n > 0) {                  // update and G^T refresh in one pass
+        hipLaunchKernelGGL(mult_update_transpose_kernel, dim3((unsigned)cdiv(t.c, 32), (unsigned)cdiv(t.n, 32)), dim3(256), 0,
+                           st, (float*)t.G.ptr, (const float*)t.E.ptr, (const float*)t.D.ptr, (int64_t)t.n, (int64_t)t.c,
+                           (uint16_t*)t.GTb.ptr, t.ldgt, (uint16_t*)t.Grow.ptr, t.ldrow);
+        check_launch("mult_update_transpose");
+        return;
+    }
+    mult_update(p, t, st);
+    refresh_gt(p, t, st);
+}
+
+// ... of every type (`done`: types the schedule has updated already)
+static void apply_update(skf_plan* p, hipStream_t st, const std::vector<char>* done = nullptr) {
     for (TypeState& t : p->types)          // known-entries relations: the factors their stored residuals belong to
         if (t.keep_prev) SKF_HIP(hipMemcpyAsync(t.Gp.ptr, t.G.ptr, t.G.bytes, hipMemcpyDeviceToDevice, st));
     p->kn_first = false;
-    for (TypeState& t : p->types) {
-        if (p->bf16 && t.n > 0) {                  // update and G^T refresh in one pass
-            hipLaunchKernelGGL(mult_update_transpose_kernel, dim3((unsigned)cdiv(t.c, 32), (unsigned)cdiv(t.n, 32)), dim3(256), 0,
-                               st, (float*)t.G.ptr, (const float*)t.E.ptr, (const float*)t.D.ptr, (int64_t)t.n, (int64_t)t.c,
-                               (uint16_t*)t.GTb.ptr, t.ldgt, (uint16_t*)t.Grow.ptr, t.ldrow);
-            check_launch("mult_update_transpose");
-            continue;
-        }
-        mult_update(p, t, st);
-        refresh_gt(p, t, st);
-    }
+    for (size_t i = 0; i < p->types.size(); ++i)
+        if (!(done && (*done)[i])) update_type(p, p->types[i], st);
 }
 
 
@@ -2006,6 +2029,7 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
             continue;
         }
         GemmArgs g = gemm_args(own(t.G, t), 1, t.c, own(t.G, t), t.c, 1, t.Gram.ptr, t.c, t.c, t.c, (int)t.tn, EPI_STORE, 1);
+        g.sym = p->sw.gram_sym;
         run_gemm(GemmTypes{SKF_F64, p->mt, p->mt}, p->engine, g, 0, gram_aux ? p->part_aux.ptr : p->part.ptr,
                  gram_aux ? p->part_aux_bytes : p->part_bytes, sg);
     }
@@ -2435,6 +2459,9 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         rels_left[r.row] += 1;
         rels_left[r.col] += 1;
     }
+    std::vector<char> updated(nt, 0), has_theta(nt, 0);       // early updates (below): DFMF only, types without constraints
+    for (const ThetaState& th : p->thetas) has_theta[th.type] = 1;
+    const bool early_ok = !dfmc && p->sw.early_update;
     // type-level terms E_i += G_i sum B-, D_i += G_i sum B+ as soon as the last relation of the type is through
     auto type_term = [&](size_t i) {
         TypeState& t = p->types[i];
@@ -2563,6 +2590,19 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         }
         backbone_chain(q);
         side_products(q, 4 * q);
+        // a type whose last relation this was has its E and D complete behind the side products just issued, and nothing
+        // that is still to come reads its factor (no later relation, no constraint on it): its update -- for the bf16 engine
+        // also the refresh of the stored G^T -- goes out on the second stream NOW, underneath the remaining relations'
+        // contractions, instead of at the exposed end of the iteration (config 3: the 100k-object type, 88 of the 150 us
+        // the three updates take).  Same arithmetic, same results.
+        if (early_ok)
+            for (int side = 0; side < 2; ++side) {
+                const size_t i = side == 0 ? (size_t)r.row : (size_t)r.col;
+                if (rels_left[i] == 0 && !updated[i] && !has_theta[i] && q + 1 < nr) {
+                    update_type(p, p->types[i], ax);
+                    updated[i] = 1;
+                }
+            }
     }
     // ---- masked relations: completion (_dfmc.py:319-325), then the two contractions of the G update
     for (size_t q = 0; q < nr; ++q) {
@@ -2603,7 +2643,7 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
     theta_terms(p, ax);
     SKF_HIP(hipEventRecord(p->ev_join, ax));
     SKF_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
-    apply_update(p, st);
+    apply_update(p, st, &updated);
 }
 
 // The DFMF iteration of a small graph in three launches (skf_small.h); n_batch > 1: of that many plans of the same graph at
@@ -2862,6 +2902,27 @@ static void build_known_lists(skf_plan* p, RelState& r, hipStream_t st) {
 }  // namespace skf
 
 using namespace skf;
+
+// the stream an iteration is issued on: the caller's, or -- SKF_MAIN_CU_DROP -- the plan's masked stream, forked from the
+// caller's stream here and joined back by join()
+struct MaskedMain {
+    skf_plan* p;
+    hipStream_t caller;
+    bool on;
+    MaskedMain(skf_plan* plan, hipStream_t st) : p(plan), caller(st), on(plan->mainq != nullptr && !plan->small_fused) {
+        if (on) {
+            SKF_HIP(hipEventRecord(p->ev_mq_in, caller));
+            SKF_HIP(hipStreamWaitEvent(p->mainq, p->ev_mq_in, 0));
+        }
+    }
+    hipStream_t stream() const { return on ? p->mainq : caller; }
+    void join() {
+        if (!on) return;
+        SKF_HIP(hipEventRecord(p->ev_mq_out, p->mainq));
+        SKF_HIP(hipStreamWaitEvent(caller, p->ev_mq_out, 0));
+    }
+};
+
 
 // ------------------------------------------------------------------------------------------
 // C ABI
@@ -3747,6 +3808,35 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
                 p->overlap = true;
             }
         }
+        if (p->variant != SKF_TRANSFORM && p->overlap && !p->mainq && !p->sw.main_cu_drop.empty()) {
+            // the contractions' stream with some CUs masked out: a contraction workgroup owns its CU outright, and a launch
+            // of >= 256 of them leaves the second stream's small launches (c x c chains, pseudo-inverses) waiting for a free
+            // CU until the first wave of the contraction retires -- CUs the main stream cannot use are always free for them
+            hipDeviceProp_t prop;
+            int dev = 0;
+            SKF_HIP(hipGetDevice(&dev));
+            SKF_HIP(hipGetDeviceProperties(&prop, dev));
+            const int ncu = prop.multiProcessorCount;
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0xffffffffu);
+            if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1u;
+            int dropped = 0;
+            const char* c = p->sw.main_cu_drop.c_str();
+            while (*c) {                                   // "a-b,c,d-e"
+                char* end = nullptr;
+                long a = strtol(c, &end, 10), b = a;
+                if (end == c) break;
+                c = end;
+                if (*c == '-') { b = strtol(c + 1, &end, 10); c = end; }
+                for (long k = a; k <= b && k < ncu; ++k)
+                    if (k >= 0 && (mask[(size_t)k / 32] >> (k % 32)) & 1u) { mask[(size_t)k / 32] &= ~(1u << (k % 32)); ++dropped; }
+                if (*c == ',') ++c;
+            }
+            if (dropped > 0 && dropped < ncu) {
+                SKF_HIP(hipExtStreamCreateWithCUMask(&p->mainq, (uint32_t)mask.size(), mask.data()));
+                SKF_HIP(hipEventCreateWithFlags(&p->ev_mq_in, hipEventDisableTiming));
+                SKF_HIP(hipEventCreateWithFlags(&p->ev_mq_out, hipEventDisableTiming));
+            }
+        }
         if (p->graph_exec) {
             (void)hipGraphExecDestroy(p->graph_exec);
             p->graph_exec = nullptr;
@@ -3840,6 +3930,8 @@ int skf_iterate(skf_plan* p, int32_t n_iters, void* stream) {
             for (int it = 0; it < n_iters; ++it) iterate_transform(p, st);
         } else {
             int it = 0;
+            MaskedMain mq(p, st);                  // (SKF_MAIN_CU_DROP: the iteration runs on the plan's masked stream)
+            st = mq.stream();
             // The iteration is ~50-80 launches; for small graphs (launch-latency regime) the
             // remaining iterations replay ONE captured hipGraph.  Capture needs a real stream
             // (not the legacy default stream) and is skipped while profiling events are recorded.
@@ -3853,6 +3945,7 @@ int skf_iterate(skf_plan* p, int32_t n_iters, void* stream) {
                     for (; it < n_iters; ++it) SKF_HIP(hipGraphLaunch(p->graph_exec, st));
             }
             for (; it < n_iters; ++it) iterate_fit(p, st);
+            mq.join();
         }
     });
 }
@@ -4140,8 +4233,10 @@ int skf_iterate_dist(skf_plan* p, int32_t n_iters, void* stream) {
             if (p->comm->world != p->part_count || p->comm->rank != p->part_index)
                 SKF_FAIL(SKF_E_STATE, "the communicator is rank %d of %d, the plan part %d of %d", p->comm->rank, p->comm->world,
                          p->part_index, p->part_count);
-            for (int it = 0; it < n_iters; ++it) iterate_owned(p, as_stream(stream));
-            finalize_owned(p, as_stream(stream));
+            MaskedMain mq(p, as_stream(stream));
+            for (int it = 0; it < n_iters; ++it) iterate_owned(p, mq.stream());
+            finalize_owned(p, mq.stream());
+            mq.join();
             return;
         }
         for (int it = 0; it < n_iters; ++it) iterate_dist(p, as_stream(stream));

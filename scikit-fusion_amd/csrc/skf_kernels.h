@@ -57,7 +57,19 @@ struct GemmArgs {
     int aop, epi, nan_to_num;
     int c_bf16;              // EPI_SQDIFF: the matrix behind C is stored as bf16
     int mask_bits;           // EPI_MASKED_STORE: the mask is packed (the engine's own masks always are)
+    int sym;                 // split-K launches of a SYMMETRIC product (Gram = G^T G): bm | bn << 16 of the launch's tile --
+                             // workgroups whose tile lies strictly above the diagonal return at once and the reduce takes such an
+                             // element from its mirror image (element (a, b) and (b, a) are the same products added in the
+                             // same order: bit for bit the full product, 6 of 8 tiles at order 256); 0 = off
 };
+
+// the partial-sum element the reduce of a split-K launch reads for output element e = (m, n) (see GemmArgs::sym)
+__device__ __forceinline__ int64_t sym_source(const GemmArgs& g, int64_t e) {
+    if (!g.sym) return e;
+    const int bm = g.sym & 0xffff, bn = g.sym >> 16;
+    const int m = (int)(e / g.N), n = (int)(e % g.N);
+    return ((n / bn) * bn >= (m / bm) * bm + bm) ? (int64_t)n * g.N + m : e;
+}
 
 __device__ __forceinline__ bool mask_test(const GemmArgs& g, int m, int n) {
     if (g.mask_bits) return (g.mask[(int64_t)m * g.ldmask + (n >> 3)] >> (n & 7)) & 1;
@@ -329,6 +341,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * (WR * MF::MT), wn0 = (wave & 1) * (WC * MF::NT);
     const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    if (g.sym && bn0 >= bm0 + BM) return;          // symmetric product: this tile is the mirror image of one that is computed
     const int kz0 = blockIdx.z * g.k_chunk;
     const int kz1 = (kz0 + g.k_chunk < g.K) ? kz0 + g.k_chunk : g.K;
     const TA* __restrict__ A = (const TA*)g.A;
@@ -1630,7 +1643,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int spli
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         T v = (T)0;
-        for (int z = 0; z < splits; ++z) v += part[(int64_t)z * total + e];
+        const int64_t src = sym_source(g, e);
+        for (int z = 0; z < splits; ++z) v += part[(int64_t)z * total + src];
         epilogue_store<T>(g, (int)(e / g.N), (int)(e % g.N), v);
     }
 }
@@ -1649,13 +1663,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_z16_kernel(GemmArgs g, int 
         const int64_t e = e0 + el;
         T v = (T)0;
         if (e < total) {
+            const int64_t src = sym_source(g, e);
             int z = zl;
             for (; z + 48 < splits; z += 64) {
-                const T a = part[(int64_t)z * total + e], b = part[(int64_t)(z + 16) * total + e];
-                const T c = part[(int64_t)(z + 32) * total + e], d = part[(int64_t)(z + 48) * total + e];
+                const T a = part[(int64_t)z * total + src], b = part[(int64_t)(z + 16) * total + src];
+                const T c = part[(int64_t)(z + 32) * total + src], d = part[(int64_t)(z + 48) * total + src];
                 v += a; v += b; v += c; v += d;
             }
-            for (; z < splits; z += 16) v += part[(int64_t)z * total + e];
+            for (; z < splits; z += 16) v += part[(int64_t)z * total + src];
         }
         red[zl][el] = v;
         __syncthreads();
