@@ -238,7 +238,10 @@ def pmc_traffic_in_run(dtype, workload='c3', steps=2, timeout=420):
                                                   "where counter_name = ? group by kernel_name", (counter,)):
                     short = re.sub(r'\(.*$', '', name).replace('skf::', '').replace('void ', '')
                     m = re.match(r'gemm_bf16_v2_kernel<\s*\d+\s*,\s*(\d+)\s*,', short)
-                    if m and m.group(1) == '1':                 # TAG = 1: the launches that walk a relation (P, Q)
+                    hit = bool(m and m.group(1) == '1')         # TAG = 1: the launches that walk a relation (P, Q)
+                    if workload == 'c5':                        # ... and the passes over lists (known entries, sparse 0/1 relations)
+                        hit = hit or short.startswith(('srp_bf16', 'srp_vec', 'srp_any', 'binary_spmm'))
+                    if hit:
                         tot += float(val)
                         n += cnt
             if n <= 0:
@@ -252,8 +255,8 @@ def pmc_traffic_in_run(dtype, workload='c3', steps=2, timeout=420):
     return {'bytes': fetch + write, 'fetch_bytes_per_launch': fetch, 'write_bytes_per_launch': write,
             'launches_counted': int(calls['FETCH_SIZE']), 'seconds': time.perf_counter() - t0, 'in_run': True,
             'source': 'this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes of bench.py, %d + 1 '
-                      'iterations each), FETCH_SIZE x2 gfx950 correction, mean over the %d relation-contraction launches'
-                      % (steps, int(calls['FETCH_SIZE']))}
+                      'iterations each), FETCH_SIZE x2 gfx950 correction, mean over the %d %s launches'
+                      % (steps, int(calls['FETCH_SIZE']), 'contraction-class (relation / list-pass)' if workload == 'c5' else 'relation-contraction')}
 
 
 def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, elapsed, pmc=None, k_bytes=None,
@@ -446,7 +449,7 @@ def gram_condition(G):
     return float(lam[-1] / max(lam[0], 1e-300))
 
 
-def parity_record(oracle_npz, engine, dtype=None):
+def parity_record(oracle_npz, engine, dtype=None, s_eps=None):
     """`parity_full_size` of one engine: its first PARITY_ITERS iterations from the hash-generated G0 against the oracle's
     (same inputs, FULL size) -- per checkpoint the max relative deviation of the backbones (Frobenius) and of PARITY_ROWS rows
     of every factor, after the last iteration that of the three relation errors; and the GATE on the backbones: every
@@ -471,13 +474,31 @@ def parity_record(oracle_npz, engine, dtype=None):
     rec.update({'S_relerr': worst_s, 'G_rows_relerr': worst_g,
                 'err_relerr': max(abs(float(engine['err_%s_%s' % (i, j)]) / float(z['err_%s_%s' % (i, j)]) - 1.0) for i, j, _ in PAIRS),
                 'oracle_err': {'%s-%s' % (i, j): float(z['err_%s_%s' % (i, j)]) for i, j, _ in PAIRS}})
-    if dtype in PARITY_S_EPS and worst_gate > 0.0:
-        rec['S_gate'] = {'S_relerr_over_conditioning': worst_gate, 'eps': PARITY_S_EPS[dtype],
-                         'ok': bool(worst_gate <= PARITY_S_EPS[dtype])}
+    eps = s_eps if s_eps is not None else PARITY_S_EPS.get(dtype)          # (s_eps: tests at another scale bring their own)
+    if eps is not None and worst_gate > 0.0:
+        rec['S_gate'] = {'S_relerr_over_conditioning': worst_gate, 'eps': eps, 'ok': bool(worst_gate <= eps)}
     return rec
 
 
-def cpu_baseline(full='auto', parity_out=None):
+def cpu_baseline_start(full='auto', parity_out=None):
+    """Start the full-size oracle child of `cpu_baseline` in the background (Popen) when this host qualifies, so that the
+    GPU-only sub-records of the default run proceed beside it (the child runs 128 BLAS threads of the host's 256 logical
+    cores, the parent one or two that enqueue launches); None otherwise.  `cpu_baseline(..., child=...)` collects it."""
+    host = host_info()
+    want_full = full is True or (full == 'auto' and (host['ram_gib'] or 0) >= 256 and (host['cpu_count'] or 0) >= 32)
+    if not want_full:
+        return None
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-full-child']
+    if parity_out:
+        cmd += ['--parity-out', parity_out]
+    try:
+        return {'proc': subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), 't0': time.perf_counter()}
+    except Exception:
+        return None
+
+
+def cpu_baseline(full='auto', parity_out=None, child=None):
     """Oracle (kind=port) on the host cores.  When the host can hold the fp64 graph (88 GB + temporaries: RAM >= 256 GiB
     and >= 32 cores) PARITY_ITERS iterations are timed at FULL size in a child process bounded to 420 s and the
     second is reported; otherwise, or when that fails, the 1/10-linear-scale sample is timed and scaled by the n_i*n_j work
@@ -490,15 +511,25 @@ def cpu_baseline(full='auto', parity_out=None):
     if want_full:
         import subprocess
         try:
-            cmd = [sys.executable, os.path.abspath(__file__), '--cpu-full-child']
-            if parity_out:
-                cmd += ['--parity-out', parity_out]
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
-            r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+            if child is not None:                  # started earlier, beside the GPU sub-records
+                left = max(420.0 - (time.perf_counter() - child['t0']), 1.0)
+                try:
+                    stdout, _ = child['proc'].communicate(timeout=left)
+                except subprocess.TimeoutExpired:
+                    child['proc'].kill()
+                    raise
+                beside = ' (run beside the GPU-only sub-records of this bench: one or two busy host threads)'
+            else:
+                cmd = [sys.executable, os.path.abspath(__file__), '--cpu-full-child']
+                if parity_out:
+                    cmd += ['--parity-out', parity_out]
+                stdout = subprocess.run(cmd, capture_output=True, text=True, timeout=420).stdout
+                beside = ''
+            r = json.loads([l for l in stdout.splitlines() if l.startswith('{')][-1])
             base.update({'value': 1.0 / r['times'][-1], 'projection': False,
                          'sample': 'oracle (NumPy fp64, reference op order, 3 big GEMMs per relation, scipy pinv) at FULL size, '
-                                   'device-identical inputs: iterations %s s, the last one reported (%.0f s with the 88 GB fill)'
-                                   % ('/'.join('%.1f' % t for t in r['times']), r['total_seconds'])})
+                                   'device-identical inputs: iterations %s s, the last one reported (%.0f s with the 88 GB fill)%s'
+                                   % ('/'.join('%.1f' % t for t in r['times']), r['total_seconds'], beside)})
             return base
         except Exception as exc:                   # time-out, memory, a host without the packages ...
             note = ' (full-size run failed: %s)' % (str(exc)[:120],)
@@ -605,6 +636,43 @@ def cpu_baseline_c5_full(scale=1.0, timeout=900):
             'sample': 'oracle dfmc (NumPy fp64, reference op order, boolean-mask completion) at FULL size (%d users x %d movies): '
                       'iterations %s s, the last one reported (%.0f s of data fill)'
                       % (r['users'], r['movies'], '/'.join('%.1f' % t for t in r['times']), r['fill_seconds'])}
+
+
+def cpu_baseline_c5_half(timeout=300):
+    """The config-5 oracle leg of the default run: MEASURED (not projected) at 1/2 linear scale -- 50k users x 20k movies, a
+    quarter of the cells, where OpenBLAS is still efficient (the 1/4-scale projection of rounds 3-4 was 1.9x pessimistic) --
+    in the bounded child of `--cpu-baseline full`; `value` is the rate AT THAT SCALE (`scale: 0.5` says so),
+    `value_times_cell_ratio` the same number times 1/4 for orientation against the full-size GPU rate, and the one full-size
+    measurement of round 4 (0.0379 it/s, profiles/r04_c5_cpu_full.txt) is quoted."""
+    r = cpu_baseline_c5_full(0.5, timeout)
+    if r is None:
+        return None
+    r.update({'scale': 0.5, 'value_times_cell_ratio': r['value'] * 0.25, 'full_size_measured_in_round_4': 0.0379,
+              'sample': r['sample'].replace('at FULL size', 'at 1/2 linear scale')})
+    return r
+
+
+def mid_size_record(dtype='bf16', scale=0.1):
+    """`workloads.c3_tenth`: SURVEY's 1/10-scale probe graph (5k x 10k / 5k x 4k / 10k x 4k, ranks 128/256/256; the reference
+    took 1.4-2.4 s per iteration there) -- between the three-launch schedule of small graphs (ranks <= 64) and the
+    sizes the relation pipeline is tuned for: it/s of the three engines, launches per iteration, and the oracle's rate on this
+    host beside them."""
+    out = {'config': 'BASELINE configs[2] at 1/10 linear scale: 5000x10000 / 5000x4000 / 10000x4000, ranks 128/256/256', 'scale': scale}
+    for dt in (dtype, 'f32', 'f64'):
+        try:
+            w = run_workload('c3', dt, 50, 5, scale=scale)
+            out[dt] = {'value': 50 / w['elapsed'], 'unit': 'iters/s', 'ms_per_step': w['elapsed'] / 50 * 1e3,
+                       'launches_per_step': w['launches_per_step'], 'host_enqueue_ms_per_step': w['enqueue_ms_per_step']}
+        except Exception as exc:
+            out[dt] = {'error': str(exc)[:200]}
+    try:
+        _oracle_timing(scale, 1)
+        times, _ = _oracle_timing(scale, 3)
+        out['oracle'] = {'value': 1.0 / min(times), 'unit': 'iters/s', 'cores': blas_threads(), 'kind': 'port',
+                         'sample': 'NumPy fp64, reference op order, best of 3 iterations'}
+    except Exception as exc:
+        out['oracle'] = {'error': str(exc)[:200]}
+    return out
 
 
 def bench_dicty(iters=100):
@@ -902,10 +970,13 @@ def compact_roofline(r):
                                   'accounting', 'traffic', 'executed_bytes_per_launch', 'traffic_kind') if k in r}
 
 
-def other_workloads(dtype='bf16'):
-    """The `workloads` sub-record of the default run (single GPU): BASELINE configs[4], configs[1] and the planted-data
-    RMSE of configs[2]; every leg reports its own failure instead of sinking the headline line."""
-    out = {}
+def other_workloads(dtype='bf16', dicty=None):
+    """The `workloads` sub-record of the default run (single GPU) -- GPU legs only: BASELINE configs[4], configs[1] (`dicty`:
+    measured by the caller while the host was still quiet -- that leg is bound by the host's launch rate), the planted-data
+    RMSE of configs[2], the rank-of-8 emulation and the 1/10-scale graph; every leg reports its own failure instead of sinking
+    the headline line.  The host legs (the oracle timing of configs[4], its PMC children) follow in `other_workloads_host`,
+    after the full-size oracle child of the headline has finished: CPU timings are not taken beside one another."""
+    out = {'c2_dicty': dicty if dicty is not None else dicty_record()}
     try:
         w = run_workload('c5', dtype, 10, 3)
         roof = roofline_record(dtype, w['n'], w['ranks'], w['spec'], w['k_ms'], w['k_launches'], w['k_flops'], 10,
@@ -914,17 +985,10 @@ def other_workloads(dtype='bf16'):
                                     '98% masked and kept as known-entry lists, five 0/1 relations, two constraints)',
                           'value': 10 / w['elapsed'], 'unit': 'iters/s', 'steps': 10, 'warmup': 3,
                           'ms_per_step': w['elapsed'] / 10 * 1e3, 'dtype': dtype, 'rmse_completed': w['rmse'],
-                          'roofline': compact_roofline(roof)}
-        try:
-            out['c5_dfmc']['cpu_baseline'] = cpu_baseline_c5()
-        except Exception as exc:
-            out['c5_dfmc']['cpu_baseline'] = {'error': str(exc)[:200]}
+                          'launches_per_step': w['launches_per_step'], 'roofline': compact_roofline(roof),
+                          '_w': {k: w[k] for k in ('n', 'ranks', 'spec', 'k_ms', 'k_launches', 'k_flops', 'elapsed', 'k_bytes')}}
     except Exception as exc:
         out['c5_dfmc'] = {'error': str(exc)[:300]}
-    try:
-        out['c2_dicty'] = dict(bench_dicty(), config='BASELINE configs[1]')
-    except Exception as exc:
-        out['c2_dicty'] = {'error': str(exc)[:300]}
     try:
         w = run_workload('c3', dtype, 30, 0, data='planted')
         floor = 0.01 / np.sqrt(12.0)
@@ -943,6 +1007,33 @@ def other_workloads(dtype='bf16'):
     except Exception as exc:
         out['c3_planted'] = {'error': str(exc)[:300]}
     out['rank_of_8'] = rank_of_8_record(dtype)
+    out['c3_tenth'] = mid_size_record(dtype)
+    return out
+
+
+def dicty_record():
+    try:
+        return dict(bench_dicty(), config='BASELINE configs[1]')
+    except Exception as exc:
+        return {'error': str(exc)[:300]}
+
+
+def other_workloads_host(out, dtype='bf16', cpu=True, pmc=True):
+    """The host legs of `workloads` (see other_workloads): the config-5 oracle at 1/2 linear scale, measured; then config 5's
+    HBM traffic from PMC children of THIS run (its roofline record rebuilt with it)."""
+    c5 = out.get('c5_dfmc') or {}
+    w = c5.pop('_w', None)
+    if 'error' in c5 or w is None:
+        return out
+    if cpu:
+        try:
+            c5['cpu_baseline'] = cpu_baseline_c5_half() or cpu_baseline_c5()
+        except Exception as exc:
+            c5['cpu_baseline'] = {'error': str(exc)[:200]}
+    traffic = pmc_traffic_in_run(dtype, 'c5') if pmc else None
+    if traffic:
+        c5['roofline'] = compact_roofline(roofline_record(dtype, w['n'], w['ranks'], w['spec'], w['k_ms'], w['k_launches'],
+                                                          w['k_flops'], 10, w['elapsed'], traffic, w['k_bytes'], executed=True))
     return out
 
 
@@ -1031,6 +1122,8 @@ def main():
     default_run = world == 1 and not c5 and args.scale == 1.0 and args.data == 'uniform'
     want_parity = default_run and not args.no_cpu_baseline
     parity_kept = {}
+    # Order of a default run: the headline (quiet host) -> the full-size oracle child starts in the background -> the GPU-only
+    # sub-records (engines, workloads) beside it -> the child is collected -> the other host timings -> the PMC children.
     w = run_workload(args.workload, args.dtype, args.steps, args.warmup, args.scale, args.data, args.mode, rank, world,
                      dist, backend, parity=want_parity, sustained=args.sustained_steps if default_run else 0)
     parity_kept[args.dtype] = w['parity']
@@ -1044,8 +1137,16 @@ def main():
                'relations': 'one fit, whole relations partitioned over the GPUs',
                'rows': 'one fit, balanced row blocks of the relations over the GPUs',
                'owned': 'one fit, every GPU owns the same share of the rows of every object type'}[args.mode]
+        cpu_child = pfile = dicty = None
+        if default_run and not args.no_workloads:
+            dicty = dicty_record()             # (bound by the host's launch rate: measured before the oracle child loads the host)
+        if world == 1 and not args.no_cpu_baseline and not c5:
+            import tempfile
+            pfile = os.path.join(tempfile.gettempdir(), 'skf_parity_%d.npz' % os.getpid()) if want_parity else None
+            if default_run and not (args.no_engines and args.no_workloads):
+                cpu_child = cpu_baseline_start({'auto': 'auto', 'full': True, 'sample': False}[args.cpu_baseline], pfile)
         pmc = None
-        if default_run and not args.no_pmc:
+        if default_run and not args.no_pmc and cpu_child is None:
             pmc = pmc_traffic_in_run(args.dtype)              # counters of THIS run when the box has rocprofv3
         roof = roofline_record(args.dtype, n, ranks_, spec, w['k_ms'], w['k_launches'], w['k_flops'], args.steps, elapsed,
                                pmc or measured_traffic(args.dtype, c5, args.scale), w['k_bytes'], executed=c5)
@@ -1095,7 +1196,7 @@ def main():
                            'achieved': r['achieved'], 'peak': r['peak'], 'unit_roofline': r['unit'], 'frac': r['frac']}
         out['engines'] = engines
     if default_run and not args.no_workloads:
-        out['workloads'] = other_workloads(args.dtype)
+        out['workloads'] = other_workloads(args.dtype, dicty)
     if world > 1 and args.mode == 'restarts' and not args.no_strong and not c5 and args.data == 'uniform':
         strong = strong_record(args.dtype, rank, world, dist, backend, scale=args.scale)      # collective: every rank runs it
         if rank == 0:
@@ -1106,10 +1207,8 @@ def main():
                 full = cpu_baseline_c5_full(args.scale) if args.cpu_baseline == 'full' else None
                 out['cpu_baseline'] = full or cpu_baseline_c5(0.25 * args.scale, args.scale)
             else:
-                import tempfile
-                pfile = os.path.join(tempfile.gettempdir(), 'skf_parity_%d.npz' % os.getpid()) if want_parity else None
                 out['cpu_baseline'] = cpu_baseline(full={'auto': 'auto', 'full': True, 'sample': False}[args.cpu_baseline],
-                                                   parity_out=pfile)
+                                                   parity_out=pfile, child=cpu_child)
                 # full-size parity: the engine's first iterations against the oracle's on the same inputs (both legs ran
                 # above; the oracle's only when the host could hold the fp64 graph)
                 if pfile and os.path.exists(pfile) and not out['cpu_baseline'].get('projection', True):
@@ -1123,6 +1222,16 @@ def main():
                     os.remove(pfile)
                 elif want_parity:
                     out['parity_full_size'] = {'error': 'no full-size oracle run on this host (cpu_baseline.projection)'}
+        if default_run and 'workloads' in out:
+            other_workloads_host(out['workloads'], args.dtype, cpu=not args.no_cpu_baseline, pmc=not args.no_pmc)
+        if default_run and not args.no_pmc and cpu_child is not None:
+            # the counters of THIS run, once the host is quiet again: two rocprofv3 children; the roofline record is rebuilt
+            pmc = pmc_traffic_in_run(args.dtype)
+            if pmc:
+                roof = roofline_record(args.dtype, n, ranks_, spec, w['k_ms'], w['k_launches'], w['k_flops'], args.steps,
+                                       elapsed, pmc, w['k_bytes'], executed=c5)
+                out.update({'roofline': roof, 'mfma_frac': (roof.get('mfma') or {}).get('frac'),
+                            'hbm_frac': (roof.get('hbm_scheduled') or roof.get('hbm_algorithmic') or {}).get('frac')})
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

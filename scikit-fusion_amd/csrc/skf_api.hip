@@ -126,9 +126,19 @@ static TileCfg pick_tile(bool is_f64, int engine, int M, int N, int K = 0, bool 
     return big ? Tiles<float>::big() : Tiles<float>::small();
 }
 
+// tiles of a symmetric M x M product that touch the lower triangle (GemmArgs::sym)
+static int sym_tiles(const TileCfg& t, int M) {
+    int n = 0;
+    for (int by = 0; by * t.bm < M; ++by) {
+        const int cnt = (by * t.bm + t.bm - 1) / t.bn + 1, all = cdiv(M, t.bn);
+        n += cnt < all ? cnt : all;
+    }
+    return n;
+}
+
 // number of K slices: fill the chip (>= ~512 workgroups) when the output has few tiles
-static int pick_splits(const TileCfg& t, int M, int N, int K) {
-    const int64_t tiles = (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn);
+static int pick_splits(const TileCfg& t, int M, int N, int K, bool sym = false) {
+    const int64_t tiles = sym ? sym_tiles(t, M) : (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn);
     if (tiles >= 256) return 1;
     const int ktiles = cdiv(K, t.bk);
     int s = (int)(512 / tiles);
@@ -193,6 +203,7 @@ static TileCfg gemm_tile(GemmTypes ty, int engine, const GemmArgs& g, bool deep_
 template <typename T, typename TA, typename TB>
 static void launch_gemm_t(int engine, const TileCfg& t, GemmArgs g, int splits, bool relation, hipStream_t st) {
     dim3 grid(cdiv(g.N, t.bn), cdiv(g.M, t.bm), splits);
+    if (g.sym) grid = dim3((unsigned)sym_tiles(t, g.M), 1, splits);      // (GemmArgs::sym: the tiles on / below the diagonal)
     dim3 block(GEMM_THREADS);
     constexpr int WRB = BigWave<T>::WR, WCB = BigWave<T>::WC;
     const bool big = (t.bm == Tiles<T>::big().bm && t.bn == Tiles<T>::big().bn);
@@ -248,7 +259,8 @@ static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void
     const bool is_f64 = (ty.c == SKF_F64);
     const bool all_f64 = (ty.c == SKF_F64 && ty.a == SKF_F64 && ty.b == SKF_F64);
     const TileCfg t = gemm_tile(ty, engine, g, all_f64 && want_splits <= 1, relation);
-    int splits = want_splits > 0 ? want_splits : pick_splits(t, g.M, g.N, g.K);
+    const bool sym_ok = g.sym && g.M == g.N && engine == SKF_ENGINE_MFMA && t.bn > t.bm && g.epi == EPI_STORE;
+    int splits = want_splits > 0 ? want_splits : pick_splits(t, g.M, g.N, g.K, sym_ok);
     if (g.epi == EPI_SQDIFF) splits = 1;
     const size_t per = (size_t)g.M * g.N;
     const size_t part_elems = part_bytes / (is_f64 ? 8 : 4);
@@ -263,7 +275,7 @@ static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void
     g.part = part;
     // a symmetric product (the caller says so: Gram = G^T G) computes the tiles on and below the diagonal only; the reduce of
     // the K slices mirrors the rest (GemmArgs::sym).  Unsplit launches write C themselves and compute every tile.
-    g.sym = (g.sym && splits > 1 && g.M == g.N && engine == SKF_ENGINE_MFMA && t.bn > t.bm) ? (t.bm | (t.bn << 16)) : 0;
+    g.sym = (sym_ok && splits > 1) ? (t.bm | (t.bn << 16)) : 0;
     if (ty.c == SKF_F64 && ty.a == SKF_F64 && ty.b == SKF_F64)
         launch_gemm_t<double, double, double>(engine, t, g, splits, relation, st);
     else if (ty.c == SKF_F32 && ty.a == SKF_F32 && ty.b == SKF_F32)
@@ -285,7 +297,10 @@ static inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
 // picked (5 / 3 / 3 / 3 slices for P12 / Q12 / P23 / Q23); a product with a handful of output tiles (config 5,
 // genre x movie: ONE 256 x 256 tile over K = 40000, 0.96 ms in one workgroup before) is cut into up to 64 slices.
 static int pick_splits_bf16(int64_t units, int ktiles, int bm, int64_t out_elems) {
-    const double slots = 256.0 * (bm >= 256 ? 1.0 : 2.0);     // resident workgroups on 256 CUs
+    // resident workgroups on 256 CUs (SKF_BF16_SLOTS=n, A/B: price the launch on n CUs, i.e. pick slices that leave
+    // 256 - n CUs to the second stream's small launches -- plans with owned rows, whose critical path that stream is)
+    static const double cus = [] { const char* v = getenv("SKF_BF16_SLOTS"); const int n = v ? atoi(v) : 0; return (n >= 64 && n <= 256) ? (double)n : 256.0; }();
+    const double slots = cus * (bm >= 256 ? 1.0 : 2.0);
     const double per_slice_us = (double)out_elems * 8.0 / 3.0e6;
     int best = 1;
     double best_t = 1e300;
@@ -451,8 +466,6 @@ struct Switches {
     int gram_sym = 1;              // SKF_GRAM_SYM=0        split-K Gram products compute every tile (default: the tiles on / below the diagonal, mirrored by the reduce)
     bool early_update = true;      // SKF_EARLY_UPDATE=0    pipeline: every type is updated at the end of the iteration (default: a type whose last relation is through
                                    //                       and that nothing reads any more is updated on the second stream, underneath the remaining contractions)
-    std::string main_cu_drop;      // SKF_MAIN_CU_DROP=a-b,c,...  bits cleared in the CU mask of the stream that carries the contractions (an internal stream
-                                   //                       with that mask replaces the caller's for the iteration: CUs kept free for the second stream's small launches)
     static Switches read() {
         auto on = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
         Switches w;
@@ -472,7 +485,6 @@ struct Switches {
         { const char* s4 = getenv("SKF_SMALL_SWEEP4"); w.small_sweep1 = s4 && atoi(s4) == 0; }
         { const char* gs = getenv("SKF_GRAM_SYM"); w.gram_sym = (gs && atoi(gs) == 0) ? 0 : 1; }
         { const char* eu = getenv("SKF_EARLY_UPDATE"); w.early_update = !(eu && atoi(eu) == 0); }
-        { const char* cd = getenv("SKF_MAIN_CU_DROP"); if (cd) w.main_cu_drop = cd; }
         const char* st = getenv("SKF_SIDE_TILE");
         w.side_tile = st ? atoi(st) : 0;
         const char* ap = getenv("SKF_AUX_PRIO");
@@ -610,10 +622,6 @@ struct skf_plan {
     // second stream: Gram + pseudo-inverse run concurrently with the relation contractions
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // SKF_MAIN_CU_DROP: an internal stream with a CU mask that carries the iteration instead of the caller's stream (the
-    // caller's stream waits for it at the end of every skf_iterate / skf_iterate_dist call)
-    hipStream_t mainq = nullptr;
-    hipEvent_t ev_mq_in = nullptr, ev_mq_out = nullptr;
     skf::Slot part_aux;
     size_t part_aux_bytes = 0;
     skf::Slot sp_part;                     // partial outputs of the parted list passes over sparse 0/1 relations
@@ -662,9 +670,6 @@ struct skf_plan {
         for (hipEvent_t e : ev_own) (void)hipEventDestroy(e);
         if (cs) (void)hipStreamDestroy(cs);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (mainq) (void)hipStreamDestroy(mainq);
-        if (ev_mq_in) (void)hipEventDestroy(ev_mq_in);
-        if (ev_mq_out) (void)hipEventDestroy(ev_mq_out);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (aux) (void)hipStreamDestroy(aux);
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -2903,30 +2908,6 @@ static void build_known_lists(skf_plan* p, RelState& r, hipStream_t st) {
 
 using namespace skf;
 
-// the stream an iteration is issued on: the caller's, or -- SKF_MAIN_CU_DROP -- the plan's masked stream, forked from the
-// caller's stream here and joined back by join()
-struct MaskedMain {
-    skf_plan* p;
-    hipStream_t caller;
-    bool on;
-    MaskedMain(skf_plan* plan, hipStream_t st) : p(plan), caller(st), on(plan->mainq != nullptr && !plan->small_fused) {
-        if (on) {
-            SKF_HIP(hipEventRecord(p->ev_mq_in, caller));
-            SKF_HIP(hipStreamWaitEvent(p->mainq, p->ev_mq_in, 0));
-        }
-    }
-    hipStream_t stream() const { return on ? p->mainq : caller; }
-    void join() {
-        if (!on) return;
-        SKF_HIP(hipEventRecord(p->ev_mq_out, p->mainq));
-        SKF_HIP(hipStreamWaitEvent(caller, p->ev_mq_out, 0));
-    }
-};
-
-
-// ------------------------------------------------------------------------------------------
-// C ABI
-// ------------------------------------------------------------------------------------------
 extern "C" {
 
 const char* skf_last_error(void) { return g_err.c_str(); }
@@ -3808,35 +3789,6 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
                 p->overlap = true;
             }
         }
-        if (p->variant != SKF_TRANSFORM && p->overlap && !p->mainq && !p->sw.main_cu_drop.empty()) {
-            // the contractions' stream with some CUs masked out: a contraction workgroup owns its CU outright, and a launch
-            // of >= 256 of them leaves the second stream's small launches (c x c chains, pseudo-inverses) waiting for a free
-            // CU until the first wave of the contraction retires -- CUs the main stream cannot use are always free for them
-            hipDeviceProp_t prop;
-            int dev = 0;
-            SKF_HIP(hipGetDevice(&dev));
-            SKF_HIP(hipGetDeviceProperties(&prop, dev));
-            const int ncu = prop.multiProcessorCount;
-            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0xffffffffu);
-            if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1u;
-            int dropped = 0;
-            const char* c = p->sw.main_cu_drop.c_str();
-            while (*c) {                                   // "a-b,c,d-e"
-                char* end = nullptr;
-                long a = strtol(c, &end, 10), b = a;
-                if (end == c) break;
-                c = end;
-                if (*c == '-') { b = strtol(c + 1, &end, 10); c = end; }
-                for (long k = a; k <= b && k < ncu; ++k)
-                    if (k >= 0 && (mask[(size_t)k / 32] >> (k % 32)) & 1u) { mask[(size_t)k / 32] &= ~(1u << (k % 32)); ++dropped; }
-                if (*c == ',') ++c;
-            }
-            if (dropped > 0 && dropped < ncu) {
-                SKF_HIP(hipExtStreamCreateWithCUMask(&p->mainq, (uint32_t)mask.size(), mask.data()));
-                SKF_HIP(hipEventCreateWithFlags(&p->ev_mq_in, hipEventDisableTiming));
-                SKF_HIP(hipEventCreateWithFlags(&p->ev_mq_out, hipEventDisableTiming));
-            }
-        }
         if (p->graph_exec) {
             (void)hipGraphExecDestroy(p->graph_exec);
             p->graph_exec = nullptr;
@@ -3930,8 +3882,6 @@ int skf_iterate(skf_plan* p, int32_t n_iters, void* stream) {
             for (int it = 0; it < n_iters; ++it) iterate_transform(p, st);
         } else {
             int it = 0;
-            MaskedMain mq(p, st);                  // (SKF_MAIN_CU_DROP: the iteration runs on the plan's masked stream)
-            st = mq.stream();
             // The iteration is ~50-80 launches; for small graphs (launch-latency regime) the
             // remaining iterations replay ONE captured hipGraph.  Capture needs a real stream
             // (not the legacy default stream) and is skipped while profiling events are recorded.
@@ -3945,7 +3895,6 @@ int skf_iterate(skf_plan* p, int32_t n_iters, void* stream) {
                     for (; it < n_iters; ++it) SKF_HIP(hipGraphLaunch(p->graph_exec, st));
             }
             for (; it < n_iters; ++it) iterate_fit(p, st);
-            mq.join();
         }
     });
 }
@@ -4233,10 +4182,8 @@ int skf_iterate_dist(skf_plan* p, int32_t n_iters, void* stream) {
             if (p->comm->world != p->part_count || p->comm->rank != p->part_index)
                 SKF_FAIL(SKF_E_STATE, "the communicator is rank %d of %d, the plan part %d of %d", p->comm->rank, p->comm->world,
                          p->part_index, p->part_count);
-            MaskedMain mq(p, as_stream(stream));
-            for (int it = 0; it < n_iters; ++it) iterate_owned(p, mq.stream());
-            finalize_owned(p, mq.stream());
-            mq.join();
+            for (int it = 0; it < n_iters; ++it) iterate_owned(p, as_stream(stream));
+            finalize_owned(p, as_stream(stream));
             return;
         }
         for (int it = 0; it < n_iters; ++it) iterate_dist(p, as_stream(stream));
@@ -4405,6 +4352,12 @@ int skf_gemm(int32_t dtype, int32_t engine, const skf_gemm_desc* d, void* worksp
         g.mask = d->mask; g.ldmask = d->ldmask;
         g.aop = d->aop;
         GemmTypes ty{dtype, d->a_dtype < 0 ? dtype : d->a_dtype, d->b_dtype < 0 ? dtype : d->b_dtype};
+        // X^T X (one operand read both ways, plain store): a symmetric product -- the split-K form computes the tiles on / below
+        // the diagonal only (GemmArgs::sym; bit for bit the full product)
+        static const int sym_on = [] { const char* v = getenv("SKF_GRAM_SYM"); return (v && atoi(v) == 0) ? 0 : 1; }();
+        if (sym_on && d->A == d->B && d->M == d->N && d->sa_m == d->sb_n && d->sa_k == d->sb_k && d->epi == EPI_STORE &&
+            d->aop == AOP_NONE && ty.a == ty.b)
+            g.sym = 1;
         run_gemm(ty, engine, g, d->splits, workspace, workspace_bytes, as_stream(stream));
     });
 }

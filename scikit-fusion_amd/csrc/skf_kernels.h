@@ -57,10 +57,11 @@ struct GemmArgs {
     int aop, epi, nan_to_num;
     int c_bf16;              // EPI_SQDIFF: the matrix behind C is stored as bf16
     int mask_bits;           // EPI_MASKED_STORE: the mask is packed (the engine's own masks always are)
-    int sym;                 // split-K launches of a SYMMETRIC product (Gram = G^T G): bm | bn << 16 of the launch's tile --
-                             // workgroups whose tile lies strictly above the diagonal return at once and the reduce takes such an
-                             // element from its mirror image (element (a, b) and (b, a) are the same products added in the
-                             // same order: bit for bit the full product, 6 of 8 tiles at order 256); 0 = off
+    int sym;                 // split-K launches of a SYMMETRIC product (Gram = G^T G): bm | bn << 16 of the launch's tile -- the
+                             // grid lists only the tiles on / below the diagonal (gridDim.x = their number, gridDim.y = 1) and
+                             // the reduce takes an element of a tile that was not computed from its mirror image (element
+                             // (a, b) and (b, a) are the same products added in the same order: bit for bit the full
+                             // product, 6 of 8 tiles at order 256); 0 = off
 };
 
 // the partial-sum element the reduce of a split-K launch reads for output element e = (m, n) (see GemmArgs::sym)
@@ -340,8 +341,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * (WR * MF::MT), wn0 = (wave & 1) * (WC * MF::NT);
-    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
-    if (g.sym && bn0 >= bm0 + BM) return;          // symmetric product: this tile is the mirror image of one that is computed
+    int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    if (g.sym) {
+        // symmetric product: the launch lists only the tiles on / below the diagonal, blockIdx.x = their running number
+        // row tile by row tile (a launch of ALL tiles whose upper ones return at once leaves whole XCDs idle: workgroups go
+        // to the XCDs round robin, and with 2 x 4 tiles the skipped ones are always the same residues mod 8)
+        int left = (int)blockIdx.x, by = 0;
+        for (;; ++by) {
+            int cnt = (by * BM + BM - 1) / BN + 1;                // column tiles of row tile `by` that touch the lower triangle
+            const int all = (g.N + BN - 1) / BN;
+            cnt = cnt < all ? cnt : all;
+            if (left < cnt) break;
+            left -= cnt;
+        }
+        bm0 = by * BM;
+        bn0 = left * BN;
+    }
     const int kz0 = blockIdx.z * g.k_chunk;
     const int kz1 = (kz0 + g.k_chunk < g.K) ? kz0 + g.k_chunk : g.K;
     const TA* __restrict__ A = (const TA*)g.A;

@@ -75,9 +75,6 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = null
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-struct hipDeviceProp_t { int multiProcessorCount; };
-inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; return hipSuccess; }
-inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { *s = nullptr; return hipSuccess; }
 typedef void* hipGraph_t;
 typedef void* hipGraphExec_t;
 typedef void* hipGraphNode_t;

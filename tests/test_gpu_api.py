@@ -68,7 +68,8 @@ def test_early_stopping_through_the_classes_single_device_and_sharded(monkeypatc
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('dtype,tol', [('f64', 1e-12), ('f32', 2e-6), ('bf16', 2e-6)])
+# measured (MI355X): f64 1.4e-16 (rounding level: the bound is a floor of ~10 ulp), f32 / bf16 (f32 masters) 6.0e-8
+@pytest.mark.parametrize('dtype,tol', [('f64', 2e-15), ('f32', 6e-7), ('bf16', 6e-7)])
 def test_chained_profiles_match_the_reference_examples(dtype, tol):
     """chained latent profiles on the device -- backbone products in f64, blocks through
     the matrix-core GEMM of the engine's master type -- against the golden of the reference's fit / fold-in with the
