@@ -206,6 +206,9 @@ def measured_traffic(dtype, c5, scale):
         return None
 
 
+PMC_ERRORS = []          # why an in-run counter pass did not deliver (surfaced in the record: `pmc_errors`)
+
+
 def pmc_traffic_in_run(dtype, workload='c3', steps=2, timeout=420):
     """HBM bytes per contraction launch measured IN THIS RUN: two children of this very script under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes;
@@ -227,7 +230,7 @@ def pmc_traffic_in_run(dtype, workload='c3', steps=2, timeout=420):
         out = tempfile.mkdtemp(prefix='skf_pmc_')
         cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '-d', out, '-o', 'pmc', '--', sys.executable,
                os.path.abspath(__file__), '--steps', str(steps), '--warmup', '1', '--workload', workload, '--dtype', dtype,
-               '--no-cpu-baseline', '--no-engines', '--no-workloads', '--no-pmc']
+               '--no-cpu-baseline', '--no-engines', '--no-workloads', '--no-pmc', '--sustained-steps', '0']
         try:
             subprocess.run(cmd, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()),
                            capture_output=True, text=True, timeout=timeout, check=True)
@@ -245,9 +248,12 @@ def pmc_traffic_in_run(dtype, workload='c3', steps=2, timeout=420):
                         tot += float(val)
                         n += cnt
             if n <= 0:
+                PMC_ERRORS.append('%s %s: no matching launches in the counter database' % (workload, counter))
                 return None
             sums[counter], calls[counter] = tot * 1024.0 * (2.0 if counter == 'FETCH_SIZE' else 1.0), n
-        except Exception:
+        except Exception as exc:
+            tail = (getattr(exc, 'stderr', None) or '')[-300:] if hasattr(exc, 'stderr') else ''
+            PMC_ERRORS.append('%s %s: %s %s' % (workload, counter, str(exc)[:200], tail))
             return None
         finally:
             shutil.rmtree(out, ignore_errors=True)
@@ -313,7 +319,7 @@ def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, ela
     if executed:
         rec['traffic'] = pmc['bytes'] if pmc else None
         if pmc:
-            rec['traffic_kind'] = 'PMC, committed pass: ' + pmc['source']
+            rec['traffic_kind'] = ('PMC, ' if pmc.get('in_run') else 'PMC, committed pass: ') + pmc['source']
             rec['executed_bytes_per_launch'] = nbytes / k_launches
         return rec
     sched_gbs = sched_iter * iters / sec / 1e9
@@ -1232,6 +1238,8 @@ def main():
                                        elapsed, pmc, w['k_bytes'], executed=c5)
                 out.update({'roofline': roof, 'mfma_frac': (roof.get('mfma') or {}).get('frac'),
                             'hbm_frac': (roof.get('hbm_scheduled') or roof.get('hbm_algorithmic') or {}).get('frac')})
+        if PMC_ERRORS:
+            out['pmc_errors'] = PMC_ERRORS[:4]
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -3771,7 +3771,9 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
                 SKF_HIP(hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking));
         }
         p->pipeline = !p->sw.no_pipeline;
-        if (p->variant != SKF_TRANSFORM && !p->aux) {
+        // (a plan on the three-launch schedule of small graphs issues everything on the caller's stream: no second stream to
+        // create and destroy -- at ten restarts of the README graph the streams of the plans were 4 of 30 ms)
+        if (p->variant != SKF_TRANSFORM && !p->aux && !p->small_fused) {
             if (!p->sw.no_overlap) {
                 {   // the second stream at the LOWEST priority: its launches fill what the contractions of the main stream
                     // leave free instead of taking CUs from them (config 5 +0.9 %, config 3 +0.5 %; SKF_AUX_PRIO=default|high: A/B)

@@ -62,7 +62,8 @@ def initial_factors(R, object_types, rank, init_type, random_state, n_run):
     n_obj = count_objects(object_types, R)
     # ('random' never reads the relations: they may live on the device already, `device_fill`)
     R_first = {} if init_type == 'random' else {k: np.asarray(v[0], dtype=float) for k, v in R.items()}
-    return [initialize(object_types, n_obj, rank, R_first, init_type, random_state)
+    pools = {}                                   # column rankings of `random_c`, shared by the restarts (R_first stays alive here)
+    return [initialize(object_types, n_obj, rank, R_first, init_type, random_state, pools)
             for _ in range(n_run)]
 
 

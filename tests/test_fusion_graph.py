@@ -139,3 +139,23 @@ def test_graph_to_seam_matrices():
     assert list(Theta.keys()) == [(a, a)] and Theta[a, a][0] is not None
     R2, T2 = graph_matrices(g)
     assert set(R2) == set(R) and set(T2) == set(Theta)
+
+
+def test_restarts_share_the_column_rankings_of_random_c_without_changing_the_stream():
+    """`initial_factors` keeps the column rankings of `random_c` (they draw nothing from the random stream) across the restarts
+    of one fit: the factors of every restart are those of n_run separate `initialize` calls on one RandomState (reference
+    dfmf.py:87-95 with n_jobs = 1: one stream, consumed restart after restart), also for a square relation and its transpose."""
+    from skfusion_amd.fusion.decomposition.dfmf import initial_factors
+    from skfusion_amd.fusion.decomposition._init import initialize
+    rs = np.random.RandomState(3)
+    a, b, c = ObjectType('a', 3), ObjectType('b', 4), ObjectType('c', 2)
+    R = {(a, b): [rs.rand(12, 12)], (b, a): [rs.rand(12, 12)], (a, c): [rs.rand(12, 9)]}
+    rank = {a: 3, b: 4, c: 2}
+    got = initial_factors(R, [a, b, c], rank, 'random_c', np.random.RandomState(11), 4)
+    state = np.random.RandomState(11)
+    first = {k: np.asarray(v[0], dtype=float) for k, v in R.items()}
+    n_obj = {a: 12, b: 12, c: 9}
+    for run in range(4):
+        want = initialize([a, b, c], n_obj, rank, first, 'random_c', state)
+        for t in (a, b, c):
+            np.testing.assert_array_equal(got[run][t, t], want[t, t])
