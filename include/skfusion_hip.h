@@ -406,8 +406,9 @@ int skf_launch_count(int64_t* launches);
 const char* skf_last_error(void);
 const char* skf_version(void);
 /* Layout version of the structs and signatures above (SKF_ABI_VERSION).  A binding built against another version must not
- * call the library: descriptors grew between versions (skf_relation_desc.known_bound: 3, skf_options.flags: 4). */
-#define SKF_ABI_VERSION 4
+ * call the library: descriptors grew between versions (skf_relation_desc.known_bound: 3, skf_options.flags: 4; version 5
+ * adds entry points only -- skf_small_graph_limits, skf_comm_info, skf_launch_count -- the structs are those of version 4). */
+#define SKF_ABI_VERSION 5
 int skf_abi_version(void);
 
 #ifdef __cplusplus

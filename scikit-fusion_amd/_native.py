@@ -70,7 +70,7 @@ class Options(C.Structure):
 
 
 SKF_OPT_OWNED_ROWS = 1
-SKF_ABI_VERSION = 4          # include/skfusion_hip.h: the struct layouts above belong to this version
+SKF_ABI_VERSION = 5          # include/skfusion_hip.h: the struct layouts above belong to this version
 
 
 class GemmDesc(C.Structure):

@@ -76,3 +76,27 @@ def test_product_runtime_fails_loudly_without_gpu():
     nat._runtime = None
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         nat.get_runtime()
+
+
+def test_round5_entry_points_without_a_device(lib):
+    """ABI version 5 adds entry points only: the limits of the small-graph schedule (what the host's `shared_launches` rule
+    reads instead of its own copy of the constants), what a communicator is, and the launch counter."""
+    assert lib.skf_abi_version() == nat.SKF_ABI_VERSION == 5
+    mr, mo, mt, ml, mc, dv = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.skf_small_graph_limits(C.byref(mr), C.byref(mo), C.byref(mt), C.byref(ml), C.byref(mc), C.byref(dv)) == 0
+    assert (mr.value, mo.value, dv.value) == (64, 8192, 16) and mt.value >= 3 and ml.value >= 3 and mc.value >= 1
+    assert lib.skf_small_graph_limits(None, None, None, None, None, None) == 0            # null pointers are skipped
+    comm = nat._P()
+    assert lib.skf_comm_create(None, 0, 1, C.byref(comm)) == 0                            # one rank: no transport needed
+    r, w, k, n = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.skf_comm_info(comm, C.byref(r), C.byref(w), C.byref(k), C.byref(n)) == 0
+    assert (r.value, w.value, k.value, n.value) == (0, 1, nat.SKF_COMM_SINGLE, 1)
+    assert lib.skf_comm_destroy(comm) == 0
+    assert lib.skf_comm_create_null(3, 8, C.byref(comm)) == 0
+    assert lib.skf_comm_info(comm, C.byref(r), C.byref(w), C.byref(k), C.byref(n)) == 0
+    assert (r.value, w.value, k.value, n.value) == (3, 8, nat.SKF_COMM_NULL, 0)
+    assert lib.skf_comm_destroy(comm) == 0
+    assert lib.skf_comm_create(None, 0, 2, C.byref(comm)) == -1                           # two ranks need the unique id
+    assert lib.skf_comm_info(None, None, None, None, None) == -1
+    count = C.c_int64(-1)
+    assert lib.skf_launch_count(C.byref(count)) == 0 and count.value >= 0

@@ -93,3 +93,42 @@ def test_sharded_fits_of_a_single_process_are_the_plain_fit(monkeypatch):
     """shard='owned' / 'rows' / 'relations' without a process group and without SKF_FORCE_COLLECTIVES: the plain fit, not G0."""
     monkeypatch.delenv('SKF_FORCE_COLLECTIVES', raising=False)
     assert A.sharded_fits_of_a_single_process_are_the_plain_fit('f64', 1e-11, max_iter=3) == 6
+
+
+def test_host_rule_for_shared_launches_is_the_librarys_verdict_on_boundary_graphs():
+    """`shared_launches` decides on the host whether restarts will share launches; its limits now come from the
+    library (skf_small_graph_limits).  On graphs that sit on either side of every limit -- rank 64 / 65, 8192 / 8193 objects,
+    a constraint with n^2/16 and n^2/16 + 1 non-zeros, an all-zero constraint -- the host verdict equals skf_plan_batchable
+    of the bound plan."""
+    import numpy as np
+    from skfusion_amd.fusion import Relation, ObjectType, FusionGraph
+    from skfusion_amd.fusion.decomposition.dfmf import shared_launches, graph_matrices
+    from skfusion_amd._engine import DevicePlan, flatten_relations, flatten_thetas, count_objects
+
+    def verdicts(rank_a, n_b, theta_nnz):
+        rs = np.random.RandomState(0)
+        a, b = ObjectType('a', rank_a), ObjectType('b', 3)
+        n_a = 32
+        rels = [Relation(rs.rand(n_a, n_b), a, b)]
+        if theta_nnz is not None:
+            th = np.zeros((n_a, n_a))
+            th.flat[:theta_nnz] = -0.1
+            rels.append(Relation(th, a, a))
+        graph = FusionGraph(rels)
+        fuser = Dfmf(n_run=3, max_iter=1, init_type='random', random_state=0)
+        fuser.fusion_graph = graph
+        R, Theta = graph_matrices(graph)
+        types = list(graph.object_types)
+        plan = DevicePlan(types, count_objects(types, R), {t: int(t.rank) for t in types}, flatten_relations(R, None),
+                          flatten_thetas(Theta), nat.SKF_DFMF, dtype='f64')
+        try:
+            return shared_launches(fuser), plan.batchable()
+        finally:
+            plan.close()
+    cases = [(64, 40, None), (65, 40, None), (8, 8192, None), (8, 8193, None), (8, 40, 64), (8, 40, 65), (8, 40, 0), (8, 40, 1)]
+    seen = set()
+    for case in cases:
+        host, lib = verdicts(*case)
+        assert host == lib, (case, host, lib)
+        seen.add(host)
+    assert seen == {True, False}
