@@ -272,7 +272,10 @@ __device__ __forceinline__ void stage_load(TS (&reg)[ROWS * BK / GEMM_THREADS], 
     }
 }
 
-template <typename T, typename TS, int ROWS, int BK, int LD>
+// FULL: the K tile lies inside [k_lo, k_end) as a whole -- no zero fill of a K tail (the test per element costs a compare
+// and a select each, and with a run-time `aop` beside it the compiler left a chain of scalar branches PER ELEMENT in the
+// store phase of the f32 contraction: callers pass the literal AOP_NONE on the hot path).
+template <typename T, typename TS, int ROWS, int BK, int LD, bool FULL = false>
 __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS * BK / GEMM_THREADS],
                                             bool k_fast, int k0, int k_end, int aop, int tid,
                                             int mode = STAGE_SCALAR) {
@@ -288,7 +291,7 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS *
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 T v = apply_aop((T)reg[i * V + j], aop);
-                lds[k + j][r] = (k0 + k + j < k_end) ? v : (T)0;
+                lds[k + j][r] = (FULL || k0 + k + j < k_end) ? v : (T)0;
             }
         }
     } else if (mode == STAGE_VEC_R) {
@@ -300,7 +303,7 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS *
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 T v = apply_aop((T)reg[i * V + j], aop);
-                lds[k][r + j] = (k0 + k < k_end) ? v : (T)0;
+                lds[k][r + j] = (FULL || k0 + k < k_end) ? v : (T)0;
             }
         }
     } else {
@@ -310,7 +313,7 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS *
             const int k = k_fast ? (e % BK) : (e / ROWS);
             const int r = k_fast ? (e / BK) : (e % ROWS);
             T v = apply_aop((T)reg[i], aop);
-            lds[k][r] = (k0 + k < k_end) ? v : (T)0;
+            lds[k][r] = (FULL || k0 + k < k_end) ? v : (T)0;
         }
     }
 }
@@ -334,9 +337,22 @@ template <typename T, typename TA, typename TB, int WR, int WC, int BK, int TAG,
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) {
     typedef Mfma<T> MF;
     constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
-    constexpr int LDA = BM + 1, LDB = BN + 1;
-    __shared__ T As[BK][LDA];
-    __shared__ T Bs[BK][LDB];
+    // Row pitch of the k-major LDS tiles.  The fragment reads (consecutive lanes, consecutive words) are conflict-free at any
+    // pitch; what matters is how the operand is WRITTEN.  A K-contiguous operand is stored transposed, one word per store and
+    // four stores a pitch apart: ds_write_b32 serves lanes 0-31 / 32-63 in one cycle each on 32 banks, and at a pitch of
+    // BM + 1 words the 8 k-columns x 4 rows of a lane group land on 32 different banks.  A row-contiguous operand is stored
+    // as four consecutive words per lane: as four ds_write_b32 they hit every bank four times (lanes l and l + 8 of a group
+    // are 32 words apart -- PMC, round 5: a third of the LDS cycles of the f32 contraction were bank conflicts); at a pitch
+    // of BM + 4 every row starts 16-byte aligned and the four words go out as ONE ds_write_b128 (conflicts: 9.4e8 -> 3e7
+    // cycles per launch).  f64 tiles keep their pitch (their products sit at the f64 matrix-core rate either way).
+    constexpr int MA = FM >= 0 ? (FM & 3) : -1, MB = FM >= 0 ? ((FM >> 2) & 3) : -1;
+    constexpr int PADA = (sizeof(T) == 4 && MA == STAGE_VEC_R) ? 4 : 1;
+    constexpr int PADB = (sizeof(T) == 4 && MB == STAGE_VEC_R) ? 4 : 1;
+    constexpr int LDA = BM + PADA, LDB = BN + PADB;
+    // (Round 5, measured and not kept: two LDS images of the tiles with one barrier per K step and the fragments of the next
+    // step read ahead of the products -- f32 P12 88 instead of 92 TFLOP/s, f64 engine 5.73 instead of 5.91 it/s.)
+    __shared__ __attribute__((aligned(16))) T As[BK][LDA];
+    __shared__ __attribute__((aligned(16))) T Bs[BK][LDB];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -376,11 +392,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
     const int nkt = (kz1 - kz0 + BK - 1) / BK;
     const int ma = FM >= 0 ? (FM & 3) : stage_mode<TA>(A, g.sa_m, g.sa_k, g.M, kz0, kz1);
     const int mb = FM >= 0 ? ((FM >> 2) & 3) : stage_mode<TB>(B, g.sb_n, g.sb_k, g.N, kz0, kz1);
+    // registers -> LDS of the tile that starts at k0.  The common case -- a whole K tile, no operand op -- is its own
+    // instantiation with compile-time constants (uniform branches, taken once per tile, not once per element).
+    auto store_tiles = [&](int k0) {
+        if (k0 + BK <= kz1 && g.aop == AOP_NONE) {
+            stage_store<T, TA, BM, BK, LDA, true>(As, ra, a_kfast, k0, kz1, AOP_NONE, tid, ma);
+            stage_store<T, TB, BN, BK, LDB, true>(Bs, rb, b_kfast, k0, kz1, AOP_NONE, tid, mb);
+        } else {
+            stage_store<T, TA, BM, BK, LDA>(As, ra, a_kfast, k0, kz1, g.aop, tid, ma);
+            stage_store<T, TB, BN, BK, LDB>(Bs, rb, b_kfast, k0, kz1, AOP_NONE, tid, mb);
+        }
+    };
     if (nkt > 0) {
         stage_load<TA, BM, BK>(ra, A, g.sa_m, g.sa_k, bm0, kz0, g.M, kz1, tid, ma);
         stage_load<TB, BN, BK>(rb, B, g.sb_n, g.sb_k, bn0, kz0, g.N, kz1, tid, mb);
-        stage_store<T, TA, BM, BK, LDA>(As, ra, a_kfast, kz0, kz1, g.aop, tid, ma);
-        stage_store<T, TB, BN, BK, LDB>(Bs, rb, b_kfast, kz0, kz1, AOP_NONE, tid, mb);
+        store_tiles(kz0);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
@@ -405,8 +431,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
         }
         __syncthreads();
         if (more) {
-            stage_store<T, TA, BM, BK, LDA>(As, ra, a_kfast, k_next, kz1, g.aop, tid, ma);
-            stage_store<T, TB, BN, BK, LDB>(Bs, rb, b_kfast, k_next, kz1, AOP_NONE, tid, mb);
+            store_tiles(k_next);
         }
         __syncthreads();
     }
@@ -504,10 +529,12 @@ template <typename T, typename TB, int WR, int WC, int BK, int FM = -1>
 __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_update_kernel(SideArgs a) {
     typedef Mfma<T> MF;
     constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
-    constexpr int LDA = BM + 1, LDB = BN + 1;
-    __shared__ T As[BK][LDA];
-    __shared__ T Bs[BK][LDB];
-    __shared__ T Bs2[BK][LDB];
+    // (pitch of the B images: the c x c operands Bn / Bp are row-contiguous -- one ds_write_b128 per lane at a 16-byte aligned
+    // pitch instead of four 4-way conflicting ds_write_b32, see gemm_mfma_kernel; f32 tiles with compile-time modes only)
+    constexpr int LDA = BM + 1, LDB = BN + ((sizeof(T) == 4 && FM >= 0 && ((FM >> 6) & 3) == STAGE_VEC_R) ? 4 : 1);
+    __shared__ __attribute__((aligned(16))) T As[BK][LDA];
+    __shared__ __attribute__((aligned(16))) T Bs[BK][LDB];
+    __shared__ __attribute__((aligned(16))) T Bs2[BK][LDB];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -542,8 +569,13 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
         }
         for (int k0 = 0; k0 < a.k1; k0 += BK) {
             __syncthreads();
-            stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.k1, AOP_NONE, tid, mx);
-            stage_store<T, TB, BN, BK, LDB>(Bs, rb, s_kfast, k0, a.k1, AOP_NONE, tid, ms);
+            if (k0 + BK <= a.k1) {             // (a whole K tile: no tail masks -- uniform)
+                stage_store<T, T, BM, BK, LDA, true>(As, ra, true, k0, a.k1, AOP_NONE, tid, mx);
+                stage_store<T, TB, BN, BK, LDB, true>(Bs, rb, s_kfast, k0, a.k1, AOP_NONE, tid, ms);
+            } else {
+                stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.k1, AOP_NONE, tid, mx);
+                stage_store<T, TB, BN, BK, LDB>(Bs, rb, s_kfast, k0, a.k1, AOP_NONE, tid, ms);
+            }
             __syncthreads();
             if (k0 + BK < a.k1) {
                 stage_load<T, BM, BK>(ra, X, a.ldx, 1, bm0, k0 + BK, a.n, a.k1, tid, mx);
@@ -599,9 +631,15 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 4 ? 2 : 1)) void side_u
         for (int k0 = 0; k0 < a.c; k0 += BK) {
             __syncthreads();
             SKF_PSTAMP(0)
-            stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.c, AOP_NONE, tid, mg);
-            stage_store<T, TB, BN, BK, LDB>(Bs, rb, a.ldb == 1, k0, a.c, AOP_NONE, tid, mbn);
-            stage_store<T, TB, BN, BK, LDB>(Bs2, rb2, a.ldb == 1, k0, a.c, AOP_NONE, tid, mbp);
+            if (k0 + BK <= a.c) {
+                stage_store<T, T, BM, BK, LDA, true>(As, ra, true, k0, a.c, AOP_NONE, tid, mg);
+                stage_store<T, TB, BN, BK, LDB, true>(Bs, rb, a.ldb == 1, k0, a.c, AOP_NONE, tid, mbn);
+                stage_store<T, TB, BN, BK, LDB, true>(Bs2, rb2, a.ldb == 1, k0, a.c, AOP_NONE, tid, mbp);
+            } else {
+                stage_store<T, T, BM, BK, LDA>(As, ra, true, k0, a.c, AOP_NONE, tid, mg);
+                stage_store<T, TB, BN, BK, LDB>(Bs, rb, a.ldb == 1, k0, a.c, AOP_NONE, tid, mbn);
+                stage_store<T, TB, BN, BK, LDB>(Bs2, rb2, a.ldb == 1, k0, a.c, AOP_NONE, tid, mbp);
+            }
             SKF_PSTAMP(1)
             __syncthreads();
             SKF_PSTAMP(2)

@@ -15,8 +15,19 @@ def main():
     cases = [('sq4096 NN', 4096, 4096, 4096, False), ('sq4096 TN', 4096, 4096, 4096, True),
              ('P12 NN', 50000, 256, 100000, False), ('Q12 TN', 100000, 128, 50000, True),
              ('side NN', 100000, 256, 256, False)]
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--dtypes', default='f32,f64')
+    ap.add_argument('--cases', default='', help='comma-separated first words of the case labels (sq4096, P12, Q12, side); default all')
+    ap.add_argument('--reps', type=int, default=3)
+    args = ap.parse_args()
+    want = [c for c in args.cases.split(',') if c]
     for dt, name in ((nat.SKF_F32, 'f32'), (nat.SKF_F64, 'f64')):
+        if name not in args.dtypes.split(','):
+            continue
         for label, M, N, K, transA in cases:
+            if want and label.split()[0] not in want:
+                continue
             if dt == nat.SKF_F64 and M * K > 3e9:
                 continue
             es = 4 if dt == nat.SKF_F32 else 8
@@ -36,7 +47,7 @@ def main():
             run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 3
+            reps = args.reps
             e0.record(rt.mem._stream)
             for _ in range(reps):
                 run()
