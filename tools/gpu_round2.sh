@@ -28,6 +28,8 @@ case "$step" in
       ( SKF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --scale 0.2 --mode $mode --no-cpu-baseline --no-engines ) > "$OUT/dist_$mode.log" 2>&1
       echo "dist $mode exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/dist_$mode.log" | cut -c1-260 | tee -a "$OUT/summary.txt"
     done
+    # (round 5) the default mode also carries the `strong` sub-record: one fit sharded by ownership over the same two ranks
+    grep '^{' "$OUT/dist_restarts.log" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('dist restarts: strong sub-record', json.dumps(d.get('strong')))" | tee -a "$OUT/summary.txt"
     for mode in rows owned; do
       ( SKF_BENCH_BACKEND=gloo timeout 600 python bench.py --workload c5 --gpus 2 --steps 2 --warmup 1 --scale 0.1 --mode $mode --no-cpu-baseline ) > "$OUT/dist_c5_$mode.log" 2>&1
       echo "dist c5 $mode exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/dist_c5_$mode.log" | cut -c1-260 | tee -a "$OUT/summary.txt"

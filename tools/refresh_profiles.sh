@@ -30,6 +30,6 @@ grep '^{' $G/c5_bf16.log > profiles/${R}_c5_bf16_bench.json
 { echo "# python -m pytest tests -m gpu -q --durations=10 on the MI355X box (final build of the round)"; tail -22 $G/pytest.log; } > profiles/${R}_pytest_gpu.log
 cp gpurun_out/test_deviations.txt profiles/${R}_test_deviations.txt
 { echo "# bench.py --gpus 2 (self-launched through torch.distributed.run) on the one-GPU box, two ranks sharing GPU 0 over a gloo group (SKF_BENCH_BACKEND=gloo): every multi-GPU mode end to end; the throughput of two ranks on one GPU is not a scaling number"
-  grep -h "^dist\|^{" $G/summary.txt | grep -A1 "^dist" | grep -v "^--" | cut -c1-700; } > profiles/${R}_dist_smoke.txt
+  grep -h "^dist\|^{" $G/summary.txt | grep -A1 "^dist" | grep -v "^--" | cut -c1-1500; } > profiles/${R}_dist_smoke.txt
 [ -f $G/foldin_scale.txt ] && grep fold-in $G/foldin_scale.txt > profiles/${R}_foldin_scale.txt
 ls -la profiles/${R}_*
