@@ -971,6 +971,29 @@ def strong_record(dtype, rank, world, dist, backend, steps=10, warmup=3, scale=1
     return out
 
 
+def run_bounded(fn, seconds, device=None):
+    """fn() in a worker thread with a time limit: (result, timed_out).  The `strong` leg of an N > 1 run enters collectives
+    that no single-GPU box can rehearse with more than one real rank; should they hang, the measured restarts line must
+    still be printed -- the caller then prints it and leaves through os._exit, skipping the process-group teardown."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            if device is not None:
+                import torch
+                torch.cuda.set_device(device)          # (the current device is per thread)
+            box['result'] = fn()
+        except Exception as exc:
+            box['result'] = {'error': str(exc)[:300]}
+    th = threading.Thread(target=work, name='bench-strong', daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return {'error': 'timed out after %.0f s (SKF_STRONG_TIMEOUT)' % seconds}, True
+    return box.get('result'), False
+
+
 def compact_roofline(r):
     return {k: r.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 't_min_ms', 't_kernel_ms', 'launches',
                                   'accounting', 'traffic', 'executed_bytes_per_launch', 'traffic_kind') if k in r}
@@ -1203,8 +1226,11 @@ def main():
         out['engines'] = engines
     if default_run and not args.no_workloads:
         out['workloads'] = other_workloads(args.dtype, dicty)
+    hung = False
     if world > 1 and args.mode == 'restarts' and not args.no_strong and not c5 and args.data == 'uniform':
-        strong = strong_record(args.dtype, rank, world, dist, backend, scale=args.scale)      # collective: every rank runs it
+        # collective: every rank runs it; bounded, so that the restarts line above survives a collective that never returns
+        strong, hung = run_bounded(lambda: strong_record(args.dtype, rank, world, dist, backend, scale=args.scale),
+                                   float(os.environ.get('SKF_STRONG_TIMEOUT', '300')), local)
         if rank == 0:
             out['strong'] = strong
     if rank == 0:
@@ -1240,7 +1266,10 @@ def main():
                             'hbm_frac': (roof.get('hbm_scheduled') or roof.get('hbm_algorithmic') or {}).get('frac')})
         if PMC_ERRORS:
             out['pmc_errors'] = PMC_ERRORS[:4]
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if hung:                       # a collective of the strong leg still holds its thread: no teardown that could wait for it
+        sys.stdout.flush()
+        os._exit(0)
     if dist is not None:
         dist.destroy_process_group()
 

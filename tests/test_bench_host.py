@@ -221,3 +221,14 @@ def test_strong_sub_record_of_an_n_gpu_run(monkeypatch):
         leg = rec[key]
         assert leg['value'] == pytest.approx(500.0) and leg['unit'] == 'iters/s' and leg['ms_per_step'] == pytest.approx(2.0)
         assert leg['transport'] == 'rccl' and leg['transport_ranks'] == 4 and leg['exchange_bytes_per_rank_and_iter'] > 1e8
+
+
+def test_bounded_leg_returns_or_times_out():
+    """The `strong` leg of an N > 1 run is bounded in time (a collective that never returns must not cost the restarts line)."""
+    import time
+    res, hung = bench.run_bounded(lambda: {'ok': 1}, 5.0)
+    assert res == {'ok': 1} and not hung
+    res, hung = bench.run_bounded(lambda: time.sleep(5.0), 0.2)
+    assert hung and 'timed out' in res['error']
+    res, hung = bench.run_bounded(lambda: 1 / 0, 5.0)
+    assert not hung and 'division' in res['error']
