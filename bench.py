@@ -24,19 +24,33 @@ The JSON line also carries
                  iteration, and frac = t_min / t_kernel (= achieved / peak of the binding roof).  Beside it: `hbm_algorithmic`
                  (one-read bytes / launch time), `hbm_scheduled` (the engine reads every relation once per contraction,
                  i.e. twice per iteration: a fused P+Q pass would have to spill one output as partial sums), `traffic` =
-                 HBM bytes per launch from committed rocprofv3 --pmc passes (profiles/pmc_traffic.json; null without one),
-                 `traffic_scheduled`, `whole_iteration`.
+                 HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE children of THIS run (`traffic_kind`:
+                 "PMC, this run ..."; the committed pass of profiles/pmc_traffic.json stands in where the box has no
+                 rocprofv3, labelled so; `pmc_errors` says why a pass did not deliver), `traffic_scheduled`, `whole_iteration`.
+  sustained    : a second timed region of 1000 steps on the same plan.
+  parity_full_size : per engine, its first FIVE iterations against the oracle's at FULL size on the same inputs (checkpoints
+                 after iterations 2 and 5: backbones, 64 rows of every factor; relation errors after 5), and `S_gate`: the
+                 backbone deviation over cond(Gram_i) cond(Gram_j) of the engine's own factors against eps(engine).
   engines      : short runs (3 steps) of the f32 and f64 engines on the same graph (the reference computes in f64).
   workloads    : the other single-GPU BASELINE configurations, default run only --
                    c5_dfmc    configs[4]: Dfmc on the MovieLens-style graph (10 steps), its own roofline (flops the launches
-                              EXECUTE and relation bytes as STORED: bitmaps, gathers, known-entry lists) and cpu_baseline
-                              (oracle dfmc at 1/4 linear scale, projected by the cell ratio, labelled);
+                              EXECUTE and relation bytes as STORED: bitmaps, gathers, known-entry lists; traffic from PMC
+                              children of this run) and cpu_baseline (oracle dfmc MEASURED at 1/2 linear scale: `scale: 0.5`,
+                              `projection: false`; the 1/4-scale projection only where the child cannot run);
                    c2_dicty   configs[1]: the dicty graph (tests/golden/dicty_inputs.npz), 100 iterations f32 and f64,
                               and the NumPy oracle on the same host;
                    c3_planted configs[2] on planted data (rank-structured + 1 % noise): RMSE after 30 iterations over the
-                              noise floor 0.01 / sqrt(12).
-  cpu_baseline : the NumPy oracle (reference operation order, fp64, all BLAS threads): TWO iterations at FULL size when the
-                 host can hold the 88 GB of fp64 relations (child process, bounded), the second one reported; inputs from
+                              noise floor 0.01 / sqrt(12);
+                   rank_of_8  rank 3 of 8 of the fit sharded by ownership, exchanges skipped, configs[2] and configs[4]:
+                              compute ms, launches, exchange bytes per iteration and their modelled wire time;
+                   c3_tenth   configs[2] at 1/10 linear scale in the three engines, the oracle's rate beside them.
+  strong       : N > 1 runs in the default mode only -- after the restarts measurement the SAME process group runs ONE fit
+                 sharded by ownership (--mode owned) on configs[2] and configs[4]: it/s, bytes per rank and iteration, the
+                 transport and the ranks it reports (RCCL: ncclCommCount).  Bounded by SKF_STRONG_TIMEOUT (300 s): a
+                 collective that never returns costs this sub-record, not the line.
+  cpu_baseline : the NumPy oracle (reference operation order, fp64, all BLAS threads): FIVE iterations at FULL size when the
+                 host can hold the 88 GB of fp64 relations (child process, bounded; it runs beside the GPU-only sub-records
+                 of the default run), the last one reported; inputs from
                  the counter-based generator the device uses; otherwise a 1/10-linear-scale sample scaled by the work ratio
                  (`projection: true`).
 

@@ -1,6 +1,9 @@
 #!/bin/bash
 # Round 5, GPU session 1: suite on the new build, CU-mask bit layout, A/B of the round-5 schedule switches on config 3,
 # rank-of-8 emulation with / without the masked contraction stream.   tools/r05_session1.sh <out-name>
+# (Kept as the record of how profiles/r05_cu_mask_ab.txt was measured: SKF_MAIN_CU_DROP named the mask bits to clear on an
+# internal stream that carried the iteration; the switch and the stream were removed after this session -- the runs below
+# that set it now measure the plain schedule.)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 N=${1:-r5s1}; OUT=gpurun_out/$N; mkdir -p $OUT
