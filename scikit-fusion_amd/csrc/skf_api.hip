@@ -149,6 +149,35 @@ static int pick_splits(const TileCfg& t, int M, int N, int K, bool sym = false) 
     return s < 1 ? 1 : s;
 }
 
+// K slices for the relation contractions of the f32 / f64 engines (tiles >= 256: pick_splits leaves them unsplit).  Their
+// launches are matrix-core bound and their workgroup counts sit just above a multiple of what the chip holds: config 3's
+// 50 000-row relations are 782 tiles of 128 x 128 on 768 slots (3 workgroups per CU), the 100 000-row one 1564 -- 14 / 28
+// workgroups run a round of their own (a workgroup alone on its CU runs about three times as fast as one of three, so the
+// tail costs a third of a round: 75 % efficiency at one round, 86 % at two).  More slices dilute the tail:
+//   time(s) = (full rounds + ceil(tail workgroups / 256) / 3) x (K tiles per slice + 4) x step + s x (partial write + read)
+// with the step of a workgroup on a full CU (f32 128 x 128 x 32: 6.5 us, f64 64 x 128 x 16: 3.7 us).  Round 5, config 3:
+// f32 engine 9.9 -> 11.4 it/s (P12: 5 slices).
+static int pick_splits_relation(const TileCfg& t, int M, int N, int K, bool is_f64) {
+    const int64_t tiles = (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn);
+    const int ktiles = cdiv(K, t.bk);
+    const double occ = 3.0, slots = 256.0 * occ, step_us = is_f64 ? 3.7 : 6.5;
+    const double slice_us = (double)M * (double)N * (is_f64 ? 8.0 : 4.0) * 2.0 / 4.0e6;      // partials written and re-read at ~4 TB/s
+    int best = 1;
+    double best_t = 1e300;
+    for (int sl = 1; sl <= 16; ++sl) {
+        if (sl > 1 && ktiles / sl < 64) break;
+        const double wgs = (double)tiles * sl;
+        const double full = (double)(int64_t)(wgs / slots), rem = wgs - full * slots;
+        const double rounds = full + (rem > 0.0 ? (double)(int64_t)((rem + 255.0) / 256.0) / occ : 0.0);
+        const double tt = rounds * (cdiv(ktiles, sl) + 4) * step_us + (sl > 1 ? sl * slice_us : 0.0);
+        if (tt < best_t * 0.97) {
+            best_t = tt;
+            best = sl;
+        }
+    }
+    return best;
+}
+
 // operand / result types of one contraction (SKF_F64 or SKF_F32 each).  Supported:
 //   (f64,f64,f64)  f64 engine, and the c x c algebra of every engine
 //   (f32,f32,f32)  relation contractions and Theta products of the f32 engine
@@ -261,6 +290,13 @@ static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void
     const TileCfg t = gemm_tile(ty, engine, g, all_f64 && want_splits <= 1, relation);
     const bool sym_ok = g.sym && g.M == g.N && engine == SKF_ENGINE_MFMA && t.bn > t.bm && g.epi == EPI_STORE;
     int splits = want_splits > 0 ? want_splits : pick_splits(t, g.M, g.N, g.K, sym_ok);
+    if (want_splits <= 0 && relation && engine == SKF_ENGINE_MFMA && g.epi == EPI_STORE && t.bm >= 64 &&
+        (int64_t)cdiv(g.M, t.bm) * cdiv(g.N, t.bn) >= 256) {
+        // SKF_REL_SPLITS=0: unsplit (rounds 1-4); =n > 1: n slices for every such launch (A/B sweeps); default: the model
+        static const int rel_on = [] { const char* v = getenv("SKF_REL_SPLITS"); return v ? atoi(v) : 1; }();
+        if (rel_on == 1) splits = pick_splits_relation(t, g.M, g.N, g.K, is_f64);
+        else if (rel_on > 1) splits = rel_on;
+    }
     if (g.epi == EPI_SQDIFF) splits = 1;
     const size_t per = (size_t)g.M * g.N;
     const size_t part_elems = part_bytes / (is_f64 ? 8 : 4);
@@ -3140,7 +3176,14 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         size_t sp_part_bytes = 0;
         auto want_part = [&](int M, int N, int K, bool out_f64) {
             TileCfg t = pick_tile(out_f64, p->engine, M, N);
-            size_t need = (size_t)pick_splits(t, M, N, K) * (size_t)M * (size_t)N * (out_f64 ? 8 : 4);
+            int sl = pick_splits(t, M, N, K);
+            if (!p->bf16 && (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn) >= 256) {      // (relation contractions of the f32 / f64 engines)
+                int rs = pick_splits_relation(t, M, N, K, out_f64);
+                const char* force = getenv("SKF_REL_SPLITS");                     // (plan creation, not a launch path)
+                if (force && atoi(force) > 1) rs = atoi(force);
+                if (rs > sl) sl = rs;
+            }
+            size_t need = (size_t)sl * (size_t)M * (size_t)N * (out_f64 ? 8 : 4);
             if (need > part_bytes) part_bytes = need;
         };
         int maxn = 2;
