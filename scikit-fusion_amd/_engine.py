@@ -296,8 +296,12 @@ def _shared_rccl_comm(rt, dist):
     import threading
     comm, box = nat._P(), {}
 
+    device = torch.cuda.current_device() if torch.cuda.is_available() else None
+
     def create():
         try:
+            if device is not None:
+                torch.cuda.set_device(device)       # the current device is per THREAD: RCCL binds the communicator to it
             raw = (C.c_char * 128).from_buffer_copy(ident[0])
             rt.call('skf_comm_create', raw, rank, world, C.byref(comm))
             box['ok'] = True

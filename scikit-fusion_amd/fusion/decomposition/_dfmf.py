@@ -304,6 +304,8 @@ def run_fits_concurrent(variant, R, M, Theta, obj_types, obj_type2rank, max_iter
 
                 def drive(plan):
                     try:
+                        if getattr(rt.mem, 'device', None) is not None and hasattr(rt.mem, 'torch'):
+                            rt.mem.torch.cuda.set_device(rt.mem.device)      # the current device is per thread
                         plan.iterate(max_iter)
                     except Exception as exc:          # surfaced after the join
                         errors.append(exc)
