@@ -1281,11 +1281,15 @@ def main():
         if PMC_ERRORS:
             out['pmc_errors'] = PMC_ERRORS[:4]
         print(json.dumps(out), flush=True)
-    if hung:                       # a collective of the strong leg still holds its thread: no teardown that could wait for it
-        sys.stdout.flush()
-        os._exit(0)
     if dist is not None:
-        dist.destroy_process_group()
+        # N > 1: every rank leaves through os._exit once all are done -- the line is out, and no teardown (process group,
+        # RCCL communicators, a strong-leg thread that may still sit in a collective) gets the chance to wait for a peer
+        sys.stdout.flush()
+        if not hung:
+            run_bounded(dist.barrier, 60.0, local if torch.cuda.is_available() else None)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':
