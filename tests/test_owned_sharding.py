@@ -309,3 +309,34 @@ def test_owned_rows_keep_the_lists_of_known_entries(dtype, ranks, tol, monkeypat
             i, j = rels[k_unmasked][0], rels[k_unmasked][1]
             assert abs(np.sqrt(tot[k_unmasked]) - eo[i, j][0]) < 1e-8 * eo[i, j][0]
             assert np.isfinite(tot).all() and (tot > 0).all()
+
+
+def test_comm_info_and_launch_count(emul):
+    """Round 5: what a communicator says about itself (skf_comm_info: the `strong` record of bench.py quotes it) and the launch
+    counter behind `launches_per_step` (skf_launch_count) -- on the emulated runtime."""
+    from skfusion_amd._engine import DevicePlan, owned_rows, launch_count
+    rs = np.random.RandomState(1)
+    types, n, rank = ['a', 'b'], {'a': 40, 'b': 30}, {'a': 4, 'b': 3}
+    Rab = rs.rand(40, 30)
+    blk = dict(absent=False, row_begin=0, n_rows=20, masked=False)
+    plan = DevicePlan(types, n, rank, [('a', 'b', Rab[:20], None, blk)], [], nat.SKF_DFMF, part=(0, 2), owned=True)
+    try:
+        assert plan.comm_info() is None
+        plan.attach_null_comm(0, 2)
+        assert plan.comm_info() == {'rank': 0, 'world': 2, 'transport': 'null', 'transport_ranks': 0}
+        plan.attach_callback_comm(0, 2, lambda op, view, count, r, w: None)
+        assert plan.comm_info() == {'rank': 0, 'world': 2, 'transport': 'callback', 'transport_ranks': 2}
+    finally:
+        plan.close()
+    plan = DevicePlan(types, n, rank, [('a', 'b', Rab, None)], [], nat.SKF_DFMF)
+    try:
+        plan.attach_single_comm()
+        assert plan.comm_info() == {'rank': 0, 'world': 1, 'transport': 'single', 'transport_ranks': 1}
+        for t in types:
+            plan.set_factor(t, rs.rand(n[t], rank[t]) + 0.1)
+        before = launch_count()
+        plan.iterate(2)
+        per_iteration = (launch_count() - before) / 2.0
+        assert per_iteration == 3.0                      # the three-launch schedule of small graphs
+    finally:
+        plan.close()
