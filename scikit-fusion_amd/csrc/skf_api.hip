@@ -500,6 +500,10 @@ struct Switches {
     bool no_sweep = false;         // SKF_PINV_SWEEP=0      orders 65 .. 256: blocked Cholesky inverse + unpack instead of the blocked sweep (A/B)
     bool small_sweep1 = false;     // SKF_SMALL_SWEEP4=0    small graphs: one pivot per barrier in the register sweep (same bits; A/B, tests)
     int gram_sym = 1;              // SKF_GRAM_SYM=0        split-K Gram products compute every tile (default: the tiles on / below the diagonal, mirrored by the reduce)
+    int sweep_step_min = 65;       // SKF_SWEEP_STEP_MIN=n  orders >= n take the blocked sweep one launch per block step with the update of a step
+                                   //                       spread over row slabs (sweep_step_kernel); below: one workgroup per matrix, one launch.
+                                   //                       0 = never (A/B; same bits either way)
+    int sweep_rows = 32;           // SKF_SWEEP_ROWS=32|64.. rows of a slab (a multiple of 32)
     bool early_update = true;      // SKF_EARLY_UPDATE=0    pipeline: every type is updated at the end of the iteration (default: a type whose last relation is through
                                    //                       and that nothing reads any more is updated on the second stream, underneath the remaining contractions)
     static Switches read() {
@@ -521,6 +525,8 @@ struct Switches {
         { const char* s4 = getenv("SKF_SMALL_SWEEP4"); w.small_sweep1 = s4 && atoi(s4) == 0; }
         { const char* gs = getenv("SKF_GRAM_SYM"); w.gram_sym = (gs && atoi(gs) == 0) ? 0 : 1; }
         { const char* eu = getenv("SKF_EARLY_UPDATE"); w.early_update = !(eu && atoi(eu) == 0); }
+        { const char* sm = getenv("SKF_SWEEP_STEP_MIN"); if (sm) w.sweep_step_min = atoi(sm); }
+        { const char* sr = getenv("SKF_SWEEP_ROWS"); if (sr && atoi(sr) >= 32) w.sweep_rows = (atoi(sr) + 31) / 32 * 32; }
         const char* st = getenv("SKF_SIDE_TILE");
         w.side_tile = st ? atoi(st) : 0;
         const char* ap = getenv("SKF_AUX_PRIO");
@@ -883,6 +889,27 @@ static void launch_chol(const Switches& sw, const EighArgs& e, int batch, int ma
     check_launch("chol_inverse");
 }
 
+// The blocked sweep of `nb` matrices of order <= max_c (65 .. SWEEP_MAXN): one workgroup per matrix in one launch, or -- from
+// order sw.sweep_step_min -- one launch per block step with the rank-32 update of the step spread over row slabs.
+static void launch_sweep(const Switches& sw, const EighArgs& e, const PinvBatch& pb, int nb, int max_c, hipStream_t st) {
+    if (sw.sweep_step_min > 0 && max_c >= sw.sweep_step_min) {
+        static DeviceOnce once;
+        allow_dynamic_lds(once, sweep_step_kernel, SWEEP_LDS_BYTES);
+        const int rs = sw.sweep_rows;
+        const int slabs = (max_c + rs - 1) / rs, steps = (max_c + SWEEP_NB - 1) / SWEEP_NB;
+        for (int step = 0; step < steps; ++step) {
+            hipLaunchKernelGGL(sweep_step_kernel, dim3((unsigned)nb, (unsigned)slabs), dim3(SWEEP_THREADS), SWEEP_LDS_BYTES, st, e, pb,
+                               chol_rel_threshold(sw), step, rs);
+            check_launch("sweep_step");
+        }
+        return;
+    }
+    static DeviceOnce once;
+    allow_dynamic_lds(once, sweep_inverse_kernel, SWEEP_LDS_BYTES);
+    hipLaunchKernelGGL(sweep_inverse_kernel, dim3((unsigned)nb), dim3(SWEEP_THREADS), SWEEP_LDS_BYTES, st, e, pb, chol_rel_threshold(sw));
+    check_launch("sweep_inverse");
+}
+
 // K_i = pinv(Gram_i) for every type (one workgroup each); `which` = 0..n_types-1, the order
 // of the per-matrix order arrays uploaded once by skf_plan_bind_workspace.
 static void pinv_fallbacks(skf_plan* p, const std::vector<int>& which, const PinvBatch& pb, const EighArgs& e, bool batched, int max_c,
@@ -930,11 +957,7 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
     const bool sweep = batched && max_c > CHOLS_MAXN && max_c <= SWEEP_MAXN && !p->sw.no_sweep && !p->sw.chol_unblocked &&
                        !p->sw.pinv_jacobi;
     if (sweep) {
-        static DeviceOnce once;
-        allow_dynamic_lds(once, sweep_inverse_kernel, SWEEP_LDS_BYTES);
-        hipLaunchKernelGGL(sweep_inverse_kernel, dim3((unsigned)nb), dim3(SWEEP_THREADS), SWEEP_LDS_BYTES, st, e, pb,
-                           chol_rel_threshold(p->sw));
-        check_launch("sweep_inverse");
+        launch_sweep(p->sw, e, pb, nb, max_c, st);
         pinv_fallbacks(p, which, pb, e, batched, max_c, st);
         return;
     }
@@ -4492,10 +4515,7 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
             PinvBatch pb;
             memset(&pb, 0, sizeof pb);
             pb.K[0] = (double*)K; pb.c[0] = n; pb.n_pad[0] = np;
-            static DeviceOnce once;
-            allow_dynamic_lds(once, sweep_inverse_kernel, SWEEP_LDS_BYTES);
-            hipLaunchKernelGGL(sweep_inverse_kernel, dim3(1), dim3(SWEEP_THREADS), SWEEP_LDS_BYTES, st, e, pb, chol_rel_threshold(sw));
-            check_launch("sweep_inverse");
+            launch_sweep(sw, e, pb, 1, n, st);
         } else {
             launch_chol(sw, e, 1, np, st);
             if (dtype == SKF_F64)

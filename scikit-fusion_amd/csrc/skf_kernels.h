@@ -3307,7 +3307,79 @@ constexpr int SWEEP_MAXN = 256;
 constexpr int SWEEP_NB = 32;
 constexpr int SWEEP_LD = SWEEP_NB + 4;      // (row r, k) -> 4 r + k mod 32: the fragments of the matrix-core tiles are conflict-free
 constexpr int SWEEP_THREADS = 512;
-constexpr int SWEEP_LDS_BYTES = ((2 * SWEEP_MAXN + SWEEP_NB) * SWEEP_LD + 2 * SWEEP_NB + SWEEP_MAXN) * 8;
+constexpr int SWEEP_LDS_BYTES = ((2 * SWEEP_MAXN + SWEEP_NB) * SWEEP_LD + 6 * SWEEP_NB + SWEEP_MAXN) * 8;
+
+// The sweep of one 32 x 32 pivot block by ONE wave (round 5, sweep_step_kernel): lane = (column c = lane & 31, half =
+// lane >> 5) holds rows 16 half .. 16 half + 15 of its column in registers; row k of the current state travels through LDS
+// (double-buffered) and the wave orders its own LDS traffic -- no workgroup barrier per pivot.  (sweep_inverse_kernel spreads
+// the block over its 512 threads, two elements each, with one __syncthreads() per pivot: 14 us per block -- barriers and LDS
+// round trips, not the 2 k FMAs.)  The chain from one pivot to the next is: element of row k + 1 -> LDS -> every lane ->
+// reciprocal -> update; so pivot k updates ROW k + 1 FIRST, the lane that holds the next pivot takes its reciprocal at once,
+// row and reciprocal go to LDS, and the other 15 rows of the lane are updated while that round trip is in flight.  The loop
+// has no data-dependent branch: a failed pivot clears `ok` and the arithmetic runs on (its results are dropped).  The
+// padding of a short block (rows / columns >= nb) is zero on entry and stays +0 under every finite pivot, so nothing masks
+// it inside the loop.  The arithmetic of an element is the same expression in the same order as in sweep_inverse_kernel
+// (1 / pivot is the same IEEE quotient whichever lane takes it), so the bits are the same.
+// rowk: SWEEP_ROWK_WORDS words.  Returns false when a pivot failed its bound (uniform).
+constexpr int SWEEP_ROWK = 2 * SWEEP_NB;          // a row of the pivot block and, behind it, the reciprocals of its elements
+constexpr int SWEEP_ROWK_WORDS = 3 * SWEEP_ROWK;  // two buffers and one nobody reads
+__device__ __forceinline__ bool sweep_pivot_block(const double* __restrict__ Cblk, double* __restrict__ Pv,
+                                                  double* __restrict__ rowk, const double* __restrict__ need, int nb, int lane) {
+    constexpr int NB = SWEEP_NB, LD = SWEEP_LD, RK = SWEEP_ROWK;
+    const int c = lane & 31, half = lane >> 5;
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = 16 * half + q;
+        v[q] = (r < nb && c < nb) ? Cblk[r * LD + c] : 0.0;
+    }
+    // every lane stores what it has of row k + 1 and the reciprocal of it -- the half that does not hold the row into a
+    // buffer nobody reads: no branch, and the quotient is scheduled among the updates of the other rows
+    {
+        double* dst = rowk + (half == 0 ? 0 : 2 * RK);
+        dst[c] = v[0];
+        dst[NB + c] = 1.0 / v[0];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {                                       // (a fixed trip count: the registers of v are named)
+        if (k < nb) {                                                    // (uniform)
+            const double* rk = rowk + (k & 1) * RK;
+            const double piv = rk[k];                                    // (every lane reads the same words)
+            ok = ok & (piv > need[k]);
+            const double d = rk[NB + k];
+            const double cc = rk[c];
+            double e[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) e[q] = rk[16 * half + q] * d;
+            auto swept = [&](int q) -> double {
+                const double gen = (c == k) ? e[q] : fma(-e[q], cc, v[q]);
+                if (q != (k & 15)) return gen;
+                const double piv_row = (c == k) ? -d : cc * d;           // row k itself, in the half that holds it
+                return (half == (k >> 4)) ? piv_row : gen;
+            };
+            const int q1 = (k + 1) & 15;                                 // row k + 1 first: it carries the next pivot
+            if (k + 1 < NB) {
+                v[q1] = swept(q1);
+                double* dst = rowk + (half == ((k + 1) >> 4) ? ((k + 1) & 1) * RK : 2 * RK);
+                dst[c] = v[q1];
+                dst[NB + c] = 1.0 / v[q1];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (!(k + 1 < NB && q == q1)) v[q] = swept(q);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Pv[(16 * half + q) * LD + c] = v[q];
+    return ok;
+}
 
 __global__ __launch_bounds__(SWEEP_THREADS) void sweep_inverse_kernel(EighArgs e, PinvBatch pb, double rel_thr) {
     constexpr int NB = SWEEP_NB, LD = SWEEP_LD;
@@ -3317,8 +3389,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_inverse_kernel(EighArgs e
     double* Cs = ssm;                              // [SWEEP_MAXN][LD]  panel C = M[:, kb .. kb + nb)
     double* Ts = Cs + SWEEP_MAXN * LD;             // [SWEEP_MAXN][LD]  T = M_rp P
     double* Pv = Ts + SWEEP_MAXN * LD;             // [NB][LD]          the swept pivot block: -P
-    double* rowk = Pv + NB * LD;                   // [2][NB]           row k of the pivot block, double-buffered
-    double* need = rowk + 2 * NB;                  // [SWEEP_MAXN]      the bound pivot k has to exceed
+    double* rowk = Pv + NB * LD;                   // [2][NB]           row k of the pivot block, double-buffered (6 NB words reserved)
+    double* need = rowk + 6 * NB;                  // [SWEEP_MAXN]      the bound pivot k has to exceed
     const int b = blockIdx.x;
     const int n = e.n_orig[b], ld = e.n[b];
     if (n > SWEEP_MAXN) return;                    // (the host sends such plans to chol_inverse_blocked_kernel)
@@ -3509,6 +3581,211 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_inverse_kernel(EighArgs e
     double* K = pb.K[b];
     for (int idx = tid; idx < n * n; idx += SWEEP_THREADS) K[idx] = -M[(idx / n) * ld + idx % n];
     if (tid == 0) e.chol_ok[b] = 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// The same sweep with the rank-32 update of a block step spread over SEVERAL workgroups (round 5): one launch per block
+// step, grid = (matrices, row slabs).  A slab is `rs` rows of the matrix (a multiple of 32); its workgroup repeats the small
+// serial part of the step -- panel to LDS, the pivot-block sweep by one wave -- and then owns everything that carries one of
+// its rows i: T_i = M_ip P, the updated M_ij, the pivot columns (i, p) and, transposed, the pivot rows (p, i); the slab that
+// holds the pivot rows also writes -P.  A step READS one copy of the matrix and WRITES the other (e.V / e.Vs alternate; the
+// first step reads the symmetrised input itself, the last one writes K = -M), so no workgroup waits for another inside a
+// launch and there is no grid barrier to hang on: the order between steps is the stream's.  Every element takes the
+// arithmetic of sweep_inverse_kernel in the same order (the accumulators of a tile start from M and run over the 32 pivots
+// in steps of four) -- the two kernels return the same bits.  chol_ok[b] carries the state between launches: 3 = steps so
+// far accepted every pivot, 0 = a pivot failed (the later steps of that matrix return at once; e.A is untouched for the
+// deflation / eigen-solver), 1 after the last step.
+// One workgroup per matrix spends 53 us per block at order 256, 27 of them in the update; here a step is the serial part
+// plus one 32 x 32 tile per wave, and a launch boundary (profiles/: tools/bench_pinv.py).
+// ------------------------------------------------------------------------------------------
+constexpr int SWEEP_RUNNING = 3;
+
+__global__ __launch_bounds__(SWEEP_THREADS) void sweep_step_kernel(EighArgs e, PinvBatch pb, double rel_thr, int step, int rs) {
+    constexpr int NB = SWEEP_NB, LD = SWEEP_LD;
+    typedef Mfma<double> MF;
+    HIP_DYNAMIC_SHARED(double, ssm)
+    __shared__ double red[SWEEP_THREADS / 64];
+    __shared__ int s_ok;
+    double* Cs = ssm;                              // [SWEEP_MAXN][LD]  panel C = M[:, kb .. kb + nb)
+    double* Ts = Cs + SWEEP_MAXN * LD;             // [SWEEP_MAXN][LD]  T = M_rp P (rows of this slab)
+    double* Pv = Ts + SWEEP_MAXN * LD;             // [NB][LD]          the swept pivot block: -P
+    double* rowk = Pv + NB * LD;                   // [SWEEP_ROWK_WORDS]
+    double* need = rowk + 6 * NB;                  // [NB]              the bounds of this step's pivots
+    const int b = blockIdx.x;
+    const int n = e.n_orig[b], ld = e.n[b];
+    const int kb = step * NB;
+    if (n > SWEEP_MAXN || kb >= n) return;
+    const int r0 = blockIdx.y * rs, r1 = (r0 + rs < n) ? r0 + rs : n;
+    if (r0 >= n) return;
+    const bool first = step == 0, last = kb + NB >= n;
+    if (!first && *(volatile const int*)(e.chol_ok + b) == 0) return;     // (uniform; slab 0 of THIS launch may already have written its verdict)
+    const int nb = (n - kb < NB) ? n - kb : NB;
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;      // 32 x 16
+    const int lane = tid & 63, wave = tid >> 6;
+    const double* A = e.A + (int64_t)b * e.stride;
+    const double* Min = ((step & 1) ? e.Vs : e.V) + (int64_t)b * e.stride;
+    double* Mout = ((step & 1) ? e.V : e.Vs) + (int64_t)b * e.stride;
+    double* K = pb.K[b];
+    auto in = [&](int i, int j) -> double { return first ? 0.5 * (A[i * ld + j] + A[j * ld + i]) : Min[i * ld + j]; };
+    auto out = [&](int i, int j, double v) {
+        if (last) K[i * n + j] = -v;
+        else Mout[i * ld + j] = v;
+    };
+
+#ifdef SKF_PROBE_STAMPS
+    long long ph[6] = {0, 0, 0, 0, 0, 0}, t_in = wall_clock64();
+#define SKF_STAMP(i) { const long long now_ = wall_clock64(); ph[i] += now_ - t_in; t_in = now_; }
+#else
+#define SKF_STAMP(i)
+#endif
+    // ---- everything the step reads from memory is asked for up front: the panel (every row: the columns j of the update
+    // come from it), the diagonal of the input for the bounds of this step's pivots (as sweep_inverse_kernel), and the
+    // wave's first tile of M -- its loads fly while wave 0 sweeps the pivot block
+    double pc[SWEEP_MAXN / 16];
+#pragma unroll
+    for (int u = 0; u < SWEEP_MAXN / 16; ++u) {
+        const int i = ty + 16 * u;
+        pc[u] = (i < n && tx < nb) ? in(i, kb + tx) : 0.0;
+    }
+    double mx = 0.0;
+    for (int k = tid; k < n; k += SWEEP_THREADS) mx = fmax(mx, fabs(A[k * ld + k]));
+    const double akk = tid < nb ? A[(kb + tid) * ld + kb + tid] : 0.0;
+    const int ncol = (n + 31) >> 5, nrow = (r1 - r0 + 31) >> 5;
+    auto tile_at = [&](int blk, int& bi, int& bj) -> bool {              // false: pivot rows / columns only (or past the end)
+        bi = r0 + (blk / ncol) * 32;
+        bj = (blk % ncol) * 32;
+        return blk < nrow * ncol && bi != kb && bj != kb;
+    };
+    auto tile_load = [&](int bi, int bj, MF::acc_t (&acc)[2][2]) {       // the accumulators start from M itself
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) {
+                const int i = bi + 16 * a + MF::d_row(lane, r);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = bj + 16 * q + MF::d_col(lane);
+                    acc[a][q][r] = (i < n && j < n) ? in(i, j) : 0.0;
+                }
+            }
+    };
+    MF::acc_t acc0[2][2];
+    int bi0, bj0;
+    const bool have0 = tile_at(wave, bi0, bj0);
+    if (have0) tile_load(bi0, bj0, acc0);
+#pragma unroll
+    for (int u = 0; u < SWEEP_MAXN / 16; ++u) {
+        const int i = ty + 16 * u;
+        if (i < n) Cs[i * LD + tx] = pc[u];
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    SKF_STAMP(0)
+    if (wave == 0) {
+        double smax = 0.0;
+#pragma unroll
+        for (int i = 0; i < SWEEP_THREADS / 64; ++i) smax = fmax(smax, red[i]);
+        if (tid < nb) need[tid] = (akk > chol_diag_floor(n) * smax) ? fmax(rel_thr * akk, 0.0) : __builtin_inf();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const bool ok = sweep_pivot_block(Cs + kb * LD, Pv, rowk, need, nb, lane);
+        if (lane == 0) s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    SKF_STAMP(1)
+    if (!s_ok) {                                                         // (uniform, and the same verdict in every slab)
+        if (tid == 0 && blockIdx.y == 0) e.chol_ok[b] = 0;
+        return;
+    }
+    // ---- T = -(C Pv) for the rows of the slab
+    {
+        const int t0 = r0 >> 4, t1 = (r1 + 15) >> 4;
+        for (int it = t0 + wave; it < t1; it += SWEEP_THREADS / 64) {
+            const int row = it * 16 + MF::a_row(lane);
+            MF::acc_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k0 = 0; k0 < NB; k0 += MF::KT) {
+                const int kk = k0 + MF::ab_k(lane);
+                const double a = row < n ? Cs[row * LD + kk] : 0.0;
+                a0 = MF::mma(a, Pv[kk * LD + MF::a_row(lane)], a0);
+                a1 = MF::mma(a, Pv[kk * LD + 16 + MF::a_row(lane)], a1);
+            }
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) {
+                const int i = it * 16 + MF::d_row(lane, r);
+                if (i < n) {
+                    Ts[i * LD + MF::d_col(lane)] = -a0[r];
+                    Ts[i * LD + 16 + MF::d_col(lane)] = -a1[r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    SKF_STAMP(2)
+    // ---- M_ij - T_i C_j^T outside the pivot rows / columns: a wave owns 32 x 32 outputs at a time
+    {
+        auto tile_finish = [&](int bi, int bj, MF::acc_t (&acc)[2][2]) {
+#pragma unroll 2
+            for (int k0 = 0; k0 < NB; k0 += MF::KT) {
+                const int kk = k0 + MF::ab_k(lane);
+                double ta[2], cb[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int i = bi + 16 * a + MF::a_row(lane);
+                    ta[a] = i < n ? -Ts[i * LD + kk] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = bj + 16 * q + MF::a_row(lane);
+                    cb[q] = j < n ? Cs[j * LD + kk] : 0.0;
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc[a][q] = MF::mma(ta[a], cb[q], acc[a][q]);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < MF::NREG; ++r) {
+                    const int i = bi + 16 * a + MF::d_row(lane, r);
+                    if (i >= r1 || (i >= kb && i < kb + nb)) continue;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int j = bj + 16 * q + MF::d_col(lane);
+                        if (j < n && !(j >= kb && j < kb + nb)) out(i, j, acc[a][q][r]);
+                    }
+                }
+        };
+        if (have0) tile_finish(bi0, bj0, acc0);
+        for (int blk = wave + SWEEP_THREADS / 64; blk < nrow * ncol; blk += SWEEP_THREADS / 64) {
+            int bi, bj;
+            if (!tile_at(blk, bi, bj)) continue;
+            MF::acc_t acc[2][2];
+            tile_load(bi, bj, acc);
+            tile_finish(bi, bj, acc);
+        }
+    }
+    SKF_STAMP(3)
+    // ---- the pivot columns of the slab's rows <- T, the pivot rows at the slab's columns <- T^T, the pivot block <- -P
+    for (int i = r0 + ty; i < r1; i += 16) {
+        if (tx >= nb) continue;
+        if (i >= kb && i < kb + nb) out(i, kb + tx, Pv[(i - kb) * LD + tx]);
+        else out(i, kb + tx, Ts[i * LD + tx]);
+    }
+    for (int idx = tid; idx < nb * (r1 - r0); idx += SWEEP_THREADS) {
+        const int c = idx / (r1 - r0), i = r0 + idx % (r1 - r0);
+        if (!(i >= kb && i < kb + nb)) out(kb + c, i, Ts[i * LD + c]);
+    }
+    SKF_STAMP(4)
+#ifdef SKF_PROBE_STAMPS
+    if (tid == 0 && n >= 200 && blockIdx.y == 1 && (step == 0 || step == 3))
+        printf("sweep_step n %d step %d: loads + panel %lld, pivot block sweep %lld, T %lld, update %lld, write-back %lld (x10 ns)\n", n, step,
+               ph[0], ph[1], ph[2], ph[3], ph[4]);
+#endif
+    if (tid == 0 && blockIdx.y == 0) e.chol_ok[b] = last ? 1 : SWEEP_RUNNING;
 }
 
 __global__ __launch_bounds__(256) void eigh_unpack_pinv_batched_kernel(PinvBatch pb, const double* __restrict__ VsAll,

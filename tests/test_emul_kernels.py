@@ -330,6 +330,38 @@ def test_pinv_blocked_sweep_orders_65_to_256(rt, n):
         assert relerr(run_pinv(rt, nat.SKF_F64, Ad), spla.pinv(Ad)) < 1e-7
 
 
+@pytest.mark.parametrize('n', [65, 96, 130, 200, 256])
+def test_pinv_sweep_one_launch_per_block_step_keeps_the_bits(rt, n):
+    """sweep_step_kernel (round 5: one launch per block step, the rank-32 update of a step spread over row slabs, the matrix
+    alternating between two copies) against sweep_inverse_kernel (one workgroup, in place): every element takes the same
+    arithmetic in the same order, so the inverses are equal bit for bit -- at slabs of 32 and 64 rows, with a ragged last
+    block, and for a matrix that fails a pivot in a late step (both hand over to the deflation)."""
+    import os
+    rs = np.random.RandomState(100 + n)
+    G = rs.rand(3 * n + 5, n)
+    A = G.T @ G
+    Gd = np.concatenate([rs.rand(n - 7, n - 7), np.zeros((n - 7, 7))], axis=1)     # pivots fail in the LAST block
+    Gd[:, -7:] = Gd[:, :7]
+    Ad = Gd.T @ Gd
+
+    def run(step_min, rows=None):
+        os.environ['SKF_SWEEP_STEP_MIN'] = str(step_min)
+        if rows:
+            os.environ['SKF_SWEEP_ROWS'] = str(rows)
+        try:
+            return run_pinv(rt, nat.SKF_F64, A), run_pinv(rt, nat.SKF_F64, Ad)
+        finally:
+            os.environ.pop('SKF_SWEEP_STEP_MIN', None)
+            os.environ.pop('SKF_SWEEP_ROWS', None)
+
+    one, one_d = run(0)
+    for rows in (32, 64):
+        stepped, stepped_d = run(65, rows)
+        assert np.array_equal(one, stepped), rows
+        assert np.array_equal(one_d, stepped_d), rows
+    assert relerr(A @ one @ A, A) < 1e-11
+
+
 def test_pinv_rank_deficient_truncates_like_scipy(rt):
     """reference tests/test_n_run.py:14: rank 50 factor of 30 objects -> Gram has rank 30."""
     import scipy.linalg as spla

@@ -67,6 +67,14 @@ def test_pinv_full_rank(rt, n):
     K.test_pinv_full_rank_matches_scipy(rt, n)
 
 
+@pytest.mark.parametrize('n', [65, 96, 130, 200, 256])
+def test_pinv_blocked_sweep(rt, n):
+    """Orders 65 .. 256 on the hardware: one launch per block step (sweep_step_kernel, the default) against scipy and the
+    blocked Cholesky inverse, and bit for bit against one workgroup per matrix (sweep_inverse_kernel)."""
+    K.test_pinv_blocked_sweep_orders_65_to_256(rt, n)
+    K.test_pinv_sweep_one_launch_per_block_step_keeps_the_bits(rt, n)
+
+
 def test_pinv_rank_deficient(rt):
     K.test_pinv_rank_deficient_truncates_like_scipy(rt)
     K.test_pinv_zero_and_diagonal(rt)
