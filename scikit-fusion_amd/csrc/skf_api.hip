@@ -504,6 +504,7 @@ struct Switches {
                                    //                       spread over row slabs (sweep_step_kernel); below: one workgroup per matrix, one launch.
                                    //                       0 = never (A/B; same bits either way)
     int sweep_rows = 32;           // SKF_SWEEP_ROWS=32|64.. rows of a slab (a multiple of 32)
+    bool no_sweep_big = false;     // SKF_SWEEP_BIG=0       orders above 256 on the blocked Cholesky inverse + unpack, as before round 5 (A/B)
     bool early_update = true;      // SKF_EARLY_UPDATE=0    pipeline: every type is updated at the end of the iteration (default: a type whose last relation is through
                                    //                       and that nothing reads any more is updated on the second stream, underneath the remaining contractions)
     static Switches read() {
@@ -527,6 +528,7 @@ struct Switches {
         { const char* eu = getenv("SKF_EARLY_UPDATE"); w.early_update = !(eu && atoi(eu) == 0); }
         { const char* sm = getenv("SKF_SWEEP_STEP_MIN"); if (sm) w.sweep_step_min = atoi(sm); }
         { const char* sr = getenv("SKF_SWEEP_ROWS"); if (sr && atoi(sr) >= 32) w.sweep_rows = (atoi(sr) + 31) / 32 * 32; }
+        { const char* sb = getenv("SKF_SWEEP_BIG"); w.no_sweep_big = sb && atoi(sb) == 0; }
         const char* st = getenv("SKF_SIDE_TILE");
         w.side_tile = st ? atoi(st) : 0;
         const char* ap = getenv("SKF_AUX_PRIO");
@@ -889,17 +891,29 @@ static void launch_chol(const Switches& sw, const EighArgs& e, int batch, int ma
     check_launch("chol_inverse");
 }
 
-// The blocked sweep of `nb` matrices of order <= max_c (65 .. SWEEP_MAXN): one workgroup per matrix in one launch, or -- from
-// order sw.sweep_step_min -- one launch per block step with the rank-32 update of the step spread over row slabs.
+// The blocked sweep of `nb` matrices of order <= max_c: from order sw.sweep_step_min (default: always) one launch per block
+// step with the rank-32 update of the step spread over row slabs -- orders up to SWEEP_MAXN with the panel in LDS, up to
+// EIGH_MAXN with the column operands from memory --, else (orders <= SWEEP_MAXN) one workgroup per matrix in one launch.
+static bool sweep_steps(const Switches& sw, int max_c) { return sw.sweep_step_min > 0 && max_c >= sw.sweep_step_min; }
+static bool sweep_takes(const Switches& sw, int max_c) {
+    if (max_c <= CHOLS_MAXN || sw.no_sweep || sw.chol_unblocked || sw.pinv_jacobi) return false;
+    return max_c <= SWEEP_MAXN || (sweep_steps(sw, max_c) && max_c <= EIGH_MAXN && !sw.no_sweep_big);
+}
 static void launch_sweep(const Switches& sw, const EighArgs& e, const PinvBatch& pb, int nb, int max_c, hipStream_t st) {
-    if (sw.sweep_step_min > 0 && max_c >= sw.sweep_step_min) {
-        static DeviceOnce once;
-        allow_dynamic_lds(once, sweep_step_kernel, SWEEP_LDS_BYTES);
-        const int rs = sw.sweep_rows;
+    if (sweep_steps(sw, max_c)) {
+        const bool big = max_c > SWEEP_MAXN;
+        static DeviceOnce once, once_big;
+        if (big) allow_dynamic_lds(once_big, sweep_step_kernel<true>, SWEEP_BIG_LDS_BYTES);
+        else allow_dynamic_lds(once, sweep_step_kernel<false>, SWEEP_LDS_BYTES);
+        const int rs = big ? SWEEP_NB : sw.sweep_rows;
         const int slabs = (max_c + rs - 1) / rs, steps = (max_c + SWEEP_NB - 1) / SWEEP_NB;
         for (int step = 0; step < steps; ++step) {
-            hipLaunchKernelGGL(sweep_step_kernel, dim3((unsigned)nb, (unsigned)slabs), dim3(SWEEP_THREADS), SWEEP_LDS_BYTES, st, e, pb,
-                               chol_rel_threshold(sw), step, rs);
+            if (big)
+                hipLaunchKernelGGL(sweep_step_kernel<true>, dim3((unsigned)nb, (unsigned)slabs), dim3(SWEEP_THREADS), SWEEP_BIG_LDS_BYTES, st,
+                                   e, pb, chol_rel_threshold(sw), step, rs);
+            else
+                hipLaunchKernelGGL(sweep_step_kernel<false>, dim3((unsigned)nb, (unsigned)slabs), dim3(SWEEP_THREADS), SWEEP_LDS_BYTES, st, e,
+                                   pb, chol_rel_threshold(sw), step, rs);
             check_launch("sweep_step");
         }
         return;
@@ -954,8 +968,7 @@ static void plan_pinv(skf_plan* p, const std::vector<int>& which, hipStream_t st
     // work for the matrices the fast path rejected -- no host round trip either way
     // orders 65 .. 256 (round 4): the blocked sweep operator writes K itself -- one launch instead of the Cholesky inverse and
     // its unpack (1.15 + 0.09 ms at order 256)
-    const bool sweep = batched && max_c > CHOLS_MAXN && max_c <= SWEEP_MAXN && !p->sw.no_sweep && !p->sw.chol_unblocked &&
-                       !p->sw.pinv_jacobi;
+    const bool sweep = batched && sweep_takes(p->sw, max_c);
     if (sweep) {
         launch_sweep(p->sw, e, pb, nb, max_c, st);
         pinv_fallbacks(p, which, pb, e, batched, max_c, st);
@@ -4509,8 +4522,7 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
         const int tot2 = n * n;
         const Switches sw = Switches::read();          // stand-alone operator: no plan to hold them
         // fast path: the blocked sweep for orders 65 .. 256 (writes a contiguous f64 K itself), else Cholesky inverse + unpack
-        const bool sweep = dtype == SKF_F64 && ldk == n && n > CHOLS_MAXN && n <= SWEEP_MAXN && !sw.no_sweep && !sw.chol_unblocked &&
-                           !sw.pinv_jacobi;
+        const bool sweep = dtype == SKF_F64 && ldk == n && sweep_takes(sw, n);
         if (sweep) {
             PinvBatch pb;
             memset(&pb, 0, sizeof pb);

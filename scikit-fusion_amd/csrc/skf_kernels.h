@@ -3599,22 +3599,31 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_inverse_kernel(EighArgs e
 // plus one 32 x 32 tile per wave, and a launch boundary (profiles/: tools/bench_pinv.py).
 // ------------------------------------------------------------------------------------------
 constexpr int SWEEP_RUNNING = 3;
+// BIG (orders above SWEEP_MAXN, up to EIGH_MAXN): the panel of every row does not fit the LDS -- it holds the pivot rows and
+// the rows of the slab only (slabs of exactly 32 rows); the column operands C_j of a tile come from the matrix in memory (L2:
+// 8 MB at order 1024), asked for together with the tile's accumulators.  Same arithmetic, element by element.
+constexpr int SWEEP_BIG_ROWS = 2 * SWEEP_NB;      // pivot rows, slab rows
+constexpr int SWEEP_BIG_LDS_BYTES = ((SWEEP_BIG_ROWS + 2 * SWEEP_NB) * SWEEP_LD + 6 * SWEEP_NB + SWEEP_NB) * 8;
 
+template <bool BIG>
 __global__ __launch_bounds__(SWEEP_THREADS) void sweep_step_kernel(EighArgs e, PinvBatch pb, double rel_thr, int step, int rs) {
     constexpr int NB = SWEEP_NB, LD = SWEEP_LD;
+    constexpr int CROWS = BIG ? SWEEP_BIG_ROWS : SWEEP_MAXN, TROWS = BIG ? SWEEP_NB : SWEEP_MAXN;
+    constexpr int PCN = BIG ? SWEEP_BIG_ROWS / 16 : SWEEP_MAXN / 16;
     typedef Mfma<double> MF;
     HIP_DYNAMIC_SHARED(double, ssm)
     __shared__ double red[SWEEP_THREADS / 64];
     __shared__ int s_ok;
-    double* Cs = ssm;                              // [SWEEP_MAXN][LD]  panel C = M[:, kb .. kb + nb)
-    double* Ts = Cs + SWEEP_MAXN * LD;             // [SWEEP_MAXN][LD]  T = M_rp P (rows of this slab)
-    double* Pv = Ts + SWEEP_MAXN * LD;             // [NB][LD]          the swept pivot block: -P
+    double* Cs = ssm;                              // panel C = M[:, kb .. kb + nb): every row | BIG: pivot rows, then slab rows
+    double* Ts = Cs + CROWS * LD;                  // T = M_rp P (rows of this slab)
+    double* Pv = Ts + TROWS * LD;                  // [NB][LD]          the swept pivot block: -P
     double* rowk = Pv + NB * LD;                   // [SWEEP_ROWK_WORDS]
     double* need = rowk + 6 * NB;                  // [NB]              the bounds of this step's pivots
     const int b = blockIdx.x;
     const int n = e.n_orig[b], ld = e.n[b];
     const int kb = step * NB;
-    if (n > SWEEP_MAXN || kb >= n) return;
+    if (n > (BIG ? EIGH_MAXN : SWEEP_MAXN) || kb >= n) return;
+    if (BIG) rs = NB;
     const int r0 = blockIdx.y * rs, r1 = (r0 + rs < n) ? r0 + rs : n;
     if (r0 >= n) return;
     const bool first = step == 0, last = kb + NB >= n;
@@ -3628,9 +3637,13 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_step_kernel(EighArgs e, P
     double* K = pb.K[b];
     auto in = [&](int i, int j) -> double { return first ? 0.5 * (A[i * ld + j] + A[j * ld + i]) : Min[i * ld + j]; };
     auto out = [&](int i, int j, double v) {
-        if (last) K[i * n + j] = -v;
+        if (last) K[(int64_t)i * n + j] = -v;
         else Mout[i * ld + j] = v;
     };
+    // rows of the panel / of T in LDS
+    auto crow = [&](int i) -> int { return BIG ? NB + (i - r0) : i; };   // a row of the slab
+    auto trow = [&](int i) -> int { return BIG ? i - r0 : i; };
+    const int piv0 = BIG ? 0 : kb;                                       // first pivot row
 
 #ifdef SKF_PROBE_STAMPS
     long long ph[6] = {0, 0, 0, 0, 0, 0}, t_in = wall_clock64();
@@ -3639,13 +3652,19 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_step_kernel(EighArgs e, P
 #define SKF_STAMP(i)
 #endif
     // ---- everything the step reads from memory is asked for up front: the panel (every row: the columns j of the update
-    // come from it), the diagonal of the input for the bounds of this step's pivots (as sweep_inverse_kernel), and the
-    // wave's first tile of M -- its loads fly while wave 0 sweeps the pivot block
-    double pc[SWEEP_MAXN / 16];
+    // come from it | BIG: pivot rows and slab rows), the diagonal of the input for the bounds of this step's pivots (as
+    // sweep_inverse_kernel), and the wave's first tile of M -- its loads fly while wave 0 sweeps the pivot block
+    auto panel_row = [&](int u) -> int {                                 // the matrix row behind LDS row ty + 16 u (-1: none)
+        const int l = ty + 16 * u;
+        if (!BIG) return l < n ? l : -1;
+        const int i = l < NB ? kb + l : r0 + (l - NB);
+        return (l < NB ? l < nb : i < r1) ? i : -1;
+    };
+    double pc[PCN];
 #pragma unroll
-    for (int u = 0; u < SWEEP_MAXN / 16; ++u) {
-        const int i = ty + 16 * u;
-        pc[u] = (i < n && tx < nb) ? in(i, kb + tx) : 0.0;
+    for (int u = 0; u < PCN; ++u) {
+        const int i = panel_row(u);
+        pc[u] = (i >= 0 && tx < nb) ? in(i, kb + tx) : 0.0;
     }
     double mx = 0.0;
     for (int k = tid; k < n; k += SWEEP_THREADS) mx = fmax(mx, fabs(A[k * ld + k]));
@@ -3656,7 +3675,11 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_step_kernel(EighArgs e, P
         bj = (blk % ncol) * 32;
         return blk < nrow * ncol && bi != kb && bj != kb;
     };
-    auto tile_load = [&](int bi, int bj, MF::acc_t (&acc)[2][2]) {       // the accumulators start from M itself
+    struct Tile {
+        MF::acc_t acc[2][2];
+        double cb[BIG ? NB / MF::KT : 1][2];                             // BIG: the column operands C_j of the tile, all K steps
+    };
+    auto tile_load = [&](int bi, int bj, Tile& t) {                      // the accumulators start from M itself
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -3665,18 +3688,29 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_step_kernel(EighArgs e, P
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int j = bj + 16 * q + MF::d_col(lane);
-                    acc[a][q][r] = (i < n && j < n) ? in(i, j) : 0.0;
+                    t.acc[a][q][r] = (i < n && j < n) ? in(i, j) : 0.0;
                 }
             }
+        if (BIG) {
+#pragma unroll
+            for (int ks = 0; ks < NB / MF::KT; ++ks) {
+                const int kk = ks * MF::KT + MF::ab_k(lane);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = bj + 16 * q + MF::a_row(lane);
+                    t.cb[BIG ? ks : 0][q] = (j < n && kk < nb) ? in(j, kb + kk) : 0.0;
+                }
+            }
+        }
     };
-    MF::acc_t acc0[2][2];
+    Tile t0;
     int bi0, bj0;
     const bool have0 = tile_at(wave, bi0, bj0);
-    if (have0) tile_load(bi0, bj0, acc0);
+    if (have0) tile_load(bi0, bj0, t0);
 #pragma unroll
-    for (int u = 0; u < SWEEP_MAXN / 16; ++u) {
-        const int i = ty + 16 * u;
-        if (i < n) Cs[i * LD + tx] = pc[u];
+    for (int u = 0; u < PCN; ++u) {
+        const int l = ty + 16 * u;
+        if (BIG || l < n) Cs[l * LD + tx] = pc[u];
     }
     for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
     if (lane == 0) red[wave] = mx;
@@ -3690,7 +3724,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_step_kernel(EighArgs e, P
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const bool ok = sweep_pivot_block(Cs + kb * LD, Pv, rowk, need, nb, lane);
+        const bool ok = sweep_pivot_block(Cs + piv0 * LD, Pv, rowk, need, nb, lane);
         if (lane == 0) s_ok = ok ? 1 : 0;
     }
     __syncthreads();
@@ -3701,23 +3735,23 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_step_kernel(EighArgs e, P
     }
     // ---- T = -(C Pv) for the rows of the slab
     {
-        const int t0 = r0 >> 4, t1 = (r1 + 15) >> 4;
-        for (int it = t0 + wave; it < t1; it += SWEEP_THREADS / 64) {
+        const int t0r = r0 >> 4, t1r = (r1 + 15) >> 4;
+        for (int it = t0r + wave; it < t1r; it += SWEEP_THREADS / 64) {
             const int row = it * 16 + MF::a_row(lane);
             MF::acc_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int k0 = 0; k0 < NB; k0 += MF::KT) {
                 const int kk = k0 + MF::ab_k(lane);
-                const double a = row < n ? Cs[row * LD + kk] : 0.0;
+                const double a = row < r1 ? Cs[crow(row) * LD + kk] : 0.0;
                 a0 = MF::mma(a, Pv[kk * LD + MF::a_row(lane)], a0);
                 a1 = MF::mma(a, Pv[kk * LD + 16 + MF::a_row(lane)], a1);
             }
 #pragma unroll
             for (int r = 0; r < MF::NREG; ++r) {
                 const int i = it * 16 + MF::d_row(lane, r);
-                if (i < n) {
-                    Ts[i * LD + MF::d_col(lane)] = -a0[r];
-                    Ts[i * LD + 16 + MF::d_col(lane)] = -a1[r];
+                if (i < r1) {
+                    Ts[trow(i) * LD + MF::d_col(lane)] = -a0[r];
+                    Ts[trow(i) * LD + 16 + MF::d_col(lane)] = -a1[r];
                 }
             }
         }
@@ -3726,25 +3760,32 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_step_kernel(EighArgs e, P
     SKF_STAMP(2)
     // ---- M_ij - T_i C_j^T outside the pivot rows / columns: a wave owns 32 x 32 outputs at a time
     {
-        auto tile_finish = [&](int bi, int bj, MF::acc_t (&acc)[2][2]) {
-#pragma unroll 2
-            for (int k0 = 0; k0 < NB; k0 += MF::KT) {
+        auto tile_finish = [&](int bi, int bj, Tile& t) {
+            auto kstep = [&](int k0) {
                 const int kk = k0 + MF::ab_k(lane);
                 double ta[2], cb[2];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const int i = bi + 16 * a + MF::a_row(lane);
-                    ta[a] = i < n ? -Ts[i * LD + kk] : 0.0;
+                    ta[a] = i < r1 ? -Ts[trow(i) * LD + kk] : 0.0;
                 }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int j = bj + 16 * q + MF::a_row(lane);
-                    cb[q] = j < n ? Cs[j * LD + kk] : 0.0;
+                    if (BIG) cb[q] = t.cb[BIG ? k0 / MF::KT : 0][q];
+                    else cb[q] = j < n ? Cs[j * LD + kk] : 0.0;
                 }
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) acc[a][q] = MF::mma(ta[a], cb[q], acc[a][q]);
+                    for (int q = 0; q < 2; ++q) t.acc[a][q] = MF::mma(ta[a], cb[q], t.acc[a][q]);
+            };
+            if (BIG) {                                                   // (unrolled: the operands of a K step are named registers)
+#pragma unroll
+                for (int k0 = 0; k0 < NB; k0 += MF::KT) kstep(k0);
+            } else {
+#pragma unroll 2
+                for (int k0 = 0; k0 < NB; k0 += MF::KT) kstep(k0);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -3755,17 +3796,17 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_step_kernel(EighArgs e, P
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int j = bj + 16 * q + MF::d_col(lane);
-                        if (j < n && !(j >= kb && j < kb + nb)) out(i, j, acc[a][q][r]);
+                        if (j < n && !(j >= kb && j < kb + nb)) out(i, j, t.acc[a][q][r]);
                     }
                 }
         };
-        if (have0) tile_finish(bi0, bj0, acc0);
+        if (have0) tile_finish(bi0, bj0, t0);
         for (int blk = wave + SWEEP_THREADS / 64; blk < nrow * ncol; blk += SWEEP_THREADS / 64) {
             int bi, bj;
             if (!tile_at(blk, bi, bj)) continue;
-            MF::acc_t acc[2][2];
-            tile_load(bi, bj, acc);
-            tile_finish(bi, bj, acc);
+            Tile t;
+            tile_load(bi, bj, t);
+            tile_finish(bi, bj, t);
         }
     }
     SKF_STAMP(3)
@@ -3773,11 +3814,11 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_step_kernel(EighArgs e, P
     for (int i = r0 + ty; i < r1; i += 16) {
         if (tx >= nb) continue;
         if (i >= kb && i < kb + nb) out(i, kb + tx, Pv[(i - kb) * LD + tx]);
-        else out(i, kb + tx, Ts[i * LD + tx]);
+        else out(i, kb + tx, Ts[trow(i) * LD + tx]);
     }
     for (int idx = tid; idx < nb * (r1 - r0); idx += SWEEP_THREADS) {
         const int c = idx / (r1 - r0), i = r0 + idx % (r1 - r0);
-        if (!(i >= kb && i < kb + nb)) out(kb + c, i, Ts[i * LD + c]);
+        if (!(i >= kb && i < kb + nb)) out(kb + c, i, Ts[trow(i) * LD + c]);
     }
     SKF_STAMP(4)
 #ifdef SKF_PROBE_STAMPS

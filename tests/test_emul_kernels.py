@@ -362,6 +362,33 @@ def test_pinv_sweep_one_launch_per_block_step_keeps_the_bits(rt, n):
     assert relerr(A @ one @ A, A) < 1e-11
 
 
+@pytest.mark.parametrize('n', [257, 300, 420])
+def test_pinv_blocked_sweep_above_order_256(rt, n):
+    """Orders above 256 (round 5): the step-per-launch sweep with the column operands of the update read from the matrix in
+    memory (sweep_step_kernel<true>; the LDS holds the pivot rows and the slab's rows only) against scipy and against the
+    blocked Cholesky inverse it replaces there (SKF_SWEEP_BIG=0); a matrix that fails a pivot is handed to the deflation."""
+    import os
+    import scipy.linalg as spla
+    rs = np.random.RandomState(n)
+    G = rs.rand(3 * n + 5, n)
+    A = G.T @ G
+    got = run_pinv(rt, nat.SKF_F64, A)
+    os.environ['SKF_SWEEP_BIG'] = '0'
+    try:
+        old = run_pinv(rt, nat.SKF_F64, A)
+    finally:
+        os.environ.pop('SKF_SWEEP_BIG', None)
+    want = spla.pinv(A)
+    bound = 1e-9 * max(1.0, np.linalg.cond(A) * 1e-3)
+    assert relerr(got, want) < bound and relerr(got, old) < bound
+    assert relerr(A @ got @ A, A) < 1e-11
+    assert np.abs(got - got.T).max() <= 1e-12 * np.abs(got).max()
+    if n == 300:
+        Gd = rs.rand(n - 40, n)                        # rank n - 40: a pivot of the last blocks fails
+        Ad = Gd.T @ Gd
+        assert relerr(run_pinv(rt, nat.SKF_F64, Ad), spla.pinv(Ad)) < 1e-7
+
+
 def test_pinv_rank_deficient_truncates_like_scipy(rt):
     """reference tests/test_n_run.py:14: rank 50 factor of 30 objects -> Gram has rank 30."""
     import scipy.linalg as spla

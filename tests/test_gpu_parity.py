@@ -75,6 +75,12 @@ def test_pinv_blocked_sweep(rt, n):
     K.test_pinv_sweep_one_launch_per_block_step_keeps_the_bits(rt, n)
 
 
+@pytest.mark.parametrize('n', [257, 300, 420, 512, 777, 1023])
+def test_pinv_blocked_sweep_above_order_256(rt, n):
+    """Orders 257 .. 1023 on the hardware (sweep_step_kernel<true>: column operands from memory)."""
+    K.test_pinv_blocked_sweep_above_order_256(rt, n)
+
+
 def test_pinv_rank_deficient(rt):
     K.test_pinv_rank_deficient_truncates_like_scipy(rt)
     K.test_pinv_zero_and_diagonal(rt)
