@@ -619,6 +619,27 @@ def test_relation_pipelined_schedule_matches_the_staged_one_and_the_oracle(monke
         assert relerr(out['pipelined', 'f64'][1][k][0], So[k][0]) < 1e-10
 
 
+def test_fit_with_a_rank_above_256(monkeypatch):
+    """A rank above 256 inside a fit (round 5): the pseudo-inverses of one pass are ONE batch of step-per-launch sweeps --
+    orders 300, 70 and 40 side by side through sweep_step_kernel<true> -- where the blocked Cholesky inverse + unpack ran
+    before (SKF_SWEEP_BIG=0).  Both against the oracle, f64; the relation of the small type is walked by the pipeline's
+    mixed-rank rules (staged schedule here: one rank is below 65)."""
+    rs = np.random.RandomState(17)
+    types = ['a', 'b', 'c']
+    n = {'a': 420, 'b': 150, 'c': 90}
+    rank = {'a': 300, 'b': 70, 'c': 40}
+    R = {('a', 'b'): [rs.rand(420, 150)], ('a', 'c'): [rs.rand(420, 90) - 0.3], ('b', 'c'): [rs.rand(150, 90)]}
+    G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.05 for t in types}
+    Go, So = orc.dfmf(R, {}, types, rank, max_iter=2, G0=G0)
+    for big in ('1', '0'):
+        monkeypatch.setenv('SKF_SWEEP_BIG', big)
+        G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=2, G0=G0, dtype='f64')
+        for t in types:
+            assert relerr(G[t, t], Go[t, t]) < 1e-11, (big, t)          # measured 1e-13 .. 1e-12 (either route)
+        for k in So:
+            assert relerr(S[k][0], So[k][0]) < 8e-11, (big, k)        # measured 2e-12 .. 8e-12
+
+
 @pytest.mark.parametrize('dtype', ['f64', 'bf16'])
 def test_round5_schedule_switches_keep_every_bit(dtype, monkeypatch):
     """Round 5: (a) split-K Gram products compute only the tiles on / below the diagonal and the reduce mirrors the rest

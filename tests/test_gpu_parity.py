@@ -167,6 +167,12 @@ def test_relation_pipeline_dfmf_and_dfmc_against_the_staged_schedule_and_the_ora
     E.test_dfmc_runs_the_relation_pipeline_with_the_completion_between_its_contractions(monkeypatch)
 
 
+def test_fit_with_a_rank_above_256_on_the_hardware(monkeypatch):
+    """Orders 300 / 70 / 40 in one batch of step-per-launch sweeps inside a fit, and the Cholesky route, against the oracle."""
+    import test_emul_engine as E
+    E.test_fit_with_a_rank_above_256(monkeypatch)
+
+
 @pytest.mark.parametrize('dtype', ['bf16', 'f32'])
 def test_two_runs_give_bit_identical_factors(dtype):
     """No float atomics and a fixed order for every sum (split-K slices, E / D contributions of the relations on the second
