@@ -324,6 +324,31 @@ static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void
         SKF_FAIL(SKF_E_INVALID, "unsupported operand type combination (c=%d a=%d b=%d)", ty.c, ty.a, ty.b);
 }
 
+// Two independent all-f64 products of the c x c chains in ONE launch (gemm_mfma_pair_kernel) when both take the deep
+// unsplit tile of the matrix-core engine -- what run_gemm picks for them one by one; anything else: two launches.
+static void run_gemm_pair_f64(int engine, GemmArgs a, GemmArgs b, hipStream_t st, bool allow) {
+    const GemmTypes ty{SKF_F64, SKF_F64, SKF_F64};
+    auto deep = [&](const GemmArgs& g) {
+        if (g.M <= 0 || g.N <= 0 || g.sym || g.epi == EPI_SQDIFF) return false;
+        const TileCfg t = gemm_tile(ty, engine, g, true, false);
+        return engine == SKF_ENGINE_MFMA && t.bk == 64 && t.bm == 32 && pick_splits(t, g.M, g.N, g.K, false) == 1;
+    };
+    if (!allow || !deep(a) || !deep(b)) {
+        run_gemm(ty, engine, a, 0, nullptr, 0, st);
+        run_gemm(ty, engine, b, 0, nullptr, 0, st);
+        return;
+    }
+    const TileCfg t = gemm_tile(ty, engine, a, true, false);
+    for (GemmArgs* g : {&a, &b}) {                  // (as run_gemm sets an unsplit launch up)
+        g->k_chunk = cdiv(g->K > 0 ? g->K : 1, t.bk) * t.bk;
+        g->part = nullptr;
+        g->sym = 0;
+    }
+    const int gx = std::max(cdiv(a.N, t.bn), cdiv(b.N, t.bn)), gy = std::max(cdiv(a.M, t.bm), cdiv(b.M, t.bm));
+    hipLaunchKernelGGL((gemm_mfma_pair_kernel<double, double, double, 1, 1, 64, 0>), dim3(gx, gy, 2), dim3(GEMM_THREADS), 0, st, a, b);
+    check_launch("gemm_pair");
+}
+
 // ---- bf16 relation contraction --------------------------------------------------------------
 static inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
 
@@ -504,6 +529,7 @@ struct Switches {
                                    //                       spread over row slabs (sweep_step_kernel); below: one workgroup per matrix, one launch.
                                    //                       0 = never (A/B; same bits either way)
     int sweep_rows = 32;           // SKF_SWEEP_ROWS=32|64.. rows of a slab (a multiple of 32)
+    bool no_pairs = false;         // SKF_CHAIN_PAIRS=0     the independent c x c products of a relation's chain as launches of their own (A/B; same bits)
     bool no_sweep_big = false;     // SKF_SWEEP_BIG=0       orders above 256 on the blocked Cholesky inverse + unpack, as before round 5 (A/B)
     bool early_update = true;      // SKF_EARLY_UPDATE=0    pipeline: every type is updated at the end of the iteration (default: a type whose last relation is through
                                    //                       and that nothing reads any more is updated on the second stream, underneath the remaining contractions)
@@ -529,6 +555,7 @@ struct Switches {
         { const char* sm = getenv("SKF_SWEEP_STEP_MIN"); if (sm) w.sweep_step_min = atoi(sm); }
         { const char* sr = getenv("SKF_SWEEP_ROWS"); if (sr && atoi(sr) >= 32) w.sweep_rows = (atoi(sr) + 31) / 32 * 32; }
         { const char* sb = getenv("SKF_SWEEP_BIG"); w.no_sweep_big = sb && atoi(sb) == 0; }
+        { const char* cp = getenv("SKF_CHAIN_PAIRS"); w.no_pairs = cp && atoi(cp) == 0; }
         const char* st = getenv("SKF_SIDE_TILE");
         w.side_tile = st ? atoi(st) : 0;
         const char* ap = getenv("SKF_AUX_PRIO");
@@ -1100,10 +1127,24 @@ static void theta_terms(skf_plan* p, hipStream_t st) { theta_terms_rows(p, -1, f
 // [Xp, Xn] (+)= split( L * Gram * Rr )  helper for B = S Gram_j S^T and D = S^T Gram_i S
 // tmp = first product, then split-store/acc of the second.
 static void relation_small_terms(skf_plan* p, RelState& r, int nan_upd, int epi_split, void* Bp, void* Bn,
-                                 void* Dp, void* Dn, bool want_row, bool want_col, hipStream_t st) {
+                                 void* Dp, void* Dn, bool want_row, bool want_col, hipStream_t st, void* U2 = nullptr) {
     TypeState& ti = p->types[r.row];
     TypeState& tj = p->types[r.col];
     const int ci = ti.c, cj = tj.c;
+    if (want_row && want_col && U2 && U2 != r.U.ptr) {
+        // both sides, and a second ci x cj buffer: the two Gram products side by side in one launch, then the two products
+        // that add into the B sums (one launch as well unless both add into the SAME sums: a relation of a type with itself)
+        const bool pairs = !p->sw.no_pairs;
+        GemmArgs gu = gemm_args(r.S.ptr, cj, 1, tj.Gram.ptr, cj, 1, r.U.ptr, cj, ci, cj, cj, EPI_STORE, 0);      // U = S Gram_j
+        GemmArgs gv = gemm_args(ti.Gram.ptr, ci, 1, r.S.ptr, cj, 1, U2, cj, ci, cj, ci, EPI_STORE, 0);          // U2 = Gram_i S
+        run_gemm_pair_f64(p->engine, gu, gv, st, pairs);
+        GemmArgs gb = gemm_args(r.U.ptr, cj, 1, r.S.ptr, 1, cj, Bp, ci, ci, ci, cj, epi_split, nan_upd);         // B = U S^T
+        gb.C2 = Bn;
+        GemmArgs gd = gemm_args(r.S.ptr, 1, cj, U2, cj, 1, Dp, cj, cj, cj, ci, epi_split, nan_upd);              // D = S^T U2
+        gd.C2 = Dn;
+        run_gemm_pair_f64(p->engine, gb, gd, st, pairs && Bp != Dp && Bn != Dn);
+        return;
+    }
     if (want_row) {
         // U = S Gram_j (ci x cj);  B = U S^T (ci x ci)          tmp2 of _dfmf.py:260
         GemmArgs g = gemm_args(r.S.ptr, cj, 1, tj.Gram.ptr, cj, 1, r.U.ptr, cj, ci, cj, cj, EPI_STORE, 0);
@@ -1120,6 +1161,17 @@ static void relation_small_terms(skf_plan* p, RelState& r, int nan_upd, int epi_
         g.C2 = Dn;
         small_gemm(p, g, st);
     }
+}
+
+// f32 engines: the f32 roundings of a type's two B sums in ONE launch (they were two)
+static void cast_b_sums(TypeState& t, hipStream_t st) {
+    const int cc = t.c * t.c;
+    CastBatch cb;
+    memset(&cb, 0, sizeof cb);
+    cb.src[0] = (const double*)t.Bn_tot.ptr; cb.dst[0] = (float*)t.Bn32.ptr; cb.count[0] = cc;
+    cb.src[1] = (const double*)t.Bp_tot.ptr; cb.dst[1] = (float*)t.Bp32.ptr; cb.count[1] = cc;
+    hipLaunchKernelGGL(cast_batched_kernel, dim3(elem_grid(cc), 2), dim3(256), 0, st, cb);
+    check_launch("cast_batched");
 }
 
 // Fused E/D update of one relation side (MFMA engine): E (+)= (X Sop)+ + G Bn, D (+)= (X Sop)- + G Bp
@@ -2147,12 +2199,7 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
                 const void* Bn = t.Bn_tot.ptr;
                 const void* Bp = t.Bp_tot.ptr;
                 if (!p->f64) {
-                    const int cc = t.c * t.c;
-                    hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid(cc)), dim3(256), 0, ax, (float*)t.Bn32.ptr,
-                                       (int64_t)cc, (const double*)t.Bn_tot.ptr, (int64_t)cc, (int64_t)1, (int64_t)cc);
-                    hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid(cc)), dim3(256), 0, ax, (float*)t.Bp32.ptr,
-                                       (int64_t)cc, (const double*)t.Bp_tot.ptr, (int64_t)cc, (int64_t)1, (int64_t)cc);
-                    check_launch("cast");
+                    cast_b_sums(t, ax);
                     Bn = t.Bn32.ptr;
                     Bp = t.Bp32.ptr;
                 }
@@ -2238,6 +2285,7 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
         TypeState& tj = p->types[r.col];
         const int ci = ti.c, cj = tj.c;
         wait(ax, ev_r(k, R_WX));
+        bool s32_here = false;
         if (chain) {
             BackboneBatch bb;
             bb.Ki[0] = (const double*)ti.K.ptr; bb.Kj[0] = (const double*)tj.K.ptr;
@@ -2260,15 +2308,23 @@ static void iterate_owned(skf_plan* p, hipStream_t st) {
             GemmArgs g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);       // T1 = K_i W
             small_gemm(p, g, ax);
             g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);                // S = T1 K_j
+            s32_here = !p->f64 && fused && !p->sw.no_pairs;        // f32 engines: the rounding of S leaves the same launch
+            if (s32_here) {
+                g.epi = EPI_STORE_F32;
+                g.C2 = r.S32.ptr;
+                g.ldc2 = cj;
+            }
             small_gemm(p, g, ax);
             relation_small_terms(p, r, nan_upd, EPI_SPLIT_ACC, ti.Bp_tot.ptr, ti.Bn_tot.ptr, tj.Bp_tot.ptr, tj.Bn_tot.ptr,
-                                 true, true, ax);
+                                 true, true, ax, r.T1.ptr);           // (T1 is free once S is there)
         }
         Sm[k] = r.S.ptr;
         if (!p->f64 && fused) {
-            hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid((int64_t)ci * cj)), dim3(256), 0, ax,
-                               (float*)r.S32.ptr, (int64_t)cj, (const double*)r.S.ptr, (int64_t)cj, (int64_t)ci, (int64_t)cj);
-            check_launch("cast");
+            if (!s32_here) {
+                hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid((int64_t)ci * cj)), dim3(256), 0, ax,
+                                   (float*)r.S32.ptr, (int64_t)cj, (const double*)r.S.ptr, (int64_t)cj, (int64_t)ci, (int64_t)cj);
+                check_launch("cast");
+            }
             Sm[k] = r.S32.ptr;
         }
     };
@@ -2545,12 +2601,7 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         const void* Bn = t.Bn_tot.ptr;
         const void* Bp = t.Bp_tot.ptr;
         if (!p->f64) {
-            const int cc = t.c * t.c;
-            hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid(cc)), dim3(256), 0, ax, (float*)t.Bn32.ptr,
-                               (int64_t)cc, (const double*)t.Bn_tot.ptr, (int64_t)cc, (int64_t)1, (int64_t)cc);
-            hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid(cc)), dim3(256), 0, ax, (float*)t.Bp32.ptr,
-                               (int64_t)cc, (const double*)t.Bp_tot.ptr, (int64_t)cc, (int64_t)1, (int64_t)cc);
-            check_launch("cast");
+            cast_b_sums(t, ax);
             Bn = t.Bn32.ptr;
             Bp = t.Bp32.ptr;
         }
@@ -2572,14 +2623,22 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         GemmArgs g = gemm_args(ti.K.ptr, ci, 1, r.W.ptr, cj, 1, r.T1.ptr, cj, ci, cj, ci, EPI_STORE, 0);       // T1 = K_i W
         small_gemm(p, g, ax);
         g = gemm_args(r.T1.ptr, cj, 1, tj.K.ptr, cj, 1, r.S.ptr, cj, ci, cj, cj, EPI_STORE, 1);                // S = T1 K_j
+        const bool s32_here = !p->f64 && !p->sw.no_pairs;          // f32 engines: the rounding of S leaves the same launch
+        if (s32_here) {
+            g.epi = EPI_STORE_F32;
+            g.C2 = r.S32.ptr;
+            g.ldc2 = cj;
+        }
         small_gemm(p, g, ax);
         relation_small_terms(p, r, nan_upd, EPI_SPLIT_ACC, ti.Bp_tot.ptr, ti.Bn_tot.ptr, tj.Bp_tot.ptr, tj.Bn_tot.ptr,
-                             true, true, ax);
+                             true, true, ax, r.T1.ptr);               // (T1 is free once S is there)
         Sm[q] = r.S.ptr;
         if (!p->f64) {
-            hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid((int64_t)ci * cj)), dim3(256), 0, ax,
-                               (float*)r.S32.ptr, (int64_t)cj, (const double*)r.S.ptr, (int64_t)cj, (int64_t)ci, (int64_t)cj);
-            check_launch("cast");
+            if (!s32_here) {
+                hipLaunchKernelGGL((cast_kernel<float, double>), dim3(elem_grid((int64_t)ci * cj)), dim3(256), 0, ax,
+                                   (float*)r.S32.ptr, (int64_t)cj, (const double*)r.S.ptr, (int64_t)cj, (int64_t)ci, (int64_t)cj);
+                check_launch("cast");
+            }
             Sm[q] = r.S32.ptr;
         }
     };

@@ -38,7 +38,8 @@ enum Epi {
     EPI_SPLIT_STORE = 2,   // C  = max(v,0) ; C2  = max(-v,0)
     EPI_SPLIT_ACC = 3,     // C += max(v,0) ; C2 += max(-v,0)       (_dfmf.py:256-258,278-282)
     EPI_MASKED_STORE = 4,  // C  = v where mask != 0                (_dfmc.py:319-325)
-    EPI_SQDIFF = 5         // per-workgroup partial of sum (C - v)^2 -> C2[block]  (C untouched)
+    EPI_SQDIFF = 5,        // per-workgroup partial of sum (C - v)^2 -> C2[block]  (C untouched)
+    EPI_STORE_F32 = 6      // C = v (f64) ; C2 = (float)v: a backbone and its f32 rounding for the f32 engines' side products
 };
 
 struct GemmArgs {
@@ -134,6 +135,10 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int m, int n, 
             break;
         case EPI_MASKED_STORE:
             if (mask_test(g, m, n)) C[i] = v;
+            break;
+        case EPI_STORE_F32:
+            C[i] = v;
+            ((float*)g.C2)[i2] = (float)v;
             break;
         default: break;
     }
@@ -334,7 +339,8 @@ __device__ __forceinline__ void stage_store(T (*lds)[LD], const TS (&reg)[ROWS *
 // spreads the unrolled staging code over 277 registers and halves the occupancy)
 // FM >= 0: compile-time staging modes (bits 0-1 operand A, 2-3 operand B), conditions checked by the host.
 template <typename T, typename TA, typename TB, int WR, int WC, int BK, int TAG, int FM = -1>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_mfma_body(const GemmArgs& g, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z,
+                                               const unsigned grid_x, const unsigned grid_z) {
     typedef Mfma<T> MF;
     constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
     // Row pitch of the k-major LDS tiles.  The fragment reads (consecutive lanes, consecutive words) are conflict-free at any
@@ -357,12 +363,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * (WR * MF::MT), wn0 = (wave & 1) * (WC * MF::NT);
-    int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    int bm0 = bid_y * BM, bn0 = bid_x * BN;
     if (g.sym) {
         // symmetric product: the launch lists only the tiles on / below the diagonal, blockIdx.x = their running number
         // row tile by row tile (a launch of ALL tiles whose upper ones return at once leaves whole XCDs idle: workgroups go
         // to the XCDs round robin, and with 2 x 4 tiles the skipped ones are always the same residues mod 8)
-        int left = (int)blockIdx.x, by = 0;
+        int left = (int)bid_x, by = 0;
         for (;; ++by) {
             int cnt = (by * BM + BM - 1) / BN + 1;                // column tiles of row tile `by` that touch the lower triangle
             const int all = (g.N + BN - 1) / BN;
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
         bm0 = by * BM;
         bn0 = left * BN;
     }
-    const int kz0 = blockIdx.z * g.k_chunk;
+    const int kz0 = bid_z * g.k_chunk;
     const int kz1 = (kz0 + g.k_chunk < g.K) ? kz0 + g.k_chunk : g.K;
     const TA* __restrict__ A = (const TA*)g.A;
     const TB* __restrict__ B = (const TB*)g.B;
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
     }
 
     // ---- epilogue
-    const bool split = (gridDim.z > 1);
+    const bool split = (grid_z > 1);
     T sq = (T)0;
     if (!split && (g.epi == EPI_ACC || g.epi == EPI_SPLIT_ACC)) {          // (uniform)
 #pragma unroll
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
                 if (m < g.M && n < g.N) {
                     const T v = acc[i][j][r];
                     if (split) {
-                        ((T*)g.part)[((int64_t)blockIdx.z * g.M + m) * g.N + n] = v;
+                        ((T*)g.part)[((int64_t)bid_z * g.M + m) * g.N + n] = v;
                     } else if (g.epi == EPI_SQDIFF) {
                         const int64_t ci = (int64_t)m * g.ldc + n;
                         const T rv = g.c_bf16 ? (T)bf16_to_f32(((const uint16_t*)g.C)[ci]) : ((const T*)g.C)[ci];
@@ -491,9 +497,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) 
         if (tid == 0) {
             T s = (T)0;
             for (int w = 0; w < GEMM_THREADS / 64; ++w) s += red[w];
-            ((T*)g.C2)[blockIdx.y * gridDim.x + blockIdx.x] = s;
+            ((T*)g.C2)[bid_y * grid_x + bid_x] = s;
         }
     }
+}
+
+template <typename T, typename TA, typename TB, int WR, int WC, int BK, int TAG, int FM = -1>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) {
+    gemm_mfma_body<T, TA, TB, WR, WC, BK, TAG, FM>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
+}
+
+// TWO independent unsplit products in one launch (blockIdx.z = which; round 5): the c x c chains of a relation hold pairs of
+// products that do not depend on each other -- S Gram_j beside Gram_i S, U S^T beside S^T U' -- and a launch on the second
+// stream costs its ~10 us whatever it computes.  The grid covers the larger tile count; a workgroup without a tile in its
+// product returns.  Element by element the arithmetic of gemm_mfma_kernel.
+template <typename T, typename TA, typename TB, int WR, int WC, int BK, int TAG, int FM = -1>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_pair_kernel(GemmArgs g0, GemmArgs g1) {
+    typedef Mfma<T> MF;
+    constexpr int BM = 2 * WR * MF::MT, BN = 2 * WC * MF::NT;
+    const GemmArgs g = blockIdx.z ? g1 : g0;
+    if ((int)(blockIdx.y * BM) >= g.M || (int)(blockIdx.x * BN) >= g.N) return;
+    gemm_mfma_body<T, TA, TB, WR, WC, BK, TAG, FM>(g, blockIdx.x, blockIdx.y, 0u, gridDim.x, 1u);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -645,7 +645,8 @@ def test_round5_schedule_switches_keep_every_bit(dtype, monkeypatch):
     """Round 5: (a) split-K Gram products compute only the tiles on / below the diagonal and the reduce mirrors the rest
     (SKF_GRAM_SYM=0: every tile) -- element (a, b) and (b, a) are the same products added in the same order; (b) a type
     whose last relation is through is updated on the second stream at once (SKF_EARLY_UPDATE=0: at the end of the
-    iteration).  Neither changes any arithmetic: factors and backbones are bit for bit those of the plain schedule.
+    iteration); (c) the independent c x c products of a relation's chain go out two to a launch (SKF_CHAIN_PAIRS=0: one
+    by one).  None changes any arithmetic: factors and backbones are bit for bit those of the plain schedule.
     Ranks 66 / 192 / 68 over 512+ objects: the Gram products are split over K and the order-192 one skips a tile; type
     `b` finishes with the first relation pair and is updated early."""
     rs = np.random.RandomState(9)
@@ -656,14 +657,14 @@ def test_round5_schedule_switches_keep_every_bit(dtype, monkeypatch):
     G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.05 for t in types}
     runs = {}
     for name, env in (('plain', {'SKF_GRAM_SYM': '0', 'SKF_EARLY_UPDATE': '0'}), ('sym', {'SKF_EARLY_UPDATE': '0'}),
-                      ('early', {'SKF_GRAM_SYM': '0'})):
-        for k in ('SKF_GRAM_SYM', 'SKF_EARLY_UPDATE'):
+                      ('early', {'SKF_GRAM_SYM': '0'}), ('unpaired', {'SKF_GRAM_SYM': '0', 'SKF_EARLY_UPDATE': '0', 'SKF_CHAIN_PAIRS': '0'})):
+        for k in ('SKF_GRAM_SYM', 'SKF_EARLY_UPDATE', 'SKF_CHAIN_PAIRS'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         runs[name] = _dfmf.dfmf(R, {}, types, rank, max_iter=2, G0=G0, dtype=dtype)
     Gp, Sp = runs['plain']
-    for name in ('sym', 'early'):
+    for name in ('sym', 'early', 'unpaired'):
         G, S = runs[name]
         for t in types:
             assert np.array_equal(G[t, t], Gp[t, t]), (name, t)

@@ -167,6 +167,13 @@ def test_relation_pipeline_dfmf_and_dfmc_against_the_staged_schedule_and_the_ora
     E.test_dfmc_runs_the_relation_pipeline_with_the_completion_between_its_contractions(monkeypatch)
 
 
+@pytest.mark.parametrize('dtype', ['f64', 'bf16'])
+def test_round5_schedule_switches_keep_every_bit_on_the_hardware(dtype, monkeypatch):
+    """Symmetric Gram launch, early update, chain products two to a launch: real streams, events and grids this time."""
+    import test_emul_engine as E
+    E.test_round5_schedule_switches_keep_every_bit(dtype, monkeypatch)
+
+
 def test_fit_with_a_rank_above_256_on_the_hardware(monkeypatch):
     """Orders 300 / 70 / 40 in one batch of step-per-launch sweeps inside a fit, and the Cholesky route, against the oracle."""
     import test_emul_engine as E
