@@ -1428,10 +1428,9 @@ static void known_operands(skf_plan* p, RelState& r, hipStream_t st, bool second
     if (second_stream) mixed_gemm_unsplit(p, g, st);
     else mixed_gemm(p, g, st);
     if (p->bf16) launch_to_bf16<float>((uint16_t*)r.FiB.ptr, r.kn_ldf, (const float*)r.Tm.ptr, (int64_t)ci, tj.n, ci, false, st);
-    g = gemm_args(r.S.ptr, 1, cj, ti.Gram.ptr, ci, 1, r.U2.ptr, ci, cj, ci, ci, EPI_STORE, 0);
-    small_gemm(p, g, st);
-    g = gemm_args(r.S.ptr, cj, 1, tj.Gram.ptr, cj, 1, r.T1.ptr, cj, ci, cj, cj, EPI_STORE, 0);
-    small_gemm(p, g, st);
+    g = gemm_args(r.S.ptr, 1, cj, ti.Gram.ptr, ci, 1, r.U2.ptr, ci, cj, ci, ci, EPI_STORE, 0);           // U2 = S^T Gram_i
+    GemmArgs h = gemm_args(r.S.ptr, cj, 1, tj.Gram.ptr, cj, 1, r.T1.ptr, cj, ci, cj, cj, EPI_STORE, 0);    // T1 = S Gram_j
+    run_gemm_pair_f64(p->engine, g, h, st, !p->sw.no_pairs);                                            // (independent: one launch)
     g = gemm_args(r.T1.ptr, cj, 1, r.S.ptr, 1, cj, r.Bf.ptr, ci, ci, ci, cj, EPI_STORE, 0);
     small_gemm(p, g, st);
 }
@@ -2583,6 +2582,9 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
         SKF_HIP(hipEventRecord(p->ev_fork, st));
         SKF_HIP(hipStreamWaitEvent(ax, p->ev_fork, 0));
     }
+    // (Round 5, measured and not kept: for DFMC on known-entry lists the pseudo-inverses on the MAIN stream behind the first
+    // relation's pass -- here they take 0.78 ms underneath the other relations' passes, 0.2 ms alone; config 5 147.9 against
+    // 149.3 it/s: the passes they hold up are worth more than the chains they release.)
     plan_pinv(p, all, ax);
     SKF_HIP(hipMemsetAsync((char*)p->ws_base + p->btot_off, 0, p->btot_bytes, ax));
 
