@@ -166,6 +166,17 @@ def fill_unknown_device(data, mask, strategy, value=0.0, dtype='f64', runtime=No
     return DeviceMatrix(buf, (rows, cols))
 
 
+def upload_matrix(data, dtype='f64', runtime=None):
+    """Host matrix -> DeviceMatrix of the engine dtype (bf16: rounded on the host, as upload_graph does)."""
+    rt = runtime or nat.get_runtime()
+    code = nat.DTYPES[dtype]
+    arr = np.ascontiguousarray(data, dtype=nat.NP_DTYPE[code])
+    if arr.ndim != 2:
+        raise ValueError('relation data is not a matrix')
+    up = nat.to_bf16_bits(arr) if code == nat.SKF_BF16 else arr
+    return DeviceMatrix(rt.mem.from_host(up), arr.shape)
+
+
 def _all_reduce_sum(t):
     """Sum a tensor view over the process group (RCCL for GPU tensors; a gloo group -- CPU tests,
     single-GPU smoke runs -- stages GPU tensors through the host)."""

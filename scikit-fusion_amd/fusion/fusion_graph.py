@@ -53,6 +53,10 @@ class ObjectType(object):
 #   'row_mean'         -> every unknown entry takes the mean of its row, and the result carries no mask any more; a row
 #                        without a usable mean (masked input: non-finite; plain input: NaN) takes the matrix mean
 #   'col_mean'         -> the same along the columns
+#   a MaskedArray that masks nothing ('row_mean' / 'col_mean'): numpy.ma masks an INFINITE line mean by itself, and the
+#                        entries that would take it come back masked with 1 beneath; a NaN line mean takes the matrix
+#                        mean (golden tags nomask / nomaskfinite; tools/fuzz_fill.py compares 78 000 random inputs with the
+#                        reference itself)
 # The same rules run on the device in skf_fill_unknown (`Relation.filled_device`).
 def _values_and_mask(x):
     values = np.ma.getdata(x)
@@ -94,10 +98,22 @@ def _fill_lines(x, axis):
     """Every unknown entry <- the mean of its line (axis=1: row, axis=0: column)."""
     values, hidden = _values_and_mask(x)
     line = np.atleast_1d(_mean_of_known(values, hidden, axis=axis))
-    unusable = np.isnan(line) if hidden is None else ~np.isfinite(line)
-    line = np.where(unusable, _mean_of_known(values, hidden), line)
     where = _unknown(values, hidden)
     filled = np.array(values, copy=True)
+    if np.ma.isMaskedArray(x) and hidden is None:
+        # a MaskedArray that masks nothing: numpy.ma's division has already masked every INFINITE line mean (its domain
+        # test; the data beneath becomes its fill for a division, 1), the reference's NaN test does not see those, and
+        # the entries that take such a mean come out MASKED with 1 beneath; a NaN mean (a line without entries, or both
+        # infinities in it) is replaced by the matrix mean, whatever that is (fusion_graph.py:483-489)
+        lost = np.isinf(line)
+        line = np.where(np.isnan(line), _mean_of_known(values, hidden), line)
+        lost_entry = np.broadcast_to(lost[:, None] if axis == 1 else lost[None, :], values.shape) & where
+        per_entry = np.broadcast_to(line[:, None] if axis == 1 else line[None, :], values.shape)
+        filled[where] = per_entry[where]
+        filled[lost_entry] = 1.0
+        return np.ma.MaskedArray(filled, mask=lost_entry.copy())
+    unusable = np.isnan(line) if hidden is None else ~np.isfinite(line)
+    line = np.where(unusable, _mean_of_known(values, hidden), line)
     per_entry = np.broadcast_to(line[:, None] if axis == 1 else line[None, :], values.shape)
     filled[where] = per_entry[where]
     return filled if not np.ma.isMaskedArray(x) else np.ma.MaskedArray(filled, mask=np.zeros(values.shape, dtype=bool))
@@ -160,6 +176,15 @@ class Relation(object):
             if self.fill_value not in _FILLERS:
                 raise KeyError(self.fill_value)
             strategy, value = self.fill_value, 0.0
+        if (np.ma.isMaskedArray(x) and mask is None and strategy in ('row_mean', 'col_mean')
+                and np.isinf(np.ma.getdata(x)).any()):
+            # a MaskedArray that masks nothing, with an infinity: numpy.ma masks the infinite line means and the
+            # reference hands those entries back masked (see _fill_lines) -- a rule of numpy.ma, not of the fill; this
+            # shape is imputed by the host statement and uploaded
+            from .._engine import upload_matrix
+            f = _FILLERS[strategy](x)
+            lost = np.ma.getmaskarray(f)
+            return upload_matrix(np.ma.getdata(f), dtype, runtime), (lost if lost.any() else None)
         dm = fill_unknown_device(np.ma.getdata(x), mask, strategy, value, dtype, runtime)
         keeps_mask = strategy in ('mean', 'const')
         return dm, (mask if (mask is not None and keeps_mask) else None)

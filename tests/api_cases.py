@@ -195,7 +195,7 @@ def device_fill_strategies():
     from helpers import golden
     z = golden('fill_strategies.npz')
     mem = nat.get_runtime().mem
-    for tag in ('masked', 'plain', 'finite', 'corner', 'plaincorner'):
+    for tag in ('masked', 'plain', 'finite', 'corner', 'plaincorner', 'nomask', 'nomaskfinite', 'maskedinf'):
         if tag.startswith('plain'):
             arr = z[tag].copy()
         else:

@@ -101,7 +101,7 @@ def test_object_type_and_relation_identity():
         FusionGraph([r1]).draw_graphviz('x.pdf')
 
 
-@pytest.mark.parametrize('tag', ['masked', 'plain', 'finite', 'corner', 'plaincorner'])
+@pytest.mark.parametrize('tag', ['masked', 'plain', 'finite', 'corner', 'plaincorner', 'nomask', 'nomaskfinite', 'maskedinf'])
 @pytest.mark.parametrize('fv', ['mean', 'row_mean', 'col_mean', 0.5])
 def test_fill_strategies_match_reference_outputs(tag, fv):
     z = golden('fill_strategies.npz')

@@ -390,12 +390,35 @@ def gen_fill():
     v[1, :] = np.nan
     v[:, 4] = np.nan
     v[3, 0], v[3, 1] = np.inf, -np.inf
+    # round 6 (advisor): a MaskedArray that masks NOTHING (numpy.ma.is_masked false) with infinite / NaN line means --
+    # numpy.ma masks an infinite mean itself and the reference then leaves those entries masked with 1 beneath -- and a
+    # genuinely masked input with infinities in its lines
+    u = rs.rand(6, 5)
+    u[0, 1] = np.inf                                            # row 0 / column 1: an infinite mean
+    u[2, 0], u[2, 3] = np.inf, -np.inf                          # row 2: both infinities -> NaN mean -> matrix mean
+    u[4, :] = np.nan                                            # row 4 without entries
+    u[1, 2] = u[3, 4] = np.nan
+    um = np.ma.MaskedArray(u.copy(), mask=np.zeros(u.shape, dtype=bool))
+    u2 = rs.rand(4, 5)                                          # the same shape with a FINITE matrix mean: one NaN row
+    u2[1, :] = np.nan
+    u2[0, 2] = u2[3, 3] = np.nan
+    um2 = np.ma.MaskedArray(u2.copy(), mask=np.zeros(u2.shape, dtype=bool))
+    q = rs.rand(6, 5)
+    qm = np.ma.masked_greater(q.copy(), 0.7)
+    qm.data[1, 1] = np.inf
+    qm.mask[1, 1] = False
+    qm.data[3, 0], qm.data[3, 2] = -np.inf, np.nan
+    qm.mask[3, 0] = qm.mask[3, 2] = False
     out = {'masked_data': xm.data, 'masked_mask': np.ma.getmaskarray(xm), 'plain': y,
            'finite_data': z.data, 'finite_mask': np.ma.getmaskarray(z),
-           'corner_data': wm.data.copy(), 'corner_mask': np.ma.getmaskarray(wm).copy(), 'plaincorner': v}
+           'corner_data': wm.data.copy(), 'corner_mask': np.ma.getmaskarray(wm).copy(), 'plaincorner': v,
+           'nomask_data': um.data.copy(), 'nomask_mask': np.ma.getmaskarray(um).copy(),
+           'nomaskfinite_data': um2.data.copy(), 'nomaskfinite_mask': np.ma.getmaskarray(um2).copy(),
+           'maskedinf_data': qm.data.copy(), 'maskedinf_mask': np.ma.getmaskarray(qm).copy()}
     t1, t2 = ObjectType('a'), ObjectType('b')
     import warnings
-    for tag, arr in (('masked', xm), ('plain', y), ('finite', z), ('corner', wm), ('plaincorner', v)):
+    for tag, arr in (('masked', xm), ('plain', y), ('finite', z), ('corner', wm), ('plaincorner', v), ('nomask', um),
+                     ('nomaskfinite', um2), ('maskedinf', qm)):
         for fv in ('mean', 'row_mean', 'col_mean', 0.5):
             with warnings.catch_warnings():
                 warnings.simplefilter('ignore')
