@@ -781,9 +781,12 @@ static GemmArgs gemm_args(const void* A, int64_t sa_m, int64_t sa_k, const void*
 static void plan_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
     run_gemm(GemmTypes{p->mt, p->mt, p->mt}, p->engine, g, 0, p->part.ptr, p->part_bytes, st);
 }
-// c x c algebra: f64 x f64 -> f64
+// c x c algebra: f64 x f64 -> f64.  A launch on the second stream takes that stream's split-K scratch (ranks above 512 leave
+// the deep unsplit tile and are cut into K slices: the main stream's partials may be in flight in `part` at that moment)
 static void small_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {
-    run_gemm(GemmTypes{SKF_F64, SKF_F64, SKF_F64}, p->engine, g, 0, p->part.ptr, p->part_bytes, st);
+    const bool on_aux = p->aux != nullptr && st == p->aux;
+    run_gemm(GemmTypes{SKF_F64, SKF_F64, SKF_F64}, p->engine, g, 0, on_aux ? p->part_aux.ptr : p->part.ptr,
+             on_aux ? p->part_aux_bytes : p->part_bytes, st);
 }
 // master x master -> f64 (Gram, G^T P: long f64 accumulation over the object dimension)
 static void wide_gemm(skf_plan* p, GemmArgs g, hipStream_t st) {

@@ -180,6 +180,26 @@ def test_fit_with_a_rank_above_256_on_the_hardware(monkeypatch):
     E.test_fit_with_a_rank_above_256(monkeypatch)
 
 
+def test_fit_with_every_rank_above_512_on_the_relation_pipeline():
+    """Ranks above 512 leave the deep unsplit tile: the c x c products of the SECOND stream are cut into K slices while
+    the main stream's split-K contractions are in flight -- each stream keeps its partials in its own scratch (round 6,
+    advisor).  Two fits are bit-identical and match the oracle."""
+    rs = np.random.RandomState(23)
+    types = ['a', 'b', 'c']
+    n = {'a': 1400, 'b': 1300, 'c': 1200}
+    rank = {'a': 528, 'b': 520, 'c': 516}
+    R = {('a', 'b'): [rs.rand(1400, 1300)], ('a', 'c'): [rs.rand(1400, 1200) - 0.3], ('b', 'c'): [rs.rand(1300, 1200)]}
+    G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.05 for t in types}
+    Go, So = orc.dfmf(R, {}, types, rank, max_iter=2, G0=G0)
+    fits = [_dfmf.dfmf(R, {}, types, rank, max_iter=2, G0=G0, dtype='f64') for _ in range(2)]
+    for t in types:
+        assert np.array_equal(fits[0][0][t, t], fits[1][0][t, t]), t
+        within(relerr(fits[0][0][t, t], Go[t, t]), 1e-10, 'rank > 512: G')
+    for k in So:
+        assert np.array_equal(fits[0][1][k][0], fits[1][1][k][0]), k
+        within(relerr(fits[0][1][k][0], So[k][0]), 1e-9, 'rank > 512: S')
+
+
 @pytest.mark.parametrize('dtype', ['bf16', 'f32'])
 def test_two_runs_give_bit_identical_factors(dtype):
     """No float atomics and a fixed order for every sum (split-K slices, E / D contributions of the relations on the second
