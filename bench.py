@@ -279,6 +279,78 @@ def pmc_traffic_in_run(dtype, workload='c3', steps=2, timeout=420):
                       % (steps, int(calls['FETCH_SIZE']), 'contraction-class (relation / list-pass)' if workload == 'c5' else 'relation-contraction')}
 
 
+MFMA_PMC_COUNTERS = ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_INSTS_VALU_MFMA_MOPS_BF16', 'SQ_WAIT_ANY',
+                     'SQ_WAVE_CYCLES', 'GRBM_GUI_ACTIVE')     # 5 SQ slots of 8, 1 GRBM slot of 2: one pass
+
+
+def pmc_mfma_in_run(dtype, steps=2, timeout=420):
+    """Matrix-core utilisation of the relation contractions measured IN THIS RUN (north_star: "rocprof MFMA utilisation"):
+    one more child of this script under `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ...
+    GRBM_GUI_ACTIVE` (counters only), `steps` + 1 iterations of config 3.  Per contraction launch:
+        cycles        = GRBM_GUI_ACTIVE / 8 XCDs                      (the counter is summed over the XCDs)
+        mfma_busy     = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs)
+        clock_ghz     = cycles / the launch's duration in the same trace
+        mfma_tflops   = mfma_busy x 2.5 PF x clock / 2.4 GHz           (what the busy share delivers at that clock)
+    Returns the record (+ the raw per-launch counter means) or None (no rocprofv3, SKF_BENCH_PMC=0, a failed child)."""
+    import glob
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if dtype != 'bf16' or os.environ.get('SKF_BENCH_PMC', '1') == '0' or not shutil.which('rocprofv3'):
+        return None
+    out = tempfile.mkdtemp(prefix='skf_pmc_')
+    cmd = ['rocprofv3', '--kernel-trace', '--pmc'] + list(MFMA_PMC_COUNTERS) + ['-d', out, '-o', 'pmc', '--', sys.executable,
+           os.path.abspath(__file__), '--steps', str(steps), '--warmup', '1', '--workload', 'c3', '--dtype', dtype,
+           '--no-cpu-baseline', '--no-engines', '--no-workloads', '--no-pmc', '--sustained-steps', '0']
+    t0 = time.perf_counter()
+    try:
+        subprocess.run(cmd, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()),
+                       capture_output=True, text=True, timeout=timeout, check=True)
+        sums, per_kernel, n_launch, dur_ns = {}, {}, 0, 0.0
+        is_hit = lambda name: bool(re.match(r'gemm_bf16_v2_kernel<\s*\d+\s*,\s*1\s*,',          # noqa: E731  (TAG = 1: P, Q)
+                                            re.sub(r'\(.*$', '', name).replace('skf::', '').replace('void ', '')))
+        for db in glob.glob(os.path.join(out, '**', '*.db'), recursive=True):
+            cur = sqlite3.connect(db).cursor()
+            for name, counter, cnt, val in cur.execute("select kernel_name, counter_name, count(*), sum(value) from "
+                                                       "counters_collection group by kernel_name, counter_name"):
+                if is_hit(name):
+                    sums[counter] = sums.get(counter, 0.0) + float(val)
+                    short = re.sub(r'\(.*$', '', name).replace('skf::', '').replace('void ', '')
+                    per_kernel.setdefault(short, {})[counter] = (float(val), int(cnt))
+            cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+            namecol = 'name' if 'name' in cols else 'kernel_name'
+            for name, cnt, tot in cur.execute("select %s, count(*), sum(end - start) from kernels group by %s" % (namecol, namecol)):
+                if is_hit(name):
+                    n_launch += int(cnt)
+                    dur_ns += float(tot)
+        if n_launch <= 0 or not sums.get('GRBM_GUI_ACTIVE') or not sums.get('SQ_VALU_MFMA_BUSY_CYCLES'):
+            PMC_ERRORS.append('c3 mfma counters: no matching launches in the counter database')
+            return None
+        cycles = sums['GRBM_GUI_ACTIVE'] / 8.0                     # all launches, per XCD
+        busy = sums['SQ_VALU_MFMA_BUSY_CYCLES'] / (cycles * 1024.0)
+        clock = cycles / dur_ns if dur_ns > 0 else None            # cycles per ns = GHz
+        rec = {'mfma_busy': busy, 'clock_ghz': clock, 'launches_counted': n_launch,
+               'avg_launch_ms_under_counters': dur_ns / n_launch / 1e6,
+               'mfma_tflops_at_clock': busy * PEAK_TFLOPS['bf16'] * (clock or 0.0) / 2.4,
+               'waves_parked': (sums.get('SQ_WAIT_ANY', 0.0) / sums['SQ_WAVE_CYCLES']) if sums.get('SQ_WAVE_CYCLES') else None,
+               'per_launch': {k: v / n_launch for k, v in sorted(sums.items())},
+               'per_kernel': {k: {c: {'per_launch': v / max(m, 1), 'launches': m} for c, (v, m) in sorted(d.items())}
+                              for k, d in sorted(per_kernel.items())},
+               'seconds': time.perf_counter() - t0,
+               'source': 'this run: rocprofv3 --kernel-trace --pmc %s (one child pass of bench.py, %d + 1 iterations); '
+                         'busy = MFMA_BUSY / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), clock = cycles / launch time in the '
+                         'same trace' % (' '.join(MFMA_PMC_COUNTERS), steps)}
+        return rec
+    except Exception as exc:
+        tail = (getattr(exc, 'stderr', None) or '')[-300:] if hasattr(exc, 'stderr') else ''
+        PMC_ERRORS.append('c3 mfma counters: %s %s' % (str(exc)[:200], tail))
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def roofline_record(dtype, n, ranks, spec, k_ms, k_launches, k_flops, steps, elapsed, pmc=None, k_bytes=None,
                     executed=False):
     """Roofline of the launches that walk a relation (hipEvent time `k_ms` over `k_launches` launches).
@@ -1188,9 +1260,10 @@ def main():
             pfile = os.path.join(tempfile.gettempdir(), 'skf_parity_%d.npz' % os.getpid()) if want_parity else None
             if default_run and not (args.no_engines and args.no_workloads):
                 cpu_child = cpu_baseline_start({'auto': 'auto', 'full': True, 'sample': False}[args.cpu_baseline], pfile)
-        pmc = None
+        pmc = mfma_pmc = None
         if default_run and not args.no_pmc and cpu_child is None:
             pmc = pmc_traffic_in_run(args.dtype)              # counters of THIS run when the box has rocprofv3
+            mfma_pmc = None if c5 else pmc_mfma_in_run(args.dtype)
         roof = roofline_record(args.dtype, n, ranks_, spec, w['k_ms'], w['k_launches'], w['k_flops'], args.steps, elapsed,
                                pmc or measured_traffic(args.dtype, c5, args.scale), w['k_bytes'], executed=c5)
         out = {
@@ -1278,6 +1351,10 @@ def main():
                                        elapsed, pmc, w['k_bytes'], executed=c5)
                 out.update({'roofline': roof, 'mfma_frac': (roof.get('mfma') or {}).get('frac'),
                             'hbm_frac': (roof.get('hbm_scheduled') or roof.get('hbm_algorithmic') or {}).get('frac')})
+            mfma_pmc = None if c5 else pmc_mfma_in_run(args.dtype)
+        if mfma_pmc and isinstance(out.get('roofline'), dict):
+            # matrix-core busy share of the contraction launches from the counters of THIS run, beside the hipEvent figure
+            out['roofline'].update({'mfma_busy': mfma_pmc['mfma_busy'], 'clock_ghz': mfma_pmc['clock_ghz'], 'mfma_pmc': mfma_pmc})
         if PMC_ERRORS:
             out['pmc_errors'] = PMC_ERRORS[:4]
         print(json.dumps(out), flush=True)
