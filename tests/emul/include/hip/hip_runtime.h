@@ -354,6 +354,18 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return simt::wave_read(v, lane); }     // v_readlane_b32
+// v_perm_b32: byte i of the result = byte sel[i] of the 8 bytes {hi : lo} (0..3 = lo, 4..7 = hi); selectors >= 8 are
+// not used by the kernels (constants: 0x0c = 0x00)
+inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel) {
+    const unsigned long long src = ((unsigned long long)hi << 32) | lo;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const unsigned s = (sel >> (8 * i)) & 0xFFu;
+        const unsigned b = s < 8 ? (unsigned)((src >> (8 * s)) & 0xFFu) : (s == 0x0c ? 0u : 0xFFu);
+        r |= b << (8 * i);
+    }
+    return r;
+}
 inline int __builtin_amdgcn_readfirstlane(int v) { return simt::wave_read(v, 0); }              // v_readfirstlane_b32 (all lanes active)
 // DPP lane exchanges used by the kernels: quad_perm (ctrl < 0x100), row_mirror (0x140), row_half_mirror (0x141),
 // row_newbcast:k (0x150 + k)

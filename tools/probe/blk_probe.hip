@@ -1,11 +1,11 @@
 // blk_probe.hip -- stand-alone probe of the BLOCKED known-entry passes (skf_blocked.h) against the per-entry gather
 // kernels of skf_known.h (srp_bf16_v6_kernel) on the same random lists: times, agreement of the outputs and of the stored
 // residuals, and a host fp64 check on sampled outer objects.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I scikit-fusion_amd/csrc -I include tools/probe/blk_probe.hip -o tools/probe/blk_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I scikit-fusion_amd/csrc -I tools/probe -I include tools/probe/blk_probe.hip -o tools/probe/blk_probe
 //   tools/probe/blk_probe <n_out> <n_in> <per> [arrange 0|1|2] [parts]      (w = 128, bf16)
 // arrange: 0 = entries of a cell in list order; 1 = positions matched to the rows' bank residues, what does not fit goes
 // to the free positions of the cell's ceil(n / 16) groups; 2 = residues strictly (extra groups instead of conflicts)
-#include "skf_blocked.h"
+#include "skf_blocked.h"   // (tools/probe: not part of the product build)
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -229,6 +229,17 @@ int main(int argc, char** argv) {
             num += (x - y) * (x - y); den += x * x; ++seen;
         }
         printf("stored residuals: %lld entries, relative difference %.3e\n", (long long)seen, sqrt(num / den));
+        if (getenv("BLK_DEBUG")) {
+            int shown = 0;
+            for (size_t s = 0; s < hb.size() && shown < 40; ++s) {
+                if (bsrc[s] < 0) continue;
+                const double x = he[(size_t)bsrc[s]], y = blk_unpack_hi_lo(hb[s]);
+                const size_t grp = s / 16; const int p_ = (int)(s % 16);
+                const uint32_t il = (meta[grp * 8 + (p_ >> 2)] >> (8 * (p_ & 3))) & 0xFF, ol = (meta[grp * 8 + 4 + (p_ >> 2)] >> (8 * (p_ & 3))) & 0xFF;
+                printf("  group %zu pos %2d il %3u ol %2u  v6 %10.4f  blocked %10.4f %s\n", grp, p_, il, ol, x, y, fabs(x - y) > 1e-2 * fabs(x) + 1e-3 ? "<<" : "");
+                ++shown;
+            }
+        }
         double worst = 0;
         for (int t = 0; t < 32; ++t) {
             const int64_t o = (int64_t)(rng() % (uint64_t)n_out);
@@ -255,5 +266,15 @@ int main(int argc, char** argv) {
     ba.rvals = nullptr;
     time_it("blocked apply", [&] { hipLaunchKernelGGL((blk_pass_kernel<BLK_APPLY>), dim3(bgrid), dim3(1024), BLK_LDS, 0, ba); });
     compare("apply pass", rparts, parts);
+    if (getenv("BLK_BOUNDS")) {        // bound-finding variants of the apply pass (wrong results by construction)
+        CK(hipFuncSetAttribute((const void*)blk_pass_kernel<BLK_APPLY, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
+        CK(hipFuncSetAttribute((const void*)blk_pass_kernel<BLK_APPLY, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
+        CK(hipFuncSetAttribute((const void*)blk_pass_kernel<BLK_APPLY, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
+        CK(hipFuncSetAttribute((const void*)blk_pass_kernel<BLK_APPLY, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
+        time_it("blocked apply, pipelined by two (spills)", [&] { hipLaunchKernelGGL((blk_pass_kernel<BLK_APPLY, 5>), dim3(bgrid), dim3(1024), BLK_LDS, 0, ba); });
+        time_it("blocked apply, no matrix-core steps", [&] { hipLaunchKernelGGL((blk_pass_kernel<BLK_APPLY, 1>), dim3(bgrid), dim3(1024), BLK_LDS, 0, ba); });
+        time_it("blocked apply, no vector-ALU preparation", [&] { hipLaunchKernelGGL((blk_pass_kernel<BLK_APPLY, 2>), dim3(bgrid), dim3(1024), BLK_LDS, 0, ba); });
+        time_it("blocked apply, no LDS reads", [&] { hipLaunchKernelGGL((blk_pass_kernel<BLK_APPLY, 3>), dim3(bgrid), dim3(1024), BLK_LDS, 0, ba); });
+    }
     return 0;
 }
