@@ -53,6 +53,13 @@ struct Error {
         if (e_ != hipSuccess) SKF_FAIL(SKF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// the ONE place the library reads its environment (test / A-B switches: Switches::read and plan creation; SKF_RCCL_PATH)
+static const char* env_str(const char* name) { return getenv(name); }
+static int env_int(const char* name, int unset) {
+    const char* v = env_str(name);
+    return v ? atoi(v) : unset;
+}
+
 static thread_local int64_t g_launches = 0;      // kernel launches this thread has issued through the library (skf_launch_count)
 
 static inline void check_launch(const char* what) {
@@ -292,10 +299,7 @@ static void run_gemm(GemmTypes ty, int engine, GemmArgs g, int want_splits, void
     int splits = want_splits > 0 ? want_splits : pick_splits(t, g.M, g.N, g.K, sym_ok);
     if (want_splits <= 0 && relation && engine == SKF_ENGINE_MFMA && g.epi == EPI_STORE && t.bm >= 64 &&
         (int64_t)cdiv(g.M, t.bm) * cdiv(g.N, t.bn) >= 256) {
-        // SKF_REL_SPLITS=0: unsplit (rounds 1-4); =n > 1: n slices for every such launch (A/B sweeps); default: the model
-        static const int rel_on = [] { const char* v = getenv("SKF_REL_SPLITS"); return v ? atoi(v) : 1; }();
-        if (rel_on == 1) splits = pick_splits_relation(t, g.M, g.N, g.K, is_f64);
-        else if (rel_on > 1) splits = rel_on;
+        splits = pick_splits_relation(t, g.M, g.N, g.K, is_f64);
     }
     if (g.epi == EPI_SQDIFF) splits = 1;
     const size_t per = (size_t)g.M * g.N;
@@ -358,9 +362,7 @@ static inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
 // picked (5 / 3 / 3 / 3 slices for P12 / Q12 / P23 / Q23); a product with a handful of output tiles (config 5,
 // genre x movie: ONE 256 x 256 tile over K = 40000, 0.96 ms in one workgroup before) is cut into up to 64 slices.
 static int pick_splits_bf16(int64_t units, int ktiles, int bm, int64_t out_elems) {
-    // resident workgroups on 256 CUs (SKF_BF16_SLOTS=n, A/B: price the launch on n CUs, i.e. pick slices that leave
-    // 256 - n CUs to the second stream's small launches -- plans with owned rows, whose critical path that stream is)
-    static const double cus = [] { const char* v = getenv("SKF_BF16_SLOTS"); const int n = v ? atoi(v) : 0; return (n >= 64 && n <= 256) ? (double)n : 256.0; }();
+    const double cus = 256.0;                                       // resident workgroups: one (256 rows) or two per CU
     const double slots = cus * (bm >= 256 ? 1.0 : 2.0);
     const double per_slice_us = (double)out_elems * 8.0 / 3.0e6;
     int best = 1;
@@ -516,11 +518,6 @@ struct Switches {
     bool no_overlap = false;       // SKF_NO_OVERLAP=1      no second stream
     bool no_pipeline = false;      // SKF_NO_PIPELINE=1     staged schedule instead of the relation pipeline
     int side_tile = 0;             // SKF_SIDE_TILE=64|128  tile shape of the fused side update
-    int aux_prio = 0;              // SKF_AUX_PRIO=default|high  priority of the second stream (0 = lowest, the default)
-    int epi_tile = 128;            // SKF_EPI_TILE=256      completion pass on the 256 x 256 tile (one workgroup per CU)
-    bool known_generic = false;    // SKF_KNOWN_GENERIC=1   the any-width list kernel for the known-entry passes (tests, A/B)
-    bool known_no_v6 = false;      // SKF_KNOWN_V6=0        the round-3a list kernel (srp_bf16_kernel) at ranks 128 / 256 too (A/B)
-    bool no_gram_aux = false;      // SKF_GRAM_AUX=0        DFMC on known entries: Gram / cross-Gram products on the main stream (A/B)
     bool no_small_fused = false;   // SKF_NO_SMALL_FUSED=1  small graphs on the general staged schedule (~33 launches per iteration)
     bool no_sweep = false;         // SKF_PINV_SWEEP=0      orders 65 .. 256: blocked Cholesky inverse + unpack instead of the blocked sweep (A/B)
     bool small_sweep1 = false;     // SKF_SMALL_SWEEP4=0    small graphs: one pivot per barrier in the register sweep (same bits; A/B, tests)
@@ -531,10 +528,15 @@ struct Switches {
     int sweep_rows = 32;           // SKF_SWEEP_ROWS=32|64.. rows of a slab (a multiple of 32)
     bool no_pairs = false;         // SKF_CHAIN_PAIRS=0     the independent c x c products of a relation's chain as launches of their own (A/B; same bits)
     bool no_sweep_big = false;     // SKF_SWEEP_BIG=0       orders above 256 on the blocked Cholesky inverse + unpack, as before round 5 (A/B)
+    int dfmc_sparse = -1;          // SKF_DFMC_SPARSE=0|1   masked relations never / whenever a bound is given as lists of their known entries
+    int known_parts = 0;           // SKF_KNOWN_PARTS=1|2|4|8  parts of the known-entry lists (0: by the size of the gathered matrix)
+    bool known_parts_forced = false;   // ... given at all: short lists are cut into parts too (tests)
+    bool comm_stream = true;       // SKF_COMM_STREAM=0     plans with owned rows: the exchanges on the main stream (A/B; tests run both)
     bool early_update = true;      // SKF_EARLY_UPDATE=0    pipeline: every type is updated at the end of the iteration (default: a type whose last relation is through
                                    //                       and that nothing reads any more is updated on the second stream, underneath the remaining contractions)
     static Switches read() {
-        auto on = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
+        auto on = [](const char* name) { return env_int(name, 0) != 0; };
+        auto off = [](const char* name) { return env_int(name, 1) == 0; };         // "=0" switches a default off
         Switches w;
         w.pinv_jacobi = on("SKF_PINV_JACOBI");
         w.chol_unblocked = on("SKF_CHOL_UNBLOCKED");
@@ -544,24 +546,20 @@ struct Switches {
         w.graph = on("SKF_GRAPH");
         w.no_overlap = on("SKF_NO_OVERLAP");
         w.no_pipeline = on("SKF_NO_PIPELINE");
-        w.known_generic = on("SKF_KNOWN_GENERIC");
-        { const char* v6 = getenv("SKF_KNOWN_V6"); w.known_no_v6 = v6 && atoi(v6) == 0; }
-        { const char* ga = getenv("SKF_GRAM_AUX"); w.no_gram_aux = ga && atoi(ga) == 0; }
         w.no_small_fused = on("SKF_NO_SMALL_FUSED");
-        { const char* sv = getenv("SKF_PINV_SWEEP"); w.no_sweep = sv && atoi(sv) == 0; }
-        { const char* s4 = getenv("SKF_SMALL_SWEEP4"); w.small_sweep1 = s4 && atoi(s4) == 0; }
-        { const char* gs = getenv("SKF_GRAM_SYM"); w.gram_sym = (gs && atoi(gs) == 0) ? 0 : 1; }
-        { const char* eu = getenv("SKF_EARLY_UPDATE"); w.early_update = !(eu && atoi(eu) == 0); }
-        { const char* sm = getenv("SKF_SWEEP_STEP_MIN"); if (sm) w.sweep_step_min = atoi(sm); }
-        { const char* sr = getenv("SKF_SWEEP_ROWS"); if (sr && atoi(sr) >= 32) w.sweep_rows = (atoi(sr) + 31) / 32 * 32; }
-        { const char* sb = getenv("SKF_SWEEP_BIG"); w.no_sweep_big = sb && atoi(sb) == 0; }
-        { const char* cp = getenv("SKF_CHAIN_PAIRS"); w.no_pairs = cp && atoi(cp) == 0; }
-        const char* st = getenv("SKF_SIDE_TILE");
-        w.side_tile = st ? atoi(st) : 0;
-        const char* ap = getenv("SKF_AUX_PRIO");
-        w.aux_prio = (ap && ap[0] == 'd') ? 1 : (ap && ap[0] == 'h') ? 2 : 0;
-        const char* et = getenv("SKF_EPI_TILE");
-        w.epi_tile = (et && atoi(et) == 256) ? 256 : 128;
+        w.no_sweep = off("SKF_PINV_SWEEP");
+        w.small_sweep1 = off("SKF_SMALL_SWEEP4");
+        w.gram_sym = off("SKF_GRAM_SYM") ? 0 : 1;
+        w.early_update = !off("SKF_EARLY_UPDATE");
+        w.sweep_step_min = env_int("SKF_SWEEP_STEP_MIN", w.sweep_step_min);
+        { const int sr = env_int("SKF_SWEEP_ROWS", 0); if (sr >= 32) w.sweep_rows = (sr + 31) / 32 * 32; }
+        w.no_sweep_big = off("SKF_SWEEP_BIG");
+        w.no_pairs = off("SKF_CHAIN_PAIRS");
+        w.side_tile = env_int("SKF_SIDE_TILE", 0);
+        w.dfmc_sparse = env_int("SKF_DFMC_SPARSE", -1);
+        { const int kp = env_int("SKF_KNOWN_PARTS", 0); w.known_parts = (kp == 1 || kp == 2 || kp == 4 || kp == 8) ? kp : 0; }
+        w.known_parts_forced = env_str("SKF_KNOWN_PARTS") != nullptr;
+        w.comm_stream = !off("SKF_COMM_STREAM");
         return w;
     }
 };
@@ -1343,7 +1341,7 @@ static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream
         a.evals = by_col ? (double*)r.KcE.ptr : nullptr;
         a.Fo = (const double*)(by_col ? Tj : Gi); a.Fi = (const double*)(by_col ? Gi : Tj);
         a.out = (double*)out;
-        waves = launch_srp(a, st, p->sw.known_generic);
+        waves = launch_srp(a, st, false);
     } else if (p->bf16) {
         SrpArgs<uint16_t, float> a;
         fill(a);
@@ -1355,8 +1353,8 @@ static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream
         // a list point there.  Byte offsets into the matrix are 32 bits wide in the v6 kernel.
         const int64_t n_in = by_col ? ti.n - r.r0 : tj.n;          // (the zero row of Grow sits behind ALL rows of the type)
         const int64_t zoff = n_in * ldv * 2;
-        a.zero_off = (zoff + ldv * 2 < (int64_t)0xffffffffLL && !p->sw.known_generic && !p->sw.known_no_v6) ? (uint32_t)zoff : 0u;
-        waves = launch_srp(a, st, p->sw.known_generic);
+        a.zero_off = (zoff + ldv * 2 < (int64_t)0xffffffffLL) ? (uint32_t)zoff : 0u;
+        waves = launch_srp(a, st, false);
     } else {
         SrpArgs<float, float> a;
         fill(a);
@@ -1364,7 +1362,7 @@ static int known_pass(skf_plan* p, RelState& r, bool by_col, int mode, hipStream
         a.evals = by_col ? (float*)r.KcE.ptr : nullptr;
         a.Fo = (const float*)(by_col ? Tj : Gi); a.Fi = (const float*)(by_col ? Gi : Tj);
         a.out = (float*)out;
-        waves = launch_srp(a, st, p->sw.known_generic);
+        waves = launch_srp(a, st, false);
     }
     if (parts > 1 && mode != SRP_ERR) {
         const int64_t total = n_out * ci;
@@ -1609,7 +1607,7 @@ static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t
         g.koff = (const uint32_t*)r.Koff.ptr;
         g.klist = (const uint32_t*)r.Klist.ptr;
     }
-    if (p->sw.epi_tile == 128 && mode == MODE_COMPLETE) {
+    if (mode == MODE_COMPLETE) {
         // 128 relation columns x 256 relation rows per workgroup, 256 threads, 68 KiB of LDS: two workgroups per CU, one
         // tile's write-out under the other's K loop (3.9 vs 4.7 ms at config 5).  The residual pass only reads the
         // relation and is faster on the 256 x 256 tile (4.7 vs 4.9 ms): it stays there.
@@ -1623,15 +1621,9 @@ static void launch_tile_epilogue(skf_plan* p, RelState& r, int mode, hipStream_t
     }
     dim3 grid(cdiv(nr, 256), cdiv(nj, 256));
     const int smem = (3 * 256 + 2 * 256) * 8 * 16;
-    if (mode == MODE_COMPLETE) {
-        static DeviceOnce once;
-        allow_dynamic_lds(once, gemm_bf16_v2_kernel<256, 0, false, EPI_T_COMPLETE>, smem);
-        hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0, false, EPI_T_COMPLETE>), grid, dim3(512), smem, st, g);
-    } else {
-        static DeviceOnce once;
-        allow_dynamic_lds(once, gemm_bf16_v2_kernel<256, 0, false, EPI_T_SQERR>, smem);
-        hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0, false, EPI_T_SQERR>), grid, dim3(512), smem, st, g);
-    }
+    static DeviceOnce once;
+    allow_dynamic_lds(once, gemm_bf16_v2_kernel<256, 0, false, EPI_T_SQERR>, smem);
+    hipLaunchKernelGGL((gemm_bf16_v2_kernel<256, 0, false, EPI_T_SQERR>), grid, dim3(512), smem, st, g);
     check_launch("tile_epilogue_bf16");
 }
 
@@ -1934,7 +1926,7 @@ static std::once_flag g_rccl_once;
 // librccl of the process if one is loaded already (PyTorch-ROCm bundles its own), else SKF_RCCL_PATH / the loader path / ROCm
 static const Rccl& rccl() {
     std::call_once(g_rccl_once, [] {
-        const char* names[] = {getenv("SKF_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        const char* names[] = {env_str("SKF_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
         void* h = nullptr;
         for (const char* nm : names)
             if (nm && !h) h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
@@ -2572,7 +2564,7 @@ static void iterate_fit_pipelined(skf_plan* p, hipStream_t st) {
     std::vector<int> all;
     bool any_kn = false;
     for (const RelState& r : p->rels) any_kn = any_kn || r.kn;
-    const bool gram_aux = dfmc && any_kn && !p->sw.no_gram_aux;
+    const bool gram_aux = dfmc && any_kn;
     if (gram_aux) {
         SKF_HIP(hipEventRecord(p->ev_fork, st));
         SKF_HIP(hipStreamWaitEvent(ax, p->ev_fork, 0));
@@ -3170,21 +3162,17 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         // 128).  SKF_DFMC_SPARSE=0: never; =1: whenever a bound is given (up to a quarter of the relation).  Plans with row
         // blocks keep the dense form.
         {
-            const char* ev = getenv("SKF_DFMC_SPARSE");
-            const int mode = ev ? atoi(ev) : -1;
+            const Switches sw0 = Switches::read();          // (plan creation: the plan's own copy is read when its workspace is bound)
+            const int mode = sw0.dfmc_sparse;
             // Parts of the lists (skf_known.h): with srp_bf16_v6_kernel the passes are no longer bound by instruction issue and
             // pinning slices of the gathered matrix to XCDs pays (profiles/r03_srp_v6.txt: 25.6 MB of user factors, 8 parts:
             // 1.75 -> 1.10 ms; 10 MB, 4 parts: 1.41 -> 1.25 ms) -- the smallest power of two that brings a slice under the
             // 4 MiB L2 of an XCD, as long as a segment still holds a batch of entries.  Other engines / widths: 1 (their
             // kernels are issue-bound; measured neutral in round 3).  SKF_KNOWN_PARTS=1|2|4|8 overrides.
-            const char* evp = getenv("SKF_KNOWN_PARTS");
-            int parts_env = evp ? atoi(evp) : 0;
-            if (parts_env != 1 && parts_env != 2 && parts_env != 4 && parts_env != 8) parts_env = 0;
-            const char* ev6 = getenv("SKF_KNOWN_V6");
-            const bool no_v6 = ev6 && atoi(ev6) == 0;
+            const int parts_env = sw0.known_parts;
             auto pick_parts = [&](int64_t n_in, int64_t n_out, int ci, int64_t cap) {
                 if (parts_env) return parts_env;
-                if (!p->bf16 || (ci != 128 && ci != 256) || no_v6) return 1;
+                if (!p->bf16 || (ci != 128 && ci != 256)) return 1;
                 int q = 1;
                 while (q < 8 && (double)n_in * ci * 2.0 / q > 3.5 * 1048576.0) q *= 2;
                 while (q > 1 && (double)cap / ((double)n_out * q) < 64.0) q /= 2;
@@ -3225,7 +3213,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             // sparse 0/1 relations as lists over bf16 factor rows (srp_bf16_v6_kernel<.., SRP_ONES>): both ranks 64 / 128 / 256
             auto gather_rank = [](int c) { return c == 64 || c == 128 || c == 256; };
             for (RelState& s : p->rels) {
-                s.sp_gather = p->bf16 && s.binary && !s.masked && !s.absent && !no_v6 && gather_rank(p->types[s.row].c) &&
+                s.sp_gather = p->bf16 && s.binary && !s.masked && !s.absent && gather_rank(p->types[s.row].c) &&
                               gather_rank(p->types[s.col].c);
                 if (!s.sp_gather) continue;
                 p->types[s.row].need_rows = p->types[s.col].need_rows = true;
@@ -3278,9 +3266,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             TileCfg t = pick_tile(out_f64, p->engine, M, N);
             int sl = pick_splits(t, M, N, K);
             if (!p->bf16 && (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn) >= 256) {      // (relation contractions of the f32 / f64 engines)
-                int rs = pick_splits_relation(t, M, N, K, out_f64);
-                const char* force = getenv("SKF_REL_SPLITS");                     // (plan creation, not a launch path)
-                if (force && atoi(force) > 1) rs = atoi(force);
+                const int rs = pick_splits_relation(t, M, N, K, out_f64);
                 if (rs > sl) sl = rs;
             }
             size_t need = (size_t)sl * (size_t)M * (size_t)N * (out_f64 ? 8 : 4);
@@ -3649,7 +3635,7 @@ static void build_sparse_pattern(skf_plan* p, RelState& r, hipStream_t st) {
         check_launch("csc_build");
     }
     if (r.sp_gather) {          // lists in parts pinned to XCDs, as long as a segment still holds a batch of entries
-        const bool forced = getenv("SKF_KNOWN_PARTS") != nullptr;       // (bind time; tests: short lists in parts too)
+        const bool forced = p->sw.known_parts_forced;                    // (tests: short lists in parts too)
         auto fit = [&](int q, int64_t n_out) {
             while (!forced && q > 1 && (double)tot / ((double)n_out * q) < 64.0) q /= 2;
             return q;
@@ -3700,13 +3686,13 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             if (p->bf16) {
                 // known entries of every tile of the completion pass (256 rows x epi_tile columns) as a compact list
                 // (count, prefix sum on the host, fill)
-                const int tx = cdiv(rows, 256), ty = cdiv(cols, p->sw.epi_tile);
+                const int tx = cdiv(rows, 256), ty = cdiv(cols, 128);
                 const size_t tiles = (size_t)tx * ty;
                 KnownArgs ka;
                 ka.mbits = (const uint8_t*)r.Mb.ptr; ka.ldmb = r.ldmb;
                 ka.Rin = (const uint16_t*)r.R_in; ka.ldin = r.ld_in;
                 ka.rows = (int)rows; ka.cols = (int)cols;
-                ka.tile_cols = p->sw.epi_tile;
+                ka.tile_cols = 128;
                 ka.counts = (uint32_t*)r.Kcnt.ptr; ka.off = nullptr; ka.list = nullptr;
                 hipLaunchKernelGGL(known_entries_kernel, dim3(tx, ty), dim3(256), 0, st, ka);
                 check_launch("known_entries(count)");
@@ -3909,8 +3895,7 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
             for (RelState& r : p->rels) SKF_HIP(hipMemsetAsync(r.Q.ptr, 0, r.Q.bytes, st));
             SKF_HIP(hipMemsetAsync((char*)ws + p->xg_off, 0, p->xg_bytes, st));
             SKF_HIP(hipMemsetAsync((char*)ws + p->xw_off, 0, p->xw_bytes, st));
-            const char* ec = getenv("SKF_COMM_STREAM");
-            if (!p->cs && !p->sw.no_overlap && !(ec && atoi(ec) == 0))
+            if (!p->cs && !p->sw.no_overlap && p->sw.comm_stream)
                 SKF_HIP(hipStreamCreateWithFlags(&p->cs, hipStreamNonBlocking));
         }
         p->pipeline = !p->sw.no_pipeline;
@@ -3919,15 +3904,13 @@ int skf_plan_bind_workspace(skf_plan* p, void* ws, size_t bytes, void* stream) {
         if (p->variant != SKF_TRANSFORM && !p->aux && !p->small_fused) {
             if (!p->sw.no_overlap) {
                 {   // the second stream at the LOWEST priority: its launches fill what the contractions of the main stream
-                    // leave free instead of taking CUs from them (config 5 +0.9 %, config 3 +0.5 %; SKF_AUX_PRIO=default|high: A/B)
+                    // leave free instead of taking CUs from them (config 5 +0.9 %, config 3 +0.5 % against the default priority)
                     int lo = 0, hi = 0;
                     SKF_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
                     // (plans with owned rows, where the second stream carries the critical path of a rank: lowest / default /
                     // highest priority measured equal -- 2.58 / 2.56 / 2.55 ms for rank 3 of 8 at config 3 --, a running
                     // contraction workgroup is not preempted; profiles/r04_owned_rank_emulation.txt)
-                    if (p->sw.aux_prio == 0) SKF_HIP(hipStreamCreateWithPriority(&p->aux, hipStreamNonBlocking, lo));
-                    else if (p->sw.aux_prio == 2) SKF_HIP(hipStreamCreateWithPriority(&p->aux, hipStreamNonBlocking, hi));
-                    else SKF_HIP(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+                    SKF_HIP(hipStreamCreateWithPriority(&p->aux, hipStreamNonBlocking, lo));
                 }
                 SKF_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
                 SKF_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
@@ -4499,7 +4482,7 @@ int skf_gemm(int32_t dtype, int32_t engine, const skf_gemm_desc* d, void* worksp
         GemmTypes ty{dtype, d->a_dtype < 0 ? dtype : d->a_dtype, d->b_dtype < 0 ? dtype : d->b_dtype};
         // X^T X (one operand read both ways, plain store): a symmetric product -- the split-K form computes the tiles on / below
         // the diagonal only (GemmArgs::sym; bit for bit the full product)
-        static const int sym_on = [] { const char* v = getenv("SKF_GRAM_SYM"); return (v && atoi(v) == 0) ? 0 : 1; }();
+        static const int sym_on = env_int("SKF_GRAM_SYM", 1) != 0;
         if (sym_on && d->A == d->B && d->M == d->N && d->sa_m == d->sb_n && d->sa_k == d->sb_k && d->epi == EPI_STORE &&
             d->aop == AOP_NONE && ty.a == ty.b)
             g.sym = 1;
