@@ -269,10 +269,9 @@ def _shared_rccl_comm(rt, dist):
     key = (rank, world, _group_token(dist))
     if key in _RCCL:
         return _RCCL[key]
-    for stale in [k for k in _RCCL if k[:2] == key[:2]]:        # communicators of groups that no longer exist
-        comm = _RCCL.pop(stale)
-        if comm:
-            rt.lib.skf_comm_destroy(comm)
+    # (communicators made for EARLIER process groups stay alive until release_rccl_comms() / process exit: a DevicePlan created
+    #  under such a group may still hold the handle, and a destroyed handle handed to skf_iterate_dist is a use after free --
+    #  a process that cycles through many groups keeps one idle communicator per group, which is the cheaper mistake)
     if not getattr(_shared_rccl_comm, '_atexit', False):
         import atexit
         atexit.register(release_rccl_comms)
@@ -323,6 +322,8 @@ def _shared_rccl_comm(rt, dist):
     th.start()
     th.join(limit)
     if th.is_alive():
+        # (the peers that did get through are now in the all_agree all-reduce below and would wait there for this rank: the
+        #  caller must treat this error as fatal for the process group -- let it propagate and the launcher tears the job down)
         raise RuntimeError('skf_comm_create: rank %d of %d still waits in ncclCommInitRank after %.0f s -- the ranks disagree '
                            '(a peer failed or never called it); SKF_COMM_TIMEOUT sets the limit' % (rank, world, limit))
     ok = bool(box.get('ok'))
@@ -926,7 +927,9 @@ class DeviceReconstructor(object):
     (f4: ``S`` is then the product of the backbones along a ``chain()`` path).  ``G_col=None``: blocks are
     ``G_row[block] @ S`` (the profile form of reference examples/pharma_chaining.py:43-53, one GEMM)."""
 
-    def __init__(self, S, G_col=None, dtype='f64', runtime=None):
+    def __init__(self, S, G_col=None, dtype='f64', runtime=None, G_col_device=None):
+        """``G_col_device``: the buffer another reconstructor of the same dtype already uploaded for this column factor
+        (``other.b`` with ``other.nj`` rows: several paths that end in one object type share one copy in HBM)."""
         self.rt = runtime or nat.get_runtime()
         code = nat.DTYPES[dtype]
         self.code = nat.SKF_F32 if code == nat.SKF_BF16 else code
@@ -939,8 +942,9 @@ class DeviceReconstructor(object):
         self.ci, self.cj = Sm.shape
         self.nj = self.cj if B is None else B.shape[0]          # columns of a block
         self.s = self.rt.mem.from_host(Sm)
-        self.b = None if B is None else self.rt.mem.from_host(B)
-        self.uploads = 1 if B is None else 2   # H2D copies of S / G_col so far (does not grow with the block count)
+        shared = B is not None and G_col_device is not None
+        self.b = None if B is None else (G_col_device if shared else self.rt.mem.from_host(B))
+        self.uploads = 1 if (B is None or shared) else 2   # H2D copies of S / G_col so far (does not grow with the block count)
         self._h = self._out = None
         self._rows = 0
 

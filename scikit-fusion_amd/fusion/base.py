@@ -116,14 +116,21 @@ class FusionBase(object):
         from .._engine import DeviceReconstructor
         run = 0 if run is None else run
         fit, G_row = self._chain_source(row_type, run)
+        for who in {id(self): self, id(fit): fit}.values():          # (a transformer and the fitted model it folds into)
+            if not 0 <= int(run) < int(getattr(who, 'n_run', 1)):
+                raise DataFusionError("run %d requested, %s holds %d" % (run, type(who).__name__, getattr(who, 'n_run', 1)))
         G_row = np.asarray(G_row)
-        parts = []
+        parts, col_on_device = [], {}             # one uploaded copy of a column factor, however many paths end in its type
         for ct, path in self.chain_paths(row_type, col_types, skip):
             bb = self.chain_backbone(path, run)
             if bb is None:
                 parts.append(None)
             else:
-                parts.append(DeviceReconstructor(bb, fit.factor(ct, run) if project else None, dtype=dtype))
+                rec = DeviceReconstructor(bb, fit.factor(ct, run) if project else None, dtype=dtype,
+                                          G_col_device=col_on_device.get(ct))
+                if project:
+                    col_on_device.setdefault(ct, rec.b)
+                parts.append(rec)
         if not parts:
             raise DataFusionError("No path from %s to the requested object types" % row_type.name)
         for r0 in range(0, G_row.shape[0], int(block_rows)):
