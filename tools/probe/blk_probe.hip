@@ -266,6 +266,21 @@ int main(int argc, char** argv) {
     ba.rvals = nullptr;
     time_it("blocked apply", [&] { hipLaunchKernelGGL((blk_pass_kernel<BLK_APPLY>), dim3(bgrid), dim3(1024), BLK_LDS, 0, ba); });
     compare("apply pass", rparts, parts);
+    {   // two strips per wave (8 waves of 256 registers)
+        CK(hipFuncSetAttribute((const void*)blk2_pass_kernel<BLK_APPLY>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
+        CK(hipFuncSetAttribute((const void*)blk2_pass_kernel<BLK_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
+        CK(hipMemset(d_out2, 0, (size_t)8 * n_out * w * 4));
+        time_it("blocked apply, two strips per wave", [&] { hipLaunchKernelGGL((blk2_pass_kernel<BLK_APPLY>), dim3(bgrid), dim3(512), BLK_LDS, 0, ba); });
+        compare("apply pass, two strips per wave", rparts, parts);
+        ba.rvals = d_brv;
+        CK(hipMemset(d_out2, 0, (size_t)8 * n_out * w * 4));
+        time_it("blocked residual + store, two strips per wave", [&] { hipLaunchKernelGGL((blk2_pass_kernel<BLK_RESIDUAL>), dim3(bgrid), dim3(512), BLK_LDS, 0, ba); });
+        sa.mode = SRP_RESIDUAL;
+        hipLaunchKernelGGL((srp_bf16_v6_kernel<1, SRP_RESIDUAL>), dim3(sgrid), dim3(256), 0, 0, sa);
+        CK(hipDeviceSynchronize());
+        compare("residual pass, two strips per wave", rparts, parts);
+        ba.rvals = nullptr;
+    }
     if (getenv("BLK_BOUNDS")) {        // bound-finding variants of the apply pass (wrong results by construction)
         CK(hipFuncSetAttribute((const void*)blk_pass_kernel<BLK_APPLY, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));
         CK(hipFuncSetAttribute((const void*)blk_pass_kernel<BLK_APPLY, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS));

@@ -1,7 +1,7 @@
 // skf_blocked.h -- the known-entry passes of DFMC as BLOCKED SDDMM + SpMM on the matrix cores (round 6).
 // PROBE ONLY (tools/probe/blk_probe.hip): measured against srp_bf16_v6_kernel and NOT taken into the product -- the W pass
 // reached 0.87 ms against 1.12 (the bar was 0.8), the residual passes stayed behind the per-entry kernels; numbers and the
-// reasons in profiles/r06_blocked_lists_probe.txt.
+// reasons in profiles/r06_blocked_lists_probe.txt (two forms: 16 waves x 1 strip, 8 waves x 2 strips).
 //
 // What skf_known.h computes entry by entry -- per known entry (o, i) of a masked relation one gathered 256-byte bf16 row
 // of the inner factor, a dot product on the vector ALU and an axpy into the outer row's accumulator (reference
@@ -418,5 +418,282 @@ __global__ __launch_bounds__(1024) void blk_pass_kernel(BlkArgs a) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// The same pass with TWO strips per wave (8 waves of up to 256 registers per workgroup instead of 16 of 128): a wave works
+// through the cells of its two strips group by group in lockstep -- preparation and reads of strip A's group, preparation and
+// reads of strip B's group, steps of A, steps of B -- so that every group's LDS latency and vector-ALU preparation lie under
+// the matrix-core steps of the other strip's group: two independent chains per wave, which the 16-wave form has no
+// registers for (its pipelined variants spilled).  Same lists, same arithmetic and summation order per strip, same bits.
+// ------------------------------------------------------------------------------------------
+constexpr int BLK2_WAVES = 8;
+
+template <int MODE>
+__global__ __launch_bounds__(512) void blk2_pass_kernel(BlkArgs a) {
+    HIP_DYNAMIC_SHARED(unsigned char, lds)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7;
+    const int lg = a.parts >= 8 ? 3 : a.parts >= 4 ? 2 : a.parts >= 2 ? 1 : 0;
+    const int part = xcd & (a.parts - 1);
+    const int64_t ob = (int64_t)(blockIdx.x >> 3) * (8 >> lg) + (xcd >> lg);
+    if (ob * BLK_WGR >= a.n_out) return;                                   // (workgroup-uniform)
+    const int b0 = part * a.blk_per_part;
+    const int b1 = b0 + a.blk_per_part < a.nblk ? b0 + a.blk_per_part : a.nblk;
+    const int nb = b1 - b0;
+    const int64_t strip0 = ob * (BLK_WGR / BLK_OS) + 2 * wv;
+    bool live[2];
+    const int* cp[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        live[s] = (strip0 + s) * BLK_OS < a.n_out;
+        cp[s] = a.cellptr + (live[s] ? strip0 + s : 0) * (int64_t)(a.nblk + 1);
+    }
+    const unsigned char* fi = (const unsigned char*)a.Fi;
+    const int64_t ldb = a.ldi * 2;
+    auto dma_block = [&](int blk, int buf) {
+        const int64_t base = (int64_t)blk * BLK_IB;
+        const unsigned char* src = fi + base * ldb;
+        const int64_t left = a.n_in - base;
+        const int rmax = (int)(left < BLK_IB ? left : BLK_IB) - 1;
+#pragma unroll
+        for (int i = 0; i < BLK_DMA / BLK2_WAVES; ++i) {                   // 72 pieces, 9 per wave
+            const int q = wv + BLK2_WAVES * i;
+            const int slot = q * 64 + lane;
+            int row = (slot * 3641) >> 16;
+            int w = slot - row * 18;
+            w = w < 16 ? w : 15;
+            row = row < rmax ? row : rmax;
+            const uint32_t off = (uint32_t)row * (uint32_t)ldb + (uint32_t)w * 16u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                             (__attribute__((address_space(3))) void*)(lds + buf * BLK_BUF + q * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[2][8];
+    u32x4 fo[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fo[s][k] = u32x4{0u, 0u, 0u, 0u};
+        if (MODE == BLK_RESIDUAL && live[s]) {
+            int64_t o = (strip0 + s) * BLK_OS + sub;
+            o = o < a.n_out ? o : a.n_out - 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fo[s][k] = *(const u32x4*)(a.Fo + o * a.ldo + 32 * k + 8 * g);
+        }
+    }
+    struct Meta {
+        uint32_t il, ol;
+        u32x4 v;
+    };
+    auto load_meta = [&](int first, int count) {
+        Meta m;
+        m.il = 0u;
+        m.ol = 0xFFFFFFFFu;
+        m.v = u32x4{0u, 0u, 0u, 0u};
+        if (count > 0) {
+            const int64_t gi = first + (sub < count ? sub : count - 1);
+            const uint32_t* mp = a.meta + gi * 8;
+            m.il = mp[g];
+            m.ol = mp[4 + g];
+            m.v = MODE == BLK_APPLY ? *(const u32x4*)(a.evals + gi * 16 + 4 * g) : *(const u32x4*)(a.rvals + gi * 16 + 4 * g);
+        }
+        return m;
+    };
+    struct Prep {
+        u32x4 af;
+        const unsigned char* rowb;
+    };
+    struct Reads {
+        s16x4 t0, t1, t2, t3, t4, t5, t6, t7;
+    };
+    auto prep = [&](auto kk, auto ss, const Meta& mt, int gfirst, const unsigned char* buf) {
+        constexpr int K = decltype(kk)::value, S = decltype(ss)::value;
+        Prep pr;
+        const uint32_t ol4 = row_bcast_u<K>(mt.ol), il4 = row_bcast_u<K>(mt.il);
+        const uint32_t v4[4] = {row_bcast_u<K>(mt.v.x), row_bcast_u<K>(mt.v.y), row_bcast_u<K>(mt.v.z), row_bcast_u<K>(mt.v.w)};
+        bool mine[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mine[j] = ((ol4 >> (8 * j)) & 0xFFu) == (uint32_t)sub;
+        if (MODE == BLK_APPLY) {
+            uint32_t mk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mk[j] = mine[j] ? v4[j] : 0u;
+            pr.af.x = __builtin_amdgcn_perm(mk[1], mk[0], 0x05040100u);
+            pr.af.y = __builtin_amdgcn_perm(mk[3], mk[2], 0x05040100u);
+            pr.af.z = __builtin_amdgcn_perm(mk[1], mk[0], 0x07060302u);
+            pr.af.w = __builtin_amdgcn_perm(mk[3], mk[2], 0x07060302u);
+        } else {
+            const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)il4, 0), s1 = (uint32_t)__builtin_amdgcn_readlane((int)il4, 16),
+                           s2 = (uint32_t)__builtin_amdgcn_readlane((int)il4, 32), s3 = (uint32_t)__builtin_amdgcn_readlane((int)il4, 48);
+            const int wa = sub >> 2;
+            const uint32_t ila4 = wa == 0 ? s0 : wa == 1 ? s1 : wa == 2 ? s2 : s3;
+            const uint32_t ila = (ila4 >> (8 * (sub & 3))) & 0xFFu;
+            const unsigned char* rowa = buf + ila * BLK_PITCH + g * 16;
+            f32x4 dd = {0.f, 0.f, 0.f, 0.f};
+            u32x4 a0 = lds_read_b128<0>(rowa), a1 = lds_read_b128<64>(rowa), a2 = lds_read_b128<128>(rowa), a3 = lds_read_b128<192>(rowa);
+            lds_wait<3>(a0);
+            dd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, fo[S][0]), dd, 0, 0, 0);
+            lds_wait<2>(a1);
+            dd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, fo[S][1]), dd, 0, 0, 0);
+            lds_wait<1>(a2);
+            dd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a2), __builtin_bit_cast(bf16x8, fo[S][2]), dd, 0, 0, 0);
+            lds_wait<0>(a3);
+            dd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3), __builtin_bit_cast(bf16x8, fo[S][3]), dd, 0, 0, 0);
+            float e[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = mine[j] ? __builtin_bit_cast(float, v4[j]) - dd[j] : 0.f;
+            pr.af.x = blk_cvt_pk(e[0], e[1]);
+            pr.af.y = blk_cvt_pk(e[2], e[3]);
+            l[0] = e[0] - __builtin_bit_cast(float, pr.af.x << 16);
+            l[1] = e[1] - __builtin_bit_cast(float, pr.af.x & 0xFFFF0000u);
+            l[2] = e[2] - __builtin_bit_cast(float, pr.af.y << 16);
+            l[3] = e[3] - __builtin_bit_cast(float, pr.af.y & 0xFFFF0000u);
+            pr.af.z = blk_cvt_pk(l[0], l[1]);
+            pr.af.w = blk_cvt_pk(l[2], l[3]);
+            if (a.evals != nullptr) {
+                uint32_t* ev = a.evals + (int64_t)(gfirst + K) * 16 + 4 * g;
+                if (mine[0]) ev[0] = __builtin_amdgcn_perm(pr.af.z, pr.af.x, 0x05040100u);
+                if (mine[1]) ev[1] = __builtin_amdgcn_perm(pr.af.z, pr.af.x, 0x07060302u);
+                if (mine[2]) ev[2] = __builtin_amdgcn_perm(pr.af.w, pr.af.y, 0x05040100u);
+                if (mine[3]) ev[3] = __builtin_amdgcn_perm(pr.af.w, pr.af.y, 0x07060302u);
+            }
+        }
+        const uint32_t ilb = (il4 >> (8 * (sub >> 2))) & 0xFFu;
+        pr.rowb = buf + ilb * BLK_PITCH + (sub & 3) * 8;
+        return pr;
+    };
+    auto reads = [&](const unsigned char* rowb) {
+        Reads r;
+        r.t0 = lds_read_tr16_b64<0>(rowb);   r.t1 = lds_read_tr16_b64<32>(rowb);  r.t2 = lds_read_tr16_b64<64>(rowb);
+        r.t3 = lds_read_tr16_b64<96>(rowb);  r.t4 = lds_read_tr16_b64<128>(rowb); r.t5 = lds_read_tr16_b64<160>(rowb);
+        r.t6 = lds_read_tr16_b64<192>(rowb); r.t7 = lds_read_tr16_b64<224>(rowb);
+        return r;
+    };
+    auto steps = [&](auto ss, auto behind, const u32x4& af, Reads& r) {
+        constexpr int S = decltype(ss)::value, B = decltype(behind)::value;
+        const bf16x8 afb = __builtin_bit_cast(bf16x8, af);
+        auto one = [&](auto cc, s16x4& t) {
+            constexpr int C = decltype(cc)::value;
+            lds_wait<B + 7 - C>(t);
+            acc[S][C] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afb, __builtin_bit_cast(bf16x8, (s16x8){t[0], t[1], t[2], t[3], t[0], t[1], t[2], t[3]}), acc[S][C], 0, 0, 0);
+        };
+        one(std::integral_constant<int, 0>(), r.t0);
+        one(std::integral_constant<int, 1>(), r.t1);
+        one(std::integral_constant<int, 2>(), r.t2);
+        one(std::integral_constant<int, 3>(), r.t3);
+        one(std::integral_constant<int, 4>(), r.t4);
+        one(std::integral_constant<int, 5>(), r.t5);
+        one(std::integral_constant<int, 6>(), r.t6);
+        one(std::integral_constant<int, 7>(), r.t7);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 8> I8;
+
+    int cpv0[2] = {0, 0}, cpv1[2] = {0, 0};
+    auto load_window = [&](int i0) {
+        const int i = i0 + lane;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            cpv0[s] = (live[s] && i <= nb) ? cp[s][b0 + i] : 0;
+            cpv1[s] = (live[s] && i + 1 <= nb) ? cp[s][b0 + i + 1] : 0;
+        }
+    };
+    Meta cur[2], nxt[2];
+    if (nb > 0) {
+        load_window(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int g0 = __builtin_amdgcn_readlane(cpv0[s], 0), g1 = __builtin_amdgcn_readlane(cpv1[s], 0);
+            cur[s] = load_meta(g0, g1 - g0 < 16 ? g1 - g0 : 16);
+        }
+        dma_block(b0, 0);
+    } else {
+        cur[0] = cur[1] = load_meta(0, 0);
+    }
+    nxt[0] = cur[0];
+    nxt[1] = cur[1];
+    __syncthreads();
+
+    for (int i = 0; i < nb; ++i) {
+        const unsigned char* buf = lds + (i & 1) * BLK_BUF;
+        int g0[2], g1[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            g0[s] = __builtin_amdgcn_readlane(cpv0[s], i & 63);
+            g1[s] = __builtin_amdgcn_readlane(cpv1[s], i & 63);
+        }
+        if (i + 1 < nb) {
+            if (((i + 1) & 63) == 0) load_window(i + 1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int n0 = __builtin_amdgcn_readlane(cpv0[s], (i + 1) & 63), n1 = __builtin_amdgcn_readlane(cpv1[s], (i + 1) & 63);
+                nxt[s] = load_meta(n0, n1 - n0 < 16 ? n1 - n0 : 16);
+            }
+            dma_block(b0 + i + 1, (i + 1) & 1);
+        }
+        const int nga = g1[0] - g0[0] < 16 ? g1[0] - g0[0] : 16, ngb = g1[1] - g0[1] < 16 ? g1[1] - g0[1] : 16;
+        // the first 16 groups of the two cells in lockstep
+        static_for<16>([&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            const bool ha = K < nga, hb = K < ngb;                         // (scalar)
+            if (ha && hb) {
+                const Prep pa = prep(kk, I0(), cur[0], g0[0], buf);
+                Reads ra = reads(pa.rowb);
+                const Prep pb = prep(kk, I1(), cur[1], g0[1], buf);
+                Reads rb = reads(pb.rowb);
+                steps(I0(), I8(), pa.af, ra);
+                steps(I1(), I0(), pb.af, rb);
+            } else if (ha) {
+                const Prep pa = prep(kk, I0(), cur[0], g0[0], buf);
+                Reads ra = reads(pa.rowb);
+                steps(I0(), I0(), pa.af, ra);
+            } else if (hb) {
+                const Prep pb = prep(kk, I1(), cur[1], g0[1], buf);
+                Reads rb = reads(pb.rowb);
+                steps(I1(), I0(), pb.af, rb);
+            }
+        });
+        // cells of more than 16 groups: the rest strip by strip, batch by batch, each behind its own load
+        static_for<2>([&](auto ss) {
+            constexpr int S = decltype(ss)::value;
+            for (int gf = g0[S] + 16; gf < g1[S]; gf += 16) {
+                const int ng = g1[S] - gf < 16 ? g1[S] - gf : 16;
+                const Meta more = load_meta(gf, ng);
+                static_for<16>([&](auto kk) {
+                    constexpr int K = decltype(kk)::value;
+                    if (K < ng) {
+                        const Prep pc = prep(kk, ss, more, gf, buf);
+                        Reads rc = reads(pc.rowb);
+                        steps(ss, I0(), pc.af, rc);
+                    }
+                });
+            }
+        });
+        cur[0] = nxt[0];
+        cur[1] = nxt[1];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (live[s]) {
+            float* dst = a.out + (int64_t)part * a.part_stride;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t o = (strip0 + s) * BLK_OS + 4 * g + r;
+                if (o < a.n_out) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) dst[o * a.ld_out + 16 * c + sub] = acc[s][c][r];
+                }
+            }
+        }
+    }
+}
+
 
 }  // namespace skf
