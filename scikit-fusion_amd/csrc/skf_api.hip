@@ -507,7 +507,7 @@ static void launch_to_bf16(uint16_t* dst, int64_t ldd, const TS* src, int64_t ld
 // plan
 // ------------------------------------------------------------------------------------------
 // Test / A-B switches from the environment.  A plan reads them ONCE, when its workspace is bound (skf::Switches::read);
-// no launch path calls getenv.  Defaults are the measured best.
+// no launch path reads the environment.  Defaults are the measured best.
 struct Switches {
     bool pinv_jacobi = false;      // SKF_PINV_JACOBI=1     every pseudo-inverse through the Jacobi eigen-solver
     bool chol_unblocked = false;   // SKF_CHOL_UNBLOCKED=1  plain (unblocked) Cholesky inverse
