@@ -684,6 +684,7 @@ struct skf_plan {
     skf::Slot part;            // split-K partials
     size_t part_bytes = 0;
     skf::Slot eigA, eigV, eigVs, eigW, eigN, eigNorig, eigOk, sqpart;
+    skf::Slot eigX;                        // scratch of the multi-workgroup deflation (plans with a rank above 256)
     skf::Slot theta_flags, theta_tmp;      // sign flags of the constraints; SKF_BF16: n x c product scratch
     int64_t eig_stride = 0;
     int eig_maxn = 0;
@@ -952,6 +953,82 @@ static void launch_sweep(const Switches& sw, const EighArgs& e, const PinvBatch&
     check_launch("sweep_inverse");
 }
 
+// Rank-revealing deflation over several workgroups (skf_kernels.h, pchol_step_kernel) for the matrices of a batch whose fast
+// path failed, orders above SWEEP_MAXN: every launch is gated on the device (chol_ok, the verdict of the steps, the verdict of
+// the sweep over B), the host issues the sequence blind.  K[b]: c x c f64, ld = c.  `scratch`: defl_scratch_bytes(nb, stride).
+static size_t defl_scratch_bytes(int nb, int64_t stride) {
+    return align_up((size_t)3 * nb * stride * 8, 256) + align_up((size_t)nb * 2 * EIGH_MAXN * 8, 256) +
+           align_up((size_t)nb * 4 * 8, 256) + align_up((size_t)nb * 8 * sizeof(int), 256);
+}
+static bool defl_multi_takes(const Switches& sw, int max_c) {
+    return max_c > SWEEP_MAXN && max_c < EIGH_MAXN && sweep_takes(sw, max_c) && !sw.pinv_jacobi;
+}
+static void launch_deflation_multi(const Switches& sw, int engine, const EighArgs& e, const PinvBatch& pb, int nb, int max_c,
+                                   void* scratch, hipStream_t st) {
+    char* base = (char*)scratch;
+    double* M0 = (double*)base;
+    double* M1 = M0 + (size_t)nb * e.stride;
+    double* Binv = M1 + (size_t)nb * e.stride;
+    base += align_up((size_t)3 * nb * e.stride * 8, 256);
+    DeflArgs da;
+    da.d = (double*)base;
+    base += align_up((size_t)nb * 2 * EIGH_MAXN * 8, 256);
+    da.vals = (double*)base;
+    base += align_up((size_t)nb * 4 * 8, 256);
+    da.state = (int*)base;
+    da.n_defl = da.state + 4 * nb;
+    da.gate = da.n_defl + nb;
+    da.ok2 = da.gate + nb;
+    da.rank = da.ok2 + nb;
+    const int np = max_c + (max_c & 1);
+    hipLaunchKernelGGL(pchol_init_kernel, dim3(elem_grid((int64_t)np * np), (unsigned)nb), dim3(256), 0, st, e, da);
+    check_launch("pchol_init");
+    const int steps = 2 * cdiv(max_c, DEFL_NB) + 1, slabs = cdiv(max_c, DEFL_ROWS);
+    for (int step = 0; step < steps; ++step) {
+        hipLaunchKernelGGL(pchol_step_kernel, dim3((unsigned)nb, (unsigned)slabs), dim3(DEFL_THREADS), 0, st, e, da, deflation_lo(sw), 1e-7,
+                           step);
+        check_launch("pchol_step");
+    }
+    const int fin = steps & 1;
+    hipLaunchKernelGGL(pchol_verdict_kernel, dim3((unsigned)nb), dim3(64), 0, st, e, da, fin);
+    check_launch("pchol_verdict");
+    const GemmTypes f64{SKF_F64, SKF_F64, SKF_F64};
+    for (int b = 0; b < nb; ++b) {                      // B = L^T L  (Lt[k][i] = L[i][k], ld = the padded order)
+        const int c = pb.c[b], ld = pb.n_pad[b];
+        const double* Lt = e.V + (int64_t)b * e.stride;
+        GemmArgs g = gemm_args(Lt, ld, 1, Lt, 1, ld, e.Vs + (int64_t)b * e.stride, ld, c, c, c, EPI_STORE, 0);
+        g.gate = da.gate + b;
+        run_gemm(f64, engine, g, 1, nullptr, 0, st);
+    }
+    hipLaunchKernelGGL(pchol_patch_kernel, dim3((unsigned)nb), dim3(256), 0, st, e, da, fin);
+    check_launch("pchol_patch");
+    {                                                   // B^-1 by the blocked sweep of the fast path (idle where n_defl = 0)
+        EighArgs e2 = e;
+        e2.A = e.Vs; e2.V = M0; e2.Vs = M1;
+        e2.n_orig = da.n_defl;
+        e2.chol_ok = da.ok2;
+        PinvBatch pb2 = pb;
+        for (int b = 0; b < nb; ++b) pb2.K[b] = Binv + (int64_t)b * e.stride;
+        launch_sweep(sw, e2, pb2, nb, max_c, st);
+    }
+    hipLaunchKernelGGL(pchol_gate2_kernel, dim3((unsigned)nb), dim3(64), 0, st, da);
+    check_launch("pchol_gate2");
+    for (int b = 0; b < nb; ++b) {
+        const int c = pb.c[b], ld = pb.n_pad[b];
+        const double* Lt = e.V + (int64_t)b * e.stride;
+        const double* Bi = Binv + (int64_t)b * e.stride;        // (the sweep writes its result with ld = the order)
+        double* Yt = M0 + (int64_t)b * e.stride;
+        GemmArgs g = gemm_args(Bi, c, 1, Lt, ld, 1, Yt, ld, c, c, c, EPI_STORE, 0);         // Y^T = B^-1 L^T
+        g.gate = da.gate + b;
+        run_gemm(f64, engine, g, 1, nullptr, 0, st);
+        g = gemm_args(Yt, 1, ld, Yt, ld, 1, pb.K[b], c, c, c, c, EPI_STORE, 0);             // K = Y Y^T
+        g.gate = da.gate + b;
+        run_gemm(f64, engine, g, 1, nullptr, 0, st);
+    }
+    hipLaunchKernelGGL(pchol_done_kernel, dim3((unsigned)nb), dim3(64), 0, st, e, da);
+    check_launch("pchol_done");
+}
+
 // K_i = pinv(Gram_i) for every type (one workgroup each); `which` = 0..n_types-1, the order
 // of the per-matrix order arrays uploaded once by skf_plan_bind_workspace.
 static void pinv_fallbacks(skf_plan* p, const std::vector<int>& which, const PinvBatch& pb, const EighArgs& e, bool batched, int max_c,
@@ -1024,6 +1101,9 @@ static void pinv_fallbacks(skf_plan* p, const std::vector<int>& which, const Pin
                            hipStream_t st) {
     const int64_t stride = p->eig_stride;
     const int nb = (int)which.size();
+    // orders above 256: the deflation over several workgroups first (round 6); what it declines is still there for the rest
+    if (batched && p->eigX.ptr && p->engine == SKF_ENGINE_MFMA && defl_multi_takes(p->sw, max_c))
+        launch_deflation_multi(p->sw, p->engine, e, pb, nb, max_c, p->eigX.ptr, st);
     // a rank-deficient Gram matrix with a clear spectral gap: rank-revealing deflation (pchol_pinv_kernel); what it
     // declines goes to the eigen-solver with the exact singular-value cut-off
     {
@@ -3569,6 +3649,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             add_slot(p, p->eigN, (size_t)n_types * sizeof(int));
             add_slot(p, p->eigNorig, (size_t)n_types * sizeof(int));
             add_slot(p, p->eigOk, (size_t)n_types * sizeof(int));
+            if (maxn > SWEEP_MAXN && n_types <= PINV_MAXB) add_slot(p, p->eigX, defl_scratch_bytes(n_types, p->eig_stride));
         }
         guard.p = nullptr;
         *out = p;
@@ -4534,6 +4615,7 @@ int skf_pinv_sym_workspace_bytes(int32_t n, size_t* bytes) {
         if (n <= 0 || n > EIGH_MAXN - 1 || !bytes) SKF_FAIL(SKF_E_INVALID, "bad order");
         const size_t np = (size_t)(n + 1) / 2 * 2;
         *bytes = align_up(np * np * 8, 256) * 3 + align_up(np * 8, 256) + 512;
+        if (n > SWEEP_MAXN) *bytes += defl_scratch_bytes(1, (int64_t)np * np) + 256;
     });
 }
 
@@ -4584,6 +4666,13 @@ int skf_pinv_sym(int32_t dtype, const void* A, int64_t lda, void* K, int64_t ldk
                 hipLaunchKernelGGL((chol_unpack_kernel<float>), dim3(elem_grid(tot2)), dim3(256), 0, st, (float*)K, ldk,
                                    eV, np, n, eOk);
             check_launch("chol_unpack");
+        }
+        if (sweep && defl_multi_takes(sw, n)) {      // orders above 256: the deflation over several workgroups first
+            PinvBatch pb;
+            memset(&pb, 0, sizeof pb);
+            pb.K[0] = (double*)K; pb.c[0] = n; pb.n_pad[0] = np;
+            char* scratch = base + align_up(mat * 3 + align_up((size_t)np * 8, 256) + 512, 256);
+            launch_deflation_multi(sw, SKF_ENGINE_MFMA, e, pb, 1, n, scratch, st);
         }
         {
             static DeviceOnce once;

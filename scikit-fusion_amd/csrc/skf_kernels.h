@@ -58,6 +58,8 @@ struct GemmArgs {
     int aop, epi, nan_to_num;
     int c_bf16;              // EPI_SQDIFF: the matrix behind C is stored as bf16
     int mask_bits;           // EPI_MASKED_STORE: the mask is packed (the engine's own masks always are)
+    const int* gate;         // when set: the launch does nothing unless *gate != 0 (a verdict earlier launches left on the device:
+                             // the finishing products of the multi-workgroup deflation, which the host issues blind)
     int sym;                 // split-K launches of a SYMMETRIC product (Gram = G^T G): bm | bn << 16 of the launch's tile -- the
                              // grid lists only the tiles on / below the diagonal (gridDim.x = their number, gridDim.y = 1) and
                              // the reduce takes an element of a tile that was not computed from its mirror image (element
@@ -504,6 +506,7 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmArgs& g, const unsigned
 
 template <typename T, typename TA, typename TB, int WR, int WC, int BK, int TAG, int FM = -1>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_kernel(GemmArgs g) {
+    if (g.gate != nullptr && *g.gate == 0) return;                         // (uniform)
     gemm_mfma_body<T, TA, TB, WR, WC, BK, TAG, FM>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
 }
 
@@ -861,6 +864,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_valu_kernel(GemmArgs g) {
     constexpr int BM = 64, BN = 64, BK = 16, LDT = BM + 1;
     __shared__ T As[BK][LDT];
     __shared__ T Bs[BK][LDT];
+    if (g.gate != nullptr && *g.gate == 0) return;                         // (uniform)
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;          // 16 x 16 threads, 4 x 4 outputs each
     const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
@@ -1715,6 +1719,7 @@ __global__ __launch_bounds__(256) void bf16_splitk_reduce_kernel(float* __restri
 // second stage of a split-K launch: fixed-order sum over the slices, then the epilogue
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int splits) {
+    if (g.gate != nullptr && *g.gate == 0) return;
     const int64_t total = (int64_t)g.M * g.N;
     const T* part = (const T*)g.part;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -1733,6 +1738,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_z16_kernel(GemmArgs g, int 
     // loads in flight), the 16 sums of an element are added in the order zl = 0 .. 15.  (One thread per element walked
     // up to 250 slices of a wide c x c product one load at a time: 75 us for 16 000 outputs.)
     __shared__ T red[16][17];
+    if (g.gate != nullptr && *g.gate == 0) return;
     const int64_t total = (int64_t)g.M * g.N;
     const T* part = (const T*)g.part;
     const int zl = threadIdx.x >> 4, el = threadIdx.x & 15;
@@ -3102,6 +3108,256 @@ __device__ __forceinline__ void pchol_pinv_body(const EighArgs& e, const int b, 
 }
 __global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, double lo, double hi, int lds_rank) {
     pchol_pinv_body(e, blockIdx.x, lo, hi, lds_rank);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same deflation over SEVERAL workgroups, for orders above 256 (round 6; pchol_pinv_kernel takes 19.5 ms at order 512 /
+// rank 256 and 146 ms at 1023 / 512 in its one workgroup -- the case reference tests/test_n_run.py:14 constructs: rank >
+// objects).  One launch per BLOCK of up to 32 pivots, grid = (matrices, slabs of 64 rows), no grid barrier: a launch reads
+// one copy of the remaining diagonal / the state and writes the other, every workgroup repeats the small serial part
+// (the 32 largest remaining diagonal entries by rank counting, their 32 x 32 block of the Schur complement, its Cholesky
+// factorisation with REJECTION of pivots that fell to the noise level inside the block) and owns the rows of its slab:
+//     C[i][p] = A[i][piv_p] - sum_{k < r} L[i][k] L[piv_p][k]      (the lazily evaluated columns, as pchol_pinv_kernel)
+//     L[i][r + a] = (C[i][p_a] - sum_{b < a} L[i][r + b] Lb[a][b]) / Lb[a][a]      for the accepted pivots p_0 < p_1 < ...
+//     d[i] -= sum_a L[i][r + a]^2
+// Same acceptance rule and the same gap test as the one-workgroup kernel (pivot > lo * d_max; an accepted pivot below
+// hi * d_max leaves the matrix to the eigen-solver); the pivots of a block are taken in the order of the diagonal as it
+// stood BEFORE the block (the one-workgroup kernel re-sorts after every pivot): the factor differs, A = L L^T and the
+// pseudo-inverse do not.  The host issues 2 ceil(n / 32) + 1 launches blind -- a launch whose matrix is finished, or was
+// inverted by the fast path, returns at once --, then
+//     pchol_verdict_kernel   gate[b] = the deflation finished cleanly; n_defl[b] = its order (0: the finishing launches idle)
+//     B = L^T L (+ 1 on the diagonal beyond the rank)      gated product, pchol_patch_kernel
+//     B^-1                                                  the blocked sweep of the fast path (sweep_step_kernel<BIG>) on B
+//     Y^T = B^-1 L^T ,  K = Y Y^T                           gated products, straight into the K slot
+//     pchol_done_kernel      chol_ok[b] = 1
+// Order 512 / rank 256: see profiles/ (tools/bench_pinv.py).  A matrix the route declines at any point keeps chol_ok = 0 and
+// falls to pchol_pinv_kernel / the eigen-solver exactly as before.
+// ------------------------------------------------------------------------------------------
+constexpr int DEFL_NB = 32, DEFL_ROWS = 64, DEFL_KC = 32, DEFL_THREADS = 256;
+struct DeflArgs {
+    double* d;         // [batch][2][EIGH_MAXN]  remaining diagonal (< 0: the index has been a pivot), two copies
+    double* vals;      // [batch][2][2]          d_max of the input, smallest accepted pivot
+    int* state;        // [batch][2][2]          rank so far, done (0 running, 1 finished, 2 declined: ambiguous spectrum)
+    int* n_defl;       // [batch]                order for the finishing launches (0 = none)
+    int* gate;         // [batch]                1 = finishing products run
+    int* ok2;          // [batch]                verdict of the sweep over B
+    int* rank;         // [batch]                numerical rank (information; tests)
+};
+
+__global__ __launch_bounds__(256) void pchol_init_kernel(EighArgs e, DeflArgs da) {     // L = 0 for the matrices the fast path declined
+    const int b = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { da.gate[b] = 0; da.n_defl[b] = 0; da.ok2[b] = 0; da.rank[b] = -1; }
+    if (e.chol_ok[b] != 0) return;
+    const int ld = e.n[b];
+    double* Lt = e.V + (int64_t)b * e.stride;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ld * ld; idx += gridDim.x * blockDim.x) Lt[idx] = 0.0;
+}
+
+__global__ __launch_bounds__(DEFL_THREADS) void pchol_step_kernel(EighArgs e, DeflArgs da, double lo, double hi, int step) {
+    __shared__ double sd[EIGH_MAXN];
+    __shared__ double Lp[DEFL_KC][DEFL_NB + 1];        // L[piv_p][k0 + kk]
+    __shared__ double Ls[DEFL_KC][DEFL_ROWS + 1];      // L[row0 + i][k0 + kk]
+    __shared__ double Cp[DEFL_NB][DEFL_NB + 1];        // pivot block, then its Cholesky factor (accepted pivots)
+    __shared__ double Cs[DEFL_ROWS][DEFL_NB + 1];      // panel of the slab, then its rows of L
+    __shared__ double red[DEFL_THREADS / 64];
+    __shared__ int piv[DEFL_NB], ord[DEFL_NB], s_elig;
+    const int b = blockIdx.x;
+    if (e.chol_ok[b] != 0) return;                                          // (uniform: the fast path inverted this matrix)
+    const int n = e.n_orig[b], ld = e.n[b];
+    const int row0 = blockIdx.y * DEFL_ROWS;
+    if (row0 >= n) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int in = step & 1, out = in ^ 1;
+    const double* A = e.A + (int64_t)b * e.stride;
+    double* Lt = e.V + (int64_t)b * e.stride;                               // Lt[k * ld + i] = L[i][k]
+    const double* din = da.d + ((int64_t)b * 2 + in) * EIGH_MAXN;
+    double* dout = da.d + ((int64_t)b * 2 + out) * EIGH_MAXN;
+    const int* sin = da.state + (b * 2 + in) * 2;
+    int* sout = da.state + (b * 2 + out) * 2;
+    const double* vin = da.vals + (b * 2 + in) * 2;
+    double* vout = da.vals + (b * 2 + out) * 2;
+    int r = 0, done = 0;
+    double dmax0 = 0.0, last = __builtin_inf();
+    if (step == 0) {
+        double mx = 0.0;
+        for (int i = tid; i < n; i += DEFL_THREADS) {
+            const double v = A[(int64_t)i * ld + i];
+            sd[i] = v;
+            mx = fmax(mx, v);
+        }
+        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        dmax0 = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    } else {
+        r = sin[0];
+        done = sin[1];
+        dmax0 = vin[0];
+        last = vin[1];
+        if (!done)
+            for (int i = tid; i < n; i += DEFL_THREADS) sd[i] = din[i];
+    }
+    if (done) {                                                             // (uniform) finished in an earlier launch: hand the state on
+        if (blockIdx.y == 0 && tid == 0) { sout[0] = r; sout[1] = done; vout[0] = dmax0; vout[1] = last; }
+        return;
+    }
+    if (tid == 0) s_elig = 0;
+    if (tid < DEFL_NB) { piv[tid] = 0; ord[tid] = -1; }
+    __syncthreads();
+    // ---- the (up to) 32 largest eligible entries of the remaining diagonal, by rank counting (ties: the smaller index first)
+    const double thr = lo * dmax0;
+    for (int i = tid; i < n; i += DEFL_THREADS) {
+        const double v = sd[i];
+        if (v > thr && v > 0.0) {
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const double w = sd[j];
+                rank += (w > v || (w == v && j < i)) ? 1 : 0;
+            }
+            if (rank < DEFL_NB) piv[rank] = i;
+            atomicAdd(&s_elig, 1);
+        }
+    }
+    __syncthreads();
+    const int m = s_elig < DEFL_NB ? s_elig : DEFL_NB;
+    if (m == 0) {                                                           // (uniform) nothing left above the noise level: finished
+        if (blockIdx.y == 0 && tid == 0) {
+            sout[0] = r;
+            sout[1] = (r > 0 && last < hi * dmax0) ? 2 : 1;
+            vout[0] = dmax0;
+            vout[1] = last;
+        }
+        return;
+    }
+    // ---- panel of the slab and pivot block, lazily: C = A[:, piv] - L[:, :r] L[piv, :r]^T
+    const int tx = tid & 31, ty = tid >> 5;                                // column p = tx; rows ty, ty + 8, ...
+    double cs[DEFL_ROWS / 8], cp[DEFL_NB / 8];
+    const int pc = tx < m ? piv[tx] : piv[0];
+#pragma unroll
+    for (int q = 0; q < DEFL_ROWS / 8; ++q) {
+        const int i = row0 + ty + 8 * q;
+        cs[q] = (i < n && tx < m) ? A[(int64_t)i * ld + pc] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < DEFL_NB / 8; ++q) {
+        const int pr = ty + 8 * q;
+        cp[q] = (pr < m && tx < m) ? A[(int64_t)piv[pr] * ld + pc] : 0.0;
+    }
+    for (int k0 = 0; k0 < r; k0 += DEFL_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < DEFL_KC / 8; ++q) {                             // Lp[kk][p]: kk = ty + 8 q, p = tx
+            const int kk = ty + 8 * q;
+            Lp[kk][tx] = (k0 + kk < r && tx < m) ? Lt[(int64_t)(k0 + kk) * ld + pc] : 0.0;
+        }
+        {
+            const int i = tid & 63;
+#pragma unroll
+            for (int q = 0; q < DEFL_KC / 4; ++q) {                         // Ls[kk][i]: kk = (tid >> 6) + 4 q
+                const int kk = (tid >> 6) + 4 * q;
+                Ls[kk][i] = (k0 + kk < r && row0 + i < n) ? Lt[(int64_t)(k0 + kk) * ld + row0 + i] : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < DEFL_KC; ++kk) {
+            const double lp = Lp[kk][tx];
+#pragma unroll
+            for (int q = 0; q < DEFL_ROWS / 8; ++q) cs[q] -= Ls[kk][ty + 8 * q] * lp;
+#pragma unroll
+            for (int q = 0; q < DEFL_NB / 8; ++q) cp[q] -= Lp[kk][ty + 8 * q] * lp;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < DEFL_ROWS / 8; ++q) Cs[ty + 8 * q][tx] = cs[q];
+#pragma unroll
+    for (int q = 0; q < DEFL_NB / 8; ++q) Cp[ty + 8 * q][tx] = cp[q];
+    __syncthreads();
+    // ---- Cholesky of the pivot block with rejection: a pivot that the block's earlier pivots took below the noise level is
+    // skipped (its row stays an ordinary row; its updated diagonal keeps it from being chosen again)
+    int n_acc = 0;
+    for (int p = 0; p < m; ++p) {
+        const double pv = Cp[p][p];
+        const bool accept = pv > thr && pv > 0.0;                           // (uniform)
+        if (accept) {
+            const double lkk = sqrt(pv);
+            __syncthreads();
+            if (tid > p && tid < m) Cp[tid][p] /= lkk;
+            __syncthreads();
+            for (int idx = tid; idx < m * m; idx += DEFL_THREADS) {
+                const int q = idx / m, c = idx % m;
+                if (q > p && c > p && c <= q) Cp[q][c] -= Cp[q][p] * Cp[c][p];
+            }
+            if (tid == 0) { Cp[p][p] = lkk; ord[p] = n_acc; }
+            ++n_acc;
+            last = fmin(last, pv);
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // ---- the slab's rows of the new columns of L, the remaining diagonal
+    if (tid < DEFL_ROWS && row0 + tid < n) {
+        const int i = row0 + tid;
+        const double di = sd[i];
+        int own = -1;                                                       // this row is pivot `own` of the block (accepted)
+        for (int p = 0; p < m; ++p)
+            if (piv[p] == i && ord[p] >= 0) own = p;
+        double sq = 0.0;
+        for (int p = 0; p < m; ++p) {
+            if (ord[p] < 0) continue;
+            double x;
+            if (di < 0.0) x = 0.0;                                          // a pivot of an earlier block: above the diagonal
+            else if (own >= 0) x = p <= own ? Cp[own][p] : 0.0;             // a pivot of this block: its row of the factor
+            else {
+                double sacc = Cs[tid][p];
+                for (int q = 0; q < p; ++q)
+                    if (ord[q] >= 0) sacc -= Cs[tid][q] * Cp[p][q];
+                x = sacc / Cp[p][p];
+            }
+            Cs[tid][p] = x;
+            sq += x * x;
+            Lt[(int64_t)(r + ord[p]) * ld + i] = x;
+        }
+        double nd = di;
+        if (own >= 0) nd = -1.0;
+        else if (di >= 0.0) { nd = di - sq; nd = nd > 0.0 ? nd : 0.0; }
+        dout[i] = nd;
+    }
+    if (blockIdx.y == 0 && tid == 0) {
+        sout[0] = r + n_acc;
+        sout[1] = 0;
+        vout[0] = dmax0;
+        vout[1] = last;
+    }
+}
+
+// after the last step: did the deflation finish cleanly?  (final = the copy of the state the last launch wrote)
+__global__ __launch_bounds__(64) void pchol_verdict_kernel(EighArgs e, DeflArgs da, int final_copy) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const int* s = da.state + (b * 2 + final_copy) * 2;
+    const bool ok = e.chol_ok[b] == 0 && s[1] == 1;
+    da.gate[b] = ok ? 1 : 0;
+    da.n_defl[b] = ok ? e.n_orig[b] : 0;
+    da.rank[b] = e.chol_ok[b] == 0 ? s[0] : -1;
+}
+// B = L^T L has rank r: 1 on the diagonal beyond it makes the matrix the sweep inverts positive definite (the block beyond r
+// is the identity and stays decoupled: L's columns there are zero)
+__global__ __launch_bounds__(256) void pchol_patch_kernel(EighArgs e, DeflArgs da, int final_copy) {
+    const int b = blockIdx.x;
+    if (!da.gate[b]) return;
+    const int n = e.n_orig[b], ld = e.n[b], r = da.state[(b * 2 + final_copy) * 2];
+    double* B = e.Vs + (int64_t)b * e.stride;
+    for (int k = r + threadIdx.x; k < n; k += blockDim.x) B[(int64_t)k * ld + k] = 1.0;
+}
+__global__ __launch_bounds__(64) void pchol_done_kernel(EighArgs e, DeflArgs da) {
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0 && da.gate[b] && da.ok2[b] == 1) e.chol_ok[b] = 1;
+}
+// the gate of the products behind the sweep over B: both verdicts
+__global__ __launch_bounds__(64) void pchol_gate2_kernel(DeflArgs da) {
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) da.gate[b] = (da.gate[b] && da.ok2[b] == 1) ? 1 : 0;
 }
 
 // K(r,c) = sum_{k >= max(r,c)} X(k,r) X(k,c)   (inverse from the inverted Cholesky factor)

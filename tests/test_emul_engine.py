@@ -640,6 +640,25 @@ def test_fit_with_a_rank_above_256(monkeypatch):
             assert relerr(S[k][0], So[k][0]) < 8e-11, (big, k)        # measured 2e-12 .. 8e-12
 
 
+def test_fit_with_a_rank_deficient_gram_above_order_256():
+    """Round 6 (reference tests/test_n_run.py:14 at a rank above 256: more latent dimensions than objects).  Type `a` has
+    150 objects and rank 280: its Gram matrix has rank 150, the fast path declines it every iteration and the deflation
+    over several workgroups (pchol_step_kernel, gated finishing products) forms the pseudo-inverse -- inside the batch that
+    also holds a full-rank order-70 matrix, which the same launches must leave alone.  Against the oracle (scipy pinv), f64."""
+    rs = np.random.RandomState(31)
+    types = ['a', 'b', 'c']
+    n = {'a': 150, 'b': 220, 'c': 90}
+    rank = {'a': 280, 'b': 70, 'c': 40}
+    R = {('a', 'b'): [rs.rand(150, 220)], ('a', 'c'): [rs.rand(150, 90) - 0.3], ('b', 'c'): [rs.rand(220, 90)]}
+    G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.05 for t in types}
+    Go, So = orc.dfmf(R, {}, types, rank, max_iter=2, G0=G0)
+    G, S = _dfmf.dfmf(R, {}, types, rank, max_iter=2, G0=G0, dtype='f64')
+    for t in types:
+        assert relerr(G[t, t], Go[t, t]) < 1e-9, t
+    for k in So:
+        assert relerr(S[k][0], So[k][0]) < 1e-8, k
+
+
 @pytest.mark.parametrize('dtype', ['f64', 'bf16'])
 def test_round5_schedule_switches_keep_every_bit(dtype, monkeypatch):
     """Round 5: (a) split-K Gram products compute only the tiles on / below the diagonal and the reduce mirrors the rest

@@ -259,7 +259,7 @@ def test_to_bf16_and_transpose(rt):
         assert (gotT[:, 70:] == 0).all()
 
 
-def run_pinv(rt, dtype, A):
+def run_pinv(rt, dtype, A, route=None):
     npd = nat.NP_DTYPE[dtype]
     n = A.shape[0]
     need = C.c_size_t()
@@ -268,6 +268,15 @@ def run_pinv(rt, dtype, A):
     k = rt.mem.empty(n * n * np.dtype(npd).itemsize)
     ws = rt.mem.empty(need.value)
     rt.call('skf_pinv_sym', dtype, a.ptr, n, k.ptr, n, n, ws.ptr, need.value, None)
+    if route is not None:
+        # the verdict word of the operator's workspace (skf_pinv_sym: three n_pad^2 f64 matrices, the eigenvalue row, then
+        # int words: order, original order at +16, verdict at +32): 1 = an inverse written straight into K (fast path, or
+        # the multi-workgroup deflation), 2 = the one-workgroup deflation, 0 = the eigen-solver
+        npad = (n + 1) // 2 * 2
+        mat = (npad * npad * 8 + 255) // 256 * 256
+        off = 3 * mat + (npad * 8 + 255) // 256 * 256 + 32 * 4
+        words = rt.mem.to_host(ws, (need.value // 4,), np.int32)
+        route.append(int(words[off // 4]))
     return rt.mem.to_host(k, (n, n), npd)
 
 
@@ -419,6 +428,50 @@ def test_pinv_deflation_matches_scipy_and_the_eigen_path(rt, n, rank, monkeypatc
     monkeypatch.setenv('SKF_PINV_JACOBI', '1')
     exact = run_pinv(rt, nat.SKF_F64, A)
     assert relerr(got, exact) < 1e-8
+
+
+@pytest.mark.parametrize('n,rank', [(300, 170), (420, 97), (260, 259)])
+def test_pinv_deflation_over_several_workgroups_above_order_256(rt, n, rank, monkeypatch):
+    """Round 6: above order 256 a rank-deficient Gram matrix is deflated by pchol_step_kernel -- one launch per block of
+    up to 32 pivots over slabs of 64 rows, pivots rejected inside a block when the block's earlier pivots took them to the
+    noise level (a duplicated column is chosen twice by the stale diagonal) --, B = L^T L is inverted by the blocked sweep of
+    the fast path and K = Y Y^T leaves two gated products: same result as scipy.linalg.pinv and as the one-workgroup
+    kernel (SKF_SWEEP_BIG=0 switches the multi-workgroup route off with the fast path it builds on)."""
+    import scipy.linalg as spla
+    rs = np.random.RandomState(n + rank)
+    G = rs.rand(rank, n)
+    G[:, n // 2] = G[:, 1]                       # an exactly duplicated latent column
+    G[:, 7] = 0.0                                # and an all-zero one
+    A = G.T @ G
+    want = spla.pinv(A)
+    route = []
+    got = run_pinv(rt, nat.SKF_F64, A, route)
+    assert route == [1]                          # written straight into K by the multi-workgroup route
+    assert relerr(got, want) < 1e-8, relerr(got, want)
+    assert relerr(A @ got @ A, A) < 1e-10
+    assert np.abs(got - got.T).max() <= 1e-10 * np.abs(got).max()
+    monkeypatch.setenv('SKF_SWEEP_BIG', '0')
+    one_wg = run_pinv(rt, nat.SKF_F64, A, route)
+    assert route == [1, 2]                       # ... and by the one-workgroup kernel (eigen format) without it
+    assert relerr(got, one_wg) < 1e-8
+
+
+def test_pinv_ambiguous_spectrum_above_order_256_is_left_to_the_exact_cut_off(rt):
+    """The multi-workgroup deflation applies the same gap test: an accepted pivot inside (1e-10, 1e-7) of the largest
+    declines the matrix, and the eigen path with scipy's cut-off takes it."""
+    import scipy.linalg as spla
+    rs = np.random.RandomState(5)
+    n = 258
+    Qm, _ = np.linalg.qr(rs.randn(n, n))
+    w = np.array([1.0] * 40 + [1e-8] * 2 + [0.0] * (n - 42))
+    A = (Qm * w) @ Qm.T
+    A = 0.5 * (A + A.T)
+    route = []
+    got = run_pinv(rt, nat.SKF_F64, A, route)
+    assert route == [0]                           # declined by both deflations: the eigen-solver
+    want = spla.pinv(A)
+    assert np.abs(got).max() > 1e6                # the 1e-8 directions were inverted, not dropped
+    assert relerr(got, want) < 1e-6
 
 
 def test_pinv_ambiguous_spectrum_falls_back_to_the_exact_cut_off(rt):

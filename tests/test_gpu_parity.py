@@ -180,6 +180,12 @@ def test_fit_with_a_rank_above_256_on_the_hardware(monkeypatch):
     E.test_fit_with_a_rank_above_256(monkeypatch)
 
 
+def test_fit_with_a_rank_deficient_gram_above_order_256_on_the_hardware():
+    """The multi-workgroup deflation inside a fit (round 6), against the oracle."""
+    import test_emul_engine as E
+    E.test_fit_with_a_rank_deficient_gram_above_order_256()
+
+
 def test_fit_with_every_rank_above_512_on_the_relation_pipeline():
     """Ranks above 512 leave the deep unsplit tile: the c x c products of the SECOND stream are cut into K slices while
     the main stream's split-K contractions are in flight -- each stream keeps its partials in its own scratch (round 6,
