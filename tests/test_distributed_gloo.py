@@ -124,6 +124,55 @@ def _bf16_owned():
     return [G[t, t] for t in types] + [S[k][0] for k in sorted(S)]
 
 
+def _rccl_rendezvous(rank, out):
+    """The failure paths of the RCCL rendezvous (_engine._shared_rccl_comm) over a real process group, with the library's two
+    entry points replaced by stand-ins: (a) ONE rank cannot bind RCCL (skf_comm_unique_id fails there) -- every rank must
+    come back with None, nobody enters ncclCommInitRank; (b) every rank has the id but skf_comm_create fails on one -- again
+    None everywhere, and the decision is cached per group; (c) both succeed -- the same handle is handed out twice."""
+    import ctypes as C
+    import torch.distributed as dist
+    import skfusion_amd._native as nat
+    import skfusion_amd._engine as eng
+
+    class Stub(object):
+        def __init__(self, fail_id=False, fail_create=False):
+            self.fail_id, self.fail_create, self.calls = fail_id, fail_create, []
+            self.lib = self
+            self.mem = None
+
+        def skf_comm_destroy(self, comm):
+            self.calls.append('destroy')
+            return 0
+
+        def call(self, fname, *args):
+            self.calls.append(fname)
+            if fname == 'skf_comm_unique_id':
+                if self.fail_id:
+                    raise nat.SkfNativeError(-5, 'RCCL not found (stand-in)')
+                C.memmove(args[0], b'x' * 128, 128)
+            elif fname == 'skf_comm_create':
+                if self.fail_create:
+                    raise nat.SkfNativeError(-5, 'ncclCommInitRank failed (stand-in)')
+                C.cast(args[3], C.POINTER(C.c_void_p))[0] = 0x1234
+            else:
+                raise AssertionError(fname)
+    seen = []
+    for case, stub in (('a', Stub(fail_id=(rank == 1))), ('b', Stub(fail_create=(rank == 0))), ('c', Stub())):
+        eng._RCCL.clear()
+        got = eng._shared_rccl_comm(stub, dist)
+        again = eng._shared_rccl_comm(stub, dist)              # cached for this group: no second rendezvous
+        n_create = stub.calls.count('skf_comm_create')
+        if case == 'a':
+            assert got is None and again is None and n_create == 0, (case, rank, stub.calls)
+        elif case == 'b':
+            assert got is None and again is None and n_create == 1, (case, rank, stub.calls)
+        else:
+            assert got is not None and again is got and n_create == 1, (case, rank, stub.calls)
+        seen.append(n_create)
+    eng._RCCL.clear()
+    np.savez(os.path.join(out, 'rccl%d.npz' % rank), np.array(seen))
+
+
 def _worker(rank, world, port, out, what):
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, HERE)
@@ -137,7 +186,9 @@ def _worker(rank, world, port, out, what):
         assert dist_world() == (rank, world)
         assert my_runs(3) == [k for k in range(3) if k % world == rank]
         with use_runtime(emulated_runtime()):
-            if what == 'runs':
+            if what == 'rccl':
+                _rccl_rendezvous(rank, out)
+            elif what == 'runs':
                 np.savez(os.path.join(out, 'rank%d.npz' % rank), *_fit())
             elif what.startswith('stop:'):
                 np.savez(os.path.join(out, 'stop%d.npz' % rank), *_probe_stopping(what[5:]))
@@ -261,3 +312,66 @@ def test_bf16_engine_sharded_by_ownership_over_two_gloo_ranks(tmp_path):
     for k, t in enumerate(types):
         np.testing.assert_array_equal(a[0]['arr_%d' % k], a[1]['arr_%d' % k])
         assert relerr(a[0]['arr_%d' % k], Gs[t, t]) < 5e-3
+
+
+def test_rccl_rendezvous_failure_paths_agree_on_every_rank(tmp_path):
+    """Round 6: the first multi-rank RCCL run must not hang on a rank that cannot bind the library or
+    whose ncclCommInitRank fails -- all ranks agree on the callback transport instead.  Two gloo ranks, the two library entry
+    points replaced by stand-ins; and the bound on a rendezvous that never returns (one rank, SKF_COMM_TIMEOUT)."""
+    import torch.multiprocessing as mp
+    from emul.runtime import build
+    build()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), 'rccl'), nprocs=2, join=True)
+    for rank in range(2):
+        z = np.load(os.path.join(str(tmp_path), 'rccl%d.npz' % rank))
+        np.testing.assert_array_equal(z['arr_0'], [0, 1, 1])
+
+
+def test_rccl_rendezvous_is_bounded_in_time(monkeypatch):
+    """A rank still inside ncclCommInitRank after SKF_COMM_TIMEOUT seconds raises (the caller treats it as fatal for the
+    process group) instead of waiting for the transport's own watchdog."""
+    import time
+    import ctypes as C
+    import skfusion_amd._engine as eng
+
+    class FakeDist(object):
+        @staticmethod
+        def get_rank():
+            return 0
+
+        @staticmethod
+        def get_world_size():
+            return 1
+
+        @staticmethod
+        def get_backend():
+            return 'gloo'
+
+        @staticmethod
+        def all_reduce(t, op=None):
+            return None
+
+        class ReduceOp(object):
+            MIN = 'min'
+
+        @staticmethod
+        def broadcast_object_list(objs, src=0):
+            return None
+
+    class Slow(object):
+        lib = None
+
+        def call(self, fname, *args):
+            if fname == 'skf_comm_unique_id':
+                C.memmove(args[0], b'y' * 128, 128)
+            else:
+                time.sleep(3.0)
+    monkeypatch.setenv('SKF_COMM_TIMEOUT', '0.3')
+    monkeypatch.setattr(eng, '_group_token', lambda dist: 'fake-group')
+    eng._RCCL.clear()
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match='still waits in ncclCommInitRank'):
+        eng._shared_rccl_comm(Slow(), FakeDist)
+    assert time.time() - t0 < 2.0
+    eng._RCCL.clear()
