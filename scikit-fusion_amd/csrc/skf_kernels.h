@@ -3121,9 +3121,9 @@ __global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, do
 //     L[i][r + a] = (C[i][p_a] - sum_{b < a} L[i][r + b] Lb[a][b]) / Lb[a][a]      for the accepted pivots p_0 < p_1 < ...
 //     d[i] -= sum_a L[i][r + a]^2
 // Same acceptance rule and the same gap test as the one-workgroup kernel (pivot > lo * d_max; an accepted pivot below
-// hi * d_max leaves the matrix to the eigen-solver); the pivots of a block are taken in the order of the diagonal as it
-// stood BEFORE the block (the one-workgroup kernel re-sorts after every pivot): the factor differs, A = L L^T and the
-// pseudo-inverse do not.  The host issues 2 ceil(n / 32) + 1 launches blind -- a launch whose matrix is finished, or was
+// hi * d_max leaves the matrix to the eigen-solver); the CANDIDATES of a block are the 32 largest entries of the diagonal as
+// it stood before the block, inside the block the pivots follow the current Schur complement (complete pivoting over the
+// candidates): the factor differs from the one-workgroup kernel's, A = L L^T and the pseudo-inverse do not.  The host issues 2 ceil(n / 32) + 1 launches blind -- a launch whose matrix is finished, or was
 // inverted by the fast path, returns at once --, then
 //     pchol_verdict_kernel   gate[b] = the deflation finished cleanly; n_defl[b] = its order (0: the finishing launches idle)
 //     B = L^T L (+ 1 on the diagonal beyond the rank)      gated product, pchol_patch_kernel
@@ -3160,7 +3160,7 @@ __global__ __launch_bounds__(DEFL_THREADS) void pchol_step_kernel(EighArgs e, De
     __shared__ double Cp[DEFL_NB][DEFL_NB + 1];        // pivot block, then its Cholesky factor (accepted pivots)
     __shared__ double Cs[DEFL_ROWS][DEFL_NB + 1];      // panel of the slab, then its rows of L
     __shared__ double red[DEFL_THREADS / 64];
-    __shared__ int piv[DEFL_NB], ord[DEFL_NB], s_elig;
+    __shared__ int piv[DEFL_NB], ord[DEFL_NB], open_[DEFL_NB], seq[DEFL_NB], s_elig, s_pick;
     const int b = blockIdx.x;
     if (e.chol_ok[b] != 0) return;                                          // (uniform: the fast path inverted this matrix)
     const int n = e.n_orig[b], ld = e.n[b];
@@ -3273,50 +3273,62 @@ __global__ __launch_bounds__(DEFL_THREADS) void pchol_step_kernel(EighArgs e, De
 #pragma unroll
     for (int q = 0; q < DEFL_NB / 8; ++q) Cp[ty + 8 * q][tx] = cp[q];
     __syncthreads();
-    // ---- Cholesky of the pivot block with rejection: a pivot that the block's earlier pivots took below the noise level is
-    // skipped (its row stays an ordinary row; its updated diagonal keeps it from being chosen again)
+    // ---- Cholesky of the pivot block with COMPLETE pivoting inside the block: the next pivot is the largest current diagonal
+    // entry among the block's open candidates (the candidates were picked by the diagonal as it stood before the block; inside
+    // it the order follows the Schur complement, as in the one-workgroup kernel), and what the block's earlier pivots took
+    // below the noise level is rejected (it stays an ordinary row; its updated diagonal keeps it from being chosen again).
+    // Cp keeps full symmetric storage of the open part; column a-th-pivot of Cp holds that column of the factor.
     int n_acc = 0;
-    for (int p = 0; p < m; ++p) {
-        const double pv = Cp[p][p];
-        const bool accept = pv > thr && pv > 0.0;                           // (uniform)
-        if (accept) {
-            const double lkk = sqrt(pv);
-            __syncthreads();
-            if (tid > p && tid < m) Cp[tid][p] /= lkk;
-            __syncthreads();
-            for (int idx = tid; idx < m * m; idx += DEFL_THREADS) {
-                const int q = idx / m, c = idx % m;
-                if (q > p && c > p && c <= q) Cp[q][c] -= Cp[q][p] * Cp[c][p];
-            }
-            if (tid == 0) { Cp[p][p] = lkk; ord[p] = n_acc; }
-            ++n_acc;
-            last = fmin(last, pv);
-            __syncthreads();
+    if (tid < DEFL_NB) { open_[tid] = tid < m ? 1 : 0; seq[tid] = 0; }
+    __syncthreads();
+    for (int t = 0; t < m; ++t) {
+        if (tid == 0) {
+            int best = -1;
+            double bv = thr;
+            for (int q = 0; q < m; ++q)
+                if (open_[q] && Cp[q][q] > bv && Cp[q][q] > 0.0) { bv = Cp[q][q]; best = q; }
+            s_pick = best;
         }
+        __syncthreads();
+        const int q0 = s_pick;
+        if (q0 < 0) break;                                                  // (uniform) the rest of the block is noise
+        const double pv = Cp[q0][q0], lkk = sqrt(pv);
+        __syncthreads();
+        if (tid < m && tid != q0 && open_[tid]) Cp[tid][q0] /= lkk;
+        __syncthreads();
+        for (int idx = tid; idx < m * m; idx += DEFL_THREADS) {
+            const int q = idx / m, c = idx % m;
+            if (q != q0 && c != q0 && open_[q] && open_[c]) Cp[q][c] -= Cp[q][q0] * Cp[c][q0];
+        }
+        __syncthreads();
+        if (tid == 0) { Cp[q0][q0] = lkk; open_[q0] = 0; ord[q0] = n_acc; seq[n_acc] = q0; }
+        ++n_acc;
+        last = fmin(last, pv);
+        __syncthreads();
     }
     __syncthreads();
-    // ---- the slab's rows of the new columns of L, the remaining diagonal
+    // ---- the slab's rows of the new columns of L (column r + a belongs to the a-th accepted pivot, candidate seq[a]), the
+    // remaining diagonal
     if (tid < DEFL_ROWS && row0 + tid < n) {
         const int i = row0 + tid;
         const double di = sd[i];
-        int own = -1;                                                       // this row is pivot `own` of the block (accepted)
+        int own = -1;                                                       // this row is an accepted pivot of the block: its candidate index
         for (int p = 0; p < m; ++p)
             if (piv[p] == i && ord[p] >= 0) own = p;
         double sq = 0.0;
-        for (int p = 0; p < m; ++p) {
-            if (ord[p] < 0) continue;
+        for (int a = 0; a < n_acc; ++a) {
+            const int ca = seq[a];
             double x;
             if (di < 0.0) x = 0.0;                                          // a pivot of an earlier block: above the diagonal
-            else if (own >= 0) x = p <= own ? Cp[own][p] : 0.0;             // a pivot of this block: its row of the factor
+            else if (own >= 0) x = a < ord[own] ? Cp[own][ca] : (a == ord[own] ? Cp[own][own] : 0.0);   // its row of the factor
             else {
-                double sacc = Cs[tid][p];
-                for (int q = 0; q < p; ++q)
-                    if (ord[q] >= 0) sacc -= Cs[tid][q] * Cp[p][q];
-                x = sacc / Cp[p][p];
+                double sacc = Cs[tid][ca];
+                for (int bb = 0; bb < a; ++bb) sacc -= Cs[tid][seq[bb]] * Cp[ca][seq[bb]];
+                x = sacc / Cp[ca][ca];
             }
-            Cs[tid][p] = x;
+            Cs[tid][ca] = x;
             sq += x * x;
-            Lt[(int64_t)(r + ord[p]) * ld + i] = x;
+            Lt[(int64_t)(r + a) * ld + i] = x;
         }
         double nd = di;
         if (own >= 0) nd = -1.0;
