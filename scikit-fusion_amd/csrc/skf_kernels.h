@@ -1685,7 +1685,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
 }
 
 // split-K second stage of the bf16 contraction: C = sum_z part[z]  (fixed order)
-__global__ __launch_bounds__(256) void bf16_splitk_reduce_kernel(float* __restrict__ C, int64_t ldc,
+static __global__ __launch_bounds__(256) void bf16_splitk_reduce_kernel(float* __restrict__ C, int64_t ldc,
                                                                  const float* __restrict__ part, int M, int N,
                                                                  int splits) {
     const int64_t total = (int64_t)M * N;
@@ -1881,7 +1881,7 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(uint16_t* __rest
 // SKF_BF16: the multiplicative update (mult_update_kernel) and the refresh of the stored bf16 G^T in one pass over a
 // 32 x 32 tile: G is read and written once, the tile leaves transposed through LDS.  grid = (ceil(c/32), ceil(n/32)).
 // `Grow` (optional): the bf16 ROWS of the new factor as well, [rows][ldrow] -- the gathered matrix of the list passes.
-__global__ __launch_bounds__(256) void mult_update_transpose_kernel(float* __restrict__ G, const float* __restrict__ E,
+static __global__ __launch_bounds__(256) void mult_update_transpose_kernel(float* __restrict__ G, const float* __restrict__ E,
                                                                     const float* __restrict__ D, int64_t rows, int64_t cols,
                                                                     uint16_t* __restrict__ GT, int64_t ldgt,
                                                                     uint16_t* __restrict__ Grow, int64_t ldrow) {
@@ -1925,7 +1925,7 @@ __global__ __launch_bounds__(256) void mask_zero_kernel(T* __restrict__ R, int64
 }
 
 // mask bytes (one per entry, != 0 = unknown) -> packed bits [rows][ldmb bytes]; bits / bytes past `cols` are zero
-__global__ __launch_bounds__(256) void pack_mask_kernel(uint8_t* __restrict__ dst, int64_t ldmb,
+static __global__ __launch_bounds__(256) void pack_mask_kernel(uint8_t* __restrict__ dst, int64_t ldmb,
                                                         const uint8_t* __restrict__ src, int64_t lds,
                                                         int64_t rows, int64_t cols) {
     const int64_t total = rows * ldmb;
@@ -1942,7 +1942,7 @@ __global__ __launch_bounds__(256) void pack_mask_kernel(uint8_t* __restrict__ ds
 }
 
 // packed mask rows copied into the engine's layout (bytes past the source row are zeroed by the caller)
-__global__ __launch_bounds__(256) void copy_mask_bits_kernel(uint8_t* __restrict__ dst, int64_t ldmb,
+static __global__ __launch_bounds__(256) void copy_mask_bits_kernel(uint8_t* __restrict__ dst, int64_t ldmb,
                                                              const uint8_t* __restrict__ src, int64_t lds,
                                                              int64_t rows, int64_t cols) {
     const int64_t nb = (cols + 7) / 8, total = rows * nb;
@@ -1958,7 +1958,7 @@ __global__ __launch_bounds__(256) void copy_mask_bits_kernel(uint8_t* __restrict
 
 // A binary relation (every entry 0 or 1, e.g. "movie has genre") as a bitmap: bit (c & 7) of dst[r * ldb + (c >> 3)] =
 // (src[r][c] == 1); rows and bytes of the padding are zero.  *bad is set when an entry is neither 0 nor 1.
-__global__ __launch_bounds__(256) void pack_binary_kernel(uint8_t* __restrict__ dst, int64_t ldb, int64_t rows_pad,
+static __global__ __launch_bounds__(256) void pack_binary_kernel(uint8_t* __restrict__ dst, int64_t ldb, int64_t rows_pad,
                                                           const uint16_t* __restrict__ src, int64_t lds,
                                                           int64_t rows, int64_t cols, int* __restrict__ bad) {
     const int64_t total = rows_pad * ldb;
@@ -1996,7 +1996,7 @@ struct KnownArgs {
     uint32_t* list;
     int tile_cols;           // 256 or 128: columns per tile (rows per tile: 256)
 };
-__global__ __launch_bounds__(256) void known_entries_kernel(KnownArgs a) {
+static __global__ __launch_bounds__(256) void known_entries_kernel(KnownArgs a) {
     __shared__ uint32_t cnt;
     const int tid = threadIdx.x;
     const int wpr = a.tile_cols >> 5;                         // 32-column words per tile row
@@ -2083,7 +2083,7 @@ __global__ __launch_bounds__(256) void fill_col_stats_kernel(const T* __restrict
 }
 
 // total sum / count from the row statistics (one workgroup, fixed order)
-__global__ __launch_bounds__(256) void fill_total_kernel(int64_t rows, int64_t cols, double* __restrict__ stats) {
+static __global__ __launch_bounds__(256) void fill_total_kernel(int64_t rows, int64_t cols, double* __restrict__ stats) {
     __shared__ double ps[256], pn[256];
     double s = 0.0, n = 0.0;
     for (int64_t r = threadIdx.x; r < rows; r += 256) { s += stats[r]; n += stats[rows + r]; }
@@ -2240,7 +2240,7 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 }
 
 // counts[r] = number of set bits of bitmap row r (words of 8 bytes; ldb % 8 == 0, padding bits are zero)
-__global__ __launch_bounds__(256) void bits_row_count_kernel(const uint8_t* __restrict__ B, int64_t ldb, int64_t rows,
+static __global__ __launch_bounds__(256) void bits_row_count_kernel(const uint8_t* __restrict__ B, int64_t ldb, int64_t rows,
                                                              int* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -2255,7 +2255,7 @@ __global__ __launch_bounds__(256) void bits_row_count_kernel(const uint8_t* __re
 }
 
 // cols[rowptr[r] ...] = the columns of the ones of row r, ascending
-__global__ __launch_bounds__(256) void bits_csr_fill_kernel(const uint8_t* __restrict__ B, int64_t ldb, int64_t rows,
+static __global__ __launch_bounds__(256) void bits_csr_fill_kernel(const uint8_t* __restrict__ B, int64_t ldb, int64_t rows,
                                                             const int64_t* __restrict__ rowptr, int* __restrict__ cols) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -2279,11 +2279,11 @@ __global__ __launch_bounds__(256) void bits_csr_fill_kernel(const uint8_t* __res
 }
 
 // transpose of the CSR pattern: per-column counts, then a fill in arbitrary order, then every column's rows sorted
-__global__ __launch_bounds__(256) void csr_col_count_kernel(const int* __restrict__ cols, int64_t nnz, int* __restrict__ colcnt) {
+static __global__ __launch_bounds__(256) void csr_col_count_kernel(const int* __restrict__ cols, int64_t nnz, int* __restrict__ colcnt) {
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x)
         atomicAdd(&colcnt[cols[q]], 1);
 }
-__global__ __launch_bounds__(256) void csr_transpose_fill_kernel(const int64_t* __restrict__ rowptr, const int* __restrict__ cols,
+static __global__ __launch_bounds__(256) void csr_transpose_fill_kernel(const int64_t* __restrict__ rowptr, const int* __restrict__ cols,
                                                                  int64_t rows, const int64_t* __restrict__ colptr,
                                                                  int* __restrict__ fillpos, int* __restrict__ rowidx) {
     const int lane = threadIdx.x & 63;
@@ -2294,7 +2294,7 @@ __global__ __launch_bounds__(256) void csr_transpose_fill_kernel(const int64_t* 
             rowidx[colptr[c] + atomicAdd(&fillpos[c], 1)] = (int)r;
         }
 }
-__global__ __launch_bounds__(256) void csc_sort_kernel(const int64_t* __restrict__ colptr, int* __restrict__ rowidx, int64_t ncols) {
+static __global__ __launch_bounds__(256) void csc_sort_kernel(const int64_t* __restrict__ colptr, int* __restrict__ rowidx, int64_t ncols) {
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * blockDim.x) {
         int* a = rowidx + colptr[c];
         const int n = (int)(colptr[c + 1] - colptr[c]);
@@ -2331,7 +2331,7 @@ __global__ __launch_bounds__(256) void csc_sort_kernel(const int64_t* __restrict
 }
 
 // out[r][0 .. c) = sum over q in [ptr[r], ptr[r+1]) of G[idx[q]][0 .. c)      (one wave per output row)
-__global__ __launch_bounds__(256) void binary_spmm_kernel(const int64_t* __restrict__ ptr, const int* __restrict__ idx,
+static __global__ __launch_bounds__(256) void binary_spmm_kernel(const int64_t* __restrict__ ptr, const int* __restrict__ idx,
                                                           const float* __restrict__ G, int64_t ldg, float* __restrict__ out,
                                                           int64_t ldo, int64_t rows, int c) {
     const int lane = threadIdx.x & 63;
@@ -2383,7 +2383,7 @@ __global__ __launch_bounds__(256) void sign_flags_kernel(const T* __restrict__ s
 }
 
 // bf16 engine: dst = bf16(max(src, 0)) (aop = AOP_POS) or bf16(max(-src, 0)) (AOP_NEG); dst is pre-zeroed
-__global__ __launch_bounds__(256) void split_to_bf16_kernel(uint16_t* __restrict__ dst, int64_t ldd,
+static __global__ __launch_bounds__(256) void split_to_bf16_kernel(uint16_t* __restrict__ dst, int64_t ldd,
                                                             const float* __restrict__ src, int64_t lds,
                                                             int64_t rows, int64_t cols, int aop) {
     const int64_t total = rows * cols;
@@ -2401,7 +2401,7 @@ __global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ x, int64_t n
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) x[e] *= f;
 }
 
-__global__ __launch_bounds__(256) void add_into_kernel(float* __restrict__ dst, const float* __restrict__ src,
+static __global__ __launch_bounds__(256) void add_into_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                        int64_t total) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x)
@@ -2587,7 +2587,7 @@ __device__ __forceinline__ void jacobi_eigh_body(const EighArgs& e, const int b)
         Vs[idx] = V[idx] * inv;
     }
 }
-__global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) { jacobi_eigh_body(e, blockIdx.x); }
+static __global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) { jacobi_eigh_body(e, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------
 // Fast path of the pseudo-inverse: a symmetric positive definite Gram matrix whose pivots stay
@@ -2609,7 +2609,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void jacobi_eigh_kernel(EighArgs e) {
 // max diag) could truncate its direction is handed to the eigen path.
 __device__ __forceinline__ double chol_diag_floor(int n) { return (double)n * (double)n * 2.220446049250313e-16; }
 
-__global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_kernel(EighArgs e, double rel_thr) {
+static __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_kernel(EighArgs e, double rel_thr) {
     __shared__ double col[EIGH_MAXN];
     __shared__ double red[EIGH_THREADS / 64];
     __shared__ double s_max;
@@ -2691,7 +2691,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_kernel(EighArgs e, 
 // ------------------------------------------------------------------------------------------
 constexpr int CHOLS_MAXN = 64;
 
-__global__ __launch_bounds__(64) void chol_inverse_small_kernel(EighArgs e, double rel_thr) {
+static __global__ __launch_bounds__(64) void chol_inverse_small_kernel(EighArgs e, double rel_thr) {
     constexpr int LD = CHOLS_MAXN + 1;
     // one array: L in the lower triangle and on the diagonal, X^T strictly above it
     // (M[j][r] = X(r, j) for r > j; X(j, j) = 1 / L(j, j) is not stored)
@@ -2763,7 +2763,7 @@ __global__ __launch_bounds__(64) void chol_inverse_small_kernel(EighArgs e, doub
 constexpr int CHOLB_NB = 32;
 constexpr int CHOLB_MAXN = 512;
 
-__global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_blocked_kernel(EighArgs e, double rel_thr) {
+static __global__ __launch_bounds__(EIGH_THREADS) void chol_inverse_blocked_kernel(EighArgs e, double rel_thr) {
     constexpr int NB = CHOLB_NB;
     HIP_DYNAMIC_SHARED(double, csm)
     __shared__ double red[EIGH_THREADS / 64];
@@ -3106,7 +3106,7 @@ __device__ __forceinline__ void pchol_pinv_body(const EighArgs& e, const int b, 
     for (int idx = tid; idx < n * n; idx += nt) Lt[idx] = W[idx];
     if (tid == 0) e.chol_ok[b] = 2;
 }
-__global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, double lo, double hi, int lds_rank) {
+static __global__ __launch_bounds__(EIGH_THREADS) void pchol_pinv_kernel(EighArgs e, double lo, double hi, int lds_rank) {
     pchol_pinv_body(e, blockIdx.x, lo, hi, lds_rank);
 }
 
@@ -3144,7 +3144,7 @@ struct DeflArgs {
     int* rank;         // [batch]                numerical rank (information; tests)
 };
 
-__global__ __launch_bounds__(256) void pchol_init_kernel(EighArgs e, DeflArgs da) {     // L = 0 for the matrices the fast path declined
+static __global__ __launch_bounds__(256) void pchol_init_kernel(EighArgs e, DeflArgs da) {     // L = 0 for the matrices the fast path declined
     const int b = blockIdx.y;
     if (blockIdx.x == 0 && threadIdx.x == 0) { da.gate[b] = 0; da.n_defl[b] = 0; da.ok2[b] = 0; da.rank[b] = -1; }
     if (e.chol_ok[b] != 0) return;
@@ -3153,7 +3153,7 @@ __global__ __launch_bounds__(256) void pchol_init_kernel(EighArgs e, DeflArgs da
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ld * ld; idx += gridDim.x * blockDim.x) Lt[idx] = 0.0;
 }
 
-__global__ __launch_bounds__(DEFL_THREADS) void pchol_step_kernel(EighArgs e, DeflArgs da, double lo, double hi, int step) {
+static __global__ __launch_bounds__(DEFL_THREADS) void pchol_step_kernel(EighArgs e, DeflArgs da, double lo, double hi, int step) {
     __shared__ double sd[EIGH_MAXN];
     __shared__ double Lp[DEFL_KC][DEFL_NB + 1];        // L[piv_p][k0 + kk]
     __shared__ double Ls[DEFL_KC][DEFL_ROWS + 1];      // L[row0 + i][k0 + kk]
@@ -3344,7 +3344,7 @@ __global__ __launch_bounds__(DEFL_THREADS) void pchol_step_kernel(EighArgs e, De
 }
 
 // after the last step: did the deflation finish cleanly?  (final = the copy of the state the last launch wrote)
-__global__ __launch_bounds__(64) void pchol_verdict_kernel(EighArgs e, DeflArgs da, int final_copy) {
+static __global__ __launch_bounds__(64) void pchol_verdict_kernel(EighArgs e, DeflArgs da, int final_copy) {
     const int b = blockIdx.x;
     if (threadIdx.x != 0) return;
     const int* s = da.state + (b * 2 + final_copy) * 2;
@@ -3355,19 +3355,19 @@ __global__ __launch_bounds__(64) void pchol_verdict_kernel(EighArgs e, DeflArgs 
 }
 // B = L^T L has rank r: 1 on the diagonal beyond it makes the matrix the sweep inverts positive definite (the block beyond r
 // is the identity and stays decoupled: L's columns there are zero)
-__global__ __launch_bounds__(256) void pchol_patch_kernel(EighArgs e, DeflArgs da, int final_copy) {
+static __global__ __launch_bounds__(256) void pchol_patch_kernel(EighArgs e, DeflArgs da, int final_copy) {
     const int b = blockIdx.x;
     if (!da.gate[b]) return;
     const int n = e.n_orig[b], ld = e.n[b], r = da.state[(b * 2 + final_copy) * 2];
     double* B = e.Vs + (int64_t)b * e.stride;
     for (int k = r + threadIdx.x; k < n; k += blockDim.x) B[(int64_t)k * ld + k] = 1.0;
 }
-__global__ __launch_bounds__(64) void pchol_done_kernel(EighArgs e, DeflArgs da) {
+static __global__ __launch_bounds__(64) void pchol_done_kernel(EighArgs e, DeflArgs da) {
     const int b = blockIdx.x;
     if (threadIdx.x == 0 && da.gate[b] && da.ok2[b] == 1) e.chol_ok[b] = 1;
 }
 // the gate of the products behind the sweep over B: both verdicts
-__global__ __launch_bounds__(64) void pchol_gate2_kernel(DeflArgs da) {
+static __global__ __launch_bounds__(64) void pchol_gate2_kernel(DeflArgs da) {
     const int b = blockIdx.x;
     if (threadIdx.x == 0) da.gate[b] = (da.gate[b] && da.ok2[b] == 1) ? 1 : 0;
 }
@@ -3440,7 +3440,7 @@ struct BackboneBatch {
 
 // dynamic LDS: Ki (ci x ci) | W, then T1 (ci x cj) | Kj (cj x cj) | T1 -- operands are staged with
 // coalesced loads first: the dot products then run on LDS latency, not on L2 round trips
-__global__ __launch_bounds__(256) void backbone_small_kernel(BackboneBatch bb) {
+static __global__ __launch_bounds__(256) void backbone_small_kernel(BackboneBatch bb) {
     HIP_DYNAMIC_SHARED(double, sm)
     const int b = blockIdx.x, ci = bb.ci[b], cj = bb.cj[b];
     double* Ki = sm;
@@ -3479,7 +3479,7 @@ struct BTermsArgs {
 };
 
 // dynamic LDS: S (ci x cj) | Gram_i (ci x ci) | Gram_j (cj x cj) | U (ci x cj)
-__global__ __launch_bounds__(256) void bterms_small_kernel(BTermsArgs a) {
+static __global__ __launch_bounds__(256) void bterms_small_kernel(BTermsArgs a) {
     HIP_DYNAMIC_SHARED(double, sm)
     const int ci = a.ci, cj = a.cj;
     double* S = sm;
@@ -3532,7 +3532,7 @@ struct CastBatch {
     float* dst[CAST_MAXB];
     int count[CAST_MAXB];
 };
-__global__ __launch_bounds__(256) void cast_batched_kernel(CastBatch cb) {
+static __global__ __launch_bounds__(256) void cast_batched_kernel(CastBatch cb) {
     const int b = blockIdx.y;
     const double* __restrict__ src = cb.src[b];
     float* __restrict__ dst = cb.dst[b];
@@ -3549,7 +3549,7 @@ struct PinvBatch {
     int c[PINV_MAXB], n_pad[PINV_MAXB];
 };
 
-__global__ __launch_bounds__(256) void eigh_pack_batched_kernel(PinvBatch pb, double* __restrict__ A, int64_t stride) {
+static __global__ __launch_bounds__(256) void eigh_pack_batched_kernel(PinvBatch pb, double* __restrict__ A, int64_t stride) {
     const int b = blockIdx.y, n = pb.c[b], n_pad = pb.n_pad[b];
     double* dst = A + (int64_t)b * stride;
     const double* src = pb.gram[b];
@@ -3559,7 +3559,7 @@ __global__ __launch_bounds__(256) void eigh_pack_batched_kernel(PinvBatch pb, do
     }
 }
 
-__global__ __launch_bounds__(256) void chol_unpack_batched_kernel(PinvBatch pb, const double* __restrict__ Xall,
+static __global__ __launch_bounds__(256) void chol_unpack_batched_kernel(PinvBatch pb, const double* __restrict__ Xall,
                                                                   int64_t stride, const int* __restrict__ chol_ok) {
     const int b = blockIdx.y;
     if (chol_ok[b] != 1) return;
@@ -3673,7 +3673,7 @@ __device__ __forceinline__ bool sweep_pivot_block(const double* __restrict__ Cbl
     return ok;
 }
 
-__global__ __launch_bounds__(SWEEP_THREADS) void sweep_inverse_kernel(EighArgs e, PinvBatch pb, double rel_thr) {
+static __global__ __launch_bounds__(SWEEP_THREADS) void sweep_inverse_kernel(EighArgs e, PinvBatch pb, double rel_thr) {
     constexpr int NB = SWEEP_NB, LD = SWEEP_LD;
     HIP_DYNAMIC_SHARED(double, ssm)
     __shared__ double red[SWEEP_THREADS / 64];
@@ -4121,7 +4121,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_step_kernel(EighArgs e, P
     if (tid == 0 && blockIdx.y == 0) e.chol_ok[b] = last ? 1 : SWEEP_RUNNING;
 }
 
-__global__ __launch_bounds__(256) void eigh_unpack_pinv_batched_kernel(PinvBatch pb, const double* __restrict__ VsAll,
+static __global__ __launch_bounds__(256) void eigh_unpack_pinv_batched_kernel(PinvBatch pb, const double* __restrict__ VsAll,
                                                                        const double* __restrict__ VAll, int64_t stride,
                                                                        const int* __restrict__ chol_ok) {
     const int b = blockIdx.y;

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void srp_bf16_v6_kernel(SrpArgs<uint16_t, floa
 
 // segment pointers of lists cut into parts of the inner index (ascending within a list): seg[o * parts + p] = the first
 // entry of list o whose inner index is >= p * pw (binary search; one thread per segment), seg[n_out * parts] = the end
-__global__ __launch_bounds__(256) void parted_ptr_kernel(const int64_t* __restrict__ ptr, const int* __restrict__ idx, int64_t n_out,
+static __global__ __launch_bounds__(256) void parted_ptr_kernel(const int64_t* __restrict__ ptr, const int* __restrict__ idx, int64_t n_out,
                                                          int parts, int64_t pw, int64_t* __restrict__ seg) {
     const int64_t total = n_out * parts;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void split_accumulate_kernel(T* __restrict__ E
 }
 
 // out[0] = sum_e A[e] * B[e] (f64, one workgroup; c x c operands)
-__global__ __launch_bounds__(256) void dot_small_kernel(const double* __restrict__ A, const double* __restrict__ B, int64_t total,
+static __global__ __launch_bounds__(256) void dot_small_kernel(const double* __restrict__ A, const double* __restrict__ B, int64_t total,
                                                         double scale, double* __restrict__ out, int accumulate) {
     __shared__ double red[4];
     double s = 0.0;
@@ -591,7 +591,7 @@ __device__ __forceinline__ unsigned long long known_word(const uint8_t* __restri
 }
 
 // counts[r * parts + p] = known entries of row r in the columns [p * part_w, (p + 1) * part_w)   (part_w % 64 == 0)
-__global__ __launch_bounds__(256) void known_row_count_kernel(const uint8_t* __restrict__ Mb, int64_t ldmb, int64_t rows,
+static __global__ __launch_bounds__(256) void known_row_count_kernel(const uint8_t* __restrict__ Mb, int64_t ldmb, int64_t rows,
                                                               int64_t cols, int parts, int64_t part_w, int* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void known_row_fill_kernel(const uint8_t* __re
 }
 
 // transpose of the row lists, cut into row parts of part_h rows: per (column, part) counts / arbitrary-order fill
-__global__ __launch_bounds__(256) void known_col_count_kernel(const int64_t* __restrict__ rptr, const int* __restrict__ idx, int rparts,
+static __global__ __launch_bounds__(256) void known_col_count_kernel(const int64_t* __restrict__ rptr, const int* __restrict__ idx, int rparts,
                                                               int64_t rows, int cparts, int64_t part_h, int* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void known_col_count_kernel(const int64_t* __r
         for (int64_t q = rptr[r * rparts] + lane; q < rptr[(r + 1) * rparts]; q += 64) atomicAdd(&counts[(int64_t)idx[q] * cparts + p], 1);
     }
 }
-__global__ __launch_bounds__(256) void known_col_fill_kernel(const int64_t* __restrict__ rptr, const int* __restrict__ idx, int rparts,
+static __global__ __launch_bounds__(256) void known_col_fill_kernel(const int64_t* __restrict__ rptr, const int* __restrict__ idx, int rparts,
                                                              int64_t rows, int cparts, int64_t part_h, const int64_t* __restrict__ cptr,
                                                              int* __restrict__ fillpos, int* __restrict__ cidx) {
     const int lane = threadIdx.x & 63;
