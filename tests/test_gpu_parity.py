@@ -86,6 +86,18 @@ def test_pinv_rank_deficient(rt):
     K.test_pinv_zero_and_diagonal(rt)
 
 
+@pytest.mark.parametrize('n,rank', [(257, 1), (300, 170), (420, 97), (512, 256), (777, 300), (1023, 512), (1023, 700)])
+def test_pinv_deflation_over_several_workgroups(rt, n, rank, monkeypatch):
+    """Round 6: rank-deficient Gram matrices above order 256 on the hardware -- block-pivoted Cholesky steps over row slabs,
+    gated finishing products, the fast path's sweep on L^T L (route asserted by the operator's verdict word); and the ambiguous
+    spectrum that both deflations must leave to the eigen-solver."""
+    K.test_pinv_deflation_over_several_workgroups_above_order_256(rt, n, rank, monkeypatch)
+
+
+def test_pinv_ambiguous_spectrum_above_order_256(rt):
+    K.test_pinv_ambiguous_spectrum_above_order_256_is_left_to_the_exact_cut_off(rt)
+
+
 def test_fill_uniform(rt):
     K.test_fill_uniform_matches_oracle_hash(rt)
 
