@@ -403,6 +403,12 @@ int skf_owned_rows(int32_t dtype, int64_t n_obj, int32_t part_index, int32_t par
  * schedule are part of its latency budget (bench.py reports them for the rank-of-8 emulation). */
 int skf_launch_count(int64_t* launches);
 
+/* Split-K launches of the calling thread whose slice count was CLAMPED because the scratch sized at plan creation could not
+ * hold the slices the launch-time model asked for (run_gemm: safe, but the modelled schedule is then not the executed one;
+ * advisor, round 5).  Zero for every plan the tests and the benchmark create; a non-zero count names a sizing rule
+ * (skf_plan_create: want_part) that has fallen behind the tile / slice pickers. */
+int skf_split_clamps(int64_t* clamps);
+
 const char* skf_last_error(void);
 const char* skf_version(void);
 /* Layout version of the structs and signatures above (SKF_ABI_VERSION).  A binding built against another version must not

@@ -259,6 +259,15 @@ def launch_count(runtime=None):
     return n.value
 
 
+def split_clamps(runtime=None):
+    """Split-K launches of this thread whose slice count the plan's scratch could not hold (skf_split_clamps): zero unless
+    the sizing rule of skf_plan_create has fallen behind the launch-time pickers."""
+    rt = runtime or nat.get_runtime()
+    n = C.c_int64()
+    rt.call('skf_split_clamps', C.byref(n))
+    return n.value
+
+
 def _shared_rccl_comm(rt, dist):
     """The process's RCCL communicator for the CURRENT default process group (created once per group, reused by every plan
     and restart), or None when it cannot be had on EVERY rank -- all ranks then agree on the callback path instead of some

@@ -116,6 +116,7 @@ SIGNATURES = {
     'skf_comm_create_null': (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_P)]),
     'skf_comm_info': (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'skf_launch_count': (C.c_int, [C.POINTER(C.c_int64)]),
+    'skf_split_clamps': (C.c_int, [C.POINTER(C.c_int64)]),
     'skf_comm_destroy': (C.c_int, [_P]),
     'skf_owned_rows': (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                  C.POINTER(C.c_int64)]),

@@ -65,6 +65,7 @@ static int env_int(const char* name, int unset) {
     return v ? atoi(v) : unset;
 }
 
+static thread_local int64_t g_split_clamps = 0;  // split-K launches whose slice count the scratch could not hold (skf_split_clamps)
 static thread_local int64_t g_launches = 0;      // kernel launches this thread has issued through the library (skf_launch_count)
 
 static inline void check_launch(const char* what) {
@@ -1361,6 +1362,13 @@ int skf_launch_count(int64_t* launches) {
     return guarded([&] {
         if (!launches) SKF_FAIL(SKF_E_INVALID, "null pointer");
         *launches = g_launches;
+    });
+}
+
+int skf_split_clamps(int64_t* clamps) {
+    return guarded([&] {
+        if (!clamps) SKF_FAIL(SKF_E_INVALID, "null pointer");
+        *clamps = g_split_clamps;
     });
 }
 

@@ -100,3 +100,4 @@ def test_round5_entry_points_without_a_device(lib):
     assert lib.skf_comm_info(None, None, None, None, None) == -1
     count = C.c_int64(-1)
     assert lib.skf_launch_count(C.byref(count)) == 0 and count.value >= 0
+    assert lib.skf_split_clamps(C.byref(count)) == 0 and count.value == 0

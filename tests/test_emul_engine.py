@@ -14,8 +14,10 @@ from helpers import (golden, readme_graph, probe_graph, rank_deficient_graph, di
 
 @pytest.fixture(scope='module', autouse=True)
 def emul():
+    from skfusion_amd._engine import split_clamps
     with use_runtime(emulated_runtime()) as rt:
         yield rt
+        assert split_clamps(rt) == 0        # no split-K launch of the module outgrew the scratch its plan sized
 
 
 @pytest.mark.parametrize('small_chain', ['fused', 'on', 'off'])

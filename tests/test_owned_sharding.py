@@ -17,8 +17,10 @@ from skfusion_amd._engine import owned_rows            # noqa: F401  (also used 
 
 @pytest.fixture(scope='module', autouse=True)
 def emul():
+    from skfusion_amd._engine import split_clamps
     with use_runtime(emulated_runtime()) as rt:
         yield rt
+        assert split_clamps(rt) == 0        # no split-K launch of the module outgrew the scratch its plan sized
 
 
 PAIRS = [('t1', 't2', 0), ('t1', 't2', 1), ('t1', 't3', 0), ('t2', 't3', 0)]
