@@ -1298,6 +1298,15 @@ def main():
             'hbm_frac': (roof.get('hbm_scheduled') or roof.get('hbm_algorithmic') or {}).get('frac'),
             'host': host_info(),
         }
+    if out is not None and world == 1:
+        # from here on the headline is measured: a TERM from an impatient caller still gets the line, without the sub-records
+        import signal
+
+        def _line_and_leave(signum, frame):
+            out['interrupted'] = 'signal %d during the sub-records; the headline fields are complete' % signum
+            print(json.dumps(out, default=str), flush=True)
+            os._exit(0)
+        signal.signal(signal.SIGTERM, _line_and_leave)
     if default_run and not args.no_engines:
         # the reference computes in f64: short runs of the f32 and f64 engines on the same graph
         engines = {}
