@@ -24,6 +24,7 @@ python tools/bench_api_small.py 2>&1 | grep -v amdgpu.ids > $G/api_small.txt
 timeout 300 python tools/fuzz_known.py 16 3 > $G/fuzz_known.txt 2>&1
 timeout 300 python tools/fuzz_small.py 20 3 > $G/fuzz_small.txt 2>&1
 timeout 600 python tools/fuzz_owned.py 40 3 > $G/fuzz_owned.txt 2>&1
+timeout 600 python tools/fuzz_pinv.py 150 3 > $G/fuzz_pinv.txt 2>&1
 du -sh gpurun_out | tail -1
 grep -E "exit|passed|failed" $G/summary.txt | cut -c1-200
-tail -1 $G/fuzz_known.txt; tail -1 $G/fuzz_small.txt; tail -1 $G/fuzz_owned.txt
+tail -1 $G/fuzz_known.txt; tail -1 $G/fuzz_small.txt; tail -1 $G/fuzz_owned.txt; tail -1 $G/fuzz_pinv.txt

@@ -24,6 +24,7 @@ done
 [ -f $G/dicty.txt ] && [ ! -f profiles/${R}_dicty_config2.txt ] && { echo "# python tools/bench_dicty.py / tools/bench_api_small.py, same box, final build of the round"; grep -h "dicty\|README\|NumPy" $G/dicty.txt $G/api_small.txt; } > profiles/${R}_dicty_config2.txt
 [ -f $G/fuzz_known.txt ] && tail -3 $G/fuzz_known.txt > profiles/${R}_fuzz_known_entries.txt
 [ -f $G/fuzz_small.txt ] && tail -3 $G/fuzz_small.txt > profiles/${R}_fuzz_small_graphs.txt
+[ -f $G/fuzz_pinv.txt ] && { head -8 tools/fuzz_pinv.py | tail -7 | sed 's/^/# /'; grep -v amdgpu.ids $G/fuzz_pinv.txt | cut -c1-200; } > profiles/${R}_fuzz_pinv.txt
 [ -f $G/fuzz_owned.txt ] && [ ! -f profiles/${R}_fuzz_owned_rows.txt ] && cut -c1-400 $G/fuzz_owned.txt > profiles/${R}_fuzz_owned_rows.txt
 grep '^{' $G/bench_full.log > profiles/${R}_bf16_bench.json
 grep '^{' $G/c5_bf16.log > profiles/${R}_c5_bf16_bench.json
