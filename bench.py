@@ -1369,6 +1369,11 @@ def main():
             out['roofline'].update({'mfma_busy': mfma_pmc['mfma_busy'], 'clock_ghz': mfma_pmc['clock_ghz'], 'mfma_pmc': mfma_pmc})
         if PMC_ERRORS:
             out['pmc_errors'] = PMC_ERRORS[:4]
+        try:                       # split-K launches of this process that outgrew their plan's scratch: zero, or a sizing rule is stale
+            from skfusion_amd._engine import split_clamps
+            out['split_clamps'] = split_clamps()
+        except Exception as exc:
+            out['split_clamps'] = str(exc)[:100]
         print(json.dumps(out), flush=True)
     if dist is not None:
         # N > 1: every rank leaves through os._exit once all are done -- the line is out, and no teardown (process group,

@@ -406,7 +406,8 @@ int skf_launch_count(int64_t* launches);
 /* Split-K launches of the calling thread whose slice count was CLAMPED because the scratch sized at plan creation could not
  * hold the slices the launch-time model asked for (run_gemm: safe, but the modelled schedule is then not the executed one;
  * advisor, round 5).  Zero for every plan the tests and the benchmark create; a non-zero count names a sizing rule
- * (skf_plan_create: want_part) that has fallen behind the tile / slice pickers. */
+ * (skf_plan_create: want_part) that has fallen behind the tile / slice pickers.  The stand-alone products (skf_gemm*)
+ * run on the caller's scratch and are not counted. */
 int skf_split_clamps(int64_t* clamps);
 
 const char* skf_last_error(void);

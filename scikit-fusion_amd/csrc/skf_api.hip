@@ -344,9 +344,10 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         const size_t es = p->esz;
         size_t part_bytes = 0;
         size_t sp_part_bytes = 0;
-        auto want_part = [&](int M, int N, int K, bool out_f64) {
+        auto want_part = [&](int M, int N, int K, bool out_f64, bool sym = false) {
             TileCfg t = pick_tile(out_f64, p->engine, M, N);
             int sl = pick_splits(t, M, N, K);
+            if (sym) sl = std::max(sl, pick_splits(t, M, N, K, true));     // (X^T X on the tiles on / below the diagonal: fewer tiles, more slices)
             if (!p->bf16 && (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn) >= 256) {      // (relation contractions of the f32 / f64 engines)
                 const int rs = pick_splits_relation(t, M, N, K, out_f64);
                 if (rs > sl) sl = rs;
@@ -389,7 +390,7 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
                 t.ldgt = pad64(t.n);
                 add_slot(p, t.GTb, (size_t)t.c * t.ldgt * 2);
             }
-            want_part(t.c, t.c, (int)t.n, true);
+            want_part(t.c, t.c, (int)t.n, true, true);
             if (t.keep_prev) add_slot(p, t.Gp, (size_t)t.n * t.c * es);
             if (p->bf16 && t.need_rows) {
                 t.ldrow = (t.c + 7) / 8 * 8;
@@ -627,7 +628,8 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         size_t aux_bytes = 0;
         for (TypeState& t : p->types) {
             TileCfg tc = pick_tile(true, p->engine, t.c, t.c);
-            size_t need = (size_t)pick_splits(tc, t.c, t.c, (int)t.n) * (size_t)t.c * t.c * 8;
+            const int sl = std::max(pick_splits(tc, t.c, t.c, (int)t.n), pick_splits(tc, t.c, t.c, (int)t.n, true));   // (gram(.., on_aux): symmetric)
+            size_t need = (size_t)sl * (size_t)t.c * t.c * 8;
             if (need > aux_bytes) aux_bytes = need;
         }
         for (RelState& r : p->rels) {          // W = G_i^T P on the second stream (pipelined schedule)
@@ -1555,9 +1557,17 @@ int skf_plan_get_profile(skf_plan* p, double* total_ms, int64_t* launches, doubl
     });
 }
 
+// The stand-alone products run on the CALLER's scratch, which may hold fewer slices than the time model asks for: that is
+// the caller's choice, not a sizing rule of the library that fell behind -- skf_split_clamps counts the plans' launches only.
+struct CallerScratch {
+    int64_t keep = g_split_clamps;
+    ~CallerScratch() { g_split_clamps = keep; }
+};
+
 int skf_gemm(int32_t dtype, int32_t engine, const skf_gemm_desc* d, void* workspace, size_t workspace_bytes,
              void* stream) {
     return guarded([&] {
+        CallerScratch scope;
         if (!d || !d->A || !d->B || !d->C) SKF_FAIL(SKF_E_INVALID, "null argument");
         if (dtype != SKF_F64 && dtype != SKF_F32) SKF_FAIL(SKF_E_INVALID, "skf_gemm: dtype must be SKF_F64 / SKF_F32");
         if (d->epi < EPI_STORE || d->epi > EPI_MASKED_STORE) SKF_FAIL(SKF_E_INVALID, "bad epilogue");
@@ -1583,6 +1593,7 @@ int skf_gemm(int32_t dtype, int32_t engine, const skf_gemm_desc* d, void* worksp
 int skf_gemm_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
                   int32_t Kp, int32_t splits, void* workspace, size_t workspace_bytes, void* stream) {
     return guarded([&] {
+        CallerScratch scope;
         if (!A || !Bt || !C || M < 0 || N < 0 || Kp < 0 || ldc < N) SKF_FAIL(SKF_E_INVALID, "bad argument");
         run_gemm_bf16((const uint16_t*)A, lda, (const uint16_t*)Bt, ldb, C, ldc, M, N, Kp, splits, workspace,
                       workspace_bytes, false, as_stream(stream));
@@ -1592,6 +1603,7 @@ int skf_gemm_bf16(const void* A, int64_t lda, const void* Bt, int64_t ldb, float
 int skf_gemm_bf16_tn(const void* A, int64_t lda, const void* Bt, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
                      int32_t Kp, int32_t splits, void* workspace, size_t workspace_bytes, void* stream) {
     return guarded([&] {
+        CallerScratch scope;
         if (!A || !Bt || !C || M < 0 || N < 0 || Kp < 0 || ldc < N) SKF_FAIL(SKF_E_INVALID, "bad argument");
         run_gemm_bf16((const uint16_t*)A, lda, (const uint16_t*)Bt, ldb, C, ldc, M, N, Kp, splits, workspace,
                       workspace_bytes, false, as_stream(stream), true);
@@ -1601,6 +1613,7 @@ int skf_gemm_bf16_tn(const void* A, int64_t lda, const void* Bt, int64_t ldb, fl
 int skf_gemm_bits(const void* A, int64_t lda_bytes, const void* Bt, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
                   int32_t Kp, int32_t transposed, int32_t splits, void* workspace, size_t workspace_bytes, void* stream) {
     return guarded([&] {
+        CallerScratch scope;
         if (!A || !Bt || !C || M < 0 || N < 0 || Kp < 0 || ldc < N) SKF_FAIL(SKF_E_INVALID, "bad argument");
         run_gemm_bf16((const uint16_t*)A, lda_bytes, (const uint16_t*)Bt, ldb, C, ldc, M, N, Kp, splits, workspace,
                       workspace_bytes, false, as_stream(stream), transposed != 0, true);

@@ -10,6 +10,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def no_split_clamps(request):
+    """Every GPU test: no split-K launch of a plan outgrows the scratch the plan sized for it (skf_split_clamps; the
+    stand-alone products on a caller's scratch are not counted).  The emulator modules assert the same at their end."""
+    if request.node.get_closest_marker('gpu') is None:
+        yield
+        return
+    import skfusion_amd._native as nat
+    from skfusion_amd._engine import split_clamps
+    rt = nat.get_runtime()
+    before = split_clamps(rt)
+    yield
+    assert split_clamps(rt) == before
+
+
 def pytest_sessionfinish(session, exitstatus):
     """Measured deviations of the parity tests next to their bounds (tests/helpers.py `within`)."""
     try:
