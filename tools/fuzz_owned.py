@@ -5,7 +5,8 @@ tests/helpers.fit_owned) against the NumPy oracle:
 random relation sets incl. multi-relations and types that sit on one side only, DFMF and DFMC with masks of every density
 (all known, None, 2 % known: the list form under row ownership), sparse and dense constraints.
 Every engine against the oracle, next to the single-device fit of the same engine against the oracle: the sharded fit must
-be within 1e-8 (f64) / 2e-4 (f32) / 3e-2 (bf16) OR within 10 x the single-device deviation -- graphs with (nearly)
+be within 1e-8 (f64) / 2e-4 (f32) / 3e-2 (bf16) OR within 10 x the single-device deviation OR (f32) within 1e8 x the f64
+deviation of the same sharded fit -- graphs with (nearly)
 rank-deficient Gram matrices (fewer objects than latent dimensions, square factors) amplify every rounding difference, a
 single-device fit as much as a sharded one (64 objects at rank 64: 2e-7 in f64, 1e-2 in f32 on one device); the bf16 engine
 is only run where every type has at least twice as many objects as latent dimensions.
@@ -102,6 +103,7 @@ def fuzz(n_graphs, seed, iters):
                 Go, So = orc.dfmc(R, M, Theta, types, rank, max_iter=iters, G0=G0)
             well = all(n[t] >= 2 * rank[t] for t in types)
             dtypes = [('f64', 1e-8), ('f32', 2e-4)] + ([('bf16', 3e-2)] if wide and well and min(rank.values()) >= 16 else [])
+            w64 = 0.0
             for dtype, tol in dtypes:
                 if variant == 'dfmf':
                     Gs, Ss = _dfmf.dfmf(R, Theta, types, rank, max_iter=iters, G0=G0, dtype=dtype)
@@ -115,7 +117,11 @@ def fuzz(n_graphs, seed, iters):
                     w = float('inf')
                     line.append('%s/%s %s: %s' % (variant, dtype, type(e).__name__, str(e)[:120]))
                 line.append('%s/%s %.1e (one device %.1e)' % (variant, dtype, w, one))
-                if not (w < max(tol, 10.0 * one)):
+                if dtype == 'f64':
+                    w64 = w
+                # f32: the same graph's f64 deviation measures how far its conditioning amplifies a rounding error (1e-13 on
+                # a well-conditioned graph); 1e8 = a fifth of eps(f32) / eps(f64) carries that over
+                if not (w < max(tol, 10.0 * one, 1e8 * w64 if dtype == 'f32' else 0.0)):
                     bad += 1
                     line.append('<-- above %.0e' % tol)
         print('graph %2d: W=%d n=%s rank=%s rel=%d theta=%d  %s' % (g, size, list(n.values()), list(rank.values()),
