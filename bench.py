@@ -1042,6 +1042,9 @@ def strong_record(dtype, rank, world, dist, backend, steps=10, warmup=3, scale=1
     it/s of the one fit, bytes a rank sends per iteration, and what the transport says about itself (RCCL: ncclCommCount).
     Every rank takes part; rank 0 keeps the record."""
     out = {'mode': 'owned', 'scaling': 'strong', 'n_gpus': world, 'dtype': dtype, 'backend': backend}
+    if os.environ.get('SKF_BENCH_DIE_IN_STRONG') == str(rank):       # rehearsal of a rank lost inside this leg (tools/gpu_round2.sh)
+        import signal
+        os.kill(os.getpid(), signal.SIGKILL)
     for key, wl in (('c3', 'c3'), ('c5', 'c5')):
         try:
             w = run_workload(wl, dtype, steps, warmup, scale, 'uniform', 'owned', rank, world, dist, backend)
@@ -1078,6 +1081,46 @@ def run_bounded(fn, seconds, device=None):
     if th.is_alive():
         return {'error': 'timed out after %.0f s (SKF_STRONG_TIMEOUT)' % seconds}, True
     return box.get('result'), False
+
+
+class LineWatchdog:
+    """Keeps the measured line of an N > 1 run safe while rank 0 enters the `strong` leg -- collectives over RCCL that no
+    single-GPU box can rehearse with more than one real rank.  A forked child (it touches no GPU state: two system calls)
+    holds the line as it stands and waits on a pipe: if rank 0 dies in there (a fault inside a collective takes the whole
+    process), the pipe closes and the child prints the line; if rank 0 comes back, it disarms the child and prints the full
+    line itself.  Hangs are bounded by run_bounded, a TERM from the launcher (a PEER died) by the signal handler of main()."""
+
+    def __init__(self, line):
+        import signal
+        self.w = self.pid = None
+        try:
+            r, w = os.pipe()
+            sys.stdout.flush()
+            pid = os.fork()
+        except OSError:
+            return
+        if pid == 0:
+            try:
+                os.close(w)
+                for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+                    signal.signal(sig, signal.SIG_IGN)
+                if os.read(r, 1) != b'd':
+                    os.write(1, line.encode() + b'\n')
+            finally:
+                os._exit(0)
+        os.close(r)
+        self.w, self.pid = w, pid
+
+    def disarm(self):
+        if self.w is None:
+            return
+        try:
+            os.write(self.w, b'd')
+            os.close(self.w)
+            os.waitpid(self.pid, 0)
+        except OSError:
+            pass
+        self.w = None
 
 
 def compact_roofline(r):
@@ -1298,12 +1341,16 @@ def main():
             'hbm_frac': (roof.get('hbm_scheduled') or roof.get('hbm_algorithmic') or {}).get('frac'),
             'host': host_info(),
         }
-    if out is not None and world == 1:
-        # from here on the headline is measured: a TERM from an impatient caller still gets the line, without the sub-records
+    watchdog = None
+    if out is not None:
+        # from here on the headline is measured: a TERM from an impatient caller (N = 1) or from the launcher after a peer
+        # died in the strong leg (N > 1) still gets the line, without the sub-records
         import signal
 
         def _line_and_leave(signum, frame):
             out['interrupted'] = 'signal %d during the sub-records; the headline fields are complete' % signum
+            if watchdog is not None:
+                watchdog.disarm()
             print(json.dumps(out, default=str), flush=True)
             os._exit(0)
         signal.signal(signal.SIGTERM, _line_and_leave)
@@ -1327,10 +1374,14 @@ def main():
         out['workloads'] = other_workloads(args.dtype, dicty)
     hung = False
     if world > 1 and args.mode == 'restarts' and not args.no_strong and not c5 and args.data == 'uniform':
-        # collective: every rank runs it; bounded, so that the restarts line above survives a collective that never returns
+        # collective: every rank runs it; bounded, so that the restarts line above survives a collective that never returns,
+        # and watched, so that it survives a rank 0 that does not come back at all
+        if rank == 0:
+            watchdog = LineWatchdog(json.dumps(dict(out, strong={'error': 'rank 0 died inside the strong leg'}), default=str))
         strong, hung = run_bounded(lambda: strong_record(args.dtype, rank, world, dist, backend, scale=args.scale),
                                    float(os.environ.get('SKF_STRONG_TIMEOUT', '300')), local)
         if rank == 0:
+            watchdog.disarm()
             out['strong'] = strong
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

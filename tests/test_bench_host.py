@@ -232,3 +232,40 @@ def test_bounded_leg_returns_or_times_out():
     assert hung and 'timed out' in res['error']
     res, hung = bench.run_bounded(lambda: 1 / 0, 5.0)
     assert not hung and 'division' in res['error']
+
+
+@pytest.mark.parametrize('ending', ['dies', 'returns', 'terminated'])
+def test_line_watchdog_prints_the_line_only_when_rank_0_does_not_come_back(ending, tmp_path):
+    """Round 6: the measured line of an N > 1 run survives a rank 0 that dies inside the `strong` leg
+    (a fault inside a collective takes the whole process) -- the forked watchdog prints it; a rank 0 that comes back
+    disarms the watchdog and prints the full line itself: ONE line either way."""
+    import json
+    import subprocess
+    body = {
+        'dies': "os.kill(os.getpid(), signal.SIGKILL)",
+        'returns': "w.disarm(); print(json.dumps({'value': 1, 'strong': {'ok': 1}}), flush=True)",
+        'terminated': "w.disarm(); print(json.dumps({'value': 1, 'interrupted': 'signal'}), flush=True); os._exit(0)",
+    }[ending]
+    code = ("import os, sys, json, signal\n"
+            "sys.path.insert(0, %r)\n"
+            "import bench\n"
+            "w = bench.LineWatchdog(json.dumps({'value': 1, 'strong': {'error': 'rank 0 died inside the strong leg'}}))\n"
+            "%s\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), body))
+    out = tmp_path / 'out.txt'
+    with open(out, 'wb') as fh:
+        proc = subprocess.run([sys.executable, '-c', code], stdout=fh, stderr=subprocess.PIPE, timeout=120)
+    import time
+    for _ in range(50):                       # the watchdog of a killed parent prints a moment after the parent is gone
+        lines = [ln for ln in out.read_text().splitlines() if ln.startswith('{')]
+        if lines:
+            break
+        time.sleep(0.1)
+    assert len(lines) == 1, (lines, proc.stderr[-300:])
+    rec = json.loads(lines[0])
+    assert rec['value'] == 1
+    if ending == 'dies':
+        assert proc.returncode == -9 and 'died' in rec['strong']['error']
+    elif ending == 'returns':
+        assert rec['strong'] == {'ok': 1}
+    else:
+        assert 'interrupted' in rec

@@ -30,6 +30,13 @@ case "$step" in
     done
     # (round 5) the default mode also carries the `strong` sub-record: one fit sharded by ownership over the same two ranks
     grep '^{' "$OUT/dist_restarts.log" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('dist restarts: strong sub-record', json.dumps(d.get('strong')))" | tee -a "$OUT/summary.txt"
+    # (round 6) a rank lost INSIDE the strong leg: the measured restarts line must still come out, exactly once -- rank 1 killed:
+    # the launcher's TERM reaches rank 0's handler; rank 0 killed: the forked watchdog prints what rank 0 held
+    for dead in 1 0; do
+      ( SKF_BENCH_DIE_IN_STRONG=$dead SKF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --scale 0.2 --no-cpu-baseline --no-engines ) > "$OUT/dist_dead$dead.log" 2>&1
+      echo "dist restarts, rank $dead killed in the strong leg: exit $?, JSON lines $(grep -c '^{' "$OUT/dist_dead$dead.log")" | tee -a "$OUT/summary.txt"
+      grep '^{' "$OUT/dist_dead$dead.log" | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('  value', round(d['value'],1), 'n_gpus', d['n_gpus'], 'strong', d.get('strong'), 'interrupted', d.get('interrupted'))" | tee -a "$OUT/summary.txt"
+    done
     for mode in rows owned; do
       ( SKF_BENCH_BACKEND=gloo timeout 600 python bench.py --workload c5 --gpus 2 --steps 2 --warmup 1 --scale 0.1 --mode $mode --no-cpu-baseline ) > "$OUT/dist_c5_$mode.log" 2>&1
       echo "dist c5 $mode exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/dist_c5_$mode.log" | cut -c1-260 | tee -a "$OUT/summary.txt"
