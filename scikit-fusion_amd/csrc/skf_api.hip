@@ -622,6 +622,11 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
         }
         if (!p->thetas.empty()) add_slot(p, p->theta_flags, p->thetas.size() * 2 * sizeof(int));
         if (theta_tmp_bytes) add_slot(p, p->theta_tmp, theta_tmp_bytes);
+        {   // the Gram products of all types side by side in one launch (gram_all): every product's slices at once
+            std::vector<std::pair<int, int64_t>> cn;
+            for (const TypeState& t : p->types) cn.emplace_back(t.c, t.n);
+            if (cn.size() >= 2 && cn.size() <= 4) part_bytes = std::max(part_bytes, gram_group_bytes(p->engine, cn));
+        }
         p->part_bytes = part_bytes;
         add_slot(p, p->part, part_bytes);
         if (sp_part_bytes) add_slot(p, p->sp_part, sp_part_bytes);
@@ -637,6 +642,11 @@ int skf_plan_create(int32_t n_types, const skf_type_desc* types, int32_t n_relat
             TileCfg tc = pick_tile(true, p->engine, ci, cj);
             size_t need = (size_t)pick_splits(tc, ci, cj, (int)r.nr) * (size_t)ci * cj * 8;
             if (need > aux_bytes) aux_bytes = need;
+        }
+        {
+            std::vector<std::pair<int, int64_t>> cn;
+            for (const TypeState& t : p->types) cn.emplace_back(t.c, t.n);
+            if (cn.size() >= 2 && cn.size() <= 4) aux_bytes = std::max(aux_bytes, gram_group_bytes(p->engine, cn));
         }
         p->part_aux_bytes = aux_bytes;
         add_slot(p, p->part_aux, aux_bytes);

@@ -523,6 +523,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_pair_kernel(GemmArg
     gemm_mfma_body<T, TA, TB, WR, WC, BK, TAG, FM>(g, blockIdx.x, blockIdx.y, 0u, gridDim.x, 1u);
 }
 
+// Up to FOUR independent split-K products of ONE instantiation in one launch (blockIdx.y = which; round 6): the Gram matrices
+// G^T G of all types open an iteration as three launches of ~500 workgroups each, every one with its own ramp and tail and a
+// reduce launch behind it.  Here they share one grid (x = the largest tile count, z = the largest slice count; a workgroup
+// outside its product's range returns) and one reduce launch.  Each product keeps its own tile list, K slices and scratch
+// region: element by element, slice by slice the arithmetic of gemm_mfma_kernel + splitk_reduce_z16_kernel.
+struct GemmGroup {
+    GemmArgs g[4];
+    int tiles[4];        // gridDim.x of the product's own launch (GemmArgs::sym: the tiles on / below the diagonal)
+    int splits[4];       // its K slices
+};
+template <typename T, typename TA, typename TB, int WR, int WC, int BK, int TAG, int FM = -1>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_mfma_group_kernel(GemmGroup m) {
+    const unsigned w = blockIdx.y;
+    const unsigned tiles = (unsigned)m.tiles[w], splits = (unsigned)m.splits[w];
+    if (blockIdx.x >= tiles || blockIdx.z >= splits) return;
+    gemm_mfma_body<T, TA, TB, WR, WC, BK, TAG, FM>(m.g[w], blockIdx.x, 0u, blockIdx.z, tiles, splits);
+}
+
 // ------------------------------------------------------------------------------------------
 // Fused accumulator update of ONE relation side (reference _dfmf.py:254-264 + 278-279, or
 // :266-276 + 281-282 for the column side):
@@ -1733,7 +1751,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, int spli
 
 // the same for MANY slices of a small output (wide c x c products: Gram, W = G_i^T P -- up to 250 slices)
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_z16_kernel(GemmArgs g, int splits) {
+__device__ __forceinline__ void splitk_reduce_z16_body(const GemmArgs& g, int splits) {
     // 16 elements per workgroup pass, 16 threads per element: thread (zl, el) sums the slices zl, zl + 16, ... (four
     // loads in flight), the 16 sums of an element are added in the order zl = 0 .. 15.  (One thread per element walked
     // up to 250 slices of a wide c x c product one load at a time: 75 us for 16 000 outputs.)
@@ -1765,6 +1783,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_z16_kernel(GemmArgs g, int 
         }
         __syncthreads();
     }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_z16_kernel(GemmArgs g, int splits) {
+    splitk_reduce_z16_body<T>(g, splits);
+}
+// ... of the products of a gemm_mfma_group_kernel launch (blockIdx.y = which; the grid-stride loop of the body makes the
+// element -> workgroup assignment irrelevant to the sums)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_z16_group_kernel(GemmGroup m) {
+    splitk_reduce_z16_body<T>(m.g[blockIdx.y], m.splits[blockIdx.y]);
 }
 
 // out[0] = sum_k part[k] in f64, fixed order (single workgroup)

@@ -697,6 +697,40 @@ def test_round5_schedule_switches_keep_every_bit(dtype, monkeypatch):
             assert relerr(Gp[t, t], Go[t, t]) < 1e-10
 
 
+@pytest.mark.parametrize('dtype', ['f64', 'f32', 'bf16'])
+def test_gram_products_of_all_types_in_one_launch_keep_every_bit(dtype, monkeypatch):
+    """Round 6: the Gram matrices of all types leave ONE grouped product launch and ONE reduce launch
+    (gemm_mfma_group_kernel / splitk_reduce_z16_group_kernel; SKF_GRAM_GROUP=0: a product and a reduce launch per type).
+    Tile list, K slices and summation order of every product are unchanged: factors and backbones bit for bit, four launches
+    fewer per iteration with three types.  1 040+ objects: the symmetric split takes 8 slices, the threshold of the group."""
+    from skfusion_amd._engine import launch_count
+    rs = np.random.RandomState(19)
+    types = ['a', 'b', 'c']
+    n = {'a': 1100, 'b': 1056, 'c': 1040}
+    rank = {'a': 68, 'b': 132, 'c': 72}           # (multiples of 4: the f32 factors then stage as vectors on the big tile)
+    R = {('a', 'b'): [rs.rand(1100, 1056)], ('a', 'c'): [rs.rand(1100, 1040) - 0.2]}
+    G0 = {(t, t): rs.rand(n[t], rank[t]) + 0.05 for t in types}
+    runs, launches = {}, {}
+    for name, env in (('one by one', {'SKF_GRAM_GROUP': '0'}), ('grouped', {})):
+        monkeypatch.delenv('SKF_GRAM_GROUP', raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        before = launch_count()
+        runs[name] = _dfmf.dfmf(R, {}, types, rank, max_iter=2, G0=G0, dtype=dtype)
+        launches[name] = launch_count() - before
+    assert launches['one by one'] - launches['grouped'] == 2 * 4, launches
+    Gp, Sp = runs['one by one']
+    G, S = runs['grouped']
+    for t in types:
+        assert np.array_equal(G[t, t], Gp[t, t]), t
+    for k in Sp:
+        assert np.array_equal(S[k][0], Sp[k][0]), k
+    if dtype == 'f64':
+        Go, So = orc.dfmf(R, {}, types, rank, max_iter=2, G0=G0)
+        for t in types:
+            assert relerr(G[t, t], Go[t, t]) < 1e-10
+
+
 def test_dfmc_runs_the_relation_pipeline_with_the_completion_between_its_contractions(monkeypatch):
     """DFMC with a rank above 64 runs the relation pipeline too: a masked relation is contracted once before its
     completion (through the narrower factor) and twice after it; its backbone and reconstruction operands are computed

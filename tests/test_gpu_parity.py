@@ -186,6 +186,13 @@ def test_round5_schedule_switches_keep_every_bit_on_the_hardware(dtype, monkeypa
     E.test_round5_schedule_switches_keep_every_bit(dtype, monkeypatch)
 
 
+@pytest.mark.parametrize('dtype', ['f64', 'f32', 'bf16'])
+def test_gram_products_of_all_types_in_one_launch_on_the_hardware(dtype, monkeypatch):
+    """Round 6: the grouped Gram launch on real grids (three products of different tile and slice counts in one grid)."""
+    import test_emul_engine as E
+    E.test_gram_products_of_all_types_in_one_launch_keep_every_bit(dtype, monkeypatch)
+
+
 def test_fit_with_a_rank_above_256_on_the_hardware(monkeypatch):
     """Orders 300 / 70 / 40 in one batch of step-per-launch sweeps inside a fit, and the Cholesky route, against the oracle."""
     import test_emul_engine as E
