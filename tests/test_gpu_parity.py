@@ -190,7 +190,7 @@ def test_round5_schedule_switches_keep_every_bit_on_the_hardware(dtype, monkeypa
 def test_gram_products_of_all_types_in_one_launch_on_the_hardware(dtype, monkeypatch):
     """Round 6: the grouped Gram launch on real grids (three products of different tile and slice counts in one grid)."""
     import test_emul_engine as E
-    E.test_gram_products_of_all_types_in_one_launch_keep_every_bit(dtype, monkeypatch)
+    E.test_gram_products_of_all_types_in_one_launch_keep_every_bit(dtype, monkeypatch, three=True)
 
 
 def test_fit_with_a_rank_above_256_on_the_hardware(monkeypatch):
