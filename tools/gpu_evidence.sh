@@ -5,7 +5,7 @@
 # (gpurun copies back at most 64 MiB).  tools/refresh_profiles.sh <name> <round> then files the summaries under profiles/.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 N=${1:-evidence}; G=gpurun_out/$N
-bash tools/gpu_round2.sh $N smoke tests_all fullbench prof_bf16 c5_bf16 c5prof_bf16 dist_smoke emulate foldin > gpurun_out/${N}_session.log 2>&1
+bash tools/gpu_round2.sh $N smoke tests_all fullbench die_sub prof_bf16 c5_bf16 c5prof_bf16 dist_smoke emulate foldin > gpurun_out/${N}_session.log 2>&1
 { echo "# rocprofv3 --kernel-trace, bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-engines --no-workloads (config 3 full size, the bf16 leg of the default bench.py run: 7 iterations + set-up), final build of the round"
   python tools/rocpd_summary.py $G/prof_bf16/prof_results.db 40; echo
   echo "# one iteration as a timeline (tools/timeline.py): start offset, duration, stream (s1 = main, s2 = second stream), grid"

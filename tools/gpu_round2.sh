@@ -55,6 +55,11 @@ case "$step" in
   fullbench)
     ( time timeout 1200 python bench.py ) > "$OUT/bench_full.log" 2>&1
     echo "bench exit $?" | tee -a "$OUT/summary.txt"; grep '^{' "$OUT/bench_full.log" | tee -a "$OUT/summary.txt" ;;
+  die_sub)
+    # (round 6) the default run killed right after its headline is measured: the forked watchdog prints the line, once
+    ( SKF_BENCH_DIE_IN_SUBRECORDS=1 timeout 600 python bench.py ) > "$OUT/die_sub.log" 2>&1
+    echo "bench killed during the sub-records: exit $?, JSON lines $(grep -c '^{' "$OUT/die_sub.log")" | tee -a "$OUT/summary.txt"
+    grep '^{' "$OUT/die_sub.log" | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('  value', round(d['value'],2), 'frac', round(d['roofline']['frac'],3), '|', d.get('interrupted'))" | tee -a "$OUT/summary.txt" ;;
   c5_*)
     dt=${step#c5_}
     ( time timeout 900 python bench.py --workload c5 --dtype $dt --steps 10 --warmup 2 --no-cpu-baseline ) > "$OUT/c5_$dt.log" 2>&1

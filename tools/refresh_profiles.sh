@@ -32,7 +32,8 @@ grep '^{' $G/c5_bf16.log > profiles/${R}_c5_bf16_bench.json
 cp gpurun_out/test_deviations.txt profiles/${R}_test_deviations.txt
 { echo "# bench.py --gpus 2 (self-launched through torch.distributed.run) on the one-GPU box, two ranks sharing GPU 0 over a gloo group (SKF_BENCH_BACKEND=gloo): every multi-GPU mode end to end; the throughput of two ranks on one GPU is not a scaling number"
   echo "# (round 6) with SKF_BENCH_DIE_IN_STRONG=<rank> one rank is killed INSIDE the strong leg: the measured restarts line still comes out, exactly once"
-  grep -h "^dist\|^{\|^  value" $G/summary.txt | grep -A1 "^dist" | grep -v "^--" | cut -c1-1500; } > profiles/${R}_dist_smoke.txt
+  grep -h "^dist\|^{\|^  value" $G/summary.txt | grep -A1 "^dist" | grep -v "^--" | cut -c1-1500
+  grep -h -A1 "^bench killed" $G/summary.txt | cut -c1-300; } > profiles/${R}_dist_smoke.txt
 python tools/pmc_mfma_summary.py profiles/${R}_bf16_bench.json $1 > profiles/${R}_bf16_contraction_pmc.txt 2>/dev/null || rm -f profiles/${R}_bf16_contraction_pmc.txt
 [ -f $G/foldin_scale.txt ] && grep fold-in $G/foldin_scale.txt > profiles/${R}_foldin_scale.txt
 ls -la profiles/${R}_*
