@@ -1595,9 +1595,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_v2_kernel(Bf16GemmArgs g) {
                     if constexpr (NJ == 4 && j == 2) expand_chunk(std::integral_constant<int, 3>{}, kt);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                constexpr int CPS = NJ / 4;                              // columns per DMA slot (4 slots per phase)
-                if constexpr ((j + 1) % CPS == 0) {
-                    slot(ksc, std::integral_constant<int, (j + 1) / CPS - 1>{}, kt);
+                // 4 DMA slots per phase, behind the FIRST column of every NJ / 4 (round 6: behind the last one -- columns 1, 3, 5, 7
+                // of 8 -- the fourth piece went out beside the four A fragment reads that close the phase, in front of the
+                // barrier; one column earlier P12 / P23 / Q23 take 1.5 / 1.3 / 0.9 % less and the iteration 1.1 - 1.8 %;
+                // all four pieces up front, or at the head of the columns, measured slower: profiles/r06_contraction_dma_schedule.txt)
+                constexpr int CPS = NJ / 4;
+                if constexpr (j % CPS == 0) {
+                    slot(ksc, std::integral_constant<int, j / CPS>{}, kt);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });

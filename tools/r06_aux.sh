@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 N=$1; shift
 OUT=gpurun_out/$N; mkdir -p "$OUT"
 run() { name=$1; shift; python tools/bench_gemm_bf16.py --shapes P12,P23,Q23,Q12 --tiles 256 --reps 10 2>&1 | grep -v -e Warning -e amdgpu.ids | sed "s/^/[$name] /" | tee -a "$OUT/standalone.txt"; }
-for rep in 1 2; do
+for rep in $(seq 1 ${AUX_REPS:-2}); do
   unset SKF_LIB_PATH; run base
   for v in "$@"; do export SKF_LIB_PATH=$PWD/scikit-fusion_amd/lib/libskf_$v.so; run $v; done
 done
